@@ -1,0 +1,233 @@
+/*
+ * tnt_hip.h -- C ABI of the MI355X (gfx950) kernel library for the fMRI->caption
+ * training hot path ("Think and Tell", seang123/Masters-Thesis).
+ *
+ * The reference has no FFI: its arithmetic is TensorFlow/Keras called from Python
+ * (SURVEY.md 8b).  Each entry point below replaces the Keras op(s) at the cited
+ * reference lines (paths relative to the reference repo root).  The reference-side
+ * binding a maintainer would add is a ctypes stub; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - all tensors float32 unless noted; token ids int32; plain device pointers;
+ *     the caller owns every buffer and workspace; no allocation, no global state;
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work;
+ *   - return 0 on success, a negative hipError_t on launch failure, -1000-k for
+ *     an argument the kernels do not support (k = argument position);
+ *   - matrices are row-major with an explicit leading dimension (in floats);
+ *   - sequence activations are time-major: row = t*B + b;
+ *   - LSTM tensors use the gate-interleaved axis order [.., U, 4] (i,f,c~,o
+ *     innermost) instead of keras' [.., 4U] blocks; the host layer converts in
+ *     get_weights/set_weights;
+ *   - dropout masks come from the Philox4x32-10 stream of csrc/tnt_rng.h:
+ *     element e of the *logical* tensor, (seed, site, step) identify the mask.
+ */
+#ifndef TNT_HIP_H
+#define TNT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TNT_ACT_NONE 0
+#define TNT_ACT_LEAKY 1 /* x>0 ? x : slope*x   (LeakyReLU(0.2): lc_NIC.py:87,98,142) */
+#define TNT_ACT_RELU 2
+#define TNT_ACT_TANH 3
+
+int32_t tnt_version(void);
+
+/* ---- GEMM: C[M,N] (+)= act(op(A)[M,K] * op(B)[K,N] + bias[N]) -------------------
+ * transA=0: A is [M][lda]; transA=1: A is stored [K][lda] (A^T), i.e. m contiguous.
+ * transB=0: B is [K][ldb]; transB=1: B is stored [N][ldb] (B^T), i.e. k contiguous.
+ * Replaces keras Dense / TimeDistributed(Dense) forward and the matmuls of
+ * tape.gradient: layers.py:33, attention.py:21-23, lc_NIC.py:140-157,261,386-387,
+ * NIC.py:64-69,92-96,143,248-249.  `pre` (nullable) receives the pre-activation.
+ * accumulate=1: C += result (bias/act must then be none).
+ * splitk>1: `work` must hold splitk*M*N floats; partials are reduced by a second
+ * launch that applies bias/act (fixed order: bitwise reproducible). */
+int32_t tnt_gemm_f32(const float* A, const float* B, float* C, const float* bias, float* pre,
+                     int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc,
+                     int32_t transA, int32_t transB, int32_t act, float slope,
+                     int32_t accumulate, int32_t splitk, float* work, void* stream);
+
+/* ---- dropout (keras Dropout, inverted; lc_NIC.py:51-55,94; LSTM dropout= :122) ---
+ * y[r][c] = keep ? x[r][c]/(1-rate) : 0 for r<rows, c<cols (ld = row stride of x,y).
+ * logical element index e = lrow*lwidth + lcol0 + c, with
+ *   lrow = r                      if tmajor_B == 0
+ *   lrow = (r % B)*T + r / B      if tmajor_B == B > 0 (buffer time-major, logical (B,T,..)),
+ * where T = rows / B.  In-place (y == x) allowed.  Backward = same call on dy.
+ * The stream step is step + *step_dev (step_dev nullable): a device-resident counter
+ * lets a captured hipGraph replay with a fresh mask each time (see tnt_step_tick). */
+int32_t tnt_dropout_f32(const float* x, float* y, int32_t rows, int32_t cols, int32_t ld,
+                        int32_t tmajor_B, int32_t lwidth, int32_t lcol0, float rate,
+                        uint64_t seed, uint32_t site, uint32_t step, const uint32_t* step_dev,
+                        void* stream);
+
+/* ---- activation backward: dx = dy * act'(pre)  ---------------------------------- */
+int32_t tnt_act_bwd_f32(const float* pre, const float* dy, float* dx, int64_t n, int32_t act,
+                        float slope, void* stream);
+
+/* ---- BatchNormalization, axis=-1, non-fused keras semantics ---------------------
+ * (layers.py:40,50; NIC.py:62,128; fullyConnected.py:18,24)
+ * x is [rows][C] (ld = C).  training=1: biased batch statistics over rows;
+ * moving <- moving*momentum + batch*(1-momentum) (updated in place).
+ * Outputs: y, xhat (saved for backward), inv_std[C].  work: C*(2*nchunk+1) floats
+ * (nchunk = tnt_bn_nchunk(rows)), same size for the backward and for LayerNorm bwd. */
+int32_t tnt_bn_nchunk(int32_t rows);
+int32_t tnt_batchnorm_fwd_f32(const float* x, const float* gamma, const float* beta,
+                              float* mov_mean, float* mov_var, float* y, float* xhat,
+                              float* inv_std, int32_t rows, int32_t C, int32_t ldy,
+                              int32_t training, float eps, float momentum, float* work,
+                              void* stream);
+/* dx (nullable), dgamma[C], dbeta[C] from dy (row stride lddy), xhat, inv_std. */
+int32_t tnt_batchnorm_bwd_f32(const float* dy, const float* xhat, const float* gamma,
+                              const float* inv_std, float* dx, float* dgamma, float* dbeta,
+                              int32_t rows, int32_t C, int32_t lddy, int32_t training,
+                              float* work, void* stream);
+
+/* ---- LayerNormalization(axis=-1) (layers.py:41 alternative; BASELINE north_star) - */
+int32_t tnt_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
+                              float* xhat, float* inv_std, int32_t rows, int32_t C,
+                              int32_t ldy, float eps, void* stream);
+int32_t tnt_layernorm_bwd_f32(const float* dy, const float* xhat, const float* gamma,
+                              const float* inv_std, float* dx, float* dgamma, float* dbeta,
+                              int32_t rows, int32_t C, int32_t lddy, float* work, void* stream);
+
+/* ---- column sums: out[c] = sum_r x[r][c]  (bias gradients of every Dense) -------
+ * work: C*tnt_bn_nchunk(rows) floats. */
+int32_t tnt_colsum_f32(const float* x, float* out, int32_t rows, int32_t C, int32_t ld,
+                       float* work, void* stream);
+
+/* ---- Embedding (lc_NIC.py:105-112,233; NIC.py:75-79,131) ------------------------
+ * fwd: out[(t*B+b)][:] = table[ids[b*T+t]][:]   (ids is the keras (B,T) int32 array)
+ * bwd: dtable[ids[b*T+t]][:] += drows[(t*B+b)][:]  (dtable zeroed by the caller);
+ *      sq_norm[0] += sum of squares of the un-merged rows (IndexedSlices clipnorm
+ *      quirk); sq_norm zeroed by the caller; rowsq_work: B*T floats.
+ *      Deterministic (no atomics): one wave per vocabulary row sums its matches in
+ *      (b,t) order and writes every row of dtable (no pre-zeroing needed). */
+int32_t tnt_embedding_fwd_f32(const float* table, const int32_t* ids, float* out, int32_t B,
+                              int32_t T, int32_t E, int32_t ldo, int32_t V, void* stream);
+int32_t tnt_embedding_bwd_f32(const float* drows, const int32_t* ids, float* dtable,
+                              float* sq_norm, float* rowsq_work, int32_t B, int32_t T,
+                              int32_t E, int32_t ldd, int32_t V, void* stream);
+
+/* ---- LSTM cell step, keras LSTM v2 semantics (lc_NIC.py:118-124,255; NIC.py:82-88,
+ * 138-140), gate-interleaved layouts.
+ * fwd:  z = xz[B][U][4] + h_prev[B][U] @ Ur[U][U][4] (+ ctx[B][D] @ Wc[D][U][4])
+ *       i,f,o = sigmoid, g = tanh; c = f*c_prev + i*g; h = o*tanh(c)
+ *       mask (nullable, int32 ids[B*T], column `mask_t`): rows with id==0 keep
+ *       (h_prev,c_prev) and repeat out_prev (zeros if out_prev is null).
+ *       Saves gates[B][U][4] (post-activation).  out (nullable) receives the
+ *       sequence output of this step. */
+int32_t tnt_lstm_step_fwd_f32(const float* xz, const float* h_prev, const float* c_prev,
+                              const float* Ur, const float* ctx, const float* Wc, int32_t D,
+                              const int32_t* mask_ids, int32_t mask_T, int32_t mask_t,
+                              const float* out_prev, float* h, float* c, float* out,
+                              float* gates, int32_t B, int32_t U, void* stream);
+/* bwd of one step, fused with the recurrent matmul of the step after it:
+ *   da = da_pass_in + dh_ext + (dz_next ? dz_next[B][U][4] @ Ur^T : 0)
+ *   dout = dout_in + dout_t ; masked rows pass (da, dc, dout) through, dz = 0
+ *   unmasked rows: dh = da + dout, standard LSTM cell backward -> dz[B][U][4],
+ *   dc_out = dc*f, da_pass_out = 0, dout_out = 0.
+ * Any of dz_next, da_pass_in, dh_ext, dc_in, dout_in, dout_t, mask_ids may be null. */
+int32_t tnt_lstm_step_bwd_f32(const float* dz_next, const float* Ur, const float* da_pass_in,
+                              const float* dh_ext, const float* dc_in, const float* dout_in,
+                              const float* dout_t, const int32_t* mask_ids, int32_t mask_T,
+                              int32_t mask_t, const float* gates, const float* c,
+                              const float* c_prev, float* dz, float* da_pass_out,
+                              float* dc_out, float* dout_out, int32_t B, int32_t U,
+                              void* stream);
+
+/* ---- softmax + CategoricalCrossentropy(from_logits=False) + accuracy ------------
+ * (lc_NIC.py:153,370-376,461-486; NIC.py:93,234-240; main.py:107-110)
+ * logits [rows][ld], V valid columns.  target ids int32[rows] (argmax of the one-hot).
+ * probs (nullable, may alias logits): softmax.  loss_row/correct_row [rows]:
+ * -log(clip(p_y/sum p, 1e-7, 1-1e-7)) and (argmax p == y).  dlogits (nullable, may
+ * alias logits): (p - onehot)*gscale, zero rows where the clip is active. */
+int32_t tnt_softmax_cce_f32(const float* logits, const int32_t* target, float* probs,
+                            float* loss_row, float* correct_row, float* dlogits,
+                            int32_t rows, int32_t V, int32_t ld, float gscale, void* stream);
+/* target ids from a dense one-hot (B,T,V) float array: ids[t*B+b] = argmax_v. */
+int32_t tnt_onehot_argmax_f32(const float* onehot, int32_t* ids_tmajor, int32_t B, int32_t T,
+                              int32_t V, void* stream);
+/* row argmax (first max wins), out int32[rows]. */
+int32_t tnt_argmax_rows_f32(const float* x, int32_t* out, int32_t rows, int32_t V, int32_t ld,
+                            void* stream);
+/* out[0] = scale * sum_i x[i]  (fixed-order, one workgroup). */
+int32_t tnt_sum_f32(const float* x, float* out, int32_t n, float scale, void* stream);
+
+/* ---- optimizer: per-variable clipnorm + Adam / SGD over a flat parameter arena --
+ * (main.py:97,100-102; lc_NIC.py:389).  The arena is cut by the host into
+ * spans of one variable ("segment") each: span_seg[k], span_off[k] (arena offset in
+ * floats, multiple of 4), span_len[k]; seg_first[s..s+1] = spans of segment s;
+ * seg_l2[s] = L2 lambda (the gradient gets + 2*lambda*theta, lc_NIC.py:47-50).
+ * sqnorm: sq[s] = sum (g + 2 lambda theta)^2, wsq[s] = sum theta^2 (L2 metric);
+ * partial: 2*nspan floats.  If sq_override[s] >= 0 it replaces sq[s] for clipping
+ * (Embedding IndexedSlices norm).  clipnorm <= 0 disables clipping.
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is read from lr_t_dev when non-null. */
+int32_t tnt_seg_sqnorm_f32(const float* theta, const float* grad, const int32_t* span_seg,
+                           const int64_t* span_off, const int32_t* span_len,
+                           const int32_t* seg_first, const float* seg_l2, float* partial,
+                           float* sq, float* wsq, int32_t nspan, int32_t nseg, void* stream);
+int32_t tnt_adam_f32(float* theta, float* m, float* v, const float* grad,
+                     const int32_t* span_seg, const int64_t* span_off, const int32_t* span_len,
+                     const float* seg_l2, const float* sq, const float* sq_override,
+                     int32_t nspan, float lr_t, const float* lr_t_dev, float beta1, float beta2,
+                     float eps, float clipnorm, void* stream);
+int32_t tnt_sgd_f32(float* theta, float* mom, const float* grad, const int32_t* span_seg,
+                    const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
+                    const float* sq, const float* sq_override, int32_t nspan, float lr,
+                    const float* lr_dev, float momentum, float clipnorm, void* stream);
+/* device-resident step state, advanced inside the (captured) step:
+ * adam_t += 1; lr_t = lr[0]*sqrt(1-b2^t)/(1-b1^t); drop_step += 1.  Pointers nullable. */
+int32_t tnt_step_tick(int64_t* adam_t, uint32_t* drop_step, const float* lr, float* lr_t,
+                      float beta1, float beta2, void* stream);
+
+/* ---- region-wise encoder: layers.LocallyDense.call (layers.py:43-48) ------------
+ * CSR groups: idx[goff[r] .. goff[r+1]) are the voxel columns of group r; W is the
+ * concatenation of the per-group kernels, [goff[R]][D]; bias [R][D].
+ * B <= 64 per call, D % 16 == 0, D <= 64.
+ * fwd: pre/y[b][r][:] = LeakyReLU(x[b][idx_r] @ W_r + b_r)    (y,pre: [B][R][D])
+ * bwd: dW_r = x[:,idx_r]^T @ dpre[:,r,:]; db_r = sum_b dpre[b][r][:]. */
+int32_t tnt_locally_dense_fwd_f32(const float* x, int32_t ldx, const int32_t* idx,
+                                  const int32_t* goff, const float* W, const float* bias,
+                                  float* pre, float* y, int32_t B, int32_t R, int32_t D,
+                                  float slope, void* stream);
+int32_t tnt_locally_dense_bwd_f32(const float* x, int32_t ldx, const int32_t* idx,
+                                  const int32_t* goff, const float* dpre, float* dW, float* db,
+                                  int32_t B, int32_t R, int32_t D, void* stream);
+
+/* ---- additive attention step: attention.Attention.call (attention.py:25-44) -----
+ * P = LeakyReLU(F @ W1 + b1) is loop-invariant and computed once with tnt_gemm_f32.
+ * fwd: q = LeakyReLU(h @ W2 + b2); s = tanh(P + q); dropout(s); e = s.v + bv;
+ *      alpha = softmax_R(e); ctx = sum_R alpha*F; ctx_d = LSTM-input dropout of ctx.
+ *      Saves qpre[B][A], alpha[B][R]. s_out (nullable) [B][R][A] post-dropout. */
+int32_t tnt_attention_step_fwd_f32(const float* h, const float* F, const float* P,
+                                   const float* W2, const float* b2, const float* v,
+                                   const float* bv, float* qpre, float* alpha, float* ctx,
+                                   float* ctx_d, float* s_out, int32_t B, int32_t R, int32_t D,
+                                   int32_t A, int32_t U, float slope, float rate_attn,
+                                   float rate_in, int32_t in_lwidth, uint64_t seed,
+                                   uint32_t site_attn, uint32_t site_in, uint32_t step,
+                                   const uint32_t* step_dev, void* stream);
+/* bwd: given dctx_d (grad wrt the dropped ctx), accumulates dP[B][R][A] += , dF[B][R][D] +=,
+ * dvb[B][A+1] += (per-sample partials of dV and dbV), writes dqpre[B][A] and
+ * dh[B][U] = dqpre @ W2^T. */
+int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* F, const float* P,
+                                   const float* W2, const float* v, const float* qpre,
+                                   const float* alpha, float* dP, float* dF, float* dvb,
+                                   float* dqpre, float* dh, int32_t B, int32_t R, int32_t D,
+                                   int32_t A, int32_t U, float slope, float rate_attn,
+                                   float rate_in, int32_t in_lwidth, uint64_t seed,
+                                   uint32_t site_attn, uint32_t site_in, uint32_t step,
+                                   const uint32_t* step_dev, void* stream);
+
+/* attention "coverage" metric (lc_NIC.py:365-367): mean over (T,R) of
+ * (1 - sum_b alpha[t][b][r])^2.  alpha is [T][B][R]. */
+int32_t tnt_attention_metric_f32(const float* alpha, float* out, int32_t T, int32_t B,
+                                 int32_t R, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TNT_HIP_H */

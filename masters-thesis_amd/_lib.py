@@ -1,0 +1,83 @@
+"""ctypes binding of the C-ABI kernel library (include/tnt_hip.h).
+
+There is NO fallback: if ``csrc/libtnt_hip.so`` is missing or a symbol is absent the
+import of the library raises.  ``import torch`` happens first on purpose: torch bundles
+its own libamdhip64 (soname libamdhip64.so.7) and the kernel library must bind to the
+same HIP runtime instance so that torch's streams and device pointers are valid in it.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtnt_hip.so")
+
+P = C.c_void_p          # any device pointer
+I32, I64, U32, U64, F32 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
+
+# name -> argtypes (restype is always int32); order mirrors include/tnt_hip.h
+SIGNATURES = {
+    "tnt_version": [],
+    "tnt_gemm_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, F32, I32, I32, P, P],
+    "tnt_dropout_f32": [P, P, I32, I32, I32, I32, I32, I32, F32, U64, U32, U32, P, P],
+    "tnt_act_bwd_f32": [P, P, P, I64, I32, F32, P],
+    "tnt_bn_nchunk": [I32],
+    "tnt_batchnorm_fwd_f32": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, F32, F32, P, P],
+    "tnt_batchnorm_bwd_f32": [P, P, P, P, P, P, P, I32, I32, I32, I32, P, P],
+    "tnt_layernorm_fwd_f32": [P, P, P, P, P, P, I32, I32, I32, F32, P],
+    "tnt_layernorm_bwd_f32": [P, P, P, P, P, P, P, I32, I32, I32, P, P],
+    "tnt_colsum_f32": [P, P, I32, I32, I32, P, P],
+    "tnt_embedding_fwd_f32": [P, P, P, I32, I32, I32, I32, I32, P],
+    "tnt_embedding_bwd_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, P],
+    "tnt_lstm_step_fwd_f32": [P, P, P, P, P, P, I32, P, I32, I32, P, P, P, P, P, I32, I32, P],
+    "tnt_lstm_step_bwd_f32": [P, P, P, P, P, P, P, P, I32, I32, P, P, P, P, P, P, P, I32, I32, P],
+    "tnt_softmax_cce_f32": [P, P, P, P, P, P, I32, I32, I32, F32, P],
+    "tnt_onehot_argmax_f32": [P, P, I32, I32, I32, P],
+    "tnt_argmax_rows_f32": [P, P, I32, I32, I32, P],
+    "tnt_sum_f32": [P, P, I32, F32, P],
+    "tnt_seg_sqnorm_f32": [P, P, P, P, P, P, P, P, P, P, I32, I32, P],
+    "tnt_adam_f32": [P, P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, F32, F32, P],
+    "tnt_sgd_f32": [P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, P],
+    "tnt_step_tick": [P, P, P, P, F32, F32, P],
+    "tnt_locally_dense_fwd_f32": [P, I32, P, P, P, P, P, P, I32, I32, I32, F32, P],
+    "tnt_locally_dense_bwd_f32": [P, I32, P, P, P, P, P, I32, I32, I32, P],
+    "tnt_attention_step_fwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, F32,
+                                   I32, U64, U32, U32, U32, P, P],
+    "tnt_attention_step_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, F32,
+                                   I32, U64, U32, U32, U32, P, P],
+    "tnt_attention_metric_f32": [P, P, I32, I32, I32, P],
+}
+
+_lib = None
+
+
+class KernelLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KernelLibraryError(
+            f"HIP kernel library not built: {LIB_PATH} is missing. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C masters-thesis_amd/csrc`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise KernelLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = I32
+    _lib = lib
+    return lib
+
+
+def check(rc, name):
+    if rc != 0:
+        raise KernelLibraryError(f"{name} failed with code {rc}")

@@ -1,0 +1,92 @@
+"""Flat parameter arena: every trainable tensor of a model lives in ONE contiguous
+float32 device buffer (theta), with parallel buffers for the gradient and the optimizer
+slots.  One buffer means one RCCL all-reduce for data-parallel training and one
+multi-tensor clip+Adam launch (reference: optimizer.apply_gradients over
+model.trainable_variables, lc_NIC.py:386-389), while each variable keeps its own
+clipnorm segment.
+"""
+from collections import OrderedDict
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+SPAN = 8192      # elements per optimizer workgroup span
+ALIGN = 64       # segment alignment in floats (256 B)
+
+
+@dataclass
+class Spans:
+    span_seg: torch.Tensor
+    span_off: torch.Tensor
+    span_len: torch.Tensor
+    seg_first: torch.Tensor
+    nspan: int
+
+
+def build_spans(offs, lens, device):
+    """Cut segments (offset, length) into spans of <= SPAN elements."""
+    seg, off, ln, first = [], [], [], [0]
+    for s, (o, n) in enumerate(zip(offs, lens)):
+        k = 0
+        while k < n:
+            m = min(SPAN, n - k)
+            seg.append(s); off.append(o + k); ln.append(m)
+            k += m
+        first.append(len(seg))
+    return Spans(torch.tensor(seg, dtype=torch.int32, device=device),
+                 torch.tensor(off, dtype=torch.int64, device=device),
+                 torch.tensor(ln, dtype=torch.int32, device=device),
+                 torch.tensor(first, dtype=torch.int32, device=device), len(seg))
+
+
+@dataclass
+class Entry:
+    name: str
+    off: int
+    shape: tuple          # storage shape inside the arena (may include padding)
+    size: int             # prod(shape)
+    l2: float
+    seg: int
+
+
+class ParamArena:
+    def __init__(self, device):
+        self.device = device
+        self.entries = OrderedDict()
+        self.total = 0
+        self.theta = self.grad = None
+
+    def add(self, name, shape, l2=0.0):
+        assert self.theta is None, "arena already finalized"
+        size = int(np.prod(shape))
+        e = Entry(name, self.total, tuple(int(s) for s in shape), size, float(l2), len(self.entries))
+        self.entries[name] = e
+        self.total += (size + ALIGN - 1) // ALIGN * ALIGN
+        return e
+
+    def finalize(self):
+        dev = self.device
+        self.theta = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        es = list(self.entries.values())
+        self.nseg = len(es)
+        self.spans = build_spans([e.off for e in es], [e.size for e in es], dev)
+        self.seg_l2 = torch.tensor([e.l2 for e in es], dtype=torch.float32, device=dev)
+        self.sq = torch.zeros(self.nseg, dtype=torch.float32, device=dev)
+        self.wsq = torch.zeros(self.nseg, dtype=torch.float32, device=dev)
+        self.sq_override = torch.full((self.nseg,), -1.0, dtype=torch.float32, device=dev)
+        self.partial = torch.zeros(2 * self.spans.nspan, dtype=torch.float32, device=dev)
+        return self
+
+    def p(self, name):
+        e = self.entries[name]
+        return self.theta[e.off:e.off + e.size].view(e.shape)
+
+    def g(self, name):
+        e = self.entries[name]
+        return self.grad[e.off:e.off + e.size].view(e.shape)
+
+    def slot(self, buf, name):
+        e = self.entries[name]
+        return buf[e.off:e.off + e.size].view(e.shape)

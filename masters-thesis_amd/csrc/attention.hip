@@ -1,0 +1,295 @@
+// Additive (Bahdanau / Show-Attend-and-Tell) attention step, forward and backward.
+//
+// Reference: attention.Attention.call (AttemptFour/Model/attention.py:25-44) called once
+// per timestep from lc_NIC.call_attention (lc_NIC.py:244-256) and
+// greedy_predict_attention (lc_NIC.py:607-611).  P = LeakyReLU(W1 F + b1) is
+// loop-invariant (the reference recomputes it every step) and is produced once by
+// tnt_gemm_f32.  One workgroup per batch row: the R x A score tile and the softmax over
+// the R regions live in LDS / registers, reductions are wave shuffles; nothing but
+// qpre[A] and alpha[R] is saved for the backward (tanh is recomputed, the dropout mask is
+// regenerated from the Philox stream).
+#include "tnt_common.h"
+#include "tnt_rng.h"
+
+namespace {
+
+constexpr int MAXR = 2048;   // regions per sample held in LDS
+constexpr int MAXU = 4096;
+
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+  v = tnt_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float r = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float block_max256(float v, float* sh) {
+  v = tnt_wave_max(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float r = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  return r;
+}
+// sum over the AP-lane group (AP = 32 or 64) a lane belongs to
+template <int AP>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = AP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct AttArgs {
+  const float* h; const float* F; const float* P; const float* W2; const float* b2; const float* v; const float* bv;
+  float* qpre; float* alpha; float* ctx; float* ctx_d; float* s_out;
+  // backward
+  const float* dctx_d; const float* qpre_in; const float* alpha_in; float* dP; float* dF; float* dvb;
+  float* dqpre; float* dh;
+  int B, R, D, A, U, in_lwidth;
+  float slope, rate_attn, rate_in;
+  uint64_t seed; uint32_t site_attn, site_in, step; const uint32_t* step_dev;
+};
+
+// q[a] = LeakyReLU(sum_k h[k] W2[k][a] + b2[a]); threads = (a = tid % AP, part = tid / AP)
+template <int AP>
+__device__ __forceinline__ void compute_q(const AttArgs& g, const float* hs, float* part, float* qs, float* qpre_s) {
+  const int a = threadIdx.x % AP, kp = threadIdx.x / AP;
+  constexpr int KP = 256 / AP;
+  float s = 0.f;
+  if (a < g.A)
+    for (int k = kp; k < g.U; k += KP) s += hs[k] * g.W2[(long)k * g.A + a];
+  part[kp * AP + a] = s;
+  __syncthreads();
+  if (threadIdx.x < AP && a < g.A) {
+    float t = g.b2[a];
+    for (int j = 0; j < KP; ++j) t += part[j * AP + a];
+    qpre_s[a] = t;
+    qs[a] = t > 0.f ? t : t * g.slope;
+  }
+  __syncthreads();
+}
+
+template <int AP>
+__global__ __launch_bounds__(256) void attention_fwd_kernel(AttArgs g) {
+  __shared__ float hs[MAXU];
+  __shared__ float es[MAXR];
+  __shared__ float part[256];
+  __shared__ float qs[AP], qpre_s[AP], red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
+  for (int k = tid; k < g.U; k += 256) hs[k] = g.h[(long)b * g.U + k];
+  __syncthreads();
+  compute_q<AP>(g, hs, part, qs, qpre_s);
+  if (tid < g.A) g.qpre[(long)b * g.A + tid] = qpre_s[tid];
+
+  // scores
+  const int a = tid % AP, rp = tid / AP;
+  constexpr int RP = 256 / AP;
+  const float scale_a = 1.f / (1.f - g.rate_attn);
+  const float va = a < g.A ? g.v[a] : 0.f;
+  const float bv = g.bv[0];
+  for (int r0 = 0; r0 < g.R; r0 += RP) {
+    const int r = r0 + rp;
+    float t = 0.f;
+    if (r < g.R && a < g.A) {
+      const long e = ((long)b * g.R + r) * g.A + a;
+      float s = tanhf(g.P[e] + qs[a]);
+      if (g.rate_attn > 0.f) s = tnt_keep((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step) ? s * scale_a : 0.f;
+      if (g.s_out) g.s_out[e] = s;
+      t = s * va;
+    }
+    t = group_sum<AP>(t);
+    if (a == 0 && r < g.R) es[r] = t + bv;
+  }
+  __syncthreads();
+  // softmax over regions (keras Softmax(axis=1), attention.py:16,40)
+  float m = -INFINITY;
+  for (int r = tid; r < g.R; r += 256) m = fmaxf(m, es[r]);
+  m = block_max256(m, red);
+  float z = 0.f;
+  for (int r = tid; r < g.R; r += 256) { const float ex = expf(es[r] - m); es[r] = ex; z += ex; }
+  z = block_sum256(z, red);
+  const float invz = 1.f / z;
+  for (int r = tid; r < g.R; r += 256) { const float al = es[r] * invz; es[r] = al; g.alpha[(long)b * g.R + r] = al; }
+  __syncthreads();
+  // context = sum_r alpha[r] F[b][r][:]   threads = (d = tid % DP, part = tid / DP), DP = AP
+  const int d = tid % AP, pp = tid / AP;
+  float c = 0.f;
+  if (d < g.D)
+    for (int r = pp; r < g.R; r += RP) c += es[r] * g.F[((long)b * g.R + r) * g.D + d];
+  part[pp * AP + d] = c;
+  __syncthreads();
+  if (tid < AP && tid < g.D) {
+    float t = 0.f;
+    for (int j = 0; j < RP; ++j) t += part[j * AP + tid];
+    g.ctx[(long)b * g.D + tid] = t;
+    if (g.ctx_d) {
+      float td = t;
+      if (g.rate_in > 0.f)
+        td = tnt_keep((uint64_t)b * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, g.site_in, step)
+                 ? t * (1.f / (1.f - g.rate_in)) : 0.f;
+      g.ctx_d[(long)b * g.D + tid] = td;
+    }
+  }
+}
+
+template <int AP>
+__global__ __launch_bounds__(256) void attention_bwd_kernel(AttArgs g) {
+  __shared__ float als[MAXR];      // alpha, then de
+  __shared__ float das[MAXR];      // dalpha
+  __shared__ float part[256], part2[256];
+  __shared__ float qs[AP], dcs[AP], dq_s[AP], red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
+  constexpr int RP = 256 / AP;
+  if (tid < AP) {
+    float q = 0.f, dc = 0.f;
+    if (tid < g.A) { q = g.qpre_in[(long)b * g.A + tid]; q = q > 0.f ? q : q * g.slope; }
+    if (tid < g.D) {
+      dc = g.dctx_d[(long)b * g.D + tid];
+      if (g.rate_in > 0.f)
+        dc = tnt_keep((uint64_t)b * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, g.site_in, step)
+                 ? dc * (1.f / (1.f - g.rate_in)) : 0.f;
+    }
+    qs[tid] = q; dcs[tid] = dc;
+  }
+  for (int r = tid; r < g.R; r += 256) als[r] = g.alpha_in[(long)b * g.R + r];
+  __syncthreads();
+  // dalpha[r] = sum_d dctx[d] F[r][d];  dF[r][d] += alpha[r] dctx[d]
+  const int d = tid % AP, rp = tid / AP;
+  for (int r0 = 0; r0 < g.R; r0 += RP) {
+    const int r = r0 + rp;
+    float t = 0.f;
+    if (r < g.R && d < g.D) {
+      const long e = ((long)b * g.R + r) * g.D + d;
+      t = dcs[d] * g.F[e];
+      g.dF[e] += als[r] * dcs[d];
+    }
+    t = group_sum<AP>(t);
+    if (d == 0 && r < g.R) das[r] = t;
+  }
+  __syncthreads();
+  float dot = 0.f;
+  for (int r = tid; r < g.R; r += 256) dot += als[r] * das[r];
+  dot = block_sum256(dot, red);
+  float dbv = 0.f;
+  for (int r = tid; r < g.R; r += 256) { const float de = als[r] * (das[r] - dot); als[r] = de; dbv += de; }
+  dbv = block_sum256(dbv, red);     // also orders the als[] writes before the reads below
+  // through e = s_d . v, dropout, tanh
+  const int a = d;
+  const float scale_a = 1.f / (1.f - g.rate_attn);
+  const float va = a < g.A ? g.v[a] : 0.f;
+  float dv = 0.f, dq = 0.f;
+  if (a < g.A) {
+    for (int r = rp; r < g.R; r += RP) {
+      const long e = ((long)b * g.R + r) * g.A + a;
+      const float s = tanhf(g.P[e] + qs[a]);
+      bool keep = true;
+      if (g.rate_attn > 0.f) keep = tnt_keep((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step);
+      const float ks = keep ? (g.rate_attn > 0.f ? scale_a : 1.f) : 0.f;
+      const float de = als[r];
+      dv += s * ks * de;
+      const float dsum = de * va * ks * (1.f - s * s);
+      g.dP[e] += dsum;
+      dq += dsum;
+    }
+  }
+  part[rp * AP + a] = dv; part2[rp * AP + a] = dq;
+  __syncthreads();
+  if (tid < AP && tid < g.A) {
+    float tv = 0.f, tq = 0.f;
+    for (int j = 0; j < RP; ++j) { tv += part[j * AP + tid]; tq += part2[j * AP + tid]; }
+    g.dvb[(long)b * (g.A + 1) + tid] += tv;
+    const float qp = g.qpre_in[(long)b * g.A + tid];
+    const float dqp = qp > 0.f ? tq : tq * g.slope;
+    dq_s[tid] = dqp;
+    g.dqpre[(long)b * g.A + tid] = dqp;
+  }
+  if (tid == 0) g.dvb[(long)b * (g.A + 1) + g.A] += dbv;
+  __syncthreads();
+  // dh[k] = sum_a dqpre[a] W2[k][a]
+  for (int k = tid; k < g.U; k += 256) {
+    float t = 0.f;
+    for (int j = 0; j < g.A; ++j) t += dq_s[j] * g.W2[(long)k * g.A + j];
+    g.dh[(long)b * g.U + k] = t;
+  }
+}
+
+__global__ __launch_bounds__(1024) void attention_metric_kernel(const float* alpha, float* out, int T, int B, int R) {
+  __shared__ float sw[16];
+  float acc = 0.f;
+  const int n = T * R;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const int t = i / R, r = i % R;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += alpha[((long)t * B + b) * R + r];
+    acc += (1.f - s) * (1.f - s);
+  }
+  acc = tnt_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += sw[w];
+    out[0] = t / (float)n;
+  }
+}
+
+int32_t check_dims(int B, int R, int D, int A, int U) {
+  if (B <= 0) return TNT_BADARG(1);
+  if (R <= 0 || R > MAXR) return TNT_BADARG(2);
+  if (D <= 0 || D > 64) return TNT_BADARG(3);
+  if (A <= 0 || A > 64) return TNT_BADARG(4);
+  if (U <= 0 || U > MAXU) return TNT_BADARG(5);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int32_t tnt_attention_step_fwd_f32(const float* h, const float* F, const float* P, const float* W2,
+                                              const float* b2, const float* v, const float* bv, float* qpre,
+                                              float* alpha, float* ctx, float* ctx_d, float* s_out, int32_t B, int32_t R,
+                                              int32_t D, int32_t A, int32_t U, float slope, float rate_attn,
+                                              float rate_in, int32_t in_lwidth, uint64_t seed, uint32_t site_attn,
+                                              uint32_t site_in, uint32_t step, const uint32_t* step_dev, void* stream) {
+  if (int32_t rc = check_dims(B, R, D, A, U)) return rc;
+  AttArgs g{};
+  g.h = h; g.F = F; g.P = P; g.W2 = W2; g.b2 = b2; g.v = v; g.bv = bv; g.qpre = qpre; g.alpha = alpha; g.ctx = ctx;
+  g.ctx_d = ctx_d; g.s_out = s_out; g.B = B; g.R = R; g.D = D; g.A = A; g.U = U; g.in_lwidth = in_lwidth;
+  g.slope = slope; g.rate_attn = rate_attn; g.rate_in = rate_in; g.seed = seed; g.site_attn = site_attn;
+  g.site_in = site_in; g.step = step; g.step_dev = step_dev;
+  if (A <= 32 && D <= 32)
+    hipLaunchKernelGGL(attention_fwd_kernel<32>, dim3(B), dim3(256), 0, tnt_stream(stream), g);
+  else
+    hipLaunchKernelGGL(attention_fwd_kernel<64>, dim3(B), dim3(256), 0, tnt_stream(stream), g);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* F, const float* P, const float* W2,
+                                              const float* v, const float* qpre, const float* alpha, float* dP, float* dF,
+                                              float* dvb, float* dqpre, float* dh, int32_t B, int32_t R, int32_t D,
+                                              int32_t A, int32_t U, float slope, float rate_attn, float rate_in,
+                                              int32_t in_lwidth, uint64_t seed, uint32_t site_attn, uint32_t site_in,
+                                              uint32_t step, const uint32_t* step_dev, void* stream) {
+  if (int32_t rc = check_dims(B, R, D, A, U)) return rc;
+  AttArgs g{};
+  g.dctx_d = dctx_d; g.F = F; g.P = P; g.W2 = W2; g.v = v; g.qpre_in = qpre; g.alpha_in = alpha; g.dP = dP; g.dF = dF;
+  g.dvb = dvb; g.dqpre = dqpre; g.dh = dh; g.B = B; g.R = R; g.D = D; g.A = A; g.U = U; g.in_lwidth = in_lwidth;
+  g.slope = slope; g.rate_attn = rate_attn; g.rate_in = rate_in; g.seed = seed; g.site_attn = site_attn;
+  g.site_in = site_in; g.step = step; g.step_dev = step_dev;
+  if (A <= 32 && D <= 32)
+    hipLaunchKernelGGL(attention_bwd_kernel<32>, dim3(B), dim3(256), 0, tnt_stream(stream), g);
+  else
+    hipLaunchKernelGGL(attention_bwd_kernel<64>, dim3(B), dim3(256), 0, tnt_stream(stream), g);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_attention_metric_f32(const float* alpha, float* out, int32_t T, int32_t B, int32_t R,
+                                            void* stream) {
+  hipLaunchKernelGGL(attention_metric_kernel, dim3(1), dim3(1024), 0, tnt_stream(stream), alpha, out, T, B, R);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}

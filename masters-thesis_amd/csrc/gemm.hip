@@ -1,0 +1,251 @@
+// FP32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled.
+//
+// Replaces every keras Dense / TimeDistributed(Dense) matmul of the hot path and the
+// matmuls tape.gradient derives from them (reference: AttemptFour/Model/layers.py:33,
+// attention.py:21-23, lc_NIC.py:140-157,261,386-387, NIC.py:64-69,92-96,143,248-249).
+// Exact f32 (fma chain per output element), which is what the 1e-4 logit parity needs.
+//
+// Tile: BM x BN x 16 per 256-thread workgroup (4 waves as 2x2, each wave owning
+// (BM/2)x(BN/2) as 32x32 MFMA tiles).  Both operand tiles live k-major in LDS
+// ([k][m], [k][n]) so an MFMA operand fetch is one conflict-free ds_read_b32 per lane;
+// operands that are k-contiguous in HBM are transposed on the way in.  Global loads of
+// chunk i+1 are issued before the MFMAs of chunk i (register prefetch, 2 LDS buffers,
+// one barrier per chunk).
+#include "tnt_common.h"
+
+namespace {
+
+struct GemmArgs {
+  const float* A; const float* B; float* C; const float* bias; float* pre; float* work;
+  int M, N, K, lda, ldb, ldc;
+  int act; float slope; int accumulate; int kchunk; int splitk;
+};
+
+constexpr int BK = 16;
+
+template <bool VEC>
+__device__ __forceinline__ float4 ldg4(const float* p, int valid) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid >= 4 && VEC) {
+    v = *reinterpret_cast<const float4*>(p);
+  } else {
+    if (valid > 0) v.x = p[0];
+    if (valid > 1) v.y = p[1];
+    if (valid > 2) v.z = p[2];
+    if (valid > 3) v.w = p[3];
+  }
+  return v;
+}
+
+// Operand tile loader.  KCONTIG: memory is [mn][ld] with k contiguous; else [k][ld] with mn contiguous.
+template <int BMN, bool KCONTIG, bool VEC>
+struct TileLoader {
+  static constexpr int NV = BMN * BK / 4 / 256;   // float4 per thread
+  static constexpr int PAD = KCONTIG ? 2 : 4;
+  static constexpr int LDS_LD = BMN + PAD;
+  float4 r[NV];
+
+  __device__ __forceinline__ void load(const float* base, int ld, int mn0, int mn_lim, int k0, int k_lim, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * 256;
+      if (KCONTIG) {
+        const int mn = f >> 2, kq = (f & 3) * 4;
+        const int gmn = mn0 + mn, gk = k0 + kq;
+        int valid = (gmn < mn_lim) ? (k_lim - gk) : 0;
+        r[i] = ldg4<VEC>(base + (long)gmn * ld + gk, valid);
+      } else {
+        const int kk = f / (BMN / 4), mn4 = (f % (BMN / 4)) * 4;
+        const int gk = k0 + kk, gmn = mn0 + mn4;
+        int valid = (gk < k_lim) ? (mn_lim - gmn) : 0;
+        r[i] = ldg4<VEC>(base + (long)gk * ld + gmn, valid);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * 256;
+      if (KCONTIG) {
+        const int mn = f >> 2, kq = (f & 3) * 4;
+        lds[(kq + 0) * LDS_LD + mn] = r[i].x;
+        lds[(kq + 1) * LDS_LD + mn] = r[i].y;
+        lds[(kq + 2) * LDS_LD + mn] = r[i].z;
+        lds[(kq + 3) * LDS_LD + mn] = r[i].w;
+      } else {
+        const int kk = f / (BMN / 4), mn4 = (f % (BMN / 4)) * 4;
+        *reinterpret_cast<float4*>(&lds[kk * LDS_LD + mn4]) = r[i];
+      }
+    }
+  }
+};
+
+template <int BM, int BN, bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  using LA = TileLoader<BM, !TA, VEC>;
+  using LB = TileLoader<BN, TB, VEC>;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (LA::LDS_LD + LB::LDS_LD)];
+  float* As = lds;
+  float* Bs = lds + 2 * BK * LA::LDS_LD;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int z = blockIdx.z;
+  const int kbeg = z * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  LA la; LB lb;
+  if (nk > 0) {
+    la.load(g.A, g.lda, m0, g.M, kbeg, kend, tid);
+    lb.load(g.B, g.ldb, n0, g.N, kbeg, kend, tid);
+    la.store(As, tid);
+    lb.store(Bs, tid);
+  }
+  __syncthreads();
+
+  const int lrow = lane & 31, lk = lane >> 5;
+  for (int i = 0; i < nk; ++i) {
+    const int cur = i & 1;
+    if (i + 1 < nk) {
+      la.load(g.A, g.lda, m0, g.M, kbeg + (i + 1) * BK, kend, tid);
+      lb.load(g.B, g.ldb, n0, g.N, kbeg + (i + 1) * BK, kend, tid);
+    }
+    const float* Ac = As + cur * BK * LA::LDS_LD;
+    const float* Bc = Bs + cur * BK * LB::LDS_LD;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) av[tm] = Ac[(kk + lk) * LA::LDS_LD + wm * WM + tm * 32 + lrow];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) bv[tn] = Bc[(kk + lk) * LB::LDS_LD + wn * WN + tn * 32 + lrow];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+    }
+    if (i + 1 < nk) {
+      la.store(As + (cur ^ 1) * BK * LA::LDS_LD, tid);
+      lb.store(Bs + (cur ^ 1) * BK * LB::LDS_LD, tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = n0 + wn * WN + tn * 32 + lrow;
+      if (col >= g.N) continue;
+      const float bcol = (g.bias != nullptr && g.splitk == 1) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= g.M) continue;
+        float v = acc[tm][tn][r];
+        if (g.splitk > 1) {
+          g.work[((long)z * g.M + row) * g.N + col] = v;
+        } else {
+          v += bcol;
+          const long o = (long)row * g.ldc + col;
+          if (g.pre) g.pre[o] = v;
+          v = tnt_act(v, g.act, g.slope);
+          if (g.accumulate) v += g.C[o];
+          g.C[o] = v;
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
+  const long total = (long)g.M * g.N;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int row = (int)(e / g.N), col = (int)(e % g.N);
+    float v = 0.f;
+    for (int z = 0; z < g.splitk; ++z) v += g.work[(long)z * total + e];
+    if (g.bias) v += g.bias[col];
+    const long o = (long)row * g.ldc + col;
+    if (g.pre) g.pre[o] = v;
+    v = tnt_act(v, g.act, g.slope);
+    if (g.accumulate) v += g.C[o];
+    g.C[o] = v;
+  }
+}
+
+template <int BM, int BN, bool TA, bool TB>
+int32_t launch_cfg(const GemmArgs& g, bool vec, hipStream_t s) {
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk);
+  if (vec)
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, TA, TB, true>), grid, dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, TA, TB, false>), grid, dim3(256), 0, s, g);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+template <bool TA, bool TB>
+int32_t launch_layout(const GemmArgs& g, int bm, int bn, bool vec, hipStream_t s) {
+  if (bm == 128 && bn == 128) return launch_cfg<128, 128, TA, TB>(g, vec, s);
+  if (bm == 64 && bn == 128) return launch_cfg<64, 128, TA, TB>(g, vec, s);
+  if (bm == 128 && bn == 64) return launch_cfg<128, 64, TA, TB>(g, vec, s);
+  return launch_cfg<64, 64, TA, TB>(g, vec, s);
+}
+
+}  // namespace
+
+extern "C" int32_t tnt_gemm_f32(const float* A, const float* B, float* C, const float* bias, float* pre,
+                                int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc,
+                                int32_t transA, int32_t transB, int32_t act, float slope,
+                                int32_t accumulate, int32_t splitk, float* work, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return TNT_BADARG(6);
+  if (transA && transB) return TNT_BADARG(12);
+  if (splitk < 1) splitk = 1;
+  if (splitk > 1 && work == nullptr) return TNT_BADARG(18);
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.pre = pre; g.work = work;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.act = act; g.slope = slope; g.accumulate = accumulate;
+  int kchunk = (K + splitk - 1) / splitk;
+  kchunk = (kchunk + BK - 1) / BK * BK;
+  splitk = (K + kchunk - 1) / kchunk;
+  g.kchunk = kchunk; g.splitk = splitk;
+
+  // tile choice: fewest rounds over 256 CUs, small tiles pay an overhead factor
+  const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+  const float ovh[4] = {1.0f, 1.12f, 1.12f, 1.3f};
+  int best = 3; float best_cost = 1e30f;
+  for (int c = 0; c < 4; ++c) {
+    const long tiles = (long)((M + cand[c][0] - 1) / cand[c][0]) * ((N + cand[c][1] - 1) / cand[c][1]) * splitk;
+    const long rounds = (tiles + 511) / 512;   // two workgroups per CU resident
+    const float cost = (float)rounds * cand[c][0] * cand[c][1] * ovh[c];
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  const bool vec = tnt_aligned16(A) && tnt_aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+  hipStream_t s = tnt_stream(stream);
+  int32_t rc;
+  if (!transA && !transB) rc = launch_layout<false, false>(g, cand[best][0], cand[best][1], vec, s);
+  else if (!transA && transB) rc = launch_layout<false, true>(g, cand[best][0], cand[best][1], vec, s);
+  else rc = launch_layout<true, false>(g, cand[best][0], cand[best][1], vec, s);
+  if (rc) return rc;
+  if (splitk > 1) {
+    const long total = (long)M * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g);
+    TNT_LAUNCH_CHECK();
+  }
+  return 0;
+}

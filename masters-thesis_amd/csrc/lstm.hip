@@ -1,0 +1,218 @@
+// Fused LSTM cell step (forward and backward) for the serial T-step decoder chain.
+//
+// Reference: keras LSTM layer 'lstm' called one timestep at a time
+// (AttemptFour/Model/lc_NIC.py:118-124,255) or over a masked sequence
+// (AttemptFour/Model/NIC.py:82-88,138-140); semantics in SURVEY.md 9.6.
+//
+// One launch per timestep does the recurrent matmul AND the gate math:
+//   fwd:  z = xz + [h_prev, ctx] @ [Ur; Wc]  ->  i,f,g,o -> c,h     (64 x (U+D) x 4U)
+//   bwd:  da = dz_next @ Ur^T (+ pass-through terms) -> cell backward -> dz
+// The batch is skinny (B = 64), so there is no operand reuse to stage through LDS:
+// every wave streams its own slice of the weights straight into VGPRs with 16-byte
+// loads and feeds v_mfma_f32_16x16x4_f32.  Workgroup = 16 batch rows x 16 hidden units;
+// its 8 waves split the contraction axis and combine through LDS.  The gate-interleaved
+// weight layout [k][U][4] puts i,f,g,o of one unit in one 16-byte load and in one lane's
+// four accumulators, so the gate math needs no cross-lane traffic.
+#include "tnt_common.h"
+
+namespace {
+
+constexpr int NW = 8;  // waves per workgroup
+
+__device__ __forceinline__ float4 ld4g(const float* p, bool ok) {
+  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+struct LstmFwdArgs {
+  const float* xz; const float* h_prev; const float* c_prev; const float* Ur; const float* ctx; const float* Wc;
+  const int* mask_ids; const float* out_prev; float* h; float* c; float* out; float* gates;
+  int D, mask_T, mask_t, B, U;
+};
+
+__global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwdArgs a) {
+  __shared__ float red[NW][4][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kq = lane >> 4, lr = lane & 15;
+  const int ub = blockIdx.x, rb = blockIdx.y;
+  const int U = a.U, B = a.B;
+  const int Ktot = U + (a.ctx ? a.D : 0);
+  const int nchunk = (Ktot + 63) / 64;
+  const int arow = rb * 16 + lr;          // batch row this lane feeds as the A operand
+  const int ucol = ub * 16 + lr;          // hidden unit this lane feeds as the B operand
+  floatx4 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+  for (int ci = w; ci < nchunk; ci += NW) {
+    const int kbase = ci * 64 + kq * 16;
+    float av[16];
+    float4 bv[16];
+    if (kbase < U) {
+      // recurrent part: U % 16 == 0, so the 16-run never straddles U
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 t = ld4g(a.h_prev + (long)arow * U + kbase + 4 * j, arow < B);
+        av[4 * j + 0] = t.x; av[4 * j + 1] = t.y; av[4 * j + 2] = t.z; av[4 * j + 3] = t.w;
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) bv[s] = ld4g(a.Ur + ((long)(kbase + s) * U + ucol) * 4, true);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int kd = kbase + s - U;
+        const bool ok = kd < a.D;
+        av[s] = (ok && arow < B) ? a.ctx[(long)arow * a.D + kd] : 0.f;
+        bv[s] = ld4g(a.Wc + ((long)kd * U + ucol) * 4, ok);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].w, acc[3], 0, 0, 0);
+    }
+  }
+  // C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w][g][kq * 4 + r][lr] = acc[g][r];
+  __syncthreads();
+  if (tid < 256) {
+    const int row = tid >> 4, col = tid & 15;
+    const int b = rb * 16 + row, u = ub * 16 + col;
+    if (b < B) {
+      const long e = (long)b * U + u;
+      const float4 x4 = *reinterpret_cast<const float4*>(a.xz + e * 4);
+      float z[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) s += red[k][g][row][col];
+        z[g] += s;
+      }
+      const float gi = tnt_sigmoid(z[0]), gf = tnt_sigmoid(z[1]), gg = tanhf(z[2]), go = tnt_sigmoid(z[3]);
+      const float cp = a.c_prev[e], hp = a.h_prev[e];
+      const float c2 = gf * cp + gi * gg;
+      const float h2 = go * tanhf(c2);
+      bool m = true;
+      if (a.mask_ids) m = a.mask_ids[b * a.mask_T + a.mask_t] != 0;
+      a.h[e] = m ? h2 : hp;
+      a.c[e] = m ? c2 : cp;
+      if (a.out) a.out[e] = m ? h2 : (a.out_prev ? a.out_prev[e] : 0.f);
+      *reinterpret_cast<float4*>(a.gates + e * 4) = make_float4(gi, gf, gg, go);
+    }
+  }
+}
+
+struct LstmBwdArgs {
+  const float* dz_next; const float* Ur; const float* da_pass_in; const float* dh_ext; const float* dc_in;
+  const float* dout_in; const float* dout_t; const int* mask_ids; const float* gates; const float* c;
+  const float* c_prev; float* dz; float* da_pass_out; float* dc_out; float* dout_out;
+  int mask_T, mask_t, B, U;
+};
+
+__global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdArgs a) {
+  __shared__ float red[NW][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kq = lane >> 4, lr = lane & 15;
+  const int ub = blockIdx.x, rb = blockIdx.y;
+  const int U = a.U, B = a.B, K = 4 * a.U;
+  floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+  if (a.dz_next) {
+    const int arow = rb * 16 + lr, ucol = ub * 16 + lr;
+    const int nchunk = K / 64;   // U % 16 == 0  =>  4U % 64 == 0
+    for (int ci = w; ci < nchunk; ci += NW) {
+      const int kbase = ci * 64 + kq * 16;
+      float av[16], bv[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 t = ld4g(a.dz_next + (long)arow * K + kbase + 4 * j, arow < B);
+        av[4 * j + 0] = t.x; av[4 * j + 1] = t.y; av[4 * j + 2] = t.z; av[4 * j + 3] = t.w;
+        const float4 q = ld4g(a.Ur + (long)ucol * K + kbase + 4 * j, true);
+        bv[4 * j + 0] = q.x; bv[4 * j + 1] = q.y; bv[4 * j + 2] = q.z; bv[4 * j + 3] = q.w;
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[w][kq * 4 + r][lr] = acc[r];
+  __syncthreads();
+  if (tid < 256) {
+    const int row = tid >> 4, col = tid & 15;
+    const int b = rb * 16 + row, u = ub * 16 + col;
+    if (b < B) {
+      const long e = (long)b * U + u;
+      float da = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) da += red[k][row][col];
+      if (a.da_pass_in) da += a.da_pass_in[e];
+      if (a.dh_ext) da += a.dh_ext[e];
+      float dout = 0.f;
+      if (a.dout_in) dout += a.dout_in[e];
+      if (a.dout_t) dout += a.dout_t[e];
+      const float dcin = a.dc_in ? a.dc_in[e] : 0.f;
+      bool m = true;
+      if (a.mask_ids) m = a.mask_ids[b * a.mask_T + a.mask_t] != 0;
+      float4 dz4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float dc_o = dcin, da_o = da, dout_o = dout;
+      if (m) {
+        const float4 g4 = *reinterpret_cast<const float4*>(a.gates + e * 4);
+        const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
+        const float tc = tanhf(a.c[e]);
+        const float dh = da + dout;
+        const float dgo = dh * tc;
+        const float dc = dcin + dh * go * (1.f - tc * tc);
+        dz4.x = dc * gg * gi * (1.f - gi);
+        dz4.y = dc * a.c_prev[e] * gf * (1.f - gf);
+        dz4.z = dc * gi * (1.f - gg * gg);
+        dz4.w = dgo * go * (1.f - go);
+        dc_o = dc * gf; da_o = 0.f; dout_o = 0.f;
+      }
+      *reinterpret_cast<float4*>(a.dz + e * 4) = dz4;
+      if (a.dc_out) a.dc_out[e] = dc_o;
+      if (a.da_pass_out) a.da_pass_out[e] = da_o;
+      if (a.dout_out) a.dout_out[e] = dout_o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int32_t tnt_lstm_step_fwd_f32(const float* xz, const float* h_prev, const float* c_prev, const float* Ur,
+                                         const float* ctx, const float* Wc, int32_t D, const int32_t* mask_ids,
+                                         int32_t mask_T, int32_t mask_t, const float* out_prev, float* h, float* c,
+                                         float* out, float* gates, int32_t B, int32_t U, void* stream) {
+  if (U <= 0 || U % 16 != 0) return TNT_BADARG(17);
+  if (B <= 0) return TNT_BADARG(16);
+  if (h == h_prev) return TNT_BADARG(12);
+  LstmFwdArgs a;
+  a.xz = xz; a.h_prev = h_prev; a.c_prev = c_prev; a.Ur = Ur; a.ctx = ctx; a.Wc = Wc; a.mask_ids = mask_ids;
+  a.out_prev = out_prev; a.h = h; a.c = c; a.out = out; a.gates = gates;
+  a.D = D; a.mask_T = mask_T; a.mask_t = mask_t; a.B = B; a.U = U;
+  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(U / 16, (B + 15) / 16), dim3(512), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_lstm_step_bwd_f32(const float* dz_next, const float* Ur, const float* da_pass_in,
+                                         const float* dh_ext, const float* dc_in, const float* dout_in,
+                                         const float* dout_t, const int32_t* mask_ids, int32_t mask_T, int32_t mask_t,
+                                         const float* gates, const float* c, const float* c_prev, float* dz,
+                                         float* da_pass_out, float* dc_out, float* dout_out, int32_t B, int32_t U,
+                                         void* stream) {
+  if (U <= 0 || U % 16 != 0) return TNT_BADARG(19);
+  if (B <= 0) return TNT_BADARG(18);
+  if (dz == dz_next) return TNT_BADARG(14);
+  LstmBwdArgs a;
+  a.dz_next = dz_next; a.Ur = Ur; a.da_pass_in = da_pass_in; a.dh_ext = dh_ext; a.dc_in = dc_in; a.dout_in = dout_in;
+  a.dout_t = dout_t; a.mask_ids = mask_ids; a.gates = gates; a.c = c; a.c_prev = c_prev; a.dz = dz;
+  a.da_pass_out = da_pass_out; a.dc_out = dc_out; a.dout_out = dout_out;
+  a.mask_T = mask_T; a.mask_t = mask_t; a.B = B; a.U = U;
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(U / 16, (B + 15) / 16), dim3(512), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}

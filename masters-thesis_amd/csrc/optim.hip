@@ -1,0 +1,191 @@
+// Per-variable clipnorm + Adam / SGD over one flat parameter arena (HBM-bound: 7 words
+// moved per parameter per step).
+// Reference: tf.keras.optimizers.Adam(1e-4, 0.9, 0.98, 1e-8, clipnorm=0.1) at
+// AttemptFour/main.py:97 applied by optimizer.apply_gradients at lc_NIC.py:389 /
+// NIC.py:250; SGD(momentum=0.9) at main.py:100-102; L2 regularisers lc_NIC.py:47-50.
+// Semantics in SURVEY.md 9.9: each variable's gradient (data gradient + 2*lambda*theta)
+// is scaled by c/max(||g||, c) on its own, then the dense Adam formulas are applied.
+//
+// The arena is cut into spans of <= SPAN elements, each inside one variable ("segment");
+// the host builds the span table once.  Norms are reduced span -> segment in fixed order.
+#include "tnt_common.h"
+
+namespace {
+
+struct SpanTab {
+  const int32_t* span_seg;     // segment of span s
+  const int64_t* span_off;     // first element (arena offset, multiple of 4)
+  const int32_t* span_len;     // elements in span (<= SPAN)
+  const int32_t* seg_first;    // [nseg+1] first span of each segment
+  const float* seg_l2;         // L2 lambda per segment
+};
+
+__global__ __launch_bounds__(256) void span_sqnorm_kernel(const float* theta, const float* grad, SpanTab t,
+                                                          float* partial, int nspan) {
+  __shared__ float s0[4], s1[4];
+  const int sp = blockIdx.x;
+  if (sp >= nspan) return;
+  const long off = t.span_off[sp];
+  const int len = t.span_len[sp];
+  const float lam2 = 2.f * t.seg_l2[t.span_seg[sp]];
+  float q = 0.f, wq = 0.f;
+  const int len4 = len & ~3;
+  for (int i = threadIdx.x * 4; i < len4; i += 1024) {
+    const float4 g = *reinterpret_cast<const float4*>(grad + off + i);
+    const float4 w = *reinterpret_cast<const float4*>(theta + off + i);
+    const float a0 = g.x + lam2 * w.x, a1 = g.y + lam2 * w.y, a2 = g.z + lam2 * w.z, a3 = g.w + lam2 * w.w;
+    q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+    wq += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+  }
+  for (int i = len4 + threadIdx.x; i < len; i += 256) {
+    const float w = theta[off + i], a0 = grad[off + i] + lam2 * w;
+    q += a0 * a0; wq += w * w;
+  }
+  q = tnt_wave_sum(q); wq = tnt_wave_sum(wq);
+  if ((threadIdx.x & 63) == 0) { s0[threadIdx.x >> 6] = q; s1[threadIdx.x >> 6] = wq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * sp + 0] = s0[0] + s0[1] + s0[2] + s0[3];
+    partial[2 * sp + 1] = s1[0] + s1[1] + s1[2] + s1[3];
+  }
+}
+
+__global__ void seg_finalize_kernel(const float* partial, SpanTab t, float* sq, float* wsq, int nseg) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= nseg) return;
+  float a = 0.f, b = 0.f;
+  for (int k = t.seg_first[s]; k < t.seg_first[s + 1]; ++k) { a += partial[2 * k]; b += partial[2 * k + 1]; }
+  sq[s] = a; wsq[s] = b;
+}
+
+__device__ __forceinline__ float clip_scale(const float* sq, const float* sq_override, int seg, float clipnorm) {
+  if (clipnorm <= 0.f) return 1.f;
+  float q = sq[seg];
+  if (sq_override && sq_override[seg] >= 0.f) q = sq_override[seg];
+  return clipnorm / fmaxf(sqrtf(q), clipnorm);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* theta, float* m, float* v, const float* grad, SpanTab t,
+                                                   const float* sq, const float* sq_override, int nspan, float lr_t,
+                                                   const float* lr_t_dev, float b1, float b2, float eps,
+                                                   float clipnorm) {
+  const int sp = blockIdx.x;
+  if (sp >= nspan) return;
+  if (lr_t_dev) lr_t = lr_t_dev[0];
+  const long off = t.span_off[sp];
+  const int len = t.span_len[sp];
+  const int seg = t.span_seg[sp];
+  const float lam2 = 2.f * t.seg_l2[seg];
+  const float cs = clip_scale(sq, sq_override, seg, clipnorm);
+  const float ob1 = 1.f - b1, ob2 = 1.f - b2;
+  const int len4 = len & ~3;
+  for (int i = threadIdx.x * 4; i < len4; i += 1024) {
+    float4 w = *reinterpret_cast<float4*>(theta + off + i);
+    const float4 g4 = *reinterpret_cast<const float4*>(grad + off + i);
+    float4 mm = *reinterpret_cast<float4*>(m + off + i);
+    float4 vv = *reinterpret_cast<float4*>(v + off + i);
+    float* wp = &w.x; float* mp = &mm.x; float* vp = &vv.x; const float* gp = &g4.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = (gp[j] + lam2 * wp[j]) * cs;
+      mp[j] = mp[j] + (g - mp[j]) * ob1;
+      vp[j] = vp[j] + (g * g - vp[j]) * ob2;
+      wp[j] = wp[j] - lr_t * mp[j] / (sqrtf(vp[j]) + eps);
+    }
+    *reinterpret_cast<float4*>(theta + off + i) = w;
+    *reinterpret_cast<float4*>(m + off + i) = mm;
+    *reinterpret_cast<float4*>(v + off + i) = vv;
+  }
+  for (int i = len4 + threadIdx.x; i < len; i += 256) {
+    const float w = theta[off + i];
+    const float g = (grad[off + i] + lam2 * w) * cs;
+    const float mm = m[off + i] + (g - m[off + i]) * ob1;
+    const float vv = v[off + i] + (g * g - v[off + i]) * ob2;
+    m[off + i] = mm; v[off + i] = vv;
+    theta[off + i] = w - lr_t * mm / (sqrtf(vv) + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* theta, float* mom, const float* grad, SpanTab t,
+                                                  const float* sq, const float* sq_override, int nspan, float lr,
+                                                  const float* lr_dev, float momentum, float clipnorm) {
+  const int sp = blockIdx.x;
+  if (sp >= nspan) return;
+  if (lr_dev) lr = lr_dev[0];
+  const long off = t.span_off[sp];
+  const int len = t.span_len[sp];
+  const int seg = t.span_seg[sp];
+  const float lam2 = 2.f * t.seg_l2[seg];
+  const float cs = clip_scale(sq, sq_override, seg, clipnorm);
+  for (int i = threadIdx.x; i < len; i += 256) {
+    const float w = theta[off + i];
+    const float g = (grad[off + i] + lam2 * w) * cs;
+    const float mv = momentum * mom[off + i] - lr * g;
+    mom[off + i] = mv;
+    theta[off + i] = w + mv;
+  }
+}
+
+// advances the device-resident step state (so a captured hipGraph replays with fresh values):
+//   adam_t += 1; lr_t = lr * sqrt(1-b2^t)/(1-b1^t); drop_step += 1
+__global__ void step_tick_kernel(int64_t* adam_t, uint32_t* drop_step, const float* lr, float* lr_t, float b1,
+                                 float b2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (drop_step) drop_step[0] += 1u;
+  if (adam_t) {
+    const int64_t t = adam_t[0] + 1;
+    adam_t[0] = t;
+    if (lr_t) {
+      const double p1 = pow((double)b1, (double)t), p2 = pow((double)b2, (double)t);
+      lr_t[0] = (float)((double)lr[0] * sqrt(1.0 - p2) / (1.0 - p1));
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int32_t tnt_step_tick(int64_t* adam_t, uint32_t* drop_step, const float* lr, float* lr_t, float beta1,
+                                 float beta2, void* stream) {
+  hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, tnt_stream(stream), adam_t, drop_step, lr, lr_t, beta1,
+                     beta2);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_seg_sqnorm_f32(const float* theta, const float* grad, const int32_t* span_seg,
+                                      const int64_t* span_off, const int32_t* span_len, const int32_t* seg_first,
+                                      const float* seg_l2, float* partial, float* sq, float* wsq, int32_t nspan,
+                                      int32_t nseg, void* stream) {
+  if (nspan <= 0 || nseg <= 0) return 0;
+  SpanTab t{span_seg, span_off, span_len, seg_first, seg_l2};
+  hipStream_t s = tnt_stream(stream);
+  hipLaunchKernelGGL(span_sqnorm_kernel, dim3(nspan), dim3(256), 0, s, theta, grad, t, partial, nspan);
+  TNT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(seg_finalize_kernel, dim3((nseg + 255) / 256), dim3(256), 0, s, partial, t, sq, wsq, nseg);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_adam_f32(float* theta, float* m, float* v, const float* grad, const int32_t* span_seg,
+                                const int64_t* span_off, const int32_t* span_len, const float* seg_l2, const float* sq,
+                                const float* sq_override, int32_t nspan, float lr_t, const float* lr_t_dev, float beta1,
+                                float beta2, float eps, float clipnorm, void* stream) {
+  if (nspan <= 0) return 0;
+  SpanTab t{span_seg, span_off, span_len, nullptr, seg_l2};
+  hipLaunchKernelGGL(adam_kernel, dim3(nspan), dim3(256), 0, tnt_stream(stream), theta, m, v, grad, t, sq, sq_override,
+                     nspan, lr_t, lr_t_dev, beta1, beta2, eps, clipnorm);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_sgd_f32(float* theta, float* mom, const float* grad, const int32_t* span_seg,
+                               const int64_t* span_off, const int32_t* span_len, const float* seg_l2, const float* sq,
+                               const float* sq_override, int32_t nspan, float lr, const float* lr_dev, float momentum,
+                               float clipnorm, void* stream) {
+  if (nspan <= 0) return 0;
+  SpanTab t{span_seg, span_off, span_len, nullptr, seg_l2};
+  hipLaunchKernelGGL(sgd_kernel, dim3(nspan), dim3(256), 0, tnt_stream(stream), theta, mom, grad, t, sq, sq_override,
+                     nspan, lr, lr_dev, momentum, clipnorm);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,221 @@
+// Embedding gather / deterministic scatter, softmax + categorical cross-entropy +
+// accuracy (+ its gradient), argmax helpers.
+// Reference ops: keras Embedding (lc_NIC.py:105-112,233; NIC.py:75-79,131), Softmax
+// activation of the output Dense (lc_NIC.py:153; NIC.py:93), CategoricalCrossentropy
+// (main.py:107-110 via lc_NIC.py:461-466), accuracy_calculation (lc_NIC.py:468-486),
+// np.argmax in the greedy decoders (lc_NIC.py:627; NIC.py:192).
+#include "tnt_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void emb_fwd_kernel(const float* table, const int* ids, float* out, int B, int T,
+                                                      int E, int ldo, int V) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // row = t*B + b
+  if (row >= B * T) return;
+  const int t = row / B, b = row % B;
+  int id = ids[b * T + t];
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+  const float* src = table + (long)id * E;
+  float* dst = out + (long)row * ldo;
+  for (int j = lane; j < E; j += 64) dst[j] = src[j];
+}
+
+__global__ __launch_bounds__(256) void rowsq_kernel(const float* x, float* rowsq, int rows, int cols, int ld) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int j = lane; j < cols; j += 64) { const float v = x[(long)row * ld + j]; s += v * v; }
+  s = tnt_wave_sum(s);
+  if (lane == 0) rowsq[row] = s;
+}
+
+// one wave per vocabulary row: sums, in (b,t) order, every contribution row whose id matches.
+// No atomics: bitwise reproducible, and every dtable row is written (no pre-zeroing needed).
+__global__ __launch_bounds__(256) void emb_bwd_kernel(const float* drows, const int* ids, float* dtable, int B, int T,
+                                                      int E, int ldd, int V) {
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (v >= V) return;
+  const int n = B * T;
+  for (int j0 = 0; j0 < E; j0 += 256) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      const int id = i < n ? ids[i] : -1;
+      unsigned long long hit = __ballot(id == v);
+      while (hit) {
+        const int src = __ffsll((long long)hit) - 1;
+        hit &= hit - 1;
+        const int k = base + src;            // k = b*T + t
+        const int b = k / T, t = k % T;
+        const float* r = drows + (long)(t * B + b) * ldd;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = j0 + q * 64 + lane;
+          if (j < E) acc[q] += r[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = j0 + q * 64 + lane;
+      if (j < E) dtable[(long)v * E + j] = acc[q];
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void sum_accum_kernel(const float* x, float* out, int n) {
+  __shared__ float sw[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) s += x[i];
+  s = tnt_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += sw[w];
+    out[0] += t;
+  }
+}
+
+struct ArgMax { float v; int i; };
+__device__ __forceinline__ ArgMax argmax_combine(ArgMax a, ArgMax b) {
+  // larger value wins; ties -> smaller index (np.argmax / tf.argmax first-max rule)
+  if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+  return a;
+}
+__device__ __forceinline__ ArgMax block_argmax(ArgMax a, ArgMax* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ArgMax b; b.v = __shfl_xor(a.v, o, 64); b.i = __shfl_xor(a.i, o, 64);
+    a = argmax_combine(a, b);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = a;
+  __syncthreads();
+  ArgMax r = sh[0];
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) r = argmax_combine(r, sh[k]);
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = tnt_wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int k = 0; k < (int)(blockDim.x >> 6); ++k) r += sh[k];
+  __syncthreads();
+  return r;
+}
+
+// one 256-thread workgroup per row
+__global__ __launch_bounds__(256) void softmax_cce_kernel(const float* logits, const int* target, float* probs,
+                                                          float* loss_row, float* correct_row, float* dlogits, int rows,
+                                                          int V, int ld, float gscale) {
+  __shared__ ArgMax sha[4];
+  __shared__ float shf[4];
+  const int row = blockIdx.x;
+  const float* x = logits + (long)row * ld;
+  ArgMax am; am.v = -INFINITY; am.i = 0x7fffffff;
+  for (int j = threadIdx.x; j < V; j += 256) {
+    const float v = x[j];
+    if (v > am.v) { am.v = v; am.i = j; }
+  }
+  am = block_argmax(am, sha);
+  const float m = am.v;
+  const int y = target ? target[row] : -1;
+  // read the target logit before any thread may overwrite the row (outputs may alias logits)
+  const float xy = (y >= 0 && y < V) ? x[y] : -INFINITY;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < V; j += 256) s += expf(x[j] - m);
+  const float Z = block_sum(s, shf);
+  const float invZ = 1.f / Z;
+  const float py = (y >= 0 && y < V) ? expf(xy - m) * invZ : 0.f;
+  const bool active = (py >= 1e-7f) && (py <= 1.f - 1e-7f);
+  if (threadIdx.x == 0 && target) {
+    const float q = fminf(fmaxf(py, 1e-7f), 1.f - 1e-7f);
+    if (loss_row) loss_row[row] = -logf(q);
+    if (correct_row) correct_row[row] = (am.i == y) ? 1.f : 0.f;
+  }
+  // logits may alias probs/dlogits: every thread reads its own elements before overwriting them
+  for (int j = threadIdx.x; j < V; j += 256) {
+    const float p = expf(x[j] - m) * invZ;
+    if (dlogits) dlogits[(long)row * ld + j] = active ? (p - (j == y ? 1.f : 0.f)) * gscale : 0.f;
+    if (probs && probs != dlogits) probs[(long)row * ld + j] = p;
+  }
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* x, int* out, int rows, int V, int ld) {
+  __shared__ ArgMax sha[4];
+  const int row = blockIdx.x;
+  ArgMax am; am.v = -INFINITY; am.i = 0x7fffffff;
+  for (int j = threadIdx.x; j < V; j += 256) {
+    const float v = x[(long)row * ld + j];
+    if (v > am.v) { am.v = v; am.i = j; }
+  }
+  am = block_argmax(am, sha);
+  if (threadIdx.x == 0) out[row] = am.i == 0x7fffffff ? 0 : am.i;
+}
+
+__global__ __launch_bounds__(256) void onehot_argmax_kernel(const float* onehot, int* ids, int B, int T, int V) {
+  __shared__ ArgMax sha[4];
+  const int k = blockIdx.x;          // k = b*T + t
+  const int b = k / T, t = k % T;
+  const float* x = onehot + (long)k * V;
+  ArgMax am; am.v = -INFINITY; am.i = 0x7fffffff;
+  for (int j = threadIdx.x; j < V; j += 256) {
+    const float v = x[j];
+    if (v > am.v) { am.v = v; am.i = j; }
+  }
+  am = block_argmax(am, sha);
+  if (threadIdx.x == 0) ids[t * B + b] = am.i == 0x7fffffff ? 0 : am.i;
+}
+
+}  // namespace
+
+extern "C" int32_t tnt_embedding_fwd_f32(const float* table, const int32_t* ids, float* out, int32_t B, int32_t T,
+                                         int32_t E, int32_t ldo, int32_t V, void* stream) {
+  hipLaunchKernelGGL(emb_fwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, tnt_stream(stream), table, ids, out, B, T, E,
+                     ldo, V);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_embedding_bwd_f32(const float* drows, const int32_t* ids, float* dtable, float* sq_norm,
+                                         float* rowsq_work, int32_t B, int32_t T, int32_t E, int32_t ldd, int32_t V,
+                                         void* stream) {
+  hipStream_t s = tnt_stream(stream);
+  if (sq_norm) {
+    if (!rowsq_work) return TNT_BADARG(5);
+    hipLaunchKernelGGL(rowsq_kernel, dim3((B * T + 3) / 4), dim3(256), 0, s, drows, rowsq_work, B * T, E, ldd);
+    TNT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_accum_kernel, dim3(1), dim3(1024), 0, s, rowsq_work, sq_norm, B * T);
+    TNT_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(emb_bwd_kernel, dim3((V + 3) / 4), dim3(256), 0, s, drows, ids, dtable, B, T, E, ldd, V);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_softmax_cce_f32(const float* logits, const int32_t* target, float* probs, float* loss_row,
+                                       float* correct_row, float* dlogits, int32_t rows, int32_t V, int32_t ld,
+                                       float gscale, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(softmax_cce_kernel, dim3(rows), dim3(256), 0, tnt_stream(stream), logits, target, probs, loss_row,
+                     correct_row, dlogits, rows, V, ld, gscale);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_onehot_argmax_f32(const float* onehot, int32_t* ids_tmajor, int32_t B, int32_t T, int32_t V,
+                                         void* stream) {
+  hipLaunchKernelGGL(onehot_argmax_kernel, dim3(B * T), dim3(256), 0, tnt_stream(stream), onehot, ids_tmajor, B, T, V);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_argmax_rows_f32(const float* x, int32_t* out, int32_t rows, int32_t V, int32_t ld, void* stream) {
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, tnt_stream(stream), x, out, rows, V, ld);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,54 @@
+// Shared helpers for the gfx950 kernel library (see include/tnt_hip.h for the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/tnt_hip.h"
+
+#define TNT_WAVE 64
+
+#define TNT_LAUNCH_CHECK()                      \
+  do {                                          \
+    hipError_t e_ = hipGetLastError();          \
+    if (e_ != hipSuccess) return -(int32_t)e_;  \
+  } while (0)
+
+#define TNT_BADARG(k) (-1000 - (k))
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+static inline hipStream_t tnt_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline bool tnt_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ float tnt_act(float x, int act, float slope) {
+  switch (act) {
+    case TNT_ACT_LEAKY: return x > 0.f ? x : x * slope;
+    case TNT_ACT_RELU: return x > 0.f ? x : 0.f;
+    case TNT_ACT_TANH: return tanhf(x);
+    default: return x;
+  }
+}
+
+__device__ __forceinline__ float tnt_act_grad(float pre, float dy, int act, float slope) {
+  switch (act) {
+    case TNT_ACT_LEAKY: return pre > 0.f ? dy : dy * slope;
+    case TNT_ACT_RELU: return pre > 0.f ? dy : 0.f;
+    case TNT_ACT_TANH: { float t = tanhf(pre); return dy * (1.f - t * t); }
+    default: return dy;
+  }
+}
+
+__device__ __forceinline__ float tnt_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// wave-wide (64 lanes) reductions
+__device__ __forceinline__ float tnt_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float tnt_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

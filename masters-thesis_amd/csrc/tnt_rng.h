@@ -1,0 +1,40 @@
+// Philox4x32-10 dropout stream (device side).  Bit-exact twin of oracle/philox.py:
+//   element e of the logical tensor: counter = (lo32(e>>2), hi32(e>>2), site, step),
+//   key = (lo32(seed), hi32(seed)); r = philox(counter,key)[e&3];
+//   u = (r>>8) * 2^-24; keep = u >= rate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct TntPhilox4 { uint32_t v[4]; };
+
+__device__ __forceinline__ TntPhilox4 tnt_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                         uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  TntPhilox4 o; o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
+}
+
+// keep decision for logical element e
+__device__ __forceinline__ bool tnt_keep(uint64_t e, float rate, uint64_t seed, uint32_t site, uint32_t step) {
+  const uint64_t g = e >> 2;
+  TntPhilox4 r = tnt_philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), site, step, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint32_t w = r.v[e & 3];
+  const float u = (float)(w >> 8) * 5.9604644775390625e-08f;  // 2^-24
+  return u >= rate;
+}
+
+// 4 consecutive elements starting at e (e % 4 == 0): one Philox call
+__device__ __forceinline__ void tnt_keep4(uint64_t e, float rate, uint64_t seed, uint32_t site, uint32_t step, bool k[4]) {
+  const uint64_t g = e >> 2;
+  TntPhilox4 r = tnt_philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), site, step, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) k[j] = ((float)(r.v[j] >> 8) * 5.9604644775390625e-08f) >= rate;
+}

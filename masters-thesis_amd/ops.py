@@ -1,0 +1,173 @@
+"""Tensor-level wrappers over the C ABI (include/tnt_hip.h).
+
+Each method takes torch device tensors (or views into the flat arenas), passes their
+``data_ptr()`` and the current torch stream to the kernel library, and returns nothing:
+all outputs are written into caller-owned buffers.  PyTorch is plumbing here (memory,
+streams); every arithmetic op of the hot path is a HIP kernel.
+
+``backend()`` returns the active backend.  The only product backend is ``HipBackend``;
+tests may install a CPU stand-in with ``set_backend`` to exercise the host
+orchestration without a GPU (tests/mock_backend.py -- never used by the product).
+"""
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.KernelLibraryError("no GPU visible: the HIP backend needs an MI355X (there is no CPU fallback)")
+
+    @staticmethod
+    def _s():
+        return torch.cuda.current_stream().cuda_stream
+
+    def bn_nchunk(self, rows):
+        return self.lib.tnt_bn_nchunk(rows)
+
+    def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, pre=None,
+             act=ACT_NONE, slope=0.2, accumulate=False, splitk=1, work=None):
+        _lib.check(self.lib.tnt_gemm_f32(_p(A), _p(B), _p(C), _p(bias), _p(pre), M, N, K, lda, ldb, ldc,
+                                         int(transA), int(transB), act, slope, int(accumulate), splitk,
+                                         _p(work), self._s()), "tnt_gemm_f32")
+
+    def dropout(self, x, y, rows, cols, ld, tmajor_B, lwidth, lcol0, rate, seed, site, step, step_dev=None):
+        _lib.check(self.lib.tnt_dropout_f32(_p(x), _p(y), rows, cols, ld, tmajor_B, lwidth, lcol0, rate, seed, site,
+                                            step, _p(step_dev), self._s()), "tnt_dropout_f32")
+
+    def act_bwd(self, pre, dy, dx, n, act, slope=0.2):
+        _lib.check(self.lib.tnt_act_bwd_f32(_p(pre), _p(dy), _p(dx), n, act, slope, self._s()), "tnt_act_bwd_f32")
+
+    def batchnorm_fwd(self, x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, training, eps,
+                      momentum, work):
+        _lib.check(self.lib.tnt_batchnorm_fwd_f32(_p(x), _p(gamma), _p(beta), _p(mov_mean), _p(mov_var), _p(y),
+                                                  _p(xhat), _p(inv_std), rows, C, ldy, int(training), eps, momentum,
+                                                  _p(work), self._s()), "tnt_batchnorm_fwd_f32")
+
+    def batchnorm_bwd(self, dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, training, work):
+        _lib.check(self.lib.tnt_batchnorm_bwd_f32(_p(dy), _p(xhat), _p(gamma), _p(inv_std), _p(dx), _p(dgamma),
+                                                  _p(dbeta), rows, C, lddy, int(training), _p(work), self._s()),
+                   "tnt_batchnorm_bwd_f32")
+
+    def layernorm_fwd(self, x, gamma, beta, y, xhat, inv_std, rows, C, ldy, eps):
+        _lib.check(self.lib.tnt_layernorm_fwd_f32(_p(x), _p(gamma), _p(beta), _p(y), _p(xhat), _p(inv_std), rows, C,
+                                                  ldy, eps, self._s()), "tnt_layernorm_fwd_f32")
+
+    def layernorm_bwd(self, dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, work):
+        _lib.check(self.lib.tnt_layernorm_bwd_f32(_p(dy), _p(xhat), _p(gamma), _p(inv_std), _p(dx), _p(dgamma),
+                                                  _p(dbeta), rows, C, lddy, _p(work), self._s()),
+                   "tnt_layernorm_bwd_f32")
+
+    def colsum(self, x, out, rows, C, ld, work):
+        _lib.check(self.lib.tnt_colsum_f32(_p(x), _p(out), rows, C, ld, _p(work), self._s()), "tnt_colsum_f32")
+
+    def embedding_fwd(self, table, ids, out, B, T, E, ldo, V):
+        _lib.check(self.lib.tnt_embedding_fwd_f32(_p(table), _p(ids), _p(out), B, T, E, ldo, V, self._s()),
+                   "tnt_embedding_fwd_f32")
+
+    def embedding_bwd(self, drows, ids, dtable, sq_norm, rowsq_work, B, T, E, ldd, V):
+        _lib.check(self.lib.tnt_embedding_bwd_f32(_p(drows), _p(ids), _p(dtable), _p(sq_norm), _p(rowsq_work), B, T,
+                                                  E, ldd, V, self._s()), "tnt_embedding_bwd_f32")
+
+    def lstm_step_fwd(self, xz, h_prev, c_prev, Ur, ctx, Wc, D, mask_ids, mask_T, mask_t, out_prev, h, c, out,
+                      gates, B, U):
+        _lib.check(self.lib.tnt_lstm_step_fwd_f32(_p(xz), _p(h_prev), _p(c_prev), _p(Ur), _p(ctx), _p(Wc), D,
+                                                  _p(mask_ids), mask_T, mask_t, _p(out_prev), _p(h), _p(c), _p(out),
+                                                  _p(gates), B, U, self._s()), "tnt_lstm_step_fwd_f32")
+
+    def lstm_step_bwd(self, dz_next, Ur, da_pass_in, dh_ext, dc_in, dout_in, dout_t, mask_ids, mask_T, mask_t,
+                      gates, c, c_prev, dz, da_pass_out, dc_out, dout_out, B, U):
+        _lib.check(self.lib.tnt_lstm_step_bwd_f32(_p(dz_next), _p(Ur), _p(da_pass_in), _p(dh_ext), _p(dc_in),
+                                                  _p(dout_in), _p(dout_t), _p(mask_ids), mask_T, mask_t, _p(gates),
+                                                  _p(c), _p(c_prev), _p(dz), _p(da_pass_out), _p(dc_out),
+                                                  _p(dout_out), B, U, self._s()), "tnt_lstm_step_bwd_f32")
+
+    def softmax_cce(self, logits, target, probs, loss_row, correct_row, dlogits, rows, V, ld, gscale):
+        _lib.check(self.lib.tnt_softmax_cce_f32(_p(logits), _p(target), _p(probs), _p(loss_row), _p(correct_row),
+                                                _p(dlogits), rows, V, ld, gscale, self._s()), "tnt_softmax_cce_f32")
+
+    def onehot_argmax(self, onehot, ids_tmajor, B, T, V):
+        _lib.check(self.lib.tnt_onehot_argmax_f32(_p(onehot), _p(ids_tmajor), B, T, V, self._s()),
+                   "tnt_onehot_argmax_f32")
+
+    def argmax_rows(self, x, out, rows, V, ld):
+        _lib.check(self.lib.tnt_argmax_rows_f32(_p(x), _p(out), rows, V, ld, self._s()), "tnt_argmax_rows_f32")
+
+    def sum(self, x, out, n, scale):
+        _lib.check(self.lib.tnt_sum_f32(_p(x), _p(out), n, scale, self._s()), "tnt_sum_f32")
+
+    def seg_sqnorm(self, theta, grad, span_seg, span_off, span_len, seg_first, seg_l2, partial, sq, wsq, nspan,
+                   nseg):
+        _lib.check(self.lib.tnt_seg_sqnorm_f32(_p(theta), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
+                                               _p(seg_first), _p(seg_l2), _p(partial), _p(sq), _p(wsq), nspan, nseg,
+                                               self._s()), "tnt_seg_sqnorm_f32")
+
+    def adam(self, theta, m, v, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr_t, lr_t_dev,
+             beta1, beta2, eps, clipnorm):
+        _lib.check(self.lib.tnt_adam_f32(_p(theta), _p(m), _p(v), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
+                                         _p(seg_l2), _p(sq), _p(sq_override), nspan, lr_t, _p(lr_t_dev), beta1,
+                                         beta2, eps, clipnorm, self._s()), "tnt_adam_f32")
+
+    def sgd(self, theta, mom, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr, lr_dev,
+            momentum, clipnorm):
+        _lib.check(self.lib.tnt_sgd_f32(_p(theta), _p(mom), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
+                                        _p(seg_l2), _p(sq), _p(sq_override), nspan, lr, _p(lr_dev), momentum,
+                                        clipnorm, self._s()), "tnt_sgd_f32")
+
+    def step_tick(self, adam_t, drop_step, lr, lr_t, beta1, beta2):
+        _lib.check(self.lib.tnt_step_tick(_p(adam_t), _p(drop_step), _p(lr), _p(lr_t), beta1, beta2, self._s()),
+                   "tnt_step_tick")
+
+    def locally_dense_fwd(self, x, ldx, idx, goff, W, bias, pre, y, B, R, D, slope=0.2):
+        _lib.check(self.lib.tnt_locally_dense_fwd_f32(_p(x), ldx, _p(idx), _p(goff), _p(W), _p(bias), _p(pre), _p(y),
+                                                      B, R, D, slope, self._s()), "tnt_locally_dense_fwd_f32")
+
+    def locally_dense_bwd(self, x, ldx, idx, goff, dpre, dW, db, B, R, D):
+        _lib.check(self.lib.tnt_locally_dense_bwd_f32(_p(x), ldx, _p(idx), _p(goff), _p(dpre), _p(dW), _p(db), B, R,
+                                                      D, self._s()), "tnt_locally_dense_bwd_f32")
+
+    def attention_step_fwd(self, h, F, P, W2, b2, v, bv, qpre, alpha, ctx, ctx_d, s_out, B, R, D, A, U, slope,
+                           rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None):
+        _lib.check(self.lib.tnt_attention_step_fwd_f32(_p(h), _p(F), _p(P), _p(W2), _p(b2), _p(v), _p(bv), _p(qpre),
+                                                       _p(alpha), _p(ctx), _p(ctx_d), _p(s_out), B, R, D, A, U, slope,
+                                                       rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step,
+                                                       _p(step_dev), self._s()), "tnt_attention_step_fwd_f32")
+
+    def attention_step_bwd(self, dctx_d, F, P, W2, v, qpre, alpha, dP, dF, dvb, dqpre, dh, B, R, D, A, U, slope,
+                           rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None):
+        _lib.check(self.lib.tnt_attention_step_bwd_f32(_p(dctx_d), _p(F), _p(P), _p(W2), _p(v), _p(qpre), _p(alpha),
+                                                       _p(dP), _p(dF), _p(dvb), _p(dqpre), _p(dh), B, R, D, A, U,
+                                                       slope, rate_attn, rate_in, in_lwidth, seed, site_attn, site_in,
+                                                       step, _p(step_dev), self._s()), "tnt_attention_step_bwd_f32")
+
+    def attention_metric(self, alpha, out, T, B, R):
+        _lib.check(self.lib.tnt_attention_metric_f32(_p(alpha), _p(out), T, B, R, self._s()),
+                   "tnt_attention_metric_f32")
+
+
+_backend = None
+
+
+def backend():
+    """The active backend; created on first use.  Raises (loudly) if the HIP library or the
+    GPU is missing -- there is no silent fallback."""
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+def set_backend(b):
+    """TEST HOOK ONLY: install a stand-in backend (tests/mock_backend.py)."""
+    global _backend
+    _backend = b

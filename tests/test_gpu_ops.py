@@ -1,0 +1,414 @@
+"""Per-kernel parity: every C-ABI entry point against the numpy oracle (float64 truth),
+called through the ctypes binding on a real MI355X.  Tolerance: 1e-4 relative (the
+north-star bound on logits) unless noted; integer/index outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+from oracle.philox import keep_mask
+from helpers import tiny_groups
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda")
+
+
+def close(got, want, rtol=RTOL, atol=None):
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    scale = np.abs(want).max() + 1e-30
+    atol = rtol * scale if atol is None else atol
+    err = np.abs(got - want).max()
+    assert err <= atol, f"max abs err {err:.3e} > {atol:.3e} (scale {scale:.3e})"
+
+
+@pytest.fixture(scope="module")
+def be():
+    import masters_thesis_amd.ops as ops
+    return ops.backend()
+
+
+def il(w, U):
+    """keras [.., 4U] gate blocks -> interleaved [.., U, 4]."""
+    lead = w.shape[:-1]
+    return np.ascontiguousarray(np.moveaxis(w.reshape(*lead, 4, U), -2, -1))
+
+
+def unil(w):
+    """interleaved [.., U, 4] -> keras [.., 4U]."""
+    lead = w.shape[:-2]
+    return np.ascontiguousarray(np.moveaxis(w, -1, -2)).reshape(*lead, -1)
+
+
+# ------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K,tA,tB,pad", [
+    (64, 512, 2000, 0, 0, 0), (960, 5001, 512, 0, 0, 3), (960, 512, 5001, 0, 1, 3), (512, 5001, 960, 1, 0, 3),
+    (33, 17, 29, 0, 0, 0), (33, 17, 29, 0, 1, 0), (33, 17, 29, 1, 0, 0), (200, 130, 64, 1, 0, 2),
+    (1024, 2048, 512, 0, 0, 0), (5, 7, 3, 0, 0, 0), (5, 7, 3, 0, 0, 1),
+])
+def test_gemm(be, M, N, K, tA, tB, pad):
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.standard_normal((M, K))
+    Bm = rng.standard_normal((K, N))
+    bias = rng.standard_normal(N)
+    As = A.T if tA else A
+    Bs = Bm.T if tB else Bm
+    lda, ldb, ldc = As.shape[1] + pad, Bs.shape[1] + pad, N + pad
+    Ad = torch.zeros(As.shape[0], lda, device="cuda"); Ad[:, :As.shape[1]] = dev(As)
+    Bd = torch.zeros(Bs.shape[0], ldb, device="cuda"); Bd[:, :Bs.shape[1]] = dev(Bs)
+    Cd = torch.full((M, ldc), 7.0, device="cuda")
+    Pd = torch.zeros(M, ldc, device="cuda")
+    be.gemm(Ad, Bd, Cd, M, N, K, lda, ldb, ldc, bool(tA), bool(tB), bias=dev(bias), pre=Pd, act=1, slope=0.2)
+    pre = A @ Bm + bias
+    close(Pd[:, :N], pre)
+    close(Cd[:, :N], np.where(pre > 0, pre, 0.2 * pre))
+    if pad:
+        assert (Cd[:, N:] == 7.0).all()      # padding untouched
+    # accumulate
+    C2 = torch.ones(M, ldc, device="cuda")
+    be.gemm(Ad, Bd, C2, M, N, K, lda, ldb, ldc, bool(tA), bool(tB), accumulate=True)
+    close(C2[:, :N], A @ Bm + 1.0)
+
+
+def test_gemm_splitk(be):
+    rng = np.random.default_rng(0)
+    M, N, K = 64, 512, 20000
+    A, Bm, bias = rng.standard_normal((M, K)), rng.standard_normal((K, N)), rng.standard_normal(N)
+    splitk = 40
+    work = torch.empty(splitk * M * N, device="cuda")
+    Cd = torch.zeros(M, N, device="cuda"); Pd = torch.zeros(M, N, device="cuda")
+    be.gemm(dev(A), dev(Bm), Cd, M, N, K, K, N, N, bias=dev(bias), pre=Pd, act=1, splitk=splitk, work=work)
+    pre = A @ Bm + bias
+    close(Pd, pre)
+    close(Cd, np.where(pre > 0, pre, 0.2 * pre))
+
+
+def test_gemm_graph_capture(be):
+    """The library's launches must be capturable on torch's stream (hipGraph replay)."""
+    rng = np.random.default_rng(1)
+    A, Bm = rng.standard_normal((128, 64)), rng.standard_normal((64, 128))
+    Ad, Bd, Cd = dev(A), dev(Bm), torch.zeros(128, 128, device="cuda")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        be.gemm(Ad, Bd, Cd, 128, 128, 64, 64, 128, 128)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        be.gemm(Ad, Bd, Cd, 128, 128, 64, 64, 128, 128)
+    Cd.zero_()
+    Ad.copy_(dev(2 * A))
+    g.replay()
+    torch.cuda.synchronize()
+    close(Cd, 2 * A @ Bm)
+
+
+# --------------------------------------------------------------------------- dropout
+@pytest.mark.parametrize("tmajor", [False, True])
+def test_dropout_bit_exact(be, tmajor):
+    rng = np.random.default_rng(2)
+    B, T, E, rate = 6, 5, 37, 0.2
+    x = rng.standard_normal((B, T, E)).astype(np.float32)
+    keep = keep_mask((B, T, E + 3), rate, seed=1234567890123, site=49, step=7)[:, :, 3:]   # lcol0 = 3
+    want = np.where(keep, x * np.float32(1.0 / (1.0 - np.float32(rate))), 0).astype(np.float32)
+    step_dev = torch.tensor([4], dtype=torch.int32, device="cuda")
+    if tmajor:
+        xd = dev(x.transpose(1, 0, 2).reshape(T * B, E)); yd = torch.zeros_like(xd)
+        be.dropout(xd, yd, T * B, E, E, B, E + 3, 3, rate, 1234567890123, 49, 3, step_dev)
+        got = yd.cpu().numpy().reshape(T, B, E).transpose(1, 0, 2)
+    else:
+        xd = dev(x.reshape(B * T, E)); yd = torch.zeros_like(xd)
+        be.dropout(xd, yd, B * T, E, E, 0, E + 3, 3, rate, 1234567890123, 49, 3, step_dev)
+        got = yd.cpu().numpy().reshape(B, T, E)
+    assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("rows,C", [(64, 512), (1440, 32), (7, 5)])
+def test_batchnorm(be, rows, C):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((rows, C)) * 2 + 1.5
+    gam, bet = rng.standard_normal(C), rng.standard_normal(C)
+    mm0, mv0 = rng.standard_normal(C), rng.random(C) + 0.5
+    dy = rng.standard_normal((rows, C))
+    nch = be.bn_nchunk(rows)
+    work = torch.zeros(C * (2 * nch + 1), device="cuda")
+    for training in (True, False):
+        mm, mv = dev(mm0), dev(mv0)
+        y, xhat, inv = torch.zeros(rows, C, device="cuda"), torch.zeros(rows, C, device="cuda"), torch.zeros(C, device="cuda")
+        be.batchnorm_fwd(dev(x), dev(gam), dev(bet), mm, mv, y, xhat, inv, rows, C, C, training, 1e-3, 0.99, work)
+        yo, cache, mmo, mvo = O.batchnorm_fwd(x, gam, bet, mm0, mv0, training)
+        close(y, yo); close(mm, mmo); close(mv, mvo)
+        dx, dg, db = torch.zeros(rows, C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        be.batchnorm_bwd(dev(dy), xhat, dev(gam), inv, dx, dg, db, rows, C, C, training, work)
+        dxo, dgo, dbo = O.batchnorm_bwd(dy, gam, cache)
+        close(dx, dxo); close(dg, dgo); close(db, dbo)
+
+
+@pytest.mark.parametrize("rows,C", [(64, 512), (9, 33)])
+def test_layernorm(be, rows, C):
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((rows, C)) * 2 + 1.5
+    gam, bet, dy = rng.standard_normal(C), rng.standard_normal(C), rng.standard_normal((rows, C))
+    y, xhat, inv = torch.zeros(rows, C, device="cuda"), torch.zeros(rows, C, device="cuda"), torch.zeros(rows, device="cuda")
+    be.layernorm_fwd(dev(x), dev(gam), dev(bet), y, xhat, inv, rows, C, C, 1e-3)
+    yo, cache = O.layernorm_fwd(x, gam, bet)
+    close(y, yo)
+    work = torch.zeros(C * (2 * be.bn_nchunk(rows) + 1), device="cuda")
+    dx, dg, db = torch.zeros(rows, C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    be.layernorm_bwd(dev(dy), xhat, dev(gam), inv, dx, dg, db, rows, C, C, work)
+    dxo, dgo, dbo = O.layernorm_bwd(dy, gam, cache)
+    close(dx, dxo); close(dg, dgo); close(db, dbo)
+
+
+def test_colsum_sum_actbwd(be):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((960, 5001))
+    xd = torch.zeros(960, 5004, device="cuda"); xd[:, :5001] = dev(x)
+    out = torch.zeros(5001, device="cuda")
+    work = torch.zeros(5001 * be.bn_nchunk(960), device="cuda")
+    be.colsum(xd, out, 960, 5001, 5004, work)
+    close(out, x.sum(0))
+    v = rng.standard_normal(960)
+    o = torch.zeros(1, device="cuda")
+    be.sum(dev(v), o, 960, 0.5)
+    close(o, [0.5 * v.sum()])
+    pre, dy = rng.standard_normal(1000), rng.standard_normal(1000)
+    dx = torch.zeros(1000, device="cuda")
+    be.act_bwd(dev(pre), dev(dy), dx, 1000, 1, 0.2)
+    close(dx, np.where(pre > 0, dy, 0.2 * dy))
+
+
+# -------------------------------------------------------------------------- embedding
+def test_embedding(be):
+    rng = np.random.default_rng(6)
+    B, T, E, V = 8, 5, 70, 23
+    table = rng.standard_normal((V, E))
+    ids = rng.integers(0, V, (B, T)).astype(np.int32)
+    ids[0, :] = 3                                        # duplicates
+    out = torch.zeros(T * B, E, device="cuda")
+    idd = dev(ids, torch.int32)
+    be.embedding_fwd(dev(table), idd, out, B, T, E, E, V)
+    want = table[ids].transpose(1, 0, 2).reshape(T * B, E)
+    assert np.array_equal(out.cpu().numpy(), want.astype(np.float32))
+    drows = rng.standard_normal((B, T, E))
+    dtab = torch.full((V, E), 9.0, device="cuda")
+    sq = torch.zeros(1, device="cuda")
+    be.embedding_bwd(dev(drows.transpose(1, 0, 2).reshape(T * B, E)), idd, dtab, sq, torch.zeros(B * T, device="cuda"),
+                     B, T, E, E, V)
+    close(dtab, O.embedding_bwd_dense(drows, ids, V))
+    close(sq, [(drows ** 2).sum()])
+
+
+# ------------------------------------------------------------------------------- LSTM
+@pytest.mark.parametrize("B,U,D,masked", [(64, 512, 0, False), (64, 512, 32, False), (5, 16, 3, False),
+                                          (20, 32, 0, True)])
+def test_lstm_step(be, B, U, D, masked):
+    rng = np.random.default_rng(7 + B)
+    xz = rng.standard_normal((B, 4 * U)) * 0.5
+    h0, c0 = rng.standard_normal((B, U)) * 0.5, rng.standard_normal((B, U)) * 0.5
+    Ur = rng.standard_normal((U, 4 * U)) / np.sqrt(U)
+    ctx = rng.standard_normal((B, D)) if D else None
+    Wc = rng.standard_normal((D, 4 * U)) / np.sqrt(max(D, 1)) if D else None
+    T = 3
+    ids = rng.integers(0, 3, (B, T)).astype(np.int32) if masked else None
+    outp = rng.standard_normal((B, U))
+    xz_eff = xz + (ctx @ Wc if D else 0)
+    h2, c2, cache = O.lstm_step_fwd(xz_eff, h0, c0, Ur)
+    i, f, g, o = cache[:4]
+    if masked:
+        m = (ids[:, 1] != 0)[:, None]
+        hw, cw, ow = np.where(m, h2, h0), np.where(m, c2, c0), np.where(m, h2, outp)
+    else:
+        hw, cw, ow = h2, c2, h2
+    z = lambda: torch.zeros(B, U, device="cuda")
+    h, c, out, gates = z(), z(), z(), torch.zeros(B, U, 4, device="cuda")
+    be.lstm_step_fwd(dev(il(xz, U)), dev(h0), dev(c0), dev(il(Ur, U)), dev(ctx) if D else None,
+                     dev(il(Wc, U)) if D else None, D, dev(ids, torch.int32) if masked else None, T, 1,
+                     dev(outp) if masked else None, h, c, out, gates, B, U)
+    close(h, hw); close(c, cw); close(out, ow)
+    close(gates, np.stack([i, f, g, o], axis=-1))
+    # backward: step t given dz_next of step t+1
+    dz_next = rng.standard_normal((B, 4 * U)) * 0.3
+    da_in, dh_ext, dc_in = rng.standard_normal((B, U)), rng.standard_normal((B, U)), rng.standard_normal((B, U))
+    dout_in, dout_t = rng.standard_normal((B, U)), rng.standard_normal((B, U))
+    da = da_in + dh_ext + dz_next @ Ur.T
+    dout = dout_in + dout_t
+    dzo, _, dcp = O.lstm_step_bwd(da + dout, dc_in, cache, Ur)
+    if masked:
+        dzw = np.where(np.repeat(m, 4 * U, 1), dzo, 0)
+        dcw, daw, dow = np.where(m, dcp, dc_in), np.where(m, 0, da), np.where(m, 0, dout)
+    else:
+        dzw, dcw, daw, dow = dzo, dcp, 0 * da, 0 * dout
+    dz, da_o, dc_o, do_o = torch.zeros(B, U, 4, device="cuda"), z(), z(), z()
+    be.lstm_step_bwd(dev(il(dz_next, U)), dev(il(Ur, U)), dev(da_in), dev(dh_ext), dev(dc_in), dev(dout_in),
+                     dev(dout_t), dev(ids, torch.int32) if masked else None, T, 1, gates, dev(c2), dev(c0), dz, da_o,
+                     dc_o, do_o, B, U)
+    close(unil(dz.cpu().numpy()), dzw); close(dc_o, dcw); close(da_o, daw); close(do_o, dow)
+    # first backward step: no dz_next, optional pointers null
+    dz.zero_()
+    be.lstm_step_bwd(None, dev(il(Ur, U)), None, None, None, None, dev(dout_t), None, 0, 0, gates, dev(c2), dev(c0),
+                     dz, None, dc_o, None, B, U)
+    dzo, _, dcp = O.lstm_step_bwd(dout_t, 0 * dc_in, cache, Ur)
+    close(unil(dz.cpu().numpy()), dzo); close(dc_o, dcp)
+
+
+# ---------------------------------------------------------------------- softmax + CCE
+def test_softmax_cce(be):
+    rng = np.random.default_rng(8)
+    rows, V, ld = 96, 5001, 5004
+    logits = rng.standard_normal((rows, V)) * 3
+    logits[0, 17] = 60.0          # p_y > 1-1e-7 when y = 17 -> clip active
+    logits[1, 5] = -60.0          # p_y < 1e-7 when y = 5
+    y = rng.integers(0, V, rows).astype(np.int32)
+    y[0], y[1] = 17, 5
+    logits[2, 100] = logits[2, 200] = logits[2].max() + 1     # tie -> first index
+    p = O.softmax(logits)
+    ld_ = torch.zeros(rows, ld, device="cuda"); ld_[:, :V] = dev(logits)
+    probs, dl = torch.zeros(rows, ld, device="cuda"), torch.zeros(rows, ld, device="cuda")
+    loss, corr = torch.zeros(rows, device="cuda"), torch.zeros(rows, device="cuda")
+    be.softmax_cce(ld_, dev(y, torch.int32), probs, loss, corr, dl, rows, V, ld, 1.0 / rows)
+    close(probs[:, :V], p)
+    close(loss, O.cce_from_probs(p, y), rtol=2e-4)
+    assert np.array_equal(corr.cpu().numpy(), (p.argmax(-1) == y).astype(np.float32))
+    want = O.cce_softmax_bwd(p, y, np.full(rows, 1.0 / rows))
+    close(dl[:, :V], want)
+    assert (dl[0] == 0).all() and (dl[1] == 0).all()
+    # in place
+    be.softmax_cce(ld_, dev(y, torch.int32), ld_, loss, corr, None, rows, V, ld, 0.0)
+    close(ld_[:, :V], p)
+    am = torch.zeros(rows, dtype=torch.int32, device="cuda")
+    be.argmax_rows(ld_, am, rows, V, ld)
+    assert np.array_equal(am.cpu().numpy(), p.argmax(-1))
+    assert am[2].item() == 100
+
+
+def test_onehot_argmax(be):
+    rng = np.random.default_rng(9)
+    B, T, V = 4, 3, 50
+    ids = rng.integers(0, V, (B, T))
+    oh = np.zeros((B, T, V), np.float32)
+    np.put_along_axis(oh, ids[..., None], 1.0, -1)
+    out = torch.zeros(T * B, dtype=torch.int32, device="cuda")
+    be.onehot_argmax(dev(oh), out, B, T, V)
+    assert np.array_equal(out.cpu().numpy().reshape(T, B).T, ids)
+
+
+# -------------------------------------------------------------------------- optimizer
+def test_optimizer(be):
+    from masters_thesis_amd.arena import build_spans
+    rng = np.random.default_rng(10)
+    lens = [20000, 7, 4096 * 3 + 5, 64]
+    l2 = [0.01, 0.0, 3e-5, 0.0]
+    offs, total = [], 0
+    for n in lens:
+        offs.append(total)
+        total += (n + 63) // 64 * 64
+    theta = np.zeros(total); grad = np.zeros(total); m0 = np.zeros(total); v0 = np.zeros(total)
+    for o, n in zip(offs, lens):
+        theta[o:o + n] = rng.standard_normal(n); grad[o:o + n] = rng.standard_normal(n) * 0.01
+        m0[o:o + n] = rng.standard_normal(n) * 0.01; v0[o:o + n] = rng.random(n) * 1e-4
+    sp = build_spans(offs, lens, device="cuda")
+    nseg = len(lens)
+    sq, wsq = torch.zeros(nseg, device="cuda"), torch.zeros(nseg, device="cuda")
+    part = torch.zeros(2 * sp.nspan, device="cuda")
+    th, gr, md, vd = dev(theta), dev(grad), dev(m0), dev(v0)
+    l2d = dev(l2)
+    be.seg_sqnorm(th, gr, sp.span_seg, sp.span_off, sp.span_len, sp.seg_first, l2d, part, sq, wsq, sp.nspan, nseg)
+    geff = [grad[o:o + n] + 2 * l * theta[o:o + n] for o, n, l in zip(offs, lens, l2)]
+    close(sq, [(g * g).sum() for g in geff], rtol=1e-5)
+    close(wsq, [(theta[o:o + n] ** 2).sum() for o, n in zip(offs, lens)], rtol=1e-5)
+    ovr = dev([-1.0, -1.0, -1.0, 25.0])
+    state_t = torch.zeros(1, dtype=torch.int64, device="cuda"); state_t += 4
+    dstep = torch.zeros(1, dtype=torch.int32, device="cuda")
+    lr, lr_t = dev([1e-4]), torch.zeros(1, device="cuda")
+    be.step_tick(state_t, dstep, lr, lr_t, 0.9, 0.98)
+    assert state_t.item() == 5 and dstep.item() == 1
+    close(lr_t, [1e-4 * np.sqrt(1 - 0.98 ** 5) / (1 - 0.9 ** 5)], rtol=1e-6)
+    be.adam(th, md, vd, gr, sp.span_seg, sp.span_off, sp.span_len, l2d, sq, ovr, sp.nspan, 0.0, lr_t, 0.9, 0.98, 1e-8,
+            0.1)
+    for k, (o, n) in enumerate(zip(offs, lens)):
+        nrm = np.sqrt((geff[k] ** 2).sum()) if k != 3 else 5.0
+        g = geff[k] * 0.1 / max(nrm, 0.1)
+        tw, mw, vw = O.adam_update(theta[o:o + n], m0[o:o + n], v0[o:o + n], g, 5)
+        close(th[o:o + n], tw, rtol=1e-6); close(md[o:o + n], mw, rtol=1e-5); close(vd[o:o + n], vw, rtol=1e-5)
+    # SGD momentum
+    th2, mom = dev(theta), dev(m0)
+    be.sgd(th2, mom, gr, sp.span_seg, sp.span_off, sp.span_len, l2d, sq, None, sp.nspan, 1e-2, None, 0.9, 0.0)
+    for k, (o, n) in enumerate(zip(offs, lens)):
+        tw, mw = O.sgd_momentum_update(theta[o:o + n], m0[o:o + n], geff[k], 1e-2)
+        close(th2[o:o + n], tw, rtol=1e-6)
+
+
+# ------------------------------------------------------------------- locally dense
+@pytest.mark.parametrize("B,N,R,D", [(64, 2000, 36, 32), (3, 37, 4, 16), (64, 3000, 5, 32)])
+def test_locally_dense(be, B, N, R, D):
+    rng = np.random.default_rng(11)
+    groups = tiny_groups(N, R, rng)
+    x = rng.standard_normal((B, N))
+    Ws = [rng.standard_normal((len(g), D)) / np.sqrt(len(g)) for g in groups]
+    bs = [rng.standard_normal(D) * 0.1 for _ in groups]
+    goff = np.concatenate([[0], np.cumsum([len(g) for g in groups])]).astype(np.int32)
+    idx = np.concatenate(groups).astype(np.int32)
+    W = np.concatenate(Ws, axis=0)
+    bias = np.stack(bs)
+    pre, y = torch.zeros(B, R, D, device="cuda"), torch.zeros(B, R, D, device="cuda")
+    xd, idd, gd = dev(x), dev(idx, torch.int32), dev(goff, torch.int32)
+    be.locally_dense_fwd(xd, N, idd, gd, dev(W), dev(bias), pre, y, B, R, D, 0.2)
+    yo, preo = O.locally_dense_fwd(x, groups, Ws, bs)
+    close(pre, preo); close(y, yo)
+    dpre = rng.standard_normal((B, R, D))
+    dW, db = torch.zeros_like(dev(W)), torch.zeros(R, D, device="cuda")
+    be.locally_dense_bwd(xd, N, idd, gd, dev(dpre), dW, db, B, R, D)
+    dWo = [x[:, g].T @ dpre[:, r] for r, g in enumerate(groups)]
+    close(dW, np.concatenate(dWo, axis=0)); close(db, dpre.sum(0))
+
+
+# ---------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,R,D,A,U,rate", [(64, 360, 32, 32, 512, 0.2), (3, 4, 5, 3, 16, 0.0), (4, 50, 48, 40, 32, 0.3)])
+def test_attention_step(be, B, R, D, A, U, rate):
+    rng = np.random.default_rng(12)
+    F, h = rng.standard_normal((B, R, D)), rng.standard_normal((B, U)) * 0.5
+    W1, b1 = rng.standard_normal((D, A)) / np.sqrt(D), rng.standard_normal(A) * 0.1
+    W2, b2 = rng.standard_normal((U, A)) / np.sqrt(U), rng.standard_normal(A) * 0.1
+    v, bv = rng.standard_normal((A, 1)), rng.standard_normal(1)
+    seed, site_a, site_i, step, lw = 77, 16 + 3, 48 + 3, 5, D + 20
+    rate_in = 0.25 if rate > 0 else 0.0
+    keep = keep_mask((B, R, A), rate, seed, site_a, step) if rate > 0 else None
+    keep_in = keep_mask((B, lw), rate_in, seed, site_i, step)[:, :D] if rate_in > 0 else None
+    P, _ = O.attention_proj_fwd(F, W1, b1)
+    (ctx, alpha, sd), cache = O.attention_step_fwd(h, F, P, W2, b2, v, bv, keep, rate)
+    ctx_d = O.dropout_fwd(ctx, keep_in, rate_in)
+    qpre, al, cx, cxd = (torch.zeros(B, A, device="cuda"), torch.zeros(B, R, device="cuda"),
+                         torch.zeros(B, D, device="cuda"), torch.zeros(B, D, device="cuda"))
+    s_out = torch.zeros(B, R, A, device="cuda")
+    Fd, Pd, W2d, vd = dev(F), dev(P), dev(W2), dev(v[:, 0])
+    be.attention_step_fwd(dev(h), Fd, Pd, W2d, dev(b2), vd, dev(bv), qpre, al, cx, cxd, s_out, B, R, D, A, U, 0.2, rate,
+                          rate_in, lw, seed, site_a, site_i, step)
+    close(al, alpha); close(cx, ctx); close(cxd, ctx_d); close(s_out, sd); close(qpre, cache[1])
+    dctx_d = rng.standard_normal((B, D))
+    dctx = O.dropout_bwd(dctx_d, keep_in, rate_in)
+    dh, dF, dsum, dW2, db2, dv, dbv = O.attention_step_bwd(dctx, F, W2, v, cache)
+    dP0, dF0 = rng.standard_normal((B, R, A)), rng.standard_normal((B, R, D))
+    dPd, dFd, dvb = dev(dP0), dev(dF0), torch.zeros(B, A + 1, device="cuda")
+    dq, dhd = torch.zeros(B, A, device="cuda"), torch.zeros(B, U, device="cuda")
+    be.attention_step_bwd(dev(dctx_d), Fd, Pd, W2d, vd, qpre, al, dPd, dFd, dvb, dq, dhd, B, R, D, A, U, 0.2, rate,
+                          rate_in, lw, seed, site_a, site_i, step)
+    close(dhd, dh); close(dPd, dP0 + dsum); close(dFd, dF0 + dF)
+    close(dvb[:, :A].sum(0), dv[:, 0], atol=1e-4 * (np.abs(dv).max() + 1))
+    close(h.T @ dq.cpu().double().numpy(), dW2, atol=1e-4 * (np.abs(dW2).max() + 1))
+    assert abs(dvb[:, A].sum().item()) < 1e-4
+
+
+def test_attention_metric(be):
+    rng = np.random.default_rng(13)
+    T, B, R = 5, 8, 30
+    alpha = O.softmax(rng.standard_normal((T, B, R)), axis=-1)
+    out = torch.zeros(1, device="cuda")
+    be.attention_metric(dev(alpha), out, T, B, R)
+    close(out, [((1 - alpha.sum(1)) ** 2).mean()])
