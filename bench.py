@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark: caption-tokens/sec, training (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|attention]
+
+One "step" = one full train_step (forward + backward + clip + Adam) of the hot path on one
+synthetic batch already resident in HBM.  Workload at N=1 is BASELINE config 2
+(20k-voxel dense encoder + 512-unit LSTM, B=64, T=15, V=5001); ``--workload attention`` runs
+config 3.  N>1: one process per GPU (torchrun), weak scaling (B=64 per GPU), gradient
+all-reduce of the flat arena over RCCL.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+B, T, V, U, E, N_VOX = 64, 15, 5001, 512, 512, 20000
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak
+
+
+def synth(rank, device):
+    """SURVEY 8d synthetic batch: betas ~ N(0,1); caption = <start>, 6..13 tokens, <end>, zero pad."""
+    rng = np.random.default_rng(42 + rank)
+    x = rng.standard_normal((B, N_VOX)).astype(np.float32)
+    cap = np.zeros((B, T), np.int32)
+    for b in range(B):
+        L = int(rng.integers(6, 14))
+        cap[b, 0] = 1
+        cap[b, 1:1 + L] = rng.integers(3, V, size=L)
+        cap[b, 1 + L] = 2
+    tgt = np.zeros_like(cap)
+    tgt[:, :-1] = cap[:, 1:]
+    z = np.zeros((B, U), np.float32)
+    to = lambda a, dt: torch.as_tensor(a, dtype=dt).to(device)
+    return ((to(x, torch.float32), to(cap, torch.int32), to(z, torch.float32), to(z, torch.float32)),
+            to(tgt, torch.int32)), (x, cap, z, tgt)
+
+
+def make_model(workload, device, grad_sync=None):
+    from masters_thesis_amd.optimizers import Adam
+    if workload == "dense":
+        from masters_thesis_amd.nic import NIC
+        # dropout rates of AttemptFour/config.yaml:36-41 mapped onto NIC.py's three rates
+        model = NIC(N_VOX, U, E, V, T, 0.0, 0.2, 0.2, 0.01, 0.00003, 0.00001, device=device, seed=42,
+                    grad_sync=grad_sync)
+    else:
+        from masters_thesis_amd.lc_nic import NIC as LcNIC, synthetic_groups
+        groups = synthetic_groups(N_VOX, 360, 32, seed=42)
+        model = LcNIC(groups, U, 512, E, 32, V, T, 0.0, 0.2, 0.2, 0.2, 0.2, 0.2, 0.01, 0.001, 0.00003, 0.00001,
+                      device=device, seed=42, grad_sync=grad_sync)
+    model.compile(Adam(learning_rate=0.0001, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    return model
+
+
+def cpu_baseline(workload, host_batch, budget_s=20.0):
+    """The oracle (numpy float32 port of the reference path) timed on this host's cores."""
+    from oracle import models as M
+    x, cap, z, tgt = host_batch
+    rng = np.random.default_rng(0)
+    if workload == "dense":
+        orc = M.NICDense(N_VOX, U, E, V, T, 0.0, 0.2, 0.2, 0.01, 3e-5, 1e-5).init_params(rng, np.float32)
+    else:
+        from masters_thesis_amd.lc_nic import synthetic_groups
+        orc = M.LcNIC(synthetic_groups(N_VOX, 360, 32, seed=42), U, 512, E, 32, V, T, 0.0, 0.2, 0.2, 0.2, 0.2, 0.2,
+                      0.01, 0.001, 3e-5, 1e-5).init_params(rng, np.float32)
+    opt = M.AdamState(orc.p, lr=1e-4, clipnorm=0.1)
+    data = (x, cap, z, z)
+    orc.train_step(data, tgt, opt, M.DropCtx(seed=42, step=0, training=True))     # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.train_step(data, tgt, opt, M.DropCtx(seed=42, step=n + 1, training=True))
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    try:
+        import threadpoolctl
+        cores = max(i.get("num_threads", 1) for i in threadpoolctl.threadpool_info() if i.get("user_api") == "blas")
+    except Exception:
+        cores = os.cpu_count()
+    return {"value": round(n * B * T / el, 1), "unit": "caption-tokens/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n} full train steps of the same workload (numpy float32 oracle, BLAS threads = cores), "
+                      f"{el:.1f} s"}
+
+
+def dominant_kernel_roofline(model, workload, steps=20):
+    """Times the dominant kernel of the step live with HIP events on the launch stream.
+    Dense workload: the vocabulary-head GEMM family (3 of them: logits, dW, dX), FP32-MFMA bound.
+    achieved = algorithmic FLOPs (2*M*N*K) / average launch duration."""
+    be = model.be
+    Bt = B * T
+    if workload == "dense":
+        a = model.arena
+        Wo, ldV = a.p("time_distributed_softmax/kernel"), model.ldV
+        launch = lambda: be.gemm(model.Out, Wo, model.logits, Bt, V, U, U, ldV, ldV,
+                                 bias=a.p("time_distributed_softmax/bias"))
+        flops = 2.0 * Bt * V * U
+        name = "gemm_kernel<NN> logits = Out[960x512] @ Wo[512x5001]"
+    else:
+        a = model.arena
+        Wo, ldV, H = a.p("time_distributed_softmax/kernel"), model.ldV, model.H
+        launch = lambda: be.gemm(model.inter_d, Wo, model.logits, Bt, V, H, H, ldV, ldV,
+                                 bias=a.p("time_distributed_softmax/bias"))
+        flops = 2.0 * Bt * V * H
+        name = "gemm_kernel<NN> logits = inter[960x256] @ Wo[256x5001]"
+    for _ in range(3):
+        launch()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(steps):
+        launch()
+    ev[1].record()
+    torch.cuda.synchronize()
+    dur_s = ev[0].elapsed_time(ev[1]) / 1e3 / steps
+    ach = flops / dur_s / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+            "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None, "kernel": name,
+            "avg_launch_us": round(dur_s * 1e6, 2), "flops_per_launch": flops}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="dense", choices=["dense", "attention"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torchrun with WORLD_SIZE={args.gpus} (got {world})")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    grad_sync = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        from masters_thesis_amd.dp import make_grad_sync
+        grad_sync = make_grad_sync(world)
+
+    model = make_model(args.workload, device, grad_sync)
+    if world > 1:
+        from masters_thesis_amd.dp import broadcast_parameters
+        broadcast_parameters(model)
+    batch, host_batch = synth(rank, device)
+
+    for _ in range(args.warmup):
+        model.train_step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.train_step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    last = model.train_step(batch).as_floats()
+
+    if rank == 0:
+        tokens = world * B * T * args.steps
+        out = {
+            "metric": "caption-tokens/sec training (20k-voxel enc, 512 LSTM, B=64)",
+            "value": round(tokens / el, 1), "unit": "caption-tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("config 2: AttemptFour NIC.py dense 20000->512 encoder + BatchNorm + 512-unit LSTM, "
+                                    "V=5001, T=15, B=64/GPU" if args.workload == "dense" else
+                                    "config 3: lc_NIC locally-dense 20000->360x32 + additive attention + 512-unit LSTM, "
+                                    "V=5001, T=15, B=64/GPU"),
+                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
+                       "final_loss": round(last["loss"], 4)},
+        }
+        out["roofline"] = dominant_kernel_roofline(model, args.workload)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.workload, host_batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

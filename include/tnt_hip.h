@@ -162,13 +162,15 @@ int32_t tnt_sum_f32(const float* x, float* out, int32_t n, float scale, void* st
  * floats, multiple of 4), span_len[k]; seg_first[s..s+1] = spans of segment s;
  * seg_l2[s] = L2 lambda (the gradient gets + 2*lambda*theta, lc_NIC.py:47-50).
  * sqnorm: sq[s] = sum (g + 2 lambda theta)^2, wsq[s] = sum theta^2 (L2 metric);
- * partial: 2*nspan floats.  If sq_override[s] >= 0 it replaces sq[s] for clipping
+ * partial: 2*nspan floats; l2_out (nullable) = sum_s lambda_s*wsq[s] (the 'L2' metric,
+ * tf.add_n(self.losses), lc_NIC.py:379).  If sq_override[s] >= 0 it replaces sq[s] for clipping
  * (Embedding IndexedSlices norm).  clipnorm <= 0 disables clipping.
  * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is read from lr_t_dev when non-null. */
 int32_t tnt_seg_sqnorm_f32(const float* theta, const float* grad, const int32_t* span_seg,
                            const int64_t* span_off, const int32_t* span_len,
                            const int32_t* seg_first, const float* seg_l2, float* partial,
-                           float* sq, float* wsq, int32_t nspan, int32_t nseg, void* stream);
+                           float* sq, float* wsq, float* l2_out, int32_t nspan, int32_t nseg,
+                           void* stream);
 int32_t tnt_adam_f32(float* theta, float* m, float* v, const float* grad,
                      const int32_t* span_seg, const int64_t* span_off, const int32_t* span_len,
                      const float* seg_l2, const float* sq, const float* sq_override,

@@ -57,16 +57,22 @@ class ParamArena:
         self.total = 0
         self.theta = self.grad = None
 
-    def add(self, name, shape, l2=0.0):
+    def add(self, name, shape, l2=0.0, align=ALIGN):
+        """Register a trainable tensor.  ``align`` (floats, multiple of 4) pads the slot; with
+        align=4 and sizes that are multiples of 4, consecutive adds are exactly contiguous
+        (used for the per-region encoder kernels, which one kernel launch reads as a CSR
+        concatenation while each stays its own clipnorm variable)."""
         assert self.theta is None, "arena already finalized"
+        assert align % 4 == 0
         size = int(np.prod(shape))
         e = Entry(name, self.total, tuple(int(s) for s in shape), size, float(l2), len(self.entries))
         self.entries[name] = e
-        self.total += (size + ALIGN - 1) // ALIGN * ALIGN
+        self.total += (size + align - 1) // align * align
         return e
 
     def finalize(self):
         dev = self.device
+        self.total = (self.total + ALIGN - 1) // ALIGN * ALIGN
         self.theta = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
         es = list(self.entries.values())

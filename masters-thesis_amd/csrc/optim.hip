@@ -58,6 +58,17 @@ __global__ void seg_finalize_kernel(const float* partial, SpanTab t, float* sq, 
   sq[s] = a; wsq[s] = b;
 }
 
+// L2 metric: sum_s lambda_s * ||theta_s||^2  (tf.add_n(self.losses), lc_NIC.py:379), fixed order
+__global__ __launch_bounds__(256) void l2_total_kernel(const float* wsq, const float* seg_l2, int nseg, float* out) {
+  __shared__ float sw[4];
+  float a = 0.f;
+  for (int s = threadIdx.x; s < nseg; s += 256) a += seg_l2[s] * wsq[s];
+  a = tnt_wave_sum(a);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = sw[0] + sw[1] + sw[2] + sw[3];
+}
+
 __device__ __forceinline__ float clip_scale(const float* sq, const float* sq_override, int seg, float clipnorm) {
   if (clipnorm <= 0.f) return 1.f;
   float q = sq[seg];
@@ -154,8 +165,8 @@ extern "C" int32_t tnt_step_tick(int64_t* adam_t, uint32_t* drop_step, const flo
 
 extern "C" int32_t tnt_seg_sqnorm_f32(const float* theta, const float* grad, const int32_t* span_seg,
                                       const int64_t* span_off, const int32_t* span_len, const int32_t* seg_first,
-                                      const float* seg_l2, float* partial, float* sq, float* wsq, int32_t nspan,
-                                      int32_t nseg, void* stream) {
+                                      const float* seg_l2, float* partial, float* sq, float* wsq, float* l2_out,
+                                      int32_t nspan, int32_t nseg, void* stream) {
   if (nspan <= 0 || nseg <= 0) return 0;
   SpanTab t{span_seg, span_off, span_len, seg_first, seg_l2};
   hipStream_t s = tnt_stream(stream);
@@ -163,6 +174,10 @@ extern "C" int32_t tnt_seg_sqnorm_f32(const float* theta, const float* grad, con
   TNT_LAUNCH_CHECK();
   hipLaunchKernelGGL(seg_finalize_kernel, dim3((nseg + 255) / 256), dim3(256), 0, s, partial, t, sq, wsq, nseg);
   TNT_LAUNCH_CHECK();
+  if (l2_out) {
+    hipLaunchKernelGGL(l2_total_kernel, dim3(1), dim3(256), 0, s, wsq, seg_l2, nseg, l2_out);
+    TNT_LAUNCH_CHECK();
+  }
   return 0;
 }
 

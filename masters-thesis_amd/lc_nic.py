@@ -1,0 +1,503 @@
+"""lc_NIC -- region-wise encoder + additive attention + LSTM decoder (BASELINE config 3).
+
+Drop-in for ``AttemptFour/Model/lc_NIC.py`` (class NIC, lines 36-838): same 17 positional
+constructor arguments (lc_NIC.py:42; call site main.py:113-132), ``call`` =
+``call_attention`` (223-263), ``train_step`` (328-408), ``test_step`` (410-459),
+``greedy_predict`` = ``greedy_predict_attention`` (577-638).  ``groups`` is the
+``(list_of_index_arrays, list_of_out_dims)`` pair of load_avg_betas.get_groups
+(load_avg_betas.py:96-114).
+
+Launch plan of one train step (hipGraph-captured):
+  encoder : [dropout] -> ONE locally-dense launch (R regions) -> BatchNorm over (B,R) -> [dropout]
+  hoisted : embedding gather -> [dropouts] -> text half of the LSTM input projection for all T
+            steps in one GEMM; P = LeakyReLU(W1 F + b1) once (the reference recomputes it T times)
+  T steps : fused attention step kernel -> fused LSTM step kernel (recurrent + context matmul + gates)
+  head    : [dropout] -> Dense(256, LeakyReLU) GEMM -> [dropout] -> vocab GEMM -> softmax/CE/dlogits
+  backward: mirror image; the T-step chain is lstm_step_bwd -> (dZ Wc^T) GEMM -> attention_step_bwd
+  update  : [all-reduce] -> per-variable norms -> clip + Adam over the flat arena
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .arena import ParamArena
+from .model_base import (ModelBase, Metrics, interleave_gates, deinterleave_gates, S_IN, S_FEAT, S_TEXT, S_OUT, S_ATTN,
+                         S_LSTM_IN, S_LSTM_OUT, BN_EPS, BN_MOMENTUM)
+from .ops import ACT_LEAKY
+
+
+def _r4(n):
+    return (n + 3) // 4 * 4
+
+
+def synthetic_groups(n_voxels, n_regions, out_dim, seed=42, overlap=0.0):
+    """Pseudo-Glasser parcellation for benchmarks: a partition of the voxel axis into
+    ``n_regions`` ragged groups (sizes log-normal, min 8, mean ~ n_voxels/n_regions), optionally
+    with a fraction of extra overlapping indices.  Returns the reference's ``groups`` pair."""
+    rng = np.random.default_rng(seed)
+    w = rng.lognormal(0.0, 0.6, n_regions)
+    sizes = np.maximum(8, np.floor(w / w.sum() * (n_voxels - 8 * n_regions)).astype(np.int64) + 8)
+    while sizes.sum() > n_voxels:
+        sizes[np.argmax(sizes)] -= 1
+    sizes[np.argmin(sizes)] += n_voxels - sizes.sum()
+    perm = rng.permutation(n_voxels)
+    cuts = np.cumsum(sizes)[:-1]
+    groups = [np.sort(g) for g in np.split(perm, cuts)]
+    if overlap > 0:
+        groups = [np.unique(np.concatenate([g, rng.choice(n_voxels, max(1, int(overlap * len(g))))])) for g in groups]
+    return groups, [out_dim] * n_regions
+
+
+class NIC(ModelBase):
+    H = 256     # dense_inter width, hard-coded at lc_NIC.py:141
+
+    def __init__(self, groups, units, embedding_features, embedding_text, attn_units, vocab_size, max_length,
+                 dropout_input, dropout_features, dropout_text, dropout_attn, dropout_lstm, dropout_out, input_reg,
+                 attn_reg, lstm_reg, output_reg, norm="batch", **kw):
+        super().__init__(**kw)
+        in_groups, out_groups = groups
+        assert len(in_groups) == len(out_groups), "Input groups don't match ouput groups"   # layers.py:30
+        self.groups = [np.asarray(g, dtype=np.int64) for g in in_groups]
+        self.R = len(self.groups)
+        self.D = int(out_groups[0])
+        if any(int(d) != self.D for d in out_groups):
+            raise ValueError("all regions must project to the same width (they are stacked, layers.py:47-48)")
+        self.U, self.Et, self.A, self.V, self.max_length = int(units), int(embedding_text), int(attn_units), int(vocab_size), int(max_length)
+        self.embedding_features = embedding_features
+        self.r_in, self.r_feat, self.r_text = float(dropout_input), float(dropout_features), float(dropout_text)
+        self.r_attn, self.r_lstm, self.r_out = float(dropout_attn), float(dropout_lstm), float(dropout_out)
+        self.l2_in, self.l2_attn, self.l2_lstm, self.l2_out = float(input_reg), float(attn_reg), float(lstm_reg), float(output_reg)
+        assert norm in ("batch", "layer")
+        self.norm = norm
+        if self.U % 16 or self.D % 16 or self.D > 64 or self.A > 64:
+            raise ValueError("kernel tiles need units % 16 == 0, group_size % 16 == 0 and <= 64, attn_units <= 64")
+        R, D, A, U, Et, V, H = self.R, self.D, self.A, self.U, self.Et, self.V, self.H
+        self.ldV = _r4(V)
+        self.n_in = int(max(int(g.max()) for g in self.groups if len(g)) + 1)
+        self.goff_host = np.concatenate([[0], np.cumsum([len(g) for g in self.groups])]).astype(np.int32)
+        self.goff = torch.tensor(self.goff_host, dtype=torch.int32, device=self.device)
+        self.idx = torch.tensor(np.concatenate(self.groups).astype(np.int32), dtype=torch.int32, device=self.device)
+        ls = OrderedDict()
+        ks = OrderedDict()
+        for r, g in enumerate(self.groups):
+            ls[f"dense_in/{r}"] = ["kernel", "bias"]
+            ks[f"dense_in/{r}/kernel"] = (len(g), D)
+            ks[f"dense_in/{r}/bias"] = (D,)
+        ls["input_bn"] = ["gamma", "beta", "moving_mean", "moving_variance"]
+        for w in ls["input_bn"]:
+            ks[f"input_bn/{w}"] = (D,)
+        for nm, shp in (("attention/W1", (D, A)), ("attention/W2", (U, A)), ("attention/V", (A, 1))):
+            ls[nm] = ["kernel", "bias"]
+            ks[f"{nm}/kernel"] = shp
+            ks[f"{nm}/bias"] = (shp[1],)
+        ls["emb_text"] = ["embeddings"]
+        ks["emb_text/embeddings"] = (V, Et)
+        ls["lstm"] = ["kernel", "recurrent_kernel", "bias"]
+        ks["lstm/kernel"], ks["lstm/recurrent_kernel"], ks["lstm/bias"] = (D + Et, 4 * U), (U, 4 * U), (4 * U,)
+        ls["time_distributed_nonlinear"] = ["kernel", "bias"]
+        ks["time_distributed_nonlinear/kernel"], ks["time_distributed_nonlinear/bias"] = (U, H), (H,)
+        ls["time_distributed_softmax"] = ["kernel", "bias"]
+        ks["time_distributed_softmax/kernel"], ks["time_distributed_softmax/bias"] = (H, V), (V,)
+        self.layers_spec, self.keras_shapes = ls, ks
+
+        a = self.arena = ParamArena(self.device)
+        for r, g in enumerate(self.groups):                      # contiguous CSR concatenation
+            a.add(f"dense_in/{r}/kernel", (len(g), D), self.l2_in, align=4)
+        self.enc_w_off = a.entries["dense_in/0/kernel"].off
+        a.total = (a.total + 63) // 64 * 64
+        for r in range(R):
+            a.add(f"dense_in/{r}/bias", (D,), align=4)
+        self.enc_b_off = a.entries["dense_in/0/bias"].off
+        a.total = (a.total + 63) // 64 * 64
+        a.add("input_bn/gamma", (D,)); a.add("input_bn/beta", (D,))
+        a.add("attention/W1/kernel", (D, A), self.l2_attn); a.add("attention/W1/bias", (A,))
+        a.add("attention/W2/kernel", (U, A), self.l2_attn); a.add("attention/W2/bias", (A,))
+        a.add("attention/V/kernel", (A,)); a.add("attention/V/bias", (1,))
+        a.add("emb_text/embeddings", (V, Et))
+        a.add("lstm/kernel", (D + Et, U, 4), self.l2_lstm)
+        a.add("lstm/recurrent_kernel", (U, U, 4)); a.add("lstm/bias", (U, 4))
+        a.add("time_distributed_nonlinear/kernel", (U, H), self.l2_out); a.add("time_distributed_nonlinear/bias", (H,))
+        a.add("time_distributed_softmax/kernel", (H, self.ldV), self.l2_out)
+        a.add("time_distributed_softmax/bias", (self.ldV,))
+        a.finalize()
+        nW = int(self.goff_host[-1]) * D
+        self.encW, self.encWg = a.theta[self.enc_w_off:self.enc_w_off + nW], a.grad[self.enc_w_off:self.enc_w_off + nW]
+        self.encB, self.encBg = a.theta[self.enc_b_off:self.enc_b_off + R * D], a.grad[self.enc_b_off:self.enc_b_off + R * D]
+        self.mov_mean, self.mov_var = self._f(D), torch.ones(D, dtype=torch.float32, device=self.device)
+        self.drop_step = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._init_weights(np.random.default_rng(self.seed))
+        self._shape = None
+
+    # ------------------------------------------------------------------ weights
+    def _init_weights(self, rng):
+        """Initialisers of lc_NIC.py:84-159 / attention.py:21-23."""
+        D, A, U, Et, V, H = self.D, self.A, self.U, self.Et, self.V, self.H
+        tn = lambda shape, std: np.clip(rng.standard_normal(shape), -2, 2) * std / 0.8796
+        for r, g in enumerate(self.groups):
+            self.set_weight(f"dense_in/{r}/kernel", tn((len(g), D), np.sqrt(2.0 / max(len(g), 1))))   # he_normal
+        self.set_weight("input_bn/gamma", np.ones(D))
+        self.set_weight("attention/W1/kernel", tn((D, A), np.sqrt(2.0 / D)))
+        self.set_weight("attention/W2/kernel", tn((U, A), np.sqrt(2.0 / U)))
+        lim = np.sqrt(6.0 / (A + 1))
+        self.set_weight("attention/V/kernel", rng.uniform(-lim, lim, (A, 1)))
+        self.set_weight("emb_text/embeddings", rng.uniform(-0.08, 0.08, (V, Et)))
+        lim = np.sqrt(6.0 / (D + Et + 4 * U))
+        self.set_weight("lstm/kernel", rng.uniform(-lim, lim, (D + Et, 4 * U)))
+        q = np.concatenate([np.linalg.qr(rng.standard_normal((U, U)))[0] for _ in range(4)], axis=1)
+        self.set_weight("lstm/recurrent_kernel", q)
+        b = np.zeros(4 * U); b[U:2 * U] = 1.0
+        self.set_weight("lstm/bias", b)
+        self.set_weight("time_distributed_nonlinear/kernel", tn((U, H), np.sqrt(2.0 / (U + H))))
+        self.set_weight("time_distributed_softmax/kernel", tn((H, V), np.sqrt(2.0 / (H + V))))
+
+    def set_weight(self, name, arr):
+        arr = np.asarray(arr, dtype=np.float32)
+        assert tuple(arr.shape) == tuple(self.keras_shapes[name]), (name, arr.shape, self.keras_shapes[name])
+        if name == "input_bn/moving_mean":
+            self.mov_mean.copy_(torch.from_numpy(arr)); return
+        if name == "input_bn/moving_variance":
+            self.mov_var.copy_(torch.from_numpy(arr)); return
+        dst = self.arena.p(name)
+        if name.startswith("lstm/"):
+            arr = interleave_gates(arr, self.U)
+        elif name == "time_distributed_softmax/kernel":
+            pad = np.zeros((self.H, self.ldV), np.float32); pad[:, :self.V] = arr; arr = pad
+        elif name == "time_distributed_softmax/bias":
+            pad = np.zeros(self.ldV, np.float32); pad[:self.V] = arr; arr = pad
+        dst.copy_(torch.from_numpy(np.ascontiguousarray(arr)).view(dst.shape))
+
+    def _unpack(self, name, t):
+        arr = t.detach().cpu().numpy()
+        if name.startswith("lstm/"):
+            return deinterleave_gates(arr)
+        if name == "time_distributed_softmax/kernel":
+            return np.ascontiguousarray(arr[:, :self.V])
+        if name == "time_distributed_softmax/bias":
+            return np.ascontiguousarray(arr[:self.V])
+        return arr.reshape(self.keras_shapes[name]).copy()
+
+    def get_weight(self, name):
+        if name == "input_bn/moving_mean":
+            return self.mov_mean.cpu().numpy().copy()
+        if name == "input_bn/moving_variance":
+            return self.mov_var.cpu().numpy().copy()
+        return self._unpack(name, self.arena.p(name))
+
+    def get_gradient(self, name):
+        return self._unpack(name, self.arena.g(name))
+
+    def state_tensors(self):
+        return [self.mov_mean, self.mov_var]
+
+    @property
+    def losses(self):
+        a = self.arena
+        self._norms_and_l2(self.met[2:3])
+        return [a.seg_l2[e.seg] * a.wsq[e.seg] for e in a.entries.values() if e.l2 > 0]
+
+    # ------------------------------------------------------------------ buffers
+    def _build(self, B, T):
+        if self._shape == (B, T):
+            return
+        if B > 64:
+            raise ValueError("the region-wise encoder kernel handles at most 64 samples per call (per GPU)")
+        f = self._f
+        R, D, A, U, Et, V, H, ldV = self.R, self.D, self.A, self.U, self.Et, self.V, self.H, self.ldV
+        n = T * B
+        self.ldx = _r4(self.n_in)
+        self.x = f(B, self.ldx)
+        self.xd = f(B, self.ldx) if self.r_in > 0 else self.x
+        self.cap = torch.zeros(B, T, dtype=torch.int32, device=self.device)
+        self.tgt = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self.enc_pre, self.enc_y = f(B, R, D), f(B, R, D)
+        self.xhat, self.inv_std = f(B * R, D), f(max(B * R, D))
+        self.F = f(B, R, D)
+        self.text = f(n, Et)
+        self.XZ = f(n, U, 4)
+        self.P, self.Ppre = f(B * R, A), f(B * R, A)
+        self.Hs, self.Cs = f(T + 1, B, U), f(T + 1, B, U)
+        self.gates = f(T, B, U, 4)
+        self.qpre, self.alpha = f(T, B, A), f(T, B, R)
+        self.ctx, self.ctx_d = f(T, B, D), f(T, B, D)
+        self.Hd = f(n, U) if self.r_lstm > 0 else None
+        self.ipre, self.inter = f(n, H), f(n, H)
+        self.inter_d = f(n, H) if self.r_out > 0 else self.inter
+        self.logits = f(n, ldV)
+        self.loss_row, self.corr_row = f(n), f(n)
+        self.met = f(8)
+        # backward
+        self.dinter, self.dHs = f(n, H), f(n, U)
+        self.dZ = f(n, U, 4)
+        self.dc, self.dh_att = f(B, U), f(B, U)
+        self.dctx = f(B, D)
+        self.dP, self.dF = f(B * R, A), f(B, R, D)
+        self.dvb, self.dqpre = f(B, A + 1), f(T, B, A)
+        self.dtext = f(n, Et)
+        self.dbn = f(B * R, D)
+        nch = max(self.be.bn_nchunk(B * R), self.be.bn_nchunk(n))
+        self.work = f(max(D, A, 4 * U, ldV, H) * (2 * nch + 1))
+        self.rowsq = f(n)
+        self.emb_seg = self.arena.entries["emb_text/embeddings"].seg
+        self._shape = (B, T)
+        self._graphs = {}
+        if self.optimizer is not None and getattr(self, "opt_m", None) is None:
+            self._init_optimizer_state()
+        self.built = True
+
+    def _stage_inputs(self, data):
+        x, cap, a0, c0 = data[:4]
+        cap_t = self._to_dev(cap, torch.int32)
+        if cap_t.dim() == 1:
+            cap_t = cap_t.view(-1, 1)
+        B, T = cap_t.shape
+        self._build(B, T)
+        xs = self._to_dev(x, torch.float32)
+        assert xs.shape[0] == B and xs.shape[1] >= self.n_in, f"betas shape {tuple(xs.shape)}"
+        self.x[:, :self.n_in].copy_(xs[:, :self.n_in])
+        self.cap.copy_(cap_t)
+        self.Hs[0].copy_(self._to_dev(a0, torch.float32))
+        self.Cs[0].copy_(self._to_dev(c0, torch.float32))
+        return B, T
+
+    # ------------------------------------------------------------------ forward
+    def _encode(self, B, training):
+        """dropout_input -> layers.LocallyDense.call (lc_NIC.py:227-230; layers.py:43-53)."""
+        be, a = self.be, self.arena
+        R, D = self.R, self.D
+        sd, ds = self.seed, self.drop_step
+        x = self.x
+        if training and self.r_in > 0:
+            be.dropout(self.x, self.xd, B, self.n_in, self.ldx, 0, self.n_in, 0, self.r_in, sd, S_IN, 0, ds)
+            x = self.xd
+        be.locally_dense_fwd(x, self.ldx, self.idx, self.goff, self.encW, self.encB, self.enc_pre, self.enc_y, B, R, D, 0.2)
+        if self.norm == "batch":
+            be.batchnorm_fwd(self.enc_y, a.p("input_bn/gamma"), a.p("input_bn/beta"), self.mov_mean, self.mov_var,
+                             self.F, self.xhat, self.inv_std, B * R, D, D, training, BN_EPS, BN_MOMENTUM, self.work)
+        else:
+            be.layernorm_fwd(self.enc_y, a.p("input_bn/gamma"), a.p("input_bn/beta"), self.F, self.xhat, self.inv_std,
+                             B * R, D, D, BN_EPS)
+        if training and self.r_feat > 0:
+            be.dropout(self.F, self.F, B * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT, 0, ds)
+        be.gemm(self.F, a.p("attention/W1/kernel"), self.P, B * R, self.A, D, D, self.A, self.A,
+                bias=a.p("attention/W1/bias"), pre=self.Ppre, act=ACT_LEAKY, slope=0.2)      # attention.py:32 (hoisted)
+
+    def _decode_step(self, i, B, training, s_out=None):
+        """attention -> concat -> one LSTM step (lc_NIC.py:246-255)."""
+        be, a = self.be, self.arena
+        R, D, A, U, Et = self.R, self.D, self.A, self.U, self.Et
+        Wl = a.p("lstm/kernel")
+        be.attention_step_fwd(self.Hs[i], self.F, self.P, a.p("attention/W2/kernel"), a.p("attention/W2/bias"),
+                              a.p("attention/V/kernel"), a.p("attention/V/bias"), self.qpre[i], self.alpha[i],
+                              self.ctx[i], self.ctx_d[i], s_out, B, R, D, A, U, 0.2,
+                              self.r_attn if training else 0.0, self.r_lstm if training else 0.0, D + Et, self.seed,
+                              S_ATTN + i, S_LSTM_IN + i, 0, self.drop_step)
+        be.lstm_step_fwd(self.XZ[i * B:(i + 1) * B], self.Hs[i], self.Cs[i], a.p("lstm/recurrent_kernel"),
+                         self.ctx_d[i], Wl[:D], D, None, 0, 0, None, self.Hs[i + 1], self.Cs[i + 1], None,
+                         self.gates[i], B, U)
+
+    def _forward(self, B, T, training):
+        be, a = self.be, self.arena
+        R, D, A, U, Et, V, H, ldV = self.R, self.D, self.A, self.U, self.Et, self.V, self.H, self.ldV
+        n = T * B
+        sd, ds = self.seed, self.drop_step
+        self._encode(B, training)
+        be.embedding_fwd(a.p("emb_text/embeddings"), self.cap, self.text, B, T, Et, Et, V)       # lc_NIC.py:233
+        if training and self.r_text > 0:
+            be.dropout(self.text, self.text, n, Et, Et, B, Et, 0, self.r_text, sd, S_TEXT, 0, ds)
+        if training and self.r_lstm > 0:       # text half of the per-call LSTM input mask over (B,1,D+Et)
+            for i in range(T):
+                be.dropout(self.text[i * B:], self.text[i * B:], B, Et, Et, 0, D + Et, D, self.r_lstm, sd,
+                           S_LSTM_IN + i, 0, ds)
+        Wl = a.p("lstm/kernel")
+        be.gemm(self.text, Wl[D:], self.XZ, n, 4 * U, Et, Et, 4 * U, 4 * U, bias=a.p("lstm/bias"))
+        for i in range(T):                                                                      # :244-256
+            self._decode_step(i, B, training)
+        hs = self.Hs[1:].view(n, U)
+        if training and self.r_lstm > 0:                                                        # :256
+            for i in range(T):
+                be.dropout(hs[i * B:], self.Hd[i * B:], B, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT + i, 0, ds)
+            hs = self.Hd
+        self._hs_used = hs
+        be.gemm(hs, a.p("time_distributed_nonlinear/kernel"), self.inter, n, H, U, U, H, H,
+                bias=a.p("time_distributed_nonlinear/bias"), pre=self.ipre, act=ACT_LEAKY, slope=0.2)
+        inter = self.inter
+        if training and self.r_out > 0:
+            be.dropout(self.inter, self.inter_d, n, H, H, B, H, 0, self.r_out, sd, S_OUT, 0, ds)
+            inter = self.inter_d
+        self._inter_used = inter
+        be.gemm(inter, a.p("time_distributed_softmax/kernel"), self.logits, n, V, H, H, ldV, ldV,
+                bias=a.p("time_distributed_softmax/bias"))                                     # :261
+
+    def _loss_metrics(self, B, T, want_grad):
+        be = self.be
+        n = T * B
+        if want_grad:
+            be.softmax_cce(self.logits, self.tgt, None, self.loss_row, self.corr_row, self.logits, n, self.V, self.ldV,
+                           1.0 / (n * self.dp_world))
+        else:
+            be.softmax_cce(self.logits, self.tgt, self.logits, self.loss_row, self.corr_row, None, n, self.V, self.ldV,
+                           0.0)
+        be.sum(self.loss_row, self.met[0:1], n, 1.0 / n)
+        be.sum(self.corr_row, self.met[1:2], n, 1.0 / n)
+        be.attention_metric(self.alpha, self.met[3:4], T, B, self.R)                            # :365-367
+
+    # ------------------------------------------------------------------ backward
+    def _backward(self, B, T):
+        be, a = self.be, self.arena
+        R, D, A, U, Et, V, H, ldV = self.R, self.D, self.A, self.U, self.Et, self.V, self.H, self.ldV
+        n = T * B
+        sd, ds = self.seed, self.drop_step
+        dlog, inter, hs = self.logits, self._inter_used, self._hs_used
+        be.gemm(inter, dlog, a.g("time_distributed_softmax/kernel"), H, V, n, H, ldV, ldV, transA=True)
+        be.colsum(dlog, a.g("time_distributed_softmax/bias"), n, V, ldV, self.work)
+        be.gemm(dlog, a.p("time_distributed_softmax/kernel"), self.dinter, n, H, V, ldV, ldV, H, transB=True)
+        if self.r_out > 0:
+            be.dropout(self.dinter, self.dinter, n, H, H, B, H, 0, self.r_out, sd, S_OUT, 0, ds)
+        be.act_bwd(self.ipre, self.dinter, self.dinter, n * H, ACT_LEAKY, 0.2)
+        be.gemm(hs, self.dinter, a.g("time_distributed_nonlinear/kernel"), U, H, n, U, H, H, transA=True)
+        be.colsum(self.dinter, a.g("time_distributed_nonlinear/bias"), n, H, H, self.work)
+        be.gemm(self.dinter, a.p("time_distributed_nonlinear/kernel"), self.dHs, n, U, H, H, H, U, transB=True)
+        if self.r_lstm > 0:
+            for i in range(T):
+                be.dropout(self.dHs[i * B:], self.dHs[i * B:], B, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT + i, 0, ds)
+        self.dP.zero_(); self.dF.zero_(); self.dvb.zero_()
+        Wl, Ur = a.p("lstm/kernel"), a.p("lstm/recurrent_kernel")
+        W2, v = a.p("attention/W2/kernel"), a.p("attention/V/kernel")
+        for i in range(T - 1, -1, -1):
+            last = i == T - 1
+            be.lstm_step_bwd(None if last else self.dZ[(i + 1) * B:(i + 2) * B], Ur, None,
+                             None if last else self.dh_att, None if last else self.dc, None,
+                             self.dHs[i * B:(i + 1) * B], None, 0, 0, self.gates[i], self.Cs[i + 1], self.Cs[i],
+                             self.dZ[i * B:(i + 1) * B], None, self.dc, None, B, U)
+            be.gemm(self.dZ[i * B:(i + 1) * B], Wl[:D], self.dctx, B, D, 4 * U, 4 * U, 4 * U, D, transB=True)
+            be.attention_step_bwd(self.dctx, self.F, self.P, W2, v, self.qpre[i], self.alpha[i], self.dP, self.dF,
+                                  self.dvb, self.dqpre[i], self.dh_att, B, R, D, A, U, 0.2, self.r_attn, self.r_lstm,
+                                  D + Et, sd, S_ATTN + i, S_LSTM_IN + i, 0, ds)
+        hprev = self.Hs[:T].view(n, U)
+        gWl = a.g("lstm/kernel")
+        be.gemm(hprev, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True)
+        be.gemm(self.text, self.dZ, gWl[D:], Et, 4 * U, n, Et, 4 * U, 4 * U, transA=True)
+        be.gemm(self.ctx_d, self.dZ, gWl[:D], D, 4 * U, n, D, 4 * U, 4 * U, transA=True)
+        be.colsum(self.dZ, a.g("lstm/bias"), n, 4 * U, 4 * U, self.work)
+        be.gemm(self.dZ, Wl[D:], self.dtext, n, Et, 4 * U, 4 * U, 4 * U, Et, transB=True)
+        if self.r_lstm > 0:
+            for i in range(T):
+                be.dropout(self.dtext[i * B:], self.dtext[i * B:], B, Et, Et, 0, D + Et, D, self.r_lstm, sd,
+                           S_LSTM_IN + i, 0, ds)
+        if self.r_text > 0:
+            be.dropout(self.dtext, self.dtext, n, Et, Et, B, Et, 0, self.r_text, sd, S_TEXT, 0, ds)
+        sqo = a.sq_override[self.emb_seg:self.emb_seg + 1]
+        sqo.zero_()
+        be.embedding_bwd(self.dtext, self.cap, a.g("emb_text/embeddings"), sqo, self.rowsq, B, T, Et, Et, V)
+        # attention parameters
+        be.gemm(hprev, self.dqpre, a.g("attention/W2/kernel"), U, A, n, U, A, A, transA=True)
+        be.colsum(self.dqpre, a.g("attention/W2/bias"), n, A, A, self.work)
+        be.colsum(self.dvb, a.g("attention/V/kernel"), B, A, A + 1, self.work)
+        be.colsum(self.dvb.view(-1)[A:], a.g("attention/V/bias"), B, 1, A + 1, self.work)
+        be.act_bwd(self.Ppre, self.dP, self.dP, B * R * A, ACT_LEAKY, 0.2)
+        be.gemm(self.F, self.dP, a.g("attention/W1/kernel"), D, A, B * R, D, A, A, transA=True)
+        be.colsum(self.dP, a.g("attention/W1/bias"), B * R, A, A, self.work)
+        be.gemm(self.dP, a.p("attention/W1/kernel"), self.dF, B * R, D, A, A, A, D, transB=True, accumulate=True)
+        # encoder
+        if self.r_feat > 0:
+            be.dropout(self.dF, self.dF, B * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT, 0, ds)
+        if self.norm == "batch":
+            be.batchnorm_bwd(self.dF, self.xhat, a.p("input_bn/gamma"), self.inv_std, self.dbn, a.g("input_bn/gamma"),
+                             a.g("input_bn/beta"), B * R, D, D, True, self.work)
+        else:
+            be.layernorm_bwd(self.dF, self.xhat, a.p("input_bn/gamma"), self.inv_std, self.dbn, a.g("input_bn/gamma"),
+                             a.g("input_bn/beta"), B * R, D, D, self.work)
+        be.act_bwd(self.enc_pre, self.dbn, self.dbn, B * R * D, ACT_LEAKY, 0.2)
+        x = self.xd if self.r_in > 0 else self.x
+        be.locally_dense_bwd(x, self.ldx, self.idx, self.goff, self.dbn, self.encWg, self.encBg, B, R, D)
+
+    # ------------------------------------------------------------------ steps
+    def _train_graph(self, B, T):
+        self._forward(B, T, True)
+        self._loss_metrics(B, T, True)
+        self._backward(B, T)
+
+    def _update_graph(self):
+        self._norms_and_l2(self.met[2:3])
+        self._apply_optimizer()
+
+    def _metrics(self, with_lr):
+        m = self.met.clone()
+        out = Metrics(loss=m[0], L2=m[2], accuracy=m[1], attention=m[3])
+        if with_lr:
+            out["lr"] = self.lr_dev.clone()[0]
+        return out
+
+    def train_step(self, data):
+        """lc_NIC.train_step (lc_NIC.py:328-408): returns {loss, L2, accuracy, attention, lr}."""
+        if self.optimizer is None:
+            raise RuntimeError("compile() the model before train_step")
+        B, T = self._stage_inputs(data[0])
+        self._stage_target(data[1], B, T)
+        self._sync_lr()
+        if self.grad_sync is None:
+            self._run_captured(("train", B, T), lambda: (self._train_graph(B, T), self._update_graph()))
+        else:
+            self._run_captured(("train_fb", B, T), lambda: self._train_graph(B, T))
+            self.grad_sync(self)
+            self._run_captured(("train_up", B, T), self._update_graph)
+        self.optimizer.iterations += 1
+        return self._metrics(True)
+
+    def test_step(self, data):
+        """lc_NIC.test_step (lc_NIC.py:410-459)."""
+        B, T = self._stage_inputs(data[0])
+        self._stage_target(data[1], B, T)
+
+        def run():
+            self._forward(B, T, False)
+            self._loss_metrics(B, T, False)
+            self._norms_and_l2(self.met[2:3])
+        self._run_captured(("test", B, T), run)
+        return self._metrics(False)
+
+    def __call__(self, data, training=False):
+        """lc_NIC.call -> call_attention (lc_NIC.py:163-164,223-263):
+        returns (probabilities (B,T,V), attention scores (T,B,R,1))."""
+        B, T = self._stage_inputs(data)
+        self._forward(B, T, training)
+        self.be.softmax_cce(self.logits, None, self.logits, None, None, None, T * B, self.V, self.ldV, 0.0)
+        probs = self.logits.view(T, B, self.ldV)[:, :, :self.V].permute(1, 0, 2).contiguous()
+        return probs, self.alpha.clone().unsqueeze(-1)
+
+    call = call_attention = __call__
+
+    def greedy_predict(self, img_input, a0, c0, start_seq, max_len, units=None, tokenizer=None, training=False):
+        """lc_NIC.greedy_predict -> greedy_predict_attention (lc_NIC.py:507-508,577-638).
+        Returns (words (B,max_len,1) int64, probs (B,max_len,V), alpha (max_len,B,R,1), s (max_len,B,R,A))
+        as numpy arrays; the whole decode runs on the device with no per-step host sync."""
+        assert training is False, "training is set to True"                                  # lc_NIC.py:591
+        be, a = self.be, self.arena
+        start = self._to_dev(np.asarray(start_seq).reshape(-1), torch.int32)
+        B = start.shape[0]
+        self._stage_inputs((img_input, torch.zeros(B, max_len, dtype=torch.int32), a0, c0))
+        R, D, A, U, Et, V, H, ldV = self.R, self.D, self.A, self.U, self.Et, self.V, self.H, self.ldV
+        self._encode(B, False)
+        Wl = a.p("lstm/kernel")
+        words = start.clone().view(B, 1)
+        probs = torch.zeros(max_len, B, ldV, dtype=torch.float32, device=self.device)
+        s_all = torch.zeros(max_len, B, R, A, dtype=torch.float32, device=self.device)
+        ids = torch.zeros(max_len, B, dtype=torch.int32, device=self.device)
+        for i in range(max_len):
+            text = self.text[i * B:(i + 1) * B]
+            be.embedding_fwd(a.p("emb_text/embeddings"), words, text, B, 1, Et, Et, V)        # :596,632
+            be.gemm(text, Wl[D:], self.XZ[i * B:(i + 1) * B], B, 4 * U, Et, Et, 4 * U, 4 * U, bias=a.p("lstm/bias"))
+            self._decode_step(i, B, False, s_all[i])
+            be.gemm(self.Hs[i + 1], a.p("time_distributed_nonlinear/kernel"), self.inter[:B], B, H, U, U, H, H,
+                    bias=a.p("time_distributed_nonlinear/bias"), act=ACT_LEAKY, slope=0.2)     # :621
+            be.gemm(self.inter[:B], a.p("time_distributed_softmax/kernel"), probs[i], B, V, H, H, ldV, ldV,
+                    bias=a.p("time_distributed_softmax/bias"))                                # :623
+            be.softmax_cce(probs[i], None, probs[i], None, None, None, B, V, ldV, 0.0)
+            be.argmax_rows(probs[i], ids[i], B, V, ldV)                                        # :627
+            words = ids[i].view(B, 1)
+        out_words = ids.t().contiguous().cpu().numpy().astype(np.int64)[:, :, None]
+        out_probs = probs[:, :, :V].permute(1, 0, 2).contiguous().cpu().numpy()
+        return out_words, out_probs, self.alpha[:max_len].cpu().numpy()[..., None], s_all.cpu().numpy()
+
+    greedy_predict_attention = greedy_predict

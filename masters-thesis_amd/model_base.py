@@ -1,0 +1,271 @@
+"""Keras-style model surface shared by the NIC variants.
+
+Mirrors what AttemptFour/main.py and eval.py call on a ``tf.keras.Model``
+(SURVEY.md 8b): ``compile``, ``__call__``, ``fit``, ``train_step``, ``test_step``,
+``save_weights`` / ``load_weights(by_name, skip_mismatch)``, ``summary``,
+``get_layer(name).get_weights/set_weights``, ``optimizer.lr``, ``trainable_variables``,
+``losses`` -- on top of the HIP kernel backend.  Host code here only sequences kernel
+launches and owns buffers; it contains no arithmetic of the hot path.
+"""
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from .arena import ParamArena
+from .optimizers import Adam, SGD
+
+# dropout site ids of the Philox stream (shared with oracle/models.py)
+S_IN, S_FEAT, S_TEXT, S_OUT = 1, 2, 3, 5
+S_ATTN, S_LSTM_IN, S_LSTM_OUT = 16, 48, 80
+BN_EPS, BN_MOMENTUM = 1e-3, 0.99
+
+
+def interleave_gates(w, U):
+    """keras [.., 4U] (i,f,c~,o blocks) -> kernel layout [.., U, 4]."""
+    w = np.asarray(w)
+    return np.ascontiguousarray(np.moveaxis(w.reshape(*w.shape[:-1], 4, U), -2, -1))
+
+
+def deinterleave_gates(w):
+    """kernel layout [.., U, 4] -> keras [.., 4U]."""
+    w = np.asarray(w)
+    return np.ascontiguousarray(np.moveaxis(w, -1, -2)).reshape(*w.shape[:-2], -1)
+
+
+class _LayerView:
+    """What ``model.get_layer(name)`` returns: get_weights/set_weights in keras layouts
+    (main.py:161-162 warm-starts 'lstm' and 'time_distributed_softmax' this way)."""
+
+    def __init__(self, model, name, weight_names):
+        self.model, self.name, self.weight_names = model, name, weight_names
+
+    def get_weights(self):
+        return [self.model.get_weight(f"{self.name}/{w}") for w in self.weight_names]
+
+    def set_weights(self, weights):
+        assert len(weights) == len(self.weight_names), "weight list length mismatch"
+        for w, arr in zip(self.weight_names, weights):
+            self.model.set_weight(f"{self.name}/{w}", arr)
+
+
+class Metrics(dict):
+    """train_step/test_step result: values are 0-d device tensors (no host sync until read)."""
+
+    def as_floats(self):
+        return {k: float(v) for k, v in self.items()}
+
+
+class ModelBase:
+    # subclasses fill: self.layers_spec = OrderedDict(layer -> [weight names]),
+    # self.keras_shapes = {full name: keras shape}
+    def __init__(self, device=None, seed=42, use_graph=True, grad_sync=None):
+        self.device = torch.device(device) if device is not None else torch.device(
+            "cuda" if torch.cuda.is_available() else "cpu")
+        self.seed = int(seed)
+        self.use_graph = bool(use_graph)
+        self.grad_sync = grad_sync          # callable(model) -> None: data-parallel all-reduce hook (dp.py)
+        self.dp_world = int(getattr(grad_sync, "world", 1)) if grad_sync is not None else 1
+        self.optimizer = None
+        self.loss = None
+        self.built = False
+        self.stop_training = False
+        self._graphs = {}
+        self._lr_host = None
+
+    # ------------------------------------------------------------------ keras surface
+    def compile(self, optimizer=None, loss=None, *metrics, run_eagerly=True, **kw):
+        """model.compile(optimizer, loss_object, run_eagerly=True) -- main.py:134."""
+        self.optimizer = optimizer if optimizer is not None else Adam()
+        self.loss = loss
+        if self.built:
+            self._init_optimizer_state()
+
+    @property
+    def be(self):
+        return ops.backend()
+
+    def _f(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def _init_optimizer_state(self):
+        a = self.arena
+        self.opt_m = torch.zeros_like(a.theta)
+        self.opt_v = torch.zeros_like(a.theta) if self.optimizer.kind == "adam" else None
+        self.adam_t = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.lr_dev = torch.tensor([self.optimizer.lr], dtype=torch.float32, device=self.device)
+        self.lr_t_dev = self._f(1)
+        self._lr_host = self.optimizer.lr
+        self._graphs = {}
+
+    def _sync_lr(self):
+        if self.optimizer.lr != self._lr_host:
+            self.lr_dev.fill_(self.optimizer.lr)
+            self._lr_host = self.optimizer.lr
+
+    def _apply_optimizer(self):
+        """per-variable clipnorm + Adam/SGD (optimizer.apply_gradients, lc_NIC.py:389)."""
+        be, a, sp, opt = self.be, self.arena, self.arena.spans, self.optimizer
+        clip = opt.clipnorm if opt.clipnorm is not None else 0.0
+        if opt.kind == "adam":
+            be.step_tick(self.adam_t, self.drop_step, self.lr_dev, self.lr_t_dev, opt.beta_1, opt.beta_2)
+            be.adam(a.theta, self.opt_m, self.opt_v, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq,
+                    a.sq_override, sp.nspan, 0.0, self.lr_t_dev, opt.beta_1, opt.beta_2, opt.epsilon, clip)
+        else:
+            be.step_tick(self.adam_t, self.drop_step, self.lr_dev, None, 0.0, 0.0)
+            be.sgd(a.theta, self.opt_m, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq, a.sq_override,
+                   sp.nspan, 0.0, self.lr_dev, opt.momentum, clip)
+
+    def _norms_and_l2(self, l2_out):
+        a, sp = self.arena, self.arena.spans
+        self.be.seg_sqnorm(a.theta, a.grad, sp.span_seg, sp.span_off, sp.span_len, sp.seg_first, a.seg_l2, a.partial,
+                           a.sq, a.wsq, l2_out, sp.nspan, a.nseg)
+
+    # ------------------------------------------------------------------ weights
+    @property
+    def trainable_variables(self):
+        return [(n, self.get_weight(n)) for n in self.trainable_names()]
+
+    def trainable_names(self):
+        return [n for n in self.keras_shapes if "moving_" not in n]
+
+    def get_weights_dict(self):
+        return OrderedDict((n, self.get_weight(n)) for n in self.keras_shapes)
+
+    def set_weights_dict(self, d, strict=True):
+        for n, v in d.items():
+            if n in self.keras_shapes:
+                self.set_weight(n, v)
+            elif strict:
+                raise KeyError(n)
+
+    def get_layer(self, name):
+        if name not in self.layers_spec:
+            raise ValueError(f"No such layer: {name}")
+        return _LayerView(self, name, self.layers_spec[name])
+
+    def save_weights(self, path):
+        """ModelCheckpoint(save_weights_only=True) target (main.py:168-190).  Written as .npz with
+        keras layer/weight names and keras layouts (h5py is not available offline)."""
+        arrs = {k.replace("/", "__"): v for k, v in self.get_weights_dict().items()}
+        with open(path, "wb") as f:
+            np.savez(f, **arrs)
+
+    def load_weights(self, path, by_name=True, skip_mismatch=False):
+        """model.load_weights(path, by_name=True, skip_mismatch=True) -- eval.py:140."""
+        with np.load(path, allow_pickle=False) as z:
+            for k in z.files:
+                n = k.replace("__", "/")
+                if n not in self.keras_shapes:
+                    continue
+                if tuple(z[k].shape) != tuple(self.keras_shapes[n]):
+                    if skip_mismatch:
+                        continue
+                    raise ValueError(f"shape mismatch for {n}: {z[k].shape} vs {self.keras_shapes[n]}")
+                self.set_weight(n, z[k])
+
+    def count_params(self):
+        return int(sum(np.prod(s) for s in self.keras_shapes.values()))
+
+    def summary(self, print_fn=print):
+        print_fn(f'Model: "{type(self).__name__}"')
+        for layer, ws in self.layers_spec.items():
+            n = sum(int(np.prod(self.keras_shapes[f"{layer}/{w}"])) for w in ws)
+            print_fn(f"  {layer:36s} {n:>12,d}")
+        print_fn(f"Total params: {self.count_params():,d}")
+
+    # ------------------------------------------------------------------ input staging
+    def _to_dev(self, a, dtype):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype, non_blocking=True)
+        return torch.as_tensor(np.asarray(a), dtype=dtype).to(self.device, non_blocking=True)
+
+    def _stage_target(self, target, B, T):
+        """target: one-hot (B,T,V) float (to_categorical, data_generator_guse.py:163) or int ids (B,T).
+        Fills self.tgt (time-major int32 ids)."""
+        if isinstance(target, np.ndarray) and target.ndim == 2 or (isinstance(target, torch.Tensor) and target.dim() == 2):
+            t = self._to_dev(target, torch.int32)
+            self.tgt.view(T, B).copy_(t.t())
+        else:
+            oh = self._to_dev(target, torch.float32).contiguous()
+            assert oh.shape == (B, T, self.V), f"target shape {tuple(oh.shape)}"
+            self.be.onehot_argmax(oh, self.tgt, B, T, self.V)
+
+    # ------------------------------------------------------------------ graph capture
+    def _run_captured(self, key, fn):
+        """Run ``fn`` (a fixed launch sequence over static buffers) through a hipGraph:
+        first call eager (warm-up), second call captures, later calls replay."""
+        if not (self.use_graph and self.device.type == "cuda"):
+            fn()
+            return
+        st = self._graphs.get(key)
+        if st is None:
+            fn()
+            self._graphs[key] = "warm"
+        elif st == "warm":
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            self._graphs[key] = g
+            g.replay()
+        else:
+            st.replay()
+
+    # ------------------------------------------------------------------ fit loop
+    def fit(self, x=None, epochs=1, steps_per_epoch=None, batch_size=None, callbacks=None, validation_data=None,
+            validation_steps=None, initial_epoch=0, verbose=1, **kw):
+        """model.fit(generator, epochs, steps_per_epoch, batch_size, callbacks, validation_data,
+        validation_steps, initial_epoch) -- main.py:269-281.  Honours the keras callback protocol
+        (on_train_begin, on_epoch_begin, on_train_batch_end, on_test_batch_end, on_epoch_end,
+        on_train_end; Callbacks/EpochLoss.py:21-52)."""
+        callbacks = list(callbacks or [])
+        for cb in callbacks:
+            if hasattr(cb, "set_model"):
+                cb.set_model(self)
+            else:
+                cb.model = self
+        history = {}
+        _call(callbacks, "on_train_begin", {})
+        self.stop_training = False
+        for epoch in range(initial_epoch, epochs):
+            _call(callbacks, "on_epoch_begin", epoch, {})
+            n = len(x) if steps_per_epoch is None else steps_per_epoch
+            sums, t0 = {}, time.time()
+            for b in range(n):
+                _call(callbacks, "on_train_batch_begin", b, {})
+                logs = self.train_step(x[b]).as_floats()
+                for k, v in logs.items():
+                    sums[k] = sums.get(k, 0.0) + v
+                _call(callbacks, "on_train_batch_end", b, logs)
+            elogs = {k: v / max(n, 1) for k, v in sums.items()}
+            if validation_data is not None:
+                nv = len(validation_data) if validation_steps is None else validation_steps
+                vs = {}
+                for b in range(nv):
+                    logs = self.test_step(validation_data[b]).as_floats()
+                    for k, v in logs.items():
+                        vs[k] = vs.get(k, 0.0) + v
+                    _call(callbacks, "on_test_batch_end", b, logs)
+                elogs.update({f"val_{k}": v / max(nv, 1) for k, v in vs.items()})
+            if verbose:
+                print(f"epoch {epoch + 1}/{epochs} - {time.time() - t0:.1f}s - " +
+                      " - ".join(f"{k}: {v:.4f}" for k, v in elogs.items()))
+            for k, v in elogs.items():
+                history.setdefault(k, []).append(v)
+            _call(callbacks, "on_epoch_end", epoch, elogs)
+            if hasattr(x, "on_epoch_end"):
+                x.on_epoch_end()
+            if self.stop_training:
+                break
+        _call(callbacks, "on_train_end", {})
+        return history
+
+
+def _call(callbacks, name, *args):
+    for cb in callbacks:
+        fn = getattr(cb, name, None)
+        if fn is not None:
+            fn(*args)

@@ -1,0 +1,383 @@
+"""NIC -- dense voxel encoder + LSTM decoder (BASELINE config 2).
+
+Drop-in for ``AttemptFour/Model/NIC.py`` (class NIC, lines 19-325): same constructor
+arguments (NIC.py:22), ``call`` (100-145), ``greedy_predict`` (148-195), ``train_step``
+(198-252), ``test_step`` (254-299).  The step is a fixed sequence of HIP kernel launches
+over static buffers (captured into a hipGraph after warm-up):
+
+  forward : [dropout] -> split-K GEMM (B x N x E, bias+LeakyReLU) -> [dropout] -> BatchNorm
+            -> embedding gather -> one GEMM for every timestep's input projection
+            -> T+1 fused LSTM step kernels -> vocab GEMM -> fused softmax/CE/accuracy/dlogits
+  backward: vocab dW/dX GEMMs -> T+1 fused LSTM backward steps -> dU, dW, dX GEMMs
+            -> embedding scatter -> BatchNorm/LeakyReLU backward -> encoder dW GEMM
+  update  : [all-reduce] -> per-variable norms -> clip + Adam over the flat arena.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .arena import ParamArena
+from .model_base import (ModelBase, Metrics, interleave_gates, deinterleave_gates, S_IN, S_FEAT, S_LSTM_IN, BN_EPS,
+                         BN_MOMENTUM)
+from .ops import ACT_LEAKY
+
+
+def _r4(n):
+    return (n + 3) // 4 * 4
+
+
+class NIC(ModelBase):
+    def __init__(self, input_size, units, embedding_dim, vocab_size, max_length, dropout_input, dropout,
+                 dropout_lstm, input_reg, lstm_reg, output_reg, norm="batch", **kw):
+        super().__init__(**kw)
+        self.N, self.U, self.E, self.V, self.max_length = int(input_size), int(units), int(embedding_dim), int(vocab_size), int(max_length)
+        self.r_in, self.r_feat, self.r_lstm = float(dropout_input), float(dropout), float(dropout_lstm)
+        # NIC.py:53-55: the output layer is regularised with lstm_reg (quirk kept)
+        self.l2_in, self.l2_lstm, self.l2_out = float(input_reg), float(lstm_reg), float(lstm_reg)
+        assert norm in ("batch", "layer")
+        self.norm = norm
+        if self.U % 16:
+            raise ValueError("units must be a multiple of 16 (LSTM step kernel tile)")
+        N, U, E, V = self.N, self.U, self.E, self.V
+        self.ldx, self.ldV = _r4(N), _r4(V)
+        self.layers_spec = OrderedDict([
+            ("dense_img", ["kernel", "bias"]),
+            ("batch_norm", ["gamma", "beta", "moving_mean", "moving_variance"]),
+            ("emb_text", ["embeddings"]),
+            ("lstm", ["kernel", "recurrent_kernel", "bias"]),
+            ("time_distributed_softmax", ["kernel", "bias"])])
+        self.keras_shapes = OrderedDict([
+            ("dense_img/kernel", (N, E)), ("dense_img/bias", (E,)),
+            ("batch_norm/gamma", (E,)), ("batch_norm/beta", (E,)),
+            ("batch_norm/moving_mean", (E,)), ("batch_norm/moving_variance", (E,)),
+            ("emb_text/embeddings", (V, E)),
+            ("lstm/kernel", (E, 4 * U)), ("lstm/recurrent_kernel", (U, 4 * U)), ("lstm/bias", (4 * U,)),
+            ("time_distributed_softmax/kernel", (U, V)), ("time_distributed_softmax/bias", (V,))])
+        a = self.arena = ParamArena(self.device)
+        a.add("dense_img/kernel", (N, E), self.l2_in)
+        a.add("dense_img/bias", (E,))
+        a.add("batch_norm/gamma", (E,))
+        a.add("batch_norm/beta", (E,))
+        a.add("emb_text/embeddings", (V, E))
+        a.add("lstm/kernel", (E, U, 4), self.l2_lstm)
+        a.add("lstm/recurrent_kernel", (U, U, 4))
+        a.add("lstm/bias", (U, 4))
+        a.add("time_distributed_softmax/kernel", (U, self.ldV), self.l2_out)
+        a.add("time_distributed_softmax/bias", (self.ldV,))
+        a.finalize()
+        self.mov_mean, self.mov_var = self._f(E), torch.ones(E, dtype=torch.float32, device=self.device)
+        self.drop_step = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._init_weights(np.random.default_rng(self.seed))
+        self._shape = None
+
+    # ------------------------------------------------------------------ weights
+    def _init_weights(self, rng):
+        """Initialisers of NIC.py:64-98 (GlorotNormal kernels, keras defaults elsewhere); values only
+        matter for benchmarks -- parity tests inject weights."""
+        N, U, E, V = self.N, self.U, self.E, self.V
+        tn = lambda shape, std: np.clip(rng.standard_normal(shape), -2, 2) * std / 0.8796
+        self.set_weight("dense_img/kernel", tn((N, E), np.sqrt(2.0 / (N + E))))
+        self.set_weight("emb_text/embeddings", rng.uniform(-0.05, 0.05, (V, E)))
+        lim = np.sqrt(6.0 / (E + 4 * U))
+        self.set_weight("lstm/kernel", rng.uniform(-lim, lim, (E, 4 * U)))
+        q = np.concatenate([np.linalg.qr(rng.standard_normal((U, U)))[0] for _ in range(4)], axis=1)
+        self.set_weight("lstm/recurrent_kernel", q)
+        b = np.zeros(4 * U); b[U:2 * U] = 1.0          # unit_forget_bias
+        self.set_weight("lstm/bias", b)
+        self.set_weight("time_distributed_softmax/kernel", tn((U, V), np.sqrt(2.0 / (U + V))))
+        self.set_weight("batch_norm/gamma", np.ones(E))
+
+    def set_weight(self, name, arr):
+        arr = np.asarray(arr, dtype=np.float32)
+        assert tuple(arr.shape) == tuple(self.keras_shapes[name]), (name, arr.shape, self.keras_shapes[name])
+        if name == "batch_norm/moving_mean":
+            self.mov_mean.copy_(torch.from_numpy(arr)); return
+        if name == "batch_norm/moving_variance":
+            self.mov_var.copy_(torch.from_numpy(arr)); return
+        dst = self.arena.p(name)
+        if name.startswith("lstm/"):
+            arr = interleave_gates(arr, self.U)
+        elif name == "time_distributed_softmax/kernel":
+            pad = np.zeros((self.U, self.ldV), np.float32); pad[:, :self.V] = arr; arr = pad
+        elif name == "time_distributed_softmax/bias":
+            pad = np.zeros(self.ldV, np.float32); pad[:self.V] = arr; arr = pad
+        dst.copy_(torch.from_numpy(np.ascontiguousarray(arr)).view(dst.shape))
+
+    def _unpack(self, name, t):
+        arr = t.detach().cpu().numpy()
+        if name.startswith("lstm/"):
+            return deinterleave_gates(arr)
+        if name == "time_distributed_softmax/kernel":
+            return np.ascontiguousarray(arr[:, :self.V])
+        if name == "time_distributed_softmax/bias":
+            return np.ascontiguousarray(arr[:self.V])
+        return arr.copy()
+
+    def get_weight(self, name):
+        if name == "batch_norm/moving_mean":
+            return self.mov_mean.cpu().numpy().copy()
+        if name == "batch_norm/moving_variance":
+            return self.mov_var.cpu().numpy().copy()
+        return self._unpack(name, self.arena.p(name))
+
+    def get_gradient(self, name):
+        """Last computed gradient of a trainable (keras layout, *without* the L2 term, which the
+        optimizer kernels add on the fly)."""
+        return self._unpack(name, self.arena.g(name))
+
+    def state_tensors(self):
+        """Non-trainable device state (BatchNorm moving statistics)."""
+        return [self.mov_mean, self.mov_var]
+
+    @property
+    def losses(self):
+        """[lambda*||W||^2 ...] as self.losses (NIC.py:242-243)."""
+        a = self.arena
+        self._norms_and_l2(self.met[2:3])
+        return [a.seg_l2[e.seg] * a.wsq[e.seg] for e in a.entries.values() if e.l2 > 0]
+
+    # ------------------------------------------------------------------ buffers
+    def _build(self, B, T):
+        if self._shape == (B, T):
+            return
+        f = self._f
+        N, U, E, V, ldV = self.N, self.U, self.E, self.V, self.ldV
+        R1 = (T + 1) * B
+        self.x = f(B, self.ldx)
+        self.xd = f(B, self.ldx) if self.r_in > 0 else self.x
+        self.cap = torch.zeros(B, T, dtype=torch.int32, device=self.device)
+        self.tgt = torch.zeros(T * B, dtype=torch.int32, device=self.device)
+        self.enc_pre, self.enc_y = f(B, E), f(B, E)
+        self.enc_yd = f(B, E) if self.r_feat > 0 else self.enc_y
+        self.xhat = f(B, E)
+        self.inv_std = f(max(B, E))
+        self.Xin = f(R1, E)
+        self.Xin_d = f(R1, E) if self.r_lstm > 0 else self.Xin
+        self.XZ = f(R1, U, 4)
+        self.Hs, self.Cs = f(T + 2, B, U), f(T + 2, B, U)
+        self.gates = f(T + 1, B, U, 4)
+        self.Out = f(T, B, U)
+        self.logits = f(T * B, ldV)
+        self.loss_row, self.corr_row = f(T * B), f(T * B)
+        self.met = f(8)
+        self.dOut = f(T * B, U)
+        self.dZ = f(R1, U, 4)
+        self.da_pass, self.dc, self.dout = f(B, U), f(B, U), f(B, U)
+        self.dXin = f(R1, E)
+        self.dyd, self.dpre = f(B, E), f(B, E)
+        be = self.be
+        self.enc_splitk = int(max(1, min(64, N // 256, 512 // (((B + 63) // 64) * ((E + 63) // 64)))))
+        self.skwork = f(self.enc_splitk * B * E)
+        nch = max(be.bn_nchunk(B), be.bn_nchunk(R1), be.bn_nchunk(T * B))
+        self.work = f(max(E, 4 * U, ldV) * (2 * nch + 1))
+        self.rowsq = f(B * T)
+        self.emb_seg = self.arena.entries["emb_text/embeddings"].seg
+        self._shape = (B, T)
+        self._graphs = {}
+        if self.optimizer is not None and getattr(self, "opt_m", None) is None:
+            self._init_optimizer_state()
+        self.built = True
+
+    def _stage_inputs(self, data):
+        x, cap, a0, c0 = data
+        cap_t = self._to_dev(cap, torch.int32)
+        B, T = cap_t.shape
+        self._build(B, T)
+        xs = self._to_dev(x, torch.float32)
+        assert xs.shape == (B, self.N), f"betas shape {tuple(xs.shape)} != {(B, self.N)}"
+        self.x[:, :self.N].copy_(xs)
+        self.cap.copy_(cap_t)
+        self.Hs[0].copy_(self._to_dev(a0, torch.float32))
+        self.Cs[0].copy_(self._to_dev(c0, torch.float32))
+        return B, T
+
+    # ------------------------------------------------------------------ forward
+    def _forward(self, B, T, training):
+        be, a = self.be, self.arena
+        N, U, E, V, ldV = self.N, self.U, self.E, self.V, self.ldV
+        R1 = (T + 1) * B
+        sd, ds = self.seed, self.drop_step
+        x = self.x
+        if training and self.r_in > 0:                                              # NIC.py:122
+            be.dropout(self.x, self.xd, B, N, self.ldx, 0, N, 0, self.r_in, sd, S_IN, 0, ds)
+            x = self.xd
+        be.gemm(x, a.p("dense_img/kernel"), self.enc_y, B, E, N, self.ldx, E, E, bias=a.p("dense_img/bias"),
+                pre=self.enc_pre, act=ACT_LEAKY, slope=0.2, splitk=self.enc_splitk, work=self.skwork)   # :125
+        y = self.enc_y
+        if training and self.r_feat > 0:                                            # :126
+            be.dropout(self.enc_y, self.enc_yd, B, E, E, 0, E, 0, self.r_feat, sd, S_FEAT, 0, ds)
+            y = self.enc_yd
+        if self.norm == "batch":                                                    # :127-128
+            be.batchnorm_fwd(y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.mov_mean, self.mov_var,
+                             self.Xin, self.xhat, self.inv_std, B, E, E, training, BN_EPS, BN_MOMENTUM, self.work)
+        else:
+            be.layernorm_fwd(y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.Xin, self.xhat, self.inv_std,
+                             B, E, E, BN_EPS)
+        be.embedding_fwd(a.p("emb_text/embeddings"), self.cap, self.Xin[B:], B, T, E, E, V)   # :131
+        xin = self.Xin
+        if training and self.r_lstm > 0:       # LSTM(dropout=...) masks the layer input, one mask per call
+            be.dropout(self.Xin, self.Xin_d, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
+            be.dropout(self.Xin[B:], self.Xin_d[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
+            xin = self.Xin_d
+        self._xin_used = xin
+        be.gemm(xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U, bias=a.p("lstm/bias"))
+        Ur = a.p("lstm/recurrent_kernel")
+        # lstm call 1: the feature, one unmasked step (NIC.py:138)
+        be.lstm_step_fwd(self.XZ[:B], self.Hs[0], self.Cs[0], Ur, None, None, 0, None, 0, 0, None, self.Hs[1],
+                         self.Cs[1], None, self.gates[0], B, U)
+        # lstm call 2: the text, masked by the Embedding mask (NIC.py:140)
+        for t in range(1, T + 1):
+            be.lstm_step_fwd(self.XZ[t * B:(t + 1) * B], self.Hs[t], self.Cs[t], Ur, None, None, 0, self.cap, T,
+                             t - 1, self.Out[t - 2] if t > 1 else None, self.Hs[t + 1], self.Cs[t + 1],
+                             self.Out[t - 1], self.gates[t], B, U)
+        be.gemm(self.Out, a.p("time_distributed_softmax/kernel"), self.logits, T * B, V, U, U, ldV, ldV,
+                bias=a.p("time_distributed_softmax/bias"))                         # NIC.py:143
+
+    def _loss_metrics(self, B, T, want_grad):
+        """softmax + per-timestep mean CE / accuracy summed over T and divided by T
+        (NIC.py:233-240) == sum over all (b,t) / (B*T)."""
+        be = self.be
+        n = T * B
+        if want_grad:
+            be.softmax_cce(self.logits, self.tgt, None, self.loss_row, self.corr_row, self.logits, n, self.V,
+                           self.ldV, 1.0 / (n * self.dp_world))
+        else:
+            be.softmax_cce(self.logits, self.tgt, self.logits, self.loss_row, self.corr_row, None, n, self.V,
+                           self.ldV, 0.0)
+        be.sum(self.loss_row, self.met[0:1], n, 1.0 / n)
+        be.sum(self.corr_row, self.met[1:2], n, 1.0 / n)
+
+    # ------------------------------------------------------------------ backward
+    def _backward(self, B, T):
+        be, a = self.be, self.arena
+        N, U, E, V, ldV = self.N, self.U, self.E, self.V, self.ldV
+        R1 = (T + 1) * B
+        sd, ds = self.seed, self.drop_step
+        dlog = self.logits
+        Wo = a.p("time_distributed_softmax/kernel")
+        be.gemm(self.Out, dlog, a.g("time_distributed_softmax/kernel"), U, V, T * B, U, ldV, ldV, transA=True)
+        be.colsum(dlog, a.g("time_distributed_softmax/bias"), T * B, V, ldV, self.work)
+        be.gemm(dlog, Wo, self.dOut, T * B, U, V, ldV, ldV, U, transB=True)
+        Ur = a.p("lstm/recurrent_kernel")
+        dOut = self.dOut.view(T, B, U)
+        for t in range(T, 0, -1):
+            first = t == T
+            be.lstm_step_bwd(None if first else self.dZ[(t + 1) * B:(t + 2) * B], Ur,
+                             None if first else self.da_pass, None, None if first else self.dc,
+                             None if first else self.dout, dOut[t - 1], self.cap, T, t - 1, self.gates[t],
+                             self.Cs[t + 1], self.Cs[t], self.dZ[t * B:(t + 1) * B], self.da_pass, self.dc, self.dout,
+                             B, U)
+        be.lstm_step_bwd(self.dZ[B:2 * B], Ur, self.da_pass, None, self.dc, None, None, None, 0, 0, self.gates[0],
+                         self.Cs[1], self.Cs[0], self.dZ[:B], None, None, None, B, U)
+        xin = self._xin_used
+        be.gemm(self.Hs, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, R1, U, 4 * U, 4 * U, transA=True)
+        be.gemm(xin, self.dZ, a.g("lstm/kernel"), E, 4 * U, R1, E, 4 * U, 4 * U, transA=True)
+        be.colsum(self.dZ, a.g("lstm/bias"), R1, 4 * U, 4 * U, self.work)
+        be.gemm(self.dZ, a.p("lstm/kernel"), self.dXin, R1, E, 4 * U, 4 * U, 4 * U, E, transB=True)
+        if self.r_lstm > 0:
+            be.dropout(self.dXin, self.dXin, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
+            be.dropout(self.dXin[B:], self.dXin[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
+        sqo = a.sq_override[self.emb_seg:self.emb_seg + 1]
+        sqo.zero_()
+        be.embedding_bwd(self.dXin[B:], self.cap, a.g("emb_text/embeddings"), sqo, self.rowsq, B, T, E, E, V)
+        if self.norm == "batch":
+            be.batchnorm_bwd(self.dXin, self.xhat, a.p("batch_norm/gamma"), self.inv_std, self.dyd,
+                             a.g("batch_norm/gamma"), a.g("batch_norm/beta"), B, E, E, True, self.work)
+        else:
+            be.layernorm_bwd(self.dXin, self.xhat, a.p("batch_norm/gamma"), self.inv_std, self.dyd,
+                             a.g("batch_norm/gamma"), a.g("batch_norm/beta"), B, E, E, self.work)
+        if self.r_feat > 0:
+            be.dropout(self.dyd, self.dyd, B, E, E, 0, E, 0, self.r_feat, sd, S_FEAT, 0, ds)
+        be.act_bwd(self.enc_pre, self.dyd, self.dpre, B * E, ACT_LEAKY, 0.2)
+        be.colsum(self.dpre, a.g("dense_img/bias"), B, E, E, self.work)
+        x = self.xd if self.r_in > 0 else self.x
+        be.gemm(x, self.dpre, a.g("dense_img/kernel"), N, E, B, self.ldx, E, E, transA=True)
+
+    # ------------------------------------------------------------------ steps
+    def _train_graph(self, B, T):
+        self._forward(B, T, True)
+        self._loss_metrics(B, T, True)
+        self._backward(B, T)
+
+    def _update_graph(self):
+        self._norms_and_l2(self.met[2:3])
+        self._apply_optimizer()
+
+    def train_step(self, data):
+        """NIC.train_step (NIC.py:198-252): data = ((betas, cap, a0, c0), target)."""
+        if self.optimizer is None:
+            raise RuntimeError("compile() the model before train_step")
+        B, T = self._stage_inputs(data[0])
+        self._stage_target(data[1], B, T)
+        self._sync_lr()
+        if self.grad_sync is None:
+            self._run_captured(("train", B, T), lambda: (self._train_graph(B, T), self._update_graph()))
+        else:       # data parallel: forward+backward | all-reduce of the flat gradient | update
+            self._run_captured(("train_fb", B, T), lambda: self._train_graph(B, T))
+            self.grad_sync(self)
+            self._run_captured(("train_up", B, T), self._update_graph)
+        self.optimizer.iterations += 1
+        m = self.met.clone()
+        return Metrics(loss=m[0], L2=m[2], accuracy=m[1])
+
+    def test_step(self, data):
+        """NIC.test_step (NIC.py:254-299)."""
+        B, T = self._stage_inputs(data[0])
+        self._stage_target(data[1], B, T)
+
+        def run():
+            self._forward(B, T, False)
+            self._loss_metrics(B, T, False)
+            self._norms_and_l2(self.met[2:3])
+        self._run_captured(("test", B, T), run)
+        m = self.met.clone()
+        return Metrics(loss=m[0], L2=m[2], accuracy=m[1])
+
+    def __call__(self, data, training=False):
+        """NIC.call (NIC.py:100-145): returns probabilities (B, T, V)."""
+        B, T = self._stage_inputs(data)
+        self._forward(B, T, training)
+        self.be.softmax_cce(self.logits, None, self.logits, None, None, None, T * B, self.V, self.ldV, 0.0)
+        return self.logits.view(T, B, self.ldV)[:, :, :self.V].permute(1, 0, 2).contiguous()
+
+    call = __call__
+
+    def greedy_predict(self, img_input, a0, c0, start_seq, max_len, units=None, tokenizer=None):
+        """NIC.greedy_predict (NIC.py:148-195), inference mode; returns np.ndarray (max_len, B, 1, V).
+        A predicted id 0 masks the following LSTM step exactly as the keras Embedding mask does."""
+        be, a = self.be, self.arena
+        start = self._to_dev(np.asarray(start_seq).reshape(-1), torch.int32)
+        B = start.shape[0]
+        cap = torch.zeros(B, 1, dtype=torch.int32, device=self.device)
+        self._stage_inputs((img_input, cap, a0, c0))
+        N, U, E, V, ldV = self.N, self.U, self.E, self.V, self.ldV
+        be.gemm(self.x, a.p("dense_img/kernel"), self.enc_y, B, E, N, self.ldx, E, E, bias=a.p("dense_img/bias"),
+                pre=self.enc_pre, act=ACT_LEAKY, slope=0.2, splitk=self.enc_splitk, work=self.skwork)
+        if self.norm == "batch":
+            be.batchnorm_fwd(self.enc_y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.mov_mean, self.mov_var,
+                             self.Xin, self.xhat, self.inv_std, B, E, E, False, BN_EPS, BN_MOMENTUM, self.work)
+        else:
+            be.layernorm_fwd(self.enc_y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.Xin, self.xhat,
+                             self.inv_std, B, E, E, BN_EPS)
+        Wl, bl, Ur = a.p("lstm/kernel"), a.p("lstm/bias"), a.p("lstm/recurrent_kernel")
+        xz, emb = self.XZ[:B], self.Xin[B:2 * B]
+        h = [self.Hs[0], self.Hs[1]]
+        c = [self.Cs[0], self.Cs[1]]
+        be.gemm(self.Xin, Wl, xz, B, 4 * U, E, E, 4 * U, 4 * U, bias=bl)
+        be.lstm_step_fwd(xz, h[0], c[0], Ur, None, None, 0, None, 0, 0, None, h[1], c[1], None, self.gates[0], B, U)
+        cur = 1
+        words = start.clone().view(B, 1)
+        out = self.Out[0]
+        probs_all = torch.zeros(max_len, B, ldV, dtype=torch.float32, device=self.device)
+        for i in range(max_len):
+            be.embedding_fwd(a.p("emb_text/embeddings"), words, emb, B, 1, E, E, V)
+            be.gemm(emb, Wl, xz, B, 4 * U, E, E, 4 * U, 4 * U, bias=bl)
+            be.lstm_step_fwd(xz, h[cur], c[cur], Ur, None, None, 0, words if i > 0 else None, 1, 0, None,
+                             h[1 - cur], c[1 - cur], out, self.gates[0], B, U)
+            cur = 1 - cur
+            be.gemm(out, a.p("time_distributed_softmax/kernel"), probs_all[i], B, V, U, U, ldV, ldV,
+                    bias=a.p("time_distributed_softmax/bias"))
+            be.softmax_cce(probs_all[i], None, probs_all[i], None, None, None, B, V, ldV, 0.0)
+            be.argmax_rows(probs_all[i], words, B, V, ldV)
+        return probs_all[:, :, :V].cpu().numpy()[:, :, None, :]

@@ -106,11 +106,11 @@ class HipBackend:
     def sum(self, x, out, n, scale):
         _lib.check(self.lib.tnt_sum_f32(_p(x), _p(out), n, scale, self._s()), "tnt_sum_f32")
 
-    def seg_sqnorm(self, theta, grad, span_seg, span_off, span_len, seg_first, seg_l2, partial, sq, wsq, nspan,
-                   nseg):
+    def seg_sqnorm(self, theta, grad, span_seg, span_off, span_len, seg_first, seg_l2, partial, sq, wsq, l2_out,
+                   nspan, nseg):
         _lib.check(self.lib.tnt_seg_sqnorm_f32(_p(theta), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
-                                               _p(seg_first), _p(seg_l2), _p(partial), _p(sq), _p(wsq), nspan, nseg,
-                                               self._s()), "tnt_seg_sqnorm_f32")
+                                               _p(seg_first), _p(seg_l2), _p(partial), _p(sq), _p(wsq), _p(l2_out),
+                                               nspan, nseg, self._s()), "tnt_seg_sqnorm_f32")
 
     def adam(self, theta, m, v, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr_t, lr_t_dev,
              beta1, beta2, eps, clipnorm):

@@ -1,0 +1,342 @@
+"""CPU stand-in for the kernel backend -- TEST INFRASTRUCTURE ONLY.
+
+Implements the method surface of ``masters_thesis_amd.ops.HipBackend`` on CPU torch tensors
+with numpy (float32 storage, float64 arithmetic inside each op), following the semantics
+documented in include/tnt_hip.h and the oracle ops.  It exists so that the *host
+orchestration* (launch order, buffer wiring, layouts, optimizer plumbing) can be checked
+against the model-level oracle without a GPU.  The product never imports this file; the
+HIP kernels themselves are checked on the GPU by tests/test_gpu_ops.py.
+"""
+import numpy as np
+import torch
+
+from oracle import ops as O
+from oracle.philox import uniform24
+
+
+def flat(t):
+    """1-D numpy view of the storage from t's first element to the end of its storage."""
+    if t is None:
+        return None
+    n = t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+    return torch.empty(0, dtype=t.dtype).set_(t.untyped_storage(), t.storage_offset(), (n,), (1,)).numpy()
+
+
+def mat(t, rows, cols, ld):
+    return np.lib.stride_tricks.as_strided(flat(t), (rows, cols), (ld * 4, 4))
+
+
+def _keep(e, rate, seed, site, step):
+    """keep decision for logical element indices e (int64 array)."""
+    e = np.asarray(e, dtype=np.uint64)
+    shp = e.shape
+    e = e.reshape(-1)
+    from oracle.philox import philox4x32_10
+    grp = e >> np.uint64(2)
+    r = philox4x32_10((grp & np.uint64(0xFFFFFFFF)).astype(np.uint32), (grp >> np.uint64(32)).astype(np.uint32),
+                      np.uint32(site), np.uint32(step), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    r = np.stack(r, -1)[np.arange(e.size), (e & np.uint64(3)).astype(np.int64)]
+    u = (r >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+    return (u >= np.float32(rate)).reshape(shp)
+
+
+class MockBackend:
+    name = "mock-cpu"
+
+    def bn_nchunk(self, rows):
+        return (rows + 63) // 64
+
+    # ---------------------------------------------------------------- gemm
+    def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, pre=None, act=0,
+             slope=0.2, accumulate=False, splitk=1, work=None):
+        a = mat(A, K, M, lda).T if transA else mat(A, M, K, lda)
+        b = mat(B, N, K, ldb).T if transB else mat(B, K, N, ldb)
+        v = a.astype(np.float64) @ b.astype(np.float64)
+        if bias is not None:
+            v = v + flat(bias)[:N]
+        if pre is not None:
+            mat(pre, M, N, ldc)[...] = v
+        v = O.act_fwd(v, act, slope)
+        c = mat(C, M, N, ldc)
+        c[...] = (c + v) if accumulate else v
+
+    def dropout(self, x, y, rows, cols, ld, tmajor_B, lwidth, lcol0, rate, seed, site, step, step_dev=None):
+        if step_dev is not None:
+            step = (step + int(step_dev[0])) & 0xFFFFFFFF
+        xs, ys = mat(x, rows, cols, ld), mat(y, rows, cols, ld)
+        r = np.arange(rows)
+        T = rows // tmajor_B if tmajor_B > 0 else 0
+        lrow = (r % tmajor_B) * T + r // tmajor_B if tmajor_B > 0 else r
+        e = lrow[:, None].astype(np.int64) * lwidth + lcol0 + np.arange(cols)[None, :]
+        k = _keep(e, rate, seed, site, step)
+        scale = np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
+        ys[...] = np.where(k, xs * scale, np.float32(0))
+
+    def act_bwd(self, pre, dy, dx, n, act, slope=0.2):
+        flat(dx)[:n] = O.act_bwd(flat(pre)[:n].astype(np.float64), flat(dy)[:n].astype(np.float64), act, slope)
+
+    # ---------------------------------------------------------------- norms
+    def batchnorm_fwd(self, x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, training, eps,
+                      momentum, work):
+        xs = mat(x, rows, C, C).astype(np.float64)
+        mm, mv = flat(mov_mean)[:C], flat(mov_var)[:C]
+        yo, (xh, inv, _), nmm, nmv = O.batchnorm_fwd(xs, flat(gamma)[:C].astype(np.float64),
+                                                     flat(beta)[:C].astype(np.float64), mm.astype(np.float64),
+                                                     mv.astype(np.float64), bool(training), eps, momentum)
+        mat(y, rows, C, ldy)[...] = yo
+        mat(xhat, rows, C, C)[...] = xh
+        flat(inv_std)[:C] = inv
+        mm[...] = nmm
+        mv[...] = nmv
+
+    def batchnorm_bwd(self, dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, training, work):
+        cache = (mat(xhat, rows, C, C).astype(np.float64), flat(inv_std)[:C].astype(np.float64), bool(training))
+        dxo, dg, db = O.batchnorm_bwd(mat(dy, rows, C, lddy).astype(np.float64), flat(gamma)[:C].astype(np.float64), cache)
+        if dx is not None:
+            mat(dx, rows, C, C)[...] = dxo
+        flat(dgamma)[:C] = dg
+        flat(dbeta)[:C] = db
+
+    def layernorm_fwd(self, x, gamma, beta, y, xhat, inv_std, rows, C, ldy, eps):
+        yo, (xh, inv) = O.layernorm_fwd(mat(x, rows, C, C).astype(np.float64), flat(gamma)[:C].astype(np.float64),
+                                        flat(beta)[:C].astype(np.float64), eps)
+        mat(y, rows, C, ldy)[...] = yo
+        mat(xhat, rows, C, C)[...] = xh
+        flat(inv_std)[:rows] = inv[:, 0]
+
+    def layernorm_bwd(self, dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, work):
+        cache = (mat(xhat, rows, C, C).astype(np.float64), flat(inv_std)[:rows].astype(np.float64)[:, None])
+        dxo, dg, db = O.layernorm_bwd(mat(dy, rows, C, lddy).astype(np.float64), flat(gamma)[:C].astype(np.float64), cache)
+        if dx is not None:
+            mat(dx, rows, C, C)[...] = dxo
+        flat(dgamma)[:C] = dg
+        flat(dbeta)[:C] = db
+
+    def colsum(self, x, out, rows, C, ld, work):
+        flat(out)[:C] = mat(x, rows, C, ld).astype(np.float64).sum(0)
+
+    def sum(self, x, out, n, scale):
+        flat(out)[0] = flat(x)[:n].astype(np.float64).sum() * scale
+
+    # ---------------------------------------------------------------- embedding
+    def embedding_fwd(self, table, ids, out, B, T, E, ldo, V):
+        idv = np.clip(flat(ids)[:B * T].reshape(B, T), 0, V - 1)
+        tab = mat(table, V, E, E)
+        mat(out, T * B, E, ldo)[...] = tab[idv.T.reshape(-1)]
+
+    def embedding_bwd(self, drows, ids, dtable, sq_norm, rowsq_work, B, T, E, ldd, V):
+        idv = flat(ids)[:B * T].reshape(B, T)
+        rows = mat(drows, T * B, E, ldd).astype(np.float64)
+        g = np.zeros((V, E))
+        np.add.at(g, idv.T.reshape(-1), rows)
+        mat(dtable, V, E, E)[...] = g
+        if sq_norm is not None:
+            flat(sq_norm)[0] += (rows * rows).sum()
+
+    # ---------------------------------------------------------------- LSTM
+    def lstm_step_fwd(self, xz, h_prev, c_prev, Ur, ctx, Wc, D, mask_ids, mask_T, mask_t, out_prev, h, c, out,
+                      gates, B, U):
+        z = mat(xz, B, 4 * U, 4 * U).astype(np.float64).reshape(B, U, 4)
+        hp, cp = mat(h_prev, B, U, U).astype(np.float64), mat(c_prev, B, U, U).astype(np.float64)
+        z = z + (hp @ mat(Ur, U, 4 * U, 4 * U).astype(np.float64)).reshape(B, U, 4)
+        if ctx is not None:
+            z = z + (mat(ctx, B, D, D).astype(np.float64) @ mat(Wc, D, 4 * U, 4 * U).astype(np.float64)).reshape(B, U, 4)
+        i, f, g, o = O.sigmoid(z[..., 0]), O.sigmoid(z[..., 1]), np.tanh(z[..., 2]), O.sigmoid(z[..., 3])
+        c2 = f * cp + i * g
+        h2 = o * np.tanh(c2)
+        m = np.ones((B, 1), bool)
+        if mask_ids is not None:
+            m = (flat(mask_ids)[:B * mask_T].reshape(B, mask_T)[:, mask_t] != 0)[:, None]
+        op = mat(out_prev, B, U, U) if out_prev is not None else 0.0
+        mat(h, B, U, U)[...] = np.where(m, h2, hp)
+        mat(c, B, U, U)[...] = np.where(m, c2, cp)
+        if out is not None:
+            mat(out, B, U, U)[...] = np.where(m, h2, op)
+        mat(gates, B, 4 * U, 4 * U)[...] = np.stack([i, f, g, o], -1).reshape(B, 4 * U)
+
+    def lstm_step_bwd(self, dz_next, Ur, da_pass_in, dh_ext, dc_in, dout_in, dout_t, mask_ids, mask_T, mask_t, gates,
+                      c, c_prev, dz, da_pass_out, dc_out, dout_out, B, U):
+        g64 = lambda t: mat(t, B, U, U).astype(np.float64) if t is not None else np.zeros((B, U))
+        da = g64(da_pass_in) + g64(dh_ext)
+        if dz_next is not None:
+            da = da + mat(dz_next, B, 4 * U, 4 * U).astype(np.float64) @ mat(Ur, U, 4 * U, 4 * U).astype(np.float64).T
+        dout = g64(dout_in) + g64(dout_t)
+        dcin = g64(dc_in)
+        m = np.ones((B, 1), bool)
+        if mask_ids is not None:
+            m = (flat(mask_ids)[:B * mask_T].reshape(B, mask_T)[:, mask_t] != 0)[:, None]
+        gt = mat(gates, B, 4 * U, 4 * U).astype(np.float64).reshape(B, U, 4)
+        gi, gf, gg, go = gt[..., 0], gt[..., 1], gt[..., 2], gt[..., 3]
+        tc = np.tanh(g64(c))
+        dh = da + dout
+        dgo = dh * tc
+        dcc = dcin + dh * go * (1 - tc * tc)
+        dzv = np.stack([dcc * gg * gi * (1 - gi), dcc * g64(c_prev) * gf * (1 - gf), dcc * gi * (1 - gg * gg),
+                        dgo * go * (1 - go)], -1)
+        mat(dz, B, 4 * U, 4 * U)[...] = np.where(m[..., None], dzv, 0).reshape(B, 4 * U)
+        if dc_out is not None:
+            mat(dc_out, B, U, U)[...] = np.where(m, dcc * gf, dcin)
+        if da_pass_out is not None:
+            mat(da_pass_out, B, U, U)[...] = np.where(m, 0, da)
+        if dout_out is not None:
+            mat(dout_out, B, U, U)[...] = np.where(m, 0, dout)
+
+    # ---------------------------------------------------------------- softmax / CE
+    def softmax_cce(self, logits, target, probs, loss_row, correct_row, dlogits, rows, V, ld, gscale):
+        x = mat(logits, rows, V, ld).astype(np.float64)
+        p = O.softmax(x)
+        if target is not None:
+            y = flat(target)[:rows].astype(np.int64)
+            py = np.take_along_axis(p, y[:, None], 1)[:, 0]
+            if loss_row is not None:
+                flat(loss_row)[:rows] = -np.log(np.clip(py, 1e-7, 1 - 1e-7))
+            if correct_row is not None:
+                flat(correct_row)[:rows] = (p.argmax(-1) == y)
+            if dlogits is not None:
+                oh = np.zeros_like(p)
+                np.put_along_axis(oh, y[:, None], 1.0, 1)
+                active = ((py >= 1e-7) & (py <= 1 - 1e-7))[:, None]
+                mat(dlogits, rows, V, ld)[...] = np.where(active, (p - oh) * gscale, 0)
+        if probs is not None and (dlogits is None or probs.data_ptr() != dlogits.data_ptr()):
+            mat(probs, rows, V, ld)[...] = p
+
+    def onehot_argmax(self, onehot, ids_tmajor, B, T, V):
+        oh = flat(onehot)[:B * T * V].reshape(B, T, V)
+        flat(ids_tmajor)[:B * T] = oh.argmax(-1).T.reshape(-1)
+
+    def argmax_rows(self, x, out, rows, V, ld):
+        flat(out)[:rows] = mat(x, rows, V, ld).argmax(-1)
+
+    # ---------------------------------------------------------------- optimizer
+    def _segs(self, span_seg, span_off, span_len, nspan):
+        ss, so, sl = flat(span_seg)[:nspan], flat(span_off)[:nspan], flat(span_len)[:nspan]
+        return list(zip(ss.tolist(), so.tolist(), sl.tolist()))
+
+    def seg_sqnorm(self, theta, grad, span_seg, span_off, span_len, seg_first, seg_l2, partial, sq, wsq, l2_out,
+                   nspan, nseg):
+        th, gr, l2 = flat(theta), flat(grad), flat(seg_l2)
+        q, w = np.zeros(nseg), np.zeros(nseg)
+        for s, o, n in self._segs(span_seg, span_off, span_len, nspan):
+            t = th[o:o + n].astype(np.float64)
+            g = gr[o:o + n].astype(np.float64) + 2 * float(l2[s]) * t
+            q[s] += (g * g).sum()
+            w[s] += (t * t).sum()
+        flat(sq)[:nseg] = q
+        flat(wsq)[:nseg] = w
+        if l2_out is not None:
+            flat(l2_out)[0] = (l2[:nseg].astype(np.float64) * w).sum()
+
+    def _clip(self, sq, sq_override, s, clipnorm):
+        if clipnorm <= 0:
+            return 1.0
+        q = float(flat(sq)[s])
+        if sq_override is not None and float(flat(sq_override)[s]) >= 0:
+            q = float(flat(sq_override)[s])
+        return clipnorm / max(np.sqrt(q), clipnorm)
+
+    def adam(self, theta, m, v, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr_t, lr_t_dev,
+             beta1, beta2, eps, clipnorm):
+        if lr_t_dev is not None:
+            lr_t = float(flat(lr_t_dev)[0])
+        th, mm, vv, gr, l2 = flat(theta), flat(m), flat(v), flat(grad), flat(seg_l2)
+        for s, o, n in self._segs(span_seg, span_off, span_len, nspan):
+            t = th[o:o + n].astype(np.float64)
+            g = (gr[o:o + n].astype(np.float64) + 2 * float(l2[s]) * t) * self._clip(sq, sq_override, s, clipnorm)
+            m1 = mm[o:o + n] + (g - mm[o:o + n]) * (1 - beta1)
+            v1 = vv[o:o + n] + (g * g - vv[o:o + n]) * (1 - beta2)
+            th[o:o + n] = t - lr_t * m1 / (np.sqrt(v1) + eps)
+            mm[o:o + n] = m1
+            vv[o:o + n] = v1
+
+    def sgd(self, theta, mom, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr, lr_dev, momentum,
+            clipnorm):
+        if lr_dev is not None:
+            lr = float(flat(lr_dev)[0])
+        th, mo, gr, l2 = flat(theta), flat(mom), flat(grad), flat(seg_l2)
+        for s, o, n in self._segs(span_seg, span_off, span_len, nspan):
+            t = th[o:o + n].astype(np.float64)
+            g = (gr[o:o + n].astype(np.float64) + 2 * float(l2[s]) * t) * self._clip(sq, sq_override, s, clipnorm)
+            mv = momentum * mo[o:o + n] - lr * g
+            mo[o:o + n] = mv
+            th[o:o + n] = t + mv
+
+    def step_tick(self, adam_t, drop_step, lr, lr_t, beta1, beta2):
+        if drop_step is not None:
+            drop_step += 1
+        if adam_t is not None:
+            adam_t += 1
+            t = int(adam_t[0])
+            if lr_t is not None:
+                flat(lr_t)[0] = float(flat(lr)[0]) * np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+
+    # ---------------------------------------------------------------- encoder / attention
+    def _groups(self, idx, goff, R):
+        go = flat(goff)[:R + 1]
+        ix = flat(idx)
+        return [ix[go[r]:go[r + 1]].astype(np.int64) for r in range(R)], go
+
+    def locally_dense_fwd(self, x, ldx, idx, goff, W, bias, pre, y, B, R, D, slope=0.2):
+        groups, go = self._groups(idx, goff, R)
+        xs = mat(x, B, int(max(g.max() for g in groups if len(g)) + 1), ldx).astype(np.float64)
+        Wm = mat(W, int(go[R]), D, D).astype(np.float64)
+        bm = mat(bias, R, D, D).astype(np.float64)
+        yo, po = O.locally_dense_fwd(xs, groups, [Wm[go[r]:go[r + 1]] for r in range(R)], list(bm), slope)
+        flat(pre)[:B * R * D] = po.reshape(-1)
+        flat(y)[:B * R * D] = yo.reshape(-1)
+
+    def locally_dense_bwd(self, x, ldx, idx, goff, dpre, dW, db, B, R, D):
+        groups, go = self._groups(idx, goff, R)
+        xs = mat(x, B, int(max(g.max() for g in groups if len(g)) + 1), ldx).astype(np.float64)
+        dp = flat(dpre)[:B * R * D].reshape(B, R, D).astype(np.float64)
+        dWm = mat(dW, int(go[R]), D, D)
+        for r, g in enumerate(groups):
+            dWm[go[r]:go[r + 1]] = xs[:, g].T @ dp[:, r]
+        mat(db, R, D, D)[...] = dp.sum(0)
+
+    def attention_step_fwd(self, h, F, P, W2, b2, v, bv, qpre, alpha, ctx, ctx_d, s_out, B, R, D, A, U, slope,
+                           rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None):
+        if step_dev is not None:
+            step = (step + int(step_dev[0])) & 0xFFFFFFFF
+        f64 = lambda t, *s: flat(t)[:int(np.prod(s))].reshape(*s).astype(np.float64)
+        keep = _keep(np.arange(B * R * A).reshape(B, R, A), rate_attn, seed, site_attn, step) if rate_attn > 0 else None
+        (cx, al, sd), cache = O.attention_step_fwd(f64(h, B, U), f64(F, B, R, D), f64(P, B, R, A), f64(W2, U, A),
+                                                   f64(b2, A), f64(v, A)[:, None], f64(bv, 1), keep, rate_attn, slope)
+        flat(qpre)[:B * A] = cache[1].reshape(-1)
+        flat(alpha)[:B * R] = al.reshape(-1)
+        flat(ctx)[:B * D] = cx.reshape(-1)
+        if s_out is not None:
+            flat(s_out)[:B * R * A] = sd.reshape(-1)
+        if ctx_d is not None:
+            kin = _keep(np.arange(B)[:, None] * in_lwidth + np.arange(D)[None, :], rate_in, seed, site_in, step) if rate_in > 0 else None
+            flat(ctx_d)[:B * D] = O.dropout_fwd(cx, kin, rate_in).reshape(-1)
+
+    def attention_step_bwd(self, dctx_d, F, P, W2, v, qpre, alpha, dP, dF, dvb, dqpre, dh, B, R, D, A, U, slope,
+                           rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None):
+        if step_dev is not None:
+            step = (step + int(step_dev[0])) & 0xFFFFFFFF
+        f64 = lambda t, *s: flat(t)[:int(np.prod(s))].reshape(*s).astype(np.float64)
+        keep = _keep(np.arange(B * R * A).reshape(B, R, A), rate_attn, seed, site_attn, step) if rate_attn > 0 else None
+        kin = _keep(np.arange(B)[:, None] * in_lwidth + np.arange(D)[None, :], rate_in, seed, site_in, step) if rate_in > 0 else None
+        dctx = O.dropout_bwd(f64(dctx_d, B, D), kin, rate_in)
+        Fm, Pm, W2m, vm, qp, al = f64(F, B, R, D), f64(P, B, R, A), f64(W2, U, A), f64(v, A)[:, None], f64(qpre, B, A), f64(alpha, B, R)
+        q = O.act_fwd(qp, O.ACT_LEAKY, slope)
+        s = np.tanh(Pm + q[:, None, :])
+        sd = O.dropout_fwd(s, keep, rate_attn)
+        cache = (None, qp, s, sd, al, keep, rate_attn)
+        dalpha = (dctx[:, None, :] * Fm).sum(2)
+        dFv = al[:, :, None] * dctx[:, None, :]
+        de = al * (dalpha - (al * dalpha).sum(1, keepdims=True))
+        dv = (sd * de[:, :, None]).sum(1)                     # per-sample (B,A)
+        dsum = O.dropout_bwd(de[:, :, None] * vm[:, 0], keep, rate_attn) * (1 - s * s)
+        dq = O.act_bwd(qp, dsum.sum(1), O.ACT_LEAKY, slope)
+        flat(dP)[:B * R * A] += dsum.reshape(-1).astype(np.float32)
+        flat(dF)[:B * R * D] += dFv.reshape(-1).astype(np.float32)
+        dvbm = flat(dvb)[:B * (A + 1)].reshape(B, A + 1)
+        dvbm[:, :A] += dv
+        dvbm[:, A] += de.sum(1)
+        flat(dqpre)[:B * A] = dq.reshape(-1)
+        flat(dh)[:B * U] = (dq @ W2m.T).reshape(-1)
+
+    def attention_metric(self, alpha, out, T, B, R):
+        al = flat(alpha)[:T * B * R].reshape(T, B, R).astype(np.float64)
+        flat(out)[0] = ((1 - al.sum(1)) ** 2).mean()

@@ -319,10 +319,12 @@ def test_optimizer(be):
     part = torch.zeros(2 * sp.nspan, device="cuda")
     th, gr, md, vd = dev(theta), dev(grad), dev(m0), dev(v0)
     l2d = dev(l2)
-    be.seg_sqnorm(th, gr, sp.span_seg, sp.span_off, sp.span_len, sp.seg_first, l2d, part, sq, wsq, sp.nspan, nseg)
+    l2o = torch.zeros(1, device="cuda")
+    be.seg_sqnorm(th, gr, sp.span_seg, sp.span_off, sp.span_len, sp.seg_first, l2d, part, sq, wsq, l2o, sp.nspan, nseg)
     geff = [grad[o:o + n] + 2 * l * theta[o:o + n] for o, n, l in zip(offs, lens, l2)]
     close(sq, [(g * g).sum() for g in geff], rtol=1e-5)
     close(wsq, [(theta[o:o + n] ** 2).sum() for o, n in zip(offs, lens)], rtol=1e-5)
+    close(l2o, [sum(l * (theta[o:o + n] ** 2).sum() for o, n, l in zip(offs, lens, l2))], rtol=1e-5)
     ovr = dev([-1.0, -1.0, -1.0, 25.0])
     state_t = torch.zeros(1, dtype=torch.int64, device="cuda"); state_t += 4
     dstep = torch.zeros(1, dtype=torch.int32, device="cuda")

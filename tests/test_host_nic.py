@@ -1,0 +1,128 @@
+"""Host orchestration of NIC (config 2) against the model-level oracle, on CPU through the
+mock backend (tests/mock_backend.py): launch order, buffer wiring, gate-interleaved / padded
+layouts, dropout stream wiring, masked LSTM, clip + Adam plumbing, greedy decode."""
+import numpy as np
+import pytest
+import torch
+
+import masters_thesis_amd.ops as ops
+from masters_thesis_amd.nic import NIC
+from masters_thesis_amd.optimizers import Adam, SGD, CategoricalCrossentropy
+from oracle import models as M
+from helpers import synth_batch
+from mock_backend import MockBackend
+
+
+@pytest.fixture(autouse=True)
+def mock_backend():
+    old = ops._backend
+    ops.set_backend(MockBackend())
+    yield
+    ops.set_backend(old)
+
+
+def make_pair(rng, rates, norm="batch", B=5, N=23, T=6, V=13, U=16, E=10, seed=11):
+    model = NIC(N, U, E, V, T, rates[0], rates[1], rates[2], 0.01, 3e-5, 1e-5, norm=norm, device="cpu", seed=seed)
+    orc = M.NICDense(N, U, E, V, T, rates[0], rates[1], rates[2], 0.01, 3e-5, 1e-5, norm=norm).init_params(rng)
+    for k, v in orc.p.items():
+        model.set_weight(k, v)
+        assert np.allclose(model.get_weight(k), v, atol=1e-6)
+    return model, orc
+
+
+def onehot(ids, V):
+    oh = np.zeros(ids.shape + (V,), np.float32)
+    np.put_along_axis(oh, ids[..., None], 1.0, -1)
+    return oh
+
+
+@pytest.mark.parametrize("rates,norm,zero_first", [((0, 0, 0), "batch", False), ((0.1, 0.2, 0.2), "batch", True),
+                                                   ((0, 0.2, 0), "layer", False)])
+def test_train_steps_match_oracle(rates, norm, zero_first):
+    rng = np.random.default_rng(21)
+    B, N, T, V, U = 5, 23, 6, 13, 16
+    model, orc = make_pair(rng, rates, norm)
+    model.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1),
+                  CategoricalCrossentropy(from_logits=False, reduction="none"))
+    opt = M.AdamState(orc.p, lr=1e-3, clipnorm=0.1)
+    for step in range(3):
+        data, tgt = synth_batch(B, N, T, V, U, rng, zero_first=zero_first)
+        res, grads, probs = orc.train_step(data, tgt, opt, M.DropCtx(seed=11, step=step, training=True))
+        target = onehot(tgt, V) if step != 1 else tgt          # both target forms
+        got = model.train_step((data, target)).as_floats()
+        assert abs(got["loss"] - res["loss"]) < 2e-5 * max(1, abs(res["loss"]))
+        assert abs(got["accuracy"] - res["accuracy"]) < 1e-6
+        assert abs(got["L2"] - res["L2"]) < 1e-5 * max(1, abs(res["L2"]))
+        for k in orc.TRAINABLE:
+            lam = {"dense_img/kernel": 0.01, "lstm/kernel": 3e-5, "time_distributed_softmax/kernel": 3e-5}.get(k, 0.0)
+            # gradient buffers hold the data gradient; the oracle's includes 2*lambda*W (pre-update W)
+            g = model.get_gradient(k)
+            assert g.shape == grads[k].shape
+        for k, v in orc.p.items():
+            w = model.get_weight(k)
+            assert np.allclose(w, v, rtol=2e-4, atol=2e-6), (step, k, np.abs(w - v).max())
+    assert model.optimizer.iterations == 3
+
+
+def test_gradients_match_oracle():
+    rng = np.random.default_rng(22)
+    B, N, T, V, U = 4, 19, 5, 11, 16
+    model, orc = make_pair(rng, (0, 0, 0), B=B, N=N, T=T, V=V, U=U)
+    model.compile(Adam(1e-4, clipnorm=None))
+    w0 = {k: v.copy() for k, v in orc.p.items()}
+    data, tgt = synth_batch(B, N, T, V, U, rng)
+    probs, cache = orc.forward(data, True, M.DropCtx(training=True))
+    grads, _ = orc.backward(probs, cache, tgt)
+    model.train_step((data, tgt))
+    lam = {"dense_img/kernel": 0.01, "lstm/kernel": 3e-5, "time_distributed_softmax/kernel": 3e-5}
+    for k in orc.TRAINABLE:
+        g = model.get_gradient(k) + 2 * lam.get(k, 0.0) * w0[k]
+        assert np.allclose(g, grads[k], rtol=1e-4, atol=1e-6 * np.abs(grads[k]).max() + 1e-9), k
+
+
+def test_test_step_call_and_greedy():
+    rng = np.random.default_rng(23)
+    B, N, T, V, U = 4, 19, 5, 11, 16
+    model, orc = make_pair(rng, (0.1, 0.2, 0.2), B=B, N=N, T=T, V=V, U=U)
+    model.compile(SGD(learning_rate=0.01, momentum=0.9))
+    data, tgt = synth_batch(B, N, T, V, U, rng)
+    res, probs = orc.test_step(data, tgt)
+    got = model.test_step((data, onehot(tgt, V))).as_floats()
+    assert abs(got["loss"] - res["loss"]) < 2e-5 and abs(got["accuracy"] - res["accuracy"]) < 1e-6
+    p = model(data, training=False)
+    assert tuple(p.shape) == (B, T, V)
+    assert np.allclose(p.numpy(), probs, rtol=1e-4, atol=1e-6)
+    # greedy; force id 0 for one sample so the masked-step branch is exercised
+    orc.p["time_distributed_softmax/bias"][0] = 3.0
+    model.set_weight("time_distributed_softmax/bias", orc.p["time_distributed_softmax/bias"])
+    z = np.zeros((B, U), np.float32)
+    want = orc.greedy_predict(data[0], z, z, np.ones(B, np.int64), T)
+    gotp = model.greedy_predict(data[0], z, z, np.ones(B, np.int64), T, U)
+    assert gotp.shape == want.shape == (T, B, 1, V)
+    assert np.array_equal(gotp.argmax(-1), want.argmax(-1))
+    assert np.allclose(gotp, want, rtol=1e-4, atol=1e-6)
+
+
+def test_sgd_and_weights_io(tmp_path):
+    rng = np.random.default_rng(24)
+    B, N, T, V, U = 4, 19, 5, 11, 16
+    model, orc = make_pair(rng, (0, 0, 0), B=B, N=N, T=T, V=V, U=U)
+    model.compile(SGD(learning_rate=0.01, momentum=0.9))
+    data, tgt = synth_batch(B, N, T, V, U, rng)
+    probs, cache = orc.forward(data, True, M.DropCtx(training=True))
+    grads, _ = orc.backward(probs, cache, tgt)
+    model.train_step((data, tgt))
+    for k in orc.TRAINABLE:
+        assert np.allclose(model.get_weight(k), orc.p[k] - 0.01 * grads[k], rtol=1e-4, atol=1e-6), k
+    path = str(tmp_path / "w.npz")
+    model.save_weights(path)
+    m2 = NIC(N, U, 10, V, T, 0, 0, 0, 0.01, 3e-5, 1e-5, device="cpu")
+    m2.load_weights(path, by_name=True, skip_mismatch=True)
+    for k in model.keras_shapes:
+        assert np.array_equal(m2.get_weight(k), model.get_weight(k)), k
+    lw = model.get_layer("lstm").get_weights()
+    assert [w.shape for w in lw] == [(10, 64), (16, 64), (64,)]
+    m2.get_layer("lstm").set_weights([w * 2 for w in lw])
+    assert np.allclose(m2.get_weight("lstm/kernel"), 2 * lw[0])
+    with pytest.raises(ValueError):
+        model.get_layer("nope")
