@@ -100,7 +100,8 @@ int32_t tnt_colsum_f32(const float* x, float* out, int32_t rows, int32_t C, int3
 
 /* ---- Embedding (lc_NIC.py:105-112,233; NIC.py:75-79,131) ------------------------
  * fwd: out[(t*B+b)][:] = table[ids[b*T+t]][:]   (ids is the keras (B,T) int32 array)
- * bwd: dtable[ids[b*T+t]][:] += drows[(t*B+b)][:]  (dtable zeroed by the caller);
+ * bwd: dtable[v][:] = sum over (b,t) with ids[b*T+t]==v of drows[(t*B+b)][:] (every row
+ *      of dtable is written: unreferenced rows are zeroed by the call itself);
  *      sq_norm[0] += sum of squares of the un-merged rows (IndexedSlices clipnorm
  *      quirk); sq_norm zeroed by the caller; rowsq_work: B*T floats.
  *      Deterministic (no atomics): one wave per vocabulary row sums its matches in

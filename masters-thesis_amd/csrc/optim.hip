@@ -50,12 +50,15 @@ __global__ __launch_bounds__(256) void span_sqnorm_kernel(const float* theta, co
   }
 }
 
-__global__ void seg_finalize_kernel(const float* partial, SpanTab t, float* sq, float* wsq, int nseg) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
+// one wave per segment: lanes stride over the segment's spans, then a fixed shuffle tree
+__global__ __launch_bounds__(64) void seg_finalize_kernel(const float* partial, SpanTab t, float* sq, float* wsq,
+                                                          int nseg) {
+  const int s = blockIdx.x;
   if (s >= nseg) return;
   float a = 0.f, b = 0.f;
-  for (int k = t.seg_first[s]; k < t.seg_first[s + 1]; ++k) { a += partial[2 * k]; b += partial[2 * k + 1]; }
-  sq[s] = a; wsq[s] = b;
+  for (int k = t.seg_first[s] + threadIdx.x; k < t.seg_first[s + 1]; k += 64) { a += partial[2 * k]; b += partial[2 * k + 1]; }
+  a = tnt_wave_sum(a); b = tnt_wave_sum(b);
+  if (threadIdx.x == 0) { sq[s] = a; wsq[s] = b; }
 }
 
 // L2 metric: sum_s lambda_s * ||theta_s||^2  (tf.add_n(self.losses), lc_NIC.py:379), fixed order
@@ -172,7 +175,7 @@ extern "C" int32_t tnt_seg_sqnorm_f32(const float* theta, const float* grad, con
   hipStream_t s = tnt_stream(stream);
   hipLaunchKernelGGL(span_sqnorm_kernel, dim3(nspan), dim3(256), 0, s, theta, grad, t, partial, nspan);
   TNT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(seg_finalize_kernel, dim3((nseg + 255) / 256), dim3(256), 0, s, partial, t, sq, wsq, nseg);
+  hipLaunchKernelGGL(seg_finalize_kernel, dim3(nseg), dim3(64), 0, s, partial, t, sq, wsq, nseg);
   TNT_LAUNCH_CHECK();
   if (l2_out) {
     hipLaunchKernelGGL(l2_total_kernel, dim3(1), dim3(256), 0, s, wsq, seg_l2, nseg, l2_out);

@@ -28,6 +28,29 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* x, float* y, 
   }
 }
 
+// 4 consecutive columns per thread: one Philox call yields the 4 decisions (cols, ld, lwidth, lcol0 % 4 == 0)
+__global__ __launch_bounds__(256) void dropout4_kernel(const float* x, float* y, int rows, int cols, int ld, int tB,
+                                                       int lwidth, int lcol0, float rate, float scale, uint64_t seed,
+                                                       uint32_t site, uint32_t step, const uint32_t* step_dev) {
+  if (step_dev) step += step_dev[0];
+  const int c4n = cols >> 2;
+  const long total = (long)rows * c4n;
+  const int T = tB > 0 ? rows / tB : 0;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int r = (int)(e / c4n), c = (int)(e % c4n) * 4;
+    const long lrow = tB > 0 ? (long)(r % tB) * T + r / tB : r;
+    const uint64_t le = (uint64_t)lrow * (uint64_t)lwidth + (uint64_t)(lcol0 + c);
+    bool k[4];
+    tnt_keep4(le, rate, seed, site, step, k);
+    const long o = (long)r * ld + c;
+    const float4 v = *reinterpret_cast<const float4*>(x + o);
+    float4 w;
+    w.x = k[0] ? v.x * scale : 0.f; w.y = k[1] ? v.y * scale : 0.f;
+    w.z = k[2] ? v.z * scale : 0.f; w.w = k[3] ? v.w * scale : 0.f;
+    *reinterpret_cast<float4*>(y + o) = w;
+  }
+}
+
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* pre, const float* dy, float* dx, long n, int act,
                                                       float slope) {
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256)
@@ -234,8 +257,13 @@ extern "C" int32_t tnt_dropout_f32(const float* x, float* y, int32_t rows, int32
   if (rows <= 0 || cols <= 0) return 0;
   if (tmajor_B > 0 && rows % tmajor_B != 0) return TNT_BADARG(6);
   const float scale = 1.0f / (1.0f - rate);
-  hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks((long)rows * cols)), dim3(256), 0, tnt_stream(stream), x, y, rows,
-                     cols, ld, tmajor_B, lwidth, lcol0, rate, scale, seed, site, step, step_dev);
+  const bool vec = ((cols | ld | lwidth | lcol0) & 3) == 0 && tnt_aligned16(x) && tnt_aligned16(y);
+  if (vec)
+    hipLaunchKernelGGL(dropout4_kernel, dim3(ew_blocks((long)rows * (cols / 4))), dim3(256), 0, tnt_stream(stream), x, y,
+                       rows, cols, ld, tmajor_B, lwidth, lcol0, rate, scale, seed, site, step, step_dev);
+  else
+    hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks((long)rows * cols)), dim3(256), 0, tnt_stream(stream), x, y, rows,
+                       cols, ld, tmajor_B, lwidth, lcol0, rate, scale, seed, site, step, step_dev);
   TNT_LAUNCH_CHECK();
   return 0;
 }

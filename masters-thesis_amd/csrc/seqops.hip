@@ -29,25 +29,48 @@ __global__ __launch_bounds__(256) void rowsq_kernel(const float* x, float* rowsq
   if (lane == 0) rowsq[row] = s;
 }
 
-// one wave per vocabulary row: sums, in (b,t) order, every contribution row whose id matches.
-// No atomics: bitwise reproducible, and every dtable row is written (no pre-zeroing needed).
+// Deterministic scatter-add without atomics.  One wave per contribution row k (k = b*T + t):
+// the wave whose row is the FIRST occurrence of its id owns that vocabulary row; it sums its own
+// row and every later duplicate in ascending k order and writes the row once.  Rows of dtable
+// that no token references are zeroed by zero_fill_kernel launched before this kernel (a captured
+// hipMemsetAsync node did not replay reliably inside torch's hipGraph on ROCm 7.0/7.2).
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* p, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0.f;
+}
+
 __global__ __launch_bounds__(256) void emb_bwd_kernel(const float* drows, const int* ids, float* dtable, int B, int T,
                                                       int E, int ldd, int V) {
-  const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (v >= V) return;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int n = B * T;
+  if (k >= n) return;
+  int id = ids[k];
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+  for (int base = 0; base < k; base += 64) {           // an earlier occurrence owns the row
+    const int i = base + lane;
+    int other = i < k ? ids[i] : -1;
+    other = other >= V ? V - 1 : other;
+    if (__ballot(i < k && other == id)) return;
+  }
   for (int j0 = 0; j0 < E; j0 += 256) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int base = 0; base < n; base += 64) {
+    float acc[4];
+    {
+      const float* r = drows + (long)((k % T) * B + k / T) * ldd;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q * 64 + lane;
+        acc[q] = j < E ? r[j] : 0.f;
+      }
+    }
+    for (int base = k + 1; base < n; base += 64) {
       const int i = base + lane;
-      const int id = i < n ? ids[i] : -1;
-      unsigned long long hit = __ballot(id == v);
+      int other = i < n ? ids[i] : -1;
+      other = other >= V ? V - 1 : other;
+      unsigned long long hit = __ballot(i < n && other == id);
       while (hit) {
         const int src = __ffsll((long long)hit) - 1;
         hit &= hit - 1;
-        const int k = base + src;            // k = b*T + t
-        const int b = k / T, t = k % T;
-        const float* r = drows + (long)(t * B + b) * ldd;
+        const int kk = base + src;
+        const float* r = drows + (long)((kk % T) * B + kk / T) * ldd;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int j = j0 + q * 64 + lane;
@@ -58,7 +81,7 @@ __global__ __launch_bounds__(256) void emb_bwd_kernel(const float* drows, const 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int j = j0 + q * 64 + lane;
-      if (j < E) dtable[(long)v * E + j] = acc[q];
+      if (j < E) dtable[(long)id * E + j] = acc[q];
     }
   }
 }
@@ -192,7 +215,13 @@ extern "C" int32_t tnt_embedding_bwd_f32(const float* drows, const int32_t* ids,
     hipLaunchKernelGGL(sum_accum_kernel, dim3(1), dim3(1024), 0, s, rowsq_work, sq_norm, B * T);
     TNT_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(emb_bwd_kernel, dim3((V + 3) / 4), dim3(256), 0, s, drows, ids, dtable, B, T, E, ldd, V);
+  {
+    const long nz = (long)V * E;
+    long zb = (nz + 255) / 256;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)(zb > 2048 ? 2048 : zb)), dim3(256), 0, s, dtable, nz);
+    TNT_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(emb_bwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, s, drows, ids, dtable, B, T, E, ldd, V);
   TNT_LAUNCH_CHECK();
   return 0;
 }

@@ -238,6 +238,7 @@ class NIC(ModelBase):
         nch = max(self.be.bn_nchunk(B * R), self.be.bn_nchunk(n))
         self.work = f(max(D, A, 4 * U, ldV, H) * (2 * nch + 1))
         self.rowsq = f(n)
+        self._alloc_splitk([(n, H, V), (n, Et, 4 * U), (n, U, H)])
         self.emb_seg = self.arena.entries["emb_text/embeddings"].seg
         self._shape = (B, T)
         self._graphs = {}
@@ -351,7 +352,7 @@ class NIC(ModelBase):
         dlog, inter, hs = self.logits, self._inter_used, self._hs_used
         be.gemm(inter, dlog, a.g("time_distributed_softmax/kernel"), H, V, n, H, ldV, ldV, transA=True)
         be.colsum(dlog, a.g("time_distributed_softmax/bias"), n, V, ldV, self.work)
-        be.gemm(dlog, a.p("time_distributed_softmax/kernel"), self.dinter, n, H, V, ldV, ldV, H, transB=True)
+        self.gemm_sk(dlog, a.p("time_distributed_softmax/kernel"), self.dinter, n, H, V, ldV, ldV, H, transB=True)
         if self.r_out > 0:
             be.dropout(self.dinter, self.dinter, n, H, H, B, H, 0, self.r_out, sd, S_OUT, 0, ds)
         be.act_bwd(self.ipre, self.dinter, self.dinter, n * H, ACT_LEAKY, 0.2)
@@ -380,7 +381,7 @@ class NIC(ModelBase):
         be.gemm(self.text, self.dZ, gWl[D:], Et, 4 * U, n, Et, 4 * U, 4 * U, transA=True)
         be.gemm(self.ctx_d, self.dZ, gWl[:D], D, 4 * U, n, D, 4 * U, 4 * U, transA=True)
         be.colsum(self.dZ, a.g("lstm/bias"), n, 4 * U, 4 * U, self.work)
-        be.gemm(self.dZ, Wl[D:], self.dtext, n, Et, 4 * U, 4 * U, 4 * U, Et, transB=True)
+        self.gemm_sk(self.dZ, Wl[D:], self.dtext, n, Et, 4 * U, 4 * U, 4 * U, Et, transB=True)
         if self.r_lstm > 0:
             for i in range(T):
                 be.dropout(self.dtext[i * B:], self.dtext[i * B:], B, Et, Et, 0, D + Et, D, self.r_lstm, sd,

@@ -118,6 +118,28 @@ class ModelBase:
             be.sgd(a.theta, self.opt_m, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq, a.sq_override,
                    sp.nspan, 0.0, self.lr_dev, opt.momentum, clip)
 
+    @staticmethod
+    def pick_splitk(M, N, K):
+        """Split-K factor for GEMMs whose output has too few 64x64 tiles to fill 256 CUs."""
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        if tiles >= 384 or K < 1024:
+            return 1
+        return int(max(1, min(64, -(-512 // tiles), K // 256)))
+
+    def _alloc_splitk(self, shapes):
+        """Workspace for the split-K GEMMs of this model: shapes = [(M, N, K), ...]."""
+        need = max([self.pick_splitk(*s) * s[0] * s[1] for s in shapes] + [1])
+        self.skwork = self._f(need)
+
+    def gemm_sk(self, A, B, C, M, N, K, lda, ldb, ldc, **kw):
+        """GEMM with an automatic split-K choice (uses self.skwork)."""
+        sk = self.pick_splitk(M, N, K)
+        if sk > 1:
+            assert sk * M * N <= self.skwork.numel(), "split-K workspace too small"
+            self.be.gemm(A, B, C, M, N, K, lda, ldb, ldc, splitk=sk, work=self.skwork, **kw)
+        else:
+            self.be.gemm(A, B, C, M, N, K, lda, ldb, ldc, **kw)
+
     def _norms_and_l2(self, l2_out):
         a, sp = self.arena, self.arena.spans
         self.be.seg_sqnorm(a.theta, a.grad, sp.span_seg, sp.span_off, sp.span_len, sp.seg_first, a.seg_l2, a.partial,

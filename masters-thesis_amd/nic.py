@@ -167,8 +167,7 @@ class NIC(ModelBase):
         self.dXin = f(R1, E)
         self.dyd, self.dpre = f(B, E), f(B, E)
         be = self.be
-        self.enc_splitk = int(max(1, min(64, N // 256, 512 // (((B + 63) // 64) * ((E + 63) // 64)))))
-        self.skwork = f(self.enc_splitk * B * E)
+        self._alloc_splitk([(B, E, N), (T * B, U, V), (R1, E, 4 * U), (R1, 4 * U, E), (T * B, V, U)])
         nch = max(be.bn_nchunk(B), be.bn_nchunk(R1), be.bn_nchunk(T * B))
         self.work = f(max(E, 4 * U, ldV) * (2 * nch + 1))
         self.rowsq = f(B * T)
@@ -202,8 +201,8 @@ class NIC(ModelBase):
         if training and self.r_in > 0:                                              # NIC.py:122
             be.dropout(self.x, self.xd, B, N, self.ldx, 0, N, 0, self.r_in, sd, S_IN, 0, ds)
             x = self.xd
-        be.gemm(x, a.p("dense_img/kernel"), self.enc_y, B, E, N, self.ldx, E, E, bias=a.p("dense_img/bias"),
-                pre=self.enc_pre, act=ACT_LEAKY, slope=0.2, splitk=self.enc_splitk, work=self.skwork)   # :125
+        self.gemm_sk(x, a.p("dense_img/kernel"), self.enc_y, B, E, N, self.ldx, E, E, bias=a.p("dense_img/bias"),
+                     pre=self.enc_pre, act=ACT_LEAKY, slope=0.2)                          # :125
         y = self.enc_y
         if training and self.r_feat > 0:                                            # :126
             be.dropout(self.enc_y, self.enc_yd, B, E, E, 0, E, 0, self.r_feat, sd, S_FEAT, 0, ds)
@@ -258,7 +257,7 @@ class NIC(ModelBase):
         Wo = a.p("time_distributed_softmax/kernel")
         be.gemm(self.Out, dlog, a.g("time_distributed_softmax/kernel"), U, V, T * B, U, ldV, ldV, transA=True)
         be.colsum(dlog, a.g("time_distributed_softmax/bias"), T * B, V, ldV, self.work)
-        be.gemm(dlog, Wo, self.dOut, T * B, U, V, ldV, ldV, U, transB=True)
+        self.gemm_sk(dlog, Wo, self.dOut, T * B, U, V, ldV, ldV, U, transB=True)
         Ur = a.p("lstm/recurrent_kernel")
         dOut = self.dOut.view(T, B, U)
         for t in range(T, 0, -1):
@@ -274,7 +273,7 @@ class NIC(ModelBase):
         be.gemm(self.Hs, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, R1, U, 4 * U, 4 * U, transA=True)
         be.gemm(xin, self.dZ, a.g("lstm/kernel"), E, 4 * U, R1, E, 4 * U, 4 * U, transA=True)
         be.colsum(self.dZ, a.g("lstm/bias"), R1, 4 * U, 4 * U, self.work)
-        be.gemm(self.dZ, a.p("lstm/kernel"), self.dXin, R1, E, 4 * U, 4 * U, 4 * U, E, transB=True)
+        self.gemm_sk(self.dZ, a.p("lstm/kernel"), self.dXin, R1, E, 4 * U, 4 * U, 4 * U, E, transB=True)
         if self.r_lstm > 0:
             be.dropout(self.dXin, self.dXin, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
             be.dropout(self.dXin[B:], self.dXin[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
@@ -352,8 +351,8 @@ class NIC(ModelBase):
         cap = torch.zeros(B, 1, dtype=torch.int32, device=self.device)
         self._stage_inputs((img_input, cap, a0, c0))
         N, U, E, V, ldV = self.N, self.U, self.E, self.V, self.ldV
-        be.gemm(self.x, a.p("dense_img/kernel"), self.enc_y, B, E, N, self.ldx, E, E, bias=a.p("dense_img/bias"),
-                pre=self.enc_pre, act=ACT_LEAKY, slope=0.2, splitk=self.enc_splitk, work=self.skwork)
+        self.gemm_sk(self.x, a.p("dense_img/kernel"), self.enc_y, B, E, N, self.ldx, E, E, bias=a.p("dense_img/bias"),
+                     pre=self.enc_pre, act=ACT_LEAKY, slope=0.2)
         if self.norm == "batch":
             be.batchnorm_fwd(self.enc_y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.mov_mean, self.mov_var,
                              self.Xin, self.xhat, self.inv_std, B, E, E, False, BN_EPS, BN_MOMENTUM, self.work)

@@ -1,0 +1,106 @@
+"""Model-level parity on the GPU: lc_NIC (BASELINE config 3: region-wise encoder + additive
+attention + LSTM) through the real HIP kernels against the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as M
+from helpers import synth_batch, tiny_groups
+
+pytestmark = pytest.mark.gpu
+
+# (B, N, R, D, A, U, Et, V, T)
+DIMS = [(3, 37, 4, 16, 3, 16, 6, 11, 4), (8, 2000, 36, 32, 32, 64, 64, 501, 15)]
+
+
+def build(rng, rates, dims, norm="batch", use_graph=True):
+    from masters_thesis_amd.lc_nic import NIC
+    B, N, R, D, A, U, Et, V, T = dims
+    g = (tiny_groups(N, R, rng), [D] * R)
+    model = NIC(g, U, 512, Et, A, V, T, *rates, 0.01, 0.001, 3e-5, 1e-5, norm=norm, seed=11, use_graph=use_graph)
+    orc = M.LcNIC(g, U, 512, Et, A, V, T, *rates, 0.01, 0.001, 3e-5, 1e-5, norm=norm).init_params(rng)
+    for k, v in orc.p.items():
+        model.set_weight(k, v)
+    return model, orc
+
+
+@pytest.mark.parametrize("dims", DIMS)
+@pytest.mark.parametrize("rates,norm", [((0,) * 6, "batch"), ((0.1, 0.2, 0.2, 0.2, 0.2, 0.2), "batch"),
+                                        ((0,) * 6, "layer")])
+def test_train_parity(dims, rates, norm):
+    from masters_thesis_amd.optimizers import Adam
+    rng = np.random.default_rng(51)
+    B, N, R, D, A, U, Et, V, T = dims
+    model, orc = build(rng, rates, dims, norm)
+    model.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    opt = M.AdamState(orc.p, lr=1e-3, clipnorm=0.1)
+    for step in range(4):                      # eager, capture, replay, replay
+        data, tgt = synth_batch(B, N, T, V, U, rng)
+        res, grads, _ = orc.train_step(data, tgt, opt, M.DropCtx(seed=11, step=step, training=True))
+        got = model.train_step((data, tgt)).as_floats()
+        for k in ("loss", "L2", "attention"):
+            assert abs(got[k] - res[k]) <= 1e-4 * abs(res[k]) + 1e-7, (step, k, got[k], res[k])
+        assert abs(got["accuracy"] - res["accuracy"]) < 1e-6
+        for k, v in orc.p.items():
+            if k == "attention/V/bias":        # zero-gradient variable: Adam amplifies rounding noise
+                continue
+            w = model.get_weight(k)
+            assert np.abs(w - v).max() <= 2e-2 * 1e-3 + 1e-4 * np.abs(v).max(), (step, k, np.abs(w - v).max())
+
+
+@pytest.mark.parametrize("dims", DIMS)
+def test_forward_gradients_greedy(dims):
+    from masters_thesis_amd.optimizers import Adam
+    rng = np.random.default_rng(52)
+    B, N, R, D, A, U, Et, V, T = dims
+    model, orc = build(rng, (0,) * 6, dims, use_graph=False)
+    model.compile(Adam(1e-4, clipnorm=None))
+    data, tgt = synth_batch(B, N, T, V, U, rng)
+    (probs, attn), cache = orc.forward(data, False)
+    p, al = model(data, training=False)
+    p, al = p.cpu().numpy(), al.cpu().numpy()
+    assert np.abs(np.log(p) - np.log(probs)).max() <= 1e-4 * np.abs(cache["logits"]).max()
+    assert np.abs(al - attn).max() <= 1e-4 * attn.max()
+    w0 = {k: v.copy() for k, v in orc.p.items()}
+    (probs, attn), cache = orc.forward(data, True, M.DropCtx(training=True))
+    grads, _ = orc.backward(probs, cache, tgt)
+    model.train_step((data, tgt))
+    lam = {"attention/W1/kernel": 0.001, "attention/W2/kernel": 0.001, "lstm/kernel": 3e-5,
+           "time_distributed_nonlinear/kernel": 1e-5, "time_distributed_softmax/kernel": 1e-5}
+    for k in orc.trainable():
+        if k == "attention/V/bias":
+            assert np.abs(model.get_gradient(k)).max() < 1e-5
+            continue
+        l = 0.01 if k.startswith("dense_in") and k.endswith("kernel") else lam.get(k, 0.0)
+        g = model.get_gradient(k) + 2 * l * w0[k]
+        assert np.abs(g - grads[k]).max() <= 2e-4 * np.abs(grads[k]).max() + 1e-9, (k, np.abs(g - grads[k]).max())
+    for k, v in w0.items():
+        model.set_weight(k, v)
+    orc.p = w0
+    z = np.zeros((B, U), np.float32)
+    ww, wp, wa, ws = orc.greedy_predict(data[0], z, z, np.ones(B, np.int64), T)
+    gw, gp, ga, gs = model.greedy_predict(data[0], z, z, np.ones(B, np.int64), T, U, None)
+    assert np.array_equal(gw, ww)                                  # identical greedy captions
+    assert np.abs(gp - wp).max() <= 1e-4 and np.abs(ga - wa).max() <= 1e-4 * wa.max()
+    assert np.abs(gs - ws).max() <= 1e-4
+
+
+def test_full_size_properties():
+    """BASELINE config-3 size (B=64, N=20000 in R=360 ragged regions -> 32, A=32, U=512, V=5001, T=15)."""
+    from masters_thesis_amd.lc_nic import NIC, synthetic_groups
+    from masters_thesis_amd.optimizers import Adam
+    rng = np.random.default_rng(53)
+    B, N, T, V, U = 64, 20000, 15, 5001, 512
+    groups = synthetic_groups(N, 360, 32, seed=42, overlap=0.05)
+    data, tgt = synth_batch(B, N, T, V, U, rng, min_len=7)
+    losses = {}
+    for use_graph in (False, True):
+        model = NIC(groups, U, 512, 512, 32, V, T, 0, 0, 0, 0, 0, 0, 0.01, 0.001, 3e-5, 1e-5, seed=5, use_graph=use_graph)
+        model.compile(Adam(1e-3, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+        p, al = model(data, training=False)
+        assert torch.allclose(p.sum(-1), torch.ones_like(p.sum(-1)), atol=1e-5)
+        assert torch.allclose(al.sum(2), torch.ones_like(al.sum(2)), atol=1e-5)      # softmax over regions
+        ls = [model.train_step((data, tgt)).as_floats()["loss"] for _ in range(6)]
+        assert abs(ls[0] - np.log(V)) < 0.5 and ls[-1] < ls[0]
+        losses[use_graph] = ls
+    assert np.allclose(losses[False], losses[True], rtol=1e-6)

@@ -1,0 +1,102 @@
+"""Host orchestration of lc_NIC (config 3, attention) against the model-level oracle, on CPU
+through the mock backend."""
+import numpy as np
+import pytest
+
+import masters_thesis_amd.ops as ops
+from masters_thesis_amd.lc_nic import NIC, synthetic_groups
+from masters_thesis_amd.optimizers import Adam
+from oracle import models as M
+from helpers import synth_batch, tiny_groups
+from mock_backend import MockBackend
+
+
+@pytest.fixture(autouse=True)
+def mock_backend():
+    old = ops._backend
+    ops.set_backend(MockBackend())
+    yield
+    ops.set_backend(old)
+
+
+ARGS = dict(B=4, N=41, R=5, D=16, A=6, U=16, Et=12, V=13, T=5)
+
+
+def make_pair(rng, rates, norm="batch", seed=11, **d):
+    d = {**ARGS, **d}
+    groups = tiny_groups(d["N"], d["R"], rng)
+    g = (groups, [d["D"]] * d["R"])
+    model = NIC(g, d["U"], 512, d["Et"], d["A"], d["V"], d["T"], *rates, 0.01, 0.001, 3e-5, 1e-5, norm=norm,
+                device="cpu", seed=seed)
+    orc = M.LcNIC(g, d["U"], 512, d["Et"], d["A"], d["V"], d["T"], *rates, 0.01, 0.001, 3e-5, 1e-5,
+                  norm=norm).init_params(rng)
+    for k, v in orc.p.items():
+        model.set_weight(k, v)
+        assert np.allclose(model.get_weight(k), v, atol=1e-6)
+    return model, orc, d
+
+
+@pytest.mark.parametrize("rates,norm", [((0,) * 6, "batch"), ((0.1, 0.2, 0.2, 0.2, 0.2, 0.2), "batch"),
+                                        ((0, 0.2, 0, 0.2, 0, 0), "layer")])
+def test_train_steps_match_oracle(rates, norm):
+    rng = np.random.default_rng(41)
+    model, orc, d = make_pair(rng, rates, norm)
+    model.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    opt = M.AdamState(orc.p, lr=1e-3, clipnorm=0.1)
+    for step in range(3):
+        data, tgt = synth_batch(d["B"], d["N"], d["T"], d["V"], d["U"], rng)
+        res, grads, _ = orc.train_step(data, tgt, opt, M.DropCtx(seed=11, step=step, training=True))
+        got = model.train_step((data, tgt)).as_floats()
+        for k in ("loss", "L2", "attention"):
+            assert abs(got[k] - res[k]) < 3e-5 * max(1, abs(res[k])), (step, k, got[k], res[k])
+        assert abs(got["accuracy"] - res["accuracy"]) < 1e-6 and abs(got["lr"] - 1e-3) < 1e-9
+        for k, v in orc.p.items():
+            w = model.get_weight(k)
+            # attention/V/bias: its gradient is identically zero (softmax shift invariance), so what
+            # Adam sees is rounding noise, which it normalises to O(lr) steps -- only bound it
+            atol = 3e-3 * (step + 1) if k == "attention/V/bias" else 3e-6
+            assert np.allclose(w, v, rtol=2e-4, atol=atol), (step, k, np.abs(w - v).max())
+
+
+def test_gradients_call_test_step_greedy():
+    rng = np.random.default_rng(42)
+    model, orc, d = make_pair(rng, (0,) * 6)
+    model.compile(Adam(1e-4, clipnorm=None))
+    w0 = {k: v.copy() for k, v in orc.p.items()}
+    data, tgt = synth_batch(d["B"], d["N"], d["T"], d["V"], d["U"], rng)
+    (probs, attn), cache = orc.forward(data, True, M.DropCtx(training=True))
+    grads, _ = orc.backward(probs, cache, tgt)
+    res, (probs_e, attn_e) = orc.test_step(data, tgt)
+    got = model.test_step((data, tgt)).as_floats()
+    for k in ("loss", "L2", "attention", "accuracy"):
+        assert abs(got[k] - res[k]) < 3e-5 * max(1, abs(res[k])), k
+    p, al = model(data, training=False)
+    assert tuple(p.shape) == (d["B"], d["T"], d["V"]) and tuple(al.shape) == (d["T"], d["B"], d["R"], 1)
+    assert np.allclose(p.numpy(), probs_e, rtol=1e-4, atol=1e-6) and np.allclose(al.numpy(), attn_e, rtol=1e-4, atol=1e-7)
+    model.train_step((data, tgt))
+    lam = {"attention/W1/kernel": 0.001, "attention/W2/kernel": 0.001, "lstm/kernel": 3e-5,
+           "time_distributed_nonlinear/kernel": 1e-5, "time_distributed_softmax/kernel": 1e-5}
+    for k in orc.trainable():
+        l = 0.01 if k.startswith("dense_in") and k.endswith("kernel") else lam.get(k, 0.0)
+        g = model.get_gradient(k) + 2 * l * w0[k]
+        assert np.allclose(g, grads[k], rtol=2e-4, atol=2e-6 * np.abs(grads[k]).max() + 1e-9), k
+    for k, v in w0.items():
+        model.set_weight(k, v)
+    orc.p = w0
+    z = np.zeros((d["B"], d["U"]), np.float32)
+    ww, wp, wa, ws = orc.greedy_predict(data[0], z, z, np.ones(d["B"], np.int64), 7)
+    gw, gp, ga, gs = model.greedy_predict(data[0], z, z, np.ones(d["B"], np.int64), 7, d["U"], None)
+    assert gw.shape == ww.shape == (d["B"], 7, 1) and gw.dtype == np.int64
+    assert np.array_equal(gw, ww)
+    assert np.allclose(gp, wp, rtol=1e-4, atol=1e-6) and np.allclose(ga, wa, rtol=1e-4, atol=1e-7)
+    assert np.allclose(gs, ws, rtol=1e-4, atol=1e-6)
+
+
+def test_synthetic_groups_partition():
+    g, out = synthetic_groups(20000, 360, 32, seed=42)
+    sizes = np.array([len(x) for x in g])
+    assert len(g) == 360 and out == [32] * 360
+    assert sizes.sum() == 20000 and sizes.min() >= 8
+    assert len(np.unique(np.concatenate(g))) == 20000
+    g2, _ = synthetic_groups(2000, 36, 32, seed=1, overlap=0.05)
+    assert sum(len(x) for x in g2) > 2000
