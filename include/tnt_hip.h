@@ -56,12 +56,15 @@ int32_t tnt_gemm_f32(const float* A, const float* B, float* C, const float* bias
  *   lrow = r                      if tmajor_B == 0
  *   lrow = (r % B)*T + r / B      if tmajor_B == B > 0 (buffer time-major, logical (B,T,..)),
  * where T = rows / B.  In-place (y == x) allowed.  Backward = same call on dy.
+ * rows_per_site > 0 (requires tmajor_B == 0): the buffer is a stack of independent
+ * (rows_per_site x cols) tensors, block k using site + k and local rows -- one launch for
+ * the T per-timestep masks of lc_NIC.py:255-256.
  * The stream step is step + *step_dev (step_dev nullable): a device-resident counter
  * lets a captured hipGraph replay with a fresh mask each time (see tnt_step_tick). */
 int32_t tnt_dropout_f32(const float* x, float* y, int32_t rows, int32_t cols, int32_t ld,
-                        int32_t tmajor_B, int32_t lwidth, int32_t lcol0, float rate,
-                        uint64_t seed, uint32_t site, uint32_t step, const uint32_t* step_dev,
-                        void* stream);
+                        int32_t tmajor_B, int32_t lwidth, int32_t lcol0, int32_t rows_per_site,
+                        float rate, uint64_t seed, uint32_t site, uint32_t step,
+                        const uint32_t* step_dev, void* stream);
 
 /* ---- activation backward: dx = dy * act'(pre)  ---------------------------------- */
 int32_t tnt_act_bwd_f32(const float* pre, const float* dy, float* dx, int64_t n, int32_t act,
@@ -215,7 +218,9 @@ int32_t tnt_attention_step_fwd_f32(const float* h, const float* F, const float* 
                                    const uint32_t* step_dev, void* stream);
 /* bwd: given dctx_d (grad wrt the dropped ctx), accumulates dP[B][R][A] += , dF[B][R][D] +=,
  * dvb[B][A+1] += (per-sample partials of dV and dbV), writes dqpre[B][A] and
- * dh[B][U] = dqpre @ W2^T. */
+ * dh[B][U] = dqpre @ W2^T.  If dz != NULL the context gradient is computed in-kernel as
+ * dctx_d[b][d] = sum_n dz[b][n] * Wc[d][n] (dz: this step's LSTM dz [B][4U]; Wc: the context
+ * rows of the LSTM kernel [D][4U]) and the dctx_d argument is ignored. */
 int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* F, const float* P,
                                    const float* W2, const float* v, const float* qpre,
                                    const float* alpha, float* dP, float* dF, float* dvb,
@@ -223,12 +228,13 @@ int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* F, const fl
                                    int32_t A, int32_t U, float slope, float rate_attn,
                                    float rate_in, int32_t in_lwidth, uint64_t seed,
                                    uint32_t site_attn, uint32_t site_in, uint32_t step,
-                                   const uint32_t* step_dev, void* stream);
+                                   const uint32_t* step_dev, const float* dz, const float* Wc,
+                                   void* stream);
 
 /* attention "coverage" metric (lc_NIC.py:365-367): mean over (T,R) of
  * (1 - sum_b alpha[t][b][r])^2.  alpha is [T][B][R]. */
-int32_t tnt_attention_metric_f32(const float* alpha, float* out, int32_t T, int32_t B,
-                                 int32_t R, void* stream);
+int32_t tnt_attention_metric_f32(const float* alpha, float* out, float* work /* T floats */,
+                                 int32_t T, int32_t B, int32_t R, void* stream);
 
 #ifdef __cplusplus
 }

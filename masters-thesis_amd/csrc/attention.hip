@@ -44,7 +44,8 @@ struct AttArgs {
   const float* h; const float* F; const float* P; const float* W2; const float* b2; const float* v; const float* bv;
   float* qpre; float* alpha; float* ctx; float* ctx_d; float* s_out;
   // backward
-  const float* dctx_d; const float* qpre_in; const float* alpha_in; float* dP; float* dF; float* dvb;
+  const float* dctx_d; const float* dz; const float* Wc; const float* qpre_in; const float* alpha_in;
+  float* dP; float* dF; float* dvb;
   float* dqpre; float* dh;
   int B, R, D, A, U, in_lwidth;
   float slope, rate_attn, rate_in;
@@ -57,8 +58,10 @@ __device__ __forceinline__ void compute_q(const AttArgs& g, const float* hs, flo
   const int a = threadIdx.x % AP, kp = threadIdx.x / AP;
   constexpr int KP = 256 / AP;
   float s = 0.f;
-  if (a < g.A)
+  if (a < g.A) {
+#pragma unroll 8
     for (int k = kp; k < g.U; k += KP) s += hs[k] * g.W2[(long)k * g.A + a];
+  }
   part[kp * AP + a] = s;
   __syncthreads();
   if (threadIdx.x < AP && a < g.A) {
@@ -89,18 +92,27 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttArgs g) {
   const float scale_a = 1.f / (1.f - g.rate_attn);
   const float va = a < g.A ? g.v[a] : 0.f;
   const float bv = g.bv[0];
-  for (int r0 = 0; r0 < g.R; r0 += RP) {
-    const int r = r0 + rp;
-    float t = 0.f;
-    if (r < g.R && a < g.A) {
-      const long e = ((long)b * g.R + r) * g.A + a;
-      float s = tanhf(g.P[e] + qs[a]);
-      if (g.rate_attn > 0.f) s = tnt_keep((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step) ? s * scale_a : 0.f;
-      if (g.s_out) g.s_out[e] = s;
-      t = s * va;
+  for (int r0 = 0; r0 < g.R; r0 += RP * 4) {
+    float pv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                       // 4 independent loads in flight
+      const int r = r0 + u * RP + rp;
+      pv[u] = (r < g.R && a < g.A) ? g.P[((long)b * g.R + r) * g.A + a] : 0.f;
     }
-    t = group_sum<AP>(t);
-    if (a == 0 && r < g.R) es[r] = t + bv;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * RP + rp;
+      float t = 0.f;
+      if (r < g.R && a < g.A) {
+        const long e = ((long)b * g.R + r) * g.A + a;
+        float s = tanhf(pv[u] + qs[a]);
+        if (g.rate_attn > 0.f) s = tnt_keep((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step) ? s * scale_a : 0.f;
+        if (g.s_out) g.s_out[e] = s;
+        t = s * va;
+      }
+      t = group_sum<AP>(t);
+      if (a == 0 && r < g.R) es[r] = t + bv;
+    }
   }
   __syncthreads();
   // softmax over regions (keras Softmax(axis=1), attention.py:16,40)
@@ -116,8 +128,10 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttArgs g) {
   // context = sum_r alpha[r] F[b][r][:]   threads = (d = tid % DP, part = tid / DP), DP = AP
   const int d = tid % AP, pp = tid / AP;
   float c = 0.f;
-  if (d < g.D)
+  if (d < g.D) {
+#pragma unroll 8
     for (int r = pp; r < g.R; r += RP) c += es[r] * g.F[((long)b * g.R + r) * g.D + d];
+  }
   part[pp * AP + d] = c;
   __syncthreads();
   if (tid < AP && tid < g.D) {
@@ -143,11 +157,28 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttArgs g) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
   constexpr int RP = 256 / AP;
+  if (g.dz) {
+    // fused: dctx_d[b][d] = sum_n dz[b][n] * Wc[d][n]   (the LSTM input-kernel rows of the context)
+    const int K4 = 4 * g.U, w = tid >> 6, lane = tid & 63;
+    const float4* dzr = reinterpret_cast<const float4*>(g.dz + (long)b * K4);
+    for (int dd = w; dd < g.D; dd += 4) {
+      const float4* wr = reinterpret_cast<const float4*>(g.Wc + (long)dd * K4);
+      float sacc = 0.f;
+#pragma unroll 4
+      for (int i = lane; i < K4 / 4; i += 64) {
+        const float4 x = dzr[i], y = wr[i];
+        sacc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      }
+      sacc = tnt_wave_sum(sacc);
+      if (lane == 0) part[dd] = sacc;
+    }
+    __syncthreads();
+  }
   if (tid < AP) {
     float q = 0.f, dc = 0.f;
     if (tid < g.A) { q = g.qpre_in[(long)b * g.A + tid]; q = q > 0.f ? q : q * g.slope; }
     if (tid < g.D) {
-      dc = g.dctx_d[(long)b * g.D + tid];
+      dc = g.dz ? part[tid] : g.dctx_d[(long)b * g.D + tid];
       if (g.rate_in > 0.f)
         dc = tnt_keep((uint64_t)b * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, g.site_in, step)
                  ? dc * (1.f / (1.f - g.rate_in)) : 0.f;
@@ -158,16 +189,29 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttArgs g) {
   __syncthreads();
   // dalpha[r] = sum_d dctx[d] F[r][d];  dF[r][d] += alpha[r] dctx[d]
   const int d = tid % AP, rp = tid / AP;
-  for (int r0 = 0; r0 < g.R; r0 += RP) {
-    const int r = r0 + rp;
-    float t = 0.f;
-    if (r < g.R && d < g.D) {
+  __syncthreads();          // part[] (fused dctx) fully consumed before it is reused below
+  for (int r0 = 0; r0 < g.R; r0 += RP * 4) {
+    float fv[4], dfv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * RP + rp;
+      const bool ok = r < g.R && d < g.D;
       const long e = ((long)b * g.R + r) * g.D + d;
-      t = dcs[d] * g.F[e];
-      g.dF[e] += als[r] * dcs[d];
+      fv[u] = ok ? g.F[e] : 0.f;
+      dfv[u] = ok ? g.dF[e] : 0.f;
     }
-    t = group_sum<AP>(t);
-    if (d == 0 && r < g.R) das[r] = t;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * RP + rp;
+      float t = 0.f;
+      if (r < g.R && d < g.D) {
+        const long e = ((long)b * g.R + r) * g.D + d;
+        t = dcs[d] * fv[u];
+        g.dF[e] = dfv[u] + als[r] * dcs[d];
+      }
+      t = group_sum<AP>(t);
+      if (d == 0 && r < g.R) das[r] = t;
+    }
   }
   __syncthreads();
   float dot = 0.f;
@@ -182,17 +226,30 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttArgs g) {
   const float va = a < g.A ? g.v[a] : 0.f;
   float dv = 0.f, dq = 0.f;
   if (a < g.A) {
-    for (int r = rp; r < g.R; r += RP) {
-      const long e = ((long)b * g.R + r) * g.A + a;
-      const float s = tanhf(g.P[e] + qs[a]);
-      bool keep = true;
-      if (g.rate_attn > 0.f) keep = tnt_keep((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step);
-      const float ks = keep ? (g.rate_attn > 0.f ? scale_a : 1.f) : 0.f;
-      const float de = als[r];
-      dv += s * ks * de;
-      const float dsum = de * va * ks * (1.f - s * s);
-      g.dP[e] += dsum;
-      dq += dsum;
+    for (int r0 = rp; r0 < g.R; r0 += RP * 4) {
+      float pv[4], dpv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * RP;
+        const long e = ((long)b * g.R + r) * g.A + a;
+        pv[u] = r < g.R ? g.P[e] : 0.f;
+        dpv[u] = r < g.R ? g.dP[e] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * RP;
+        if (r >= g.R) continue;
+        const long e = ((long)b * g.R + r) * g.A + a;
+        const float s = tanhf(pv[u] + qs[a]);
+        bool keep = true;
+        if (g.rate_attn > 0.f) keep = tnt_keep((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step);
+        const float ks = keep ? (g.rate_attn > 0.f ? scale_a : 1.f) : 0.f;
+        const float de = als[r];
+        dv += s * ks * de;
+        const float dsum = de * va * ks * (1.f - s * s);
+        g.dP[e] = dpv[u] + dsum;
+        dq += dsum;
+      }
     }
   }
   part[rp * AP + a] = dv; part2[rp * AP + a] = dq;
@@ -211,28 +268,31 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttArgs g) {
   // dh[k] = sum_a dqpre[a] W2[k][a]
   for (int k = tid; k < g.U; k += 256) {
     float t = 0.f;
+#pragma unroll 8
     for (int j = 0; j < g.A; ++j) t += dq_s[j] * g.W2[(long)k * g.A + j];
     g.dh[(long)b * g.U + k] = t;
   }
 }
 
-__global__ __launch_bounds__(1024) void attention_metric_kernel(const float* alpha, float* out, int T, int B, int R) {
-  __shared__ float sw[16];
+// one workgroup per timestep: partial[t] = sum_r (1 - sum_b alpha[t][b][r])^2
+__global__ __launch_bounds__(256) void attention_metric_kernel(const float* alpha, float* partial, int T, int B, int R) {
+  __shared__ float sw[4];
+  const int t = blockIdx.x;
   float acc = 0.f;
-  const int n = T * R;
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    const int t = i / R, r = i % R;
+  for (int r = threadIdx.x; r < R; r += 256) {
     float s = 0.f;
+#pragma unroll 8
     for (int b = 0; b < B; ++b) s += alpha[((long)t * B + b) * R + r];
     acc += (1.f - s) * (1.f - s);
   }
-  acc = tnt_wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int w = 0; w < 16; ++w) t += sw[w];
-    out[0] = t / (float)n;
+  acc = block_sum256(acc, sw);
+  if (threadIdx.x == 0) partial[t] = acc;
+}
+__global__ void attention_metric_final_kernel(const float* partial, float* out, int T, float scale) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += partial[t];
+    out[0] = s * scale;
   }
 }
 
@@ -272,9 +332,13 @@ extern "C" int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* 
                                               float* dvb, float* dqpre, float* dh, int32_t B, int32_t R, int32_t D,
                                               int32_t A, int32_t U, float slope, float rate_attn, float rate_in,
                                               int32_t in_lwidth, uint64_t seed, uint32_t site_attn, uint32_t site_in,
-                                              uint32_t step, const uint32_t* step_dev, void* stream) {
+                                              uint32_t step, const uint32_t* step_dev, const float* dz, const float* Wc,
+                                              void* stream) {
   if (int32_t rc = check_dims(B, R, D, A, U)) return rc;
+  if (dz != nullptr && (U % 16 != 0 || Wc == nullptr)) return TNT_BADARG(27);
+  if (dz == nullptr && dctx_d == nullptr) return TNT_BADARG(1);
   AttArgs g{};
+  g.dz = dz; g.Wc = Wc;
   g.dctx_d = dctx_d; g.F = F; g.P = P; g.W2 = W2; g.v = v; g.qpre_in = qpre; g.alpha_in = alpha; g.dP = dP; g.dF = dF;
   g.dvb = dvb; g.dqpre = dqpre; g.dh = dh; g.B = B; g.R = R; g.D = D; g.A = A; g.U = U; g.in_lwidth = in_lwidth;
   g.slope = slope; g.rate_attn = rate_attn; g.rate_in = rate_in; g.seed = seed; g.site_attn = site_attn;
@@ -287,9 +351,12 @@ extern "C" int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* 
   return 0;
 }
 
-extern "C" int32_t tnt_attention_metric_f32(const float* alpha, float* out, int32_t T, int32_t B, int32_t R,
-                                            void* stream) {
-  hipLaunchKernelGGL(attention_metric_kernel, dim3(1), dim3(1024), 0, tnt_stream(stream), alpha, out, T, B, R);
+extern "C" int32_t tnt_attention_metric_f32(const float* alpha, float* out, float* work, int32_t T, int32_t B,
+                                            int32_t R, void* stream) {
+  hipLaunchKernelGGL(attention_metric_kernel, dim3(T), dim3(256), 0, tnt_stream(stream), alpha, work, T, B, R);
+  TNT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attention_metric_final_kernel, dim3(1), dim3(64), 0, tnt_stream(stream), work, out, T,
+                     1.f / ((float)T * (float)R));
   TNT_LAUNCH_CHECK();
   return 0;
 }

@@ -25,18 +25,32 @@ struct EncArgs {
 };
 
 // gather Xs[row][k] = x[row][idx[g0 + k0 + k]] for row < 64, k < kc
-__device__ __forceinline__ void gather_tile(const EncArgs& g, float* Xs, int g0, int k0, int kc) {
-  for (int e = threadIdx.x; e < 64 * kc; e += 256) {
-    const int row = e / kc, k = e % kc;
-    float v = 0.f;
-    if (row < g.B) v = g.x[(long)row * g.ldx + g.idx[g0 + k0 + k]];
-    Xs[row * XLD + k] = v;
+// The index list is staged in LDS first so that the voxel loads are independent of each other
+// (8 in flight per thread) instead of each waiting on its own index load.
+__device__ __forceinline__ void gather_tile(const EncArgs& g, float* Xs, int* Is, int g0, int k0, int kc) {
+  for (int k = threadIdx.x; k < kc; k += 256) Is[k] = g.idx[g0 + k0 + k];
+  __syncthreads();
+  const int total = 64 * kc;
+  for (int e0 = threadIdx.x; e0 < total; e0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 256;
+      const int row = e / kc, k = e % kc;
+      v[u] = (e < total && row < g.B) ? g.x[(long)row * g.ldx + Is[k]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 256;
+      if (e < total) Xs[(e / kc) * XLD + e % kc] = v[u];
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void locally_dense_fwd_kernel(EncArgs g) {
   __shared__ float Xs[64 * XLD];
   __shared__ float Ws[KC * WLD];
+  __shared__ int Is[KC];
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
   const int g0 = g.goff[r], nr = g.goff[r + 1] - g0;
@@ -48,7 +62,7 @@ __global__ __launch_bounds__(256) void locally_dense_fwd_kernel(EncArgs g) {
     const int kc = min(KC, nr - k0);
     const int kc4 = (kc + 3) & ~3;
     __syncthreads();
-    gather_tile(g, Xs, g0, k0, kc);
+    gather_tile(g, Xs, Is, g0, k0, kc);
     // zero the k padding up to a multiple of 4 so the MFMA tail multiplies zeros
     for (int e = tid; e < 64 * (kc4 - kc); e += 256) Xs[(e / (kc4 - kc)) * XLD + kc + e % (kc4 - kc)] = 0.f;
     for (int e = tid; e < kc4 * g.D; e += 256) {
@@ -86,6 +100,7 @@ __global__ __launch_bounds__(256) void locally_dense_fwd_kernel(EncArgs g) {
 __global__ __launch_bounds__(256) void locally_dense_bwd_kernel(EncArgs g) {
   __shared__ float Xs[64 * XLD];
   __shared__ float Ds[64 * WLD];
+  __shared__ int Is[KC];
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
   const int g0 = g.goff[r], nr = g.goff[r + 1] - g0;
@@ -104,7 +119,7 @@ __global__ __launch_bounds__(256) void locally_dense_bwd_kernel(EncArgs g) {
   for (int k0 = 0; k0 < nr; k0 += KC) {
     const int kc = min(KC, nr - k0);
     __syncthreads();
-    gather_tile(g, Xs, g0, k0, kc);
+    gather_tile(g, Xs, Is, g0, k0, kc);
     __syncthreads();
     // dW[k][d] = sum_b Xs[b][k] * Ds[b][d]; wave w owns m-tiles w, w+4, ...
     for (int mt = w; mt * 16 < kc; mt += 4) {

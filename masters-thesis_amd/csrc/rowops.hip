@@ -8,46 +8,58 @@
 
 namespace {
 
-constexpr int CHUNK_ROWS = 64;
+// column reductions run in two levels: <= MAX_CHUNKS row chunks -> per-column finalize
+constexpr int MAX_CHUNKS = 32;
+inline int chunk_count(int rows) { int n = (rows + 63) / 64; return n > MAX_CHUNKS ? MAX_CHUNKS : (n < 1 ? 1 : n); }
+inline int chunk_rows(int rows) { const int n = chunk_count(rows); return (rows + n - 1) / n; }
 
 // ------------------------------------------------------------------------- dropout
-__global__ __launch_bounds__(256) void dropout_kernel(const float* x, float* y, int rows, int cols, int ld,
-                                                      int tB, int lwidth, int lcol0, float rate, float scale,
-                                                      uint64_t seed, uint32_t site, uint32_t step,
-                                                      const uint32_t* step_dev) {
-  if (step_dev) step += step_dev[0];
-  const long total = (long)rows * cols;
-  const int T = tB > 0 ? rows / tB : 0;
+struct DropArgs {
+  const float* x; float* y; int rows, cols, ld, tB, lwidth, lcol0, rows_per_site;
+  float rate, scale; uint64_t seed; uint32_t site, step; const uint32_t* step_dev;
+};
+
+// logical row / site of buffer row r
+__device__ __forceinline__ void drop_row(const DropArgs& a, int r, int T, long& lrow, uint32_t& site) {
+  site = a.site;
+  if (a.rows_per_site > 0) { site += (uint32_t)(r / a.rows_per_site); r = r % a.rows_per_site; }
+  lrow = a.tB > 0 ? (long)(r % a.tB) * T + r / a.tB : r;
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(DropArgs a) {
+  const uint32_t step = a.step + (a.step_dev ? a.step_dev[0] : 0u);
+  const long total = (long)a.rows * a.cols;
+  const int T = a.tB > 0 ? a.rows / a.tB : 0;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int r = (int)(e / cols), c = (int)(e % cols);
-    const long lrow = tB > 0 ? (long)(r % tB) * T + r / tB : r;
-    const uint64_t le = (uint64_t)lrow * (uint64_t)lwidth + (uint64_t)(lcol0 + c);
-    const bool k = tnt_keep(le, rate, seed, site, step);
-    const long o = (long)r * ld + c;
-    y[o] = k ? x[o] * scale : 0.f;
+    const int r = (int)(e / a.cols), c = (int)(e % a.cols);
+    long lrow; uint32_t site;
+    drop_row(a, r, T, lrow, site);
+    const uint64_t le = (uint64_t)lrow * (uint64_t)a.lwidth + (uint64_t)(a.lcol0 + c);
+    const bool k = tnt_keep(le, a.rate, a.seed, site, step);
+    const long o = (long)r * a.ld + c;
+    a.y[o] = k ? a.x[o] * a.scale : 0.f;
   }
 }
 
 // 4 consecutive columns per thread: one Philox call yields the 4 decisions (cols, ld, lwidth, lcol0 % 4 == 0)
-__global__ __launch_bounds__(256) void dropout4_kernel(const float* x, float* y, int rows, int cols, int ld, int tB,
-                                                       int lwidth, int lcol0, float rate, float scale, uint64_t seed,
-                                                       uint32_t site, uint32_t step, const uint32_t* step_dev) {
-  if (step_dev) step += step_dev[0];
-  const int c4n = cols >> 2;
-  const long total = (long)rows * c4n;
-  const int T = tB > 0 ? rows / tB : 0;
+__global__ __launch_bounds__(256) void dropout4_kernel(DropArgs a) {
+  const uint32_t step = a.step + (a.step_dev ? a.step_dev[0] : 0u);
+  const int c4n = a.cols >> 2;
+  const long total = (long)a.rows * c4n;
+  const int T = a.tB > 0 ? a.rows / a.tB : 0;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int r = (int)(e / c4n), c = (int)(e % c4n) * 4;
-    const long lrow = tB > 0 ? (long)(r % tB) * T + r / tB : r;
-    const uint64_t le = (uint64_t)lrow * (uint64_t)lwidth + (uint64_t)(lcol0 + c);
+    long lrow; uint32_t site;
+    drop_row(a, r, T, lrow, site);
+    const uint64_t le = (uint64_t)lrow * (uint64_t)a.lwidth + (uint64_t)(a.lcol0 + c);
     bool k[4];
-    tnt_keep4(le, rate, seed, site, step, k);
-    const long o = (long)r * ld + c;
-    const float4 v = *reinterpret_cast<const float4*>(x + o);
+    tnt_keep4(le, a.rate, a.seed, site, step, k);
+    const long o = (long)r * a.ld + c;
+    const float4 v = *reinterpret_cast<const float4*>(a.x + o);
     float4 w;
-    w.x = k[0] ? v.x * scale : 0.f; w.y = k[1] ? v.y * scale : 0.f;
-    w.z = k[2] ? v.z * scale : 0.f; w.w = k[3] ? v.w * scale : 0.f;
-    *reinterpret_cast<float4*>(y + o) = w;
+    w.x = k[0] ? v.x * a.scale : 0.f; w.y = k[1] ? v.y * a.scale : 0.f;
+    w.z = k[2] ? v.z * a.scale : 0.f; w.w = k[3] ? v.w * a.scale : 0.f;
+    *reinterpret_cast<float4*>(a.y + o) = w;
   }
 }
 
@@ -58,21 +70,23 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* pre, const fl
 }
 
 // --------------------------------------------------------------- column partials
-// grid (ceil(C/64), nchunk), block 256 = 64 columns x 4 row lanes.
+// grid (ceil(C/CL), nchunk), block 256 = CL column lanes x (256/CL) row lanes.
 // MODE 0: Welford (mean, M2) of x          -> work[chunk][0][c]=mean, [1][c]=M2
 // MODE 1: sums of a and a*b                -> work[chunk][0][c]=sum a, [1][c]=sum a*b
 // MODE 2: sum of a only                    -> work[chunk][0][c]
-template <int MODE>
+template <int MODE, int CL>
 __global__ __launch_bounds__(256) void col_partial_kernel(const float* a, int lda, const float* b, int ldb, int rows,
-                                                          int C, float* work) {
-  __shared__ float s0[4][64], s1[4][64], sn[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+                                                          int C, int crows, float* work) {
+  constexpr int RL = 256 / CL;
+  __shared__ float s0[RL][CL], s1[RL][CL], sn[RL][CL];
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const int c = blockIdx.x * CL + cl;
   const int chunk = blockIdx.y;
-  const int r0 = chunk * CHUNK_ROWS, r1 = min(rows, r0 + CHUNK_ROWS);
+  const int r0 = chunk * crows, r1 = min(rows, r0 + crows);
   float v0 = 0.f, v1 = 0.f, n = 0.f;
   if (c < C) {
-    for (int r = r0 + rl; r < r1; r += 4) {
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += RL) {
       const float x = a[(long)r * lda + c];
       if (MODE == 0) {
         n += 1.f;
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* a, int ld
   if (rl == 0 && c < C) {
     if (MODE == 0) {
       float nn = sn[0][cl], mean = s0[0][cl], m2 = s1[0][cl];
-      for (int j = 1; j < 4; ++j) {
+      for (int j = 1; j < RL; ++j) {
         const float nj = sn[j][cl];
         if (nj > 0.f) {
           const float d = s0[j][cl] - mean, nt = nn + nj;
@@ -105,7 +119,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* a, int ld
       work[((long)chunk * 2 + 1) * C + c] = m2;
     } else {
       float t0 = 0.f, t1 = 0.f;
-      for (int j = 0; j < 4; ++j) { t0 += s0[j][cl]; t1 += s1[j][cl]; }
+      for (int j = 0; j < RL; ++j) { t0 += s0[j][cl]; t1 += s1[j][cl]; }
       if (MODE == 1) {
         work[((long)chunk * 2 + 0) * C + c] = t0;
         work[((long)chunk * 2 + 1) * C + c] = t1;
@@ -116,14 +130,26 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* a, int ld
   }
 }
 
+template <int MODE>
+void launch_col_partial(const float* a, int lda, const float* b, int ldb, int rows, int C, float* work, hipStream_t s) {
+  const int nchunk = chunk_count(rows), crows = chunk_rows(rows);
+  if (C <= 32)
+    hipLaunchKernelGGL((col_partial_kernel<MODE, 32>), dim3((C + 31) / 32, nchunk), dim3(256), 0, s, a, lda, b, ldb, rows,
+                       C, crows, work);
+  else
+    hipLaunchKernelGGL((col_partial_kernel<MODE, 64>), dim3((C + 63) / 64, nchunk), dim3(256), 0, s, a, lda, b, ldb, rows,
+                       C, crows, work);
+}
+
 // BN statistics finalize (training): Chan merge over chunks in fixed order.
-__global__ void bn_finalize_kernel(const float* work, int rows, int C, int nchunk, float eps, float momentum,
+__global__ void bn_finalize_kernel(const float* work, int rows, int C, int nchunk, int crows, float eps, float momentum,
                                    float* mov_mean, float* mov_var, float* mean_out, float* inv_std) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= C) return;
   float nn = 0.f, mean = 0.f, m2 = 0.f;
   for (int k = 0; k < nchunk; ++k) {
-    const float nj = (float)(min(rows, (k + 1) * CHUNK_ROWS) - k * CHUNK_ROWS);
+    const float nj = (float)(min(rows, (k + 1) * crows) - k * crows);
+    if (nj <= 0.f) continue;
     const float mj = work[((long)k * 2 + 0) * C + c], m2j = work[((long)k * 2 + 1) * C + c];
     const float d = mj - mean, nt = nn + nj;
     mean += d * nj / nt;
@@ -139,7 +165,7 @@ __global__ void bn_finalize_kernel(const float* work, int rows, int C, int nchun
 
 __global__ void bn_infer_prep_kernel(const float* mov_mean, const float* mov_var, int C, float eps, float* mean_out,
                                      float* inv_std) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= C) return;
   mean_out[c] = mov_mean[c];
   inv_std[c] = 1.f / sqrtf(mov_var[c] + eps);
@@ -160,9 +186,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
 // sums over chunks: out0[c] = sum_k work[k][0][c] (and out1 from slot 1 if TWO)
 template <bool TWO>
 __global__ void col_finalize_kernel(const float* work, int C, int nchunk, float* out0, float* out1) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= C) return;
   float t0 = 0.f, t1 = 0.f;
+#pragma unroll 8
   for (int k = 0; k < nchunk; ++k) {
     if (TWO) {
       t0 += work[((long)k * 2 + 0) * C + c];
@@ -249,21 +276,24 @@ inline int ew_blocks(long total) {
 
 }  // namespace
 
-extern "C" int32_t tnt_bn_nchunk(int32_t rows) { return (rows + CHUNK_ROWS - 1) / CHUNK_ROWS; }
+extern "C" int32_t tnt_bn_nchunk(int32_t rows) { return chunk_count(rows); }
 
 extern "C" int32_t tnt_dropout_f32(const float* x, float* y, int32_t rows, int32_t cols, int32_t ld, int32_t tmajor_B,
-                                   int32_t lwidth, int32_t lcol0, float rate, uint64_t seed, uint32_t site,
-                                   uint32_t step, const uint32_t* step_dev, void* stream) {
+                                   int32_t lwidth, int32_t lcol0, int32_t rows_per_site, float rate, uint64_t seed,
+                                   uint32_t site, uint32_t step, const uint32_t* step_dev, void* stream) {
   if (rows <= 0 || cols <= 0) return 0;
-  if (tmajor_B > 0 && rows % tmajor_B != 0) return TNT_BADARG(6);
-  const float scale = 1.0f / (1.0f - rate);
+  const int rsite = rows_per_site > 0 ? rows_per_site : rows;
+  if (tmajor_B > 0 && rsite % tmajor_B != 0) return TNT_BADARG(6);
+  if (rows_per_site > 0 && tmajor_B > 0) return TNT_BADARG(9);     // per-site blocks are (rows_per_site, cols) row-major
+  DropArgs a;
+  a.x = x; a.y = y; a.rows = rows; a.cols = cols; a.ld = ld; a.tB = tmajor_B; a.lwidth = lwidth; a.lcol0 = lcol0;
+  a.rows_per_site = rows_per_site; a.rate = rate; a.scale = 1.0f / (1.0f - rate); a.seed = seed; a.site = site;
+  a.step = step; a.step_dev = step_dev;
   const bool vec = ((cols | ld | lwidth | lcol0) & 3) == 0 && tnt_aligned16(x) && tnt_aligned16(y);
   if (vec)
-    hipLaunchKernelGGL(dropout4_kernel, dim3(ew_blocks((long)rows * (cols / 4))), dim3(256), 0, tnt_stream(stream), x, y,
-                       rows, cols, ld, tmajor_B, lwidth, lcol0, rate, scale, seed, site, step, step_dev);
+    hipLaunchKernelGGL(dropout4_kernel, dim3(ew_blocks((long)rows * (cols / 4))), dim3(256), 0, tnt_stream(stream), a);
   else
-    hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks((long)rows * cols)), dim3(256), 0, tnt_stream(stream), x, y, rows,
-                       cols, ld, tmajor_B, lwidth, lcol0, rate, scale, seed, site, step, step_dev);
+    hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks((long)rows * cols)), dim3(256), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
 }
@@ -283,18 +313,17 @@ extern "C" int32_t tnt_batchnorm_fwd_f32(const float* x, const float* gamma, con
                                          int32_t ldy, int32_t training, float eps, float momentum, float* work,
                                          void* stream) {
   hipStream_t s = tnt_stream(stream);
-  const int nchunk = tnt_bn_nchunk(rows);
+  const int nchunk = chunk_count(rows);
   float* mean = work;
   float* part = work + C;
   if (training) {
-    hipLaunchKernelGGL(col_partial_kernel<0>, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, x, C, (const float*)nullptr,
-                       0, rows, C, part);
+    launch_col_partial<0>(x, C, nullptr, 0, rows, C, part, s);
     TNT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, rows, C, nchunk, eps, momentum,
-                       mov_mean, mov_var, mean, inv_std);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, part, rows, C, nchunk, chunk_rows(rows),
+                       eps, momentum, mov_mean, mov_var, mean, inv_std);
     TNT_LAUNCH_CHECK();
   } else {
-    hipLaunchKernelGGL(bn_infer_prep_kernel, dim3((C + 255) / 256), dim3(256), 0, s, mov_mean, mov_var, C, eps, mean,
+    hipLaunchKernelGGL(bn_infer_prep_kernel, dim3((C + 63) / 64), dim3(64), 0, s, mov_mean, mov_var, C, eps, mean,
                        inv_std);
     TNT_LAUNCH_CHECK();
   }
@@ -308,12 +337,11 @@ extern "C" int32_t tnt_batchnorm_bwd_f32(const float* dy, const float* xhat, con
                                          float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, int32_t lddy,
                                          int32_t training, float* work, void* stream) {
   hipStream_t s = tnt_stream(stream);
-  const int nchunk = tnt_bn_nchunk(rows);
+  const int nchunk = chunk_count(rows);
   float* part = work + C;
-  hipLaunchKernelGGL(col_partial_kernel<1>, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, dy, lddy, xhat, C, rows, C,
-                     part);
+  launch_col_partial<1>(dy, lddy, xhat, C, rows, C, part, s);
   TNT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_finalize_kernel<true>, dim3((C + 255) / 256), dim3(256), 0, s, part, C, nchunk, dbeta, dgamma);
+  hipLaunchKernelGGL(col_finalize_kernel<true>, dim3((C + 63) / 64), dim3(64), 0, s, part, C, nchunk, dbeta, dgamma);
   TNT_LAUNCH_CHECK();
   if (dx) {
     hipLaunchKernelGGL(bn_dx_kernel, dim3(ew_blocks((long)rows * C)), dim3(256), 0, s, dy, lddy, xhat, gamma, inv_std,
@@ -335,12 +363,11 @@ extern "C" int32_t tnt_layernorm_bwd_f32(const float* dy, const float* xhat, con
                                          float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, int32_t lddy,
                                          float* work, void* stream) {
   hipStream_t s = tnt_stream(stream);
-  const int nchunk = tnt_bn_nchunk(rows);
+  const int nchunk = chunk_count(rows);
   float* part = work + C;
-  hipLaunchKernelGGL(col_partial_kernel<1>, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, dy, lddy, xhat, C, rows, C,
-                     part);
+  launch_col_partial<1>(dy, lddy, xhat, C, rows, C, part, s);
   TNT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_finalize_kernel<true>, dim3((C + 255) / 256), dim3(256), 0, s, part, C, nchunk, dbeta, dgamma);
+  hipLaunchKernelGGL(col_finalize_kernel<true>, dim3((C + 63) / 64), dim3(64), 0, s, part, C, nchunk, dbeta, dgamma);
   TNT_LAUNCH_CHECK();
   if (dx) {
     hipLaunchKernelGGL(ln_dx_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dy, lddy, xhat, gamma, inv_std, dx, rows, C);
@@ -352,11 +379,10 @@ extern "C" int32_t tnt_layernorm_bwd_f32(const float* dy, const float* xhat, con
 extern "C" int32_t tnt_colsum_f32(const float* x, float* out, int32_t rows, int32_t C, int32_t ld, float* work,
                                   void* stream) {
   hipStream_t s = tnt_stream(stream);
-  const int nchunk = tnt_bn_nchunk(rows);
-  hipLaunchKernelGGL(col_partial_kernel<2>, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, x, ld, (const float*)nullptr,
-                     0, rows, C, work);
+  const int nchunk = chunk_count(rows);
+  launch_col_partial<2>(x, ld, nullptr, 0, rows, C, work, s);
   TNT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_finalize_kernel<false>, dim3((C + 255) / 256), dim3(256), 0, s, work, C, nchunk, out,
+  hipLaunchKernelGGL(col_finalize_kernel<false>, dim3((C + 63) / 64), dim3(64), 0, s, work, C, nchunk, out,
                      (float*)nullptr);
   TNT_LAUNCH_CHECK();
   return 0;
@@ -368,4 +394,4 @@ extern "C" int32_t tnt_sum_f32(const float* x, float* out, int32_t n, float scal
   return 0;
 }
 
-extern "C" int32_t tnt_version(void) { return 100; }
+extern "C" int32_t tnt_version(void) { return 101; }

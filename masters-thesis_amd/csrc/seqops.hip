@@ -29,61 +29,62 @@ __global__ __launch_bounds__(256) void rowsq_kernel(const float* x, float* rowsq
   if (lane == 0) rowsq[row] = s;
 }
 
-// Deterministic scatter-add without atomics.  One wave per contribution row k (k = b*T + t):
-// the wave whose row is the FIRST occurrence of its id owns that vocabulary row; it sums its own
-// row and every later duplicate in ascending k order and writes the row once.  Rows of dtable
-// that no token references are zeroed by zero_fill_kernel launched before this kernel (a captured
-// hipMemsetAsync node did not replay reliably inside torch's hipGraph on ROCm 7.0/7.2).
+// Deterministic scatter-add without atomics.  Block (k, jc): contribution row k (k = b*T + t),
+// 64-column chunk jc.  The block whose row is the FIRST occurrence of its id owns that vocabulary
+// row: its 4 waves sum a fixed strided subset of the later duplicates each (4 independent row loads
+// in flight per wave -- the pad/start tokens have hundreds of duplicates), and the 4 partials are
+// combined in wave order through LDS.  Fixed partition + fixed order = bitwise reproducible.
+// Rows of dtable that no token references are zeroed by zero_fill_kernel launched before this
+// kernel (a captured hipMemsetAsync node did not replay reliably inside torch's hipGraph).
 __global__ __launch_bounds__(256) void zero_fill_kernel(float* p, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0.f;
 }
 
 __global__ __launch_bounds__(256) void emb_bwd_kernel(const float* drows, const int* ids, float* dtable, int B, int T,
                                                       int E, int ldd, int V) {
-  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  __shared__ float part[4][64];
+  __shared__ int s_dup;
+  const int k = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = B * T;
-  if (k >= n) return;
   int id = ids[k];
   id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-  for (int base = 0; base < k; base += 64) {           // an earlier occurrence owns the row
-    const int i = base + lane;
-    int other = i < k ? ids[i] : -1;
-    other = other >= V ? V - 1 : other;
-    if (__ballot(i < k && other == id)) return;
+  if (threadIdx.x == 0) s_dup = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < k; i += 256) {           // an earlier occurrence owns the row
+    int other = ids[i];
+    other = other < 0 ? 0 : (other >= V ? V - 1 : other);
+    if (other == id) s_dup = 1;
   }
-  for (int j0 = 0; j0 < E; j0 += 256) {
-    float acc[4];
-    {
-      const float* r = drows + (long)((k % T) * B + k / T) * ldd;
+  __syncthreads();
+  if (s_dup) return;
+  const int j = blockIdx.y * 64 + lane;
+  const bool jok = j < E;
+  float acc = 0.f;
+  if (w == 0 && jok) acc = drows[(long)((k % T) * B + k / T) * ldd + j];
+  // wave w scans positions k+1+64w, +256, ... ; hits processed 4 at a time
+  for (int base = k + 1 + 64 * w; base < n; base += 256) {
+    const int i = base + lane;
+    int other = i < n ? ids[i] : -1;
+    other = other >= V ? V - 1 : other;
+    unsigned long long hit = __ballot(i < n && other == id);
+    while (hit) {
+      int kk[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int j = j0 + q * 64 + lane;
-        acc[q] = j < E ? r[j] : 0.f;
+        kk[q] = -1;
+        if (hit) { kk[q] = base + __ffsll((long long)hit) - 1; hit &= hit - 1; }
       }
-    }
-    for (int base = k + 1; base < n; base += 64) {
-      const int i = base + lane;
-      int other = i < n ? ids[i] : -1;
-      other = other >= V ? V - 1 : other;
-      unsigned long long hit = __ballot(i < n && other == id);
-      while (hit) {
-        const int src = __ffsll((long long)hit) - 1;
-        hit &= hit - 1;
-        const int kk = base + src;
-        const float* r = drows + (long)((kk % T) * B + kk / T) * ldd;
+      float v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int j = j0 + q * 64 + lane;
-          if (j < E) acc[q] += r[j];
-        }
-      }
-    }
+      for (int q = 0; q < 4; ++q)
+        v[q] = (kk[q] >= 0 && jok) ? drows[(long)((kk[q] % T) * B + kk[q] / T) * ldd + j] : 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int j = j0 + q * 64 + lane;
-      if (j < E) dtable[(long)id * E + j] = acc[q];
+      for (int q = 0; q < 4; ++q) acc += v[q];
     }
   }
+  part[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && jok) dtable[(long)id * E + j] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
 __global__ __launch_bounds__(1024) void sum_accum_kernel(const float* x, float* out, int n) {
@@ -221,7 +222,7 @@ extern "C" int32_t tnt_embedding_bwd_f32(const float* drows, const int32_t* ids,
     hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)(zb > 2048 ? 2048 : zb)), dim3(256), 0, s, dtable, nz);
     TNT_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(emb_bwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, s, drows, ids, dtable, B, T, E, ldd, V);
+  hipLaunchKernelGGL(emb_bwd_kernel, dim3(B * T, (E + 63) / 64), dim3(256), 0, s, drows, ids, dtable, B, T, E, ldd, V);
   TNT_LAUNCH_CHECK();
   return 0;
 }

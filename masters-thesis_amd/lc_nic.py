@@ -238,7 +238,7 @@ class NIC(ModelBase):
         nch = max(self.be.bn_nchunk(B * R), self.be.bn_nchunk(n))
         self.work = f(max(D, A, 4 * U, ldV, H) * (2 * nch + 1))
         self.rowsq = f(n)
-        self._alloc_splitk([(n, H, V), (n, Et, 4 * U), (n, U, H)])
+        self._alloc_splitk([(n, H, V), (n, Et, 4 * U), (n, U, H), (D, 4 * U, n), (U, A, n), (D, A, B * R)])
         self.emb_seg = self.arena.entries["emb_text/embeddings"].seg
         self._shape = (B, T)
         self._graphs = {}
@@ -307,17 +307,15 @@ class NIC(ModelBase):
         if training and self.r_text > 0:
             be.dropout(self.text, self.text, n, Et, Et, B, Et, 0, self.r_text, sd, S_TEXT, 0, ds)
         if training and self.r_lstm > 0:       # text half of the per-call LSTM input mask over (B,1,D+Et)
-            for i in range(T):
-                be.dropout(self.text[i * B:], self.text[i * B:], B, Et, Et, 0, D + Et, D, self.r_lstm, sd,
-                           S_LSTM_IN + i, 0, ds)
+            be.dropout(self.text, self.text, n, Et, Et, 0, D + Et, D, self.r_lstm, sd, S_LSTM_IN, 0, ds,
+                       rows_per_site=B)
         Wl = a.p("lstm/kernel")
         be.gemm(self.text, Wl[D:], self.XZ, n, 4 * U, Et, Et, 4 * U, 4 * U, bias=a.p("lstm/bias"))
         for i in range(T):                                                                      # :244-256
             self._decode_step(i, B, training)
         hs = self.Hs[1:].view(n, U)
         if training and self.r_lstm > 0:                                                        # :256
-            for i in range(T):
-                be.dropout(hs[i * B:], self.Hd[i * B:], B, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT + i, 0, ds)
+            be.dropout(hs, self.Hd, n, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds, rows_per_site=B)
             hs = self.Hd
         self._hs_used = hs
         be.gemm(hs, a.p("time_distributed_nonlinear/kernel"), self.inter, n, H, U, U, H, H,
@@ -341,7 +339,7 @@ class NIC(ModelBase):
                            0.0)
         be.sum(self.loss_row, self.met[0:1], n, 1.0 / n)
         be.sum(self.corr_row, self.met[1:2], n, 1.0 / n)
-        be.attention_metric(self.alpha, self.met[3:4], T, B, self.R)                            # :365-367
+        be.attention_metric(self.alpha, self.met[3:4], self.rowsq, T, B, self.R)                            # :365-367
 
     # ------------------------------------------------------------------ backward
     def _backward(self, B, T):
@@ -360,8 +358,7 @@ class NIC(ModelBase):
         be.colsum(self.dinter, a.g("time_distributed_nonlinear/bias"), n, H, H, self.work)
         be.gemm(self.dinter, a.p("time_distributed_nonlinear/kernel"), self.dHs, n, U, H, H, H, U, transB=True)
         if self.r_lstm > 0:
-            for i in range(T):
-                be.dropout(self.dHs[i * B:], self.dHs[i * B:], B, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT + i, 0, ds)
+            be.dropout(self.dHs, self.dHs, n, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds, rows_per_site=B)
         self.dP.zero_(); self.dF.zero_(); self.dvb.zero_()
         Wl, Ur = a.p("lstm/kernel"), a.p("lstm/recurrent_kernel")
         W2, v = a.p("attention/W2/kernel"), a.p("attention/V/kernel")
@@ -371,33 +368,33 @@ class NIC(ModelBase):
                              None if last else self.dh_att, None if last else self.dc, None,
                              self.dHs[i * B:(i + 1) * B], None, 0, 0, self.gates[i], self.Cs[i + 1], self.Cs[i],
                              self.dZ[i * B:(i + 1) * B], None, self.dc, None, B, U)
-            be.gemm(self.dZ[i * B:(i + 1) * B], Wl[:D], self.dctx, B, D, 4 * U, 4 * U, 4 * U, D, transB=True)
-            be.attention_step_bwd(self.dctx, self.F, self.P, W2, v, self.qpre[i], self.alpha[i], self.dP, self.dF,
+            # dctx = dZ_i @ Wc^T is computed inside the attention backward kernel
+            be.attention_step_bwd(None, self.F, self.P, W2, v, self.qpre[i], self.alpha[i], self.dP, self.dF,
                                   self.dvb, self.dqpre[i], self.dh_att, B, R, D, A, U, 0.2, self.r_attn, self.r_lstm,
-                                  D + Et, sd, S_ATTN + i, S_LSTM_IN + i, 0, ds)
+                                  D + Et, sd, S_ATTN + i, S_LSTM_IN + i, 0, ds, dz=self.dZ[i * B:(i + 1) * B],
+                                  Wc=Wl[:D])
         hprev = self.Hs[:T].view(n, U)
         gWl = a.g("lstm/kernel")
         be.gemm(hprev, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True)
         be.gemm(self.text, self.dZ, gWl[D:], Et, 4 * U, n, Et, 4 * U, 4 * U, transA=True)
-        be.gemm(self.ctx_d, self.dZ, gWl[:D], D, 4 * U, n, D, 4 * U, 4 * U, transA=True)
+        self.gemm_sk(self.ctx_d, self.dZ, gWl[:D], D, 4 * U, n, D, 4 * U, 4 * U, transA=True)
         be.colsum(self.dZ, a.g("lstm/bias"), n, 4 * U, 4 * U, self.work)
         self.gemm_sk(self.dZ, Wl[D:], self.dtext, n, Et, 4 * U, 4 * U, 4 * U, Et, transB=True)
         if self.r_lstm > 0:
-            for i in range(T):
-                be.dropout(self.dtext[i * B:], self.dtext[i * B:], B, Et, Et, 0, D + Et, D, self.r_lstm, sd,
-                           S_LSTM_IN + i, 0, ds)
+            be.dropout(self.dtext, self.dtext, n, Et, Et, 0, D + Et, D, self.r_lstm, sd, S_LSTM_IN, 0, ds,
+                       rows_per_site=B)
         if self.r_text > 0:
             be.dropout(self.dtext, self.dtext, n, Et, Et, B, Et, 0, self.r_text, sd, S_TEXT, 0, ds)
         sqo = a.sq_override[self.emb_seg:self.emb_seg + 1]
         sqo.zero_()
         be.embedding_bwd(self.dtext, self.cap, a.g("emb_text/embeddings"), sqo, self.rowsq, B, T, Et, Et, V)
         # attention parameters
-        be.gemm(hprev, self.dqpre, a.g("attention/W2/kernel"), U, A, n, U, A, A, transA=True)
+        self.gemm_sk(hprev, self.dqpre, a.g("attention/W2/kernel"), U, A, n, U, A, A, transA=True)
         be.colsum(self.dqpre, a.g("attention/W2/bias"), n, A, A, self.work)
         be.colsum(self.dvb, a.g("attention/V/kernel"), B, A, A + 1, self.work)
         be.colsum(self.dvb.view(-1)[A:], a.g("attention/V/bias"), B, 1, A + 1, self.work)
         be.act_bwd(self.Ppre, self.dP, self.dP, B * R * A, ACT_LEAKY, 0.2)
-        be.gemm(self.F, self.dP, a.g("attention/W1/kernel"), D, A, B * R, D, A, A, transA=True)
+        self.gemm_sk(self.F, self.dP, a.g("attention/W1/kernel"), D, A, B * R, D, A, A, transA=True)
         be.colsum(self.dP, a.g("attention/W1/bias"), B * R, A, A, self.work)
         be.gemm(self.dP, a.p("attention/W1/kernel"), self.dF, B * R, D, A, A, A, D, transB=True, accumulate=True)
         # encoder

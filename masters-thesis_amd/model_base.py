@@ -122,9 +122,9 @@ class ModelBase:
     def pick_splitk(M, N, K):
         """Split-K factor for GEMMs whose output has too few 64x64 tiles to fill 256 CUs."""
         tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        if tiles >= 384 or K < 1024:
+        if tiles >= 384 or K < 512:
             return 1
-        return int(max(1, min(64, -(-512 // tiles), K // 256)))
+        return int(max(1, min(64, -(-512 // tiles), K // 128)))
 
     def _alloc_splitk(self, shapes):
         """Workspace for the split-K GEMMs of this model: shapes = [(M, N, K), ...]."""

@@ -41,9 +41,10 @@ class HipBackend:
                                          int(transA), int(transB), act, slope, int(accumulate), splitk,
                                          _p(work), self._s()), "tnt_gemm_f32")
 
-    def dropout(self, x, y, rows, cols, ld, tmajor_B, lwidth, lcol0, rate, seed, site, step, step_dev=None):
-        _lib.check(self.lib.tnt_dropout_f32(_p(x), _p(y), rows, cols, ld, tmajor_B, lwidth, lcol0, rate, seed, site,
-                                            step, _p(step_dev), self._s()), "tnt_dropout_f32")
+    def dropout(self, x, y, rows, cols, ld, tmajor_B, lwidth, lcol0, rate, seed, site, step, step_dev=None,
+                rows_per_site=0):
+        _lib.check(self.lib.tnt_dropout_f32(_p(x), _p(y), rows, cols, ld, tmajor_B, lwidth, lcol0, rows_per_site,
+                                            rate, seed, site, step, _p(step_dev), self._s()), "tnt_dropout_f32")
 
     def act_bwd(self, pre, dy, dx, n, act, slope=0.2):
         _lib.check(self.lib.tnt_act_bwd_f32(_p(pre), _p(dy), _p(dx), n, act, slope, self._s()), "tnt_act_bwd_f32")
@@ -144,14 +145,16 @@ class HipBackend:
                                                        _p(step_dev), self._s()), "tnt_attention_step_fwd_f32")
 
     def attention_step_bwd(self, dctx_d, F, P, W2, v, qpre, alpha, dP, dF, dvb, dqpre, dh, B, R, D, A, U, slope,
-                           rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None):
+                           rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None, dz=None,
+                           Wc=None):
         _lib.check(self.lib.tnt_attention_step_bwd_f32(_p(dctx_d), _p(F), _p(P), _p(W2), _p(v), _p(qpre), _p(alpha),
                                                        _p(dP), _p(dF), _p(dvb), _p(dqpre), _p(dh), B, R, D, A, U,
                                                        slope, rate_attn, rate_in, in_lwidth, seed, site_attn, site_in,
-                                                       step, _p(step_dev), self._s()), "tnt_attention_step_bwd_f32")
+                                                       step, _p(step_dev), _p(dz), _p(Wc), self._s()),
+                   "tnt_attention_step_bwd_f32")
 
-    def attention_metric(self, alpha, out, T, B, R):
-        _lib.check(self.lib.tnt_attention_metric_f32(_p(alpha), _p(out), T, B, R, self._s()),
+    def attention_metric(self, alpha, out, work, T, B, R):
+        _lib.check(self.lib.tnt_attention_metric_f32(_p(alpha), _p(out), _p(work), T, B, R, self._s()),
                    "tnt_attention_metric_f32")
 
 

@@ -60,9 +60,17 @@ class MockBackend:
         c = mat(C, M, N, ldc)
         c[...] = (c + v) if accumulate else v
 
-    def dropout(self, x, y, rows, cols, ld, tmajor_B, lwidth, lcol0, rate, seed, site, step, step_dev=None):
+    def dropout(self, x, y, rows, cols, ld, tmajor_B, lwidth, lcol0, rate, seed, site, step, step_dev=None,
+                rows_per_site=0):
         if step_dev is not None:
             step = (step + int(step_dev[0])) & 0xFFFFFFFF
+        if rows_per_site > 0:
+            assert tmajor_B == 0
+            for blk in range(0, rows, rows_per_site):
+                nb = min(rows_per_site, rows - blk)
+                self.dropout(x.view(-1)[blk * ld:], y.view(-1)[blk * ld:], nb, cols, ld, 0, lwidth, lcol0, rate, seed,
+                             site + blk // rows_per_site, step)
+            return
         xs, ys = mat(x, rows, cols, ld), mat(y, rows, cols, ld)
         r = np.arange(rows)
         T = rows // tmajor_B if tmajor_B > 0 else 0
@@ -311,13 +319,15 @@ class MockBackend:
             flat(ctx_d)[:B * D] = O.dropout_fwd(cx, kin, rate_in).reshape(-1)
 
     def attention_step_bwd(self, dctx_d, F, P, W2, v, qpre, alpha, dP, dF, dvb, dqpre, dh, B, R, D, A, U, slope,
-                           rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None):
+                           rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None, dz=None,
+                           Wc=None):
         if step_dev is not None:
             step = (step + int(step_dev[0])) & 0xFFFFFFFF
         f64 = lambda t, *s: flat(t)[:int(np.prod(s))].reshape(*s).astype(np.float64)
         keep = _keep(np.arange(B * R * A).reshape(B, R, A), rate_attn, seed, site_attn, step) if rate_attn > 0 else None
         kin = _keep(np.arange(B)[:, None] * in_lwidth + np.arange(D)[None, :], rate_in, seed, site_in, step) if rate_in > 0 else None
-        dctx = O.dropout_bwd(f64(dctx_d, B, D), kin, rate_in)
+        raw = f64(dz, B, 4 * U) @ f64(Wc, D, 4 * U).T if dz is not None else f64(dctx_d, B, D)
+        dctx = O.dropout_bwd(raw, kin, rate_in)
         Fm, Pm, W2m, vm, qp, al = f64(F, B, R, D), f64(P, B, R, A), f64(W2, U, A), f64(v, A)[:, None], f64(qpre, B, A), f64(alpha, B, R)
         q = O.act_fwd(qp, O.ACT_LEAKY, slope)
         s = np.tanh(Pm + q[:, None, :])
@@ -337,6 +347,6 @@ class MockBackend:
         flat(dqpre)[:B * A] = dq.reshape(-1)
         flat(dh)[:B * U] = (dq @ W2m.T).reshape(-1)
 
-    def attention_metric(self, alpha, out, T, B, R):
+    def attention_metric(self, alpha, out, work, T, B, R):
         al = flat(alpha)[:T * B * R].reshape(T, B, R).astype(np.float64)
         flat(out)[0] = ((1 - al.sum(1)) ** 2).mean()

@@ -1,0 +1,104 @@
+"""Data-parallel path on CPU: world_size 2 over gloo, mock kernel backend.
+Contract (dp.py): G ranks x local batch == one rank on the concatenated batch (LayerNorm
+encoder, since BatchNorm statistics are per replica by design), replicas stay identical."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DIMS = dict(B=4, N=23, T=5, V=13, U=16, E=10)
+
+
+def _worker(rank, world, port, kind, q):
+    sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import masters_thesis_amd.ops as ops
+    from masters_thesis_amd import dp
+    from masters_thesis_amd.optimizers import Adam
+    from mock_backend import MockBackend
+    from helpers import synth_batch
+    ops.set_backend(MockBackend())
+    model = _make(kind, seed=100 + rank)           # different init per rank: broadcast must fix it
+    model.compile(Adam(1e-3, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    dp.attach(model)
+    rng = np.random.default_rng(7)
+    out = []
+    for step in range(2):
+        data, tgt = _global_batch(rng, world)
+        sl = slice(rank * DIMS["B"], (rank + 1) * DIMS["B"])
+        local = tuple(a[sl] for a in data)
+        m = model.train_step((local, tgt[sl]))
+        out.append({k: float(v) for k, v in dp.allreduce_metrics(m).items()})
+    q.put((rank, {k: v for k, v in model.get_weights_dict().items()}, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _make(kind, seed, **kw):
+    d = DIMS
+    if kind == "nic":
+        from masters_thesis_amd.nic import NIC
+        return NIC(d["N"], d["U"], d["E"], d["V"], d["T"], 0.0, 0.2, 0.2, 0.01, 3e-5, 1e-5, norm="layer", device="cpu",
+                   seed=seed, **kw)
+    from masters_thesis_amd.lc_nic import NIC
+    from helpers import tiny_groups
+    g = (tiny_groups(d["N"], 4, np.random.default_rng(3)), [16] * 4)
+    return NIC(g, d["U"], 512, d["E"], 6, d["V"], d["T"], 0, 0, 0, 0, 0, 0, 0.01, 0.001, 3e-5, 1e-5, norm="layer",
+               device="cpu", seed=seed, **kw)
+
+
+def _global_batch(rng, world):
+    from helpers import synth_batch
+    d = DIMS
+    return synth_batch(world * d["B"], d["N"], d["T"], d["V"], d["U"], rng)
+
+
+@pytest.mark.parametrize("kind", ["nic", "lcnic"])
+def test_dp2_equals_single_process(kind):
+    world, port = 2, 29500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in range(world):
+        r, w, out = q.get(timeout=120)
+        res[r] = (w, out)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # replicas identical
+    for k in res[0][0]:
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
+    # single process on the concatenated batch (rank 0's initial weights = seed 100)
+    sys.path.insert(0, HERE)
+    import masters_thesis_amd.ops as ops
+    from masters_thesis_amd.optimizers import Adam
+    from mock_backend import MockBackend
+    old = ops._backend
+    ops.set_backend(MockBackend())
+    try:
+        ref = _make(kind, seed=100)
+        ref.compile(Adam(1e-3, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+        rng = np.random.default_rng(7)
+        for step in range(2):
+            data, tgt = _global_batch(rng, world)
+            m = ref.train_step((data, tgt)).as_floats()
+            if kind == "nic":        # no dropout-dependent terms in the rank-mean of loss for lcnic (rates 0)
+                pass
+            else:
+                assert abs(m["loss"] - res[0][1][step]["loss"]) < 1e-5
+        if kind == "lcnic":          # dropout-free: weights must match the single-process run
+            for k, v in ref.get_weights_dict().items():
+                if k == "attention/V/bias":
+                    continue
+                assert np.allclose(res[0][0][k], v, rtol=1e-4, atol=2e-6), k
+    finally:
+        ops.set_backend(old)

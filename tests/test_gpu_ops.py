@@ -128,6 +128,19 @@ def test_dropout_bit_exact(be, tmajor):
     assert np.array_equal(got, want)
 
 
+def test_dropout_rows_per_site(be):
+    rng = np.random.default_rng(21)
+    T, B, E, D, rate = 5, 6, 8, 4, 0.3
+    x = rng.standard_normal((T * B, E)).astype(np.float32)
+    xd, yd = dev(x), torch.zeros(T * B, E, device="cuda")
+    be.dropout(xd, yd, T * B, E, E, 0, D + E, D, rate, 99, 48, 2, None, rows_per_site=B)
+    scale = np.float32(1.0 / (1.0 - np.float32(rate)))
+    for i in range(T):
+        keep = keep_mask((B, D + E), rate, 99, 48 + i, 2)[:, D:]
+        want = np.where(keep, x[i * B:(i + 1) * B] * scale, 0).astype(np.float32)
+        assert np.array_equal(yd[i * B:(i + 1) * B].cpu().numpy(), want)
+
+
 # ------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("rows,C", [(64, 512), (1440, 32), (7, 5)])
 def test_batchnorm(be, rows, C):
@@ -405,6 +418,16 @@ def test_attention_step(be, B, R, D, A, U, rate):
     close(dvb[:, :A].sum(0), dv[:, 0], atol=1e-4 * (np.abs(dv).max() + 1))
     close(h.T @ dq.cpu().double().numpy(), dW2, atol=1e-4 * (np.abs(dW2).max() + 1))
     assert abs(dvb[:, A].sum().item()) < 1e-4
+    if U % 16 == 0:
+        # fused form: dctx_d = dz @ Wc^T computed inside the kernel
+        dz = rng.standard_normal((B, 4 * U)) * 0.3
+        Wc = rng.standard_normal((D, 4 * U)) / np.sqrt(4 * U)
+        dctx2 = O.dropout_bwd(dz @ Wc.T, keep_in, rate_in)
+        dh2, dF2, dsum2, _, _, _, _ = O.attention_step_bwd(dctx2, F, W2, v, cache)
+        dPd2, dFd2, dvb2 = torch.zeros(B, R, A, device="cuda"), torch.zeros(B, R, D, device="cuda"), torch.zeros(B, A + 1, device="cuda")
+        be.attention_step_bwd(None, Fd, Pd, W2d, vd, qpre, al, dPd2, dFd2, dvb2, dq, dhd, B, R, D, A, U, 0.2, rate,
+                              rate_in, lw, seed, site_a, site_i, step, None, dev(dz), dev(Wc))
+        close(dhd, dh2); close(dPd2, dsum2); close(dFd2, dF2)
 
 
 def test_attention_metric(be):
@@ -412,5 +435,5 @@ def test_attention_metric(be):
     T, B, R = 5, 8, 30
     alpha = O.softmax(rng.standard_normal((T, B, R)), axis=-1)
     out = torch.zeros(1, device="cuda")
-    be.attention_metric(dev(alpha), out, T, B, R)
+    be.attention_metric(dev(alpha), out, torch.zeros(T, device="cuda"), T, B, R)
     close(out, [((1 - alpha.sum(1)) ** 2).mean()])
