@@ -234,7 +234,8 @@ int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* F, const fl
 /* attention "coverage" metric (lc_NIC.py:365-367): mean over (T,R) of
  * (1 - sum_b alpha[t][b][r])^2.  alpha is [T][B][R]. */
 int32_t tnt_attention_metric_f32(const float* alpha, float* out, float* work /* T floats */,
-                                 int32_t T, int32_t B, int32_t R, void* stream);
+                                 int32_t T, int32_t B, int32_t R,
+                                 int64_t tstride /* floats between timesteps; 0 = B*R */, void* stream);
 
 #ifdef __cplusplus
 }

@@ -46,7 +46,7 @@ SIGNATURES = {
                                    I32, U64, U32, U32, U32, P, P],
     "tnt_attention_step_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, F32,
                                    I32, U64, U32, U32, U32, P, P, P, P],
-    "tnt_attention_metric_f32": [P, P, P, I32, I32, I32, P],
+    "tnt_attention_metric_f32": [P, P, P, I32, I32, I32, I64, P],
 }
 
 _lib = None

@@ -275,14 +275,15 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttArgs g) {
 }
 
 // one workgroup per timestep: partial[t] = sum_r (1 - sum_b alpha[t][b][r])^2
-__global__ __launch_bounds__(256) void attention_metric_kernel(const float* alpha, float* partial, int T, int B, int R) {
+__global__ __launch_bounds__(256) void attention_metric_kernel(const float* alpha, float* partial, int T, int B, int R,
+                                                               long tstride) {
   __shared__ float sw[4];
   const int t = blockIdx.x;
   float acc = 0.f;
   for (int r = threadIdx.x; r < R; r += 256) {
     float s = 0.f;
 #pragma unroll 8
-    for (int b = 0; b < B; ++b) s += alpha[((long)t * B + b) * R + r];
+    for (int b = 0; b < B; ++b) s += alpha[(long)t * tstride + (long)b * R + r];
     acc += (1.f - s) * (1.f - s);
   }
   acc = block_sum256(acc, sw);
@@ -352,8 +353,10 @@ extern "C" int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* 
 }
 
 extern "C" int32_t tnt_attention_metric_f32(const float* alpha, float* out, float* work, int32_t T, int32_t B,
-                                            int32_t R, void* stream) {
-  hipLaunchKernelGGL(attention_metric_kernel, dim3(T), dim3(256), 0, tnt_stream(stream), alpha, work, T, B, R);
+                                            int32_t R, int64_t tstride, void* stream) {
+  if (tstride <= 0) tstride = (int64_t)B * R;
+  hipLaunchKernelGGL(attention_metric_kernel, dim3(T), dim3(256), 0, tnt_stream(stream), alpha, work, T, B, R,
+                     (long)tstride);
   TNT_LAUNCH_CHECK();
   hipLaunchKernelGGL(attention_metric_final_kernel, dim3(1), dim3(64), 0, tnt_stream(stream), work, out, T,
                      1.f / ((float)T * (float)R));

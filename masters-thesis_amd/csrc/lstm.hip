@@ -43,11 +43,37 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwdArgs a) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) acc[g] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
+  // epilogue operands do not depend on the matmul: fetch them now, under the weight stream
+  const int erow = tid >> 4, ecol = tid & 15;
+  const int eb = rb * 16 + erow, eu = ub * 16 + ecol;
+  const bool eok = tid < 256 && eb < B;
+  const long ee = (long)eb * U + eu;
+  float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float cp = 0.f, hp = 0.f, op = 0.f;
+  int mid = 1;
+  if (eok) {
+    x4 = *reinterpret_cast<const float4*>(a.xz + ee * 4);
+    cp = a.c_prev[ee]; hp = a.h_prev[ee];
+    if (a.mask_ids) mid = a.mask_ids[eb * a.mask_T + a.mask_t];
+    if (a.out_prev) op = a.out_prev[ee];
+  }
+
   for (int ci = w; ci < nchunk; ci += NW) {
     const int kbase = ci * 64 + kq * 16;
     float av[16];
     float4 bv[16];
-    if (kbase < U) {
+    if (ci * 64 + 64 <= U) {
+      // whole chunk inside the recurrent part: k = ci*64 + 16*(s>>2) + 4*kq + (s&3), so that one
+      // load instruction reads 64 contiguous bytes per row (4 lanes x 16 B) instead of 16-B pieces
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 t = ld4g(a.h_prev + (long)arow * U + ci * 64 + j * 16 + kq * 4, arow < B);
+        av[4 * j + 0] = t.x; av[4 * j + 1] = t.y; av[4 * j + 2] = t.z; av[4 * j + 3] = t.w;
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        bv[s] = ld4g(a.Ur + ((long)(ci * 64 + (s >> 2) * 16 + kq * 4 + (s & 3)) * U + ucol) * 4, true);
+    } else if (kbase < U) {
       // recurrent part: U % 16 == 0, so the 16-run never straddles U
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -79,31 +105,25 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[w][g][kq * 4 + r][lr] = acc[g][r];
   __syncthreads();
-  if (tid < 256) {
-    const int row = tid >> 4, col = tid & 15;
-    const int b = rb * 16 + row, u = ub * 16 + col;
-    if (b < B) {
-      const long e = (long)b * U + u;
-      const float4 x4 = *reinterpret_cast<const float4*>(a.xz + e * 4);
-      float z[4] = {x4.x, x4.y, x4.z, x4.w};
+  if (eok) {
+    const int row = erow, col = ecol;
+    const long e = ee;
+    float z[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float s = 0.f;
+    for (int g = 0; g < 4; ++g) {
+      float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < NW; ++k) s += red[k][g][row][col];
-        z[g] += s;
-      }
-      const float gi = tnt_sigmoid(z[0]), gf = tnt_sigmoid(z[1]), gg = tanhf(z[2]), go = tnt_sigmoid(z[3]);
-      const float cp = a.c_prev[e], hp = a.h_prev[e];
-      const float c2 = gf * cp + gi * gg;
-      const float h2 = go * tanhf(c2);
-      bool m = true;
-      if (a.mask_ids) m = a.mask_ids[b * a.mask_T + a.mask_t] != 0;
-      a.h[e] = m ? h2 : hp;
-      a.c[e] = m ? c2 : cp;
-      if (a.out) a.out[e] = m ? h2 : (a.out_prev ? a.out_prev[e] : 0.f);
-      *reinterpret_cast<float4*>(a.gates + e * 4) = make_float4(gi, gf, gg, go);
+      for (int k = 0; k < NW; ++k) s += red[k][g][row][col];
+      z[g] += s;
     }
+    const float gi = tnt_sigmoid(z[0]), gf = tnt_sigmoid(z[1]), gg = tanhf(z[2]), go = tnt_sigmoid(z[3]);
+    const float c2 = gf * cp + gi * gg;
+    const float h2 = go * tanhf(c2);
+    const bool m = mid != 0;
+    a.h[e] = m ? h2 : hp;
+    a.c[e] = m ? c2 : cp;
+    if (a.out) a.out[e] = m ? h2 : op;
+    *reinterpret_cast<float4*>(a.gates + e * 4) = make_float4(gi, gf, gg, go);
   }
 }
 
@@ -121,62 +141,78 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdArgs a) {
   const int ub = blockIdx.x, rb = blockIdx.y;
   const int U = a.U, B = a.B, K = 4 * a.U;
   floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+  // epilogue operands do not depend on the matmul: fetch them now, under the weight stream
+  const int erow = tid >> 4, ecol = tid & 15;
+  const int eb = rb * 16 + erow, eu = ub * 16 + ecol;
+  const bool eok = tid < 256 && eb < B;
+  const long e = (long)eb * U + eu;
+  float da0 = 0.f, dout = 0.f, dcin = 0.f, cval = 0.f, cprev = 0.f;
+  float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  int mid = 1;
+  if (eok) {
+    if (a.da_pass_in) da0 += a.da_pass_in[e];
+    if (a.dh_ext) da0 += a.dh_ext[e];
+    if (a.dout_in) dout += a.dout_in[e];
+    if (a.dout_t) dout += a.dout_t[e];
+    if (a.dc_in) dcin = a.dc_in[e];
+    if (a.mask_ids) mid = a.mask_ids[eb * a.mask_T + a.mask_t];
+    g4 = *reinterpret_cast<const float4*>(a.gates + e * 4);
+    cval = a.c[e]; cprev = a.c_prev[e];
+  }
   if (a.dz_next) {
     const int arow = rb * 16 + lr, ucol = ub * 16 + lr;
     const int nchunk = K / 64;   // U % 16 == 0  =>  4U % 64 == 0
-    for (int ci = w; ci < nchunk; ci += NW) {
-      const int kbase = ci * 64 + kq * 16;
-      float av[16], bv[16];
+    // 4 chunks per pass: all 32 16-byte loads of a pass are in flight before the first MFMA
+    for (int c0 = w; c0 < nchunk; c0 += NW * 4) {
+      float4 ta[4][4], tb[4][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 t = ld4g(a.dz_next + (long)arow * K + kbase + 4 * j, arow < B);
-        av[4 * j + 0] = t.x; av[4 * j + 1] = t.y; av[4 * j + 2] = t.z; av[4 * j + 3] = t.w;
-        const float4 q = ld4g(a.Ur + (long)ucol * K + kbase + 4 * j, true);
-        bv[4 * j + 0] = q.x; bv[4 * j + 1] = q.y; bv[4 * j + 2] = q.z; bv[4 * j + 3] = q.w;
+      for (int cc = 0; cc < 4; ++cc) {
+        const int ci = c0 + cc * NW;
+        const int kbase = ci * 64 + kq * 4;      // + 16*j: 64 contiguous bytes per row per instruction
+        const bool cok = ci < nchunk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ta[cc][j] = ld4g(a.dz_next + (long)arow * K + kbase + 16 * j, cok && arow < B);
+          tb[cc][j] = ld4g(a.Ur + (long)ucol * K + kbase + 16 * j, cok);
+        }
       }
 #pragma unroll
-      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+      for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[cc][j].x, tb[cc][j].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[cc][j].y, tb[cc][j].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[cc][j].z, tb[cc][j].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[cc][j].w, tb[cc][j].w, acc, 0, 0, 0);
+        }
     }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[w][kq * 4 + r][lr] = acc[r];
   __syncthreads();
-  if (tid < 256) {
-    const int row = tid >> 4, col = tid & 15;
-    const int b = rb * 16 + row, u = ub * 16 + col;
-    if (b < B) {
-      const long e = (long)b * U + u;
-      float da = 0.f;
+  if (eok) {
+    float da = da0;
 #pragma unroll
-      for (int k = 0; k < NW; ++k) da += red[k][row][col];
-      if (a.da_pass_in) da += a.da_pass_in[e];
-      if (a.dh_ext) da += a.dh_ext[e];
-      float dout = 0.f;
-      if (a.dout_in) dout += a.dout_in[e];
-      if (a.dout_t) dout += a.dout_t[e];
-      const float dcin = a.dc_in ? a.dc_in[e] : 0.f;
-      bool m = true;
-      if (a.mask_ids) m = a.mask_ids[b * a.mask_T + a.mask_t] != 0;
-      float4 dz4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      float dc_o = dcin, da_o = da, dout_o = dout;
-      if (m) {
-        const float4 g4 = *reinterpret_cast<const float4*>(a.gates + e * 4);
-        const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
-        const float tc = tanhf(a.c[e]);
-        const float dh = da + dout;
-        const float dgo = dh * tc;
-        const float dc = dcin + dh * go * (1.f - tc * tc);
-        dz4.x = dc * gg * gi * (1.f - gi);
-        dz4.y = dc * a.c_prev[e] * gf * (1.f - gf);
-        dz4.z = dc * gi * (1.f - gg * gg);
-        dz4.w = dgo * go * (1.f - go);
-        dc_o = dc * gf; da_o = 0.f; dout_o = 0.f;
-      }
-      *reinterpret_cast<float4*>(a.dz + e * 4) = dz4;
-      if (a.dc_out) a.dc_out[e] = dc_o;
-      if (a.da_pass_out) a.da_pass_out[e] = da_o;
-      if (a.dout_out) a.dout_out[e] = dout_o;
+    for (int k = 0; k < NW; ++k) da += red[k][erow][ecol];
+    const bool m = mid != 0;
+    float4 dz4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dc_o = dcin, da_o = da, dout_o = dout;
+    if (m) {
+      const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
+      const float tc = tanhf(cval);
+      const float dh = da + dout;
+      const float dgo = dh * tc;
+      const float dc = dcin + dh * go * (1.f - tc * tc);
+      dz4.x = dc * gg * gi * (1.f - gi);
+      dz4.y = dc * cprev * gf * (1.f - gf);
+      dz4.z = dc * gi * (1.f - gg * gg);
+      dz4.w = dgo * go * (1.f - go);
+      dc_o = dc * gf; da_o = 0.f; dout_o = 0.f;
     }
+    *reinterpret_cast<float4*>(a.dz + e * 4) = dz4;
+    if (a.dc_out) a.dc_out[e] = dc_o;
+    if (a.da_pass_out) a.da_pass_out[e] = da_o;
+    if (a.dout_out) a.dout_out[e] = dout_o;
   }
 }
 

@@ -24,6 +24,9 @@ import torch
 from .arena import ParamArena
 from .model_base import (ModelBase, Metrics, interleave_gates, deinterleave_gates, S_IN, S_FEAT, S_TEXT, S_OUT, S_ATTN,
                          S_LSTM_IN, S_LSTM_OUT, BN_EPS, BN_MOMENTUM)
+
+SUBJ_SITE = 1000      # dropout-site offset per subject (multi-subject model)
+S_FEAT2 = 4           # second application of the feature dropout (ms2_NIC.py:214)
 from .ops import ACT_LEAKY
 
 
@@ -54,8 +57,13 @@ class NIC(ModelBase):
 
     def __init__(self, groups, units, embedding_features, embedding_text, attn_units, vocab_size, max_length,
                  dropout_input, dropout_features, dropout_text, dropout_attn, dropout_lstm, dropout_out, input_reg,
-                 attn_reg, lstm_reg, output_reg, norm="batch", **kw):
+                 attn_reg, lstm_reg, output_reg, norm="batch", n_subjects=1, **kw):
         super().__init__(**kw)
+        # n_subjects > 1: AttemptFour/Model/ms2_NIC.py generalised to S subjects -- one region-wise
+        # encoder (+ its own BatchNorm) per subject on S equal batch slices, shared decoder.
+        self.S = int(n_subjects)
+        self.enc_name = (lambda q: "dense_in") if self.S == 1 else (lambda q: f"dense_in_{q}")
+        self.bn_name = (lambda q: "input_bn") if self.S == 1 else (lambda q: f"input_bn_{q}")
         in_groups, out_groups = groups
         assert len(in_groups) == len(out_groups), "Input groups don't match ouput groups"   # layers.py:30
         self.groups = [np.asarray(g, dtype=np.int64) for g in in_groups]
@@ -80,13 +88,15 @@ class NIC(ModelBase):
         self.idx = torch.tensor(np.concatenate(self.groups).astype(np.int32), dtype=torch.int32, device=self.device)
         ls = OrderedDict()
         ks = OrderedDict()
-        for r, g in enumerate(self.groups):
-            ls[f"dense_in/{r}"] = ["kernel", "bias"]
-            ks[f"dense_in/{r}/kernel"] = (len(g), D)
-            ks[f"dense_in/{r}/bias"] = (D,)
-        ls["input_bn"] = ["gamma", "beta", "moving_mean", "moving_variance"]
-        for w in ls["input_bn"]:
-            ks[f"input_bn/{w}"] = (D,)
+        for q in range(self.S):
+            en, bn = self.enc_name(q), self.bn_name(q)
+            for r, g in enumerate(self.groups):
+                ls[f"{en}/{r}"] = ["kernel", "bias"]
+                ks[f"{en}/{r}/kernel"] = (len(g), D)
+                ks[f"{en}/{r}/bias"] = (D,)
+            ls[bn] = ["gamma", "beta", "moving_mean", "moving_variance"]
+            for w in ls[bn]:
+                ks[f"{bn}/{w}"] = (D,)
         for nm, shp in (("attention/W1", (D, A)), ("attention/W2", (U, A)), ("attention/V", (A, 1))):
             ls[nm] = ["kernel", "bias"]
             ks[f"{nm}/kernel"] = shp
@@ -102,15 +112,18 @@ class NIC(ModelBase):
         self.layers_spec, self.keras_shapes = ls, ks
 
         a = self.arena = ParamArena(self.device)
-        for r, g in enumerate(self.groups):                      # contiguous CSR concatenation
-            a.add(f"dense_in/{r}/kernel", (len(g), D), self.l2_in, align=4)
-        self.enc_w_off = a.entries["dense_in/0/kernel"].off
-        a.total = (a.total + 63) // 64 * 64
-        for r in range(R):
-            a.add(f"dense_in/{r}/bias", (D,), align=4)
-        self.enc_b_off = a.entries["dense_in/0/bias"].off
-        a.total = (a.total + 63) // 64 * 64
-        a.add("input_bn/gamma", (D,)); a.add("input_bn/beta", (D,))
+        enc_off = []
+        for q in range(self.S):
+            en, bn = self.enc_name(q), self.bn_name(q)
+            for r, g in enumerate(self.groups):                  # contiguous CSR concatenation
+                a.add(f"{en}/{r}/kernel", (len(g), D), self.l2_in, align=4)
+            w_off = a.entries[f"{en}/0/kernel"].off
+            a.total = (a.total + 63) // 64 * 64
+            for r in range(R):
+                a.add(f"{en}/{r}/bias", (D,), align=4)
+            enc_off.append((w_off, a.entries[f"{en}/0/bias"].off))
+            a.total = (a.total + 63) // 64 * 64
+            a.add(f"{bn}/gamma", (D,)); a.add(f"{bn}/beta", (D,))
         a.add("attention/W1/kernel", (D, A), self.l2_attn); a.add("attention/W1/bias", (A,))
         a.add("attention/W2/kernel", (U, A), self.l2_attn); a.add("attention/W2/bias", (A,))
         a.add("attention/V/kernel", (A,)); a.add("attention/V/bias", (1,))
@@ -122,9 +135,12 @@ class NIC(ModelBase):
         a.add("time_distributed_softmax/bias", (self.ldV,))
         a.finalize()
         nW = int(self.goff_host[-1]) * D
-        self.encW, self.encWg = a.theta[self.enc_w_off:self.enc_w_off + nW], a.grad[self.enc_w_off:self.enc_w_off + nW]
-        self.encB, self.encBg = a.theta[self.enc_b_off:self.enc_b_off + R * D], a.grad[self.enc_b_off:self.enc_b_off + R * D]
-        self.mov_mean, self.mov_var = self._f(D), torch.ones(D, dtype=torch.float32, device=self.device)
+        self.encW = [a.theta[w:w + nW] for w, _ in enc_off]
+        self.encWg = [a.grad[w:w + nW] for w, _ in enc_off]
+        self.encB = [a.theta[b:b + R * D] for _, b in enc_off]
+        self.encBg = [a.grad[b:b + R * D] for _, b in enc_off]
+        self.mov_mean = [self._f(D) for _ in range(self.S)]
+        self.mov_var = [torch.ones(D, dtype=torch.float32, device=self.device) for _ in range(self.S)]
         self.drop_step = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._init_weights(np.random.default_rng(self.seed))
         self._shape = None
@@ -134,9 +150,10 @@ class NIC(ModelBase):
         """Initialisers of lc_NIC.py:84-159 / attention.py:21-23."""
         D, A, U, Et, V, H = self.D, self.A, self.U, self.Et, self.V, self.H
         tn = lambda shape, std: np.clip(rng.standard_normal(shape), -2, 2) * std / 0.8796
-        for r, g in enumerate(self.groups):
-            self.set_weight(f"dense_in/{r}/kernel", tn((len(g), D), np.sqrt(2.0 / max(len(g), 1))))   # he_normal
-        self.set_weight("input_bn/gamma", np.ones(D))
+        for q in range(self.S):
+            for r, g in enumerate(self.groups):
+                self.set_weight(f"{self.enc_name(q)}/{r}/kernel", tn((len(g), D), np.sqrt(2.0 / max(len(g), 1))))  # he_normal
+            self.set_weight(f"{self.bn_name(q)}/gamma", np.ones(D))
         self.set_weight("attention/W1/kernel", tn((D, A), np.sqrt(2.0 / D)))
         self.set_weight("attention/W2/kernel", tn((U, A), np.sqrt(2.0 / U)))
         lim = np.sqrt(6.0 / (A + 1))
@@ -154,10 +171,11 @@ class NIC(ModelBase):
     def set_weight(self, name, arr):
         arr = np.asarray(arr, dtype=np.float32)
         assert tuple(arr.shape) == tuple(self.keras_shapes[name]), (name, arr.shape, self.keras_shapes[name])
-        if name == "input_bn/moving_mean":
-            self.mov_mean.copy_(torch.from_numpy(arr)); return
-        if name == "input_bn/moving_variance":
-            self.mov_var.copy_(torch.from_numpy(arr)); return
+        for q in range(self.S):
+            if name == f"{self.bn_name(q)}/moving_mean":
+                self.mov_mean[q].copy_(torch.from_numpy(arr)); return
+            if name == f"{self.bn_name(q)}/moving_variance":
+                self.mov_var[q].copy_(torch.from_numpy(arr)); return
         dst = self.arena.p(name)
         if name.startswith("lstm/"):
             arr = interleave_gates(arr, self.U)
@@ -178,17 +196,18 @@ class NIC(ModelBase):
         return arr.reshape(self.keras_shapes[name]).copy()
 
     def get_weight(self, name):
-        if name == "input_bn/moving_mean":
-            return self.mov_mean.cpu().numpy().copy()
-        if name == "input_bn/moving_variance":
-            return self.mov_var.cpu().numpy().copy()
+        for q in range(self.S):
+            if name == f"{self.bn_name(q)}/moving_mean":
+                return self.mov_mean[q].cpu().numpy().copy()
+            if name == f"{self.bn_name(q)}/moving_variance":
+                return self.mov_var[q].cpu().numpy().copy()
         return self._unpack(name, self.arena.p(name))
 
     def get_gradient(self, name):
         return self._unpack(name, self.arena.g(name))
 
     def state_tensors(self):
-        return [self.mov_mean, self.mov_var]
+        return list(self.mov_mean) + list(self.mov_var)
 
     @property
     def losses(self):
@@ -200,8 +219,9 @@ class NIC(ModelBase):
     def _build(self, B, T):
         if self._shape == (B, T):
             return
-        if B > 64:
-            raise ValueError("the region-wise encoder kernel handles at most 64 samples per call (per GPU)")
+        if B % self.S or B // self.S > 64:
+            raise ValueError("batch must split into n_subjects equal slices of at most 64 samples "
+                             "(region-wise encoder kernel limit per call)")
         f = self._f
         R, D, A, U, Et, V, H, ldV = self.R, self.D, self.A, self.U, self.Et, self.V, self.H, self.ldV
         n = T * B
@@ -211,7 +231,7 @@ class NIC(ModelBase):
         self.cap = torch.zeros(B, T, dtype=torch.int32, device=self.device)
         self.tgt = torch.zeros(n, dtype=torch.int32, device=self.device)
         self.enc_pre, self.enc_y = f(B, R, D), f(B, R, D)
-        self.xhat, self.inv_std = f(B * R, D), f(max(B * R, D))
+        self.xhat, self.inv_std = f(B * R, D), f(self.S, max(B * R, D))
         self.F = f(B, R, D)
         self.text = f(n, Et)
         self.XZ = f(n, U, 4)
@@ -225,7 +245,8 @@ class NIC(ModelBase):
         self.inter_d = f(n, H) if self.r_out > 0 else self.inter
         self.logits = f(n, ldV)
         self.loss_row, self.corr_row = f(n), f(n)
-        self.met = f(8)
+        self.met = f(8 + 4 * self.S)
+        self.colB = f(2 * B)
         # backward
         self.dinter, self.dHs = f(n, H), f(n, U)
         self.dZ = f(n, U, 4)
@@ -265,21 +286,31 @@ class NIC(ModelBase):
     def _encode(self, B, training):
         """dropout_input -> layers.LocallyDense.call (lc_NIC.py:227-230; layers.py:43-53)."""
         be, a = self.be, self.arena
-        R, D = self.R, self.D
+        R, D, S = self.R, self.D, self.S
         sd, ds = self.seed, self.drop_step
-        x = self.x
-        if training and self.r_in > 0:
-            be.dropout(self.x, self.xd, B, self.n_in, self.ldx, 0, self.n_in, 0, self.r_in, sd, S_IN, 0, ds)
-            x = self.xd
-        be.locally_dense_fwd(x, self.ldx, self.idx, self.goff, self.encW, self.encB, self.enc_pre, self.enc_y, B, R, D, 0.2)
-        if self.norm == "batch":
-            be.batchnorm_fwd(self.enc_y, a.p("input_bn/gamma"), a.p("input_bn/beta"), self.mov_mean, self.mov_var,
-                             self.F, self.xhat, self.inv_std, B * R, D, D, training, BN_EPS, BN_MOMENTUM, self.work)
-        else:
-            be.layernorm_fwd(self.enc_y, a.p("input_bn/gamma"), a.p("input_bn/beta"), self.F, self.xhat, self.inv_std,
-                             B * R, D, D, BN_EPS)
-        if training and self.r_feat > 0:
-            be.dropout(self.F, self.F, B * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT, 0, ds)
+        Bs = B // S
+        for q in range(S):                       # one encoder per subject on its batch slice (ms2_NIC.py:181-203)
+            off = SUBJ_SITE * (q + 1) if S > 1 else 0
+            r0, r1 = q * Bs, (q + 1) * Bs
+            x = self.x[r0:r1]
+            if training and self.r_in > 0:
+                be.dropout(x, self.xd[r0:r1], Bs, self.n_in, self.ldx, 0, self.n_in, 0, self.r_in, sd, S_IN + off, 0, ds)
+                x = self.xd[r0:r1]
+            be.locally_dense_fwd(x, self.ldx, self.idx, self.goff, self.encW[q], self.encB[q], self.enc_pre[r0:r1],
+                                 self.enc_y[r0:r1], Bs, R, D, 0.2)
+            bn = self.bn_name(q)
+            Fq, xh = self.F[r0:r1], self.xhat[r0 * R:r1 * R]
+            if self.norm == "batch":
+                be.batchnorm_fwd(self.enc_y[r0:r1], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), self.mov_mean[q],
+                                 self.mov_var[q], Fq, xh, self.inv_std[q], Bs * R, D, D, training, BN_EPS, BN_MOMENTUM,
+                                 self.work)
+            else:
+                be.layernorm_fwd(self.enc_y[r0:r1], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), Fq, xh, self.inv_std[q],
+                                 Bs * R, D, D, BN_EPS)
+            if training and self.r_feat > 0:
+                be.dropout(Fq, Fq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT + off, 0, ds)        # layers.py:51
+                if S > 1:                        # ms2_NIC.py:214,257: the feature Dropout is applied a second time
+                    be.dropout(Fq, Fq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT2 + off, 0, ds)
         be.gemm(self.F, a.p("attention/W1/kernel"), self.P, B * R, self.A, D, D, self.A, self.A,
                 bias=a.p("attention/W1/bias"), pre=self.Ppre, act=ACT_LEAKY, slope=0.2)      # attention.py:32 (hoisted)
 
@@ -339,7 +370,18 @@ class NIC(ModelBase):
                            0.0)
         be.sum(self.loss_row, self.met[0:1], n, 1.0 / n)
         be.sum(self.corr_row, self.met[1:2], n, 1.0 / n)
-        be.attention_metric(self.alpha, self.met[3:4], self.rowsq, T, B, self.R)                            # :365-367
+        if self.S == 1:
+            be.attention_metric(self.alpha, self.met[3:4], self.rowsq, T, B, self.R)                        # :365-367
+        else:       # per-subject loss / accuracy / attention metric (ms2_NIC.py:324-372)
+            S, Bs = self.S, B // self.S
+            be.colsum(self.loss_row, self.colB[:B], T, B, B, self.work)
+            be.colsum(self.corr_row, self.colB[B:], T, B, B, self.work)
+            for q in range(S):
+                k = 8 + 4 * q
+                be.sum(self.colB[q * Bs:], self.met[k:k + 1], Bs, 1.0 / (Bs * T))
+                be.sum(self.colB[B + q * Bs:], self.met[k + 1:k + 2], Bs, 1.0 / (Bs * T))
+                be.attention_metric(self.alpha.view(-1)[q * Bs * self.R:], self.met[k + 2:k + 3], self.rowsq, T, Bs,
+                                    self.R, B * self.R)
 
     # ------------------------------------------------------------------ backward
     def _backward(self, B, T):
@@ -398,17 +440,26 @@ class NIC(ModelBase):
         be.colsum(self.dP, a.g("attention/W1/bias"), B * R, A, A, self.work)
         be.gemm(self.dP, a.p("attention/W1/kernel"), self.dF, B * R, D, A, A, A, D, transB=True, accumulate=True)
         # encoder
-        if self.r_feat > 0:
-            be.dropout(self.dF, self.dF, B * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT, 0, ds)
-        if self.norm == "batch":
-            be.batchnorm_bwd(self.dF, self.xhat, a.p("input_bn/gamma"), self.inv_std, self.dbn, a.g("input_bn/gamma"),
-                             a.g("input_bn/beta"), B * R, D, D, True, self.work)
-        else:
-            be.layernorm_bwd(self.dF, self.xhat, a.p("input_bn/gamma"), self.inv_std, self.dbn, a.g("input_bn/gamma"),
-                             a.g("input_bn/beta"), B * R, D, D, self.work)
-        be.act_bwd(self.enc_pre, self.dbn, self.dbn, B * R * D, ACT_LEAKY, 0.2)
-        x = self.xd if self.r_in > 0 else self.x
-        be.locally_dense_bwd(x, self.ldx, self.idx, self.goff, self.dbn, self.encWg, self.encBg, B, R, D)
+        S = self.S
+        Bs = B // S
+        for q in range(S):
+            off = SUBJ_SITE * (q + 1) if S > 1 else 0
+            r0, r1 = q * Bs, (q + 1) * Bs
+            dFq, xh, dbn = self.dF[r0:r1], self.xhat[r0 * R:r1 * R], self.dbn[r0 * R:r1 * R]
+            if self.r_feat > 0:
+                if S > 1:
+                    be.dropout(dFq, dFq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT2 + off, 0, ds)
+                be.dropout(dFq, dFq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT + off, 0, ds)
+            bn = self.bn_name(q)
+            if self.norm == "batch":
+                be.batchnorm_bwd(dFq, xh, a.p(f"{bn}/gamma"), self.inv_std[q], dbn, a.g(f"{bn}/gamma"),
+                                 a.g(f"{bn}/beta"), Bs * R, D, D, True, self.work)
+            else:
+                be.layernorm_bwd(dFq, xh, a.p(f"{bn}/gamma"), self.inv_std[q], dbn, a.g(f"{bn}/gamma"),
+                                 a.g(f"{bn}/beta"), Bs * R, D, D, self.work)
+            be.act_bwd(self.enc_pre[r0:r1], dbn, dbn, Bs * R * D, ACT_LEAKY, 0.2)
+            x = (self.xd if self.r_in > 0 else self.x)[r0:r1]
+            be.locally_dense_bwd(x, self.ldx, self.idx, self.goff, dbn, self.encWg[q], self.encBg[q], Bs, R, D)
 
     # ------------------------------------------------------------------ steps
     def _train_graph(self, B, T):
@@ -422,7 +473,13 @@ class NIC(ModelBase):
 
     def _metrics(self, with_lr):
         m = self.met.clone()
-        out = Metrics(loss=m[0], L2=m[2], accuracy=m[1], attention=m[3])
+        if self.S == 1:
+            out = Metrics(loss=m[0], L2=m[2], accuracy=m[1], attention=m[3])
+        else:       # keys of ms2_NIC.train_step's return dict (ms2_NIC.py:366-374), A, B, C ... per subject
+            out = Metrics(loss=m[0], L2=m[2])
+            for q in range(self.S):
+                tag, k = chr(ord("A") + q), 8 + 4 * q
+                out[f"loss{tag}"], out[f"accuracy{tag}"], out[f"attention{tag}"] = m[k], m[k + 1], m[k + 2]
         if with_lr:
             out["lr"] = self.lr_dev.clone()[0]
         return out
@@ -448,10 +505,15 @@ class NIC(ModelBase):
         B, T = self._stage_inputs(data[0])
         self._stage_target(data[1], B, T)
 
+        # ms2_NIC.test_step calls its sub-models with training=True (ms2_NIC.py:419,426) -- quirk kept
+        train_flag = self.S > 1
+
         def run():
-            self._forward(B, T, False)
+            self._forward(B, T, train_flag)
             self._loss_metrics(B, T, False)
             self._norms_and_l2(self.met[2:3])
+            if train_flag:
+                self.be.step_tick(None, self.drop_step, None, None, 0.0, 0.0)
         self._run_captured(("test", B, T), run)
         return self._metrics(False)
 

@@ -153,8 +153,8 @@ class HipBackend:
                                                        step, _p(step_dev), _p(dz), _p(Wc), self._s()),
                    "tnt_attention_step_bwd_f32")
 
-    def attention_metric(self, alpha, out, work, T, B, R):
-        _lib.check(self.lib.tnt_attention_metric_f32(_p(alpha), _p(out), _p(work), T, B, R, self._s()),
+    def attention_metric(self, alpha, out, work, T, B, R, tstride=0):
+        _lib.check(self.lib.tnt_attention_metric_f32(_p(alpha), _p(out), _p(work), T, B, R, tstride, self._s()),
                    "tnt_attention_metric_f32")
 
 

@@ -349,6 +349,15 @@ class LcNIC:
         B, T = ids.shape
         drop = drop or DropCtx(training=training)
         F, enc = self._encode(x, training, drop)
+        out, cache = self._decode_fwd(F, ids, a0, c0, training, drop)
+        cache['enc'] = enc
+        return out, cache
+
+    def _decode_fwd(self, F, ids, a0, c0, training, drop):
+        """Everything of call_attention after the encoder (lc_NIC.py:233-263)."""
+        p = self.p
+        dt = p['lstm/kernel'].dtype
+        B, T = ids.shape
         emb = O.embedding_fwd(p['emb_text/embeddings'], ids)
         k_text = drop.mask(emb.shape, self.r_text, S_TEXT)
         text = O.dropout_fwd(emb, k_text, self.r_text)                              # :233
@@ -377,7 +386,7 @@ class LcNIC:
         logits = inter_d @ p['time_distributed_softmax/kernel'] + p['time_distributed_softmax/bias']
         probs = O.softmax(logits, axis=-1)                                          # :261
         attn = np.stack(alphas, axis=0)[..., None]                                  # (T,B,R,1) :263
-        cache = dict(enc=enc, F=F, P=P, Ppre=Ppre, k_text=k_text, steps=steps, Hs=Hs, ipre=ipre,
+        cache = dict(F=F, P=P, Ppre=Ppre, k_text=k_text, steps=steps, Hs=Hs, ipre=ipre,
                      k_out=k_out, inter_d=inter_d, ids=ids, logits=logits)
         return (probs, attn), cache
 
@@ -401,6 +410,11 @@ class LcNIC:
         return ce, acc, attn_loss
 
     def backward(self, probs, cache, y_ids):
+        g, sparse, dF = self._decode_bwd(probs, cache, y_ids)
+        self._encode_bwd(dF, cache['enc'], g)
+        return g, sparse
+
+    def _decode_bwd(self, probs, cache, y_ids):
         p = self.p
         B, T = y_ids.shape
         U, D = self.U, self.D
@@ -458,7 +472,10 @@ class LcNIC:
         rows, _ = O.embedding_bwd_rows(demb, cache['ids'])
         g['emb_text/embeddings'] = O.embedding_bwd_dense(demb, cache['ids'], self.V)
         sparse = {'emb_text/embeddings': np.sqrt((rows * rows).sum())}
-        enc = cache['enc']
+        return g, sparse, dF
+
+    def _encode_bwd(self, dF, enc, g, prefix=''):
+        p = self.p
         dbn = O.dropout_bwd(dF, enc['k_feat'], self.r_feat)
         if self.norm == 'batch':
             dy, dgam, dbet = O.batchnorm_bwd(dbn, p['input_bn/gamma'], enc['bn'])
@@ -469,7 +486,6 @@ class LcNIC:
         for r in range(self.R):
             g[f'dense_in/{r}/kernel'] = dWs[r] + 2 * self.l2_in * p[f'dense_in/{r}/kernel']
             g[f'dense_in/{r}/bias'] = dbs[r]
-        return g, sparse
 
     def train_step(self, data, y_ids, opt, drop=None):
         """lc_NIC.train_step (lc_NIC.py:328-408)."""

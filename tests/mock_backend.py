@@ -347,6 +347,7 @@ class MockBackend:
         flat(dqpre)[:B * A] = dq.reshape(-1)
         flat(dh)[:B * U] = (dq @ W2m.T).reshape(-1)
 
-    def attention_metric(self, alpha, out, work, T, B, R):
-        al = flat(alpha)[:T * B * R].reshape(T, B, R).astype(np.float64)
+    def attention_metric(self, alpha, out, work, T, B, R, tstride=0):
+        ts = tstride if tstride > 0 else B * R
+        al = np.lib.stride_tricks.as_strided(flat(alpha), (T, B, R), (ts * 4, R * 4, 4)).astype(np.float64)
         flat(out)[0] = ((1 - al.sum(1)) ** 2).mean()

@@ -1,0 +1,54 @@
+"""Multi-subject model (BASELINE config 5 shape family) on the GPU against the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as M
+from oracle.models_ms import MsLcNIC
+from helpers import synth_batch, tiny_groups
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("S,Bs,N,R,U,V,rates", [(2, 4, 300, 12, 32, 101, (0.1, 0.2, 0.2, 0.2, 0.2, 0.2)),
+                                                (4, 3, 200, 8, 16, 53, (0,) * 6)])
+def test_ms_train_parity(S, Bs, N, R, U, V, rates):
+    from masters_thesis_amd.ms_nic import NIC
+    from masters_thesis_amd.optimizers import Adam
+    rng = np.random.default_rng(71)
+    Dg, A, Et, T = 32, 16, 32, 6
+    g = (tiny_groups(N, R, rng), [Dg] * R)
+    args = (g, U, 512, Et, A, V, T, *rates, 0.01, 0.001, 3e-5, 1e-5)
+    orc = MsLcNIC(*args, n_subjects=S).init_params(rng)
+    model = NIC(*args, n_subjects=S, seed=11)
+    for k, v in orc.p.items():
+        model.set_weight(k, v)
+    model.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    opt = M.AdamState(orc.p, lr=1e-3, clipnorm=0.1)
+    for step in range(3):
+        data, tgt = synth_batch(S * Bs, N, T, V, U, rng)
+        res, _, _ = orc.train_step(data, tgt, opt, M.DropCtx(seed=11, step=step, training=True))
+        got = model.train_step((data, tgt)).as_floats()
+        for k in res:
+            assert abs(got[k] - res[k]) <= 1e-4 * abs(res[k]) + 1e-6, (step, k, got[k], res[k])
+        for k, v in orc.p.items():
+            if k == "attention/V/bias":
+                continue
+            w = model.get_weight(k)
+            assert np.abs(w - v).max() <= 2e-2 * 1e-3 + 1e-4 * np.abs(v).max(), (step, k)
+
+
+def test_ms_config5_shape():
+    """config 5: S=4 subjects x ~30k voxels, R=360 regions each, B=16 per subject (64 per GPU)."""
+    from masters_thesis_amd.ms_nic import NIC
+    from masters_thesis_amd.lc_nic import synthetic_groups
+    from masters_thesis_amd.optimizers import Adam
+    rng = np.random.default_rng(72)
+    S, Bs, N, T, V, U = 4, 16, 30000, 15, 5001, 512
+    groups = synthetic_groups(N, 360, 32, seed=42)
+    model = NIC(groups, U, 512, 512, 32, V, T, 0, 0.2, 0.2, 0.2, 0.2, 0.2, 0.01, 0.001, 3e-5, 1e-5, n_subjects=S, seed=5)
+    model.compile(Adam(1e-3, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    data, tgt = synth_batch(S * Bs, N, T, V, U, rng, min_len=7)
+    ls = [model.train_step((data, tgt)).as_floats() for _ in range(5)]
+    assert abs(ls[0]["loss"] - np.log(V)) < 0.5 and ls[-1]["loss"] < ls[0]["loss"]
+    assert abs(ls[0]["loss"] - np.mean([ls[0][f"loss{t}"] for t in "ABCD"])) < 1e-5
