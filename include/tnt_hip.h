@@ -147,10 +147,14 @@ int32_t tnt_lstm_step_bwd_f32(const float* dz_next, const float* Ur, const float
  * logits [rows][ld], V valid columns.  target ids int32[rows] (argmax of the one-hot).
  * probs (nullable, may alias logits): softmax.  loss_row/correct_row [rows]:
  * -log(clip(p_y/sum p, 1e-7, 1-1e-7)) and (argmax p == y).  dlogits (nullable, may
- * alias logits): (p - onehot)*gscale, zero rows where the clip is active. */
+ * alias logits): (p - onehot)*gscale, zero rows where the clip is active.
+ * from_logits=1: tf SparseCategoricalCrossentropy(from_logits=True) (ThinkAndTell/train.py:262-263):
+ * loss = logsumexp - x_y, no clipping.  mask_zero=1: rows whose target id is 0 give zero loss
+ * and zero gradient (CaptionGenerator.loss_function, ThinkAndTell/model.py:319-334). */
 int32_t tnt_softmax_cce_f32(const float* logits, const int32_t* target, float* probs,
                             float* loss_row, float* correct_row, float* dlogits,
-                            int32_t rows, int32_t V, int32_t ld, float gscale, void* stream);
+                            int32_t rows, int32_t V, int32_t ld, float gscale,
+                            int32_t from_logits, int32_t mask_zero, void* stream);
 /* target ids from a dense one-hot (B,T,V) float array: ids[t*B+b] = argmax_v. */
 int32_t tnt_onehot_argmax_f32(const float* onehot, int32_t* ids_tmajor, int32_t B, int32_t T,
                               int32_t V, void* stream);
@@ -184,6 +188,12 @@ int32_t tnt_sgd_f32(float* theta, float* mom, const float* grad, const int32_t* 
                     const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
                     const float* sq, const float* sq_override, int32_t nspan, float lr,
                     const float* lr_dev, float momentum, float clipnorm, void* stream);
+/* Sharpness-aware minimisation helper (CaptionGenerator.train_step_SAM, ThinkAndTell/model.py:166-233;
+ * lc_NIC.train_step_sam, lc_NIC.py:713-838).  mode 0: e_w = (g + 2 lambda theta) * rho/(||g||+1e-12)
+ * with ||g||^2 = sum_s sq[s] (from tnt_seg_sqnorm_f32); theta += e_w; e_w stored.  mode 1: theta -= e_w. */
+int32_t tnt_sam_f32(float* theta, const float* grad, float* ew, const int32_t* span_seg,
+                    const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
+                    const float* sq, int32_t nseg, int32_t nspan, float rho, int32_t mode, void* stream);
 /* device-resident step state, advanced inside the (captured) step:
  * adam_t += 1; lr_t = lr[0]*sqrt(1-b2^t)/(1-b1^t); drop_step += 1.  Pointers nullable. */
 int32_t tnt_step_tick(int64_t* adam_t, uint32_t* drop_step, const float* lr, float* lr_t,

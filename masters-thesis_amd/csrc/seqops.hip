@@ -135,7 +135,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // one 256-thread workgroup per row
 __global__ __launch_bounds__(256) void softmax_cce_kernel(const float* logits, const int* target, float* probs,
                                                           float* loss_row, float* correct_row, float* dlogits, int rows,
-                                                          int V, int ld, float gscale) {
+                                                          int V, int ld, float gscale, int from_logits, int mask_zero) {
   __shared__ ArgMax sha[4];
   __shared__ float shf[4];
   const int row = blockIdx.x;
@@ -155,10 +155,16 @@ __global__ __launch_bounds__(256) void softmax_cce_kernel(const float* logits, c
   const float Z = block_sum(s, shf);
   const float invZ = 1.f / Z;
   const float py = (y >= 0 && y < V) ? expf(xy - m) * invZ : 0.f;
-  const bool active = (py >= 1e-7f) && (py <= 1.f - 1e-7f);
+  // keras from_logits=False: clip(p, 1e-7, 1-1e-7), zero gradient where the clip is active.
+  // from_logits=True (SparseCategoricalCrossentropy, ThinkAndTell/train.py:262-263): lse - x_y, no clip.
+  // mask_zero: rows whose target id is 0 contribute neither loss nor gradient (model.py:319-334).
+  const bool live = !(mask_zero && y == 0);
+  const bool active = live && (from_logits || ((py >= 1e-7f) && (py <= 1.f - 1e-7f)));
   if (threadIdx.x == 0 && target) {
-    const float q = fminf(fmaxf(py, 1e-7f), 1.f - 1e-7f);
-    if (loss_row) loss_row[row] = -logf(q);
+    float l;
+    if (from_logits) l = logf(Z) + m - xy;
+    else l = -logf(fminf(fmaxf(py, 1e-7f), 1.f - 1e-7f));
+    if (loss_row) loss_row[row] = live ? l : 0.f;
     if (correct_row) correct_row[row] = (am.i == y) ? 1.f : 0.f;
   }
   // logits may alias probs/dlogits: every thread reads its own elements before overwriting them
@@ -229,10 +235,10 @@ extern "C" int32_t tnt_embedding_bwd_f32(const float* drows, const int32_t* ids,
 
 extern "C" int32_t tnt_softmax_cce_f32(const float* logits, const int32_t* target, float* probs, float* loss_row,
                                        float* correct_row, float* dlogits, int32_t rows, int32_t V, int32_t ld,
-                                       float gscale, void* stream) {
+                                       float gscale, int32_t from_logits, int32_t mask_zero, void* stream) {
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(softmax_cce_kernel, dim3(rows), dim3(256), 0, tnt_stream(stream), logits, target, probs, loss_row,
-                     correct_row, dlogits, rows, V, ld, gscale);
+                     correct_row, dlogits, rows, V, ld, gscale, from_logits, mask_zero);
   TNT_LAUNCH_CHECK();
   return 0;
 }

@@ -93,9 +93,11 @@ class HipBackend:
                                                   _p(c), _p(c_prev), _p(dz), _p(da_pass_out), _p(dc_out),
                                                   _p(dout_out), B, U, self._s()), "tnt_lstm_step_bwd_f32")
 
-    def softmax_cce(self, logits, target, probs, loss_row, correct_row, dlogits, rows, V, ld, gscale):
+    def softmax_cce(self, logits, target, probs, loss_row, correct_row, dlogits, rows, V, ld, gscale,
+                    from_logits=False, mask_zero=False):
         _lib.check(self.lib.tnt_softmax_cce_f32(_p(logits), _p(target), _p(probs), _p(loss_row), _p(correct_row),
-                                                _p(dlogits), rows, V, ld, gscale, self._s()), "tnt_softmax_cce_f32")
+                                                _p(dlogits), rows, V, ld, gscale, int(from_logits), int(mask_zero),
+                                                self._s()), "tnt_softmax_cce_f32")
 
     def onehot_argmax(self, onehot, ids_tmajor, B, T, V):
         _lib.check(self.lib.tnt_onehot_argmax_f32(_p(onehot), _p(ids_tmajor), B, T, V, self._s()),
@@ -124,6 +126,10 @@ class HipBackend:
         _lib.check(self.lib.tnt_sgd_f32(_p(theta), _p(mom), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
                                         _p(seg_l2), _p(sq), _p(sq_override), nspan, lr, _p(lr_dev), momentum,
                                         clipnorm, self._s()), "tnt_sgd_f32")
+
+    def sam(self, theta, grad, ew, span_seg, span_off, span_len, seg_l2, sq, nseg, nspan, rho, mode):
+        _lib.check(self.lib.tnt_sam_f32(_p(theta), _p(grad), _p(ew), _p(span_seg), _p(span_off), _p(span_len),
+                                        _p(seg_l2), _p(sq), nseg, nspan, rho, mode, self._s()), "tnt_sam_f32")
 
     def step_tick(self, adam_t, drop_step, lr, lr_t, beta1, beta2):
         _lib.check(self.lib.tnt_step_tick(_p(adam_t), _p(drop_step), _p(lr), _p(lr_t), beta1, beta2, self._s()),

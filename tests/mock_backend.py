@@ -190,20 +190,23 @@ class MockBackend:
             mat(dout_out, B, U, U)[...] = np.where(m, 0, dout)
 
     # ---------------------------------------------------------------- softmax / CE
-    def softmax_cce(self, logits, target, probs, loss_row, correct_row, dlogits, rows, V, ld, gscale):
+    def softmax_cce(self, logits, target, probs, loss_row, correct_row, dlogits, rows, V, ld, gscale,
+                    from_logits=False, mask_zero=False):
         x = mat(logits, rows, V, ld).astype(np.float64)
         p = O.softmax(x)
         if target is not None:
             y = flat(target)[:rows].astype(np.int64)
             py = np.take_along_axis(p, y[:, None], 1)[:, 0]
+            live = (y != 0) if mask_zero else np.ones(rows, bool)
             if loss_row is not None:
-                flat(loss_row)[:rows] = -np.log(np.clip(py, 1e-7, 1 - 1e-7))
+                l = O.sparse_cce_from_logits(x, y)[0] if from_logits else -np.log(np.clip(py, 1e-7, 1 - 1e-7))
+                flat(loss_row)[:rows] = np.where(live, l, 0.0)
             if correct_row is not None:
                 flat(correct_row)[:rows] = (p.argmax(-1) == y)
             if dlogits is not None:
                 oh = np.zeros_like(p)
                 np.put_along_axis(oh, y[:, None], 1.0, 1)
-                active = ((py >= 1e-7) & (py <= 1 - 1e-7))[:, None]
+                active = (live & (from_logits | ((py >= 1e-7) & (py <= 1 - 1e-7))))[:, None]
                 mat(dlogits, rows, V, ld)[...] = np.where(active, (p - oh) * gscale, 0)
         if probs is not None and (dlogits is None or probs.data_ptr() != dlogits.data_ptr()):
             mat(probs, rows, V, ld)[...] = p
@@ -267,6 +270,17 @@ class MockBackend:
             mv = momentum * mo[o:o + n] - lr * g
             mo[o:o + n] = mv
             th[o:o + n] = t + mv
+
+    def sam(self, theta, grad, ew, span_seg, span_off, span_len, seg_l2, sq, nseg, nspan, rho, mode):
+        th, gr, e, l2 = flat(theta), flat(grad), flat(ew), flat(seg_l2)
+        scale = rho / (np.sqrt(flat(sq)[:nseg].astype(np.float64).sum()) + 1e-12)
+        for s, o, n in self._segs(span_seg, span_off, span_len, nspan):
+            if mode == 1:
+                th[o:o + n] -= e[o:o + n]
+            else:
+                t = th[o:o + n].astype(np.float64)
+                e[o:o + n] = (gr[o:o + n].astype(np.float64) + 2 * float(l2[s]) * t) * scale
+                th[o:o + n] = t + e[o:o + n]
 
     def step_tick(self, adam_t, drop_step, lr, lr_t, beta1, beta2):
         if drop_step is not None:
