@@ -1,0 +1,229 @@
+"""Input contract of the hot path: tokeniser, padding, batch generators.
+
+Mirrors what ``AttemptFour/DataLoaders/data_generator_guse.py:129-171`` hands to the model:
+``((betas f32 (B,N), cap i32 (B,T), a0 (B,U), c0 (B,U)), target)`` where
+``target[:, :-1] = cap[:, 1:]`` (last column 0), one-hot via ``to_categorical`` or -- cheaper,
+accepted by every model here -- the int ids themselves.  The NSD files and the lab paths of the
+reference are not available (component 8), so the beta loader is a callable and a
+synthetic generator with the identical tuple layout is provided for benchmarks.
+
+Host-side staging for wide inputs (full cortex: 327 684 voxels = 84 MB per batch, f1): batches
+are assembled in pinned host memory and copied with non_blocking H2D on a side stream,
+double-buffered, so the copy of batch i+1 overlaps the step on batch i.
+"""
+import json
+import re
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+KERAS_FILTERS = '!"#$%&()*+,-./:;<=>?@[\\]^_`{|}~\t\n'
+
+
+class Tokenizer:
+    """keras.preprocessing.text.Tokenizer subset used by the reference
+    (load_avg_betas.py:184-188: num_words=top_k, oov_token='<unk>', custom filters)."""
+
+    def __init__(self, num_words=None, filters=KERAS_FILTERS, lower=True, split=" ", oov_token=None):
+        self.num_words, self.filters, self.lower, self.split, self.oov_token = num_words, filters, lower, split, oov_token
+        self.word_counts = OrderedDict()
+        self.word_index, self.index_word = {}, {}
+
+    def _seq(self, text):
+        if self.lower:
+            text = text.lower()
+        table = str.maketrans({c: self.split for c in self.filters})
+        return [w for w in text.translate(table).split(self.split) if w]
+
+    def fit_on_texts(self, texts):
+        for t in texts:
+            for w in self._seq(t):
+                self.word_counts[w] = self.word_counts.get(w, 0) + 1
+        # keras: sort by count descending (stable), OOV token first
+        wcounts = sorted(self.word_counts.items(), key=lambda kv: kv[1], reverse=True)
+        vocab = ([self.oov_token] if self.oov_token is not None else []) + [w for w, _ in wcounts]
+        self.word_index = {w: i + 1 for i, w in enumerate(vocab)}
+        self.index_word = {i: w for w, i in self.word_index.items()}
+
+    def texts_to_sequences(self, texts):
+        oov = self.word_index.get(self.oov_token) if self.oov_token is not None else None
+        out = []
+        for t in texts:
+            seq = []
+            for w in self._seq(t):
+                i = self.word_index.get(w)
+                if i is not None and (self.num_words is None or i < self.num_words):
+                    seq.append(i)
+                elif oov is not None:
+                    seq.append(oov)
+            out.append(seq)
+        return out
+
+    def sequences_to_texts(self, seqs):
+        return [" ".join(self.index_word.get(int(i), self.oov_token or "") for i in s if int(i) in self.index_word or self.oov_token)
+                for s in seqs]
+
+    def to_json(self):
+        cfg = dict(num_words=self.num_words, filters=self.filters, lower=self.lower, split=self.split,
+                   oov_token=self.oov_token, word_counts=json.dumps(self.word_counts),
+                   word_index=json.dumps(self.word_index), index_word=json.dumps(self.index_word))
+        return json.dumps({"class_name": "Tokenizer", "config": cfg})
+
+
+def tokenizer_from_json(s):
+    """keras tokenizer_from_json (load_avg_betas.py:136-138): accepts the keras JSON layout."""
+    obj = json.loads(s) if isinstance(s, str) else s
+    cfg = obj["config"]
+    t = Tokenizer(cfg.get("num_words"), cfg.get("filters", KERAS_FILTERS), cfg.get("lower", True), cfg.get("split", " "),
+                  cfg.get("oov_token"))
+    t.word_counts = OrderedDict(json.loads(cfg.get("word_counts", "{}")))
+    t.word_index = json.loads(cfg["word_index"])
+    t.index_word = {int(k): v for k, v in json.loads(cfg["index_word"]).items()}
+    return t
+
+
+def pad_sequences(seqs, maxlen, truncating="post", padding="post", value=0, dtype=np.int32):
+    """keras pad_sequences as called at data_generator_guse.py:158."""
+    out = np.full((len(seqs), maxlen), value, dtype=dtype)
+    for i, s in enumerate(seqs):
+        s = list(s)
+        if len(s) > maxlen:
+            s = s[:maxlen] if truncating == "post" else s[-maxlen:]
+        if padding == "post":
+            out[i, :len(s)] = s
+        else:
+            out[i, maxlen - len(s):] = s
+    return out
+
+
+def to_categorical(ids, num_classes):
+    ids = np.asarray(ids)
+    out = np.zeros(ids.shape + (num_classes,), np.float32)
+    np.put_along_axis(out, ids[..., None], 1.0, axis=-1)
+    return out
+
+
+def make_target(cap_vector):
+    """target[:, :-1] = cap[:, 1:], last column 0 (data_generator_guse.py:161-163)."""
+    t = np.zeros_like(cap_vector)
+    t[:, :-1] = cap_vector[:, 1:]
+    return t
+
+
+class DataGenerator:
+    """keras.utils.Sequence protocol of data_generator_guse.DataGenerator (lines 25-171).
+    ``pairs`` rows are (nsd_key, caption, ...); ``load_betas(key, row) -> (N,) float32`` replaces the
+    hard-coded np.load of the lab paths (data_generator_guse.py:147-153)."""
+
+    def __init__(self, pairs, batch_size, tokenizer, units, max_len, vocab_size, load_betas, n_voxels, shuffle=True,
+                 training=False, one_hot=True, seed=None):
+        self.pairs = np.array(pairs, dtype=object)
+        self.batch_size, self.tokenizer, self.units, self.max_len, self.vocab_size = batch_size, tokenizer, units, max_len, vocab_size
+        self.load_betas, self.n_voxels = load_betas, n_voxels
+        self.shuffle, self.training, self.one_hot = shuffle, training, one_hot
+        self.rng = np.random.default_rng(seed)
+        self.on_epoch_end()
+
+    def __len__(self):
+        return len(self.pairs) // self.batch_size
+
+    def on_epoch_end(self):
+        if self.shuffle:
+            self.rng.shuffle(self.pairs)
+
+    def __getitem__(self, index):
+        batch = self.pairs[index * self.batch_size:(index + 1) * self.batch_size]
+        B = len(batch)
+        betas = np.zeros((B, self.n_voxels), np.float32)
+        for i, row in enumerate(batch):
+            betas[i] = self.load_betas(row[0], row)
+        cap = pad_sequences(self.tokenizer.texts_to_sequences([r[1] for r in batch]), self.max_len)
+        target = make_target(cap)
+        if self.one_hot:
+            target = to_categorical(target, self.vocab_size)
+        init = np.zeros((B, self.units), np.float32)
+        x = (betas, cap, init, init.copy())
+        return (x, target) if self.training else (x, target, np.array([r[0] for r in batch]))
+
+
+class SyntheticGenerator:
+    """Synthetic batches with the reference's tuple layout: betas ~ N(0,1) (the reference's
+    betas are z-scored per voxel), captions = <start>, 6..13 tokens uniform in [3, V), <end>, zero
+    padding.  ``device`` set: tensors are created once on the device (benchmarks)."""
+
+    def __init__(self, n_batches, batch_size, n_voxels, units, max_len, vocab_size, seed=42, one_hot=False, device=None):
+        self.n, self.B, self.N, self.U, self.T, self.V = n_batches, batch_size, n_voxels, units, max_len, vocab_size
+        self.seed, self.one_hot, self.device = seed, one_hot, device
+        self._cache = {}
+
+    def __len__(self):
+        return self.n
+
+    def on_epoch_end(self):
+        pass
+
+    def __getitem__(self, index):
+        if index in self._cache:
+            return self._cache[index]
+        rng = np.random.default_rng(self.seed + index)
+        x = rng.standard_normal((self.B, self.N)).astype(np.float32)
+        cap = np.zeros((self.B, self.T), np.int32)
+        for b in range(self.B):
+            hi = max(1, self.T - 2)
+            L = int(rng.integers(min(6, hi), min(13, hi) + 1))
+            cap[b, 0] = 1
+            cap[b, 1:1 + L] = rng.integers(3, self.V, size=L)
+            cap[b, 1 + L] = 2
+        tgt = make_target(cap)
+        z = np.zeros((self.B, self.U), np.float32)
+        item = ((x, cap, z, z.copy()), to_categorical(tgt, self.V) if self.one_hot else tgt)
+        if self.device is not None:
+            dev = lambda a: torch.as_tensor(a).to(self.device)
+            item = (tuple(dev(a) for a in item[0]), dev(item[1]))
+            self._cache[index] = item
+        return item
+
+
+class PinnedPrefetcher:
+    """Double-buffered host->device staging for wide batches: wraps any generator; batch i+1 is
+    copied H2D from pinned memory on a side stream while the model steps on batch i."""
+
+    def __init__(self, generator, device):
+        self.gen, self.device = generator, torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._next = None
+        self._pinned = [None, None]
+
+    def __len__(self):
+        return len(self.gen)
+
+    def on_epoch_end(self):
+        self.gen.on_epoch_end()
+        self._next = None
+
+    def _stage(self, index, slot):
+        (x, cap, a0, c0), tgt = self.gen[index][:2]
+        arrs = [np.ascontiguousarray(a) for a in (x, cap, a0, c0, tgt)]
+        if self.stream is None:
+            return tuple(torch.as_tensor(a) for a in arrs), None
+        if self._pinned[slot] is None or any(p.shape != a.shape for p, a in zip(self._pinned[slot], arrs)):
+            self._pinned[slot] = [torch.empty(a.shape, dtype=torch.as_tensor(a).dtype).pin_memory() for a in arrs]
+        with torch.cuda.stream(self.stream):
+            outs = []
+            for p, a in zip(self._pinned[slot], arrs):
+                p.copy_(torch.as_tensor(a))
+                outs.append(p.to(self.device, non_blocking=True))
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return tuple(outs), ev
+
+    def __getitem__(self, index):
+        if self._next is None or self._next[0] != index:
+            self._next = (index, self._stage(index, index & 1))
+        (x, cap, a0, c0, tgt), ev = self._next[1]
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        nxt = index + 1
+        self._next = (nxt, self._stage(nxt, nxt & 1)) if nxt < len(self.gen) else None
+        return ((x, cap, a0, c0), tgt)
