@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="dense", choices=["dense", "attention"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dp", action="store_true", help="run the data-parallel schedule even at world size 1 (rehearsal)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -145,17 +146,17 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     grad_sync = None
-    if world > 1:
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        from masters_thesis_amd.dp import make_grad_sync
-        grad_sync = make_grad_sync(world)
 
-    model = make_model(args.workload, device, grad_sync)
-    if world > 1:
-        from masters_thesis_amd.dp import broadcast_parameters
-        broadcast_parameters(model)
+    model = make_model(args.workload, device, None)
+    if use_dp:
+        from masters_thesis_amd import dp
+        dp.attach(model, world)
     batch, host_batch = synth(rank, device)
 
     for _ in range(args.warmup):
@@ -196,7 +197,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, host_batch)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -229,7 +229,8 @@ class ModelBase:
         elif st == "warm":
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: RCCL's watchdog thread may query events while we capture (data parallel)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
             self._graphs[key] = g
             g.replay()

@@ -249,15 +249,26 @@ class NIC(ModelBase):
 
     # ------------------------------------------------------------------ backward
     def _backward(self, B, T):
+        self._bwd_head(B, T)
+        self._bwd_seq(B, T)
+        self._bwd_enc(B, T)
+
+    def _bwd_head(self, B, T):
+        """vocabulary head: dW, db, dX (gradients ready first -> first all-reduce bucket under DP)."""
         be, a = self.be, self.arena
-        N, U, E, V, ldV = self.N, self.U, self.E, self.V, self.ldV
-        R1 = (T + 1) * B
-        sd, ds = self.seed, self.drop_step
+        U, V, ldV = self.U, self.V, self.ldV
         dlog = self.logits
         Wo = a.p("time_distributed_softmax/kernel")
         be.gemm(self.Out, dlog, a.g("time_distributed_softmax/kernel"), U, V, T * B, U, ldV, ldV, transA=True)
         be.colsum(dlog, a.g("time_distributed_softmax/bias"), T * B, V, ldV, self.work)
         self.gemm_sk(dlog, Wo, self.dOut, T * B, U, V, ldV, ldV, U, transB=True)
+
+    def _bwd_seq(self, B, T):
+        """BPTT, LSTM / embedding / BatchNorm gradients, down to dpre of the encoder Dense."""
+        be, a = self.be, self.arena
+        N, U, E, V, ldV = self.N, self.U, self.E, self.V, self.ldV
+        R1 = (T + 1) * B
+        sd, ds = self.seed, self.drop_step
         Ur = a.p("lstm/recurrent_kernel")
         dOut = self.dOut.view(T, B, U)
         for t in range(T, 0, -1):
@@ -290,8 +301,19 @@ class NIC(ModelBase):
             be.dropout(self.dyd, self.dyd, B, E, E, 0, E, 0, self.r_feat, sd, S_FEAT, 0, ds)
         be.act_bwd(self.enc_pre, self.dyd, self.dpre, B * E, ACT_LEAKY, 0.2)
         be.colsum(self.dpre, a.g("dense_img/bias"), B, E, E, self.work)
+
+    def _bwd_enc(self, B, T, x_all=None, dpre_all=None):
+        """encoder kernel gradient dW = X^T dpre.  Under DP the operands of all ranks are passed
+        (all-gathered: 5 MB of betas + 128 KB per rank) and every rank computes the full global-batch
+        gradient itself, instead of all-reducing the 41 MB result."""
+        be, a = self.be, self.arena
         x = self.xd if self.r_in > 0 else self.x
-        be.gemm(x, self.dpre, a.g("dense_img/kernel"), N, E, B, self.ldx, E, E, transA=True)
+        rows = B
+        if x_all is not None:
+            x, dpre, rows = x_all, dpre_all, x_all.shape[0]
+        else:
+            dpre = self.dpre
+        be.gemm(x, dpre, a.g("dense_img/kernel"), self.N, self.E, rows, self.ldx, self.E, self.E, transA=True)
 
     # ------------------------------------------------------------------ steps
     def _train_graph(self, B, T):
@@ -312,6 +334,8 @@ class NIC(ModelBase):
         self._sync_lr()
         if self.grad_sync is None:
             self._run_captured(("train", B, T), lambda: (self._train_graph(B, T), self._update_graph()))
+        elif getattr(self.grad_sync, "pipelined", False):
+            self.grad_sync.step(self, B, T)
         else:       # data parallel: forward+backward | all-reduce of the flat gradient | update
             self._run_captured(("train_fb", B, T), lambda: self._train_graph(B, T))
             self.grad_sync(self)

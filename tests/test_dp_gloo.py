@@ -44,7 +44,7 @@ def _make(kind, seed, **kw):
     d = DIMS
     if kind == "nic":
         from masters_thesis_amd.nic import NIC
-        return NIC(d["N"], d["U"], d["E"], d["V"], d["T"], 0.0, 0.2, 0.2, 0.01, 3e-5, 1e-5, norm="layer", device="cpu",
+        return NIC(d["N"], d["U"], d["E"], d["V"], d["T"], 0.0, 0.0, 0.0, 0.01, 3e-5, 1e-5, norm="layer", device="cpu",
                    seed=seed, **kw)
     from masters_thesis_amd.lc_nic import NIC
     from helpers import tiny_groups
@@ -91,11 +91,8 @@ def test_dp2_equals_single_process(kind):
         for step in range(2):
             data, tgt = _global_batch(rng, world)
             m = ref.train_step((data, tgt)).as_floats()
-            if kind == "nic":        # no dropout-dependent terms in the rank-mean of loss for lcnic (rates 0)
-                pass
-            else:
-                assert abs(m["loss"] - res[0][1][step]["loss"]) < 1e-5
-        if kind == "lcnic":          # dropout-free: weights must match the single-process run
+            assert abs(m["loss"] - res[0][1][step]["loss"]) < 1e-5
+        if True:                     # dropout-free: weights must match the single-process run
             for k, v in ref.get_weights_dict().items():
                 if k == "attention/V/bias":
                     continue
