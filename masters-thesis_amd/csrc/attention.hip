@@ -297,6 +297,321 @@ __global__ void attention_metric_final_kernel(const float* partial, float* out, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide variants (A % 4 == 0, D % 4 == 0): 1024 threads per sample, 16-byte loads, one Philox call per
+// 4 mask decisions, every thread's loads of a phase issued before their first use.  The 256-thread
+// kernels above remain the general fallback.
+// ---------------------------------------------------------------------------------------------
+constexpr int WT = 1024;            // threads per workgroup
+constexpr int WW = WT / 64;         // waves
+constexpr int MAXP = 6;             // row passes held in registers: R <= MAXP * (WT / (A/4))
+
+__device__ __forceinline__ float block_sum_w(float v, float* sh) {
+  v = tnt_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int k = 0; k < WW; ++k) r += sh[k];
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float block_max_w(float v, float* sh) {
+  v = tnt_wave_max(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sh[0];
+#pragma unroll
+  for (int k = 1; k < WW; ++k) r = fmaxf(r, sh[k]);
+  __syncthreads();
+  return r;
+}
+// sum of v over the lanes of a wave that share (lane % G): xor offsets G, 2G, ..., 32
+template <int G>
+__device__ __forceinline__ float stride_sum(float v) {
+#pragma unroll
+  for (int o = G; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over a group of G adjacent lanes
+template <int G>
+__device__ __forceinline__ float adj_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// G4 = A/4 (= D/4 after padding to the larger of the two): lanes per row
+template <int G4>
+__global__ __launch_bounds__(WT) void attention_fwd_wide_kernel(AttArgs g) {
+  constexpr int RPP = WT / G4;               // rows per pass
+  __shared__ __attribute__((aligned(16))) float hs[MAXU];
+  __shared__ float es[MAXR];
+  __shared__ __attribute__((aligned(16))) float wred[WW][64];
+  __shared__ __attribute__((aligned(16))) float qs[64];
+  __shared__ float red[WW];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c4 = tid % G4, rl = tid / G4;    // 4-column group, row lane
+  const int A = g.A, D = g.D, R = g.R, U = g.U;
+  const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
+  for (int k = tid; k < U; k += WT) hs[k] = g.h[(long)b * U + k];
+  __syncthreads();
+  // ---- q = LeakyReLU(h W2 + b2): thread (c4, rl) sums rows k = rl, rl+RPP, ...
+  {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 * 4 < A) {
+#pragma unroll 4
+      for (int k = rl; k < U; k += RPP) {
+        const float4 wv = *reinterpret_cast<const float4*>(g.W2 + (long)k * A + c4 * 4);
+        const float hk = hs[k];
+        acc.x += hk * wv.x; acc.y += hk * wv.y; acc.z += hk * wv.z; acc.w += hk * wv.w;
+      }
+    }
+    acc.x = stride_sum<G4>(acc.x); acc.y = stride_sum<G4>(acc.y);
+    acc.z = stride_sum<G4>(acc.z); acc.w = stride_sum<G4>(acc.w);
+    if (lane < G4) *reinterpret_cast<float4*>(&wred[w][lane * 4]) = acc;
+    __syncthreads();
+    if (tid < A) {
+      float t = g.b2[tid];
+#pragma unroll
+      for (int k = 0; k < WW; ++k) t += wred[k][tid];
+      g.qpre[(long)b * A + tid] = t;
+      qs[tid] = t > 0.f ? t : t * g.slope;
+    }
+    __syncthreads();
+  }
+  // ---- scores e[r] = sum_a dropout(tanh(P + q)) v + bv
+  {
+    float4 pv[MAXP];
+    const bool cok = c4 * 4 < A;
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int r = p * RPP + rl;
+      pv[p] = (cok && r < R) ? *reinterpret_cast<const float4*>(g.P + ((long)b * R + r) * A + c4 * 4)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4 q4 = cok ? *reinterpret_cast<const float4*>(&qs[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v4 = cok ? *reinterpret_cast<const float4*>(g.v + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float scale_a = 1.f / (1.f - g.rate_attn), bv = g.bv[0];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int r = p * RPP + rl;
+      float t = 0.f;
+      if (cok && r < R) {
+        const long e = ((long)b * R + r) * A + c4 * 4;
+        float s0 = tanhf(pv[p].x + q4.x), s1 = tanhf(pv[p].y + q4.y), s2 = tanhf(pv[p].z + q4.z), s3 = tanhf(pv[p].w + q4.w);
+        if (g.rate_attn > 0.f) {
+          bool k[4];
+          tnt_keep4((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step, k);
+          s0 = k[0] ? s0 * scale_a : 0.f; s1 = k[1] ? s1 * scale_a : 0.f;
+          s2 = k[2] ? s2 * scale_a : 0.f; s3 = k[3] ? s3 * scale_a : 0.f;
+        }
+        if (g.s_out) *reinterpret_cast<float4*>(g.s_out + e) = make_float4(s0, s1, s2, s3);
+        t = s0 * v4.x + s1 * v4.y + s2 * v4.z + s3 * v4.w;
+      }
+      t = adj_sum<G4>(t);
+      if (c4 == 0 && r < R) es[r] = t + bv;
+    }
+    __syncthreads();
+  }
+  // ---- softmax over regions
+  float m = -INFINITY;
+  for (int r = tid; r < R; r += WT) m = fmaxf(m, es[r]);
+  m = block_max_w(m, red);
+  float z = 0.f;
+  for (int r = tid; r < R; r += WT) { const float ex = expf(es[r] - m); es[r] = ex; z += ex; }
+  z = block_sum_w(z, red);
+  const float invz = 1.f / z;
+  for (int r = tid; r < R; r += WT) { const float al = es[r] * invz; es[r] = al; g.alpha[(long)b * R + r] = al; }
+  __syncthreads();
+  // ---- context = sum_r alpha[r] F[r][:]
+  {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool cok = c4 * 4 < D;
+    float4 fv[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int r = p * RPP + rl;
+      fv[p] = (cok && r < R) ? *reinterpret_cast<const float4*>(g.F + ((long)b * R + r) * D + c4 * 4)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int r = p * RPP + rl;
+      const float al = r < R ? es[r] : 0.f;
+      acc.x += al * fv[p].x; acc.y += al * fv[p].y; acc.z += al * fv[p].z; acc.w += al * fv[p].w;
+    }
+    acc.x = stride_sum<G4>(acc.x); acc.y = stride_sum<G4>(acc.y);
+    acc.z = stride_sum<G4>(acc.z); acc.w = stride_sum<G4>(acc.w);
+    if (lane < G4) *reinterpret_cast<float4*>(&wred[w][lane * 4]) = acc;
+    __syncthreads();
+    if (tid < D) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < WW; ++k) t += wred[k][tid];
+      g.ctx[(long)b * D + tid] = t;
+      if (g.ctx_d) {
+        float td = t;
+        if (g.rate_in > 0.f)
+          td = tnt_keep((uint64_t)b * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, g.site_in, step)
+                   ? t * (1.f / (1.f - g.rate_in)) : 0.f;
+        g.ctx_d[(long)b * D + tid] = td;
+      }
+    }
+  }
+}
+
+template <int G4>
+__global__ __launch_bounds__(WT) void attention_bwd_wide_kernel(AttArgs g) {
+  constexpr int RPP = WT / G4;
+  __shared__ float als[MAXR];      // alpha, then de
+  __shared__ float das[MAXR];      // dalpha
+  __shared__ __attribute__((aligned(16))) float wred[WW][64], wred2[WW][64];
+  __shared__ __attribute__((aligned(16))) float qs[64], dcs[64], dq_s[64];
+  __shared__ float red[WW];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c4 = tid % G4, rl = tid / G4;
+  const int A = g.A, D = g.D, R = g.R, U = g.U;
+  const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
+  // ---- dctx (fused dz Wc^T, or given), un-dropped
+  if (g.dz) {
+    const int K4 = 4 * U;
+    const float4* dzr = reinterpret_cast<const float4*>(g.dz + (long)b * K4);
+    for (int dd = w; dd < D; dd += WW) {
+      const float4* wr = reinterpret_cast<const float4*>(g.Wc + (long)dd * K4);
+      float sacc = 0.f;
+#pragma unroll 8
+      for (int i = lane; i < K4 / 4; i += 64) {
+        const float4 x = dzr[i], y = wr[i];
+        sacc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      }
+      sacc = tnt_wave_sum(sacc);
+      if (lane == 0) dcs[dd] = sacc;
+    }
+  } else if (tid < D) {
+    dcs[tid] = g.dctx_d[(long)b * D + tid];
+  }
+  if (tid < 64) {
+    float q = 0.f;
+    if (tid < A) { q = g.qpre_in[(long)b * A + tid]; q = q > 0.f ? q : q * g.slope; }
+    qs[tid] = q;
+  }
+  for (int r = tid; r < R; r += WT) als[r] = g.alpha_in[(long)b * R + r];
+  __syncthreads();
+  if (tid < 64) {
+    float dc = tid < D ? dcs[tid] : 0.f;
+    if (tid < D && g.rate_in > 0.f)
+      dc = tnt_keep((uint64_t)b * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, g.site_in, step)
+               ? dc * (1.f / (1.f - g.rate_in)) : 0.f;
+    dcs[tid] = dc;
+  }
+  __syncthreads();
+  // ---- dalpha[r] = dctx . F[r];  dF[r] += alpha[r] dctx
+  {
+    const bool cok = c4 * 4 < D;
+    const float4 dc4 = cok ? *reinterpret_cast<const float4*>(&dcs[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 fv[MAXP], dfv[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int r = p * RPP + rl;
+      const bool ok = cok && r < R;
+      const long e = ((long)b * R + r) * D + c4 * 4;
+      fv[p] = ok ? *reinterpret_cast<const float4*>(g.F + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dfv[p] = ok ? *reinterpret_cast<const float4*>(g.dF + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int r = p * RPP + rl;
+      float t = 0.f;
+      if (cok && r < R) {
+        const long e = ((long)b * R + r) * D + c4 * 4;
+        t = dc4.x * fv[p].x + dc4.y * fv[p].y + dc4.z * fv[p].z + dc4.w * fv[p].w;
+        const float al = als[r];
+        *reinterpret_cast<float4*>(g.dF + e) = make_float4(dfv[p].x + al * dc4.x, dfv[p].y + al * dc4.y,
+                                                           dfv[p].z + al * dc4.z, dfv[p].w + al * dc4.w);
+      }
+      t = adj_sum<G4>(t);
+      if (c4 == 0 && r < R) das[r] = t;
+    }
+    __syncthreads();
+  }
+  float dot = 0.f;
+  for (int r = tid; r < R; r += WT) dot += als[r] * das[r];
+  dot = block_sum_w(dot, red);
+  float dbv = 0.f;
+  for (int r = tid; r < R; r += WT) { const float de = als[r] * (das[r] - dot); als[r] = de; dbv += de; }
+  dbv = block_sum_w(dbv, red);
+  // ---- through e = s_d . v, dropout, tanh
+  {
+    const bool cok = c4 * 4 < A;
+    const float4 q4 = cok ? *reinterpret_cast<const float4*>(&qs[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v4 = cok ? *reinterpret_cast<const float4*>(g.v + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float scale_a = g.rate_attn > 0.f ? 1.f / (1.f - g.rate_attn) : 1.f;
+    float4 pv[MAXP], dpv[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int r = p * RPP + rl;
+      const bool ok = cok && r < R;
+      const long e = ((long)b * R + r) * A + c4 * 4;
+      pv[p] = ok ? *reinterpret_cast<const float4*>(g.P + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dpv[p] = ok ? *reinterpret_cast<const float4*>(g.dP + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), dq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int r = p * RPP + rl;
+      if (!(cok && r < R)) continue;
+      const long e = ((long)b * R + r) * A + c4 * 4;
+      const float s0 = tanhf(pv[p].x + q4.x), s1 = tanhf(pv[p].y + q4.y), s2 = tanhf(pv[p].z + q4.z), s3 = tanhf(pv[p].w + q4.w);
+      bool k[4] = {true, true, true, true};
+      if (g.rate_attn > 0.f) tnt_keep4((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step, k);
+      const float k0 = k[0] ? scale_a : 0.f, k1 = k[1] ? scale_a : 0.f, k2 = k[2] ? scale_a : 0.f, k3 = k[3] ? scale_a : 0.f;
+      const float de = als[r];
+      dv.x += s0 * k0 * de; dv.y += s1 * k1 * de; dv.z += s2 * k2 * de; dv.w += s3 * k3 * de;
+      const float d0 = de * v4.x * k0 * (1.f - s0 * s0), d1 = de * v4.y * k1 * (1.f - s1 * s1);
+      const float d2 = de * v4.z * k2 * (1.f - s2 * s2), d3 = de * v4.w * k3 * (1.f - s3 * s3);
+      *reinterpret_cast<float4*>(g.dP + e) = make_float4(dpv[p].x + d0, dpv[p].y + d1, dpv[p].z + d2, dpv[p].w + d3);
+      dq.x += d0; dq.y += d1; dq.z += d2; dq.w += d3;
+    }
+    dv.x = stride_sum<G4>(dv.x); dv.y = stride_sum<G4>(dv.y); dv.z = stride_sum<G4>(dv.z); dv.w = stride_sum<G4>(dv.w);
+    dq.x = stride_sum<G4>(dq.x); dq.y = stride_sum<G4>(dq.y); dq.z = stride_sum<G4>(dq.z); dq.w = stride_sum<G4>(dq.w);
+    if (lane < G4) {
+      *reinterpret_cast<float4*>(&wred[w][lane * 4]) = dv;
+      *reinterpret_cast<float4*>(&wred2[w][lane * 4]) = dq;
+    }
+    __syncthreads();
+    if (tid < A) {
+      float tv = 0.f, tq = 0.f;
+#pragma unroll
+      for (int k = 0; k < WW; ++k) { tv += wred[k][tid]; tq += wred2[k][tid]; }
+      g.dvb[(long)b * (A + 1) + tid] += tv;
+      const float qp = g.qpre_in[(long)b * A + tid];
+      const float dqp = qp > 0.f ? tq : tq * g.slope;
+      dq_s[tid] = dqp;
+      g.dqpre[(long)b * A + tid] = dqp;
+    }
+    if (tid == 0) g.dvb[(long)b * (A + 1) + A] += dbv;
+    __syncthreads();
+  }
+  // ---- dh[k] = sum_a dqpre[a] W2[k][a]
+  for (int k = tid; k < U; k += WT) {
+    float t = 0.f;
+    const float4* wr = reinterpret_cast<const float4*>(g.W2 + (long)k * A);
+#pragma unroll 4
+    for (int j = 0; j < A / 4; ++j) {
+      const float4 wv = wr[j];
+      t += dq_s[4 * j] * wv.x + dq_s[4 * j + 1] * wv.y + dq_s[4 * j + 2] * wv.z + dq_s[4 * j + 3] * wv.w;
+    }
+    g.dh[(long)b * U + k] = t;
+  }
+}
+
+inline bool wide_ok(int R, int D, int A) {
+  if ((A & 3) || (D & 3)) return false;
+  const int g4 = (A > D ? A : D) / 4 <= 8 ? 8 : 16;
+  return R <= MAXP * (WT / g4);
+}
+
 int32_t check_dims(int B, int R, int D, int A, int U) {
   if (B <= 0) return TNT_BADARG(1);
   if (R <= 0 || R > MAXR) return TNT_BADARG(2);
@@ -320,7 +635,13 @@ extern "C" int32_t tnt_attention_step_fwd_f32(const float* h, const float* F, co
   g.ctx_d = ctx_d; g.s_out = s_out; g.B = B; g.R = R; g.D = D; g.A = A; g.U = U; g.in_lwidth = in_lwidth;
   g.slope = slope; g.rate_attn = rate_attn; g.rate_in = rate_in; g.seed = seed; g.site_attn = site_attn;
   g.site_in = site_in; g.step = step; g.step_dev = step_dev;
-  if (A <= 32 && D <= 32)
+  if (wide_ok(R, D, A) && tnt_aligned16(P) && tnt_aligned16(F) && tnt_aligned16(W2) && tnt_aligned16(v) &&
+      (s_out == nullptr || tnt_aligned16(s_out))) {
+    if (A <= 32 && D <= 32)
+      hipLaunchKernelGGL(attention_fwd_wide_kernel<8>, dim3(B), dim3(WT), 0, tnt_stream(stream), g);
+    else
+      hipLaunchKernelGGL(attention_fwd_wide_kernel<16>, dim3(B), dim3(WT), 0, tnt_stream(stream), g);
+  } else if (A <= 32 && D <= 32)
     hipLaunchKernelGGL(attention_fwd_kernel<32>, dim3(B), dim3(256), 0, tnt_stream(stream), g);
   else
     hipLaunchKernelGGL(attention_fwd_kernel<64>, dim3(B), dim3(256), 0, tnt_stream(stream), g);
@@ -344,7 +665,13 @@ extern "C" int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* 
   g.dvb = dvb; g.dqpre = dqpre; g.dh = dh; g.B = B; g.R = R; g.D = D; g.A = A; g.U = U; g.in_lwidth = in_lwidth;
   g.slope = slope; g.rate_attn = rate_attn; g.rate_in = rate_in; g.seed = seed; g.site_attn = site_attn;
   g.site_in = site_in; g.step = step; g.step_dev = step_dev;
-  if (A <= 32 && D <= 32)
+  if (wide_ok(R, D, A) && tnt_aligned16(P) && tnt_aligned16(F) && tnt_aligned16(W2) && tnt_aligned16(v) &&
+      tnt_aligned16(dP) && tnt_aligned16(dF) && (dz == nullptr || (tnt_aligned16(dz) && tnt_aligned16(Wc)))) {
+    if (A <= 32 && D <= 32)
+      hipLaunchKernelGGL(attention_bwd_wide_kernel<8>, dim3(B), dim3(WT), 0, tnt_stream(stream), g);
+    else
+      hipLaunchKernelGGL(attention_bwd_wide_kernel<16>, dim3(B), dim3(WT), 0, tnt_stream(stream), g);
+  } else if (A <= 32 && D <= 32)
     hipLaunchKernelGGL(attention_bwd_kernel<32>, dim3(B), dim3(256), 0, tnt_stream(stream), g);
   else
     hipLaunchKernelGGL(attention_bwd_kernel<64>, dim3(B), dim3(256), 0, tnt_stream(stream), g);
