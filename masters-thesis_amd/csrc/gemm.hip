@@ -239,16 +239,14 @@ int32_t gemm_dispatch(const float* A, const float* B, float* C, const float* bia
   splitk = (K + kchunk - 1) / kchunk;
   g.kchunk = kchunk; g.splitk = splitk;
 
-  // tile choice: fewest rounds over 256 CUs, small tiles pay an overhead factor
+  // tile choice, calibrated with tools/gemm_bench.py / tools/gemm_scan.py on MI355X (profiles/r01_gemm_*):
+  // at the hot-path sizes (<= ~2k tiles) the 64x64 tile wins on every shape because it fills the 256 CUs
+  // (4 workgroups/CU by LDS) and quantises best; the larger tiles only pay off in steady state.
   const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
-  const float ovh[4] = {1.0f, 1.08f, 1.08f, 1.2f};
-  int best = 3; float best_cost = 1e30f;
-  for (int c = 0; c < 4; ++c) {
-    const long tiles = (long)((M + cand[c][0] - 1) / cand[c][0]) * ((N + cand[c][1] - 1) / cand[c][1]) * splitk;
-    const long rounds = (tiles + 511) / 512;   // two workgroups per CU resident
-    const float cost = (float)rounds * cand[c][0] * cand[c][1] * ovh[c];
-    if (cost < best_cost) { best_cost = cost; best = c; }
-  }
+  const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64) * splitk;
+  int best = 3;
+  if (tiles64 >= 16384) best = 0;
+  else if (tiles64 >= 8192) best = (M >= N) ? 2 : 1;
   for (int c = 0; c < 4; ++c)
     if (cand[c][0] == force_bm && cand[c][1] == force_bn) best = c;
   const bool vec = tnt_aligned16(A) && tnt_aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);

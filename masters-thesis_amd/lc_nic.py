@@ -311,7 +311,7 @@ class NIC(ModelBase):
                 be.dropout(Fq, Fq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT + off, 0, ds)        # layers.py:51
                 if S > 1:                        # ms2_NIC.py:214,257: the feature Dropout is applied a second time
                     be.dropout(Fq, Fq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT2 + off, 0, ds)
-        be.gemm(self.F, a.p("attention/W1/kernel"), self.P, B * R, self.A, D, D, self.A, self.A,
+        self.gemm_sk(self.F, a.p("attention/W1/kernel"), self.P, B * R, self.A, D, D, self.A, self.A,
                 bias=a.p("attention/W1/bias"), pre=self.Ppre, act=ACT_LEAKY, slope=0.2)      # attention.py:32 (hoisted)
 
     def _decode_step(self, i, B, training, s_out=None):
@@ -341,7 +341,7 @@ class NIC(ModelBase):
             be.dropout(self.text, self.text, n, Et, Et, 0, D + Et, D, self.r_lstm, sd, S_LSTM_IN, 0, ds,
                        rows_per_site=B)
         Wl = a.p("lstm/kernel")
-        be.gemm(self.text, Wl[D:], self.XZ, n, 4 * U, Et, Et, 4 * U, 4 * U, bias=a.p("lstm/bias"))
+        self.gemm_sk(self.text, Wl[D:], self.XZ, n, 4 * U, Et, Et, 4 * U, 4 * U, bias=a.p("lstm/bias"))
         for i in range(T):                                                                      # :244-256
             self._decode_step(i, B, training)
         hs = self.Hs[1:].view(n, U)
@@ -349,14 +349,14 @@ class NIC(ModelBase):
             be.dropout(hs, self.Hd, n, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds, rows_per_site=B)
             hs = self.Hd
         self._hs_used = hs
-        be.gemm(hs, a.p("time_distributed_nonlinear/kernel"), self.inter, n, H, U, U, H, H,
+        self.gemm_sk(hs, a.p("time_distributed_nonlinear/kernel"), self.inter, n, H, U, U, H, H,
                 bias=a.p("time_distributed_nonlinear/bias"), pre=self.ipre, act=ACT_LEAKY, slope=0.2)
         inter = self.inter
         if training and self.r_out > 0:
             be.dropout(self.inter, self.inter_d, n, H, H, B, H, 0, self.r_out, sd, S_OUT, 0, ds)
             inter = self.inter_d
         self._inter_used = inter
-        be.gemm(inter, a.p("time_distributed_softmax/kernel"), self.logits, n, V, H, H, ldV, ldV,
+        self.gemm_sk(inter, a.p("time_distributed_softmax/kernel"), self.logits, n, V, H, H, ldV, ldV,
                 bias=a.p("time_distributed_softmax/bias"))                                     # :261
 
     def _loss_metrics(self, B, T, want_grad):
@@ -390,15 +390,15 @@ class NIC(ModelBase):
         n = T * B
         sd, ds = self.seed, self.drop_step
         dlog, inter, hs = self.logits, self._inter_used, self._hs_used
-        be.gemm(inter, dlog, a.g("time_distributed_softmax/kernel"), H, V, n, H, ldV, ldV, transA=True)
+        self.gemm_sk(inter, dlog, a.g("time_distributed_softmax/kernel"), H, V, n, H, ldV, ldV, transA=True)
         be.colsum(dlog, a.g("time_distributed_softmax/bias"), n, V, ldV, self.work)
         self.gemm_sk(dlog, a.p("time_distributed_softmax/kernel"), self.dinter, n, H, V, ldV, ldV, H, transB=True)
         if self.r_out > 0:
             be.dropout(self.dinter, self.dinter, n, H, H, B, H, 0, self.r_out, sd, S_OUT, 0, ds)
         be.act_bwd(self.ipre, self.dinter, self.dinter, n * H, ACT_LEAKY, 0.2)
-        be.gemm(hs, self.dinter, a.g("time_distributed_nonlinear/kernel"), U, H, n, U, H, H, transA=True)
+        self.gemm_sk(hs, self.dinter, a.g("time_distributed_nonlinear/kernel"), U, H, n, U, H, H, transA=True)
         be.colsum(self.dinter, a.g("time_distributed_nonlinear/bias"), n, H, H, self.work)
-        be.gemm(self.dinter, a.p("time_distributed_nonlinear/kernel"), self.dHs, n, U, H, H, H, U, transB=True)
+        self.gemm_sk(self.dinter, a.p("time_distributed_nonlinear/kernel"), self.dHs, n, U, H, H, H, U, transB=True)
         if self.r_lstm > 0:
             be.dropout(self.dHs, self.dHs, n, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds, rows_per_site=B)
         self.dP.zero_(); self.dF.zero_(); self.dvb.zero_()
@@ -417,8 +417,8 @@ class NIC(ModelBase):
                                   Wc=Wl[:D])
         hprev = self.Hs[:T].view(n, U)
         gWl = a.g("lstm/kernel")
-        be.gemm(hprev, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True)
-        be.gemm(self.text, self.dZ, gWl[D:], Et, 4 * U, n, Et, 4 * U, 4 * U, transA=True)
+        self.gemm_sk(hprev, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True)
+        self.gemm_sk(self.text, self.dZ, gWl[D:], Et, 4 * U, n, Et, 4 * U, 4 * U, transA=True)
         self.gemm_sk(self.ctx_d, self.dZ, gWl[:D], D, 4 * U, n, D, 4 * U, 4 * U, transA=True)
         be.colsum(self.dZ, a.g("lstm/bias"), n, 4 * U, 4 * U, self.work)
         self.gemm_sk(self.dZ, Wl[D:], self.dtext, n, Et, 4 * U, 4 * U, 4 * U, Et, transB=True)
@@ -438,7 +438,7 @@ class NIC(ModelBase):
         be.act_bwd(self.Ppre, self.dP, self.dP, B * R * A, ACT_LEAKY, 0.2)
         self.gemm_sk(self.F, self.dP, a.g("attention/W1/kernel"), D, A, B * R, D, A, A, transA=True)
         be.colsum(self.dP, a.g("attention/W1/bias"), B * R, A, A, self.work)
-        be.gemm(self.dP, a.p("attention/W1/kernel"), self.dF, B * R, D, A, A, A, D, transB=True, accumulate=True)
+        self.gemm_sk(self.dP, a.p("attention/W1/kernel"), self.dF, B * R, D, A, A, A, D, transB=True, accumulate=True)
         # encoder
         S = self.S
         Bs = B // S
@@ -547,11 +547,11 @@ class NIC(ModelBase):
         for i in range(max_len):
             text = self.text[i * B:(i + 1) * B]
             be.embedding_fwd(a.p("emb_text/embeddings"), words, text, B, 1, Et, Et, V)        # :596,632
-            be.gemm(text, Wl[D:], self.XZ[i * B:(i + 1) * B], B, 4 * U, Et, Et, 4 * U, 4 * U, bias=a.p("lstm/bias"))
+            self.gemm_sk(text, Wl[D:], self.XZ[i * B:(i + 1) * B], B, 4 * U, Et, Et, 4 * U, 4 * U, bias=a.p("lstm/bias"))
             self._decode_step(i, B, False, s_all[i])
-            be.gemm(self.Hs[i + 1], a.p("time_distributed_nonlinear/kernel"), self.inter[:B], B, H, U, U, H, H,
+            self.gemm_sk(self.Hs[i + 1], a.p("time_distributed_nonlinear/kernel"), self.inter[:B], B, H, U, U, H, H,
                     bias=a.p("time_distributed_nonlinear/bias"), act=ACT_LEAKY, slope=0.2)     # :621
-            be.gemm(self.inter[:B], a.p("time_distributed_softmax/kernel"), probs[i], B, V, H, H, ldV, ldV,
+            self.gemm_sk(self.inter[:B], a.p("time_distributed_softmax/kernel"), probs[i], B, V, H, H, ldV, ldV,
                     bias=a.p("time_distributed_softmax/bias"))                                # :623
             be.softmax_cce(probs[i], None, probs[i], None, None, None, B, V, ldV, 0.0)
             be.argmax_rows(probs[i], ids[i], B, V, ldV)                                        # :627

@@ -120,11 +120,16 @@ class ModelBase:
 
     @staticmethod
     def pick_splitk(M, N, K):
-        """Split-K factor for GEMMs whose output has too few 64x64 tiles to fill 256 CUs."""
+        """Split-K factor (power of two) so that a GEMM launches ~1024 workgroups of 64x64 tiles
+        (4 per CU), calibrated with tools/gemm_bench.py: head dX (120 tiles) -> 8, dXin (128) -> 8,
+        dU (256) -> 4, head dW (632) -> 2, encoder forward (8 tiles, K = 20000) -> 64."""
         tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        if tiles >= 384 or K < 512:
+        if K < 256:
             return 1
-        return int(max(1, min(64, -(-512 // tiles), K // 128)))
+        sk = 1
+        while sk * 2 * tiles <= 1280 and K // (sk * 2) >= 128 and sk < 64:
+            sk *= 2
+        return sk
 
     def _alloc_splitk(self, shapes):
         """Workspace for the split-K GEMMs of this model: shapes = [(M, N, K), ...]."""
@@ -132,10 +137,15 @@ class ModelBase:
         self.skwork = self._f(need)
 
     def gemm_sk(self, A, B, C, M, N, K, lda, ldb, ldc, **kw):
-        """GEMM with an automatic split-K choice (uses self.skwork)."""
+        """GEMM with the calibrated split-K choice.  The workspace grows on demand during eager
+        (warm-up) passes; growing it invalidates captured graphs, which are then re-captured."""
         sk = self.pick_splitk(M, N, K)
         if sk > 1:
-            assert sk * M * N <= self.skwork.numel(), "split-K workspace too small"
+            if sk * M * N > self.skwork.numel():
+                if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("split-K workspace too small inside a graph capture")
+                self.skwork = self._f(sk * M * N)
+                self._graphs = {}
             self.be.gemm(A, B, C, M, N, K, lda, ldb, ldc, splitk=sk, work=self.skwork, **kw)
         else:
             self.be.gemm(A, B, C, M, N, K, lda, ldb, ldc, **kw)

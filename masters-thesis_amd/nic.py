@@ -220,7 +220,7 @@ class NIC(ModelBase):
             be.dropout(self.Xin[B:], self.Xin_d[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
             xin = self.Xin_d
         self._xin_used = xin
-        be.gemm(xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U, bias=a.p("lstm/bias"))
+        self.gemm_sk(xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U, bias=a.p("lstm/bias"))
         Ur = a.p("lstm/recurrent_kernel")
         # lstm call 1: the feature, one unmasked step (NIC.py:138)
         be.lstm_step_fwd(self.XZ[:B], self.Hs[0], self.Cs[0], Ur, None, None, 0, None, 0, 0, None, self.Hs[1],
@@ -230,7 +230,7 @@ class NIC(ModelBase):
             be.lstm_step_fwd(self.XZ[t * B:(t + 1) * B], self.Hs[t], self.Cs[t], Ur, None, None, 0, self.cap, T,
                              t - 1, self.Out[t - 2] if t > 1 else None, self.Hs[t + 1], self.Cs[t + 1],
                              self.Out[t - 1], self.gates[t], B, U)
-        be.gemm(self.Out, a.p("time_distributed_softmax/kernel"), self.logits, T * B, V, U, U, ldV, ldV,
+        self.gemm_sk(self.Out, a.p("time_distributed_softmax/kernel"), self.logits, T * B, V, U, U, ldV, ldV,
                 bias=a.p("time_distributed_softmax/bias"))                         # NIC.py:143
 
     def _loss_metrics(self, B, T, want_grad):
@@ -259,7 +259,7 @@ class NIC(ModelBase):
         U, V, ldV = self.U, self.V, self.ldV
         dlog = self.logits
         Wo = a.p("time_distributed_softmax/kernel")
-        be.gemm(self.Out, dlog, a.g("time_distributed_softmax/kernel"), U, V, T * B, U, ldV, ldV, transA=True)
+        self.gemm_sk(self.Out, dlog, a.g("time_distributed_softmax/kernel"), U, V, T * B, U, ldV, ldV, transA=True)
         be.colsum(dlog, a.g("time_distributed_softmax/bias"), T * B, V, ldV, self.work)
         self.gemm_sk(dlog, Wo, self.dOut, T * B, U, V, ldV, ldV, U, transB=True)
 
@@ -281,8 +281,8 @@ class NIC(ModelBase):
         be.lstm_step_bwd(self.dZ[B:2 * B], Ur, self.da_pass, None, self.dc, None, None, None, 0, 0, self.gates[0],
                          self.Cs[1], self.Cs[0], self.dZ[:B], None, None, None, B, U)
         xin = self._xin_used
-        be.gemm(self.Hs, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, R1, U, 4 * U, 4 * U, transA=True)
-        be.gemm(xin, self.dZ, a.g("lstm/kernel"), E, 4 * U, R1, E, 4 * U, 4 * U, transA=True)
+        self.gemm_sk(self.Hs, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, R1, U, 4 * U, 4 * U, transA=True)
+        self.gemm_sk(xin, self.dZ, a.g("lstm/kernel"), E, 4 * U, R1, E, 4 * U, 4 * U, transA=True)
         be.colsum(self.dZ, a.g("lstm/bias"), R1, 4 * U, 4 * U, self.work)
         self.gemm_sk(self.dZ, a.p("lstm/kernel"), self.dXin, R1, E, 4 * U, 4 * U, 4 * U, E, transB=True)
         if self.r_lstm > 0:
@@ -313,7 +313,7 @@ class NIC(ModelBase):
             x, dpre, rows = x_all, dpre_all, x_all.shape[0]
         else:
             dpre = self.dpre
-        be.gemm(x, dpre, a.g("dense_img/kernel"), self.N, self.E, rows, self.ldx, self.E, self.E, transA=True)
+        self.gemm_sk(x, dpre, a.g("dense_img/kernel"), self.N, self.E, rows, self.ldx, self.E, self.E, transA=True)
 
     # ------------------------------------------------------------------ steps
     def _train_graph(self, B, T):
@@ -387,7 +387,7 @@ class NIC(ModelBase):
         xz, emb = self.XZ[:B], self.Xin[B:2 * B]
         h = [self.Hs[0], self.Hs[1]]
         c = [self.Cs[0], self.Cs[1]]
-        be.gemm(self.Xin, Wl, xz, B, 4 * U, E, E, 4 * U, 4 * U, bias=bl)
+        self.gemm_sk(self.Xin, Wl, xz, B, 4 * U, E, E, 4 * U, 4 * U, bias=bl)
         be.lstm_step_fwd(xz, h[0], c[0], Ur, None, None, 0, None, 0, 0, None, h[1], c[1], None, self.gates[0], B, U)
         cur = 1
         words = start.clone().view(B, 1)
@@ -395,11 +395,11 @@ class NIC(ModelBase):
         probs_all = torch.zeros(max_len, B, ldV, dtype=torch.float32, device=self.device)
         for i in range(max_len):
             be.embedding_fwd(a.p("emb_text/embeddings"), words, emb, B, 1, E, E, V)
-            be.gemm(emb, Wl, xz, B, 4 * U, E, E, 4 * U, 4 * U, bias=bl)
+            self.gemm_sk(emb, Wl, xz, B, 4 * U, E, E, 4 * U, 4 * U, bias=bl)
             be.lstm_step_fwd(xz, h[cur], c[cur], Ur, None, None, 0, words if i > 0 else None, 1, 0, None,
                              h[1 - cur], c[1 - cur], out, self.gates[0], B, U)
             cur = 1 - cur
-            be.gemm(out, a.p("time_distributed_softmax/kernel"), probs_all[i], B, V, U, U, ldV, ldV,
+            self.gemm_sk(out, a.p("time_distributed_softmax/kernel"), probs_all[i], B, V, U, U, ldV, ldV,
                     bias=a.p("time_distributed_softmax/bias"))
             be.softmax_cce(probs_all[i], None, probs_all[i], None, None, None, B, V, ldV, 0.0)
             be.argmax_rows(probs_all[i], words, B, V, ldV)

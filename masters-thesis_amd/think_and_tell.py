@@ -197,7 +197,7 @@ class CaptionGenerator(ModelBase):
         if training and self.r_enc > 0:
             be.dropout(self.Xin, self.Xin, B, E, E, 0, E, 0, self.r_enc, sd, S_FEAT, 0, ds)
         be.embedding_fwd(a.p("embedding/embeddings"), self.cap, self.Xin[B:], B, T, E, E, V)
-        be.gemm(self.Xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U, bias=a.p("lstm/bias"))
+        self.gemm_sk(self.Xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U, bias=a.p("lstm/bias"))
         Ur = a.p("lstm/recurrent_kernel")
         mask = self.lenmask if self.sat else None
         for t in range(T + 1):
@@ -209,10 +209,10 @@ class CaptionGenerator(ModelBase):
             hd = self.Hd
         self._hd_used = hd
         if self.sat:
-            be.gemm(hd, a.p("fc1/kernel"), self.mid, R1, U, U, U, U, U, bias=a.p("fc1/bias"))
-            be.gemm(self.mid, a.p("fc_vocab/kernel"), self.logits, R1, V, U, U, ldV, ldV, bias=a.p("fc_vocab/bias"))
+            self.gemm_sk(hd, a.p("fc1/kernel"), self.mid, R1, U, U, U, U, U, bias=a.p("fc1/bias"))
+            self.gemm_sk(self.mid, a.p("fc_vocab/kernel"), self.logits, R1, V, U, U, ldV, ldV, bias=a.p("fc_vocab/bias"))
         else:
-            be.gemm(hd, a.p("fc_vocab/kernel"), self.logits, R1, V, U, U, ldV, ldV, bias=a.p("fc_vocab/bias"),
+            self.gemm_sk(hd, a.p("fc_vocab/kernel"), self.logits, R1, V, U, U, ldV, ldV, bias=a.p("fc_vocab/bias"),
                     act=ACT_RELU)
 
     def _loss(self, B, T, want_grad, grad_scale):
@@ -235,16 +235,16 @@ class CaptionGenerator(ModelBase):
         sd, ds = self.seed, self.drop_step
         hd = self._hd_used
         if self.sat:
-            be.gemm(self.mid, self.dlogits, a.g("fc_vocab/kernel"), U, V, R1, U, ldV, ldV, transA=True)
+            self.gemm_sk(self.mid, self.dlogits, a.g("fc_vocab/kernel"), U, V, R1, U, ldV, ldV, transA=True)
             be.colsum(self.dlogits, a.g("fc_vocab/bias"), R1, V, ldV, self.work)
             self.gemm_sk(self.dlogits, a.p("fc_vocab/kernel"), self.dmid, R1, U, V, ldV, ldV, U, transB=True)
-            be.gemm(hd, self.dmid, a.g("fc1/kernel"), U, U, R1, U, U, U, transA=True)
+            self.gemm_sk(hd, self.dmid, a.g("fc1/kernel"), U, U, R1, U, U, U, transA=True)
             be.colsum(self.dmid, a.g("fc1/bias"), R1, U, U, self.work)
-            be.gemm(self.dmid, a.p("fc1/kernel"), self.dOut, R1, U, U, U, U, U, transB=True)
+            self.gemm_sk(self.dmid, a.p("fc1/kernel"), self.dOut, R1, U, U, U, U, U, transB=True)
         else:
             # ReLU backward: relu'(pre) == (output > 0), so the stored output serves as "pre"
             be.act_bwd(self.logits, self.dlogits, self.dlogits, R1 * ldV, ACT_RELU, 0.0)
-            be.gemm(hd, self.dlogits, a.g("fc_vocab/kernel"), U, V, R1, U, ldV, ldV, transA=True)
+            self.gemm_sk(hd, self.dlogits, a.g("fc_vocab/kernel"), U, V, R1, U, ldV, ldV, transA=True)
             be.colsum(self.dlogits, a.g("fc_vocab/bias"), R1, V, ldV, self.work)
             self.gemm_sk(self.dlogits, a.p("fc_vocab/kernel"), self.dOut, R1, U, V, ldV, ldV, U, transB=True)
         if self.r_dec > 0:
@@ -257,8 +257,8 @@ class CaptionGenerator(ModelBase):
                              None, None if first else self.dc, None, self.dOut[t * B:(t + 1) * B], mask, T + 1, t,
                              self.gates[t], self.Cs[t + 1], self.Cs[t], self.dZ[t * B:(t + 1) * B], self.da_pass,
                              self.dc, None, B, U)
-        be.gemm(self.Hs, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, R1, U, 4 * U, 4 * U, transA=True)
-        be.gemm(self.Xin, self.dZ, a.g("lstm/kernel"), E, 4 * U, R1, E, 4 * U, 4 * U, transA=True)
+        self.gemm_sk(self.Hs, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, R1, U, 4 * U, 4 * U, transA=True)
+        self.gemm_sk(self.Xin, self.dZ, a.g("lstm/kernel"), E, 4 * U, R1, E, 4 * U, 4 * U, transA=True)
         be.colsum(self.dZ, a.g("lstm/bias"), R1, 4 * U, 4 * U, self.work)
         self.gemm_sk(self.dZ, a.p("lstm/kernel"), self.dXin, R1, E, 4 * U, 4 * U, 4 * U, E, transB=True)
         sqo = a.sq_override[self.emb_seg:self.emb_seg + 1]
@@ -268,7 +268,7 @@ class CaptionGenerator(ModelBase):
             be.dropout(self.dXin, self.dXin, B, E, E, 0, E, 0, self.r_enc, sd, S_FEAT, 0, ds)
         be.act_bwd(self.enc_pre, self.dXin, self.dpre, B * E, ACT_RELU if self.sat else ACT_TANH, 0.0)
         be.colsum(self.dpre, a.g("fc_embedding/bias"), B, E, E, self.work)
-        be.gemm(self.x, self.dpre, a.g("fc_embedding/kernel"), N, E, B, self.ldx, E, E, transA=True)
+        self.gemm_sk(self.x, self.dpre, a.g("fc_embedding/kernel"), N, E, B, self.ldx, E, E, transA=True)
 
     # ------------------------------------------------------------------ steps
     def _unpack_batch(self, data):
