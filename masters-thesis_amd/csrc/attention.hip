@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttArgs g) {
       float t = 0.f;
       if (r < g.R && a < g.A) {
         const long e = ((long)b * g.R + r) * g.A + a;
-        float s = tanhf(pv[u] + qs[a]);
+        float s = tnt_tanh(pv[u] + qs[a]);
         if (g.rate_attn > 0.f) s = tnt_keep((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step) ? s * scale_a : 0.f;
         if (g.s_out) g.s_out[e] = s;
         t = s * va;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttArgs g) {
         const int r = r0 + u * RP;
         if (r >= g.R) continue;
         const long e = ((long)b * g.R + r) * g.A + a;
-        const float s = tanhf(pv[u] + qs[a]);
+        const float s = tnt_tanh(pv[u] + qs[a]);
         bool keep = true;
         if (g.rate_attn > 0.f) keep = tnt_keep((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step);
         const float ks = keep ? (g.rate_attn > 0.f ? scale_a : 1.f) : 0.f;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(WT) void attention_fwd_wide_kernel(AttArgs g) {
       float t = 0.f;
       if (cok && r < R) {
         const long e = ((long)b * R + r) * A + c4 * 4;
-        float s0 = tanhf(pv[p].x + q4.x), s1 = tanhf(pv[p].y + q4.y), s2 = tanhf(pv[p].z + q4.z), s3 = tanhf(pv[p].w + q4.w);
+        float s0 = tnt_tanh(pv[p].x + q4.x), s1 = tnt_tanh(pv[p].y + q4.y), s2 = tnt_tanh(pv[p].z + q4.z), s3 = tnt_tanh(pv[p].w + q4.w);
         if (g.rate_attn > 0.f) {
           bool k[4];
           tnt_keep4((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step, k);
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(WT) void attention_bwd_wide_kernel(AttArgs g) {
       const int r = p * RPP + rl;
       if (!(cok && r < R)) continue;
       const long e = ((long)b * R + r) * A + c4 * 4;
-      const float s0 = tanhf(pv[p].x + q4.x), s1 = tanhf(pv[p].y + q4.y), s2 = tanhf(pv[p].z + q4.z), s3 = tanhf(pv[p].w + q4.w);
+      const float s0 = tnt_tanh(pv[p].x + q4.x), s1 = tnt_tanh(pv[p].y + q4.y), s2 = tnt_tanh(pv[p].z + q4.z), s3 = tnt_tanh(pv[p].w + q4.w);
       bool k[4] = {true, true, true, true};
       if (g.rate_attn > 0.f) tnt_keep4((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step, k);
       const float k0 = k[0] ? scale_a : 0.f, k1 = k[1] ? scale_a : 0.f, k2 = k[2] ? scale_a : 0.f, k3 = k[3] ? scale_a : 0.f;

@@ -134,31 +134,62 @@ struct LstmBwdArgs {
   int mask_T, mask_t, B, U;
 };
 
+// ---- shared pieces of the two backward variants
+struct BwdEpi {
+  float da0, dout, dcin, cval, cprev; float4 g4; int mid; bool eok; long e; int erow, ecol;
+};
+__device__ __forceinline__ BwdEpi bwd_prefetch(const LstmBwdArgs& a, int tid, int rb, int ub) {
+  BwdEpi p;
+  p.erow = tid >> 4; p.ecol = tid & 15;
+  const int eb = rb * 16 + p.erow, eu = ub * 16 + p.ecol;
+  p.eok = tid < 256 && eb < a.B;
+  p.e = (long)eb * a.U + eu;
+  p.da0 = 0.f; p.dout = 0.f; p.dcin = 0.f; p.cval = 0.f; p.cprev = 0.f; p.mid = 1;
+  p.g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.eok) {
+    if (a.da_pass_in) p.da0 += a.da_pass_in[p.e];
+    if (a.dh_ext) p.da0 += a.dh_ext[p.e];
+    if (a.dout_in) p.dout += a.dout_in[p.e];
+    if (a.dout_t) p.dout += a.dout_t[p.e];
+    if (a.dc_in) p.dcin = a.dc_in[p.e];
+    if (a.mask_ids) p.mid = a.mask_ids[eb * a.mask_T + a.mask_t];
+    p.g4 = *reinterpret_cast<const float4*>(a.gates + p.e * 4);
+    p.cval = a.c[p.e]; p.cprev = a.c_prev[p.e];
+  }
+  return p;
+}
+__device__ __forceinline__ void bwd_epilogue(const LstmBwdArgs& a, const BwdEpi& p, float da) {
+  if (!p.eok) return;
+  const bool m = p.mid != 0;
+  float4 dz4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dc_o = p.dcin, da_o = da, dout_o = p.dout;
+  if (m) {
+    const float gi = p.g4.x, gf = p.g4.y, gg = p.g4.z, go = p.g4.w;
+    const float tc = tanhf(p.cval);
+    const float dh = da + p.dout;
+    const float dgo = dh * tc;
+    const float dc = p.dcin + dh * go * (1.f - tc * tc);
+    dz4.x = dc * gg * gi * (1.f - gi);
+    dz4.y = dc * p.cprev * gf * (1.f - gf);
+    dz4.z = dc * gi * (1.f - gg * gg);
+    dz4.w = dgo * go * (1.f - go);
+    dc_o = dc * gf; da_o = 0.f; dout_o = 0.f;
+  }
+  *reinterpret_cast<float4*>(a.dz + p.e * 4) = dz4;
+  if (a.dc_out) a.dc_out[p.e] = dc_o;
+  if (a.da_pass_out) a.da_pass_out[p.e] = da_o;
+  if (a.dout_out) a.dout_out[p.e] = dout_o;
+}
+
+// general variant: operands straight to registers (any U % 16 == 0; also the no-matmul first step)
 __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdArgs a) {
   __shared__ float red[NW][16][17];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
   const int ub = blockIdx.x, rb = blockIdx.y;
-  const int U = a.U, B = a.B, K = 4 * a.U;
+  const int B = a.B, K = 4 * a.U;
   floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
-  // epilogue operands do not depend on the matmul: fetch them now, under the weight stream
-  const int erow = tid >> 4, ecol = tid & 15;
-  const int eb = rb * 16 + erow, eu = ub * 16 + ecol;
-  const bool eok = tid < 256 && eb < B;
-  const long e = (long)eb * U + eu;
-  float da0 = 0.f, dout = 0.f, dcin = 0.f, cval = 0.f, cprev = 0.f;
-  float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  int mid = 1;
-  if (eok) {
-    if (a.da_pass_in) da0 += a.da_pass_in[e];
-    if (a.dh_ext) da0 += a.dh_ext[e];
-    if (a.dout_in) dout += a.dout_in[e];
-    if (a.dout_t) dout += a.dout_t[e];
-    if (a.dc_in) dcin = a.dc_in[e];
-    if (a.mask_ids) mid = a.mask_ids[eb * a.mask_T + a.mask_t];
-    g4 = *reinterpret_cast<const float4*>(a.gates + e * 4);
-    cval = a.c[e]; cprev = a.c_prev[e];
-  }
+  const BwdEpi ep = bwd_prefetch(a, tid, rb, ub);
   if (a.dz_next) {
     const int arow = rb * 16 + lr, ucol = ub * 16 + lr;
     const int nchunk = K / 64;   // U % 16 == 0  =>  4U % 64 == 0
@@ -190,29 +221,82 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdArgs a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[w][kq * 4 + r][lr] = acc[r];
   __syncthreads();
-  if (eok) {
-    float da = da0;
+  if (ep.eok) {
+    float da = ep.da0;
 #pragma unroll
-    for (int k = 0; k < NW; ++k) da += red[k][erow][ecol];
-    const bool m = mid != 0;
-    float4 dz4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float dc_o = dcin, da_o = da, dout_o = dout;
-    if (m) {
-      const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
-      const float tc = tanhf(cval);
-      const float dh = da + dout;
-      const float dgo = dh * tc;
-      const float dc = dcin + dh * go * (1.f - tc * tc);
-      dz4.x = dc * gg * gi * (1.f - gi);
-      dz4.y = dc * cprev * gf * (1.f - gf);
-      dz4.z = dc * gi * (1.f - gg * gg);
-      dz4.w = dgo * go * (1.f - go);
-      dc_o = dc * gf; da_o = 0.f; dout_o = 0.f;
+    for (int k = 0; k < NW; ++k) da += red[k][ep.erow][ep.ecol];
+    bwd_epilogue(a, ep, da);
+  }
+}
+
+// LDS-staged variant (4U % 1024 == 0): both operands are k-contiguous rows (dz_next[b][:], Ur[u][:]),
+// so fragment-shaped register loads touch 16 rows x 64 B per instruction -- slow in the texture
+// addresser.  Here all 512 threads stream whole rows (1 KiB contiguous per wave-instruction) into LDS,
+// 1024 k at a time, and the waves read their MFMA operands back with conflict-free ds_read_b128
+// (row stride KC+8 floats).  The loads of chunk i+1 are in flight during the MFMAs of chunk i.
+constexpr int KC = 1024, KLD = KC + 8;
+__global__ __launch_bounds__(512) void lstm_bwd_lds_kernel(LstmBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Zs = smem;                       // [16][KLD]  dz_next rows of this row block
+  float* Us = smem + 16 * KLD;            // [16][KLD]  Ur rows of this unit block
+  float (*red)[16][17] = reinterpret_cast<float (*)[16][17]>(smem + 32 * KLD);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kq = lane >> 4, lr = lane & 15;
+  const int ub = blockIdx.x, rb = blockIdx.y;
+  const int B = a.B, K = 4 * a.U;
+  const int nchunk = K / KC;
+  floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+  const BwdEpi ep = bwd_prefetch(a, tid, rb, ub);
+  constexpr int NLD = 16 * KC / 4 / 512;     // float4 per thread per operand per chunk
+  float4 rz[NLD], ru[NLD];
+  auto gload = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int f = tid + i * 512;                 // 16 rows x KC/4 float4
+      const int row = f / (KC / 4), c4 = (f % (KC / 4)) * 4;
+      rz[i] = ld4g(a.dz_next + (long)(rb * 16 + row) * K + c * KC + c4, rb * 16 + row < B);
+      ru[i] = ld4g(a.Ur + (long)(ub * 16 + row) * K + c * KC + c4, true);
     }
-    *reinterpret_cast<float4*>(a.dz + e * 4) = dz4;
-    if (a.dc_out) a.dc_out[e] = dc_o;
-    if (a.da_pass_out) a.da_pass_out[e] = da_o;
-    if (a.dout_out) a.dout_out[e] = dout_o;
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int f = tid + i * 512;
+      const int row = f / (KC / 4), c4 = (f % (KC / 4)) * 4;
+      *reinterpret_cast<float4*>(&Zs[row * KLD + c4]) = rz[i];
+      *reinterpret_cast<float4*>(&Us[row * KLD + c4]) = ru[i];
+    }
+  };
+  gload(0);
+  sstore();
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    if (c + 1 < nchunk) gload(c + 1);
+    const float* zr = Zs + lr * KLD + w * (KC / NW) + 4 * kq;
+    const float* ur = Us + lr * KLD + w * (KC / NW) + 4 * kq;
+#pragma unroll
+    for (int j = 0; j < KC / NW / 16; ++j) {
+      const float4 x = *reinterpret_cast<const float4*>(zr + 16 * j);
+      const float4 y = *reinterpret_cast<const float4*>(ur + 16 * j);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, y.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, y.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, y.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, y.w, acc, 0, 0, 0);
+    }
+    if (c + 1 < nchunk) {
+      __syncthreads();
+      sstore();
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[w][kq * 4 + r][lr] = acc[r];
+  __syncthreads();
+  if (ep.eok) {
+    float da = ep.da0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) da += red[k][ep.erow][ep.ecol];
+    bwd_epilogue(a, ep, da);
   }
 }
 
@@ -248,7 +332,19 @@ extern "C" int32_t tnt_lstm_step_bwd_f32(const float* dz_next, const float* Ur, 
   a.dout_t = dout_t; a.mask_ids = mask_ids; a.gates = gates; a.c = c; a.c_prev = c_prev; a.dz = dz;
   a.da_pass_out = da_pass_out; a.dc_out = dc_out; a.dout_out = dout_out;
   a.mask_T = mask_T; a.mask_t = mask_t; a.B = B; a.U = U;
-  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(U / 16, (B + 15) / 16), dim3(512), 0, tnt_stream(stream), a);
+  if (dz_next != nullptr && (4 * U) % KC == 0) {
+    const size_t smem = (size_t)(32 * KLD + NW * 16 * 17) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_lds_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return -(int32_t)e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(lstm_bwd_lds_kernel, dim3(U / 16, (B + 15) / 16), dim3(512), smem, tnt_stream(stream), a);
+  } else {
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(U / 16, (B + 15) / 16), dim3(512), 0, tnt_stream(stream), a);
+  }
   TNT_LAUNCH_CHECK();
   return 0;
 }
