@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="dense", choices=["dense", "attention"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-inputs", action="store_true", help="feed numpy batches (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel schedule even at world size 1 (rehearsal)")
     args = ap.parse_args()
 
@@ -158,6 +159,9 @@ def main():
         from masters_thesis_amd import dp
         dp.attach(model, world)
     batch, host_batch = synth(rank, device)
+    if args.host_inputs:
+        x, cap, z, tgt = host_batch
+        batch = ((x, cap, z, z), tgt)
 
     for _ in range(args.warmup):
         model.train_step(batch)
@@ -185,7 +189,8 @@ def main():
             "metric": "caption-tokens/sec training (20k-voxel enc, 512 LSTM, B=64)",
             "value": round(tokens / el, 1), "unit": "caption-tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" + (" (host numpy batches, PCIe-inclusive)" if args.host_inputs else ""),
             "config": {"workload": ("config 2: AttemptFour NIC.py dense 20000->512 encoder + BatchNorm + 512-unit LSTM, "
                                     "V=5001, T=15, B=64/GPU" if args.workload == "dense" else
                                     "config 3: lc_NIC locally-dense 20000->360x32 + additive attention + 512-unit LSTM, "
