@@ -9,6 +9,7 @@ launches and owns buffers; it contains no arithmetic of the hot path.
 """
 import time
 from collections import OrderedDict
+from contextlib import contextmanager
 
 import numpy as np
 import torch
@@ -136,19 +137,53 @@ class ModelBase:
         need = max([self.pick_splitk(*s) * s[0] * s[1] for s in shapes] + [1])
         self.skwork = self._f(need)
 
-    def gemm_sk(self, A, B, C, M, N, K, lda, ldb, ldc, **kw):
-        """GEMM with the calibrated split-K choice.  The workspace grows on demand during eager
-        (warm-up) passes; growing it invalidates captured graphs, which are then re-captured."""
+    def gemm_sk(self, A, B, C, M, N, K, lda, ldb, ldc, ws=0, **kw):
+        """GEMM with the calibrated split-K choice.  ``ws`` selects the split-K workspace (one per
+        concurrent branch, see ``side``).  Workspaces grow on demand during eager (warm-up) passes;
+        growing one invalidates captured graphs, which are then re-captured."""
         sk = self.pick_splitk(M, N, K)
         if sk > 1:
-            if sk * M * N > self.skwork.numel():
+            pool = self.__dict__.setdefault("_skw", {})
+            buf = self.skwork if ws == 0 else pool.get(ws)
+            if buf is None or sk * M * N > buf.numel():
                 if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
                     raise RuntimeError("split-K workspace too small inside a graph capture")
-                self.skwork = self._f(sk * M * N)
+                buf = self._f(sk * M * N)
+                if ws == 0:
+                    self.skwork = buf
+                else:
+                    pool[ws] = buf
                 self._graphs = {}
-            self.be.gemm(A, B, C, M, N, K, lda, ldb, ldc, splitk=sk, work=self.skwork, **kw)
+            self.be.gemm(A, B, C, M, N, K, lda, ldb, ldc, splitk=sk, work=buf, **kw)
         else:
             self.be.gemm(A, B, C, M, N, K, lda, ldb, ldc, **kw)
+
+    # ---- intra-step concurrency: independent gradient GEMMs run on side streams (captured as parallel
+    # graph branches) next to the latency-bound BPTT chain, which leaves most CUs idle.
+    @contextmanager
+    def side(self, i):
+        # Measured on MI355X (tools/side_bench.py): 0.868 ms/step without, 0.94-1.07 ms with side branches --
+        # the concurrent GEMM workgroups crowd out the LDS-heavy BPTT step kernels.  Off by default.
+        if i < 0 or self.device.type != "cuda" or not getattr(self, "use_side_streams", False):
+            yield
+            return
+        streams = self.__dict__.setdefault("_side_streams", {})
+        if i not in streams:
+            streams[i] = torch.cuda.Stream(device=self.device)
+        s = streams[i]
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            yield
+        self.__dict__.setdefault("_side_used", set()).add(i)
+
+    def join(self):
+        used = self.__dict__.get("_side_used")
+        if not used:
+            return
+        main = torch.cuda.current_stream()
+        for i in sorted(used):
+            main.wait_stream(self._side_streams[i])
+        used.clear()
 
     def _norms_and_l2(self, l2_out):
         a, sp = self.arena, self.arena.spans

@@ -170,6 +170,7 @@ class NIC(ModelBase):
         self._alloc_splitk([(B, E, N), (T * B, U, V), (R1, E, 4 * U), (R1, 4 * U, E), (T * B, V, U)])
         nch = max(be.bn_nchunk(B), be.bn_nchunk(R1), be.bn_nchunk(T * B))
         self.work = f(max(E, 4 * U, ldV) * (2 * nch + 1))
+        self.work2 = f(max(E, 4 * U, ldV) * (2 * nch + 1))
         self.rowsq = f(B * T)
         self.emb_seg = self.arena.entries["emb_text/embeddings"].seg
         self._shape = (B, T)
@@ -249,21 +250,26 @@ class NIC(ModelBase):
 
     # ------------------------------------------------------------------ backward
     def _backward(self, B, T):
-        self._bwd_head(B, T)
-        self._bwd_seq(B, T)
+        self._bwd_head(B, T, join=False)       # dW of the head keeps running beside the BPTT chain
+        self._bwd_seq(B, T, join=False)
         self._bwd_enc(B, T)
+        self.join()
 
-    def _bwd_head(self, B, T):
+    def _bwd_head(self, B, T, join=True):
         """vocabulary head: dW, db, dX (gradients ready first -> first all-reduce bucket under DP)."""
         be, a = self.be, self.arena
         U, V, ldV = self.U, self.V, self.ldV
         dlog = self.logits
         Wo = a.p("time_distributed_softmax/kernel")
-        self.gemm_sk(self.Out, dlog, a.g("time_distributed_softmax/kernel"), U, V, T * B, U, ldV, ldV, transA=True)
-        be.colsum(dlog, a.g("time_distributed_softmax/bias"), T * B, V, ldV, self.work)
+        with self.side(0 if getattr(self, "side_head", True) else -1):
+            self.gemm_sk(self.Out, dlog, a.g("time_distributed_softmax/kernel"), U, V, T * B, U, ldV, ldV, transA=True,
+                         ws=1)
+            be.colsum(dlog, a.g("time_distributed_softmax/bias"), T * B, V, ldV, self.work2)
         self.gemm_sk(dlog, Wo, self.dOut, T * B, U, V, ldV, ldV, U, transB=True)
+        if join:
+            self.join()
 
-    def _bwd_seq(self, B, T):
+    def _bwd_seq(self, B, T, join=True):
         """BPTT, LSTM / embedding / BatchNorm gradients, down to dpre of the encoder Dense."""
         be, a = self.be, self.arena
         N, U, E, V, ldV = self.N, self.U, self.E, self.V, self.ldV
@@ -281,9 +287,11 @@ class NIC(ModelBase):
         be.lstm_step_bwd(self.dZ[B:2 * B], Ur, self.da_pass, None, self.dc, None, None, None, 0, 0, self.gates[0],
                          self.Cs[1], self.Cs[0], self.dZ[:B], None, None, None, B, U)
         xin = self._xin_used
-        self.gemm_sk(self.Hs, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, R1, U, 4 * U, 4 * U, transA=True)
-        self.gemm_sk(xin, self.dZ, a.g("lstm/kernel"), E, 4 * U, R1, E, 4 * U, 4 * U, transA=True)
-        be.colsum(self.dZ, a.g("lstm/bias"), R1, 4 * U, 4 * U, self.work)
+        with self.side(1):
+            self.gemm_sk(self.Hs, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, R1, U, 4 * U, 4 * U, transA=True, ws=2)
+        with self.side(0):
+            self.gemm_sk(xin, self.dZ, a.g("lstm/kernel"), E, 4 * U, R1, E, 4 * U, 4 * U, transA=True, ws=1)
+            be.colsum(self.dZ, a.g("lstm/bias"), R1, 4 * U, 4 * U, self.work2)
         self.gemm_sk(self.dZ, a.p("lstm/kernel"), self.dXin, R1, E, 4 * U, 4 * U, 4 * U, E, transB=True)
         if self.r_lstm > 0:
             be.dropout(self.dXin, self.dXin, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
@@ -301,6 +309,8 @@ class NIC(ModelBase):
             be.dropout(self.dyd, self.dyd, B, E, E, 0, E, 0, self.r_feat, sd, S_FEAT, 0, ds)
         be.act_bwd(self.enc_pre, self.dyd, self.dpre, B * E, ACT_LEAKY, 0.2)
         be.colsum(self.dpre, a.g("dense_img/bias"), B, E, E, self.work)
+        if join:
+            self.join()
 
     def _bwd_enc(self, B, T, x_all=None, dpre_all=None):
         """encoder kernel gradient dW = X^T dpre.  Under DP the operands of all ranks are passed
