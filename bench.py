@@ -148,16 +148,27 @@ def main():
     device = torch.device("cuda", local_rank)
     grad_sync = None
     use_dp = world > 1 or args.force_dp
+    saved_stdout = None
     if use_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # RCCL prints banner lines ("Hostname", "Librccl path") on fd 1 when the communicator is created;
+        # stdout must carry exactly one JSON line, so fd 1 points at stderr until the communicator exists.
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     model = make_model(args.workload, device, None)
     if use_dp:
         from masters_thesis_amd import dp
         dp.attach(model, world)
+        torch.cuda.synchronize()
+        dist.barrier()
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     batch, host_batch = synth(rank, device)
     if args.host_inputs:
         x, cap, z, tgt = host_batch
