@@ -179,6 +179,10 @@ int32_t tnt_seg_sqnorm_f32(const float* theta, const float* grad, const int32_t*
                            const int32_t* seg_first, const float* seg_l2, float* partial,
                            float* sq, float* wsq, float* l2_out, int32_t nspan, int32_t nseg,
                            void* stream);
+/* out[0] = sum_s seg_l2[s]*wsq[s]; for callers that run tnt_seg_sqnorm_f32 on slices of the span
+ * table (offset pointers, slice-local seg_first; the pipelined data-parallel update) and need the
+ * total afterwards. */
+int32_t tnt_l2_total_f32(const float* wsq, const float* seg_l2, int32_t nseg, float* out, void* stream);
 int32_t tnt_adam_f32(float* theta, float* m, float* v, const float* grad,
                      const int32_t* span_seg, const int64_t* span_off, const int32_t* span_len,
                      const float* seg_l2, const float* sq, const float* sq_override,

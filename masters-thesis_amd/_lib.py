@@ -36,6 +36,7 @@ SIGNATURES = {
     "tnt_onehot_argmax_f32": [P, P, I32, I32, I32, P],
     "tnt_argmax_rows_f32": [P, P, I32, I32, I32, P],
     "tnt_sum_f32": [P, P, I32, F32, P],
+    "tnt_l2_total_f32": [P, P, I32, P, P],
     "tnt_seg_sqnorm_f32": [P, P, P, P, P, P, P, P, P, P, P, I32, I32, P],
     "tnt_adam_f32": [P, P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, F32, F32, P],
     "tnt_sgd_f32": [P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, P],

@@ -22,6 +22,24 @@ class Spans:
     span_len: torch.Tensor
     seg_first: torch.Tensor
     nspan: int
+    first_host: tuple = ()
+
+
+@dataclass
+class SegSlice:
+    """Spans of the contiguous segment range [seg0, seg1): views into the arena's span table with a
+    slice-local seg_first, so norms + clip + Adam can run on part of the arena as soon as that part's
+    gradients are final (pipelined data-parallel update)."""
+    seg0: int
+    nseg: int
+    nspan: int
+    span_seg: torch.Tensor
+    span_off: torch.Tensor
+    span_len: torch.Tensor
+    seg_first: torch.Tensor
+    partial: torch.Tensor
+    sq: torch.Tensor
+    wsq: torch.Tensor
 
 
 def build_spans(offs, lens, device):
@@ -37,7 +55,7 @@ def build_spans(offs, lens, device):
     return Spans(torch.tensor(seg, dtype=torch.int32, device=device),
                  torch.tensor(off, dtype=torch.int64, device=device),
                  torch.tensor(ln, dtype=torch.int32, device=device),
-                 torch.tensor(first, dtype=torch.int32, device=device), len(seg))
+                 torch.tensor(first, dtype=torch.int32, device=device), len(seg), tuple(first))
 
 
 @dataclass
@@ -84,6 +102,13 @@ class ParamArena:
         self.sq_override = torch.full((self.nseg,), -1.0, dtype=torch.float32, device=dev)
         self.partial = torch.zeros(2 * self.spans.nspan, dtype=torch.float32, device=dev)
         return self
+
+    def seg_slice(self, seg0, seg1):
+        sp, fh = self.spans, self.spans.first_host
+        s0, s1 = fh[seg0], fh[seg1]
+        local = torch.tensor([f - s0 for f in fh[seg0:seg1 + 1]], dtype=torch.int32, device=self.device)
+        return SegSlice(seg0, seg1 - seg0, s1 - s0, sp.span_seg[s0:s1], sp.span_off[s0:s1], sp.span_len[s0:s1], local,
+                        self.partial[2 * s0:2 * s1], self.sq[seg0:seg1], self.wsq[seg0:seg1])
 
     def p(self, name):
         e = self.entries[name]

@@ -213,6 +213,13 @@ extern "C" int32_t tnt_seg_sqnorm_f32(const float* theta, const float* grad, con
   return 0;
 }
 
+extern "C" int32_t tnt_l2_total_f32(const float* wsq, const float* seg_l2, int32_t nseg, float* out, void* stream) {
+  if (nseg <= 0) return 0;
+  hipLaunchKernelGGL(l2_total_kernel, dim3(1), dim3(256), 0, tnt_stream(stream), wsq, seg_l2, nseg, out);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int32_t tnt_adam_f32(float* theta, float* m, float* v, const float* grad, const int32_t* span_seg,
                                 const int64_t* span_off, const int32_t* span_len, const float* seg_l2, const float* sq,
                                 const float* sq_override, int32_t nspan, float lr_t, const float* lr_t_dev, float beta1,

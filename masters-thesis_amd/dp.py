@@ -12,8 +12,12 @@ BatchNorm batch statistics, which stay per replica.  Mechanics:
   * L2 terms and per-variable clipping are applied after the all-reduce by the optimizer
     kernels, identically on every rank, so replicas stay bit-identical.
 """
+import warnings
+
 import torch
 import torch.distributed as dist
+
+warnings.filterwarnings("ignore", message=".*all_reduce_coalesced.*")
 
 
 def make_grad_sync(world, bucket_elems=None):
@@ -37,25 +41,33 @@ def make_grad_sync(world, bucket_elems=None):
 
 
 class PipelinedDenseSync:
-    """DP schedule for the dense-encoder NIC (config 2), shaped for xGMI point-to-point links:
+    """DP schedule for the dense-encoder NIC (config 2), shaped for xGMI point-to-point links.
+    Five captured graphs; every collective is issued async right after the graph that produces its
+    operand and is waited for only by the graph that consumes it:
 
-      graph A : forward + loss + vocabulary-head backward
-         -> async all-reduce of the head gradients (10 MB), async all-gather of the betas X (5 MB/rank)
-      graph B : BPTT, LSTM / embedding / BatchNorm gradients, dpre          (runs while A's collectives fly)
-         -> async all-reduce of the middle gradient slice (18 MB) + sparse-norm scalar, all-gather of dpre
-      graph C : encoder dW = X_all^T dpre_all on every rank (K = G*B), norms, clip + Adam
+      A  : forward + loss + vocabulary-head backward
+             -> all-reduce head gradients (10 MB), all-gather the betas X (5 MB / rank)
+      B1 : BPTT + LSTM kernel / recurrent-kernel / bias gradients
+             -> all-reduce LSTM gradients (8 MB)
+      B2 : dXin, embedding rows, BatchNorm / activation backward, encoder bias, dpre
+             -> all-reduce {encoder bias, BN, embedding} (10 MB) + sparse-norm scalar, all-gather dpre
+      C1 : (waits X, dpre, head)   encoder dW = X_all^T dpre_all on every rank (K = G*B);
+           norms + clip + Adam of the encoder kernel and the head  (73 % of the arena)
+      C2 : (waits LSTM, embedding) norms + clip + Adam of the rest, L2 metric
 
     The 41 MB encoder-kernel gradient -- 59 % of the arena and the LAST gradient backward produces --
     is never reduced: its operands are gathered instead (8x less traffic, and X's transfer hides under
-    the whole step), and each rank computes the identical global-batch gradient.  Collectives are
-    issued with async_op on the compute stream: RCCL runs them on its own stream after the work already
-    queued, and ``wait()`` only makes the compute stream wait before graph C.
+    the whole step), and each rank computes the identical global-batch gradient.  The head all-reduce
+    hides under B1+B2, the LSTM one under B2+C1, and the last bucket under C1, so at 8 ranks only the
+    tail of that last 10 MB bucket is exposed.  RCCL runs the collectives on its own stream after the
+    work already queued on the compute stream; ``wait()`` makes the compute stream wait, not the host.
     """
     pipelined = True
 
     def __init__(self, world):
         self.world = world
         self._bufs = {}
+        self._slices = None
 
     def _gather(self, out, t):
         if dist.get_backend() == "gloo":
@@ -63,6 +75,10 @@ class PipelinedDenseSync:
         else:
             w = dist.all_gather_into_tensor(out, t, async_op=True)
         return w
+
+    @staticmethod
+    def _ar(t):
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
     def step(self, m, B, T):
         a = m.arena
@@ -73,17 +89,32 @@ class PipelinedDenseSync:
                                torch.zeros(G * B, m.E, dtype=torch.float32, device=m.device))
         x_all, dpre_all = self._bufs[key]
         e = a.entries
-        mid0 = e["dense_img/bias"].off
-        head0 = e["time_distributed_softmax/kernel"].off
-        m._run_captured(("dpA", B, T), lambda: (m._forward(B, T, True), m._loss_metrics(B, T, True), m._bwd_head(B, T)))
+        if self._slices is None:
+            sg = {k: v.seg for k, v in e.items()}
+            self._slices = (a.seg_slice(0, 1),                                                     # encoder kernel
+                            a.seg_slice(sg["time_distributed_softmax/kernel"], a.nseg),            # head
+                            a.seg_slice(1, sg["time_distributed_softmax/kernel"]))                 # the rest
+        s_enc, s_head, s_mid = self._slices
+        front0, lstm0, head0 = e["dense_img/bias"].off, e["lstm/kernel"].off, e["time_distributed_softmax/kernel"].off
         x_used = m.xd if m.r_in > 0 else m.x
-        works = [dist.all_reduce(a.grad[head0:], op=dist.ReduceOp.SUM, async_op=True), self._gather(x_all, x_used)]
-        m._run_captured(("dpB", B, T), lambda: m._bwd_seq(B, T))
-        works += [dist.all_reduce(a.grad[mid0:head0], op=dist.ReduceOp.SUM, async_op=True),
-                  dist.all_reduce(a.sq_override, op=dist.ReduceOp.SUM, async_op=True), self._gather(dpre_all, m.dpre)]
-        for w in works:
+
+        m._run_captured(("dpA", B, T), lambda: (m._forward(B, T, True), m._loss_metrics(B, T, True),
+                                                m._bwd_head(B, T)))
+        w_head, w_x = self._ar(a.grad[head0:]), self._gather(x_all, x_used)
+        m._run_captured(("dpB1", B, T), lambda: (m._bwd_seq_lstm(B, T), m.join()))
+        w_lstm = self._ar(a.grad[lstm0:head0])
+        m._run_captured(("dpB2", B, T), lambda: (m._bwd_seq_front(B, T), m.join()))
+        # the 40-byte sparse-norm vector rides in the same launch as the last gradient bucket
+        w_front = dist.all_reduce_coalesced([a.grad[front0:lstm0], a.sq_override], op=dist.ReduceOp.SUM, async_op=True)
+        w_dpre = self._gather(dpre_all, m.dpre)
+        for w in (w_x, w_dpre, w_head):
             w.wait()
-        m._run_captured(("dpC", B, T), lambda: (m._bwd_enc(B, T, x_all, dpre_all), m._update_graph()))
+        m._run_captured(("dpC1", B, T), lambda: (m._tick(), m._bwd_enc(B, T, x_all, dpre_all), m._update_slice(s_head),
+                                                 m._update_slice(s_enc)))
+        for w in (w_lstm, w_front):
+            w.wait()
+        m._run_captured(("dpC2", B, T), lambda: (m._update_slice(s_mid),
+                                                 m.be.l2_total(a.wsq, a.seg_l2, a.nseg, m.met[2:3])))
 
     def __call__(self, model):          # generic fallback (models without a pipelined schedule)
         make_grad_sync(self.world)(model)

@@ -119,6 +119,27 @@ class ModelBase:
             be.sgd(a.theta, self.opt_m, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq, a.sq_override,
                    sp.nspan, 0.0, self.lr_dev, opt.momentum, clip)
 
+    def _tick(self):
+        opt = self.optimizer
+        if opt.kind == "adam":
+            self.be.step_tick(self.adam_t, self.drop_step, self.lr_dev, self.lr_t_dev, opt.beta_1, opt.beta_2)
+        else:
+            self.be.step_tick(self.adam_t, self.drop_step, self.lr_dev, None, 0.0, 0.0)
+
+    def _update_slice(self, sl):
+        """norms + clip + optimizer on one contiguous range of variables (arena.seg_slice); the caller
+        runs _tick() once before the first slice and l2_total after the last."""
+        be, a, opt = self.be, self.arena, self.optimizer
+        clip = opt.clipnorm if opt.clipnorm is not None else 0.0
+        be.seg_sqnorm(a.theta, a.grad, sl.span_seg, sl.span_off, sl.span_len, sl.seg_first, a.seg_l2, sl.partial,
+                      sl.sq, sl.wsq, None, sl.nspan, sl.nseg)
+        if opt.kind == "adam":
+            be.adam(a.theta, self.opt_m, self.opt_v, a.grad, sl.span_seg, sl.span_off, sl.span_len, a.seg_l2, a.sq,
+                    a.sq_override, sl.nspan, 0.0, self.lr_t_dev, opt.beta_1, opt.beta_2, opt.epsilon, clip)
+        else:
+            be.sgd(a.theta, self.opt_m, a.grad, sl.span_seg, sl.span_off, sl.span_len, a.seg_l2, a.sq, a.sq_override,
+                   sl.nspan, 0.0, self.lr_dev, opt.momentum, clip)
+
     @staticmethod
     def pick_splitk(M, N, K):
         """Split-K factor (power of two) so that a GEMM launches ~1024 workgroups of 64x64 tiles

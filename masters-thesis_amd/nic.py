@@ -271,6 +271,13 @@ class NIC(ModelBase):
 
     def _bwd_seq(self, B, T, join=True):
         """BPTT, LSTM / embedding / BatchNorm gradients, down to dpre of the encoder Dense."""
+        self._bwd_seq_lstm(B, T)
+        self._bwd_seq_front(B, T)
+        if join:
+            self.join()
+
+    def _bwd_seq_lstm(self, B, T):
+        """BPTT over the T+1 LSTM steps and the three LSTM parameter gradients."""
         be, a = self.be, self.arena
         N, U, E, V, ldV = self.N, self.U, self.E, self.V, self.ldV
         R1 = (T + 1) * B
@@ -292,6 +299,13 @@ class NIC(ModelBase):
         with self.side(0):
             self.gemm_sk(xin, self.dZ, a.g("lstm/kernel"), E, 4 * U, R1, E, 4 * U, 4 * U, transA=True, ws=1)
             be.colsum(self.dZ, a.g("lstm/bias"), R1, 4 * U, 4 * U, self.work2)
+
+    def _bwd_seq_front(self, B, T):
+        """LSTM input gradient -> embedding rows, BatchNorm, encoder activation, encoder bias."""
+        be, a = self.be, self.arena
+        N, U, E, V, ldV = self.N, self.U, self.E, self.V, self.ldV
+        R1 = (T + 1) * B
+        sd, ds = self.seed, self.drop_step
         self.gemm_sk(self.dZ, a.p("lstm/kernel"), self.dXin, R1, E, 4 * U, 4 * U, 4 * U, E, transB=True)
         if self.r_lstm > 0:
             be.dropout(self.dXin, self.dXin, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
@@ -309,8 +323,6 @@ class NIC(ModelBase):
             be.dropout(self.dyd, self.dyd, B, E, E, 0, E, 0, self.r_feat, sd, S_FEAT, 0, ds)
         be.act_bwd(self.enc_pre, self.dyd, self.dpre, B * E, ACT_LEAKY, 0.2)
         be.colsum(self.dpre, a.g("dense_img/bias"), B, E, E, self.work)
-        if join:
-            self.join()
 
     def _bwd_enc(self, B, T, x_all=None, dpre_all=None):
         """encoder kernel gradient dW = X^T dpre.  Under DP the operands of all ranks are passed

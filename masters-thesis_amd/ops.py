@@ -115,6 +115,9 @@ class HipBackend:
                                                _p(seg_first), _p(seg_l2), _p(partial), _p(sq), _p(wsq), _p(l2_out),
                                                nspan, nseg, self._s()), "tnt_seg_sqnorm_f32")
 
+    def l2_total(self, wsq, seg_l2, nseg, out):
+        _lib.check(self.lib.tnt_l2_total_f32(_p(wsq), _p(seg_l2), nseg, _p(out), self._s()), "tnt_l2_total_f32")
+
     def adam(self, theta, m, v, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr_t, lr_t_dev,
              beta1, beta2, eps, clipnorm):
         _lib.check(self.lib.tnt_adam_f32(_p(theta), _p(m), _p(v), _p(grad), _p(span_seg), _p(span_off), _p(span_len),

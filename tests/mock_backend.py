@@ -227,15 +227,20 @@ class MockBackend:
                    nspan, nseg):
         th, gr, l2 = flat(theta), flat(grad), flat(seg_l2)
         q, w = np.zeros(nseg), np.zeros(nseg)
-        for s, o, n in self._segs(span_seg, span_off, span_len, nspan):
+        first = flat(seg_first)[:nseg + 1]          # like the kernel: spans -> segment via seg_first (slice-local)
+        for k, (s, o, n) in enumerate(self._segs(span_seg, span_off, span_len, nspan)):
             t = th[o:o + n].astype(np.float64)
             g = gr[o:o + n].astype(np.float64) + 2 * float(l2[s]) * t
-            q[s] += (g * g).sum()
-            w[s] += (t * t).sum()
+            loc = int(np.searchsorted(first, k, side="right")) - 1
+            q[loc] += (g * g).sum()
+            w[loc] += (t * t).sum()
         flat(sq)[:nseg] = q
         flat(wsq)[:nseg] = w
         if l2_out is not None:
             flat(l2_out)[0] = (l2[:nseg].astype(np.float64) * w).sum()
+
+    def l2_total(self, wsq, seg_l2, nseg, out):
+        flat(out)[0] = (flat(seg_l2)[:nseg].astype(np.float64) * flat(wsq)[:nseg].astype(np.float64)).sum()
 
     def _clip(self, sq, sq_override, s, clipnorm):
         if clipnorm <= 0:
