@@ -126,9 +126,10 @@ def attach(model, world=None, bucket_elems=None, pipelined=None):
     world = dist.get_world_size() if world is None else world
     model.dp_world = world
     from .nic import NIC as DenseNIC
+    dense = type(model) is DenseNIC          # subclasses (fc mode) have other variables -> generic schedule
     if pipelined is None:
-        pipelined = isinstance(model, DenseNIC)
-    model.grad_sync = PipelinedDenseSync(world) if (pipelined and isinstance(model, DenseNIC)) else make_grad_sync(world, bucket_elems)
+        pipelined = dense
+    model.grad_sync = PipelinedDenseSync(world) if (pipelined and dense) else make_grad_sync(world, bucket_elems)
     model._graphs = {}
     broadcast_parameters(model)
     return model
