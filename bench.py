@@ -25,6 +25,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 B, T, V, U, E, N_VOX = 64, 15, 5001, 512, 512, 20000
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak
+# vocabulary-head forward GEMM, measured HBM bytes per launch: 2 x FETCH_SIZE(16190 KiB) + WRITE_SIZE(19625 KiB)
+# (algorithmic: 31.4 MB -- A 1.97 + B 10.25 read, C 19.2 written)
+PMC_TRAFFIC_BYTES = int((2 * 16190.0 + 19625.1) * 1024)
 
 
 def synth(rank, device):
@@ -123,9 +126,28 @@ def dominant_kernel_roofline(model, workload, steps=20):
     torch.cuda.synchronize()
     dur_s = ev[0].elapsed_time(ev[1]) / 1e3 / steps
     ach = flops / dur_s / 1e12
+    # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    # separate runs, gfx950 correction of MI355X_MICROARCH.md applied): dense workload only.
+    traffic = PMC_TRAFFIC_BYTES if workload == "dense" else None
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-            "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None, "kernel": name,
+            "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": traffic,
+            "traffic_source": "profiles/r01_gemm_head_pmc_traffic.txt" if traffic else None, "kernel": name,
             "avg_launch_us": round(dur_s * 1e6, 2), "flops_per_launch": flops}
+
+
+def step_percentiles(model, batch, steps):
+    """p10 / p50 / p90 of the per-step device time (HIP events between consecutive steps), measured in a
+    separate loop after the timed region so the K timed steps stay undisturbed."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for i in range(steps):
+        model.train_step(batch)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    d = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    pick = lambda q: round(d[min(steps - 1, int(q * steps))], 4)
+    return [pick(0.10), pick(0.50), pick(0.90)]
 
 
 def main():
@@ -192,6 +214,7 @@ def main():
         t = torch.tensor([el], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    pct = step_percentiles(model, batch, min(args.steps, 200)) if args.steps >= 10 else None
     last = model.train_step(batch).as_floats()
 
     if rank == 0:
@@ -207,7 +230,7 @@ def main():
                                     "config 3: lc_NIC locally-dense 20000->360x32 + additive attention + 512-unit LSTM, "
                                     "V=5001, T=15, B=64/GPU"),
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
-                       "final_loss": round(last["loss"], 4)},
+                       "final_loss": round(last["loss"], 4), "step_ms_p10_p50_p90": pct},
         }
         out["roofline"] = dominant_kernel_roofline(model, args.workload)
         if not args.no_cpu_baseline and world == 1:

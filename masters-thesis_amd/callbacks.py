@@ -70,6 +70,16 @@ class ModelCheckpoint(Callback):
     def on_epoch_end(self, epoch, logs=None):
         logs = logs or {}
         cur = logs.get(self.monitor)
+        rank0 = True
+        if getattr(self.model, "dp_world", 1) > 1:
+            # data parallel: every rank averages the per-replica BatchNorm moving statistics (a collective,
+            # so it runs before any rank-local decision), then only rank 0 writes the file
+            import torch.distributed as dist
+            from . import dp
+            dp.average_moving_stats(self.model)
+            rank0 = dist.get_rank() == 0
+        if not rank0:
+            return
         if self.best_only:
             if cur is None or self.sign * cur >= self.best:
                 return

@@ -142,6 +142,16 @@ def broadcast_parameters(model, src=0):
         dist.broadcast(t, src)
 
 
+def average_moving_stats(model):
+    """BatchNorm moving mean / variance are per-replica state (each replica normalises over its own
+    local batch, exactly the single-GPU behaviour); a checkpoint stores their mean over the replicas
+    (SURVEY 8e).  Collective: every rank calls it (ModelCheckpoint does, before rank 0 writes)."""
+    world = dist.get_world_size()
+    for t in model.state_tensors():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t.div_(world)
+
+
 def allreduce_metrics(metrics):
     """Mean of the logged scalars over ranks (logging only)."""
     world = dist.get_world_size()

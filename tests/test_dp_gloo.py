@@ -99,3 +99,53 @@ def test_dp2_equals_single_process(kind):
                 assert np.allclose(res[0][0][k], v, rtol=1e-4, atol=2e-6), k
     finally:
         ops.set_backend(old)
+
+
+def _worker_bn(rank, world, port, tmp, q):
+    sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import masters_thesis_amd.ops as ops
+    from masters_thesis_amd import dp
+    from masters_thesis_amd.callbacks import ModelCheckpoint
+    from masters_thesis_amd.nic import NIC
+    from masters_thesis_amd.optimizers import Adam
+    from mock_backend import MockBackend
+    ops.set_backend(MockBackend())
+    d = DIMS
+    model = NIC(d["N"], d["U"], d["E"], d["V"], d["T"], 0.0, 0.0, 0.0, 0.01, 3e-5, 1e-5, norm="batch", device="cpu",
+                seed=100 + rank)
+    model.compile(Adam(1e-3, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    dp.attach(model)
+    data, tgt = _global_batch(np.random.default_rng(9), world)
+    sl = slice(rank * d["B"], (rank + 1) * d["B"])
+    model.train_step((tuple(a[sl] for a in data), tgt[sl]))
+    local = model.get_weight("batch_norm/moving_mean")
+    ck = ModelCheckpoint(os.path.join(tmp, "w.npz"), save_best_only=False)
+    ck.set_model(model)
+    ck.on_epoch_end(0, {"val_loss": 1.0 + rank})
+    q.put((rank, local, model.get_weight("batch_norm/moving_mean"), model.get_weight("lstm/kernel")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp2_batchnorm_stats_are_per_replica_and_averaged_at_checkpoint(tmp_path):
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bn, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, local, avg, w = q.get(timeout=120)
+        res[r] = (local, avg, w)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert not np.allclose(res[0][0], res[1][0])                      # each replica saw its own batch
+    want = (res[0][0] + res[1][0]) / 2
+    assert np.allclose(res[0][1], want, atol=1e-7) and np.allclose(res[1][1], want, atol=1e-7)
+    assert np.array_equal(res[0][2], res[1][2])                       # trainables stay identical
+    with np.load(os.path.join(str(tmp_path), "w.npz")) as z:          # written once, by rank 0
+        assert np.allclose(z["batch_norm__moving_mean"], want, atol=1e-7)
