@@ -162,6 +162,13 @@ int32_t tnt_onehot_argmax_f32(const float* onehot, int32_t* ids_tmajor, int32_t 
 int32_t tnt_argmax_rows_f32(const float* x, int32_t* out, int32_t rows, int32_t V, int32_t ld,
                             void* stream);
 /* out[0] = scale * sum_i x[i]  (fixed-order, one workgroup). */
+/* Categorical sampling per row (tf.random.categorical(logits / temperature, 1): ThinkAndTell/evaluate.py:223,278;
+ * lc_NIC.sample_choice lc_NIC.py:571-575 samples from log(probs)).  x: logits (from_logits=1) or probabilities.
+ * out[row] = first j with  w_0+..+w_j > u*sum(w),  w_j = exp((l_j - max l)/temperature),  u = the Philox
+ * uniform of element `row` in stream (seed, site, step + *step_dev).  Deterministic; restated by the oracle. */
+int32_t tnt_sample_rows_f32(const float* x, int32_t* out, int32_t rows, int32_t V, int32_t ld,
+                            float temperature, int32_t from_logits, uint64_t seed, uint32_t site,
+                            uint32_t step, const uint32_t* step_dev, void* stream);
 int32_t tnt_sum_f32(const float* x, float* out, int32_t n, float scale, void* stream);
 
 /* ---- optimizer: per-variable clipnorm + Adam / SGD over a flat parameter arena --

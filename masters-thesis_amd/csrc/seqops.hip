@@ -5,6 +5,7 @@
 // (main.py:107-110 via lc_NIC.py:461-466), accuracy_calculation (lc_NIC.py:468-486),
 // np.argmax in the greedy decoders (lc_NIC.py:627; NIC.py:192).
 #include "tnt_common.h"
+#include "tnt_rng.h"
 
 namespace {
 
@@ -201,7 +202,71 @@ __global__ __launch_bounds__(256) void onehot_argmax_kernel(const float* onehot,
   if (threadIdx.x == 0) ids[t * B + b] = am.i == 0x7fffffff ? 0 : am.i;
 }
 
+// Categorical sampling, one workgroup per row (tf.random.categorical(logits / temperature, 1),
+// ThinkAndTell/evaluate.py:223,278; lc_NIC.sample_choice, lc_NIC.py:571-575).  Inverse CDF in a fixed
+// order with one Philox uniform per row, so the CPU oracle can restate it:
+//   w_j = exp((l_j - max_j l) / temperature), l = x (logits) or log(x) (probabilities)
+//   pick the first j with  w_0 + ... + w_j > u * sum(w),  u = uniform24(element = row)
+__global__ __launch_bounds__(256) void sample_rows_kernel(const float* x, int* out, int rows, int V, int ld,
+                                                          float inv_temp, int from_logits, uint64_t seed, uint32_t site,
+                                                          uint32_t step, const uint32_t* step_dev) {
+  __shared__ float shm[4];
+  __shared__ float part[257];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* xr = x + (long)row * ld;
+  const int C = (V + 255) / 256;
+  const int j0 = tid * C, j1 = min(V, j0 + C);
+  float mx = -INFINITY;
+  for (int j = j0; j < j1; ++j) {
+    const float l = from_logits ? xr[j] : logf(xr[j]);
+    mx = fmaxf(mx, l);
+  }
+  mx = tnt_wave_max(mx);
+  if ((tid & 63) == 0) shm[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+  float loc = 0.f;
+  for (int j = j0; j < j1; ++j) {
+    const float l = from_logits ? xr[j] : logf(xr[j]);
+    loc += expf((l - mx) * inv_temp);
+  }
+  part[tid + 1] = loc;
+  __syncthreads();
+  if (tid == 0) {                      // fixed-order prefix over the 256 chunk sums
+    part[0] = 0.f;
+    float run = 0.f;
+    for (int t = 1; t <= 256; ++t) { run += part[t]; part[t] = run; }
+  }
+  __syncthreads();
+  if (step_dev) step += step_dev[0];
+  const uint64_t e = (uint64_t)row, g = e >> 2;
+  const TntPhilox4 r = tnt_philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), site, step, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float u = (float)(r.v[e & 3] >> 8) * 5.9604644775390625e-08f;
+  const float target = u * part[256];
+  const int tlast = (V - 1) / C;       // last thread that owns elements (takes the u*sum == sum rounding case)
+  if (part[tid] <= target && (target < part[tid + 1] || tid == tlast)) {
+    float run = part[tid];
+    int pick = j1 - 1;
+    for (int j = j0; j < j1; ++j) {
+      const float l = from_logits ? xr[j] : logf(xr[j]);
+      run += expf((l - mx) * inv_temp);
+      if (run > target) { pick = j; break; }
+    }
+    out[row] = pick;
+  }
+}
+
 }  // namespace
+
+extern "C" int32_t tnt_sample_rows_f32(const float* x, int32_t* out, int32_t rows, int32_t V, int32_t ld,
+                                       float temperature, int32_t from_logits, uint64_t seed, uint32_t site,
+                                       uint32_t step, const uint32_t* step_dev, void* stream) {
+  if (rows <= 0 || V <= 0 || !(temperature > 0.f)) return TNT_BADARG(3);
+  hipLaunchKernelGGL(sample_rows_kernel, dim3(rows), dim3(256), 0, tnt_stream(stream), x, out, rows, V, ld,
+                     1.f / temperature, from_logits, seed, site, step, step_dev);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int32_t tnt_embedding_fwd_f32(const float* table, const int32_t* ids, float* out, int32_t B, int32_t T,
                                          int32_t E, int32_t ldo, int32_t V, void* stream) {

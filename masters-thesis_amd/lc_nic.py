@@ -23,7 +23,7 @@ import torch
 
 from .arena import ParamArena
 from .model_base import (ModelBase, Metrics, interleave_gates, deinterleave_gates, S_IN, S_FEAT, S_TEXT, S_OUT, S_ATTN,
-                         S_LSTM_IN, S_LSTM_OUT, BN_EPS, BN_MOMENTUM)
+                         S_LSTM_IN, S_LSTM_OUT, S_SAMPLE, BN_EPS, BN_MOMENTUM)
 
 SUBJ_SITE = 1000      # dropout-site offset per subject (multi-subject model)
 S_FEAT2 = 4           # second application of the feature dropout (ms2_NIC.py:214)
@@ -528,7 +528,17 @@ class NIC(ModelBase):
 
     call = call_attention = __call__
 
-    def greedy_predict(self, img_input, a0, c0, start_seq, max_len, units=None, tokenizer=None, training=False):
+    def sample_predict(self, img_input, a0, c0, start_seq, max_len, units=None, tokenizer=None, temperature=1.0,
+                       sample_step=0):
+        """greedy_predict_attention with the argmax replaced by lc_NIC.sample_choice (lc_NIC.py:571-575:
+        tf.random.categorical(log(probs), 1)); ``temperature`` as in ThinkAndTell/evaluate.py:223.  TF's
+        sampler cannot be reproduced; the draw is the Philox stream (seed, S_SAMPLE + position, sample_step),
+        restated by oracle.ops.sample_rows.  Same return tuple as greedy_predict."""
+        return self.greedy_predict(img_input, a0, c0, start_seq, max_len, units, tokenizer,
+                                   _sample=(float(temperature), int(sample_step)))
+
+    def greedy_predict(self, img_input, a0, c0, start_seq, max_len, units=None, tokenizer=None, training=False,
+                       _sample=None):
         """lc_NIC.greedy_predict -> greedy_predict_attention (lc_NIC.py:507-508,577-638).
         Returns (words (B,max_len,1) int64, probs (B,max_len,V), alpha (max_len,B,R,1), s (max_len,B,R,A))
         as numpy arrays; the whole decode runs on the device with no per-step host sync."""
@@ -554,7 +564,10 @@ class NIC(ModelBase):
             self.gemm_sk(self.inter[:B], a.p("time_distributed_softmax/kernel"), probs[i], B, V, H, H, ldV, ldV,
                     bias=a.p("time_distributed_softmax/bias"))                                # :623
             be.softmax_cce(probs[i], None, probs[i], None, None, None, B, V, ldV, 0.0)
-            be.argmax_rows(probs[i], ids[i], B, V, ldV)                                        # :627
+            if _sample is None:
+                be.argmax_rows(probs[i], ids[i], B, V, ldV)                                    # :627
+            else:
+                be.sample_rows(probs[i], ids[i], B, V, ldV, _sample[0], False, self.seed, S_SAMPLE + i, _sample[1])
             words = ids[i].view(B, 1)
         out_words = ids.t().contiguous().cpu().numpy().astype(np.int64)[:, :, None]
         out_probs = probs[:, :, :V].permute(1, 0, 2).contiguous().cpu().numpy()

@@ -21,6 +21,7 @@ from .optimizers import Adam, SGD
 # dropout site ids of the Philox stream (shared with oracle/models.py)
 S_IN, S_FEAT, S_TEXT, S_OUT = 1, 2, 3, 5
 S_ATTN, S_LSTM_IN, S_LSTM_OUT = 16, 48, 80
+S_SAMPLE = 112          # + decode position: categorical-sampling stream of sample_predict
 BN_EPS, BN_MOMENTUM = 1e-3, 0.99
 
 

@@ -106,6 +106,11 @@ class HipBackend:
     def argmax_rows(self, x, out, rows, V, ld):
         _lib.check(self.lib.tnt_argmax_rows_f32(_p(x), _p(out), rows, V, ld, self._s()), "tnt_argmax_rows_f32")
 
+    def sample_rows(self, x, out, rows, V, ld, temperature, from_logits, seed, site, step, step_dev=None):
+        _lib.check(self.lib.tnt_sample_rows_f32(_p(x), _p(out), rows, V, ld, float(temperature), int(from_logits),
+                                                int(seed), int(site), int(step), _p(step_dev), self._s()),
+                   "tnt_sample_rows_f32")
+
     def sum(self, x, out, n, scale):
         _lib.check(self.lib.tnt_sum_f32(_p(x), _p(out), n, scale, self._s()), "tnt_sum_f32")
 

@@ -17,6 +17,7 @@ from .philox import keep_mask
 # dropout site ids (shared with the product's host code; see csrc/tnt_rng.h)
 S_IN, S_FEAT, S_TEXT, S_OUT = 1, 2, 3, 5
 S_ATTN, S_LSTM_IN, S_LSTM_OUT = 16, 48, 80
+S_SAMPLE = 112          # + decode position: the categorical-sampling stream of sample_predict
 
 
 class DropCtx:
@@ -505,9 +506,10 @@ class LcNIC:
         ce, acc, al = self.metrics(probs, attn, y_ids)
         return {'loss': ce, 'L2': self.l2_loss(), 'accuracy': acc, 'attention': al}, (probs, attn)
 
-    def greedy_predict(self, x, a0, c0, start_seq, max_len):
+    def greedy_predict(self, x, a0, c0, start_seq, max_len, sampler=None):
         """lc_NIC.greedy_predict_attention (lc_NIC.py:577-638), training=False.
-        Returns (words (B,T,1) int64, probs (B,T,V), alpha (T,B,R,1), s (T,B,R,A))."""
+        Returns (words (B,T,1) int64, probs (B,T,V), alpha (T,B,R,1), s (T,B,R,A)).
+        sampler(probs, i) -> ids replaces the argmax (lc_NIC.sample_choice, lc_NIC.py:571-575)."""
         p = self.p
         dt = p['lstm/kernel'].dtype
         drop = DropCtx(training=False)
@@ -525,7 +527,7 @@ class LcNIC:
             inter, _ = O.dense_fwd(a, p['time_distributed_nonlinear/kernel'],
                                    p['time_distributed_nonlinear/bias'], O.ACT_LEAKY)
             probs = O.softmax(inter @ p['time_distributed_softmax/kernel'] + p['time_distributed_softmax/bias'])
-            word = probs.argmax(axis=-1)
+            word = probs.argmax(axis=-1) if sampler is None else sampler(probs, len(words))
             words.append(word[:, None])
             raws.append(probs)
             alphas.append(alpha[..., None])

@@ -311,3 +311,23 @@ def sgd_momentum_update(theta, mom, g, lr, momentum=0.9):
     """keras SGD(momentum=0.9, nesterov=False) (main.py:100-102)."""
     mom = momentum * mom - lr * g
     return theta + mom, mom
+
+
+def sample_rows(x, temperature, from_logits, seed, site, step):
+    """Categorical sampling per row, inverse CDF with one Philox uniform per row -- the definition of
+    tnt_sample_rows_f32 (stands for tf.random.categorical(logits / temperature, 1),
+    ThinkAndTell/evaluate.py:223,278; lc_NIC.sample_choice lc_NIC.py:571-575 passes log(probs)).
+    Returns (ids, margin): margin[r] = distance of u*sum from the nearest CDF edge relative to sum
+    (a float32 implementation may legitimately differ where the margin is ~1e-6)."""
+    from .philox import uniform24
+    x = np.asarray(x, dtype=np.float64)
+    with np.errstate(divide='ignore'):
+        l = x if from_logits else np.log(x)
+    w = np.exp((l - l.max(axis=-1, keepdims=True)) / temperature)
+    cdf = np.cumsum(w, axis=-1)
+    u = uniform24(x.shape[0], int(seed), int(site), int(step)).astype(np.float64)
+    target = u * cdf[:, -1]
+    ids = np.array([int(np.searchsorted(cdf[r], target[r], side='right')) for r in range(x.shape[0])])
+    ids = np.minimum(ids, x.shape[1] - 1)
+    margin = np.abs(cdf - target[:, None]).min(axis=-1) / cdf[:, -1]
+    return ids, margin

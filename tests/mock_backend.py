@@ -239,6 +239,11 @@ class MockBackend:
         if l2_out is not None:
             flat(l2_out)[0] = (l2[:nseg].astype(np.float64) * w).sum()
 
+    def sample_rows(self, x, out, rows, V, ld, temperature, from_logits, seed, site, step, step_dev=None):
+        st = step + (int(flat(step_dev)[0]) if step_dev is not None else 0)
+        ids, _ = O.sample_rows(flat(x)[:rows * ld].reshape(rows, ld)[:, :V], temperature, from_logits, seed, site, st)
+        flat(out)[:rows] = ids
+
     def l2_total(self, wsq, seg_l2, nseg, out):
         flat(out)[0] = (flat(seg_l2)[:nseg].astype(np.float64) * flat(wsq)[:nseg].astype(np.float64)).sum()
 

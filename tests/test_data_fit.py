@@ -95,3 +95,61 @@ def test_config_yaml_fit_callbacks(tmp_path):
     m2.load_weights(str(tmp_path / "model" / "model-ep002.npz"), by_name=True, skip_mismatch=True)
     for k in model.keras_shapes:
         assert np.array_equal(m2.get_weight(k), model.get_weight(k)), k
+
+
+def test_bleu_known_answers():
+    """sentence_bleu restates nltk's published algorithm (ThinkAndTell/img_evaluate.py:245-248 calls it with
+    SmoothingFunction().method1).  Known answers: the worked example of the nltk documentation and closed forms."""
+    from masters_thesis_amd.evaluate import sentence_bleu, bleu_scores
+    hyp1 = "It is a guide to action which ensures that the military always obeys the commands of the party".split()
+    ref1 = "It is a guide to action that ensures that the military will forever heed Party commands".split()
+    ref2 = ("It is the guiding principle which guarantees the military forces always being under the command of "
+            "the Party").split()
+    ref3 = "It is the practical guide for the army always to heed the directions of the party".split()
+    assert abs(sentence_bleu([ref1, ref2, ref3], hyp1, smoothing=None) - 0.5045666840058485) < 1e-12
+    assert sentence_bleu([ref1], ref1) == pytest.approx(1.0)
+    assert sentence_bleu([["a", "b"]], ["c", "d"]) == 0.0
+    # one matching unigram of two, no bigram: p1 = 1/2, p2 = eps/1 with method 1; without smoothing 0
+    assert sentence_bleu([["a", "b", "c"]], ["a", "x"], weights=(0.5, 0.5), smoothing=None) == 0.0
+    import math
+    want = math.exp(1 - 3 / 2) * math.exp(0.5 * math.log(0.5) + 0.5 * math.log(0.1))
+    assert sentence_bleu([["a", "b", "c"]], ["a", "x"], weights=(0.5, 0.5)) == pytest.approx(want)
+    b = bleu_scores([ref1, ref2, ref3], hyp1)
+    assert len(b) == 4 and b[0] > b[1] > b[2] > b[3] > 0
+
+
+def test_eval_dumps_have_the_reference_layouts(tmp_path):
+    """eval.py:148-216: output_captions / output_captions_raw / attention_scores .npy + tokenizer.json."""
+    from masters_thesis_amd import evaluate as EV
+    from masters_thesis_amd.lc_nic import NIC
+    from masters_thesis_amd.fc_nic import NICfc
+    from helpers import tiny_groups
+    B, N, T, V, U, R, Dg = 3, 40, 5, 21, 16, 4, 16
+    tok = D_tok()
+    cfg = dict(max_length=T, units=U)
+    gen = D.SyntheticGenerator(2, B, N, U, T, V, seed=3)
+    groups = (tiny_groups(N, R, np.random.default_rng(1)), [Dg] * R)
+    model = NIC(groups, U, 512, 12, 8, V, T, 0, 0, 0, 0, 0, 0, 0.01, 0.001, 3e-5, 1e-5, device="cpu")
+    outs, attn = EV.eval_model(model, gen, tok, cfg, str(tmp_path), 7)
+    assert outs.shape == (2 * B, T, 1) and attn.shape == (2 * B, T, R, 1)
+    assert np.load(tmp_path / "output_captions_7.npy").shape == (2 * B, T, 1)
+    assert np.load(tmp_path / "output_captions_raw_7.npy").shape == (2 * B, T, V)
+    assert np.load(tmp_path / "attention_scores_7.npy").shape == (2 * B, T, R, 1)
+    tok2 = D.tokenizer_from_json(open(tmp_path / "tokenizer.json").read())
+    assert tok2.word_index == tok.word_index
+    fc = NICfc(N, U, 12, 12, V, T, 0, 0, 0, 0, 0, 0.01, 3e-5, 1e-5, device="cpu")
+    ids = EV.eval_fc_model(fc, gen, tok, cfg, str(tmp_path / "fc"), 2)
+    assert ids.shape == (2 * B, T, 1) and np.load(tmp_path / "fc" / "output_captions_2.npy").shape == (2 * B, T, 1)
+    caps = EV.ids_to_captions(np.array([[[1], [5], [6], [2], [7]], [[5], [0], [0], [0], [0]]]), tok)
+    assert caps == [[tok.index_word[5], tok.index_word[6]], [tok.index_word[5]]]
+
+
+def D_tok():
+    tok = D.Tokenizer(num_words=20, oov_token="<unk>", filters='!"#$%&()*+.,-/:;=?@[\\]^_`{|}~ ')
+    tok.fit_on_texts(["<start> a man rides a horse <end>", "<start> a dog runs on the beach <end>"])
+    tok.word_index["<pad>"] = 0
+    tok.index_word[0] = "<pad>"
+    # ids used by the test: 1 = <start>? make them explicit
+    tok.word_index.update({"<start>": 1, "<end>": 2})
+    tok.index_word.update({1: "<start>", 2: "<end>"})
+    return tok

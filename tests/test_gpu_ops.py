@@ -437,3 +437,45 @@ def test_attention_metric(be):
     out = torch.zeros(1, device="cuda")
     be.attention_metric(dev(alpha), out, torch.zeros(T, device="cuda"), T, B, R)
     close(out, [((1 - alpha.sum(1)) ** 2).mean()])
+
+
+@pytest.mark.parametrize("V,ld,from_logits,temp", [(11, 12, True, 1.0), (5001, 5004, False, 1.0), (5001, 5004, True, 0.7),
+                                                   (300, 300, False, 2.0)])
+def test_sample_rows(be, V, ld, from_logits, temp):
+    """Categorical sampling: ids equal the oracle's inverse-CDF pick except where u*sum sits within float32
+    rounding of a CDF edge; the empirical distribution follows the probabilities."""
+    rng = np.random.default_rng(91)
+    rows = 512
+    logits = rng.standard_normal((rows, ld)) * 2.0
+    p = np.exp(logits[:, :V]); p /= p.sum(-1, keepdims=True)
+    p[:, 3] = 0.0                                            # zero-probability class is never drawn
+    x = logits.copy() if from_logits else np.zeros((rows, ld))
+    if not from_logits:
+        x[:, :V] = p
+    out = torch.zeros(rows, dtype=torch.int32, device="cuda")
+    step_dev = torch.tensor([2], dtype=torch.int32, device="cuda")
+    be.sample_rows(dev(x), out, rows, V, ld, temp, from_logits, 1234, 7, 3, step_dev)
+    got = out.cpu().numpy()
+    want, margin = O.sample_rows(x[:, :V], temp, from_logits, 1234, 7, 5)
+    bad = got != want
+    assert np.all(margin[bad] < 1e-5), (int(bad.sum()), margin[bad].max() if bad.any() else 0)
+    assert bad.mean() < 0.01
+    assert (got >= 0).all() and (got < V).all()
+    if not from_logits:
+        assert not (got == 3).any()
+    # same (seed, site, step) -> same draw; another step -> another draw
+    out2 = torch.zeros_like(out)
+    be.sample_rows(dev(x), out2, rows, V, ld, temp, from_logits, 1234, 7, 5, None)
+    assert torch.equal(out, out2)
+    be.sample_rows(dev(x), out2, rows, V, ld, temp, from_logits, 1234, 7, 6, None)
+    assert not torch.equal(out, out2)
+
+
+def test_sample_rows_distribution(be):
+    V, rows = 6, 60000
+    p = np.array([0.05, 0.3, 0.0, 0.4, 0.2, 0.05])
+    x = np.tile(p, (rows, 1))
+    out = torch.zeros(rows, dtype=torch.int32, device="cuda")
+    be.sample_rows(dev(x), out, rows, V, V, 1.0, False, 99, 1, 0, None)
+    freq = np.bincount(out.cpu().numpy(), minlength=V) / rows
+    assert np.abs(freq - p).max() < 0.01
