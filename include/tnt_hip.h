@@ -88,6 +88,25 @@ int32_t tnt_batchnorm_bwd_f32(const float* dy, const float* xhat, const float* g
                               int32_t rows, int32_t C, int32_t lddy, int32_t training,
                               float* work, void* stream);
 
+/* ---- fused tail of the dense voxel encoder at small batch (rows <= 256, C % 4 == 0, 16-byte aligned
+ * operands), NIC.py:126-128,138 ------------------------------------------------------------------
+ * fwd: out = lstm_in_dropout( BatchNorm( feature_dropout(y) ) ), training statistics over the rows (moving
+ *      statistics updated), or the moving statistics when training=0 (dropouts off).  Saves xhat, inv_std.
+ *      Dropout element index = r*C + c in streams (seed, site_feat | site_lstm, *step_dev).
+ * bwd: dout (gradient w.r.t. out, row stride ldo) -> lstm-in dropout' -> BatchNorm' (dgamma, dbeta) ->
+ *      feature dropout' -> LeakyReLU'(pre, slope) -> dpre [rows][C]; dbias[c] = sum_r dpre.
+ * One launch each, replacing 5 / 7 dependent launches of the generic entry points above (same arithmetic). */
+int32_t tnt_enc_tail_fwd_f32(const float* y, const float* gamma, const float* beta, float* mov_mean,
+                             float* mov_var, float* out, float* xhat, float* inv_std, int32_t rows,
+                             int32_t C, int32_t ldo, int32_t training, float eps, float momentum,
+                             float r_feat, float r_lstm, uint64_t seed, uint32_t site_feat,
+                             uint32_t site_lstm, const uint32_t* step_dev, void* stream);
+int32_t tnt_enc_tail_bwd_f32(const float* dout, const float* xhat, const float* gamma, const float* inv_std,
+                             const float* pre, float* dpre, float* dgamma, float* dbeta, float* dbias,
+                             int32_t rows, int32_t C, int32_t ldo, float r_feat, float r_lstm, float slope,
+                             uint64_t seed, uint32_t site_feat, uint32_t site_lstm,
+                             const uint32_t* step_dev, void* stream);
+
 /* ---- LayerNormalization(axis=-1) (layers.py:41 alternative; BASELINE north_star) - */
 int32_t tnt_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
                               float* xhat, float* inv_std, int32_t rows, int32_t C,

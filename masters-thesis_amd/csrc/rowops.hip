@@ -307,6 +307,212 @@ extern "C" int32_t tnt_act_bwd_f32(const float* pre, const float* dy, float* dx,
   return 0;
 }
 
+// ------------------------------------------------------------ fused dense-encoder tail
+// NIC.py:126-128,138 at small batch: Dropout(features) -> BatchNorm (batch statistics) -> the LSTM layer's
+// input dropout of the feature step, and its backward (+ LeakyReLU' + encoder bias gradient), as ONE launch each
+// instead of 5 / 7 dependent small kernels (each costs ~3 us of launch latency in the captured step).
+// A workgroup owns 32 columns; 8 row groups x 32 columns of threads; every thread keeps its <= MAXR rows in
+// registers, column reductions go through LDS in a fixed order.
+namespace {
+constexpr int ET_CW = 32, ET_RG = 32, ET_MAXR = 8;      // rows <= ET_RG * ET_MAXR = 256; C % 4 == 0
+// thread = (row group rg = tid / 8, column quad c4 = tid % 8): one float4 (and one Philox call) per 4 columns
+
+struct EncTailArgs {
+  // forward
+  const float* y; const float* gamma; const float* beta; float* mov_mean; float* mov_var;
+  float* out; float* xhat; float* inv_std;
+  // backward
+  const float* dout; const float* pre; float* dpre; float* dgamma; float* dbeta; float* dbias;
+  int rows, C, ldo, training;
+  float eps, momentum, r_feat, r_lstm, slope;
+  uint64_t seed; uint32_t site_feat, site_lstm; const uint32_t* step_dev;
+};
+
+// column sums of a per-thread float4 over the 32 row groups, fixed order; result valid in every thread
+__device__ __forceinline__ float4 et_colsum4(float4 v, float4 (*red)[ET_CW / 4], int rg, int c4) {
+  __syncthreads();
+  red[rg][c4] = v;
+  __syncthreads();
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (int k = 0; k < ET_RG; ++k) {
+    const float4 r = red[k][c4];
+    t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+  }
+  return t;
+}
+
+__device__ __forceinline__ float4 et_drop4(float4 v, uint64_t e, float rate, float scale, uint64_t seed, uint32_t site,
+                                           uint32_t step) {
+  bool k[4];
+  tnt_keep4(e, rate, seed, site, step, k);
+  return make_float4(k[0] ? v.x * scale : 0.f, k[1] ? v.y * scale : 0.f, k[2] ? v.z * scale : 0.f,
+                     k[3] ? v.w * scale : 0.f);
+}
+
+__global__ __launch_bounds__(256) void enc_tail_fwd_kernel(EncTailArgs a) {
+  __shared__ float4 red[ET_RG][ET_CW / 4];
+  const int c4 = threadIdx.x % (ET_CW / 4), rg = threadIdx.x / (ET_CW / 4);
+  const int col = blockIdx.x * ET_CW + 4 * c4;
+  const bool cok = col < a.C;
+  const uint32_t step = a.step_dev ? a.step_dev[0] : 0u;
+  const float sc_f = 1.0f / (1.0f - a.r_feat), sc_l = 1.0f / (1.0f - a.r_lstm);
+  float4 v[ET_MAXR];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < ET_MAXR; ++k) {
+    const int r = rg + ET_RG * k;
+    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cok && r < a.rows) {
+      float4 x = *reinterpret_cast<const float4*>(a.y + (long)r * a.C + col);
+      if (a.training && a.r_feat > 0.f) x = et_drop4(x, (uint64_t)r * a.C + col, a.r_feat, sc_f, a.seed, a.site_feat, step);
+      v[k] = x;
+      s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+    }
+  }
+  float4 mean, inv;
+  if (a.training) {
+    const float n = (float)a.rows;
+    mean = et_colsum4(s, red, rg, c4);
+    mean.x /= n; mean.y /= n; mean.z /= n; mean.w /= n;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < ET_MAXR; ++k) {
+      const int r = rg + ET_RG * k;
+      if (cok && r < a.rows) {
+        const float dx = v[k].x - mean.x, dy = v[k].y - mean.y, dz = v[k].z - mean.z, dw = v[k].w - mean.w;
+        q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+      }
+    }
+    float4 var = et_colsum4(q, red, rg, c4);                                 // biased, keras
+    var.x /= n; var.y /= n; var.z /= n; var.w /= n;
+    inv = make_float4(1.f / sqrtf(var.x + a.eps), 1.f / sqrtf(var.y + a.eps), 1.f / sqrtf(var.z + a.eps),
+                      1.f / sqrtf(var.w + a.eps));
+    if (rg == 0 && cok) {
+      const float mo = a.momentum, om = 1.f - a.momentum;
+      float4 mm = *reinterpret_cast<float4*>(a.mov_mean + col), mv = *reinterpret_cast<float4*>(a.mov_var + col);
+      mm.x = mm.x * mo + mean.x * om; mm.y = mm.y * mo + mean.y * om; mm.z = mm.z * mo + mean.z * om; mm.w = mm.w * mo + mean.w * om;
+      mv.x = mv.x * mo + var.x * om; mv.y = mv.y * mo + var.y * om; mv.z = mv.z * mo + var.z * om; mv.w = mv.w * mo + var.w * om;
+      *reinterpret_cast<float4*>(a.mov_mean + col) = mm;
+      *reinterpret_cast<float4*>(a.mov_var + col) = mv;
+    }
+  } else {
+    mean = make_float4(0.f, 0.f, 0.f, 0.f); inv = mean;
+    if (cok) {
+      mean = *reinterpret_cast<const float4*>(a.mov_mean + col);
+      const float4 mv = *reinterpret_cast<const float4*>(a.mov_var + col);
+      inv = make_float4(1.f / sqrtf(mv.x + a.eps), 1.f / sqrtf(mv.y + a.eps), 1.f / sqrtf(mv.z + a.eps),
+                        1.f / sqrtf(mv.w + a.eps));
+    }
+  }
+  if (!cok) return;
+  if (rg == 0) *reinterpret_cast<float4*>(a.inv_std + col) = inv;
+  const float4 g = *reinterpret_cast<const float4*>(a.gamma + col), b = *reinterpret_cast<const float4*>(a.beta + col);
+#pragma unroll
+  for (int k = 0; k < ET_MAXR; ++k) {
+    const int r = rg + ET_RG * k;
+    if (r >= a.rows) continue;
+    const float4 xh = make_float4((v[k].x - mean.x) * inv.x, (v[k].y - mean.y) * inv.y, (v[k].z - mean.z) * inv.z,
+                                  (v[k].w - mean.w) * inv.w);
+    *reinterpret_cast<float4*>(a.xhat + (long)r * a.C + col) = xh;
+    float4 o = make_float4(xh.x * g.x + b.x, xh.y * g.y + b.y, xh.z * g.z + b.z, xh.w * g.w + b.w);
+    if (a.training && a.r_lstm > 0.f) o = et_drop4(o, (uint64_t)r * a.C + col, a.r_lstm, sc_l, a.seed, a.site_lstm, step);
+    *reinterpret_cast<float4*>(a.out + (long)r * a.ldo + col) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void enc_tail_bwd_kernel(EncTailArgs a) {
+  __shared__ float4 red[ET_RG][ET_CW / 4];
+  const int c4 = threadIdx.x % (ET_CW / 4), rg = threadIdx.x / (ET_CW / 4);
+  const int col = blockIdx.x * ET_CW + 4 * c4;
+  const bool cok = col < a.C;
+  const uint32_t step = a.step_dev ? a.step_dev[0] : 0u;
+  const float sc_f = 1.0f / (1.0f - a.r_feat), sc_l = 1.0f / (1.0f - a.r_lstm);
+  float4 dy[ET_MAXR], xh[ET_MAXR];
+  float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sg = sb;
+#pragma unroll
+  for (int k = 0; k < ET_MAXR; ++k) {
+    const int r = rg + ET_RG * k;
+    dy[k] = make_float4(0.f, 0.f, 0.f, 0.f); xh[k] = dy[k];
+    if (cok && r < a.rows) {
+      float4 g = *reinterpret_cast<const float4*>(a.dout + (long)r * a.ldo + col);
+      if (a.r_lstm > 0.f) g = et_drop4(g, (uint64_t)r * a.C + col, a.r_lstm, sc_l, a.seed, a.site_lstm, step);
+      dy[k] = g;
+      xh[k] = *reinterpret_cast<const float4*>(a.xhat + (long)r * a.C + col);
+      sb.x += g.x; sb.y += g.y; sb.z += g.z; sb.w += g.w;
+      sg.x += g.x * xh[k].x; sg.y += g.y * xh[k].y; sg.z += g.z * xh[k].z; sg.w += g.w * xh[k].w;
+    }
+  }
+  const float4 dbeta = et_colsum4(sb, red, rg, c4);
+  const float4 dgamma = et_colsum4(sg, red, rg, c4);
+  const float n = (float)a.rows;
+  float4 kk = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cok) {
+    const float4 g = *reinterpret_cast<const float4*>(a.gamma + col), iv = *reinterpret_cast<const float4*>(a.inv_std + col);
+    kk = make_float4(g.x * iv.x / n, g.y * iv.y / n, g.z * iv.z / n, g.w * iv.w / n);
+  }
+  float4 sbias = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < ET_MAXR; ++k) {
+    const int r = rg + ET_RG * k;
+    if (cok && r < a.rows) {
+      float4 dx = make_float4(kk.x * (n * dy[k].x - dbeta.x - xh[k].x * dgamma.x), kk.y * (n * dy[k].y - dbeta.y - xh[k].y * dgamma.y),
+                              kk.z * (n * dy[k].z - dbeta.z - xh[k].z * dgamma.z), kk.w * (n * dy[k].w - dbeta.w - xh[k].w * dgamma.w));
+      if (a.r_feat > 0.f) dx = et_drop4(dx, (uint64_t)r * a.C + col, a.r_feat, sc_f, a.seed, a.site_feat, step);
+      const float4 p = *reinterpret_cast<const float4*>(a.pre + (long)r * a.C + col);
+      dx.x = p.x > 0.f ? dx.x : dx.x * a.slope; dx.y = p.y > 0.f ? dx.y : dx.y * a.slope;     // LeakyReLU'
+      dx.z = p.z > 0.f ? dx.z : dx.z * a.slope; dx.w = p.w > 0.f ? dx.w : dx.w * a.slope;
+      *reinterpret_cast<float4*>(a.dpre + (long)r * a.C + col) = dx;
+      sbias.x += dx.x; sbias.y += dx.y; sbias.z += dx.z; sbias.w += dx.w;
+    }
+  }
+  const float4 dbias = et_colsum4(sbias, red, rg, c4);
+  if (cok && rg == 0) {
+    *reinterpret_cast<float4*>(a.dgamma + col) = dgamma;
+    *reinterpret_cast<float4*>(a.dbeta + col) = dbeta;
+    *reinterpret_cast<float4*>(a.dbias + col) = dbias;
+  }
+}
+
+}  // namespace
+
+extern "C" int32_t tnt_enc_tail_fwd_f32(const float* y, const float* gamma, const float* beta, float* mov_mean,
+                                        float* mov_var, float* out, float* xhat, float* inv_std, int32_t rows,
+                                        int32_t C, int32_t ldo, int32_t training, float eps, float momentum,
+                                        float r_feat, float r_lstm, uint64_t seed, uint32_t site_feat,
+                                        uint32_t site_lstm, const uint32_t* step_dev, void* stream) {
+  if (rows <= 0 || rows > ET_RG * ET_MAXR) return TNT_BADARG(9);
+  if (C <= 0 || C % 4 != 0 || ldo < C || ldo % 4 != 0) return TNT_BADARG(10);
+  if (!tnt_aligned16(y) || !tnt_aligned16(out) || !tnt_aligned16(xhat) || !tnt_aligned16(gamma) || !tnt_aligned16(beta) ||
+      !tnt_aligned16(mov_mean) || !tnt_aligned16(mov_var) || !tnt_aligned16(inv_std)) return TNT_BADARG(1);
+  EncTailArgs a{};
+  a.y = y; a.gamma = gamma; a.beta = beta; a.mov_mean = mov_mean; a.mov_var = mov_var; a.out = out; a.xhat = xhat;
+  a.inv_std = inv_std; a.rows = rows; a.C = C; a.ldo = ldo; a.training = training; a.eps = eps; a.momentum = momentum;
+  a.r_feat = r_feat; a.r_lstm = r_lstm; a.seed = seed; a.site_feat = site_feat; a.site_lstm = site_lstm;
+  a.step_dev = step_dev;
+  hipLaunchKernelGGL(enc_tail_fwd_kernel, dim3((C + ET_CW - 1) / ET_CW), dim3(256), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_enc_tail_bwd_f32(const float* dout, const float* xhat, const float* gamma, const float* inv_std,
+                                        const float* pre, float* dpre, float* dgamma, float* dbeta, float* dbias,
+                                        int32_t rows, int32_t C, int32_t ldo, float r_feat, float r_lstm, float slope,
+                                        uint64_t seed, uint32_t site_feat, uint32_t site_lstm, const uint32_t* step_dev,
+                                        void* stream) {
+  if (rows <= 0 || rows > ET_RG * ET_MAXR) return TNT_BADARG(10);
+  if (C <= 0 || C % 4 != 0 || ldo < C || ldo % 4 != 0) return TNT_BADARG(11);
+  if (!tnt_aligned16(dout) || !tnt_aligned16(xhat) || !tnt_aligned16(gamma) || !tnt_aligned16(inv_std) || !tnt_aligned16(pre) ||
+      !tnt_aligned16(dpre) || !tnt_aligned16(dgamma) || !tnt_aligned16(dbeta) || !tnt_aligned16(dbias)) return TNT_BADARG(1);
+  EncTailArgs a{};
+  a.dout = dout; a.xhat = const_cast<float*>(xhat); a.gamma = gamma; a.inv_std = const_cast<float*>(inv_std); a.pre = pre; a.dpre = dpre; a.dgamma = dgamma;
+  a.dbeta = dbeta; a.dbias = dbias; a.rows = rows; a.C = C; a.ldo = ldo; a.r_feat = r_feat; a.r_lstm = r_lstm;
+  a.slope = slope; a.seed = seed; a.site_feat = site_feat; a.site_lstm = site_lstm; a.step_dev = step_dev;
+  hipLaunchKernelGGL(enc_tail_bwd_kernel, dim3((C + ET_CW - 1) / ET_CW), dim3(256), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
 // work layout for BN: [mean C][partials 2*C*nchunk]
 extern "C" int32_t tnt_batchnorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* mov_mean,
                                          float* mov_var, float* y, float* xhat, float* inv_std, int32_t rows, int32_t C,

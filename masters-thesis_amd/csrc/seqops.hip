@@ -176,6 +176,94 @@ __global__ __launch_bounds__(256) void softmax_cce_kernel(const float* logits, c
   }
 }
 
+// Register-resident variant: the row (V <= 1024*NV4, ld % 4 == 0, 16-byte aligned rows) is read once with
+// float4 loads, kept in VGPRs through max / exp / sum, and written once.  The generic kernel above is
+// instruction-bound at V = 5001 (1750 instructions per wave: index-tracking argmax, two expf per element,
+// per-element target select); here the inner work per element is mask, max, expf, add, mul -- the argmax
+// index is recovered from an equality pass and the target element is patched by its owner afterwards.
+// Pad columns [V, ld) are read (they are zero by the layout contract) and rewritten as zero.
+template <int NV4>
+__global__ __launch_bounds__(256) void softmax_cce_reg_kernel(const float* logits, const int* target, float* probs,
+                                                              float* loss_row, float* correct_row, float* dlogits,
+                                                              int rows, int V, int ld, float gscale, int from_logits,
+                                                              int mask_zero) {
+  __shared__ float shf[4];
+  __shared__ int shi[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* x = logits + (long)row * ld;
+  float4 v[NV4];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    const int j = 4 * (tid + 256 * i);
+    v[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (j < ld) {
+      v[i] = *reinterpret_cast<const float4*>(x + j);
+      if (j + 1 >= V) v[i].y = -INFINITY;
+      if (j + 2 >= V) v[i].z = -INFINITY;
+      if (j + 3 >= V) v[i].w = -INFINITY;
+      if (j >= V) v[i].x = -INFINITY;
+    }
+    m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+  }
+  m = tnt_wave_max(m);
+  if ((tid & 63) == 0) shf[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(shf[0], shf[1]), fmaxf(shf[2], shf[3]));
+  // first index holding the maximum (np.argmax / tf.argmax rule)
+  int am = 0x7fffffff;
+#pragma unroll
+  for (int i = NV4 - 1; i >= 0; --i) {
+    const int j = 4 * (tid + 256 * i);
+    if (v[i].w == m) am = j + 3;
+    if (v[i].z == m) am = j + 2;
+    if (v[i].y == m) am = j + 1;
+    if (v[i].x == m) am = j;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) am = min(am, __shfl_xor(am, o, 64));
+  if ((tid & 63) == 0) shi[tid >> 6] = am;
+  const int y = target ? target[row] : -1;
+  const float xy = (y >= 0 && y < V) ? x[y] : -INFINITY;     // before any thread overwrites the row (aliasing)
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    v[i].x = expf(v[i].x - m); v[i].y = expf(v[i].y - m); v[i].z = expf(v[i].z - m); v[i].w = expf(v[i].w - m);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  s = tnt_wave_sum(s);
+  __syncthreads();                       // everyone has read shf (max) before it is reused for the sum
+  if ((tid & 63) == 0) shf[tid >> 6] = s;
+  __syncthreads();
+  const float Z = (shf[0] + shf[1]) + (shf[2] + shf[3]);
+  am = min(min(shi[0], shi[1]), min(shi[2], shi[3]));
+  const float invZ = 1.f / Z;
+  const float py = (y >= 0 && y < V) ? expf(xy - m) * invZ : 0.f;
+  const bool live = !(mask_zero && y == 0);
+  const bool active = live && (from_logits || ((py >= 1e-7f) && (py <= 1.f - 1e-7f)));
+  if (tid == 0 && target) {
+    float l;
+    if (from_logits) l = logf(Z) + m - xy;
+    else l = -logf(fminf(fmaxf(py, 1e-7f), 1.f - 1e-7f));
+    if (loss_row) loss_row[row] = live ? l : 0.f;
+    if (correct_row) correct_row[row] = (am == y) ? 1.f : 0.f;
+  }
+  const float gs = active ? gscale : 0.f;
+  float* drow = dlogits ? dlogits + (long)row * ld : nullptr;
+  float* prow = (probs && probs != dlogits) ? probs + (long)row * ld : nullptr;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    const int j = 4 * (tid + 256 * i);
+    if (j >= ld) continue;
+    const float4 p = make_float4(v[i].x * invZ, v[i].y * invZ, v[i].z * invZ, v[i].w * invZ);
+    if (drow) *reinterpret_cast<float4*>(drow + j) = make_float4(p.x * gs, p.y * gs, p.z * gs, p.w * gs);
+    if (prow) *reinterpret_cast<float4*>(prow + j) = p;
+  }
+  // the thread that owns column y patches d[y] = (p_y - 1) * gs after its own vector store (same thread, same
+  // address: program order)
+  if (drow && y >= 0 && y < V && ((y >> 2) & 255) == tid) drow[y] = (py - 1.f) * gs;
+}
+
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* x, int* out, int rows, int V, int ld) {
   __shared__ ArgMax sha[4];
   const int row = blockIdx.x;
@@ -302,8 +390,22 @@ extern "C" int32_t tnt_softmax_cce_f32(const float* logits, const int32_t* targe
                                        float* correct_row, float* dlogits, int32_t rows, int32_t V, int32_t ld,
                                        float gscale, int32_t from_logits, int32_t mask_zero, void* stream) {
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(softmax_cce_kernel, dim3(rows), dim3(256), 0, tnt_stream(stream), logits, target, probs, loss_row,
-                     correct_row, dlogits, rows, V, ld, gscale, from_logits, mask_zero);
+  hipStream_t s = tnt_stream(stream);
+  const bool al = (ld % 4 == 0) && tnt_aligned16(logits) && (!probs || tnt_aligned16(probs)) &&
+                  (!dlogits || tnt_aligned16(dlogits));
+  const int nv4 = (V + 1023) / 1024;
+#define TNT_SMX(N)                                                                                              \
+  hipLaunchKernelGGL((softmax_cce_reg_kernel<N>), dim3(rows), dim3(256), 0, s, logits, target, probs, loss_row, \
+                     correct_row, dlogits, rows, V, ld, gscale, from_logits, mask_zero)
+  if (al && nv4 == 1) TNT_SMX(1);
+  else if (al && nv4 == 2) TNT_SMX(2);
+  else if (al && nv4 <= 4) TNT_SMX(4);
+  else if (al && nv4 <= 5) TNT_SMX(5);
+  else if (al && nv4 <= 8) TNT_SMX(8);
+  else
+    hipLaunchKernelGGL(softmax_cce_kernel, dim3(rows), dim3(256), 0, s, logits, target, probs, loss_row, correct_row,
+                       dlogits, rows, V, ld, gscale, from_logits, mask_zero);
+#undef TNT_SMX
   TNT_LAUNCH_CHECK();
   return 0;
 }

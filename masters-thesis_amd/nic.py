@@ -192,6 +192,10 @@ class NIC(ModelBase):
         self.Cs[0].copy_(self._to_dev(c0, torch.float32))
         return B, T
 
+    def _fused_tail(self, B):
+        """one-launch encoder tail (tnt_enc_tail_*): BatchNorm encoder, batch <= 256 rows, E % 4 == 0"""
+        return self.norm == "batch" and B <= 256 and self.E % 4 == 0 and getattr(self, "fuse_tail", True)
+
     # ------------------------------------------------------------------ forward
     def _forward(self, B, T, training):
         be, a = self.be, self.arena
@@ -205,21 +209,29 @@ class NIC(ModelBase):
         self.gemm_sk(x, a.p("dense_img/kernel"), self.enc_y, B, E, N, self.ldx, E, E, bias=a.p("dense_img/bias"),
                      pre=self.enc_pre, act=ACT_LEAKY, slope=0.2)                          # :125
         y = self.enc_y
-        if training and self.r_feat > 0:                                            # :126
-            be.dropout(self.enc_y, self.enc_yd, B, E, E, 0, E, 0, self.r_feat, sd, S_FEAT, 0, ds)
-            y = self.enc_yd
-        if self.norm == "batch":                                                    # :127-128
-            be.batchnorm_fwd(y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.mov_mean, self.mov_var,
-                             self.Xin, self.xhat, self.inv_std, B, E, E, training, BN_EPS, BN_MOMENTUM, self.work)
+        drop_l = training and self.r_lstm > 0
+        xin = self.Xin_d if drop_l else self.Xin
+        fused = self._fused_tail(B)
+        if fused:       # :126-128 + the feature step's LSTM input dropout in one launch
+            be.enc_tail_fwd(y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.mov_mean, self.mov_var, xin,
+                            self.xhat, self.inv_std, B, E, E, training, BN_EPS, BN_MOMENTUM,
+                            self.r_feat if training else 0.0, self.r_lstm if training else 0.0, sd, S_FEAT,
+                            S_LSTM_IN + 0, ds)
         else:
-            be.layernorm_fwd(y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.Xin, self.xhat, self.inv_std,
-                             B, E, E, BN_EPS)
+            if training and self.r_feat > 0:                                            # :126
+                be.dropout(self.enc_y, self.enc_yd, B, E, E, 0, E, 0, self.r_feat, sd, S_FEAT, 0, ds)
+                y = self.enc_yd
+            if self.norm == "batch":                                                    # :127-128
+                be.batchnorm_fwd(y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.mov_mean, self.mov_var,
+                                 self.Xin, self.xhat, self.inv_std, B, E, E, training, BN_EPS, BN_MOMENTUM, self.work)
+            else:
+                be.layernorm_fwd(y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.Xin, self.xhat,
+                                 self.inv_std, B, E, E, BN_EPS)
         be.embedding_fwd(a.p("emb_text/embeddings"), self.cap, self.Xin[B:], B, T, E, E, V)   # :131
-        xin = self.Xin
-        if training and self.r_lstm > 0:       # LSTM(dropout=...) masks the layer input, one mask per call
-            be.dropout(self.Xin, self.Xin_d, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
+        if drop_l:       # LSTM(dropout=...) masks the layer input, one mask per call
+            if not fused:
+                be.dropout(self.Xin, self.Xin_d, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
             be.dropout(self.Xin[B:], self.Xin_d[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
-            xin = self.Xin_d
         self._xin_used = xin
         self.gemm_sk(xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U, bias=a.p("lstm/bias"))
         Ur = a.p("lstm/recurrent_kernel")
@@ -307,12 +319,19 @@ class NIC(ModelBase):
         R1 = (T + 1) * B
         sd, ds = self.seed, self.drop_step
         self.gemm_sk(self.dZ, a.p("lstm/kernel"), self.dXin, R1, E, 4 * U, 4 * U, 4 * U, E, transB=True)
+        fused = self._fused_tail(B)
         if self.r_lstm > 0:
-            be.dropout(self.dXin, self.dXin, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
+            if not fused:
+                be.dropout(self.dXin, self.dXin, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
             be.dropout(self.dXin[B:], self.dXin[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
         sqo = a.sq_override[self.emb_seg:self.emb_seg + 1]
         sqo.zero_()
         be.embedding_bwd(self.dXin[B:], self.cap, a.g("emb_text/embeddings"), sqo, self.rowsq, B, T, E, E, V)
+        if fused:       # dropout' -> BatchNorm' -> dropout' -> LeakyReLU' -> dpre, encoder bias gradient: one launch
+            be.enc_tail_bwd(self.dXin, self.xhat, a.p("batch_norm/gamma"), self.inv_std, self.enc_pre, self.dpre,
+                            a.g("batch_norm/gamma"), a.g("batch_norm/beta"), a.g("dense_img/bias"), B, E, E,
+                            self.r_feat, self.r_lstm, 0.2, sd, S_FEAT, S_LSTM_IN + 0, ds)
+            return
         if self.norm == "batch":
             be.batchnorm_bwd(self.dXin, self.xhat, a.p("batch_norm/gamma"), self.inv_std, self.dyd,
                              a.g("batch_norm/gamma"), a.g("batch_norm/beta"), B, E, E, True, self.work)

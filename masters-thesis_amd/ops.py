@@ -106,6 +106,20 @@ class HipBackend:
     def argmax_rows(self, x, out, rows, V, ld):
         _lib.check(self.lib.tnt_argmax_rows_f32(_p(x), _p(out), rows, V, ld, self._s()), "tnt_argmax_rows_f32")
 
+    def enc_tail_fwd(self, y, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C, ldo, training, eps, momentum,
+                     r_feat, r_lstm, seed, site_feat, site_lstm, step_dev=None):
+        _lib.check(self.lib.tnt_enc_tail_fwd_f32(_p(y), _p(gamma), _p(beta), _p(mov_mean), _p(mov_var), _p(out), _p(xhat),
+                                                 _p(inv_std), rows, C, ldo, int(training), eps, momentum, r_feat, r_lstm,
+                                                 int(seed), int(site_feat), int(site_lstm), _p(step_dev), self._s()),
+                   "tnt_enc_tail_fwd_f32")
+
+    def enc_tail_bwd(self, dout, xhat, gamma, inv_std, pre, dpre, dgamma, dbeta, dbias, rows, C, ldo, r_feat, r_lstm,
+                     slope, seed, site_feat, site_lstm, step_dev=None):
+        _lib.check(self.lib.tnt_enc_tail_bwd_f32(_p(dout), _p(xhat), _p(gamma), _p(inv_std), _p(pre), _p(dpre), _p(dgamma),
+                                                 _p(dbeta), _p(dbias), rows, C, ldo, r_feat, r_lstm, slope, int(seed),
+                                                 int(site_feat), int(site_lstm), _p(step_dev), self._s()),
+                   "tnt_enc_tail_bwd_f32")
+
     def sample_rows(self, x, out, rows, V, ld, temperature, from_logits, seed, site, step, step_dev=None):
         _lib.check(self.lib.tnt_sample_rows_f32(_p(x), _p(out), rows, V, ld, float(temperature), int(from_logits),
                                                 int(seed), int(site), int(step), _p(step_dev), self._s()),

@@ -105,6 +105,31 @@ class MockBackend:
         flat(dgamma)[:C] = dg
         flat(dbeta)[:C] = db
 
+    def enc_tail_fwd(self, y, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C, ldo, training, eps, momentum,
+                     r_feat, r_lstm, seed, site_feat, site_lstm, step_dev=None):
+        """composition the fused kernel stands for: dropout -> batchnorm -> dropout"""
+        tmp = torch.zeros(rows, C, dtype=torch.float32)
+        tmp.copy_(y.view(-1)[:rows * C].view(rows, C))
+        if training and r_feat > 0:
+            self.dropout(tmp, tmp, rows, C, C, 0, C, 0, r_feat, seed, site_feat, 0, step_dev)
+        self.batchnorm_fwd(tmp, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C, ldo, training, eps,
+                           momentum, None)
+        if training and r_lstm > 0:
+            self.dropout(out, out, rows, C, ldo, 0, C, 0, r_lstm, seed, site_lstm, 0, step_dev)
+
+    def enc_tail_bwd(self, dout, xhat, gamma, inv_std, pre, dpre, dgamma, dbeta, dbias, rows, C, ldo, r_feat, r_lstm,
+                     slope, seed, site_feat, site_lstm, step_dev=None):
+        dy = torch.zeros(rows, C, dtype=torch.float32)
+        dy.copy_(torch.as_strided(dout, (rows, C), (ldo, 1)))
+        if r_lstm > 0:
+            self.dropout(dy, dy, rows, C, C, 0, C, 0, r_lstm, seed, site_lstm, 0, step_dev)
+        dx = torch.zeros(rows, C, dtype=torch.float32)
+        self.batchnorm_bwd(dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, C, True, None)
+        if r_feat > 0:
+            self.dropout(dx, dx, rows, C, C, 0, C, 0, r_feat, seed, site_feat, 0, step_dev)
+        self.act_bwd(pre, dx, dpre, rows * C, 1, slope)
+        self.colsum(dpre, dbias, rows, C, C, None)
+
     def layernorm_fwd(self, x, gamma, beta, y, xhat, inv_std, rows, C, ldy, eps):
         yo, (xh, inv) = O.layernorm_fwd(mat(x, rows, C, C).astype(np.float64), flat(gamma)[:C].astype(np.float64),
                                         flat(beta)[:C].astype(np.float64), eps)

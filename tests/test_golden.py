@@ -73,7 +73,10 @@ def _check_steps(model, gold, rates_attr, rates_on, skip=()):
             if k in skip:
                 continue
             w = model.get_weight(k)
-            assert np.abs(w - v).max() <= 2e-2 * G.LR + 1e-4 * np.abs(v).max(), (step, k, np.abs(w - v).max())
+            tol = 2e-2 * G.LR + 1e-4 * np.abs(v).max()
+            if f"g/{k}" in gold:      # zero-gradient elements: float32 rounding noise through Adam's g/(|g|+eps)
+                tol = tol + G.LR * (step + 1) * (np.abs(gold[f"g/{k}"]) < 1e-8)
+            assert (np.abs(w - v) <= tol).all(), (step, k, np.abs(w - v).max())
 
 
 @pytest.mark.gpu

@@ -33,6 +33,7 @@ def test_train_parity(dims, rates, norm):
     model, orc = build(rng, rates, dims, norm)
     model.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
     opt = M.AdamState(orc.p, lr=1e-3, clipnorm=0.1)
+    noisy_el = {}
     for step in range(4):                      # eager, capture, replay, replay
         data, tgt = synth_batch(B, N, T, V, U, rng, zero_first=(step == 2))
         res, grads, probs = orc.train_step(data, tgt, opt, M.DropCtx(seed=11, step=step, training=True))
@@ -43,8 +44,15 @@ def test_train_parity(dims, rates, norm):
         for k, v in orc.p.items():
             w = model.get_weight(k)
             # Adam's first steps move every weight by ~lr regardless of gradient scale, so compare
-            # against the update size, not the weight size
-            assert np.abs(w - v).max() <= 2e-2 * 1e-3 + 1e-4 * np.abs(v).max(), (step, k, np.abs(w - v).max())
+            # against the update size, not the weight size.  Elements whose true gradient is zero (an
+            # encoder bias whose rows all sit on one side of the LeakyReLU: BatchNorm' sums to 0 over the
+            # batch) carry float32 rounding noise ~1e-10 that Adam's g/(|g|+eps) turns into a fraction of lr.
+            tol = 2e-2 * 1e-3 + 1e-4 * np.abs(v).max()
+            if k in grads and grads[k] is not None:
+                noisy = noisy_el.setdefault(k, np.zeros(v.shape, bool))
+                noisy |= np.abs(grads[k]) < 1e-8
+                tol = tol + 1e-3 * (step + 1) * noisy
+            assert (np.abs(w - v) <= tol).all(), (step, k, np.abs(w - v).max())
 
 
 @pytest.mark.parametrize("dims", DIMS)

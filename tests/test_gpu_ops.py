@@ -479,3 +479,60 @@ def test_sample_rows_distribution(be):
     be.sample_rows(dev(x), out, rows, V, V, 1.0, False, 99, 1, 0, None)
     freq = np.bincount(out.cpu().numpy(), minlength=V) / rows
     assert np.abs(freq - p).max() < 0.01
+
+
+@pytest.mark.parametrize("rows,C,training,rates", [(64, 512, True, (0.2, 0.3)), (3, 36, True, (0.0, 0.0)),
+                                                   (200, 96, True, (0.1, 0.0)), (64, 512, False, (0.2, 0.3))])
+def test_enc_tail_fused_equals_composition(be, rows, C, training, rates):
+    """tnt_enc_tail_{fwd,bwd}: the one-launch encoder tail against the generic entry points it replaces
+    (dropout -> batchnorm -> dropout; and the reverse chain + LeakyReLU' + bias gradient) and the oracle."""
+    rng = np.random.default_rng(95)
+    r_feat, r_lstm = rates
+    y = rng.standard_normal((rows, C)) * 2 + 0.5
+    gamma, beta = 1 + 0.1 * rng.standard_normal(C), 0.1 * rng.standard_normal(C)
+    mm0, mv0 = 0.1 * rng.standard_normal(C), 1 + 0.1 * rng.random(C)
+    step_dev = torch.tensor([4], dtype=torch.int32, device="cuda")
+    seed, sf, sl = 77, 2, 48
+    f = lambda *s: torch.zeros(*s, dtype=torch.float32, device="cuda")
+    work = f(C * (2 * be.bn_nchunk(rows) + 1))
+    # --- composition
+    mm_a, mv_a = dev(mm0), dev(mv0)
+    yd = dev(y).clone()
+    if training and r_feat > 0:
+        be.dropout(yd, yd, rows, C, C, 0, C, 0, r_feat, seed, sf, 0, step_dev)
+    out_a, xhat_a, inv_a = f(rows, C), f(rows, C), f(max(rows, C))
+    be.batchnorm_fwd(yd, dev(gamma), dev(beta), mm_a, mv_a, out_a, xhat_a, inv_a, rows, C, C, training, 1e-3, 0.99, work)
+    if training and r_lstm > 0:
+        be.dropout(out_a, out_a, rows, C, C, 0, C, 0, r_lstm, seed, sl, 0, step_dev)
+    # --- fused
+    mm_b, mv_b = dev(mm0), dev(mv0)
+    out_b, xhat_b, inv_b = f(rows, C), f(rows, C), f(max(rows, C))
+    be.enc_tail_fwd(dev(y), dev(gamma), dev(beta), mm_b, mv_b, out_b, xhat_b, inv_b, rows, C, C, training, 1e-3, 0.99,
+                    r_feat if training else 0.0, r_lstm if training else 0.0, seed, sf, sl, step_dev)
+    for a_, b_ in ((out_a, out_b), (xhat_a, xhat_b), (inv_a[:C], inv_b[:C]), (mm_a, mm_b), (mv_a, mv_b)):
+        close(b_, a_.cpu().numpy(), rtol=2e-5)
+    assert torch.equal(out_a == 0, out_b == 0)                       # identical dropout pattern
+    if not training:
+        return
+    # oracle (float64) for the forward statistics
+    want, cache, mm_w, mv_w = O.batchnorm_fwd(yd.cpu().double().numpy(), gamma, beta, mm0, mv0, True)
+    close(xhat_b, cache[0])
+    close(mm_b, mm_w); close(mv_b, mv_w)
+    # --- backward
+    dout = rng.standard_normal((rows, C))
+    pre = rng.standard_normal((rows, C))
+    d = dev(dout).clone()
+    if r_lstm > 0:
+        be.dropout(d, d, rows, C, C, 0, C, 0, r_lstm, seed, sl, 0, step_dev)
+    dx, dg_a, db_a = f(rows, C), f(C), f(C)
+    be.batchnorm_bwd(d, xhat_a, dev(gamma), inv_a, dx, dg_a, db_a, rows, C, C, True, work)
+    if r_feat > 0:
+        be.dropout(dx, dx, rows, C, C, 0, C, 0, r_feat, seed, sf, 0, step_dev)
+    dpre_a, dbias_a = f(rows, C), f(C)
+    be.act_bwd(dev(pre), dx, dpre_a, rows * C, 1, 0.2)
+    be.colsum(dpre_a, dbias_a, rows, C, C, work)
+    dpre_b, dg_b, db_b, dbias_b = f(rows, C), f(C), f(C), f(C)
+    be.enc_tail_bwd(dev(dout), xhat_b, dev(gamma), inv_b, dev(pre), dpre_b, dg_b, db_b, dbias_b, rows, C, C, r_feat,
+                    r_lstm, 0.2, seed, sf, sl, step_dev)
+    for a_, b_ in ((dpre_a, dpre_b), (dg_a, dg_b), (db_a, db_b), (dbias_a, dbias_b)):
+        close(b_, a_.cpu().numpy(), rtol=5e-5)
