@@ -124,12 +124,19 @@ int32_t tnt_colsum_f32(const float* x, float* out, int32_t rows, int32_t C, int3
  * fwd: out[(t*B+b)][:] = table[ids[b*T+t]][:]   (ids is the keras (B,T) int32 array)
  * bwd: dtable[v][:] = sum over (b,t) with ids[b*T+t]==v of drows[(t*B+b)][:] (every row
  *      of dtable is written: unreferenced rows are zeroed by the call itself);
- *      sq_norm[0] += sum of squares of the un-merged rows (IndexedSlices clipnorm
- *      quirk); sq_norm zeroed by the caller; rowsq_work: B*T floats.
+ *      sq_norm[0] = sum of squares of the un-merged rows (IndexedSlices clipnorm
+ *      quirk), overwritten; rowsq_work: B*T floats.
  *      Deterministic (no atomics): one wave per vocabulary row sums its matches in
  *      (b,t) order and writes every row of dtable (no pre-zeroing needed). */
 int32_t tnt_embedding_fwd_f32(const float* table, const int32_t* ids, float* out, int32_t B,
                               int32_t T, int32_t E, int32_t ldo, int32_t V, void* stream);
+/* fwd + keras Dropout over the logical (B,T,E) tensor in the same pass (NIC.py:131,140): out_drop gets the
+ * masked rows (stream (seed, site, step + *step_dev), element (b*T+t)*E + j); out (nullable) the plain ones.
+ * E % 4 == 0, ldo % 4 == 0, 16-byte aligned. */
+int32_t tnt_embedding_fwd_drop_f32(const float* table, const int32_t* ids, float* out, float* out_drop,
+                                   int32_t B, int32_t T, int32_t E, int32_t ldo, int32_t V, float rate,
+                                   uint64_t seed, uint32_t site, uint32_t step, const uint32_t* step_dev,
+                                   void* stream);
 int32_t tnt_embedding_bwd_f32(const float* drows, const int32_t* ids, float* dtable,
                               float* sq_norm, float* rowsq_work, int32_t B, int32_t T,
                               int32_t E, int32_t ldd, int32_t V, void* stream);
@@ -189,6 +196,16 @@ int32_t tnt_sample_rows_f32(const float* x, int32_t* out, int32_t rows, int32_t 
                             float temperature, int32_t from_logits, uint64_t seed, uint32_t site,
                             uint32_t step, const uint32_t* step_dev, void* stream);
 int32_t tnt_sum_f32(const float* x, float* out, int32_t n, float scale, void* stream);
+/* two of them in one launch: out0[0] = scale*sum(x0[0..n)), out1[0] = scale*sum(x1[0..n))  (loss + accuracy) */
+int32_t tnt_sum2_f32(const float* x0, float* out0, const float* x1, float* out1, int32_t n, float scale,
+                     void* stream);
+/* Input staging of one device-resident batch in one launch (the generator tuple of
+ * data_generator_guse.py:156-171 -> the static buffers of the captured step): x (B,N) -> x_dst (B,ldx);
+ * cap (B,T) int32 -> cap_dst; tgt (B,T) int32 ids (nullable) -> tgt_tmajor (T,B); a0, c0 (B,U) -> h0, c0_dst. */
+int32_t tnt_stage_batch_f32(const float* x, float* x_dst, const int32_t* cap, int32_t* cap_dst,
+                            const int32_t* tgt, int32_t* tgt_tmajor, const float* a0, float* h0,
+                            const float* c0, float* c0_dst, int32_t B, int32_t T, int32_t N, int32_t ldx,
+                            int32_t U, void* stream);
 
 /* ---- optimizer: per-variable clipnorm + Adam / SGD over a flat parameter arena --
  * (main.py:97,100-102; lc_NIC.py:389).  The arena is cut by the host into

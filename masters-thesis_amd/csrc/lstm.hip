@@ -116,9 +116,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwdArgs a) {
       for (int k = 0; k < NW; ++k) s += red[k][g][row][col];
       z[g] += s;
     }
-    const float gi = tnt_sigmoid(z[0]), gf = tnt_sigmoid(z[1]), gg = tanhf(z[2]), go = tnt_sigmoid(z[3]);
+    const float gi = tnt_sigmoid_fast(z[0]), gf = tnt_sigmoid_fast(z[1]), gg = tnt_tanh(z[2]), go = tnt_sigmoid_fast(z[3]);
     const float c2 = gf * cp + gi * gg;
-    const float h2 = go * tanhf(c2);
+    const float h2 = go * tnt_tanh(c2);
     const bool m = mid != 0;
     a.h[e] = m ? h2 : hp;
     a.c[e] = m ? c2 : cp;
@@ -165,7 +165,7 @@ __device__ __forceinline__ void bwd_epilogue(const LstmBwdArgs& a, const BwdEpi&
   float dc_o = p.dcin, da_o = da, dout_o = p.dout;
   if (m) {
     const float gi = p.g4.x, gf = p.g4.y, gg = p.g4.z, go = p.g4.w;
-    const float tc = tanhf(p.cval);
+    const float tc = tnt_tanh(p.cval);
     const float dh = da + p.dout;
     const float dgo = dh * tc;
     const float dc = p.dcin + dh * go * (1.f - tc * tc);

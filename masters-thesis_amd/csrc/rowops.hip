@@ -269,6 +269,53 @@ __global__ __launch_bounds__(1024) void sum_kernel(const float* x, float* out, i
   }
 }
 
+// two independent sums in one launch (loss and accuracy of a step): block b reduces x[b] into out[b]
+__global__ __launch_bounds__(1024) void sum2_kernel(const float* x0, float* out0, const float* x1, float* out1, int n,
+                                                    float scale) {
+  __shared__ float sw[16];
+  const float* x = blockIdx.x == 0 ? x0 : x1;
+  float* out = blockIdx.x == 0 ? out0 : out1;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) s += x[i];
+  s = tnt_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += sw[w];
+    out[0] = t * scale;
+  }
+}
+
+// One launch for the per-step input staging of a batch that is already on the device
+// (data_generator_guse.py:156-171 tuple -> the static buffers of the captured step).
+struct StageArgs {
+  const float* x; float* xd; const int* cap; int* capd; const int* tgt; int* tgtd;
+  const float* a0; float* h0; const float* c0; float* c0d;
+  int B, T, N, ldx, U;
+};
+__global__ __launch_bounds__(256) void stage_batch_kernel(StageArgs a) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x, gsz = (long)gridDim.x * 256;
+  if (a.N % 4 == 0 && a.ldx % 4 == 0) {
+    const int n4 = a.N / 4;
+    for (long e = gid; e < (long)a.B * n4; e += gsz) {
+      const int r = (int)(e / n4), c = (int)(e % n4) * 4;
+      *reinterpret_cast<float4*>(a.xd + (long)r * a.ldx + c) = *reinterpret_cast<const float4*>(a.x + (long)r * a.N + c);
+    }
+  } else {
+    for (long e = gid; e < (long)a.B * a.N; e += gsz) {
+      const int r = (int)(e / a.N), c = (int)(e % a.N);
+      a.xd[(long)r * a.ldx + c] = a.x[e];
+    }
+  }
+  const int bt = a.B * a.T, bu = a.B * a.U;
+  for (long e = gid; e < bt; e += gsz) {
+    a.capd[e] = a.cap[e];
+    if (a.tgt) { const int b = (int)(e / a.T), t = (int)(e % a.T); a.tgtd[t * a.B + b] = a.tgt[e]; }
+  }
+  for (long e = gid; e < bu; e += gsz) { a.h0[e] = a.a0[e]; a.c0d[e] = a.c0[e]; }
+}
+
 inline int ew_blocks(long total) {
   long b = (total + 255) / 256;
   return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
@@ -600,4 +647,24 @@ extern "C" int32_t tnt_sum_f32(const float* x, float* out, int32_t n, float scal
   return 0;
 }
 
-extern "C" int32_t tnt_version(void) { return 101; }
+extern "C" int32_t tnt_sum2_f32(const float* x0, float* out0, const float* x1, float* out1, int32_t n, float scale,
+                                void* stream) {
+  hipLaunchKernelGGL(sum2_kernel, dim3(2), dim3(1024), 0, tnt_stream(stream), x0, out0, x1, out1, n, scale);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_stage_batch_f32(const float* x, float* x_dst, const int32_t* cap, int32_t* cap_dst,
+                                       const int32_t* tgt, int32_t* tgt_tmajor, const float* a0, float* h0,
+                                       const float* c0, float* c0_dst, int32_t B, int32_t T, int32_t N, int32_t ldx,
+                                       int32_t U, void* stream) {
+  if (B <= 0 || T <= 0 || N <= 0 || ldx < N || U <= 0) return TNT_BADARG(11);
+  const bool vec = (N % 4 == 0) && (ldx % 4 == 0);
+  if (vec && (!tnt_aligned16(x) || !tnt_aligned16(x_dst))) return TNT_BADARG(1);
+  StageArgs a{x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U};
+  hipLaunchKernelGGL(stage_batch_kernel, dim3(ew_blocks((long)B * N / (vec ? 4 : 1))), dim3(256), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_version(void) { return 102; }

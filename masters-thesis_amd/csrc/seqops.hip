@@ -21,6 +21,29 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(const float* table, const 
   for (int j = lane; j < E; j += 64) dst[j] = src[j];
 }
 
+// gather + keras Dropout over the logical (B,T,E) tensor in one pass (NIC.py:131,140: Embedding -> the LSTM
+// layer's input dropout): element index (b*T + t)*E + j, 4 columns per Philox call (E % 4 == 0).
+__global__ __launch_bounds__(256) void emb_fwd_drop_kernel(const float* table, const int* ids, float* out, float* out_drop,
+                                                           int B, int T, int E, int ldo, int V, float rate, uint64_t seed,
+                                                           uint32_t site, uint32_t step, const uint32_t* step_dev) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // row = t*B + b
+  if (row >= B * T) return;
+  if (step_dev) step += step_dev[0];
+  const int t = row / B, b = row % B;
+  int id = ids[b * T + t];
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+  const float* src = table + (long)id * E;
+  const float scale = 1.0f / (1.0f - rate);
+  for (int j = lane * 4; j < E; j += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(src + j);
+    if (out) *reinterpret_cast<float4*>(out + (long)row * ldo + j) = v;
+    bool k[4];
+    tnt_keep4((uint64_t)(b * T + t) * E + j, rate, seed, site, step, k);
+    *reinterpret_cast<float4*>(out_drop + (long)row * ldo + j) =
+        make_float4(k[0] ? v.x * scale : 0.f, k[1] ? v.y * scale : 0.f, k[2] ? v.z * scale : 0.f, k[3] ? v.w * scale : 0.f);
+  }
+}
+
 __global__ __launch_bounds__(256) void rowsq_kernel(const float* x, float* rowsq, int rows, int cols, int ld) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -33,7 +56,7 @@ __global__ __launch_bounds__(256) void rowsq_kernel(const float* x, float* rowsq
 // Deterministic scatter-add without atomics.  Block (k, jc): contribution row k (k = b*T + t),
 // 64-column chunk jc.  The block whose row is the FIRST occurrence of its id owns that vocabulary
 // row: its 4 waves sum a fixed strided subset of the later duplicates each (4 independent row loads
-// in flight per wave -- the pad/start tokens have hundreds of duplicates), and the 4 partials are
+// (16 at a time) in flight per wave -- the pad/start tokens have hundreds of duplicates), and the 4 partials are
 // combined in wave order through LDS.  Fixed partition + fixed order = bitwise reproducible.
 // Rows of dtable that no token references are zeroed by zero_fill_kernel launched before this
 // kernel (a captured hipMemsetAsync node did not replay reliably inside torch's hipGraph).
@@ -62,25 +85,27 @@ __global__ __launch_bounds__(256) void emb_bwd_kernel(const float* drows, const 
   const bool jok = j < E;
   float acc = 0.f;
   if (w == 0 && jok) acc = drows[(long)((k % T) * B + k / T) * ldd + j];
-  // wave w scans positions k+1+64w, +256, ... ; hits processed 4 at a time
+  // wave w scans positions k+1+64w, +256, ... ; hits processed 16 at a time (16 row loads in flight: the
+  // pad / start tokens have hundreds of duplicates and their owner block is the kernel's critical path)
+  constexpr int NF = 16;
   for (int base = k + 1 + 64 * w; base < n; base += 256) {
     const int i = base + lane;
     int other = i < n ? ids[i] : -1;
     other = other >= V ? V - 1 : other;
     unsigned long long hit = __ballot(i < n && other == id);
     while (hit) {
-      int kk[4];
+      int kk[NF];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NF; ++q) {
         kk[q] = -1;
         if (hit) { kk[q] = base + __ffsll((long long)hit) - 1; hit &= hit - 1; }
       }
-      float v[4];
+      float v[NF];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < NF; ++q)
         v[q] = (kk[q] >= 0 && jok) ? drows[(long)((kk[q] % T) * B + kk[q] / T) * ldd + j] : 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc += v[q];
+      for (int q = 0; q < NF; ++q) acc += v[q];
     }
   }
   part[w][lane] = acc;
@@ -98,7 +123,7 @@ __global__ __launch_bounds__(1024) void sum_accum_kernel(const float* x, float* 
   if (threadIdx.x == 0) {
     float t = 0.f;
     for (int w = 0; w < 16; ++w) t += sw[w];
-    out[0] += t;
+    out[0] = t;
   }
 }
 
@@ -360,6 +385,18 @@ extern "C" int32_t tnt_embedding_fwd_f32(const float* table, const int32_t* ids,
                                          int32_t E, int32_t ldo, int32_t V, void* stream) {
   hipLaunchKernelGGL(emb_fwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, tnt_stream(stream), table, ids, out, B, T, E,
                      ldo, V);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_embedding_fwd_drop_f32(const float* table, const int32_t* ids, float* out, float* out_drop,
+                                              int32_t B, int32_t T, int32_t E, int32_t ldo, int32_t V, float rate,
+                                              uint64_t seed, uint32_t site, uint32_t step, const uint32_t* step_dev,
+                                              void* stream) {
+  if (E % 4 != 0 || ldo % 4 != 0 || !tnt_aligned16(table) || !tnt_aligned16(out_drop) || (out && !tnt_aligned16(out)))
+    return TNT_BADARG(7);
+  hipLaunchKernelGGL(emb_fwd_drop_kernel, dim3((B * T + 3) / 4), dim3(256), 0, tnt_stream(stream), table, ids, out,
+                     out_drop, B, T, E, ldo, V, rate, seed, site, step, step_dev);
   TNT_LAUNCH_CHECK();
   return 0;
 }

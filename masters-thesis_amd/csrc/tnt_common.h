@@ -49,6 +49,11 @@ __device__ __forceinline__ float tnt_tanh(float x) {
   return 1.f - __fdividef(2.f, t + 1.f);
 }
 
+// logistic via one hardware exp and one reciprocal (absolute error ~1e-7); used where the activation sits on
+// the serial critical path of the T-step chain (LSTM gate math: ocml expf/tanhf cost ~300 VALU instructions per
+// step there, ~0.4 us of a 6.6 us step).
+__device__ __forceinline__ float tnt_sigmoid_fast(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+
 // wave-wide (64 lanes) reductions
 __device__ __forceinline__ float tnt_wave_sum(float v) {
 #pragma unroll

@@ -235,7 +235,6 @@ class NICfc(_DenseNIC):
         if self.r_text > 0:
             be.dropout(self.dtext, self.dtext, n, E, E, B, E, 0, self.r_text, sd, S_TEXT, 0, ds)
         sqo = a.sq_override[self.emb_seg:self.emb_seg + 1]
-        sqo.zero_()
         be.embedding_bwd(self.dtext, self.cap, a.g("emb_text/embeddings"), sqo, self.rowsq, B, T, E, E, V)
         # encoder gradients stay zero (arena.grad is zero-initialised and never written for them)
 
@@ -249,8 +248,7 @@ class NICfc(_DenseNIC):
         """lc_NIC.train_step (lc_NIC.py:328-408) over call_fc: {loss, L2, accuracy, lr}."""
         if self.optimizer is None:
             raise RuntimeError("compile() the model before train_step")
-        B, T = self._stage_inputs(data[0])
-        self._stage_target(data[1], B, T)
+        B, T = self._stage_batch(data[0], data[1], self.N)
         self._sync_lr()
         if self.grad_sync is None:
             self._run_captured(("train", B, T), lambda: (self._train_graph(B, T), self._update_graph()))

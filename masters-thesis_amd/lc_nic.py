@@ -368,8 +368,7 @@ class NIC(ModelBase):
         else:
             be.softmax_cce(self.logits, self.tgt, self.logits, self.loss_row, self.corr_row, None, n, self.V, self.ldV,
                            0.0)
-        be.sum(self.loss_row, self.met[0:1], n, 1.0 / n)
-        be.sum(self.corr_row, self.met[1:2], n, 1.0 / n)
+        be.sum2(self.loss_row, self.met[0:1], self.corr_row, self.met[1:2], n, 1.0 / n)
         if self.S == 1:
             be.attention_metric(self.alpha, self.met[3:4], self.rowsq, T, B, self.R)                        # :365-367
         else:       # per-subject loss / accuracy / attention metric (ms2_NIC.py:324-372)
@@ -428,7 +427,6 @@ class NIC(ModelBase):
         if self.r_text > 0:
             be.dropout(self.dtext, self.dtext, n, Et, Et, B, Et, 0, self.r_text, sd, S_TEXT, 0, ds)
         sqo = a.sq_override[self.emb_seg:self.emb_seg + 1]
-        sqo.zero_()
         be.embedding_bwd(self.dtext, self.cap, a.g("emb_text/embeddings"), sqo, self.rowsq, B, T, Et, Et, V)
         # attention parameters
         self.gemm_sk(hprev, self.dqpre, a.g("attention/W2/kernel"), U, A, n, U, A, A, transA=True)
@@ -488,8 +486,7 @@ class NIC(ModelBase):
         """lc_NIC.train_step (lc_NIC.py:328-408): returns {loss, L2, accuracy, attention, lr}."""
         if self.optimizer is None:
             raise RuntimeError("compile() the model before train_step")
-        B, T = self._stage_inputs(data[0])
-        self._stage_target(data[1], B, T)
+        B, T = self._stage_batch(data[0], data[1], self.n_in)
         self._sync_lr()
         if self.grad_sync is None:
             self._run_captured(("train", B, T), lambda: (self._train_graph(B, T), self._update_graph()))
@@ -502,8 +499,7 @@ class NIC(ModelBase):
 
     def test_step(self, data):
         """lc_NIC.test_step (lc_NIC.py:410-459)."""
-        B, T = self._stage_inputs(data[0])
-        self._stage_target(data[1], B, T)
+        B, T = self._stage_batch(data[0], data[1], self.n_in)
 
         # ms2_NIC.test_step calls its sub-models with training=True (ms2_NIC.py:419,426) -- quirk kept
         train_flag = self.S > 1

@@ -271,6 +271,30 @@ class ModelBase:
             return a.to(device=self.device, dtype=dtype, non_blocking=True)
         return torch.as_tensor(np.asarray(a), dtype=dtype).to(self.device, non_blocking=True)
 
+    def _stage_batch(self, inputs, target, n_cols):
+        """(inputs, target) -> static buffers.  A batch that already sits on the model's device in the staged
+        dtypes (float32 betas / states, int32 ids, contiguous) goes through ONE launch (tnt_stage_batch_f32);
+        anything else (numpy, one-hot targets, other dtypes) takes the general per-tensor path."""
+        x, cap, a0, c0 = inputs[:4]
+        ts = [x, cap, a0, c0] + ([target] if target is not None else [])
+        dev = self.device
+        same = lambda t: t.device.type == dev.type and (t.device.index or 0) == (dev.index or 0)
+        ok = all(isinstance(t, torch.Tensor) and same(t) and t.is_contiguous() for t in ts)
+        ok = ok and x.dtype == a0.dtype == c0.dtype == torch.float32 and cap.dtype == torch.int32
+        ok = ok and x.dim() == 2 and cap.dim() == 2 and x.shape == (cap.shape[0], n_cols)
+        ok = ok and (target is None or (target.dtype == torch.int32 and target.shape == cap.shape))
+        if not ok:
+            B, T = self._stage_inputs(inputs)
+            if target is not None:
+                self._stage_target(target, B, T)
+            return B, T
+        B, T = cap.shape
+        self._build(B, T)
+        assert a0.shape == c0.shape == (B, self.U), f"state shape {tuple(a0.shape)} != {(B, self.U)}"
+        self.be.stage_batch(x, self.x, cap, self.cap, target, self.tgt, a0, self.Hs[0], c0, self.Cs[0], B, T, n_cols,
+                            self.ldx, self.U)
+        return B, T
+
     def _stage_target(self, target, B, T):
         """target: one-hot (B,T,V) float (to_categorical, data_generator_guse.py:163) or int ids (B,T).
         Fills self.tgt (time-major int32 ids)."""

@@ -227,11 +227,15 @@ class NIC(ModelBase):
             else:
                 be.layernorm_fwd(y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.Xin, self.xhat,
                                  self.inv_std, B, E, E, BN_EPS)
-        be.embedding_fwd(a.p("emb_text/embeddings"), self.cap, self.Xin[B:], B, T, E, E, V)   # :131
-        if drop_l:       # LSTM(dropout=...) masks the layer input, one mask per call
-            if not fused:
-                be.dropout(self.Xin, self.Xin_d, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
-            be.dropout(self.Xin[B:], self.Xin_d[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
+        if drop_l and not fused:
+            be.dropout(self.Xin, self.Xin_d, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
+        if drop_l and E % 4 == 0:       # :131 + the text call's LSTM(dropout=...) input mask in one launch
+            be.embedding_fwd_drop(a.p("emb_text/embeddings"), self.cap, None, self.Xin_d[B:], B, T, E, E, V, self.r_lstm,
+                                  sd, S_LSTM_IN + 1, 0, ds)
+        else:
+            be.embedding_fwd(a.p("emb_text/embeddings"), self.cap, self.Xin[B:], B, T, E, E, V)   # :131
+            if drop_l:       # LSTM(dropout=...) masks the layer input, one mask per call
+                be.dropout(self.Xin[B:], self.Xin_d[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
         self._xin_used = xin
         self.gemm_sk(xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U, bias=a.p("lstm/bias"))
         Ur = a.p("lstm/recurrent_kernel")
@@ -257,8 +261,7 @@ class NIC(ModelBase):
         else:
             be.softmax_cce(self.logits, self.tgt, self.logits, self.loss_row, self.corr_row, None, n, self.V,
                            self.ldV, 0.0)
-        be.sum(self.loss_row, self.met[0:1], n, 1.0 / n)
-        be.sum(self.corr_row, self.met[1:2], n, 1.0 / n)
+        be.sum2(self.loss_row, self.met[0:1], self.corr_row, self.met[1:2], n, 1.0 / n)
 
     # ------------------------------------------------------------------ backward
     def _backward(self, B, T):
@@ -325,7 +328,6 @@ class NIC(ModelBase):
                 be.dropout(self.dXin, self.dXin, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
             be.dropout(self.dXin[B:], self.dXin[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
         sqo = a.sq_override[self.emb_seg:self.emb_seg + 1]
-        sqo.zero_()
         be.embedding_bwd(self.dXin[B:], self.cap, a.g("emb_text/embeddings"), sqo, self.rowsq, B, T, E, E, V)
         if fused:       # dropout' -> BatchNorm' -> dropout' -> LeakyReLU' -> dpre, encoder bias gradient: one launch
             be.enc_tail_bwd(self.dXin, self.xhat, a.p("batch_norm/gamma"), self.inv_std, self.enc_pre, self.dpre,
@@ -370,8 +372,7 @@ class NIC(ModelBase):
         """NIC.train_step (NIC.py:198-252): data = ((betas, cap, a0, c0), target)."""
         if self.optimizer is None:
             raise RuntimeError("compile() the model before train_step")
-        B, T = self._stage_inputs(data[0])
-        self._stage_target(data[1], B, T)
+        B, T = self._stage_batch(data[0], data[1], self.N)
         self._sync_lr()
         if self.grad_sync is None:
             self._run_captured(("train", B, T), lambda: (self._train_graph(B, T), self._update_graph()))
@@ -387,8 +388,7 @@ class NIC(ModelBase):
 
     def test_step(self, data):
         """NIC.test_step (NIC.py:254-299)."""
-        B, T = self._stage_inputs(data[0])
-        self._stage_target(data[1], B, T)
+        B, T = self._stage_batch(data[0], data[1], self.N)
 
         def run():
             self._forward(B, T, False)

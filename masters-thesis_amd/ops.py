@@ -76,6 +76,11 @@ class HipBackend:
         _lib.check(self.lib.tnt_embedding_fwd_f32(_p(table), _p(ids), _p(out), B, T, E, ldo, V, self._s()),
                    "tnt_embedding_fwd_f32")
 
+    def embedding_fwd_drop(self, table, ids, out, out_drop, B, T, E, ldo, V, rate, seed, site, step, step_dev=None):
+        _lib.check(self.lib.tnt_embedding_fwd_drop_f32(_p(table), _p(ids), _p(out), _p(out_drop), B, T, E, ldo, V, rate,
+                                                       int(seed), int(site), int(step), _p(step_dev), self._s()),
+                   "tnt_embedding_fwd_drop_f32")
+
     def embedding_bwd(self, drows, ids, dtable, sq_norm, rowsq_work, B, T, E, ldd, V):
         _lib.check(self.lib.tnt_embedding_bwd_f32(_p(drows), _p(ids), _p(dtable), _p(sq_norm), _p(rowsq_work), B, T,
                                                   E, ldd, V, self._s()), "tnt_embedding_bwd_f32")
@@ -119,6 +124,14 @@ class HipBackend:
                                                  _p(dbeta), _p(dbias), rows, C, ldo, r_feat, r_lstm, slope, int(seed),
                                                  int(site_feat), int(site_lstm), _p(step_dev), self._s()),
                    "tnt_enc_tail_bwd_f32")
+
+    def sum2(self, x0, out0, x1, out1, n, scale):
+        _lib.check(self.lib.tnt_sum2_f32(_p(x0), _p(out0), _p(x1), _p(out1), n, scale, self._s()), "tnt_sum2_f32")
+
+    def stage_batch(self, x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U):
+        _lib.check(self.lib.tnt_stage_batch_f32(_p(x), _p(x_dst), _p(cap), _p(cap_dst), _p(tgt), _p(tgt_tmajor), _p(a0),
+                                                _p(h0), _p(c0), _p(c0_dst), B, T, N, ldx, U, self._s()),
+                   "tnt_stage_batch_f32")
 
     def sample_rows(self, x, out, rows, V, ld, temperature, from_logits, seed, site, step, step_dev=None):
         _lib.check(self.lib.tnt_sample_rows_f32(_p(x), _p(out), rows, V, ld, float(temperature), int(from_logits),

@@ -262,7 +262,6 @@ class CaptionGenerator(ModelBase):
         be.colsum(self.dZ, a.g("lstm/bias"), R1, 4 * U, 4 * U, self.work)
         self.gemm_sk(self.dZ, a.p("lstm/kernel"), self.dXin, R1, E, 4 * U, 4 * U, 4 * U, E, transB=True)
         sqo = a.sq_override[self.emb_seg:self.emb_seg + 1]
-        sqo.zero_()
         be.embedding_bwd(self.dXin[B:], self.cap, a.g("embedding/embeddings"), sqo, self.rowsq, B, T, E, E, V)
         if self.r_enc > 0:
             be.dropout(self.dXin, self.dXin, B, E, E, 0, E, 0, self.r_enc, sd, S_FEAT, 0, ds)

@@ -148,6 +148,18 @@ class MockBackend:
     def colsum(self, x, out, rows, C, ld, work):
         flat(out)[:C] = mat(x, rows, C, ld).astype(np.float64).sum(0)
 
+    def sum2(self, x0, out0, x1, out1, n, scale):
+        self.sum(x0, out0, n, scale)
+        self.sum(x1, out1, n, scale)
+
+    def stage_batch(self, x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U):
+        mat(x_dst, B, N, ldx)[...] = flat(x)[:B * N].reshape(B, N)
+        flat(cap_dst)[:B * T] = flat(cap)[:B * T]
+        if tgt is not None:
+            flat(tgt_tmajor)[:B * T] = flat(tgt)[:B * T].reshape(B, T).T.reshape(-1)
+        flat(h0)[:B * U] = flat(a0)[:B * U]
+        flat(c0_dst)[:B * U] = flat(c0)[:B * U]
+
     def sum(self, x, out, n, scale):
         flat(out)[0] = flat(x)[:n].astype(np.float64).sum() * scale
 
@@ -157,6 +169,11 @@ class MockBackend:
         tab = mat(table, V, E, E)
         mat(out, T * B, E, ldo)[...] = tab[idv.T.reshape(-1)]
 
+    def embedding_fwd_drop(self, table, ids, out, out_drop, B, T, E, ldo, V, rate, seed, site, step, step_dev=None):
+        tmp = out if out is not None else torch.zeros(B * T, ldo, dtype=torch.float32)
+        self.embedding_fwd(table, ids, tmp, B, T, E, ldo, V)
+        self.dropout(tmp, out_drop, T * B, E, ldo, B, E, 0, rate, seed, site, step, step_dev)
+
     def embedding_bwd(self, drows, ids, dtable, sq_norm, rowsq_work, B, T, E, ldd, V):
         idv = flat(ids)[:B * T].reshape(B, T)
         rows = mat(drows, T * B, E, ldd).astype(np.float64)
@@ -164,7 +181,7 @@ class MockBackend:
         np.add.at(g, idv.T.reshape(-1), rows)
         mat(dtable, V, E, E)[...] = g
         if sq_norm is not None:
-            flat(sq_norm)[0] += (rows * rows).sum()
+            flat(sq_norm)[0] = (rows * rows).sum()
 
     # ---------------------------------------------------------------- LSTM
     def lstm_step_fwd(self, xz, h_prev, c_prev, Ur, ctx, Wc, D, mask_ids, mask_T, mask_t, out_prev, h, c, out,

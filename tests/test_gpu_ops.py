@@ -536,3 +536,37 @@ def test_enc_tail_fused_equals_composition(be, rows, C, training, rates):
                     r_lstm, 0.2, seed, sf, sl, step_dev)
     for a_, b_ in ((dpre_a, dpre_b), (dg_a, dg_b), (db_a, db_b), (dbias_a, dbias_b)):
         close(b_, a_.cpu().numpy(), rtol=5e-5)
+
+
+def test_embedding_fwd_drop_stage_sum2(be):
+    rng = np.random.default_rng(96)
+    B, T, E, V, N, U = 5, 7, 24, 31, 40, 16
+    table = rng.standard_normal((V, E))
+    ids = rng.integers(0, V, (B, T)).astype(np.int32)
+    step_dev = torch.tensor([3], dtype=torch.int32, device="cuda")
+    plain, dropped = torch.zeros(T * B, E, device="cuda"), torch.zeros(T * B, E, device="cuda")
+    be.embedding_fwd_drop(dev(table), dev(ids, torch.int32), plain, dropped, B, T, E, E, V, 0.3, 11, 49, 0, step_dev)
+    want = O.embedding_fwd(table, ids)                                    # (B,T,E)
+    close(plain.view(T, B, E).permute(1, 0, 2), want)
+    k = keep_mask((B, T, E), 0.3, 11, 49, 3)
+    close(dropped.view(T, B, E).permute(1, 0, 2), np.where(k, want / np.float32(0.7), 0.0), rtol=1e-6)
+    ref = torch.zeros(T * B, E, device="cuda")
+    be.dropout(plain, ref, T * B, E, E, B, E, 0, 0.3, 11, 49, 0, step_dev)  # the two-launch composition
+    assert torch.equal(ref, dropped)
+    # --- staging of a device-resident batch
+    x = dev(rng.standard_normal((B, N))); cap = dev(ids, torch.int32); tgt = dev(rng.integers(0, V, (B, T)), torch.int32)
+    a0, c0 = dev(rng.standard_normal((B, U))), dev(rng.standard_normal((B, U)))
+    xd, capd, tgtd = torch.zeros(B, N, device="cuda"), torch.zeros(B, T, dtype=torch.int32, device="cuda"), \
+        torch.zeros(T * B, dtype=torch.int32, device="cuda")
+    h0, c0d = torch.zeros(B, U, device="cuda"), torch.zeros(B, U, device="cuda")
+    be.stage_batch(x, xd, cap, capd, tgt, tgtd, a0, h0, c0, c0d, B, T, N, N, U)
+    assert torch.equal(xd, x) and torch.equal(capd, cap) and torch.equal(h0, a0) and torch.equal(c0d, c0)
+    assert torch.equal(tgtd.view(T, B), tgt.t())
+    x2 = dev(rng.standard_normal((B, 37))); xd2 = torch.zeros(B, 40, device="cuda")      # ragged width, padded rows
+    be.stage_batch(x2, xd2, cap, capd, None, tgtd, a0, h0, c0, c0d, B, T, 37, 40, U)
+    assert torch.equal(xd2[:, :37], x2) and float(xd2[:, 37:].abs().sum()) == 0.0
+    # --- two sums in one launch
+    v0, v1 = dev(rng.standard_normal(960)), dev(rng.standard_normal(960))
+    out = torch.zeros(2, device="cuda")
+    be.sum2(v0, out[0:1], v1, out[1:2], 960, 0.5)
+    close(out, [0.5 * v0.double().sum().item(), 0.5 * v1.double().sum().item()], rtol=1e-5)

@@ -126,3 +126,27 @@ def test_sgd_and_weights_io(tmp_path):
     assert np.allclose(m2.get_weight("lstm/kernel"), 2 * lw[0])
     with pytest.raises(ValueError):
         model.get_layer("nope")
+
+
+def test_device_resident_batch_is_staged_in_one_launch():
+    """torch tensors on the model's device in the staged dtypes take tnt_stage_batch_f32; results equal the
+    general per-tensor path (numpy inputs)."""
+    rng = np.random.default_rng(25)
+    B, N, T, V, U = 4, 19, 5, 11, 16
+    m1, orc = make_pair(rng, (0, 0, 0), B=B, N=N, T=T, V=V, U=U)
+    m2, _ = make_pair(np.random.default_rng(25), (0, 0, 0), B=B, N=N, T=T, V=V, U=U)
+    for m in (m1, m2):
+        m.compile(Adam(1e-3, clipnorm=0.1))
+    data, tgt = synth_batch(B, N, T, V, U, rng)
+    calls = []
+    be = ops.backend()
+    orig = be.stage_batch
+    be.stage_batch = lambda *a: (calls.append(1), orig(*a))[1]
+    r1 = m1.train_step((data, tgt)).as_floats()                                     # numpy -> general path
+    assert not calls
+    tdata = tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in data)
+    r2 = m2.train_step((tdata, torch.from_numpy(tgt.astype(np.int32)))).as_floats()  # tensors -> one launch
+    assert calls == [1]
+    assert r1 == r2
+    for k in m1.keras_shapes:
+        assert np.array_equal(m1.get_weight(k), m2.get_weight(k)), k
