@@ -88,6 +88,13 @@ int32_t tnt_batchnorm_bwd_f32(const float* dy, const float* xhat, const float* g
                               int32_t rows, int32_t C, int32_t lddy, int32_t training,
                               float* work, void* stream);
 
+/* ---- weight gradient of the dense voxel encoder at small batch:  dw[N][E] = x^T @ dpre --------------
+ * x [Bk][ldx] (the betas, Bk <= 64 rows), dpre [Bk][E] (E % 32 == 0, E <= 512, 16-byte aligned), dw [N][E].
+ * (NIC.py:64-69,248-249; ThinkAndTell model.py:22-33.)  Same result as tnt_gemm_f32(transA=1) up to f32
+ * summation order; a persistent, write-bound kernel instead of 2504 two-chunk tiles. */
+int32_t tnt_dense_dw_skinny_f32(const float* x, const float* dpre, float* dw, int32_t N, int32_t E,
+                                int32_t Bk, int32_t ldx, void* stream);
+
 /* ---- fused tail of the dense voxel encoder at small batch (rows <= 256, C % 4 == 0, 16-byte aligned
  * operands), NIC.py:126-128,138 ------------------------------------------------------------------
  * fwd: out = lstm_in_dropout( BatchNorm( feature_dropout(y) ) ), training statistics over the rows (moving

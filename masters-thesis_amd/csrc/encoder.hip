@@ -175,3 +175,139 @@ extern "C" int32_t tnt_locally_dense_bwd_f32(const float* x, int32_t ldx, const 
   TNT_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Skinny-K weight gradient of the dense voxel encoder:  dW[N][E] = X^T[N][Bk] @ dpre[Bk][E]  with Bk <= 64
+// (tape.gradient of NIC.dense_in / ThinkAndTell Encoder.fc, NIC.py:64-69,248-249; model.py:22-33).
+// 41 MB of output from 5 MB + 128 KB of input: 8.3 us of FP32 matrix work and 8 us of HBM writes -- the generic
+// tiled GEMM spends 28 us on it (2504 short-lived 64x64 tiles, K = 64 = two chunks: all prologue and epilogue).
+// Here 256 persistent workgroups walk over 16-row strips of voxels.  The B operand (dpre) never changes, so
+// each of the 8 waves keeps ITS fragments of it (<= 16 k-steps x 4 column tiles = 64 VGPRs) in registers for
+// the whole kernel; the strip's X^T tile (Bk x 16) is staged through a double-buffered LDS tile one strip
+// ahead, so a strip is 16 ds_read_b32 + 64 back-to-back v_mfma_f32_16x16x4_f32 + 16 row-piece stores.
+namespace {
+
+constexpr int DW_MS = 16;            // voxel rows per strip
+constexpr int DW_LDA = 48;           // As row stride: 48 % 32 == 16 -> the two k-rows of a half-wave hit disjoint banks
+constexpr int DW_KS = 16;            // k-steps of 4 (Bk <= 64)
+
+struct DwArgs { const float* x; const float* dpre; float* dw; int N, E, Bk, ldx; };
+
+template <int TPW>       // 16-column tiles per wave; a workgroup covers 8 * TPW * 16 columns (blockIdx.y picks the group)
+__global__ __launch_bounds__(512) void dense_dw_skinny_kernel(DwArgs a) {
+  constexpr int DW_MAXT = TPW;
+  __shared__ float As[2][DW_KS * 4 * DW_LDA];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lk = lane >> 4, lc = lane & 15;
+  const int NT = a.E / 16, t0 = (blockIdx.y * 8 + w) * TPW;        // 16-column tiles of this wave: t0 .. t0+TPW
+  // B fragments of this wave, resident for the whole kernel: bq[ks][j] = dpre[4 ks + lk][(t0 + j) * 16 + lc].
+  // Branch-free: out-of-range rows / tiles read a clamped address and are multiplied by 0.
+  float bq[DW_KS][DW_MAXT];
+#pragma unroll
+  for (int ks = 0; ks < DW_KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < DW_MAXT; ++j) {
+      const int k = 4 * ks + lk, t = t0 + j;
+      const float keep = (k < a.Bk && t < NT) ? 1.f : 0.f;
+      bq[ks][j] = keep * a.dpre[(long)min(k, a.Bk - 1) * a.E + min(t, NT - 1) * 16 + lc];
+    }
+  const int nstrip = (a.N + DW_MS - 1) / DW_MS;
+  // A staging: 64 x 16 floats per strip = 2 per thread; thread -> (k = e / 16, m = e % 16).  Addresses are hoisted:
+  // per thread a fixed row pointer, advanced by a strip; columns past N are clamped (their products are never stored).
+  float pa[2];
+  const float* xrow[2];
+  float xkeep[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + i * 512, k = e >> 4;
+    xrow[i] = a.x + (long)min(k, a.Bk - 1) * a.ldx;
+    xkeep[i] = k < a.Bk ? 1.f : 0.f;
+  }
+  const int mcol = tid & 15;
+  auto gload = [&](int s) {
+    const int m = min(min(s, nstrip - 1) * DW_MS + mcol, a.N - 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) pa[i] = xkeep[i] * xrow[i][m];
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * 512;
+      As[buf][(e >> 4) * DW_LDA + (e & 15)] = pa[i];
+    }
+  };
+  // C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.  Row pointers hoisted; full strips (all but
+  // possibly the last) and full tile sets store without per-lane predicates.
+  float* wrow = a.dw + (long)(lk * 4) * a.E + t0 * 16 + lc;
+  const bool tiles_full = t0 + DW_MAXT <= NT;
+  auto store_strip = [&](const floatx4* o, int st) {
+    float* p0 = wrow + (long)st * DW_MS * a.E;
+    if (tiles_full && st * DW_MS + DW_MS <= a.N) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < DW_MAXT; ++j) p0[(long)r * a.E + j * 16] = o[j][r];
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < DW_MAXT; ++j) {
+      if (t0 + j < NT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (st * DW_MS + lk * 4 + r < a.N) p0[(long)r * a.E + j * 16] = o[j][r];
+      }
+    }
+  };
+  int s = blockIdx.x, cur = 0, sprev = -1;
+  floatx4 outp[DW_MAXT];
+  gload(s);
+  sstore(0);
+  gload(s + gridDim.x);
+  __syncthreads();
+  for (; s < nstrip; s += gridDim.x, cur ^= 1) {
+    float av[DW_KS];
+#pragma unroll
+    for (int ks = 0; ks < DW_KS; ++ks) av[ks] = As[cur][(4 * ks + lk) * DW_LDA + lc];
+    // Stores count in vmcnt on gfx9, and the compiler drains it (vmcnt(0)) before the prefetched tile may be
+    // written to LDS.  So the order inside an iteration is: consume the prefetch (everything still outstanding was
+    // issued before the previous strip's 64 MFMAs and has long landed), THEN issue the previous strip's stores and
+    // the next prefetch, THEN multiply -- the stores drain under the MFMAs instead of in front of a wait (PMC before
+    // this reordering: waves 60 % in s_waitcnt, MFMA pipe 30 % busy).
+    sstore(cur ^ 1);                                   // next strip (already in registers)
+    if (sprev >= 0) store_strip(outp, sprev);
+    gload(s + 2 * gridDim.x);                          // the one after, in flight during the MFMAs
+    floatx4 acc[DW_MAXT];
+#pragma unroll
+    for (int j = 0; j < DW_MAXT; ++j) acc[j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < DW_KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < DW_MAXT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bq[ks][j], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < DW_MAXT; ++j) outp[j] = acc[j];
+    sprev = s;
+    // As[cur^1] complete; everyone done reading As[cur].  Only LDS traffic has to be ordered (not vmcnt).
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  if (sprev >= 0) store_strip(outp, sprev);
+}
+
+}  // namespace
+
+extern "C" int32_t tnt_dense_dw_skinny_f32(const float* x, const float* dpre, float* dw, int32_t N, int32_t E,
+                                           int32_t Bk, int32_t ldx, void* stream) {
+  if (N <= 0 || Bk <= 0 || Bk > 4 * DW_KS || ldx < N) return TNT_BADARG(6);
+  if (E <= 0 || E % 16 != 0) return TNT_BADARG(5);
+  const int nstrip = (N + DW_MS - 1) / DW_MS;
+  DwArgs a{x, dpre, dw, N, E, Bk, ldx};
+  // Tiles per wave / grid measured on MI355X at 20000 x 512 x 64 (tools/dw_dbg.py): every combination of 1/2/4 tiles
+  // and 128..1250 workgroups lands at 21-24 us (the generic GEMM: 28.4); 4 tiles x 256 workgroups is the best by a hair.
+  const int tpw = E > 256 ? 4 : (E > 128 ? 2 : 1), grid = 256;
+  const int NT = E / 16;
+  dim3 g(nstrip < grid ? nstrip : grid, (NT + 8 * tpw - 1) / (8 * tpw));
+  if (tpw == 1) hipLaunchKernelGGL(dense_dw_skinny_kernel<1>, g, dim3(512), 0, tnt_stream(stream), a);
+  else if (tpw == 2) hipLaunchKernelGGL(dense_dw_skinny_kernel<2>, g, dim3(512), 0, tnt_stream(stream), a);
+  else hipLaunchKernelGGL(dense_dw_skinny_kernel<4>, g, dim3(512), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}

@@ -356,7 +356,10 @@ class NIC(ModelBase):
             x, dpre, rows = x_all, dpre_all, x_all.shape[0]
         else:
             dpre = self.dpre
-        self.gemm_sk(x, dpre, a.g("dense_img/kernel"), self.N, self.E, rows, self.ldx, self.E, self.E, transA=True)
+        if rows <= 64 and self.E % 16 == 0 and getattr(self, "skinny_dw", True):
+            be.dense_dw_skinny(x, dpre, a.g("dense_img/kernel"), self.N, self.E, rows, self.ldx)
+        else:
+            self.gemm_sk(x, dpre, a.g("dense_img/kernel"), self.N, self.E, rows, self.ldx, self.E, self.E, transA=True)
 
     # ------------------------------------------------------------------ steps
     def _train_graph(self, B, T):

@@ -125,6 +125,10 @@ class HipBackend:
                                                  int(site_feat), int(site_lstm), _p(step_dev), self._s()),
                    "tnt_enc_tail_bwd_f32")
 
+    def dense_dw_skinny(self, x, dpre, dw, N, E, Bk, ldx):
+        _lib.check(self.lib.tnt_dense_dw_skinny_f32(_p(x), _p(dpre), _p(dw), N, E, Bk, ldx, self._s()),
+                   "tnt_dense_dw_skinny_f32")
+
     def sum2(self, x0, out0, x1, out1, n, scale):
         _lib.check(self.lib.tnt_sum2_f32(_p(x0), _p(out0), _p(x1), _p(out1), n, scale, self._s()), "tnt_sum2_f32")
 

@@ -267,7 +267,10 @@ class CaptionGenerator(ModelBase):
             be.dropout(self.dXin, self.dXin, B, E, E, 0, E, 0, self.r_enc, sd, S_FEAT, 0, ds)
         be.act_bwd(self.enc_pre, self.dXin, self.dpre, B * E, ACT_RELU if self.sat else ACT_TANH, 0.0)
         be.colsum(self.dpre, a.g("fc_embedding/bias"), B, E, E, self.work)
-        self.gemm_sk(self.x, self.dpre, a.g("fc_embedding/kernel"), N, E, B, self.ldx, E, E, transA=True)
+        if B <= 64 and E % 16 == 0:
+            be.dense_dw_skinny(self.x, self.dpre, a.g("fc_embedding/kernel"), N, E, B, self.ldx)
+        else:
+            self.gemm_sk(self.x, self.dpre, a.g("fc_embedding/kernel"), N, E, B, self.ldx, E, E, transA=True)
 
     # ------------------------------------------------------------------ steps
     def _unpack_batch(self, data):

@@ -148,6 +148,10 @@ class MockBackend:
     def colsum(self, x, out, rows, C, ld, work):
         flat(out)[:C] = mat(x, rows, C, ld).astype(np.float64).sum(0)
 
+    def dense_dw_skinny(self, x, dpre, dw, N, E, Bk, ldx):
+        xs = mat(x, Bk, N, ldx).astype(np.float64)
+        mat(dw, N, E, E)[...] = xs.T @ mat(dpre, Bk, E, E).astype(np.float64)
+
     def sum2(self, x0, out0, x1, out1, n, scale):
         self.sum(x0, out0, n, scale)
         self.sum(x1, out1, n, scale)

@@ -570,3 +570,17 @@ def test_embedding_fwd_drop_stage_sum2(be):
     out = torch.zeros(2, device="cuda")
     be.sum2(v0, out[0:1], v1, out[1:2], 960, 0.5)
     close(out, [0.5 * v0.double().sum().item(), 0.5 * v1.double().sum().item()], rtol=1e-5)
+
+
+@pytest.mark.parametrize("N,E,Bk,ldx", [(20000, 512, 64, 20000), (37, 32, 3, 40), (1000, 96, 17, 1000), (2000, 64, 8, 2000)])
+def test_dense_dw_skinny(be, N, E, Bk, ldx):
+    """dW = X^T dpre of the dense encoder (persistent skinny-K kernel) against float64 and the generic GEMM."""
+    rng = np.random.default_rng(97)
+    x = np.zeros((Bk, ldx)); x[:, :N] = rng.standard_normal((Bk, N))
+    dpre = rng.standard_normal((Bk, E)) * 0.01
+    dw = torch.full((N, E), 7.0, device="cuda")
+    be.dense_dw_skinny(dev(x), dev(dpre), dw, N, E, Bk, ldx)
+    close(dw, x[:, :N].T @ dpre)
+    ref = torch.zeros(N, E, device="cuda")
+    be.gemm(dev(x), dev(dpre), ref, N, E, Bk, ldx, E, E, transA=True)
+    close(dw, ref.cpu().numpy(), rtol=2e-6)

@@ -35,3 +35,16 @@ print("encoder dW   dW[20000x512] = X^T[20000x64] @ dpre[64x512]")
 for bm, bn in ((64, 64), (64, 128), (128, 64), (128, 128)):
     t = timeit(lambda s: lib.tnt_gemm_f32_tile(X.data_ptr(), dpre.data_ptr(), dW.data_ptr(), None, None, N, E, B, N, E, E, 1, 0, 0, 0.2, 0, 1, None, bm, bn, s))
     print(f"  tile {bm}x{bn}: {t:7.2f} us   ({N * E * 4 / t / 1e6:.2f} TB/s of output)")
+import masters_thesis_amd.ops as ops
+be = ops.backend()
+lib.tnt_dense_dw_skinny_f32.argtypes = [P, P, P, I32, I32, I32, I32, P]
+t = timeit(lambda s: lib.tnt_dense_dw_skinny_f32(X.data_ptr(), dpre.data_ptr(), dW.data_ptr(), N, E, B, N, s))
+print(f"  skinny dW kernel: {t:7.2f} us   ({N * E * 4 / t / 1e6:.2f} TB/s of output)")
+XT = X.t().contiguous()
+for bm, bn in ((64, 64), (64, 128), (128, 128)):
+    t = timeit(lambda s: lib.tnt_gemm_f32_tile(XT.data_ptr(), dpre.data_ptr(), dW.data_ptr(), None, None, N, E, B, B, E, E, 0, 0, 0, 0.2, 0, 1, None, bm, bn, s))
+    print(f"  NN on pre-transposed X^T, tile {bm}x{bn}: {t:7.2f} us")
+Xs = torch.randn(B, 2048, device="cuda")      # small-N control: same kernel, X rows 8 KB apart
+dWs = torch.zeros(2048, E, device="cuda")
+t = timeit(lambda s: lib.tnt_dense_dw_skinny_f32(Xs.data_ptr(), dpre.data_ptr(), dWs.data_ptr(), 2048, E, B, 2048, s))
+print(f"  skinny dW kernel, N=2048: {t:7.2f} us")
