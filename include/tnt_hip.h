@@ -175,6 +175,22 @@ int32_t tnt_lstm_step_bwd_f32(const float* dz_next, const float* Ur, const float
                               float* dc_out, float* dout_out, int32_t B, int32_t U,
                               void* stream);
 
+/* ---- GRU cell step, keras GRU v2 semantics (reset_after=True): the decoder of ThinkAndTell/att_model.py
+ * (att_model.py:84-93,118).  Gate-interleaved layouts [..][U][4] with slots (z, r, h, 0 pad).
+ * fwd:  rec = h_prev[B][U] @ Uk[U][U][4] + br[U][4];  z = sigmoid(xz_z + rec_z), r = sigmoid(xz_r + rec_r),
+ *       hh = tanh(xz_h + r*rec_h);  h = z*h_prev + (1-z)*hh.   xz[B][U][4] = x @ W + b_i (one GEMM for all steps).
+ *       Saves gates[B][U][4] = (z, r, hh, rec_h).
+ * bwd:  dh = dh_ext + dh_pass_in + (drec_next ? drec_next[B][U][4] @ Uk^T : 0);
+ *       dxz = (da_z, da_r, da_h, 0)  [input side: kernel / input-bias gradients, dX],
+ *       drec = (da_z, da_r, da_h*r, 0)  [recurrent side: recurrent-kernel / recurrent-bias gradients, and the
+ *       matmul the call of the step before applies];  dh_pass_out = dh*z.  Nullable: drec_next, dh_pass_in, dh_ext,
+ *       dh_pass_out. */
+int32_t tnt_gru_step_fwd_f32(const float* xz, const float* h_prev, const float* Uk, const float* br, float* h,
+                             float* gates, int32_t B, int32_t U, void* stream);
+int32_t tnt_gru_step_bwd_f32(const float* drec_next, const float* Uk, const float* dh_pass_in,
+                             const float* dh_ext, const float* gates, const float* h_prev, float* dxz,
+                             float* drec, float* dh_pass_out, int32_t B, int32_t U, void* stream);
+
 /* ---- softmax + CategoricalCrossentropy(from_logits=False) + accuracy ------------
  * (lc_NIC.py:153,370-376,461-486; NIC.py:93,234-240; main.py:107-110)
  * logits [rows][ld], V valid columns.  target ids int32[rows] (argmax of the one-hot).

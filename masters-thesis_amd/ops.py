@@ -98,6 +98,15 @@ class HipBackend:
                                                   _p(c), _p(c_prev), _p(dz), _p(da_pass_out), _p(dc_out),
                                                   _p(dout_out), B, U, self._s()), "tnt_lstm_step_bwd_f32")
 
+    def gru_step_fwd(self, xz, h_prev, Uk, br, h, gates, B, U):
+        _lib.check(self.lib.tnt_gru_step_fwd_f32(_p(xz), _p(h_prev), _p(Uk), _p(br), _p(h), _p(gates), B, U, self._s()),
+                   "tnt_gru_step_fwd_f32")
+
+    def gru_step_bwd(self, drec_next, Uk, dh_pass_in, dh_ext, gates, h_prev, dxz, drec, dh_pass_out, B, U):
+        _lib.check(self.lib.tnt_gru_step_bwd_f32(_p(drec_next), _p(Uk), _p(dh_pass_in), _p(dh_ext), _p(gates), _p(h_prev),
+                                                 _p(dxz), _p(drec), _p(dh_pass_out), B, U, self._s()),
+                   "tnt_gru_step_bwd_f32")
+
     def softmax_cce(self, logits, target, probs, loss_row, correct_row, dlogits, rows, V, ld, gscale,
                     from_logits=False, mask_zero=False):
         _lib.check(self.lib.tnt_softmax_cce_f32(_p(logits), _p(target), _p(probs), _p(loss_row), _p(correct_row),

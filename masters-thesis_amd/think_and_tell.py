@@ -11,8 +11,7 @@ Drop-in for ``ThinkAndTell/model.py`` -- ``Encoder(embedding_dim, l2_reg, init_m
 Launch plan: Dense(tanh|relu) GEMM -> [dropout] -> embedding gather -> one input-projection GEMM
 for all T+1 steps -> T+1 fused LSTM steps -> [dropout] -> vocab GEMM(s) (ReLU epilogue) ->
 fused sparse-CE-from-logits with the zero-target mask -> mirror-image backward -> clip + Adam/SGD.
-The GRU decoder of ThinkAndTell/att_model.py (84-93,118) is not implemented (its attention is an
-empty stub, att_model.py:11-29).
+The GRU decoder of ThinkAndTell/att_model.py (84-93,118) lives in think_and_tell_att.py.
 """
 from collections import OrderedDict
 

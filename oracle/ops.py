@@ -251,6 +251,30 @@ def lstm_step_bwd(dh2, dc2, cache, U):
 
 
 # ----------------------------------------------------------- softmax + losses
+def gru_step_fwd(xz, h, Uk, br):
+    """keras GRU cell, reset_after=True (the TF2 default; ThinkAndTell/att_model.py:84-93): xz = x@W + b_i (B,3U)
+    in keras gate order [z, r, h]; Uk (U,3U); br (3U,) the recurrent bias."""
+    U = h.shape[1]
+    rec = h @ Uk + br
+    z = sigmoid(xz[:, :U] + rec[:, :U])
+    r = sigmoid(xz[:, U:2 * U] + rec[:, U:2 * U])
+    hh = np.tanh(xz[:, 2 * U:] + r * rec[:, 2 * U:])
+    h2 = z * h + (1 - z) * hh
+    return h2, (z, r, hh, rec[:, 2 * U:], h)
+
+
+def gru_step_bwd(dh2, cache, Uk):
+    """returns (dxz (B,3U), drec (B,3U), dh_prev)."""
+    z, r, hh, rech, h = cache
+    dz = dh2 * (h - hh)
+    dah = dh2 * (1 - z) * (1 - hh * hh)
+    daz = dz * z * (1 - z)
+    dar = dah * rech * r * (1 - r)
+    dxz = np.concatenate([daz, dar, dah], axis=1)
+    drec = np.concatenate([daz, dar, dah * r], axis=1)
+    return dxz, drec, dh2 * z + drec @ Uk.T
+
+
 def cce_from_probs(p, y_ids, eps=CCE_EPS):
     """keras CategoricalCrossentropy(from_logits=False, reduction='none') on a one-hot target
     (main.py:107-110): p <- p/sum(p); clip(p, eps, 1-eps); -log p[y].

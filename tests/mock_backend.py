@@ -236,6 +236,42 @@ class MockBackend:
             mat(dout_out, B, U, U)[...] = np.where(m, 0, dout)
 
     # ---------------------------------------------------------------- softmax / CE
+    @staticmethod
+    def _gru3(t, lead, U):
+        """interleaved [lead][U][4] (slots z, r, h, pad) -> keras [lead][3U]"""
+        a = flat(t)[:lead * U * 4].reshape(lead, U, 4).astype(np.float64)
+        return np.concatenate([a[:, :, 0], a[:, :, 1], a[:, :, 2]], axis=1)
+
+    @staticmethod
+    def _gru3_store(t, arr, lead, U):
+        out = np.zeros((lead, U, 4), np.float32)
+        for g in range(3):
+            out[:, :, g] = arr[:, g * U:(g + 1) * U]
+        flat(t)[:lead * U * 4] = out.reshape(-1)
+
+    def gru_step_fwd(self, xz, h_prev, Uk, br, h, gates, B, U):
+        hp = mat(h_prev, B, U, U).astype(np.float64)
+        h2, (z, r, hh, rech, _) = O.gru_step_fwd(self._gru3(xz, B, U), hp, self._gru3(Uk, U, U), self._gru3(br, 1, U)[0])
+        mat(h, B, U, U)[...] = h2
+        flat(gates)[:B * U * 4] = np.stack([z, r, hh, rech], axis=-1).astype(np.float32).reshape(-1)
+
+    def gru_step_bwd(self, drec_next, Uk, dh_pass_in, dh_ext, gates, h_prev, dxz, drec, dh_pass_out, B, U):
+        Ukk = self._gru3(Uk, U, U)
+        dh = np.zeros((B, U))
+        if dh_pass_in is not None:
+            dh += mat(dh_pass_in, B, U, U)
+        if dh_ext is not None:
+            dh += mat(dh_ext, B, U, U)
+        if drec_next is not None:
+            dh += self._gru3(drec_next, B, U) @ Ukk.T
+        g = flat(gates)[:B * U * 4].reshape(B, U, 4).astype(np.float64)
+        cache = (g[:, :, 0], g[:, :, 1], g[:, :, 2], g[:, :, 3], mat(h_prev, B, U, U).astype(np.float64))
+        dx, dr, _ = O.gru_step_bwd(dh, cache, Ukk)
+        self._gru3_store(dxz, dx, B, U)
+        self._gru3_store(drec, dr, B, U)
+        if dh_pass_out is not None:
+            mat(dh_pass_out, B, U, U)[...] = dh * cache[0]
+
     def softmax_cce(self, logits, target, probs, loss_row, correct_row, dlogits, rows, V, ld, gscale,
                     from_logits=False, mask_zero=False):
         x = mat(logits, rows, V, ld).astype(np.float64)
