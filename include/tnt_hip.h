@@ -272,7 +272,7 @@ int32_t tnt_step_tick(int64_t* adam_t, uint32_t* drop_step, const float* lr, flo
 /* ---- region-wise encoder: layers.LocallyDense.call (layers.py:43-48) ------------
  * CSR groups: idx[goff[r] .. goff[r+1]) are the voxel columns of group r; W is the
  * concatenation of the per-group kernels, [goff[R]][D]; bias [R][D].
- * B <= 64 per call, D % 16 == 0, D <= 64.
+ * Any B (processed in row blocks of 64, in order), D % 16 == 0, D <= 64.
  * fwd: pre/y[b][r][:] = LeakyReLU(x[b][idx_r] @ W_r + b_r)    (y,pre: [B][R][D])
  * bwd: dW_r = x[:,idx_r]^T @ dpre[:,r,:]; db_r = sum_b dpre[b][r][:]. */
 int32_t tnt_locally_dense_fwd_f32(const float* x, int32_t ldx, const int32_t* idx,

@@ -21,7 +21,7 @@ constexpr int WLD = MAXD + 16;   // Ws / Ds row stride (stride % 32 == 16)
 struct EncArgs {
   const float* x; int ldx; const int* idx; const int* goff; const float* W; const float* bias;
   float* pre; float* y; const float* dpre; float* dW; float* db;
-  int B, R, D; float slope;
+  int B, R, D; float slope; int accumulate;
 };
 
 // gather Xs[row][k] = x[row][idx[g0 + k0 + k]] for row < 64, k < kc
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void locally_dense_bwd_kernel(EncArgs g) {
   if (tid < g.D) {
     float s = 0.f;
     for (int b = 0; b < 64; ++b) s += Ds[b * WLD + tid];
-    g.db[(long)r * g.D + tid] = s;
+    float* o = g.db + (long)r * g.D + tid;
+    *o = g.accumulate ? *o + s : s;
   }
   for (int k0 = 0; k0 < nr; k0 += KC) {
     const int kc = min(KC, nr - k0);
@@ -139,7 +140,10 @@ __global__ __launch_bounds__(256) void locally_dense_bwd_kernel(EncArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int k = mt * 16 + kq * 4 + j;
-          if (k < kc) g.dW[(long)(g0 + k0 + k) * g.D + c * 16 + lr] = acc[c][j];
+          if (k < kc) {
+            float* o = g.dW + (long)(g0 + k0 + k) * g.D + c * 16 + lr;
+            *o = g.accumulate ? *o + acc[c][j] : acc[c][j];
+          }
         }
       }
     }
@@ -151,28 +155,33 @@ __global__ __launch_bounds__(256) void locally_dense_bwd_kernel(EncArgs g) {
 extern "C" int32_t tnt_locally_dense_fwd_f32(const float* x, int32_t ldx, const int32_t* idx, const int32_t* goff,
                                              const float* W, const float* bias, float* pre, float* y, int32_t B,
                                              int32_t R, int32_t D, float slope, void* stream) {
-  if (B <= 0 || B > 64) return TNT_BADARG(9);
+  if (B <= 0) return TNT_BADARG(9);
   if (D <= 0 || D > MAXD || D % 16 != 0) return TNT_BADARG(11);
   if (R <= 0) return TNT_BADARG(10);
-  EncArgs g{};
-  g.x = x; g.ldx = ldx; g.idx = idx; g.goff = goff; g.W = W; g.bias = bias; g.pre = pre; g.y = y;
-  g.B = B; g.R = R; g.D = D; g.slope = slope;
-  hipLaunchKernelGGL(locally_dense_fwd_kernel, dim3(R), dim3(256), 0, tnt_stream(stream), g);
-  TNT_LAUNCH_CHECK();
+  for (int b0 = 0; b0 < B; b0 += 64) {         // the kernels tile 64 batch rows; larger batches go in row blocks
+    EncArgs g{};
+    g.x = x + (long)b0 * ldx; g.ldx = ldx; g.idx = idx; g.goff = goff; g.W = W; g.bias = bias;
+    g.pre = pre + (long)b0 * R * D; g.y = y + (long)b0 * R * D;
+    g.B = B - b0 < 64 ? B - b0 : 64; g.R = R; g.D = D; g.slope = slope;
+    hipLaunchKernelGGL(locally_dense_fwd_kernel, dim3(R), dim3(256), 0, tnt_stream(stream), g);
+    TNT_LAUNCH_CHECK();
+  }
   return 0;
 }
 
 extern "C" int32_t tnt_locally_dense_bwd_f32(const float* x, int32_t ldx, const int32_t* idx, const int32_t* goff,
                                              const float* dpre, float* dW, float* db, int32_t B, int32_t R, int32_t D,
                                              void* stream) {
-  if (B <= 0 || B > 64) return TNT_BADARG(8);
+  if (B <= 0) return TNT_BADARG(8);
   if (D <= 0 || D > MAXD || D % 16 != 0) return TNT_BADARG(10);
   if (R <= 0) return TNT_BADARG(9);
-  EncArgs g{};
-  g.x = x; g.ldx = ldx; g.idx = idx; g.goff = goff; g.dpre = dpre; g.dW = dW; g.db = db;
-  g.B = B; g.R = R; g.D = D;
-  hipLaunchKernelGGL(locally_dense_bwd_kernel, dim3(R), dim3(256), 0, tnt_stream(stream), g);
-  TNT_LAUNCH_CHECK();
+  for (int b0 = 0; b0 < B; b0 += 64) {         // row blocks of 64; blocks after the first accumulate (fixed order)
+    EncArgs g{};
+    g.x = x + (long)b0 * ldx; g.ldx = ldx; g.idx = idx; g.goff = goff; g.dpre = dpre + (long)b0 * R * D;
+    g.dW = dW; g.db = db; g.B = B - b0 < 64 ? B - b0 : 64; g.R = R; g.D = D; g.accumulate = b0 > 0;
+    hipLaunchKernelGGL(locally_dense_bwd_kernel, dim3(R), dim3(256), 0, tnt_stream(stream), g);
+    TNT_LAUNCH_CHECK();
+  }
   return 0;
 }
 

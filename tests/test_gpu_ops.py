@@ -361,7 +361,7 @@ def test_optimizer(be):
 
 
 # ------------------------------------------------------------------- locally dense
-@pytest.mark.parametrize("B,N,R,D", [(64, 2000, 36, 32), (3, 37, 4, 16), (64, 3000, 5, 32)])
+@pytest.mark.parametrize("B,N,R,D", [(64, 2000, 36, 32), (3, 37, 4, 16), (64, 3000, 5, 32), (150, 500, 7, 32)])
 def test_locally_dense(be, B, N, R, D):
     rng = np.random.default_rng(11)
     groups = tiny_groups(N, R, rng)
