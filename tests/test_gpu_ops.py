@@ -198,12 +198,13 @@ def test_colsum_sum_actbwd(be):
 
 
 # -------------------------------------------------------------------------- embedding
-def test_embedding(be):
+@pytest.mark.parametrize("B,T,E,V", [(8, 5, 70, 23), (64, 15, 512, 5001), (9, 4, 36, 11)])
+def test_embedding(be, B, T, E, V):
     rng = np.random.default_rng(6)
-    B, T, E, V = 8, 5, 70, 23
     table = rng.standard_normal((V, E))
     ids = rng.integers(0, V, (B, T)).astype(np.int32)
     ids[0, :] = 3                                        # duplicates
+    ids[:, T // 2:] = np.where(rng.random((B, T - T // 2)) < 0.7, 0, ids[:, T // 2:])   # heavy pad token
     out = torch.zeros(T * B, E, device="cuda")
     idd = dev(ids, torch.int32)
     be.embedding_fwd(dev(table), idd, out, B, T, E, E, V)
