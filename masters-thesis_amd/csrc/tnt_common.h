@@ -46,13 +46,13 @@ __device__ __forceinline__ float tnt_sigmoid(float x) { return 1.f / (1.f + expf
 // attention step kernels (R x A tanh per sample per step, forward and recomputed in backward).
 __device__ __forceinline__ float tnt_tanh(float x) {
   const float t = __expf(2.f * x);
-  return 1.f - __fdividef(2.f, t + 1.f);
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);      // v_rcp_f32 (1 ulp), not the 10-instruction IEEE divide
 }
 
 // logistic via one hardware exp and one reciprocal (absolute error ~1e-7); used where the activation sits on
 // the serial critical path of the T-step chain (LSTM gate math: ocml expf/tanhf cost ~300 VALU instructions per
 // step there, ~0.4 us of a 6.6 us step).
-__device__ __forceinline__ float tnt_sigmoid_fast(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+__device__ __forceinline__ float tnt_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 // wave-wide (64 lanes) reductions
 __device__ __forceinline__ float tnt_wave_sum(float v) {
