@@ -408,7 +408,9 @@ __global__ __launch_bounds__(256) void sample_rows_kernel(const float* x, int* o
   if (step_dev) step += step_dev[0];
   const uint64_t e = (uint64_t)row, g = e >> 2;
   const TntPhilox4 r = tnt_philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), site, step, (uint32_t)seed, (uint32_t)(seed >> 32));
-  const float u = (float)(r.v[e & 3] >> 8) * 5.9604644775390625e-08f;
+  const uint32_t sel = (uint32_t)e & 3u;      // select chain: a runtime index would put r.v in scratch memory
+  const uint32_t rw = sel == 0u ? r.v[0] : (sel == 1u ? r.v[1] : (sel == 2u ? r.v[2] : r.v[3]));
+  const float u = (float)(rw >> 8) * 5.9604644775390625e-08f;
   const float target = u * part[256];
   const int tlast = (V - 1) / C;       // last thread that owns elements (takes the u*sum == sum rounding case)
   if (part[tid] <= target && (target < part[tid + 1] || tid == tlast)) {

@@ -26,7 +26,10 @@ __device__ __forceinline__ TntPhilox4 tnt_philox4x32_10(uint32_t c0, uint32_t c1
 __device__ __forceinline__ bool tnt_keep(uint64_t e, float rate, uint64_t seed, uint32_t site, uint32_t step) {
   const uint64_t g = e >> 2;
   TntPhilox4 r = tnt_philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), site, step, (uint32_t)seed, (uint32_t)(seed >> 32));
-  const uint32_t w = r.v[e & 3];
+  // select chain, NOT r.v[e & 3]: a runtime index into the 4-word result sends the array to scratch memory
+  // (measured: +10 us on a kernel in which 32 threads make this call once)
+  const uint32_t sel = (uint32_t)e & 3u;
+  const uint32_t w = sel == 0u ? r.v[0] : (sel == 1u ? r.v[1] : (sel == 2u ? r.v[2] : r.v[3]));
   const float u = (float)(w >> 8) * 5.9604644775390625e-08f;  // 2^-24
   return u >= rate;
 }

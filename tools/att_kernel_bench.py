@@ -1,0 +1,29 @@
+"""attention_step_fwd kernel alone, captured graph of 20 launches, for the four on/off combinations of its two dropouts."""
+import sys
+import torch
+sys.path.insert(0, ".")
+import masters_thesis_amd.ops as ops
+be = ops.backend()
+B, R, D, A, U = 64, 360, 32, 32, 512
+f = lambda *s: torch.randn(*s, device="cuda")
+h, F, P, W2, b2, v, bv = f(B, U), f(B, R, D), f(B, R, A), f(U, A) * 0.05, f(A), f(A), f(1)
+qpre, alpha, ctx, ctx_d = f(B, A), f(B, R), f(B, D), f(B, D)
+step_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+def timeit(fn, n=20):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+            for _ in range(n): fn()
+        g.replay(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s); g.replay(); b.record(s); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+for ra, ri, cd in ((0.2, 0.2, ctx_d), (0.2, 0.0, ctx_d), (0.0, 0.2, ctx_d), (0.0, 0.0, ctx_d), (0.2, 0.2, None)):
+    t = timeit(lambda: be.attention_step_fwd(h, F, P, W2, b2, v, bv, qpre, alpha, ctx, cd, None, B, R, D, A, U, 0.2, ra, ri,
+                                             D + 512, 42, 16, 48, 0, step_dev))
+    print(f"rate_attn={ra} rate_in={ri} ctx_d={'yes' if cd is not None else 'no '}: {t:6.2f} us")
