@@ -35,8 +35,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwdArgs a) {
   const int kq = lane >> 4, lr = lane & 15;
   const int ub = blockIdx.x, rb = blockIdx.y;
   const int U = a.U, B = a.B;
-  const int Ktot = U + (a.ctx ? a.D : 0);
-  const int nchunk = (Ktot + 63) / 64;
+  const int nchunk = (U + 63) / 64;       // 64-wide chunks of the recurrent contraction, one per wave at U = 512
   const int arow = rb * 16 + lr;          // batch row this lane feeds as the A operand
   const int ucol = ub * 16 + lr;          // hidden unit this lane feeds as the B operand
   floatx4 acc[4];
@@ -58,6 +57,19 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwdArgs a) {
     if (a.out_prev) op = a.out_prev[ee];
   }
 
+  // context rows (the attention model's second operand, D extra contraction rows): spread over the waves in
+  // MFMA k-steps of 4 -- wave w takes k = 4w .. 4w+3, 4w+32 .. -- instead of a ninth chunk that one wave would
+  // have to run after its own (D = 32: one extra k-step per wave, +4 MFMAs, instead of +64 on wave 0)
+  // (operands of the first such step are fetched here, ahead of the weight stream; the MFMAs come after it)
+  float cav = 0.f;
+  float4 cbv = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool has_ctx = a.ctx != nullptr && w * 4 < a.D;
+  if (has_ctx) {
+    const int kd = w * 4 + kq;
+    const bool ok = kd < a.D;
+    cav = (ok && arow < B) ? a.ctx[(long)arow * a.D + kd] : 0.f;
+    cbv = ld4g(a.Wc + ((long)min(kd, a.D - 1) * U + ucol) * 4, ok);
+  }
   for (int ci = w; ci < nchunk; ci += NW) {
     const int kbase = ci * 64 + kq * 16;
     float av[16];
@@ -73,23 +85,16 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwdArgs a) {
 #pragma unroll
       for (int s = 0; s < 16; ++s)
         bv[s] = ld4g(a.Ur + ((long)(ci * 64 + (s >> 2) * 16 + kq * 4 + (s & 3)) * U + ucol) * 4, true);
-    } else if (kbase < U) {
-      // recurrent part: U % 16 == 0, so the 16-run never straddles U
+    } else {
+      // last, partial chunk (U % 64 != 0; U % 16 == 0, so a 16-run never straddles U): lanes past U feed zeros
+      const bool kok = kbase < U;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float4 t = ld4g(a.h_prev + (long)arow * U + kbase + 4 * j, arow < B);
+        const float4 t = ld4g(a.h_prev + (long)arow * U + kbase + 4 * j, kok && arow < B);
         av[4 * j + 0] = t.x; av[4 * j + 1] = t.y; av[4 * j + 2] = t.z; av[4 * j + 3] = t.w;
       }
 #pragma unroll
-      for (int s = 0; s < 16; ++s) bv[s] = ld4g(a.Ur + ((long)(kbase + s) * U + ucol) * 4, true);
-    } else {
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const int kd = kbase + s - U;
-        const bool ok = kd < a.D;
-        av[s] = (ok && arow < B) ? a.ctx[(long)arow * a.D + kd] : 0.f;
-        bv[s] = ld4g(a.Wc + ((long)kd * U + ucol) * 4, ok);
-      }
+      for (int s = 0; s < 16; ++s) bv[s] = ld4g(a.Ur + ((long)(kbase + s) * U + ucol) * 4, kok);
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -97,6 +102,20 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwdArgs a) {
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].y, acc[1], 0, 0, 0);
       acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].z, acc[2], 0, 0, 0);
       acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].w, acc[3], 0, 0, 0);
+    }
+  }
+  if (has_ctx) {
+    for (int st = w;;) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cav, cbv.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cav, cbv.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(cav, cbv.z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(cav, cbv.w, acc[3], 0, 0, 0);
+      st += NW;
+      if (st * 4 >= a.D) break;
+      const int kd = st * 4 + kq;                      // D > 32: further k-steps of this wave
+      const bool ok = kd < a.D;
+      cav = (ok && arow < B) ? a.ctx[(long)arow * a.D + kd] : 0.f;
+      cbv = ld4g(a.Wc + ((long)min(kd, a.D - 1) * U + ucol) * 4, ok);
     }
   }
   // C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg

@@ -27,3 +27,21 @@ for ra, ri, cd in ((0.2, 0.2, ctx_d), (0.2, 0.0, ctx_d), (0.0, 0.2, ctx_d), (0.0
     t = timeit(lambda: be.attention_step_fwd(h, F, P, W2, b2, v, bv, qpre, alpha, ctx, cd, None, B, R, D, A, U, 0.2, ra, ri,
                                              D + 512, 42, 16, 48, 0, step_dev))
     print(f"rate_attn={ra} rate_in={ri} ctx_d={'yes' if cd is not None else 'no '}: {t:6.2f} us")
+
+# ---- backward kernel
+dP, dF, dvb, dqpre, dh = torch.zeros(B, R, A, device="cuda"), torch.zeros(B, R, D, device="cuda"), torch.zeros(B, A + 1, device="cuda"), f(B, A), f(B, U)
+dz, Wc, dctx = f(B, U, 4) * 0.01, f(D, U, 4) * 0.05, f(B, D)
+alpha_n = torch.softmax(f(B, R), dim=1)
+for ra, ri, fused in ((0.2, 0.2, True), (0.2, 0.0, True), (0.0, 0.0, True), (0.2, 0.2, False), (0.0, 0.0, False)):
+    t = timeit(lambda: be.attention_step_bwd(None if fused else dctx, F, P, W2, v, qpre, alpha_n, dP, dF, dvb, dqpre, dh, B, R, D, A, U,
+                                             0.2, ra, ri, D + 512, 42, 16, 48, 0, step_dev, dz=dz if fused else None,
+                                             Wc=Wc if fused else None))
+    print(f"bwd rate_attn={ra} rate_in={ri} fused_dctx={fused}: {t:6.2f} us")
+# ---- LSTM step kernels as used by the attention model (ctx operand) and by the dense model
+Ur, xz, c0 = f(U, U, 4) * 0.05, f(B, U, 4), f(B, U)
+h2, c2, gates = f(B, U), f(B, U), f(B, U, 4)
+Wc2 = f(D, U, 4) * 0.05
+for use_ctx in (True, False):
+    t = timeit(lambda: be.lstm_step_fwd(xz, h, c0, Ur, ctx if use_ctx else None, Wc2 if use_ctx else None, D if use_ctx else 0,
+                                        None, 0, 0, None, h2, c2, None, gates, B, U))
+    print(f"lstm fwd ctx={use_ctx}: {t:6.2f} us")
