@@ -49,6 +49,13 @@ int32_t tnt_gemm_f32(const float* A, const float* B, float* C, const float* bias
                      int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc,
                      int32_t transA, int32_t transB, int32_t act, float slope,
                      int32_t accumulate, int32_t splitk, float* work, void* stream);
+/* tuning entry point: tnt_gemm_f32 with the workgroup tile forced to bm x bn (each 64 or 128; anything else =
+ * the library's own choice).  Used by tools/gemm_bench.py / gemm_scan.py to calibrate the tile heuristic. */
+int32_t tnt_gemm_f32_tile(const float* A, const float* B, float* C, const float* bias, float* pre,
+                          int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc,
+                          int32_t transA, int32_t transB, int32_t act, float slope,
+                          int32_t accumulate, int32_t splitk, float* work, int32_t bm, int32_t bn,
+                          void* stream);
 
 /* ---- dropout (keras Dropout, inverted; lc_NIC.py:51-55,94; LSTM dropout= :122) ---
  * y[r][c] = keep ? x[r][c]/(1-rate) : 0 for r<rows, c<cols (ld = row stride of x,y).

@@ -1,0 +1,73 @@
+"""The drop-in boundary: every entry point include/tnt_hip.h declares is exported by the built library
+(masters-thesis_amd/csrc/libtnt_hip.so), bound in masters_thesis_amd/_lib.py with the declared arity and
+argument kinds, and nothing is bound that the header does not declare.  No compute call is made (runs without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "tnt_hip.h")
+
+
+def declared():
+    """name -> list of parameter type strings, parsed from the header's prototypes."""
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\bint32_t\s+(tnt_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        name, params = m.group(1), m.group(2).strip()
+        ps = [] if params in ("", "void") else [" ".join(p.split()) for p in params.split(",")]
+        out[name] = [re.sub(r"\s*\w+$", "", p).strip() for p in ps]      # drop the parameter name
+    return out
+
+
+def kind(ctype):
+    from masters_thesis_amd import _lib
+    return {_lib.P: "ptr", _lib.I32: "int32_t", _lib.I64: "int64_t", _lib.U32: "uint32_t", _lib.U64: "uint64_t",
+            _lib.F32: "float"}[ctype]
+
+
+def test_header_is_plain_c_abi():
+    src = open(HEADER).read()
+    assert 'extern "C"' in src
+    for bad in ("torch", "at::", "std::", "hipStream_t stream"):       # plain pointers and sizes; streams travel as void*
+        assert bad not in re.sub(r"/\*.*?\*/", " ", src, flags=re.S), bad
+    d = declared()
+    assert len(d) >= 35
+    for name, params in d.items():
+        if params:
+            assert params[-1] == "void*" or name in ("tnt_bn_nchunk",), (name, params[-1])    # trailing stream argument
+
+
+def test_library_exports_and_binding_match_the_header():
+    from masters_thesis_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build the kernel library first: __graft_entry__.build()"
+    lib = _lib.load()
+    d = declared()
+    assert set(_lib.SIGNATURES) == set(d), (sorted(set(d) - set(_lib.SIGNATURES)), sorted(set(_lib.SIGNATURES) - set(d)))
+    raw = C.CDLL(_lib.LIB_PATH)
+    for name, params in d.items():
+        assert hasattr(raw, name), f"{name} is declared in the header but not exported"
+        sig = _lib.SIGNATURES[name]
+        assert len(sig) == len(params), (name, len(sig), len(params))
+        for i, (ct, ps) in enumerate(zip(sig, params)):
+            want = "ptr" if ps.endswith("*") else ps.replace("const ", "")
+            assert kind(ct) == want, (name, i, ps, kind(ct))
+    assert lib.tnt_version() >= 102
+
+
+def test_product_has_no_cpu_fallback():
+    """ops.backend() must refuse to run without the HIP extension / a GPU instead of degrading silently."""
+    import torch
+    import masters_thesis_amd.ops as ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    old = ops._backend
+    ops._backend = None
+    try:
+        with pytest.raises(Exception):
+            ops.backend()
+    finally:
+        ops._backend = old
