@@ -219,9 +219,8 @@ class NIC(ModelBase):
     def _build(self, B, T):
         if self._shape == (B, T):
             return
-        if B % self.S or B // self.S > 64:
-            raise ValueError("batch must split into n_subjects equal slices of at most 64 samples "
-                             "(region-wise encoder kernel limit per call)")
+        if B % self.S:
+            raise ValueError("batch must split into n_subjects equal slices")
         f = self._f
         R, D, A, U, Et, V, H, ldV = self.R, self.D, self.A, self.U, self.Et, self.V, self.H, self.ldV
         n = T * B
