@@ -49,6 +49,14 @@ int32_t tnt_gemm_f32(const float* A, const float* B, float* C, const float* bias
                      int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc,
                      int32_t transA, int32_t transB, int32_t act, float slope,
                      int32_t accumulate, int32_t splitk, float* work, void* stream);
+/* Plain library GEMM (rocBLAS sgemm, exact f32, atomics disabled => bitwise reproducible), same operand conventions as
+ * tnt_gemm_f32 without the epilogue arguments: C = op(A) op(B) (+ C if accumulate).  For the matmuls that carry no
+ * fused epilogue (weight / input gradients); the fused ones use tnt_gemm_f32.  The first call creates the process-wide
+ * rocBLAS handle and loads its kernels -- make it outside a stream capture. */
+int32_t tnt_gemm_blas_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K,
+                          int32_t lda, int32_t ldb, int32_t ldc, int32_t transA, int32_t transB,
+                          int32_t accumulate, void* stream);
+
 /* tuning entry point: tnt_gemm_f32 with the workgroup tile forced to bm x bn (each 64 or 128; anything else =
  * the library's own choice).  Used by tools/gemm_bench.py / gemm_scan.py to calibrate the tile heuristic. */
 int32_t tnt_gemm_f32_tile(const float* A, const float* B, float* C, const float* bias, float* pre,

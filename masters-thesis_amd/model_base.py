@@ -163,6 +163,13 @@ class ModelBase:
         """GEMM with the calibrated split-K choice.  ``ws`` selects the split-K workspace (one per
         concurrent branch, see ``side``).  Workspaces grow on demand during eager (warm-up) passes;
         growing one invalidates captured graphs, which are then re-captured."""
+        plain = kw.get("bias") is None and kw.get("pre") is None and kw.get("act", 0) == 0
+        if plain and getattr(self, "use_blas", True) and hasattr(self.be, "gemm_blas"):
+            # no fused epilogue (weight / input gradients): the vendor's stream-K sgemm (tnt_gemm_blas_f32) needs no
+            # split-K pass + reduce launch on these skinny-output / long-K shapes
+            self.be.gemm_blas(A, B, C, M, N, K, lda, ldb, ldc, transA=kw.get("transA", False),
+                              transB=kw.get("transB", False), accumulate=kw.get("accumulate", False))
+            return
         sk = self.pick_splitk(M, N, K)
         if sk > 1:
             pool = self.__dict__.setdefault("_skw", {})

@@ -138,6 +138,10 @@ class HipBackend:
         _lib.check(self.lib.tnt_dense_dw_skinny_f32(_p(x), _p(dpre), _p(dw), N, E, Bk, ldx, self._s()),
                    "tnt_dense_dw_skinny_f32")
 
+    def gemm_blas(self, A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, accumulate=False):
+        _lib.check(self.lib.tnt_gemm_blas_f32(_p(A), _p(B), _p(C), M, N, K, lda, ldb, ldc, int(transA), int(transB),
+                                              int(accumulate), self._s()), "tnt_gemm_blas_f32")
+
     def sum2(self, x0, out0, x1, out1, n, scale):
         _lib.check(self.lib.tnt_sum2_f32(_p(x0), _p(out0), _p(x1), _p(out1), n, scale, self._s()), "tnt_sum2_f32")
 
