@@ -170,12 +170,13 @@ int32_t tnt_embedding_bwd_f32(const float* drows, const int32_t* ids, float* dta
  *       mask (nullable, int32 ids[B*T], column `mask_t`): rows with id==0 keep
  *       (h_prev,c_prev) and repeat out_prev (zeros if out_prev is null).
  *       Saves gates[B][U][4] (post-activation).  out (nullable) receives the
- *       sequence output of this step. */
+ *       sequence output of this step.  xz_bias (nullable, [U][4]) is added to xz inside the kernel, so that
+ *       the input projection of all timesteps can be an epilogue-free GEMM. */
 int32_t tnt_lstm_step_fwd_f32(const float* xz, const float* h_prev, const float* c_prev,
                               const float* Ur, const float* ctx, const float* Wc, int32_t D,
                               const int32_t* mask_ids, int32_t mask_T, int32_t mask_t,
                               const float* out_prev, float* h, float* c, float* out,
-                              float* gates, int32_t B, int32_t U, void* stream);
+                              float* gates, int32_t B, int32_t U, const float* xz_bias, void* stream);
 /* bwd of one step, fused with the recurrent matmul of the step after it:
  *   da = da_pass_in + dh_ext + (dz_next ? dz_next[B][U][4] @ Ur^T : 0)
  *   dout = dout_in + dout_t ; masked rows pass (da, dc, dout) through, dz = 0

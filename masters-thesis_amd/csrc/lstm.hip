@@ -27,6 +27,7 @@ struct LstmFwdArgs {
   const float* xz; const float* h_prev; const float* c_prev; const float* Ur; const float* ctx; const float* Wc;
   const int* mask_ids; const float* out_prev; float* h; float* c; float* out; float* gates;
   int D, mask_T, mask_t, B, U;
+  const float* zbias;      // nullable [U][4]: added to xz here, so the input projection can be an epilogue-free GEMM
 };
 
 __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwdArgs a) {
@@ -52,6 +53,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwdArgs a) {
   int mid = 1;
   if (eok) {
     x4 = *reinterpret_cast<const float4*>(a.xz + ee * 4);
+    if (a.zbias) {
+      const float4 b4 = *reinterpret_cast<const float4*>(a.zbias + (long)eu * 4);
+      x4.x += b4.x; x4.y += b4.y; x4.z += b4.z; x4.w += b4.w;
+    }
     cp = a.c_prev[ee]; hp = a.h_prev[ee];
     if (a.mask_ids) mid = a.mask_ids[eb * a.mask_T + a.mask_t];
     if (a.out_prev) op = a.out_prev[ee];
@@ -324,14 +329,15 @@ __global__ __launch_bounds__(512) void lstm_bwd_lds_kernel(LstmBwdArgs a) {
 extern "C" int32_t tnt_lstm_step_fwd_f32(const float* xz, const float* h_prev, const float* c_prev, const float* Ur,
                                          const float* ctx, const float* Wc, int32_t D, const int32_t* mask_ids,
                                          int32_t mask_T, int32_t mask_t, const float* out_prev, float* h, float* c,
-                                         float* out, float* gates, int32_t B, int32_t U, void* stream) {
+                                         float* out, float* gates, int32_t B, int32_t U, const float* xz_bias,
+                                         void* stream) {
   if (U <= 0 || U % 16 != 0) return TNT_BADARG(17);
   if (B <= 0) return TNT_BADARG(16);
   if (h == h_prev) return TNT_BADARG(12);
   LstmFwdArgs a;
   a.xz = xz; a.h_prev = h_prev; a.c_prev = c_prev; a.Ur = Ur; a.ctx = ctx; a.Wc = Wc; a.mask_ids = mask_ids;
   a.out_prev = out_prev; a.h = h; a.c = c; a.out = out; a.gates = gates;
-  a.D = D; a.mask_T = mask_T; a.mask_t = mask_t; a.B = B; a.U = U;
+  a.D = D; a.mask_T = mask_T; a.mask_t = mask_t; a.B = B; a.U = U; a.zbias = xz_bias;
   hipLaunchKernelGGL(lstm_fwd_kernel, dim3(U / 16, (B + 15) / 16), dim3(512), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;

@@ -178,12 +178,12 @@ class NICfc(_DenseNIC):
             be.dropout(self.text, self.text, n, E, E, B, E, 0, self.r_text, sd, S_TEXT, 0, ds)
         if training and self.r_lstm > 0:                                                            # LSTM(dropout=)
             be.dropout(self.text, self.text, n, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
-        self.gemm_sk(self.text, a.p("lstm/kernel"), self.XZ, n, 4 * U, E, E, 4 * U, 4 * U, bias=a.p("lstm/bias"))
-        Ur = a.p("lstm/recurrent_kernel")
+        self.gemm_sk(self.text, a.p("lstm/kernel"), self.XZ, n, 4 * U, E, E, 4 * U, 4 * U)   # bias: in the step kernel
+        Ur, bl = a.p("lstm/recurrent_kernel"), a.p("lstm/bias")
         for t in range(T):                                                                          # :318
             be.lstm_step_fwd(self.XZ[t * B:(t + 1) * B], self.Hs[t], self.Cs[t], Ur, None, None, 0, self.cap, T, t,
                              self.Out[t - 1] if t > 0 else None, self.Hs[t + 1], self.Cs[t + 1], self.Out[t],
-                             self.gates[t], B, U)
+                             self.gates[t], B, U, xz_bias=bl)
         out = self.Out
         if training and self.r_lstm > 0:                                                            # :321
             be.dropout(self.Out, self.Out_d, n, U, U, B, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds)

@@ -313,7 +313,7 @@ class NIC(ModelBase):
         self.gemm_sk(self.F, a.p("attention/W1/kernel"), self.P, B * R, self.A, D, D, self.A, self.A,
                 bias=a.p("attention/W1/bias"), pre=self.Ppre, act=ACT_LEAKY, slope=0.2)      # attention.py:32 (hoisted)
 
-    def _decode_step(self, i, B, training, s_out=None):
+    def _decode_step(self, i, B, training, s_out=None, xz_bias=None):
         """attention -> concat -> one LSTM step (lc_NIC.py:246-255)."""
         be, a = self.be, self.arena
         R, D, A, U, Et = self.R, self.D, self.A, self.U, self.Et
@@ -325,7 +325,7 @@ class NIC(ModelBase):
                               S_ATTN + i, S_LSTM_IN + i, 0, self.drop_step)
         be.lstm_step_fwd(self.XZ[i * B:(i + 1) * B], self.Hs[i], self.Cs[i], a.p("lstm/recurrent_kernel"),
                          self.ctx_d[i], Wl[:D], D, None, 0, 0, None, self.Hs[i + 1], self.Cs[i + 1], None,
-                         self.gates[i], B, U)
+                         self.gates[i], B, U, xz_bias=xz_bias)
 
     def _forward(self, B, T, training):
         be, a = self.be, self.arena
@@ -340,9 +340,10 @@ class NIC(ModelBase):
             be.dropout(self.text, self.text, n, Et, Et, 0, D + Et, D, self.r_lstm, sd, S_LSTM_IN, 0, ds,
                        rows_per_site=B)
         Wl = a.p("lstm/kernel")
-        self.gemm_sk(self.text, Wl[D:], self.XZ, n, 4 * U, Et, Et, 4 * U, 4 * U, bias=a.p("lstm/bias"))
+        # text half of the input projection for all T steps: one epilogue-free GEMM; bias added in the step kernel
+        self.gemm_sk(self.text, Wl[D:], self.XZ, n, 4 * U, Et, Et, 4 * U, 4 * U)
         for i in range(T):                                                                      # :244-256
-            self._decode_step(i, B, training)
+            self._decode_step(i, B, training, xz_bias=a.p("lstm/bias"))
         hs = self.Hs[1:].view(n, U)
         if training and self.r_lstm > 0:                                                        # :256
             be.dropout(hs, self.Hd, n, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds, rows_per_site=B)

@@ -237,16 +237,17 @@ class NIC(ModelBase):
             if drop_l:       # LSTM(dropout=...) masks the layer input, one mask per call
                 be.dropout(self.Xin[B:], self.Xin_d[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
         self._xin_used = xin
-        self.gemm_sk(xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U, bias=a.p("lstm/bias"))
-        Ur = a.p("lstm/recurrent_kernel")
+        # input projection of all T+1 steps as ONE epilogue-free GEMM; the LSTM bias is added inside the step kernel
+        self.gemm_sk(xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U)
+        Ur, bl = a.p("lstm/recurrent_kernel"), a.p("lstm/bias")
         # lstm call 1: the feature, one unmasked step (NIC.py:138)
         be.lstm_step_fwd(self.XZ[:B], self.Hs[0], self.Cs[0], Ur, None, None, 0, None, 0, 0, None, self.Hs[1],
-                         self.Cs[1], None, self.gates[0], B, U)
+                         self.Cs[1], None, self.gates[0], B, U, xz_bias=bl)
         # lstm call 2: the text, masked by the Embedding mask (NIC.py:140)
         for t in range(1, T + 1):
             be.lstm_step_fwd(self.XZ[t * B:(t + 1) * B], self.Hs[t], self.Cs[t], Ur, None, None, 0, self.cap, T,
                              t - 1, self.Out[t - 2] if t > 1 else None, self.Hs[t + 1], self.Cs[t + 1],
-                             self.Out[t - 1], self.gates[t], B, U)
+                             self.Out[t - 1], self.gates[t], B, U, xz_bias=bl)
         self.gemm_sk(self.Out, a.p("time_distributed_softmax/kernel"), self.logits, T * B, V, U, U, ldV, ldV,
                 bias=a.p("time_distributed_softmax/bias"))                         # NIC.py:143
 

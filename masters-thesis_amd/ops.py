@@ -86,10 +86,10 @@ class HipBackend:
                                                   E, ldd, V, self._s()), "tnt_embedding_bwd_f32")
 
     def lstm_step_fwd(self, xz, h_prev, c_prev, Ur, ctx, Wc, D, mask_ids, mask_T, mask_t, out_prev, h, c, out,
-                      gates, B, U):
+                      gates, B, U, xz_bias=None):
         _lib.check(self.lib.tnt_lstm_step_fwd_f32(_p(xz), _p(h_prev), _p(c_prev), _p(Ur), _p(ctx), _p(Wc), D,
                                                   _p(mask_ids), mask_T, mask_t, _p(out_prev), _p(h), _p(c), _p(out),
-                                                  _p(gates), B, U, self._s()), "tnt_lstm_step_fwd_f32")
+                                                  _p(gates), B, U, _p(xz_bias), self._s()), "tnt_lstm_step_fwd_f32")
 
     def lstm_step_bwd(self, dz_next, Ur, da_pass_in, dh_ext, dc_in, dout_in, dout_t, mask_ids, mask_T, mask_t,
                       gates, c, c_prev, dz, da_pass_out, dc_out, dout_out, B, U):

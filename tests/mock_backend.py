@@ -189,8 +189,10 @@ class MockBackend:
 
     # ---------------------------------------------------------------- LSTM
     def lstm_step_fwd(self, xz, h_prev, c_prev, Ur, ctx, Wc, D, mask_ids, mask_T, mask_t, out_prev, h, c, out,
-                      gates, B, U):
+                      gates, B, U, xz_bias=None):
         z = mat(xz, B, 4 * U, 4 * U).astype(np.float64).reshape(B, U, 4)
+        if xz_bias is not None:
+            z = z + flat(xz_bias)[:4 * U].astype(np.float64).reshape(1, U, 4)
         hp, cp = mat(h_prev, B, U, U).astype(np.float64), mat(c_prev, B, U, U).astype(np.float64)
         z = z + (hp @ mat(Ur, U, 4 * U, 4 * U).astype(np.float64)).reshape(B, U, 4)
         if ctx is not None:
