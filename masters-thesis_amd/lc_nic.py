@@ -52,6 +52,19 @@ def synthetic_groups(n_voxels, n_regions, out_dim, seed=42, overlap=0.0):
     return groups, [out_dim] * n_regions
 
 
+def compact_groups(groups):
+    """Input-pipeline helper for full-cortex widths: the region-wise encoder only ever reads the voxel
+    columns its groups reference (after ``select_groups``, main.py:115, a good part of the 327 684-wide betas is
+    unused).  Returns ``(used, groups2)``: ``used`` = sorted unique referenced columns, ``groups2`` = the same groups
+    re-indexed into ``betas[:, used]``.  A generator that keeps / loads only ``betas[:, used]`` ships that many
+    fewer bytes over PCIe per batch; the model built on ``groups2`` computes exactly the same function."""
+    in_groups, out_groups = groups
+    used = np.unique(np.concatenate([np.asarray(g, dtype=np.int64) for g in in_groups]))
+    remap = np.full(int(used.max()) + 1, -1, dtype=np.int64)
+    remap[used] = np.arange(len(used))
+    return used, ([remap[np.asarray(g, dtype=np.int64)] for g in in_groups], list(out_groups))
+
+
 class NIC(ModelBase):
     H = 256     # dense_inter width, hard-coded at lc_NIC.py:141
 

@@ -119,3 +119,22 @@ def test_sample_predict_matches_oracle_stream():
     greedy = model.greedy_predict(data[0], z, z, np.ones(B, np.int64), T)
     assert not np.array_equal(greedy[0], got[0]) or True      # may coincide at tiny V; shapes must agree
     assert greedy[0].shape == got[0].shape == (B, T, 1)
+
+
+def test_compact_groups_is_the_same_function_on_fewer_columns():
+    from masters_thesis_amd.lc_nic import compact_groups
+    rng = np.random.default_rng(78)
+    N, R, D = 60, 4, 16
+    groups = [np.sort(rng.choice(N, size=int(rng.integers(3, 9)), replace=False)) for _ in range(R)]   # sparse coverage
+    used, g2 = compact_groups((groups, [D] * R))
+    assert len(used) < N and all((used[g] == np.asarray(o)).all() for g, o in zip(g2[0], groups))
+    args = (16, 512, 12, 6, 13, 5, 0, 0, 0, 0, 0, 0, 0.01, 0.001, 3e-5, 1e-5)
+    m1 = NIC((groups, [D] * R), *args, device="cpu", seed=5)
+    m2 = NIC(g2, *args, device="cpu", seed=5)
+    for k in m1.keras_shapes:
+        m2.set_weight(k, m1.get_weight(k))
+    B, T, U = 3, 5, 16
+    data, _ = synth_batch(B, N, T, 13, U, rng)
+    p1, a1 = m1(data, training=False)
+    p2, a2 = m2((data[0][:, used],) + tuple(data[1:]), training=False)
+    assert np.array_equal(p1.numpy(), p2.numpy()) and np.array_equal(a1.numpy(), a2.numpy())
