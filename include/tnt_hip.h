@@ -103,6 +103,21 @@ int32_t tnt_batchnorm_bwd_f32(const float* dy, const float* xhat, const float* g
                               int32_t rows, int32_t C, int32_t lddy, int32_t training,
                               float* work, void* stream);
 
+/* Split mode of the two entry points above: the launch runs over PIECES of at most `piece` voxels of a region's index
+ * list, so that one large region does not set the kernel time (regions span 8..400+ voxels; measured 39 -> ~12 us
+ * at 360 regions of 18..240 voxels).  Tables (host-built from goff): vgoff[NV+1] CSR range of each piece, vreg[NV] its
+ * region, vfirst[NV] 1 for a region's first piece, rfirst[R+1] first piece of each region.  Forward = piece partials
+ * (partial: NV*64*D floats) + a combine launch; results equal the unsplit ones up to f32 summation order. */
+int32_t tnt_locally_dense_fwd_split_f32(const float* x, int32_t ldx, const int32_t* idx, const int32_t* vgoff,
+                                        const int32_t* vreg, const int32_t* rfirst, int32_t NV,
+                                        const float* W, const float* bias, float* pre, float* y,
+                                        float* partial, int32_t B, int32_t R, int32_t D, float slope,
+                                        void* stream);
+int32_t tnt_locally_dense_bwd_split_f32(const float* x, int32_t ldx, const int32_t* idx, const int32_t* vgoff,
+                                        const int32_t* vreg, const int32_t* vfirst, int32_t NV,
+                                        const float* dpre, float* dW, float* db, int32_t B, int32_t R,
+                                        int32_t D, void* stream);
+
 /* ---- weight gradient of the dense voxel encoder at small batch:  dw[N][E] = x^T @ dpre --------------
  * x [Bk][ldx] (the betas, Bk <= 64 rows), dpre [Bk][E] (E % 32 == 0, E <= 512, 16-byte aligned), dw [N][E].
  * (NIC.py:64-69,248-249; ThinkAndTell model.py:22-33.)  Same result as tnt_gemm_f32(transA=1) up to f32

@@ -22,6 +22,10 @@ struct EncArgs {
   const float* x; int ldx; const int* idx; const int* goff; const float* W; const float* bias;
   float* pre; float* y; const float* dpre; float* dW; float* db;
   int B, R, D; float slope; int accumulate;
+  // split mode (nullable): the launch runs over VIRTUAL regions -- contiguous pieces of at most `piece` voxels of a
+  // region's index list -- so that one large region does not set the kernel time (Glasser regions span 8..400+
+  // voxels).  vgoff[v..v+1] = CSR range of piece v, vreg[v] = its region, vfirst[v] = 1 for a region's first piece.
+  const int* vgoff; const int* vreg; const int* vfirst; float* partial;
 };
 
 // gather Xs[row][k] = x[row][idx[g0 + k0 + k]] for row < 64, k < kc
@@ -51,9 +55,10 @@ __global__ __launch_bounds__(256) void locally_dense_fwd_kernel(EncArgs g) {
   __shared__ float Xs[64 * XLD];
   __shared__ float Ws[KC * WLD];
   __shared__ int Is[KC];
-  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int vr = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
-  const int g0 = g.goff[r], nr = g.goff[r + 1] - g0;
+  const int r = g.vreg ? g.vreg[vr] : vr;
+  const int g0 = g.vreg ? g.vgoff[vr] : g.goff[r], nr = (g.vreg ? g.vgoff[vr + 1] : g.goff[r + 1]) - g0;
   const int DT = g.D / 16;
   floatx4 acc[MAXD / 16];
 #pragma unroll
@@ -88,12 +93,30 @@ __global__ __launch_bounds__(256) void locally_dense_fwd_kernel(EncArgs g) {
     for (int j = 0; j < 4; ++j) {
       const int b = w * 16 + kq * 4 + j;
       if (b < g.B) {
-        const float p = acc[c][j] + bd;
-        const long o = ((long)b * g.R + r) * g.D + d;
-        g.pre[o] = p;
-        g.y[o] = p > 0.f ? p : p * g.slope;
+        if (g.vreg) {                        // split mode: partial sum of this piece, combined by the kernel below
+          g.partial[((long)vr * 64 + b) * g.D + d] = acc[c][j];
+        } else {
+          const float p = acc[c][j] + bd;
+          const long o = ((long)b * g.R + r) * g.D + d;
+          g.pre[o] = p;
+          g.y[o] = p > 0.f ? p : p * g.slope;
+        }
       }
     }
+  }
+}
+
+// split mode, second half of the forward: pre[b][r][:] = bias_r + sum over the pieces of region r (in piece order)
+__global__ __launch_bounds__(256) void locally_dense_combine_kernel(EncArgs g, const int* rfirst) {
+  const int r = blockIdx.x;
+  const int v0 = rfirst[r], v1 = rfirst[r + 1];
+  for (int e = threadIdx.x; e < g.B * g.D; e += 256) {
+    const int b = e / g.D, d = e % g.D;
+    float p = g.bias[(long)r * g.D + d];
+    for (int v = v0; v < v1; ++v) p += g.partial[((long)v * 64 + b) * g.D + d];
+    const long o = ((long)b * g.R + r) * g.D + d;
+    g.pre[o] = p;
+    g.y[o] = p > 0.f ? p : p * g.slope;
   }
 }
 
@@ -101,9 +124,11 @@ __global__ __launch_bounds__(256) void locally_dense_bwd_kernel(EncArgs g) {
   __shared__ float Xs[64 * XLD];
   __shared__ float Ds[64 * WLD];
   __shared__ int Is[KC];
-  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int vr = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
-  const int g0 = g.goff[r], nr = g.goff[r + 1] - g0;
+  const int r = g.vreg ? g.vreg[vr] : vr;
+  const int g0 = g.vreg ? g.vgoff[vr] : g.goff[r], nr = (g.vreg ? g.vgoff[vr + 1] : g.goff[r + 1]) - g0;
+  const bool first = g.vreg ? g.vfirst[vr] != 0 : true;      // the bias gradient belongs to the region, not the piece
   const int DT = g.D / 16;
   // stage dpre[:, r, :] (rows beyond B are zero)
   for (int e = tid; e < 64 * g.D; e += 256) {
@@ -111,7 +136,7 @@ __global__ __launch_bounds__(256) void locally_dense_bwd_kernel(EncArgs g) {
     Ds[b * WLD + d] = b < g.B ? g.dpre[((long)b * g.R + r) * g.D + d] : 0.f;
   }
   __syncthreads();
-  if (tid < g.D) {
+  if (first && tid < g.D) {
     float s = 0.f;
     for (int b = 0; b < 64; ++b) s += Ds[b * WLD + tid];
     float* o = g.db + (long)r * g.D + tid;
@@ -180,6 +205,50 @@ extern "C" int32_t tnt_locally_dense_bwd_f32(const float* x, int32_t ldx, const 
     g.x = x + (long)b0 * ldx; g.ldx = ldx; g.idx = idx; g.goff = goff; g.dpre = dpre + (long)b0 * R * D;
     g.dW = dW; g.db = db; g.B = B - b0 < 64 ? B - b0 : 64; g.R = R; g.D = D; g.accumulate = b0 > 0;
     hipLaunchKernelGGL(locally_dense_bwd_kernel, dim3(R), dim3(256), 0, tnt_stream(stream), g);
+    TNT_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// Split mode: the same two kernels launched over pieces of at most `piece` voxels (tables built once by the host from
+// goff: vgoff[NV+1], vreg[NV], vfirst[NV], rfirst[R+1]); forward = piece partials + a combine launch.
+// partial: NV * 64 * D floats (one 64-row block at a time).
+extern "C" int32_t tnt_locally_dense_fwd_split_f32(const float* x, int32_t ldx, const int32_t* idx, const int32_t* vgoff,
+                                                   const int32_t* vreg, const int32_t* rfirst, int32_t NV,
+                                                   const float* W, const float* bias, float* pre, float* y,
+                                                   float* partial, int32_t B, int32_t R, int32_t D, float slope,
+                                                   void* stream) {
+  if (B <= 0) return TNT_BADARG(13);
+  if (D <= 0 || D > MAXD || D % 16 != 0) return TNT_BADARG(15);
+  if (R <= 0 || NV < R) return TNT_BADARG(7);
+  hipStream_t s = tnt_stream(stream);
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    EncArgs g{};
+    g.x = x + (long)b0 * ldx; g.ldx = ldx; g.idx = idx; g.W = W; g.bias = bias;
+    g.pre = pre + (long)b0 * R * D; g.y = y + (long)b0 * R * D;
+    g.B = B - b0 < 64 ? B - b0 : 64; g.R = R; g.D = D; g.slope = slope;
+    g.vgoff = vgoff; g.vreg = vreg; g.partial = partial;
+    hipLaunchKernelGGL(locally_dense_fwd_kernel, dim3(NV), dim3(256), 0, s, g);
+    TNT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(locally_dense_combine_kernel, dim3(R), dim3(256), 0, s, g, rfirst);
+    TNT_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int32_t tnt_locally_dense_bwd_split_f32(const float* x, int32_t ldx, const int32_t* idx, const int32_t* vgoff,
+                                                   const int32_t* vreg, const int32_t* vfirst, int32_t NV,
+                                                   const float* dpre, float* dW, float* db, int32_t B, int32_t R,
+                                                   int32_t D, void* stream) {
+  if (B <= 0) return TNT_BADARG(11);
+  if (D <= 0 || D > MAXD || D % 16 != 0) return TNT_BADARG(13);
+  if (R <= 0 || NV < R) return TNT_BADARG(7);
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    EncArgs g{};
+    g.x = x + (long)b0 * ldx; g.ldx = ldx; g.idx = idx; g.dpre = dpre + (long)b0 * R * D;
+    g.dW = dW; g.db = db; g.B = B - b0 < 64 ? B - b0 : 64; g.R = R; g.D = D; g.accumulate = b0 > 0;
+    g.vgoff = vgoff; g.vreg = vreg; g.vfirst = vfirst;
+    hipLaunchKernelGGL(locally_dense_bwd_kernel, dim3(NV), dim3(256), 0, tnt_stream(stream), g);
     TNT_LAUNCH_CHECK();
   }
   return 0;

@@ -67,6 +67,7 @@ def compact_groups(groups):
 
 class NIC(ModelBase):
     H = 256     # dense_inter width, hard-coded at lc_NIC.py:141
+    PIECE = 64  # voxels per encoder workgroup (split mode)
 
     def __init__(self, groups, units, embedding_features, embedding_text, attn_units, vocab_size, max_length,
                  dropout_input, dropout_features, dropout_text, dropout_attn, dropout_lstm, dropout_out, input_reg,
@@ -98,6 +99,21 @@ class NIC(ModelBase):
         self.n_in = int(max(int(g.max()) for g in self.groups if len(g)) + 1)
         self.goff_host = np.concatenate([[0], np.cumsum([len(g) for g in self.groups])]).astype(np.int32)
         self.goff = torch.tensor(self.goff_host, dtype=torch.int32, device=self.device)
+        # pieces of at most PIECE voxels per workgroup of the encoder kernels: one large region (Glasser regions span
+        # 8..400+ voxels) would otherwise set the kernel time (tnt_locally_dense_*_split_f32)
+        vg, vr, vf, rf = [0], [], [], [0]
+        for r in range(self.R):
+            g0, g1 = int(self.goff_host[r]), int(self.goff_host[r + 1])
+            k = g0
+            while True:
+                k2 = min(g1, k + self.PIECE)
+                vg.append(k2); vr.append(r); vf.append(1 if k == g0 else 0)
+                k = k2
+                if k >= g1:
+                    break
+            rf.append(len(vr))
+        ti = lambda a: torch.tensor(a, dtype=torch.int32, device=self.device)
+        self.vgoff, self.vreg, self.vfirst, self.rfirst, self.NV = ti(vg), ti(vr), ti(vf), ti(rf), len(vr)
         self.idx = torch.tensor(np.concatenate(self.groups).astype(np.int32), dtype=torch.int32, device=self.device)
         ls = OrderedDict()
         ks = OrderedDict()
@@ -243,6 +259,7 @@ class NIC(ModelBase):
         self.cap = torch.zeros(B, T, dtype=torch.int32, device=self.device)
         self.tgt = torch.zeros(n, dtype=torch.int32, device=self.device)
         self.enc_pre, self.enc_y = f(B, R, D), f(B, R, D)
+        self.enc_part = f(self.NV, 64, D)                    # piece partials of the split encoder forward
         self.xhat, self.inv_std = f(B * R, D), f(self.S, max(B * R, D))
         self.F = f(B, R, D)
         self.text = f(n, Et)
@@ -308,8 +325,13 @@ class NIC(ModelBase):
             if training and self.r_in > 0:
                 be.dropout(x, self.xd[r0:r1], Bs, self.n_in, self.ldx, 0, self.n_in, 0, self.r_in, sd, S_IN + off, 0, ds)
                 x = self.xd[r0:r1]
-            be.locally_dense_fwd(x, self.ldx, self.idx, self.goff, self.encW[q], self.encB[q], self.enc_pre[r0:r1],
-                                 self.enc_y[r0:r1], Bs, R, D, 0.2)
+            if self.NV > R and hasattr(be, "locally_dense_fwd_split") and getattr(self, "split_encoder", True):
+                be.locally_dense_fwd_split(x, self.ldx, self.idx, self.vgoff, self.vreg, self.rfirst, self.NV, self.encW[q],
+                                           self.encB[q], self.enc_pre[r0:r1], self.enc_y[r0:r1], self.enc_part, Bs, R, D,
+                                           0.2)
+            else:
+                be.locally_dense_fwd(x, self.ldx, self.idx, self.goff, self.encW[q], self.encB[q],
+                                     self.enc_pre[r0:r1], self.enc_y[r0:r1], Bs, R, D, 0.2)
             bn = self.bn_name(q)
             Fq, xh = self.F[r0:r1], self.xhat[r0 * R:r1 * R]
             if self.norm == "batch":
@@ -470,7 +492,11 @@ class NIC(ModelBase):
                                  a.g(f"{bn}/beta"), Bs * R, D, D, self.work)
             be.act_bwd(self.enc_pre[r0:r1], dbn, dbn, Bs * R * D, ACT_LEAKY, 0.2)
             x = (self.xd if self.r_in > 0 else self.x)[r0:r1]
-            be.locally_dense_bwd(x, self.ldx, self.idx, self.goff, dbn, self.encWg[q], self.encBg[q], Bs, R, D)
+            if self.NV > R and hasattr(be, "locally_dense_bwd_split") and getattr(self, "split_encoder", True):
+                be.locally_dense_bwd_split(x, self.ldx, self.idx, self.vgoff, self.vreg, self.vfirst, self.NV, dbn,
+                                           self.encWg[q], self.encBg[q], Bs, R, D)
+            else:
+                be.locally_dense_bwd(x, self.ldx, self.idx, self.goff, dbn, self.encWg[q], self.encBg[q], Bs, R, D)
 
     # ------------------------------------------------------------------ steps
     def _train_graph(self, B, T):

@@ -585,3 +585,42 @@ def test_dense_dw_skinny(be, N, E, Bk, ldx):
     ref = torch.zeros(N, E, device="cuda")
     be.gemm(dev(x), dev(dpre), ref, N, E, Bk, ldx, E, E, transA=True)
     close(dw, ref.cpu().numpy(), rtol=2e-6)
+
+
+@pytest.mark.parametrize("B,N,R,D,piece", [(64, 2000, 36, 32, 64), (5, 300, 7, 16, 8), (150, 900, 9, 32, 50)])
+def test_locally_dense_split_equals_unsplit(be, B, N, R, D, piece):
+    """Split mode (pieces of <= `piece` voxels per workgroup) of the region-wise encoder against the one-workgroup-
+    per-region entry points and the oracle."""
+    rng = np.random.default_rng(12)
+    groups = tiny_groups(N, R, rng)
+    goff = np.concatenate([[0], np.cumsum([len(g) for g in groups])]).astype(np.int32)
+    vg, vr, vf, rf = [0], [], [], [0]
+    for r in range(R):
+        k = int(goff[r])
+        while True:
+            k2 = min(int(goff[r + 1]), k + piece)
+            vg.append(k2); vr.append(r); vf.append(int(k == goff[r])); k = k2
+            if k >= goff[r + 1]:
+                break
+        rf.append(len(vr))
+    NV = len(vr)
+    assert NV > R
+    x = rng.standard_normal((B, N))
+    Ws = [rng.standard_normal((len(g), D)) / np.sqrt(len(g)) for g in groups]
+    bs = [0.1 * rng.standard_normal(D) for _ in groups]
+    ti = lambda a: dev(np.asarray(a), torch.int32)
+    idx, Wc, bc = ti(np.concatenate(groups)), dev(np.concatenate(Ws)), dev(np.stack(bs))
+    f = lambda *s: torch.zeros(*s, dtype=torch.float32, device="cuda")
+    pre, y, part = f(B, R, D), f(B, R, D), f(NV, 64, D)
+    be.locally_dense_fwd_split(dev(x), N, idx, ti(vg), ti(vr), ti(rf), NV, Wc, bc, pre, y, part, B, R, D, 0.2)
+    want_y, want_pre = O.locally_dense_fwd(x, groups, Ws, bs)
+    close(pre, want_pre); close(y, want_y)
+    pre2, y2 = f(B, R, D), f(B, R, D)
+    be.locally_dense_fwd(dev(x), N, idx, ti(goff), Wc, bc, pre2, y2, B, R, D, 0.2)
+    close(pre, pre2.cpu().numpy(), rtol=1e-5)
+    dpre = rng.standard_normal((B, R, D))
+    dW, db, dW2, db2 = f(int(goff[-1]), D), f(R, D), f(int(goff[-1]), D), f(R, D)
+    be.locally_dense_bwd_split(dev(x), N, idx, ti(vg), ti(vr), ti(vf), NV, dev(dpre), dW, db, B, R, D)
+    be.locally_dense_bwd(dev(x), N, idx, ti(goff), dev(dpre), dW2, db2, B, R, D)
+    close(dW, dW2.cpu().numpy(), rtol=1e-5); close(db, db2.cpu().numpy(), rtol=1e-5)
+    close(db, dpre.sum(0))
