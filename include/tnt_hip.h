@@ -52,7 +52,7 @@ int32_t tnt_gemm_f32(const float* A, const float* B, float* C, const float* bias
 /* Plain library GEMM (rocBLAS sgemm, exact f32, atomics disabled => bitwise reproducible), same operand conventions as
  * tnt_gemm_f32 without the epilogue arguments: C = op(A) op(B) (+ C if accumulate).  For the matmuls that carry no
  * fused epilogue (weight / input gradients); the fused ones use tnt_gemm_f32.  The first call creates the process-wide
- * rocBLAS handle and loads its kernels -- make it outside a stream capture. */
+ * rocBLAS handle, and the first call of each shape loads its kernel -- make those outside a stream capture. */
 int32_t tnt_gemm_blas_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K,
                           int32_t lda, int32_t ldb, int32_t ldc, int32_t transA, int32_t transB,
                           int32_t accumulate, void* stream);
@@ -107,16 +107,19 @@ int32_t tnt_batchnorm_bwd_f32(const float* dy, const float* xhat, const float* g
  * list, so that one large region does not set the kernel time (regions span 8..400+ voxels; measured 39 -> ~12 us
  * at 360 regions of 18..240 voxels).  Tables (host-built from goff): vgoff[NV+1] CSR range of each piece, vreg[NV] its
  * region, vfirst[NV] 1 for a region's first piece, rfirst[R+1] first piece of each region.  Forward = piece partials
- * (partial: NV*64*D floats) + a combine launch; results equal the unsplit ones up to f32 summation order. */
+ * (partial: NV*64*D floats) + a combine launch; results equal the unsplit ones up to f32 summation order.
+ * x_voxel_major = 1: x is stored [n_voxels][ldx] (ldx >= B, ldx % 4 == 0): a voxel's batch values are contiguous, the
+ * gather reads whole 256-byte rows and every byte of the betas is fetched once per piece -- the layout to stage at
+ * full-cortex width, where the batch-major gather re-fetches each 128-byte line once per region that shares it. */
 int32_t tnt_locally_dense_fwd_split_f32(const float* x, int32_t ldx, const int32_t* idx, const int32_t* vgoff,
                                         const int32_t* vreg, const int32_t* rfirst, int32_t NV,
                                         const float* W, const float* bias, float* pre, float* y,
                                         float* partial, int32_t B, int32_t R, int32_t D, float slope,
-                                        void* stream);
+                                        int32_t x_voxel_major, void* stream);
 int32_t tnt_locally_dense_bwd_split_f32(const float* x, int32_t ldx, const int32_t* idx, const int32_t* vgoff,
                                         const int32_t* vreg, const int32_t* vfirst, int32_t NV,
                                         const float* dpre, float* dW, float* db, int32_t B, int32_t R,
-                                        int32_t D, void* stream);
+                                        int32_t D, int32_t x_voxel_major, void* stream);
 
 /* ---- weight gradient of the dense voxel encoder at small batch:  dw[N][E] = x^T @ dpre --------------
  * x [Bk][ldx] (the betas, Bk <= 64 rows), dpre [Bk][E] (E % 32 == 0, E <= 512, 16-byte aligned), dw [N][E].
@@ -255,11 +258,12 @@ int32_t tnt_sum2_f32(const float* x0, float* out0, const float* x1, float* out1,
                      void* stream);
 /* Input staging of one device-resident batch in one launch (the generator tuple of
  * data_generator_guse.py:156-171 -> the static buffers of the captured step): x (B,N) -> x_dst (B,ldx);
- * cap (B,T) int32 -> cap_dst; tgt (B,T) int32 ids (nullable) -> tgt_tmajor (T,B); a0, c0 (B,U) -> h0, c0_dst. */
+ * cap (B,T) int32 -> cap_dst; tgt (B,T) int32 ids (nullable) -> tgt_tmajor (T,B); a0, c0 (B,U) -> h0, c0_dst.
+ * xT_dst (nullable): additionally the voxel-major copy xT[N][ldt] (ldt >= B) the region-wise encoder gathers from. */
 int32_t tnt_stage_batch_f32(const float* x, float* x_dst, const int32_t* cap, int32_t* cap_dst,
                             const int32_t* tgt, int32_t* tgt_tmajor, const float* a0, float* h0,
                             const float* c0, float* c0_dst, int32_t B, int32_t T, int32_t N, int32_t ldx,
-                            int32_t U, void* stream);
+                            int32_t U, float* xT_dst, int32_t ldt, void* stream);
 
 /* ---- optimizer: per-variable clipnorm + Adam / SGD over a flat parameter arena --
  * (main.py:97,100-102; lc_NIC.py:389).  The arena is cut by the host into

@@ -13,7 +13,8 @@ rocblas_handle g_handle = nullptr;       // one per process (one process per GPU
 
 int32_t blas_init() {
   if (g_handle) return 0;
-  rocblas_initialize();                  // load the Tensile code objects now, not inside a stream capture
+  // No rocblas_initialize(): preloading every Tensile code object costs ~30 s per process.  The kernels a step needs
+  // are loaded lazily by the first (eager, un-captured) pass that every captured launch sequence is preceded by.
   if (rocblas_create_handle(&g_handle) != rocblas_status_success) { g_handle = nullptr; return -1001; }
   // bitwise run-to-run reproducibility is part of this library's contract: no atomics-based split reductions
   if (rocblas_set_atomics_mode(g_handle, rocblas_atomics_not_allowed) != rocblas_status_success) return -1002;

@@ -26,6 +26,7 @@ struct EncArgs {
   // region's index list -- so that one large region does not set the kernel time (Glasser regions span 8..400+
   // voxels).  vgoff[v..v+1] = CSR range of piece v, vreg[v] = its region, vfirst[v] = 1 for a region's first piece.
   const int* vgoff; const int* vreg; const int* vfirst; float* partial;
+  int x_voxel_major;       // 1: x is [n_voxels][ldx] (a voxel's batch values contiguous), 0: [B][ldx]
 };
 
 // gather Xs[row][k] = x[row][idx[g0 + k0 + k]] for row < 64, k < kc
@@ -34,6 +35,35 @@ struct EncArgs {
 __device__ __forceinline__ void gather_tile(const EncArgs& g, float* Xs, int* Is, int g0, int k0, int kc) {
   for (int k = threadIdx.x; k < kc; k += 256) Is[k] = g.idx[g0 + k0 + k];
   __syncthreads();
+  if (g.x_voxel_major) {
+    // one voxel = 64 consecutive floats: a wave reads whole 256-byte rows; every byte of x is fetched once per piece
+    // (the batch-major gather below touches a different 128-byte line for each of its 4-byte elements)
+    const int total4 = 16 * kc;                          // float4 per tile: kc voxels x 16
+    for (int e0 = threadIdx.x; e0 < total4; e0 += 256 * 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * 256;
+        const int k = e >> 4, r4 = (e & 15) * 4;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < total4) {
+          const float* src = g.x + (long)Is[k] * g.ldx + r4;
+          if (r4 + 3 < g.B) v[u] = *reinterpret_cast<const float4*>(src);
+          else { if (r4 < g.B) v[u].x = src[0]; if (r4 + 1 < g.B) v[u].y = src[1]; if (r4 + 2 < g.B) v[u].z = src[2]; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * 256;
+        if (e < total4) {
+          const int k = e >> 4, r4 = (e & 15) * 4;
+          Xs[(r4 + 0) * XLD + k] = v[u].x; Xs[(r4 + 1) * XLD + k] = v[u].y;
+          Xs[(r4 + 2) * XLD + k] = v[u].z; Xs[(r4 + 3) * XLD + k] = v[u].w;
+        }
+      }
+    }
+    return;
+  }
   const int total = 64 * kc;
   for (int e0 = threadIdx.x; e0 < total; e0 += 256 * 8) {
     float v[8];
@@ -217,17 +247,18 @@ extern "C" int32_t tnt_locally_dense_fwd_split_f32(const float* x, int32_t ldx, 
                                                    const int32_t* vreg, const int32_t* rfirst, int32_t NV,
                                                    const float* W, const float* bias, float* pre, float* y,
                                                    float* partial, int32_t B, int32_t R, int32_t D, float slope,
-                                                   void* stream) {
+                                                   int32_t x_voxel_major, void* stream) {
   if (B <= 0) return TNT_BADARG(13);
+  if (x_voxel_major && (ldx % 4 != 0 || !tnt_aligned16(x))) return TNT_BADARG(2);
   if (D <= 0 || D > MAXD || D % 16 != 0) return TNT_BADARG(15);
   if (R <= 0 || NV < R) return TNT_BADARG(7);
   hipStream_t s = tnt_stream(stream);
   for (int b0 = 0; b0 < B; b0 += 64) {
     EncArgs g{};
-    g.x = x + (long)b0 * ldx; g.ldx = ldx; g.idx = idx; g.W = W; g.bias = bias;
+    g.x = x_voxel_major ? x + b0 : x + (long)b0 * ldx; g.ldx = ldx; g.idx = idx; g.W = W; g.bias = bias;
     g.pre = pre + (long)b0 * R * D; g.y = y + (long)b0 * R * D;
     g.B = B - b0 < 64 ? B - b0 : 64; g.R = R; g.D = D; g.slope = slope;
-    g.vgoff = vgoff; g.vreg = vreg; g.partial = partial;
+    g.vgoff = vgoff; g.vreg = vreg; g.partial = partial; g.x_voxel_major = x_voxel_major;
     hipLaunchKernelGGL(locally_dense_fwd_kernel, dim3(NV), dim3(256), 0, s, g);
     TNT_LAUNCH_CHECK();
     hipLaunchKernelGGL(locally_dense_combine_kernel, dim3(R), dim3(256), 0, s, g, rfirst);
@@ -239,15 +270,16 @@ extern "C" int32_t tnt_locally_dense_fwd_split_f32(const float* x, int32_t ldx, 
 extern "C" int32_t tnt_locally_dense_bwd_split_f32(const float* x, int32_t ldx, const int32_t* idx, const int32_t* vgoff,
                                                    const int32_t* vreg, const int32_t* vfirst, int32_t NV,
                                                    const float* dpre, float* dW, float* db, int32_t B, int32_t R,
-                                                   int32_t D, void* stream) {
+                                                   int32_t D, int32_t x_voxel_major, void* stream) {
   if (B <= 0) return TNT_BADARG(11);
+  if (x_voxel_major && (ldx % 4 != 0 || !tnt_aligned16(x))) return TNT_BADARG(2);
   if (D <= 0 || D > MAXD || D % 16 != 0) return TNT_BADARG(13);
   if (R <= 0 || NV < R) return TNT_BADARG(7);
   for (int b0 = 0; b0 < B; b0 += 64) {
     EncArgs g{};
-    g.x = x + (long)b0 * ldx; g.ldx = ldx; g.idx = idx; g.dpre = dpre + (long)b0 * R * D;
+    g.x = x_voxel_major ? x + b0 : x + (long)b0 * ldx; g.ldx = ldx; g.idx = idx; g.dpre = dpre + (long)b0 * R * D;
     g.dW = dW; g.db = db; g.B = B - b0 < 64 ? B - b0 : 64; g.R = R; g.D = D; g.accumulate = b0 > 0;
-    g.vgoff = vgoff; g.vreg = vreg; g.vfirst = vfirst;
+    g.vgoff = vgoff; g.vreg = vreg; g.vfirst = vfirst; g.x_voxel_major = x_voxel_major;
     hipLaunchKernelGGL(locally_dense_bwd_kernel, dim3(NV), dim3(256), 0, tnt_stream(stream), g);
     TNT_LAUNCH_CHECK();
   }

@@ -293,9 +293,29 @@ struct StageArgs {
   const float* x; float* xd; const int* cap; int* capd; const int* tgt; int* tgtd;
   const float* a0; float* h0; const float* c0; float* c0d;
   int B, T, N, ldx, U;
+  float* xT; int ldt; int ncopy;      // optional voxel-major copy xT[N][ldt] (blocks >= ncopy transpose 64x64 tiles)
 };
 __global__ __launch_bounds__(256) void stage_batch_kernel(StageArgs a) {
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x, gsz = (long)gridDim.x * 256;
+  if ((int)blockIdx.x >= a.ncopy) {
+    // voxel-major copy for the region-wise encoder's gather: tile = 64 voxels x 64 batch rows through LDS
+    __shared__ float tile[64][65];
+    const int ntc = (a.N + 63) / 64, ntr = (a.B + 63) / 64;
+    for (int t = blockIdx.x - a.ncopy; t < ntc * ntr; t += gridDim.x - a.ncopy) {
+      const int c0 = (t % ntc) * 64, r0 = (t / ntc) * 64;
+      __syncthreads();
+      for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        tile[r][c] = (r0 + r < a.B && c0 + c < a.N) ? a.x[(long)(r0 + r) * a.N + c0 + c] : 0.f;
+      }
+      __syncthreads();
+      for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int c = e >> 6, r = e & 63;
+        if (c0 + c < a.N && r0 + r < a.ldt) a.xT[(long)(c0 + c) * a.ldt + r0 + r] = tile[r][c];
+      }
+    }
+    return;
+  }
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x, gsz = (long)a.ncopy * 256;
   if (a.N % 4 == 0 && a.ldx % 4 == 0) {
     const int n4 = a.N / 4;
     for (long e = gid; e < (long)a.B * n4; e += gsz) {
@@ -657,12 +677,16 @@ extern "C" int32_t tnt_sum2_f32(const float* x0, float* out0, const float* x1, f
 extern "C" int32_t tnt_stage_batch_f32(const float* x, float* x_dst, const int32_t* cap, int32_t* cap_dst,
                                        const int32_t* tgt, int32_t* tgt_tmajor, const float* a0, float* h0,
                                        const float* c0, float* c0_dst, int32_t B, int32_t T, int32_t N, int32_t ldx,
-                                       int32_t U, void* stream) {
+                                       int32_t U, float* xT_dst, int32_t ldt, void* stream) {
   if (B <= 0 || T <= 0 || N <= 0 || ldx < N || U <= 0) return TNT_BADARG(11);
+  if (xT_dst && ldt < B) return TNT_BADARG(16);
   const bool vec = (N % 4 == 0) && (ldx % 4 == 0);
   if (vec && (!tnt_aligned16(x) || !tnt_aligned16(x_dst))) return TNT_BADARG(1);
-  StageArgs a{x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U};
-  hipLaunchKernelGGL(stage_batch_kernel, dim3(ew_blocks((long)B * N / (vec ? 4 : 1))), dim3(256), 0, tnt_stream(stream), a);
+  StageArgs a{x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U, xT_dst, ldt, 0};
+  a.ncopy = ew_blocks((long)B * N / (vec ? 4 : 1));
+  int nt = 0;
+  if (xT_dst) { nt = ((N + 63) / 64) * ((B + 63) / 64); if (nt > 1024) nt = 1024; }
+  hipLaunchKernelGGL(stage_batch_kernel, dim3(a.ncopy + nt), dim3(256), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
 }

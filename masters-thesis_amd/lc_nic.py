@@ -260,6 +260,9 @@ class NIC(ModelBase):
         self.tgt = torch.zeros(n, dtype=torch.int32, device=self.device)
         self.enc_pre, self.enc_y = f(B, R, D), f(B, R, D)
         self.enc_part = f(self.NV, 64, D)                    # piece partials of the split encoder forward
+        # voxel-major copy of the betas for the encoder's gather (a voxel's batch values contiguous); not with input
+        # dropout, whose mask is defined on the batch-major tensor
+        self.xT = f(self.n_in, (B + 3) // 4 * 4) if (self.r_in == 0 and self.ldx == self.n_in) else None
         self.xhat, self.inv_std = f(B * R, D), f(self.S, max(B * R, D))
         self.F = f(B, R, D)
         self.text = f(n, Et)
@@ -306,6 +309,8 @@ class NIC(ModelBase):
         xs = self._to_dev(x, torch.float32)
         assert xs.shape[0] == B and xs.shape[1] >= self.n_in, f"betas shape {tuple(xs.shape)}"
         self.x[:, :self.n_in].copy_(xs[:, :self.n_in])
+        if self.xT is not None:
+            self.xT[:, :B].copy_(self.x[:, :self.n_in].t())
         self.cap.copy_(cap_t)
         self.Hs[0].copy_(self._to_dev(a0, torch.float32))
         self.Cs[0].copy_(self._to_dev(c0, torch.float32))
@@ -326,9 +331,11 @@ class NIC(ModelBase):
                 be.dropout(x, self.xd[r0:r1], Bs, self.n_in, self.ldx, 0, self.n_in, 0, self.r_in, sd, S_IN + off, 0, ds)
                 x = self.xd[r0:r1]
             if self.NV > R and hasattr(be, "locally_dense_fwd_split") and getattr(self, "split_encoder", True):
-                be.locally_dense_fwd_split(x, self.ldx, self.idx, self.vgoff, self.vreg, self.rfirst, self.NV, self.encW[q],
-                                           self.encB[q], self.enc_pre[r0:r1], self.enc_y[r0:r1], self.enc_part, Bs, R, D,
-                                           0.2)
+                vm = self.xT is not None and getattr(self, "voxel_major", True)
+                be.locally_dense_fwd_split(self.xT[:, r0:r1] if vm else x, self.xT.shape[1] if vm else self.ldx, self.idx,
+                                           self.vgoff, self.vreg, self.rfirst, self.NV, self.encW[q], self.encB[q],
+                                           self.enc_pre[r0:r1], self.enc_y[r0:r1], self.enc_part, Bs, R, D, 0.2,
+                                           voxel_major=vm)
             else:
                 be.locally_dense_fwd(x, self.ldx, self.idx, self.goff, self.encW[q], self.encB[q],
                                      self.enc_pre[r0:r1], self.enc_y[r0:r1], Bs, R, D, 0.2)
@@ -493,8 +500,10 @@ class NIC(ModelBase):
             be.act_bwd(self.enc_pre[r0:r1], dbn, dbn, Bs * R * D, ACT_LEAKY, 0.2)
             x = (self.xd if self.r_in > 0 else self.x)[r0:r1]
             if self.NV > R and hasattr(be, "locally_dense_bwd_split") and getattr(self, "split_encoder", True):
-                be.locally_dense_bwd_split(x, self.ldx, self.idx, self.vgoff, self.vreg, self.vfirst, self.NV, dbn,
-                                           self.encWg[q], self.encBg[q], Bs, R, D)
+                vm = self.xT is not None and getattr(self, "voxel_major", True)
+                be.locally_dense_bwd_split(self.xT[:, r0:r1] if vm else x, self.xT.shape[1] if vm else self.ldx, self.idx,
+                                           self.vgoff, self.vreg, self.vfirst, self.NV, dbn, self.encWg[q], self.encBg[q],
+                                           Bs, R, D, voxel_major=vm)
             else:
                 be.locally_dense_bwd(x, self.ldx, self.idx, self.goff, dbn, self.encWg[q], self.encBg[q], Bs, R, D)
 

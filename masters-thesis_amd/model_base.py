@@ -298,8 +298,13 @@ class ModelBase:
         B, T = cap.shape
         self._build(B, T)
         assert a0.shape == c0.shape == (B, self.U), f"state shape {tuple(a0.shape)} != {(B, self.U)}"
-        self.be.stage_batch(x, self.x, cap, self.cap, target, self.tgt, a0, self.Hs[0], c0, self.Cs[0], B, T, n_cols,
-                            self.ldx, self.U)
+        xT = getattr(self, "xT", None)       # voxel-major copy for the region-wise encoder, written in the same launch
+        if xT is not None:
+            self.be.stage_batch(x, self.x, cap, self.cap, target, self.tgt, a0, self.Hs[0], c0, self.Cs[0], B, T, n_cols,
+                                self.ldx, self.U, xT, xT.shape[1])
+        else:
+            self.be.stage_batch(x, self.x, cap, self.cap, target, self.tgt, a0, self.Hs[0], c0, self.Cs[0], B, T, n_cols,
+                                self.ldx, self.U)
         return B, T
 
     def _stage_target(self, target, B, T):

@@ -142,22 +142,23 @@ class HipBackend:
         _lib.check(self.lib.tnt_gemm_blas_f32(_p(A), _p(B), _p(C), M, N, K, lda, ldb, ldc, int(transA), int(transB),
                                               int(accumulate), self._s()), "tnt_gemm_blas_f32")
 
-    def locally_dense_fwd_split(self, x, ldx, idx, vgoff, vreg, rfirst, NV, W, bias, pre, y, partial, B, R, D, slope=0.2):
+    def locally_dense_fwd_split(self, x, ldx, idx, vgoff, vreg, rfirst, NV, W, bias, pre, y, partial, B, R, D, slope=0.2,
+                                voxel_major=False):
         _lib.check(self.lib.tnt_locally_dense_fwd_split_f32(_p(x), ldx, _p(idx), _p(vgoff), _p(vreg), _p(rfirst), NV, _p(W),
                                                             _p(bias), _p(pre), _p(y), _p(partial), B, R, D, slope,
-                                                            self._s()), "tnt_locally_dense_fwd_split_f32")
+                                                            int(voxel_major), self._s()), "tnt_locally_dense_fwd_split_f32")
 
-    def locally_dense_bwd_split(self, x, ldx, idx, vgoff, vreg, vfirst, NV, dpre, dW, db, B, R, D):
+    def locally_dense_bwd_split(self, x, ldx, idx, vgoff, vreg, vfirst, NV, dpre, dW, db, B, R, D, voxel_major=False):
         _lib.check(self.lib.tnt_locally_dense_bwd_split_f32(_p(x), ldx, _p(idx), _p(vgoff), _p(vreg), _p(vfirst), NV,
-                                                            _p(dpre), _p(dW), _p(db), B, R, D, self._s()),
+                                                            _p(dpre), _p(dW), _p(db), B, R, D, int(voxel_major), self._s()),
                    "tnt_locally_dense_bwd_split_f32")
 
     def sum2(self, x0, out0, x1, out1, n, scale):
         _lib.check(self.lib.tnt_sum2_f32(_p(x0), _p(out0), _p(x1), _p(out1), n, scale, self._s()), "tnt_sum2_f32")
 
-    def stage_batch(self, x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U):
+    def stage_batch(self, x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U, xT_dst=None, ldt=0):
         _lib.check(self.lib.tnt_stage_batch_f32(_p(x), _p(x_dst), _p(cap), _p(cap_dst), _p(tgt), _p(tgt_tmajor), _p(a0),
-                                                _p(h0), _p(c0), _p(c0_dst), B, T, N, ldx, U, self._s()),
+                                                _p(h0), _p(c0), _p(c0_dst), B, T, N, ldx, U, _p(xT_dst), ldt, self._s()),
                    "tnt_stage_batch_f32")
 
     def sample_rows(self, x, out, rows, V, ld, temperature, from_logits, seed, site, step, step_dev=None):

@@ -560,8 +560,10 @@ def test_embedding_fwd_drop_stage_sum2(be):
     xd, capd, tgtd = torch.zeros(B, N, device="cuda"), torch.zeros(B, T, dtype=torch.int32, device="cuda"), \
         torch.zeros(T * B, dtype=torch.int32, device="cuda")
     h0, c0d = torch.zeros(B, U, device="cuda"), torch.zeros(B, U, device="cuda")
-    be.stage_batch(x, xd, cap, capd, tgt, tgtd, a0, h0, c0, c0d, B, T, N, N, U)
+    xT = torch.full((N, 8), 7.0, device="cuda")
+    be.stage_batch(x, xd, cap, capd, tgt, tgtd, a0, h0, c0, c0d, B, T, N, N, U, xT, 8)
     assert torch.equal(xd, x) and torch.equal(capd, cap) and torch.equal(h0, a0) and torch.equal(c0d, c0)
+    assert torch.equal(xT[:, :B], x.t()) and float(xT[:, B:].abs().sum()) == 0.0
     assert torch.equal(tgtd.view(T, B), tgt.t())
     x2 = dev(rng.standard_normal((B, 37))); xd2 = torch.zeros(B, 40, device="cuda")      # ragged width, padded rows
     be.stage_batch(x2, xd2, cap, capd, None, tgtd, a0, h0, c0, c0d, B, T, 37, 40, U)
@@ -624,3 +626,10 @@ def test_locally_dense_split_equals_unsplit(be, B, N, R, D, piece):
     be.locally_dense_bwd(dev(x), N, idx, ti(goff), dev(dpre), dW2, db2, B, R, D)
     close(dW, dW2.cpu().numpy(), rtol=1e-5); close(db, db2.cpu().numpy(), rtol=1e-5)
     close(db, dpre.sum(0))
+    # voxel-major betas (xT[N][ldt]): same results, coalesced gather
+    ldt = (B + 3) // 4 * 4
+    xT = torch.zeros(N, ldt, device="cuda"); xT[:, :B] = dev(x).t()
+    pre3, y3, dW3, db3 = f(B, R, D), f(B, R, D), f(int(goff[-1]), D), f(R, D)
+    be.locally_dense_fwd_split(xT, ldt, idx, ti(vg), ti(vr), ti(rf), NV, Wc, bc, pre3, y3, part, B, R, D, 0.2, voxel_major=True)
+    be.locally_dense_bwd_split(xT, ldt, idx, ti(vg), ti(vr), ti(vf), NV, dev(dpre), dW3, db3, B, R, D, voxel_major=True)
+    assert torch.equal(pre3, pre) and torch.equal(y3, y) and torch.equal(dW3, dW) and torch.equal(db3, db)

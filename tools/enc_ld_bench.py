@@ -58,3 +58,7 @@ for piece in (32, 64, 128):
     tf = timeit(lambda: be.locally_dense_fwd_split(x, N, idx, vgo, vre, rfi, NV, W, bias, pre, y, part, B, R, D, 0.2))
     tb = timeit(lambda: be.locally_dense_bwd_split(x, N, idx, vgo, vre, vfi, NV, dpre, dW, db, B, R, D))
     print(f"split piece={piece:3d} (NV={NV}): fwd {tf:6.2f} us (2 launches)  bwd {tb:6.2f} us")
+    xT = x.t().contiguous()
+    tf = timeit(lambda: be.locally_dense_fwd_split(xT, B, idx, vgo, vre, rfi, NV, W, bias, pre, y, part, B, R, D, 0.2, voxel_major=True))
+    tb = timeit(lambda: be.locally_dense_bwd_split(xT, B, idx, vgo, vre, vfi, NV, dpre, dW, db, B, R, D, voxel_major=True))
+    print(f"   voxel-major       : fwd {tf:6.2f} us               bwd {tb:6.2f} us")
