@@ -200,14 +200,17 @@ int32_t tnt_lstm_step_fwd_f32(const float* xz, const float* h_prev, const float*
  *   dout = dout_in + dout_t ; masked rows pass (da, dc, dout) through, dz = 0
  *   unmasked rows: dh = da + dout, standard LSTM cell backward -> dz[B][U][4],
  *   dc_out = dc*f, da_pass_out = 0, dout_out = 0.
- * Any of dz_next, da_pass_in, dh_ext, dc_in, dout_in, dout_t, mask_ids may be null. */
+ * Any of dz_next, da_pass_in, dh_ext, dc_in, dout_in, dout_t, mask_ids may be null.
+ * dctx_part (nullable; attention model): [U/16][B][D] partial context gradients of this step,
+ *   dctx_part[ub][b][d] = sum over the 16 units of block ub and the 4 gates of dz[b][u][g] * Wc[d][u][g]
+ *   (Wc = the context rows of the LSTM kernel, [D][U][4], D <= 64); tnt_attention_step_bwd_f32 sums the parts. */
 int32_t tnt_lstm_step_bwd_f32(const float* dz_next, const float* Ur, const float* da_pass_in,
                               const float* dh_ext, const float* dc_in, const float* dout_in,
                               const float* dout_t, const int32_t* mask_ids, int32_t mask_T,
                               int32_t mask_t, const float* gates, const float* c,
                               const float* c_prev, float* dz, float* da_pass_out,
                               float* dc_out, float* dout_out, int32_t B, int32_t U,
-                              void* stream);
+                              const float* Wc, int32_t D, float* dctx_part, void* stream);
 
 /* ---- GRU cell step, keras GRU v2 semantics (reset_after=True): the decoder of ThinkAndTell/att_model.py
  * (att_model.py:84-93,118).  Gate-interleaved layouts [..][U][4] with slots (z, r, h, 0 pad).
@@ -335,7 +338,8 @@ int32_t tnt_attention_step_fwd_f32(const float* h, const float* F, const float* 
  * dvb[B][A+1] += (per-sample partials of dV and dbV), writes dqpre[B][A] and
  * dh[B][U] = dqpre @ W2^T.  If dz != NULL the context gradient is computed in-kernel as
  * dctx_d[b][d] = sum_n dz[b][n] * Wc[d][n] (dz: this step's LSTM dz [B][4U]; Wc: the context
- * rows of the LSTM kernel [D][4U]) and the dctx_d argument is ignored. */
+ * rows of the LSTM kernel [D][4U]) and the dctx_d argument is ignored.  If dctx_part is non-null ([nparts][B][D], written
+ * by tnt_lstm_step_bwd_f32; nparts*D <= 1024) the context gradient is the sum of the parts and dctx_d / dz are ignored. */
 int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* F, const float* P,
                                    const float* W2, const float* v, const float* qpre,
                                    const float* alpha, float* dP, float* dF, float* dvb,
@@ -344,7 +348,7 @@ int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* F, const fl
                                    float rate_in, int32_t in_lwidth, uint64_t seed,
                                    uint32_t site_attn, uint32_t site_in, uint32_t step,
                                    const uint32_t* step_dev, const float* dz, const float* Wc,
-                                   void* stream);
+                                   const float* dctx_part, int32_t nparts, void* stream);
 
 /* attention "coverage" metric (lc_NIC.py:365-367): mean over (T,R) of
  * (1 - sum_b alpha[t][b][r])^2.  alpha is [T][B][R]. */

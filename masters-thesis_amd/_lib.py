@@ -31,7 +31,7 @@ SIGNATURES = {
     "tnt_embedding_fwd_f32": [P, P, P, I32, I32, I32, I32, I32, P],
     "tnt_embedding_bwd_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, P],
     "tnt_lstm_step_fwd_f32": [P, P, P, P, P, P, I32, P, I32, I32, P, P, P, P, P, I32, I32, P, P],
-    "tnt_lstm_step_bwd_f32": [P, P, P, P, P, P, P, P, I32, I32, P, P, P, P, P, P, P, I32, I32, P],
+    "tnt_lstm_step_bwd_f32": [P, P, P, P, P, P, P, P, I32, I32, P, P, P, P, P, P, P, I32, I32, P, I32, P, P],
     "tnt_softmax_cce_f32": [P, P, P, P, P, P, I32, I32, I32, F32, I32, I32, P],
     "tnt_onehot_argmax_f32": [P, P, I32, I32, I32, P],
     "tnt_argmax_rows_f32": [P, P, I32, I32, I32, P],
@@ -60,7 +60,7 @@ SIGNATURES = {
     "tnt_attention_step_fwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, F32,
                                    I32, U64, U32, U32, U32, P, P],
     "tnt_attention_step_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, F32,
-                                   I32, U64, U32, U32, U32, P, P, P, P],
+                                   I32, U64, U32, U32, U32, P, P, P, P, I32, P],
     "tnt_attention_metric_f32": [P, P, P, I32, I32, I32, I64, P],
 }
 

@@ -45,6 +45,7 @@ struct AttArgs {
   float* qpre; float* alpha; float* ctx; float* ctx_d; float* s_out;
   // backward
   const float* dctx_d; const float* dz; const float* Wc; const float* qpre_in; const float* alpha_in;
+  const float* dctx_part; int nparts;     // [nparts][B][D] partial context gradients from tnt_lstm_step_bwd_f32
   float* dP; float* dF; float* dvb;
   float* dqpre; float* dh;
   int B, R, D, A, U, in_lwidth;
@@ -157,7 +158,14 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttArgs g) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
   constexpr int RP = 256 / AP;
-  if (g.dz) {
+  if (g.dctx_part) {
+    if (tid < g.D) {
+      float t = 0.f;
+      for (int p = 0; p < g.nparts; ++p) t += g.dctx_part[((long)p * g.B + b) * g.D + tid];
+      part[tid] = t;
+    }
+    __syncthreads();
+  } else if (g.dz) {
     // fused: dctx_d[b][d] = sum_n dz[b][n] * Wc[d][n]   (the LSTM input-kernel rows of the context)
     const int K4 = 4 * g.U, w = tid >> 6, lane = tid & 63;
     const float4* dzr = reinterpret_cast<const float4*>(g.dz + (long)b * K4);
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttArgs g) {
     float q = 0.f, dc = 0.f;
     if (tid < g.A) { q = g.qpre_in[(long)b * g.A + tid]; q = q > 0.f ? q : q * g.slope; }
     if (tid < g.D) {
-      dc = g.dz ? part[tid] : g.dctx_d[(long)b * g.D + tid];
+      dc = (g.dz || g.dctx_part) ? part[tid] : g.dctx_d[(long)b * g.D + tid];
       if (g.rate_in > 0.f)
         dc = tnt_keep((uint64_t)b * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, g.site_in, step)
                  ? dc * (1.f / (1.f - g.rate_in)) : 0.f;
@@ -473,8 +481,22 @@ __global__ __launch_bounds__(WT) void attention_bwd_wide_kernel(AttArgs g) {
   const int c4 = tid % G4, rl = tid / G4;
   const int A = g.A, D = g.D, R = g.R, U = g.U;
   const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
-  // ---- dctx (fused dz Wc^T, or given), un-dropped
-  if (g.dz) {
+  // ---- dctx (sum of the LSTM backward's per-unit-block partials, or fused dz Wc^T, or given), un-dropped
+  if (g.dctx_part) {
+    // thread (p, d): one partial each, then a fixed-order sum over p through LDS (wred is free here: [WW][64] floats)
+    float* scratch = &wred[0][0];
+    const int np = g.nparts;
+    for (int d = tid; d < D; d += WT) dcs[d] = 0.f;
+    for (int e = tid; e < np * D; e += WT) scratch[e % (WW * 64)] = 0.f;     // (np*D <= 1024 by the launch check)
+    __syncthreads();
+    if (tid < np * D) scratch[tid] = g.dctx_part[((long)(tid / D) * g.B + b) * D + tid % D];
+    __syncthreads();
+    if (tid < D) {
+      float t = 0.f;
+      for (int p = 0; p < np; ++p) t += scratch[p * D + tid];
+      dcs[tid] = t;
+    }
+  } else if (g.dz) {
     const int K4 = 4 * U;
     const float4* dzr = reinterpret_cast<const float4*>(g.dz + (long)b * K4);
     for (int dd = w; dd < D; dd += WW) {
@@ -655,12 +677,13 @@ extern "C" int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* 
                                               int32_t A, int32_t U, float slope, float rate_attn, float rate_in,
                                               int32_t in_lwidth, uint64_t seed, uint32_t site_attn, uint32_t site_in,
                                               uint32_t step, const uint32_t* step_dev, const float* dz, const float* Wc,
-                                              void* stream) {
+                                              const float* dctx_part, int32_t nparts, void* stream) {
   if (int32_t rc = check_dims(B, R, D, A, U)) return rc;
   if (dz != nullptr && (U % 16 != 0 || Wc == nullptr)) return TNT_BADARG(27);
-  if (dz == nullptr && dctx_d == nullptr) return TNT_BADARG(1);
+  if (dz == nullptr && dctx_d == nullptr && dctx_part == nullptr) return TNT_BADARG(1);
+  if (dctx_part != nullptr && (nparts <= 0 || nparts * D > 1024)) return TNT_BADARG(30);
   AttArgs g{};
-  g.dz = dz; g.Wc = Wc;
+  g.dz = dz; g.Wc = Wc; g.dctx_part = dctx_part; g.nparts = nparts;
   g.dctx_d = dctx_d; g.F = F; g.P = P; g.W2 = W2; g.v = v; g.qpre_in = qpre; g.alpha_in = alpha; g.dP = dP; g.dF = dF;
   g.dvb = dvb; g.dqpre = dqpre; g.dh = dh; g.B = B; g.R = R; g.D = D; g.A = A; g.U = U; g.in_lwidth = in_lwidth;
   g.slope = slope; g.rate_attn = rate_attn; g.rate_in = rate_in; g.seed = seed; g.site_attn = site_attn;

@@ -156,6 +156,10 @@ struct LstmBwdArgs {
   const float* dout_in; const float* dout_t; const int* mask_ids; const float* gates; const float* c;
   const float* c_prev; float* dz; float* da_pass_out; float* dc_out; float* dout_out;
   int mask_T, mask_t, B, U;
+  // optional (attention model): partial context gradient of this workgroup's 16 units,
+  // dctx_part[ub][b][d] = sum_{u in block ub, g} dz[b][u][g] * Wc[d][u][g];  the attention backward sums the U/16 parts
+  // instead of running the whole dz @ Wc^T product per sample on its own critical path.
+  const float* Wc; float* dctx_part; int D;
 };
 
 // ---- shared pieces of the two backward variants
@@ -182,7 +186,43 @@ __device__ __forceinline__ BwdEpi bwd_prefetch(const LstmBwdArgs& a, int tid, in
   }
   return p;
 }
-__device__ __forceinline__ void bwd_epilogue(const LstmBwdArgs& a, const BwdEpi& p, float da) {
+constexpr int CXLD = 68;      // row stride of the dz / Wc tiles of the context-gradient epilogue (68 % 32 == 4)
+
+// context-gradient partial of one workgroup (see LstmBwdArgs): dzs[16][CXLD] holds this step's dz tile (16 rows x 64
+// gate columns), wcs[D][CXLD] the matching 64 columns of Wc.  All 512 threads; D <= 64.
+__device__ __forceinline__ void bwd_ctx_partial(const LstmBwdArgs& a, const float* dzs, const float* wcs, int ub, int rb) {
+  for (int o = threadIdx.x; o < 16 * a.D; o += 512) {
+    const int row = o / a.D, d = o % a.D;
+    const float4* zr = reinterpret_cast<const float4*>(dzs + row * CXLD);
+    const float4* wr = reinterpret_cast<const float4*>(wcs + d * CXLD);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float4 z = zr[j], w = wr[j];
+      acc += z.x * w.x + z.y * w.y + z.z * w.z + z.w * w.w;
+    }
+    const int b = rb * 16 + row;
+    if (b < a.B) a.dctx_part[((long)ub * a.B + b) * a.D + d] = acc;
+  }
+}
+// the 64 Wc columns of unit block ub, D rows: D*16 float4, <= 2 per thread, fetched at kernel start
+__device__ __forceinline__ void bwd_ctx_prefetch(const LstmBwdArgs& a, int ub, float4 wq[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = threadIdx.x + i * 512;
+    wq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.dctx_part && f < a.D * 16) wq[i] = *reinterpret_cast<const float4*>(a.Wc + ((long)(f >> 4) * a.U + ub * 16) * 4 + (f & 15) * 4);
+  }
+}
+__device__ __forceinline__ void bwd_ctx_stage(const LstmBwdArgs& a, float* wcs, const float4 wq[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = threadIdx.x + i * 512;
+    if (f < a.D * 16) *reinterpret_cast<float4*>(wcs + (f >> 4) * CXLD + (f & 15) * 4) = wq[i];
+  }
+}
+
+__device__ __forceinline__ void bwd_epilogue(const LstmBwdArgs& a, const BwdEpi& p, float da, float* dzs = nullptr) {
   if (!p.eok) return;
   const bool m = p.mid != 0;
   float4 dz4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -200,6 +240,7 @@ __device__ __forceinline__ void bwd_epilogue(const LstmBwdArgs& a, const BwdEpi&
     dc_o = dc * gf; da_o = 0.f; dout_o = 0.f;
   }
   *reinterpret_cast<float4*>(a.dz + p.e * 4) = dz4;
+  if (dzs) *reinterpret_cast<float4*>(dzs + p.erow * CXLD + p.ecol * 4) = dz4;
   if (a.dc_out) a.dc_out[p.e] = dc_o;
   if (a.da_pass_out) a.da_pass_out[p.e] = da_o;
   if (a.dout_out) a.dout_out[p.e] = dout_o;
@@ -208,12 +249,15 @@ __device__ __forceinline__ void bwd_epilogue(const LstmBwdArgs& a, const BwdEpi&
 // general variant: operands straight to registers (any U % 16 == 0; also the no-matmul first step)
 __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdArgs a) {
   __shared__ float red[NW][16][17];
+  __shared__ __attribute__((aligned(16))) float cx[(16 + 64) * CXLD];      // dz tile + Wc tile of the context epilogue
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
   const int ub = blockIdx.x, rb = blockIdx.y;
   const int B = a.B, K = 4 * a.U;
   floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
   const BwdEpi ep = bwd_prefetch(a, tid, rb, ub);
+  float4 wq[2];
+  bwd_ctx_prefetch(a, ub, wq);
   if (a.dz_next) {
     const int arow = rb * 16 + lr, ucol = ub * 16 + lr;
     const int nchunk = K / 64;   // U % 16 == 0  =>  4U % 64 == 0
@@ -245,11 +289,20 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdArgs a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[w][kq * 4 + r][lr] = acc[r];
   __syncthreads();
+  if (a.dctx_part) {
+    bwd_ctx_stage(a, cx + 16 * CXLD, wq);
+    for (int e = tid; e < 16 * CXLD; e += 512) cx[e] = 0.f;          // rows past B stay zero
+    __syncthreads();
+  }
   if (ep.eok) {
     float da = ep.da0;
 #pragma unroll
     for (int k = 0; k < NW; ++k) da += red[k][ep.erow][ep.ecol];
-    bwd_epilogue(a, ep, da);
+    bwd_epilogue(a, ep, da, a.dctx_part ? cx : nullptr);
+  }
+  if (a.dctx_part) {
+    __syncthreads();
+    bwd_ctx_partial(a, cx, cx + 16 * CXLD, ub, rb);
   }
 }
 
@@ -271,6 +324,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_lds_kernel(LstmBwdArgs a) {
   const int nchunk = K / KC;
   floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
   const BwdEpi ep = bwd_prefetch(a, tid, rb, ub);
+  float4 wq[2];
+  bwd_ctx_prefetch(a, ub, wq);
   constexpr int NLD = 16 * KC / 4 / 512;     // float4 per thread per operand per chunk
   float4 rz[NLD], ru[NLD];
   auto gload = [&](int c) {
@@ -316,11 +371,22 @@ __global__ __launch_bounds__(512) void lstm_bwd_lds_kernel(LstmBwdArgs a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[w][kq * 4 + r][lr] = acc[r];
   __syncthreads();
+  // the operand staging area is free now: reuse its head for the context-gradient tiles
+  float* cx = smem;
+  if (a.dctx_part) {
+    for (int e = tid; e < 16 * CXLD; e += 512) cx[e] = 0.f;
+    bwd_ctx_stage(a, cx + 16 * CXLD, wq);
+    __syncthreads();
+  }
   if (ep.eok) {
     float da = ep.da0;
 #pragma unroll
     for (int k = 0; k < NW; ++k) da += red[k][ep.erow][ep.ecol];
-    bwd_epilogue(a, ep, da);
+    bwd_epilogue(a, ep, da, a.dctx_part ? cx : nullptr);
+  }
+  if (a.dctx_part) {
+    __syncthreads();
+    bwd_ctx_partial(a, cx, cx + 16 * CXLD, ub, rb);
   }
 }
 
@@ -348,15 +414,17 @@ extern "C" int32_t tnt_lstm_step_bwd_f32(const float* dz_next, const float* Ur, 
                                          const float* dout_t, const int32_t* mask_ids, int32_t mask_T, int32_t mask_t,
                                          const float* gates, const float* c, const float* c_prev, float* dz,
                                          float* da_pass_out, float* dc_out, float* dout_out, int32_t B, int32_t U,
-                                         void* stream) {
+                                         const float* Wc, int32_t D, float* dctx_part, void* stream) {
   if (U <= 0 || U % 16 != 0) return TNT_BADARG(19);
   if (B <= 0) return TNT_BADARG(18);
   if (dz == dz_next) return TNT_BADARG(14);
+  if (dctx_part && (Wc == nullptr || D <= 0 || D > 64 || !tnt_aligned16(Wc))) return TNT_BADARG(20);
   LstmBwdArgs a;
   a.dz_next = dz_next; a.Ur = Ur; a.da_pass_in = da_pass_in; a.dh_ext = dh_ext; a.dc_in = dc_in; a.dout_in = dout_in;
   a.dout_t = dout_t; a.mask_ids = mask_ids; a.gates = gates; a.c = c; a.c_prev = c_prev; a.dz = dz;
   a.da_pass_out = da_pass_out; a.dc_out = dc_out; a.dout_out = dout_out;
   a.mask_T = mask_T; a.mask_t = mask_t; a.B = B; a.U = U;
+  a.Wc = Wc; a.dctx_part = dctx_part; a.D = dctx_part ? D : 0;
   if (dz_next != nullptr && (4 * U) % KC == 0) {
     const size_t smem = (size_t)(32 * KLD + NW * 16 * 17) * sizeof(float);
     static bool attr_set = false;

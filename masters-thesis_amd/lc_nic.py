@@ -260,6 +260,7 @@ class NIC(ModelBase):
         self.tgt = torch.zeros(n, dtype=torch.int32, device=self.device)
         self.enc_pre, self.enc_y = f(B, R, D), f(B, R, D)
         self.enc_part = f(self.NV, 64, D)                    # piece partials of the split encoder forward
+        self.dctx_part = f(U // 16, B, D)                    # per-unit-block context-gradient partials of a BPTT step
         # voxel-major copy of the betas for the encoder's gather (a voxel's batch values contiguous); not with input
         # dropout, whose mask is defined on the batch-major tensor
         self.xT = f(self.n_in, (B + 3) // 4 * 4) if (self.r_in == 0 and self.ldx == self.n_in) else None
@@ -447,15 +448,24 @@ class NIC(ModelBase):
         W2, v = a.p("attention/W2/kernel"), a.p("attention/V/kernel")
         for i in range(T - 1, -1, -1):
             last = i == T - 1
+            # dctx_i = dZ_i @ Wc^T: every LSTM-backward workgroup leaves the partial of its 16 units, the attention
+            # backward sums the U/16 parts (instead of running the whole product per sample on its own critical path)
+            parts = (U // 16) * D <= 1024 and getattr(self, "ctx_parts", True)
             be.lstm_step_bwd(None if last else self.dZ[(i + 1) * B:(i + 2) * B], Ur, None,
                              None if last else self.dh_att, None if last else self.dc, None,
                              self.dHs[i * B:(i + 1) * B], None, 0, 0, self.gates[i], self.Cs[i + 1], self.Cs[i],
-                             self.dZ[i * B:(i + 1) * B], None, self.dc, None, B, U)
-            # dctx = dZ_i @ Wc^T is computed inside the attention backward kernel
-            be.attention_step_bwd(None, self.F, self.P, W2, v, self.qpre[i], self.alpha[i], self.dP, self.dF,
-                                  self.dvb, self.dqpre[i], self.dh_att, B, R, D, A, U, 0.2, self.r_attn, self.r_lstm,
-                                  D + Et, sd, S_ATTN + i, S_LSTM_IN + i, 0, ds, dz=self.dZ[i * B:(i + 1) * B],
-                                  Wc=Wl[:D])
+                             self.dZ[i * B:(i + 1) * B], None, self.dc, None, B, U,
+                             Wc=Wl[:D] if parts else None, D=D, dctx_part=self.dctx_part if parts else None)
+            if parts:
+                be.attention_step_bwd(None, self.F, self.P, W2, v, self.qpre[i], self.alpha[i], self.dP, self.dF,
+                                      self.dvb, self.dqpre[i], self.dh_att, B, R, D, A, U, 0.2, self.r_attn, self.r_lstm,
+                                      D + Et, sd, S_ATTN + i, S_LSTM_IN + i, 0, ds, dctx_part=self.dctx_part,
+                                      nparts=U // 16)
+            else:
+                be.attention_step_bwd(None, self.F, self.P, W2, v, self.qpre[i], self.alpha[i], self.dP, self.dF,
+                                      self.dvb, self.dqpre[i], self.dh_att, B, R, D, A, U, 0.2, self.r_attn, self.r_lstm,
+                                      D + Et, sd, S_ATTN + i, S_LSTM_IN + i, 0, ds, dz=self.dZ[i * B:(i + 1) * B],
+                                      Wc=Wl[:D])
         hprev = self.Hs[:T].view(n, U)
         gWl = a.g("lstm/kernel")
         self.gemm_sk(hprev, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True)

@@ -92,11 +92,12 @@ class HipBackend:
                                                   _p(gates), B, U, _p(xz_bias), self._s()), "tnt_lstm_step_fwd_f32")
 
     def lstm_step_bwd(self, dz_next, Ur, da_pass_in, dh_ext, dc_in, dout_in, dout_t, mask_ids, mask_T, mask_t,
-                      gates, c, c_prev, dz, da_pass_out, dc_out, dout_out, B, U):
+                      gates, c, c_prev, dz, da_pass_out, dc_out, dout_out, B, U, Wc=None, D=0, dctx_part=None):
         _lib.check(self.lib.tnt_lstm_step_bwd_f32(_p(dz_next), _p(Ur), _p(da_pass_in), _p(dh_ext), _p(dc_in),
                                                   _p(dout_in), _p(dout_t), _p(mask_ids), mask_T, mask_t, _p(gates),
                                                   _p(c), _p(c_prev), _p(dz), _p(da_pass_out), _p(dc_out),
-                                                  _p(dout_out), B, U, self._s()), "tnt_lstm_step_bwd_f32")
+                                                  _p(dout_out), B, U, _p(Wc), D, _p(dctx_part), self._s()),
+                   "tnt_lstm_step_bwd_f32")
 
     def gru_step_fwd(self, xz, h_prev, Uk, br, h, gates, B, U):
         _lib.check(self.lib.tnt_gru_step_fwd_f32(_p(xz), _p(h_prev), _p(Uk), _p(br), _p(h), _p(gates), B, U, self._s()),
@@ -215,11 +216,12 @@ class HipBackend:
 
     def attention_step_bwd(self, dctx_d, F, P, W2, v, qpre, alpha, dP, dF, dvb, dqpre, dh, B, R, D, A, U, slope,
                            rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None, dz=None,
-                           Wc=None):
+                           Wc=None, dctx_part=None, nparts=0):
         _lib.check(self.lib.tnt_attention_step_bwd_f32(_p(dctx_d), _p(F), _p(P), _p(W2), _p(v), _p(qpre), _p(alpha),
                                                        _p(dP), _p(dF), _p(dvb), _p(dqpre), _p(dh), B, R, D, A, U,
                                                        slope, rate_attn, rate_in, in_lwidth, seed, site_attn, site_in,
-                                                       step, _p(step_dev), _p(dz), _p(Wc), self._s()),
+                                                       step, _p(step_dev), _p(dz), _p(Wc), _p(dctx_part), nparts,
+                                                       self._s()),
                    "tnt_attention_step_bwd_f32")
 
     def attention_metric(self, alpha, out, work, T, B, R, tstride=0):

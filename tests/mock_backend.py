@@ -213,7 +213,7 @@ class MockBackend:
         mat(gates, B, 4 * U, 4 * U)[...] = np.stack([i, f, g, o], -1).reshape(B, 4 * U)
 
     def lstm_step_bwd(self, dz_next, Ur, da_pass_in, dh_ext, dc_in, dout_in, dout_t, mask_ids, mask_T, mask_t, gates,
-                      c, c_prev, dz, da_pass_out, dc_out, dout_out, B, U):
+                      c, c_prev, dz, da_pass_out, dc_out, dout_out, B, U, Wc=None, D=0, dctx_part=None):
         g64 = lambda t: mat(t, B, U, U).astype(np.float64) if t is not None else np.zeros((B, U))
         da = g64(da_pass_in) + g64(dh_ext)
         if dz_next is not None:
@@ -232,6 +232,10 @@ class MockBackend:
         dzv = np.stack([dcc * gg * gi * (1 - gi), dcc * g64(c_prev) * gf * (1 - gf), dcc * gi * (1 - gg * gg),
                         dgo * go * (1 - go)], -1)
         mat(dz, B, 4 * U, 4 * U)[...] = np.where(m[..., None], dzv, 0).reshape(B, 4 * U)
+        if dctx_part is not None:           # per-unit-block partials of dz @ Wc^T
+            dzf = mat(dz, B, 4 * U, 4 * U).astype(np.float64).reshape(B, U // 16, 64)
+            wc = flat(Wc)[:D * 4 * U].astype(np.float64).reshape(D, U // 16, 64)
+            flat(dctx_part)[:(U // 16) * B * D] = np.einsum("bpk,dpk->pbd", dzf, wc).reshape(-1)
         if dc_out is not None:
             mat(dc_out, B, U, U)[...] = np.where(m, dcc * gf, dcin)
         if da_pass_out is not None:
@@ -430,13 +434,16 @@ class MockBackend:
 
     def attention_step_bwd(self, dctx_d, F, P, W2, v, qpre, alpha, dP, dF, dvb, dqpre, dh, B, R, D, A, U, slope,
                            rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None, dz=None,
-                           Wc=None):
+                           Wc=None, dctx_part=None, nparts=0):
         if step_dev is not None:
             step = (step + int(step_dev[0])) & 0xFFFFFFFF
         f64 = lambda t, *s: flat(t)[:int(np.prod(s))].reshape(*s).astype(np.float64)
         keep = _keep(np.arange(B * R * A).reshape(B, R, A), rate_attn, seed, site_attn, step) if rate_attn > 0 else None
         kin = _keep(np.arange(B)[:, None] * in_lwidth + np.arange(D)[None, :], rate_in, seed, site_in, step) if rate_in > 0 else None
-        raw = f64(dz, B, 4 * U) @ f64(Wc, D, 4 * U).T if dz is not None else f64(dctx_d, B, D)
+        if dctx_part is not None:
+            raw = f64(dctx_part, nparts, B, D).sum(0)
+        else:
+            raw = f64(dz, B, 4 * U) @ f64(Wc, D, 4 * U).T if dz is not None else f64(dctx_d, B, D)
         dctx = O.dropout_bwd(raw, kin, rate_in)
         Fm, Pm, W2m, vm, qp, al = f64(F, B, R, D), f64(P, B, R, A), f64(W2, U, A), f64(v, A)[:, None], f64(qpre, B, A), f64(alpha, B, R)
         q = O.act_fwd(qp, O.ACT_LEAKY, slope)

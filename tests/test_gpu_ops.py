@@ -633,3 +633,28 @@ def test_locally_dense_split_equals_unsplit(be, B, N, R, D, piece):
     be.locally_dense_fwd_split(xT, ldt, idx, ti(vg), ti(vr), ti(rf), NV, Wc, bc, pre3, y3, part, B, R, D, 0.2, voxel_major=True)
     be.locally_dense_bwd_split(xT, ldt, idx, ti(vg), ti(vr), ti(vf), NV, dev(dpre), dW3, db3, B, R, D, voxel_major=True)
     assert torch.equal(pre3, pre) and torch.equal(y3, y) and torch.equal(dW3, dW) and torch.equal(db3, db)
+
+
+@pytest.mark.parametrize("B,U,D,with_next", [(64, 512, 32, True), (64, 512, 32, False), (5, 48, 16, True), (20, 256, 64, True)])
+def test_lstm_bwd_context_partials(be, B, U, D, with_next):
+    """tnt_lstm_step_bwd_f32 leaves dctx partials per 16-unit block; their sum is dz @ Wc^T (what the attention
+    backward otherwise computes itself), and dz is unchanged by asking for them."""
+    rng = np.random.default_rng(98)
+    f = lambda *s: torch.zeros(*s, dtype=torch.float32, device="cuda")
+    Ur = dev(il(rng.standard_normal((U, 4 * U)) / np.sqrt(U), U))
+    Wc = dev(il(rng.standard_normal((D, 4 * U)) / np.sqrt(D), U))
+    gates = dev(rng.uniform(0.1, 0.9, (B, U, 4)))
+    c, cprev = dev(rng.standard_normal((B, U))), dev(rng.standard_normal((B, U)))
+    dz_next = dev(il(rng.standard_normal((B, 4 * U)) * 0.1, U)) if with_next else None
+    dh_ext, dc_in = dev(rng.standard_normal((B, U))), dev(rng.standard_normal((B, U)))
+    outs = []
+    for want_parts in (False, True):
+        dz, dc_out = f(B, U, 4), f(B, U)
+        parts = f(U // 16, B, D) if want_parts else None
+        be.lstm_step_bwd(dz_next, Ur, None, dh_ext, dc_in, None, None, None, 0, 0, gates, c, cprev, dz, None, dc_out, None,
+                         B, U, Wc=Wc if want_parts else None, D=D, dctx_part=parts)
+        outs.append((dz, dc_out, parts))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    dz, parts = outs[1][0], outs[1][2]
+    want = dz.view(B, 4 * U).double().cpu().numpy() @ Wc.view(D, 4 * U).double().cpu().numpy().T
+    close(parts.sum(0), want)
