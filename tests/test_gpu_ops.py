@@ -658,3 +658,34 @@ def test_lstm_bwd_context_partials(be, B, U, D, with_next):
     dz, parts = outs[1][0], outs[1][2]
     want = dz.view(B, 4 * U).double().cpu().numpy() @ Wc.view(D, 4 * U).double().cpu().numpy().T
     close(parts.sum(0), want)
+
+
+@pytest.mark.parametrize("M,N,K,tA,tB,pad", [
+    (960, 512, 5001, 0, 1, 3), (512, 5001, 960, 1, 0, 3), (1024, 2048, 512, 0, 0, 0), (512, 2048, 1024, 1, 0, 0),
+    (33, 17, 29, 0, 0, 0), (33, 17, 29, 0, 1, 2), (33, 17, 29, 1, 0, 1), (5, 7, 3, 0, 0, 1), (32, 32, 23040, 1, 0, 0),
+])
+def test_gemm_blas(be, M, N, K, tA, tB, pad):
+    """tnt_gemm_blas_f32 (rocBLAS sgemm behind the C ABI, row-major operands with leading dimensions): same operand
+    conventions and results as tnt_gemm_f32 without an epilogue; padding untouched; accumulate; run-to-run bit-exact."""
+    rng = np.random.default_rng(M * 5 + N * 3 + K)
+    A = rng.standard_normal((M, K))
+    Bm = rng.standard_normal((K, N))
+    As = A.T if tA else A
+    Bs = Bm.T if tB else Bm
+    lda, ldb, ldc = As.shape[1] + pad, Bs.shape[1] + pad, N + pad
+    Ad = torch.zeros(As.shape[0], lda, device="cuda"); Ad[:, :As.shape[1]] = dev(As)
+    Bd = torch.zeros(Bs.shape[0], ldb, device="cuda"); Bd[:, :Bs.shape[1]] = dev(Bs)
+    Cd = torch.full((M, ldc), 7.0, device="cuda")
+    be.gemm_blas(Ad, Bd, Cd, M, N, K, lda, ldb, ldc, bool(tA), bool(tB))
+    close(Cd[:, :N], A @ Bm)
+    if pad:
+        assert (Cd[:, N:] == 7.0).all()
+    C2 = torch.full((M, ldc), 7.0, device="cuda")
+    be.gemm_blas(Ad, Bd, C2, M, N, K, lda, ldb, ldc, bool(tA), bool(tB))
+    assert torch.equal(Cd, C2)                                   # atomics off: bitwise reproducible
+    C3 = torch.ones(M, ldc, device="cuda")
+    be.gemm_blas(Ad, Bd, C3, M, N, K, lda, ldb, ldc, bool(tA), bool(tB), accumulate=True)
+    close(C3[:, :N], A @ Bm + 1.0)
+    ref = torch.zeros(M, ldc, device="cuda")
+    be.gemm(Ad, Bd, ref, M, N, K, lda, ldb, ldc, bool(tA), bool(tB))
+    close(Cd[:, :N], ref[:, :N].cpu().numpy(), rtol=2e-5)
