@@ -91,7 +91,60 @@ def fc_nic():
     return _run(orc, ("r_in", "r_feat", "r_text", "r_lstm", "r_out"), (0.1, 0.2, 0.1, 0.2, 0.3), rng, greedy, False)
 
 
-FIXTURES = {"nic_dense_tiny": nic_dense, "lc_nic_tiny": lc_nic, "fc_nic_tiny": fc_nic}
+def ms2_tiny():
+    """ms2_NIC (two subjects, shared decoder): three train steps (its sub-calls always run with training=True, the
+    feature Dropout is applied twice; all rates on) + one test_step."""
+    from oracle.models_ms import MsLcNIC
+    rng = np.random.default_rng(104)
+    S, Bs = 2, 2
+    g = (tiny_groups(N, R, rng), [D] * R)
+    orc = MsLcNIC(g, U, 512, ET, A, V, T, *RATES_LC, 0.01, 0.001, 3e-5, 1e-5, n_subjects=S).init_params(rng)
+    out = {f"w/{k}": v.copy() for k, v in orc.p.items()}
+    out["goff"] = np.concatenate([[0], np.cumsum([len(i) for i in g[0]])]).astype(np.int64)
+    out["gidx"] = np.concatenate(g[0]).astype(np.int64)
+    opt = M.AdamState(orc.p, lr=LR, clipnorm=0.1)
+    for step in range(3):
+        data, tgt = synth_batch(S * Bs, N, T, V, U, rng)
+        out[f"x{step}"], out[f"cap{step}"], out[f"tgt{step}"] = data[0], data[1], tgt
+        res, _, _ = orc.train_step(data, tgt, opt, M.DropCtx(seed=SEED, step=step, training=True))
+        for k, v in res.items():
+            out[f"m{step}/{k}"] = np.float64(v)
+        for k, v in orc.p.items():
+            out[f"p{step}/{k}"] = v.copy()
+    data, tgt = synth_batch(S * Bs, N, T, V, U, rng)
+    out["x_test"], out["cap_test"], out["tgt_test"] = data[0], data[1], tgt
+    res, _ = orc.test_step(data, tgt, M.DropCtx(seed=SEED, step=3, training=True))
+    for k, v in res.items():
+        out[f"mtest/{k}"] = np.float64(v)
+    return out
+
+
+MID = dict(B=8, N=2000, R=36, D=32, A=32, U=64, ET=64, V=501, T=15)       # the mid-size shape of SURVEY 8c(2)
+
+
+def lc_nic_mid():
+    """call_attention at the mid-size shape: eval probabilities, attention maps and the greedy caption ids.
+    Stored as float32 (weights are rounded to float32 BEFORE the oracle runs, so the file is self-consistent)."""
+    m = MID
+    rng = np.random.default_rng(105)
+    g = (tiny_groups(m["N"], m["R"], rng), [m["D"]] * m["R"])
+    orc = M.LcNIC(g, m["U"], 512, m["ET"], m["A"], m["V"], m["T"], 0, 0, 0, 0, 0, 0, 0.01, 0.001, 3e-5, 1e-5).init_params(rng)
+    orc.p = {k: v.astype(np.float32).astype(np.float64) for k, v in orc.p.items()}
+    out = {f"w/{k}": v.astype(np.float32) for k, v in orc.p.items()}
+    out["goff"] = np.concatenate([[0], np.cumsum([len(i) for i in g[0]])]).astype(np.int64)
+    out["gidx"] = np.concatenate(g[0]).astype(np.int64)
+    data, _ = synth_batch(m["B"], m["N"], m["T"], m["V"], m["U"], rng)
+    out["x_eval"], out["cap_eval"] = data[0], data[1]
+    (probs, alpha), _ = orc.forward(data, False)
+    out["probs_eval"], out["alpha_eval"] = probs.astype(np.float32), alpha.astype(np.float32)
+    z = np.zeros((m["B"], m["U"]))
+    words, gp, _, _ = orc.greedy_predict(data[0], z, z, np.ones(m["B"], np.int64), m["T"])
+    out["greedy_words"], out["greedy_probs"] = words, gp.astype(np.float32)
+    return out
+
+
+FIXTURES = {"nic_dense_tiny": nic_dense, "lc_nic_tiny": lc_nic, "fc_nic_tiny": fc_nic, "ms2_tiny": ms2_tiny,
+            "lc_nic_mid": lc_nic_mid}
 
 
 def closed_forms():

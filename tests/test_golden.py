@@ -127,3 +127,56 @@ def test_gpu_fc_nic_golden():
     ids = model.greedy_predict(gold["x_eval"], z, z, np.ones(G.B, np.int64), G.T)
     assert np.array_equal(ids, gold["greedy/0"])
     _check_steps(model, gold, ("r_in", "r_feat", "r_text", "r_lstm", "r_out"), (0.1, 0.2, 0.1, 0.2, 0.3))
+
+
+@pytest.mark.gpu
+def test_gpu_ms2_golden():
+    """ms2_NIC (two subjects) on the HIP path against the frozen vectors: three train steps + one test_step."""
+    from masters_thesis_amd.ms_nic import NIC
+    from masters_thesis_amd.optimizers import Adam
+    gold = load("ms2_tiny")
+    groups = [gold["gidx"][a:b] for a, b in zip(gold["goff"][:-1], gold["goff"][1:])]
+    model = NIC((groups, [G.D] * G.R), G.U, 512, G.ET, G.A, G.V, G.T, *G.RATES_LC, 0.01, 0.001, 3e-5, 1e-5, n_subjects=2,
+                seed=G.SEED)
+    for k, v in _weights(gold, "w/").items():
+        model.set_weight(k, v)
+    model.compile(Adam(learning_rate=G.LR, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    B = gold["x0"].shape[0]
+    z = np.zeros((B, G.U), np.float32)
+    for step in range(3):
+        got = model.train_step(((gold[f"x{step}"], gold[f"cap{step}"], z, z), gold[f"tgt{step}"])).as_floats()
+        for k in got:
+            if k == "lr":
+                continue
+            want = float(gold[f"m{step}/{k}"])
+            assert abs(got[k] - want) <= 1e-4 * abs(want) + 1e-6, (step, k, got[k], want)
+        for k, v in _weights(gold, f"p{step}/").items():
+            if k == "attention/V/bias":
+                continue
+            assert np.abs(model.get_weight(k) - v).max() <= 2e-2 * G.LR + 1e-4 * np.abs(v).max(), (step, k)
+    got = model.test_step(((gold["x_test"], gold["cap_test"], z, z), gold["tgt_test"])).as_floats()
+    for k in got:
+        want = float(gold[f"mtest/{k}"])
+        assert abs(got[k] - want) <= 1e-4 * abs(want) + 1e-6, (k, got[k], want)
+
+
+@pytest.mark.gpu
+def test_gpu_lc_nic_mid_golden():
+    """call_attention at the mid-size shape (B=8, N=2000, R=36, U=64, V=501, T=15): eval probabilities, attention maps
+    and greedy captions against the frozen vectors."""
+    from masters_thesis_amd.lc_nic import NIC
+    gold = load("lc_nic_mid")
+    m = G.MID
+    groups = [gold["gidx"][a:b] for a, b in zip(gold["goff"][:-1], gold["goff"][1:])]
+    model = NIC((groups, [m["D"]] * m["R"]), m["U"], 512, m["ET"], m["A"], m["V"], m["T"], 0, 0, 0, 0, 0, 0, 0.01, 0.001,
+                3e-5, 1e-5, seed=G.SEED)
+    for k, v in _weights(gold, "w/").items():
+        model.set_weight(k, v)
+    z = np.zeros((m["B"], m["U"]), np.float32)
+    p, alpha = model((gold["x_eval"], gold["cap_eval"], z, z))
+    p = p.cpu().numpy()
+    assert np.abs(np.log(p) - np.log(gold["probs_eval"])).max() <= 1e-4 * max(1.0, np.abs(np.log(gold["probs_eval"])).max())
+    assert np.abs(alpha.cpu().numpy() - gold["alpha_eval"]).max() <= 1e-5
+    words, probs, _, _ = model.greedy_predict(gold["x_eval"], z, z, np.ones(m["B"], np.int64), m["T"], m["U"], None)
+    assert np.array_equal(words, gold["greedy_words"])
+    assert np.abs(probs - gold["greedy_probs"]).max() <= 1e-4
