@@ -78,21 +78,32 @@ def cpu_baseline(workload, host_batch, budget_s=20.0):
     opt = M.AdamState(orc.p, lr=1e-4, clipnorm=0.1)
     data = (x, cap, z, z)
     orc.train_step(data, tgt, opt, M.DropCtx(seed=42, step=0, training=True))     # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        orc.train_step(data, tgt, opt, M.DropCtx(seed=42, step=n + 1, training=True))
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 50:
-            break
+
+    def timed(budget):
+        n, t0 = 0, time.perf_counter()
+        while True:
+            orc.train_step(data, tgt, opt, M.DropCtx(seed=42, step=n + 1, training=True))
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget or n >= 50:
+                return n, el
     try:
         import threadpoolctl
         cores = max(i.get("num_threads", 1) for i in threadpoolctl.threadpool_info() if i.get("user_api") == "blas")
     except Exception:
-        cores = os.cpu_count()
-    return {"value": round(n * B * T / el, 1), "unit": "caption-tokens/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n} full train steps of the same workload (numpy float32 oracle, BLAS threads = cores), "
-                      f"{el:.1f} s"}
+        threadpoolctl, cores = None, os.cpu_count()
+    n, el = timed(budget_s * 0.5)
+    rates = {int(cores): (n * B * T / el, n, el)}
+    if threadpoolctl is not None and cores > 8:        # SURVEY 8d also asks for the 8-thread figure
+        with threadpoolctl.threadpool_limits(limits=8, user_api="blas"):
+            n8, el8 = timed(budget_s * 0.5)
+        rates[8] = (n8 * B * T / el8, n8, el8)
+    best = max(rates, key=lambda c: rates[c][0])        # the small GEMMs of this step oversubscribe a 64-thread BLAS
+    v, nb, elb = rates[best]
+    out = {"value": round(v, 1), "unit": "caption-tokens/s", "cores": best, "kind": "port",
+           "sample": f"{nb} full train steps of the same workload (numpy float32 oracle, {best} BLAS threads), {elb:.1f} s",
+           "by_threads": {str(c): round(r[0], 1) for c, r in sorted(rates.items())}}
+    return out
 
 
 def dominant_kernel_roofline(model, workload, steps=20):
