@@ -30,13 +30,16 @@ struct LstmFwdArgs {
   const float* zbias;      // nullable [U][4]: added to xz here, so the input projection can be an epilogue-free GEMM
 };
 
-__global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwdArgs a) {
-  __shared__ float red[NW][4][16][17];
+// NWF waves split the contraction axis; each takes chunks of CK = 4*SS columns (SS MFMA k-steps of 4 per chunk)
+template <int NWF, int SS>
+__global__ __launch_bounds__(64 * NWF) void lstm_fwd_kernel(LstmFwdArgs a) {
+  constexpr int CK = 4 * SS;
+  __shared__ float red[NWF][4][16][17];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
   const int ub = blockIdx.x, rb = blockIdx.y;
   const int U = a.U, B = a.B;
-  const int nchunk = (U + 63) / 64;       // 64-wide chunks of the recurrent contraction, one per wave at U = 512
+  const int nchunk = (U + CK - 1) / CK;       // 64-wide chunks of the recurrent contraction, one per wave at U = 512
   const int arow = rb * 16 + lr;          // batch row this lane feeds as the A operand
   const int ucol = ub * 16 + lr;          // hidden unit this lane feeds as the B operand
   floatx4 acc[4];
@@ -75,34 +78,34 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwdArgs a) {
     cav = (ok && arow < B) ? a.ctx[(long)arow * a.D + kd] : 0.f;
     cbv = ld4g(a.Wc + ((long)min(kd, a.D - 1) * U + ucol) * 4, ok);
   }
-  for (int ci = w; ci < nchunk; ci += NW) {
-    const int kbase = ci * 64 + kq * 16;
-    float av[16];
-    float4 bv[16];
-    if (ci * 64 + 64 <= U) {
+  for (int ci = w; ci < nchunk; ci += NWF) {
+    const int kbase = ci * CK + kq * SS;
+    float av[SS];
+    float4 bv[SS];
+    if (ci * CK + CK <= U) {
       // whole chunk inside the recurrent part: k = ci*64 + 16*(s>>2) + 4*kq + (s&3), so that one
       // load instruction reads 64 contiguous bytes per row (4 lanes x 16 B) instead of 16-B pieces
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 t = ld4g(a.h_prev + (long)arow * U + ci * 64 + j * 16 + kq * 4, arow < B);
+      for (int j = 0; j < SS / 4; ++j) {
+        const float4 t = ld4g(a.h_prev + (long)arow * U + ci * CK + j * 16 + kq * 4, arow < B);
         av[4 * j + 0] = t.x; av[4 * j + 1] = t.y; av[4 * j + 2] = t.z; av[4 * j + 3] = t.w;
       }
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
-        bv[s] = ld4g(a.Ur + ((long)(ci * 64 + (s >> 2) * 16 + kq * 4 + (s & 3)) * U + ucol) * 4, true);
+      for (int s = 0; s < SS; ++s)
+        bv[s] = ld4g(a.Ur + ((long)(ci * CK + (s >> 2) * 16 + kq * 4 + (s & 3)) * U + ucol) * 4, true);
     } else {
       // last, partial chunk (U % 64 != 0; U % 16 == 0, so a 16-run never straddles U): lanes past U feed zeros
       const bool kok = kbase < U;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < SS / 4; ++j) {
         const float4 t = ld4g(a.h_prev + (long)arow * U + kbase + 4 * j, kok && arow < B);
         av[4 * j + 0] = t.x; av[4 * j + 1] = t.y; av[4 * j + 2] = t.z; av[4 * j + 3] = t.w;
       }
 #pragma unroll
-      for (int s = 0; s < 16; ++s) bv[s] = ld4g(a.Ur + ((long)(kbase + s) * U + ucol) * 4, kok);
+      for (int s = 0; s < SS; ++s) bv[s] = ld4g(a.Ur + ((long)(kbase + s) * U + ucol) * 4, kok);
     }
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s < SS; ++s) {
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].x, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].y, acc[1], 0, 0, 0);
       acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].z, acc[2], 0, 0, 0);
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwdArgs a) {
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cav, cbv.y, acc[1], 0, 0, 0);
       acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(cav, cbv.z, acc[2], 0, 0, 0);
       acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(cav, cbv.w, acc[3], 0, 0, 0);
-      st += NW;
+      st += NWF;
       if (st * 4 >= a.D) break;
       const int kd = st * 4 + kq;                      // D > 32: further k-steps of this wave
       const bool ok = kd < a.D;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwdArgs a) {
     for (int g = 0; g < 4; ++g) {
       float s = 0.f;
 #pragma unroll
-      for (int k = 0; k < NW; ++k) s += red[k][g][row][col];
+      for (int k = 0; k < NWF; ++k) s += red[k][g][row][col];
       z[g] += s;
     }
     const float gi = tnt_sigmoid_fast(z[0]), gf = tnt_sigmoid_fast(z[1]), gg = tnt_tanh(z[2]), go = tnt_sigmoid_fast(z[3]);
@@ -191,7 +194,7 @@ constexpr int CXLD = 68;      // row stride of the dz / Wc tiles of the context-
 // context-gradient partial of one workgroup (see LstmBwdArgs): dzs[16][CXLD] holds this step's dz tile (16 rows x 64
 // gate columns), wcs[D][CXLD] the matching 64 columns of Wc.  All 512 threads; D <= 64.
 __device__ __forceinline__ void bwd_ctx_partial(const LstmBwdArgs& a, const float* dzs, const float* wcs, int ub, int rb) {
-  for (int o = threadIdx.x; o < 16 * a.D; o += 512) {
+  for (int o = threadIdx.x; o < 16 * a.D; o += blockDim.x) {
     const int row = o / a.D, d = o % a.D;
     const float4* zr = reinterpret_cast<const float4*>(dzs + row * CXLD);
     const float4* wr = reinterpret_cast<const float4*>(wcs + d * CXLD);
@@ -209,7 +212,7 @@ __device__ __forceinline__ void bwd_ctx_partial(const LstmBwdArgs& a, const floa
 __device__ __forceinline__ void bwd_ctx_prefetch(const LstmBwdArgs& a, int ub, float4 wq[2]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int f = threadIdx.x + i * 512;
+    const int f = threadIdx.x + i * blockDim.x;
     wq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.dctx_part && f < a.D * 16) wq[i] = *reinterpret_cast<const float4*>(a.Wc + ((long)(f >> 4) * a.U + ub * 16) * 4 + (f & 15) * 4);
   }
@@ -217,7 +220,7 @@ __device__ __forceinline__ void bwd_ctx_prefetch(const LstmBwdArgs& a, int ub, f
 __device__ __forceinline__ void bwd_ctx_stage(const LstmBwdArgs& a, float* wcs, const float4 wq[2]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int f = threadIdx.x + i * 512;
+    const int f = threadIdx.x + i * blockDim.x;
     if (f < a.D * 16) *reinterpret_cast<float4*>(wcs + (f >> 4) * CXLD + (f & 15) * 4) = wq[i];
   }
 }
@@ -312,7 +315,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdArgs a) {
 // 1024 k at a time, and the waves read their MFMA operands back with conflict-free ds_read_b128
 // (row stride KC+8 floats).  The loads of chunk i+1 are in flight during the MFMAs of chunk i.
 constexpr int KC = 1024, KLD = KC + 8;
-__global__ __launch_bounds__(512) void lstm_bwd_lds_kernel(LstmBwdArgs a) {
+template <int NWB>
+__global__ __launch_bounds__(64 * NWB) void lstm_bwd_lds_kernel(LstmBwdArgs a) {
+  constexpr int NT = 64 * NWB;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Zs = smem;                       // [16][KLD]  dz_next rows of this row block
   float* Us = smem + 16 * KLD;            // [16][KLD]  Ur rows of this unit block
@@ -326,12 +331,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_lds_kernel(LstmBwdArgs a) {
   const BwdEpi ep = bwd_prefetch(a, tid, rb, ub);
   float4 wq[2];
   bwd_ctx_prefetch(a, ub, wq);
-  constexpr int NLD = 16 * KC / 4 / 512;     // float4 per thread per operand per chunk
+  constexpr int NLD = 16 * KC / 4 / NT;     // float4 per thread per operand per chunk
   float4 rz[NLD], ru[NLD];
   auto gload = [&](int c) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int f = tid + i * 512;                 // 16 rows x KC/4 float4
+      const int f = tid + i * NT;                  // 16 rows x KC/4 float4
       const int row = f / (KC / 4), c4 = (f % (KC / 4)) * 4;
       rz[i] = ld4g(a.dz_next + (long)(rb * 16 + row) * K + c * KC + c4, rb * 16 + row < B);
       ru[i] = ld4g(a.Ur + (long)(ub * 16 + row) * K + c * KC + c4, true);
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_lds_kernel(LstmBwdArgs a) {
   auto sstore = [&]() {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int f = tid + i * 512;
+      const int f = tid + i * NT;
       const int row = f / (KC / 4), c4 = (f % (KC / 4)) * 4;
       *reinterpret_cast<float4*>(&Zs[row * KLD + c4]) = rz[i];
       *reinterpret_cast<float4*>(&Us[row * KLD + c4]) = ru[i];
@@ -351,10 +356,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_lds_kernel(LstmBwdArgs a) {
   __syncthreads();
   for (int c = 0; c < nchunk; ++c) {
     if (c + 1 < nchunk) gload(c + 1);
-    const float* zr = Zs + lr * KLD + w * (KC / NW) + 4 * kq;
-    const float* ur = Us + lr * KLD + w * (KC / NW) + 4 * kq;
+    const float* zr = Zs + lr * KLD + w * (KC / NWB) + 4 * kq;
+    const float* ur = Us + lr * KLD + w * (KC / NWB) + 4 * kq;
 #pragma unroll
-    for (int j = 0; j < KC / NW / 16; ++j) {
+    for (int j = 0; j < KC / NWB / 16; ++j) {
       const float4 x = *reinterpret_cast<const float4*>(zr + 16 * j);
       const float4 y = *reinterpret_cast<const float4*>(ur + 16 * j);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, y.x, acc, 0, 0, 0);
@@ -374,14 +379,14 @@ __global__ __launch_bounds__(512) void lstm_bwd_lds_kernel(LstmBwdArgs a) {
   // the operand staging area is free now: reuse its head for the context-gradient tiles
   float* cx = smem;
   if (a.dctx_part) {
-    for (int e = tid; e < 16 * CXLD; e += 512) cx[e] = 0.f;
+    for (int e = tid; e < 16 * CXLD; e += NT) cx[e] = 0.f;
     bwd_ctx_stage(a, cx + 16 * CXLD, wq);
     __syncthreads();
   }
   if (ep.eok) {
     float da = ep.da0;
 #pragma unroll
-    for (int k = 0; k < NW; ++k) da += red[k][ep.erow][ep.ecol];
+    for (int k = 0; k < NWB; ++k) da += red[k][ep.erow][ep.ecol];
     bwd_epilogue(a, ep, da, a.dctx_part ? cx : nullptr);
   }
   if (a.dctx_part) {
@@ -404,7 +409,12 @@ extern "C" int32_t tnt_lstm_step_fwd_f32(const float* xz, const float* h_prev, c
   a.xz = xz; a.h_prev = h_prev; a.c_prev = c_prev; a.Ur = Ur; a.ctx = ctx; a.Wc = Wc; a.mask_ids = mask_ids;
   a.out_prev = out_prev; a.h = h; a.c = c; a.out = out; a.gates = gates;
   a.D = D; a.mask_T = mask_T; a.mask_t = mask_t; a.B = B; a.U = U; a.zbias = xz_bias;
-  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(U / 16, (B + 15) / 16), dim3(512), 0, tnt_stream(stream), a);
+  // 16 waves x 32-column chunks when the contraction has at least 16 such chunks (U >= 512): the per-wave MFMA chain and
+  // load burst halve; measured 7.1 -> 6.3 us per step at U = 512 (0.738 -> 0.727 ms per training step)
+  if (U % 32 == 0 && U / 32 >= 16)
+    hipLaunchKernelGGL((lstm_fwd_kernel<16, 8>), dim3(U / 16, (B + 15) / 16), dim3(1024), 0, tnt_stream(stream), a);
+  else
+    hipLaunchKernelGGL((lstm_fwd_kernel<8, 16>), dim3(U / 16, (B + 15) / 16), dim3(512), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
 }
@@ -426,15 +436,17 @@ extern "C" int32_t tnt_lstm_step_bwd_f32(const float* dz_next, const float* Ur, 
   a.mask_T = mask_T; a.mask_t = mask_t; a.B = B; a.U = U;
   a.Wc = Wc; a.dctx_part = dctx_part; a.D = dctx_part ? D : 0;
   if (dz_next != nullptr && (4 * U) % KC == 0) {
-    const size_t smem = (size_t)(32 * KLD + NW * 16 * 17) * sizeof(float);
+    // 8 waves: a 16-wave variant of this kernel measured no faster (config 2) or slower (config 3, with the context
+    // epilogue) -- unlike the forward kernel
+    const size_t smem = (size_t)(32 * KLD + 8 * 16 * 17) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_lds_kernel),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bwd_lds_kernel<8>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return -(int32_t)e;
       attr_set = true;
     }
-    hipLaunchKernelGGL(lstm_bwd_lds_kernel, dim3(U / 16, (B + 15) / 16), dim3(512), smem, tnt_stream(stream), a);
+    hipLaunchKernelGGL(lstm_bwd_lds_kernel<8>, dim3(U / 16, (B + 15) / 16), dim3(512), smem, tnt_stream(stream), a);
   } else {
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3(U / 16, (B + 15) / 16), dim3(512), 0, tnt_stream(stream), a);
   }
