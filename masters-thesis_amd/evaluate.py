@@ -79,6 +79,34 @@ def ids_to_captions(ids, tokenizer, end_token="<end>", drop=("<start>", "<pad>")
     return caps
 
 
+def simple_eval(model, betas, target, tokenizer=None, temperature=1.0, sample_step=0, end_token="<end>"):
+    """ThinkAndTell/evaluate.py:261-284 (`simple_eval`): one teacher-forced forward of the caption generator, then one
+    categorical draw per position from the logits (tf.random.categorical(logits, 1)); the caption is cut at the first
+    <end>.  The draw runs on the device (tnt_sample_rows_f32, Philox stream (seed, S_SAMPLE, sample_step)).
+    Returns (ids (B, T+1) int64, captions or None)."""
+    import torch
+    from . import ops
+    from .model_base import S_SAMPLE
+    logits = model((betas, None, target), training=False)                 # (B, T+1, V), device tensor
+    Bn, Tn, V = logits.shape
+    flat = logits.reshape(Bn * Tn, V).contiguous()
+    ids = torch.zeros(Bn * Tn, dtype=torch.int32, device=flat.device)
+    ops.backend().sample_rows(flat, ids, Bn * Tn, V, V, temperature, True, model.seed, S_SAMPLE, sample_step)
+    ids = ids.view(Bn, Tn).cpu().numpy().astype(np.int64)
+    caps = None
+    if tokenizer is not None:
+        caps = []
+        for row in ids:
+            words = []
+            for i in row:
+                w = tokenizer.index_word.get(int(i), "<unk>")
+                words.append(w)
+                if w == end_token:
+                    break
+            caps.append(words)
+    return ids, caps
+
+
 def _ngrams(seq, n):
     return Counter(tuple(seq[i:i + n]) for i in range(len(seq) - n + 1))
 

@@ -92,3 +92,21 @@ def test_sam_step_matches_oracle():
             assert abs(got[k] - res[k]) < 5e-5 * max(1, abs(res[k])), (step, k, got[k], res[k])
         for k, v in orc.p.items():
             assert np.allclose(model.get_weight(k), v, rtol=3e-4, atol=5e-6), (step, k)
+
+
+def test_simple_eval_samples_from_the_logits():
+    """evaluate.simple_eval (ThinkAndTell/evaluate.py:261-284): teacher-forced forward + one categorical draw per position."""
+    from masters_thesis_amd.evaluate import simple_eval
+    from oracle import ops as O
+    rng = np.random.default_rng(85)
+    model, orc, (B, N, T, V) = make(rng, False)
+    x, tgt = batch(rng, B, N, T, V)
+    model._stage(x, tgt)
+    for k, v in orc.p.items():
+        model.set_weight(k, v)
+    ids, caps = simple_eval(model, x, tgt, None, temperature=0.9, sample_step=2)
+    logits, _ = orc.forward(x, tgt, False)
+    want, margin = O.sample_rows(logits.reshape(B * (T + 1), V), 0.9, True, model.seed, M.S_SAMPLE, 2)
+    assert caps is None and ids.shape == (B, T + 1)
+    bad = ids.reshape(-1) != want
+    assert np.all(margin[bad] < 1e-5)
