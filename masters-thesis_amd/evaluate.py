@@ -29,7 +29,7 @@ def eval_model(model, data_generator, tokenizer, config, out_path, epoch, add_na
         features, _, a0, c0 = sample[0][:4]
         start_seq = np.repeat([tokenizer.word_index["<start>"]], features.shape[0])
         words, probs, alpha, _ = model.greedy_predict(features, a0, c0, start_seq, config["max_length"], config["units"],
-                                                      tokenizer)
+                                                      tokenizer, return_s=False)     # eval.py never reads `s`
         outs.append(words); raws.append(probs); attns.append(alpha)
     outputs = np.concatenate(outs, axis=0)
     outputs_raw = np.concatenate(raws, axis=0)

@@ -592,7 +592,7 @@ class NIC(ModelBase):
                                    _sample=(float(temperature), int(sample_step)))
 
     def greedy_predict(self, img_input, a0, c0, start_seq, max_len, units=None, tokenizer=None, training=False,
-                       _sample=None):
+                       _sample=None, return_s=True):
         """lc_NIC.greedy_predict -> greedy_predict_attention (lc_NIC.py:507-508,577-638).
         Returns (words (B,max_len,1) int64, probs (B,max_len,V), alpha (max_len,B,R,1), s (max_len,B,R,A))
         as numpy arrays; the whole decode runs on the device with no per-step host sync."""
@@ -602,29 +602,46 @@ class NIC(ModelBase):
         B = start.shape[0]
         self._stage_inputs((img_input, torch.zeros(B, max_len, dtype=torch.int32), a0, c0))
         R, D, A, U, Et, V, H, ldV = self.R, self.D, self.A, self.U, self.Et, self.V, self.H, self.ldV
-        self._encode(B, False)
         Wl = a.p("lstm/kernel")
-        words = start.clone().view(B, 1)
-        probs = torch.zeros(max_len, B, ldV, dtype=torch.float32, device=self.device)
-        s_all = torch.zeros(max_len, B, R, A, dtype=torch.float32, device=self.device)
-        ids = torch.zeros(max_len, B, dtype=torch.int32, device=self.device)
-        for i in range(max_len):
-            text = self.text[i * B:(i + 1) * B]
-            be.embedding_fwd(a.p("emb_text/embeddings"), words, text, B, 1, Et, Et, V)        # :596,632
-            self.gemm_sk(text, Wl[D:], self.XZ[i * B:(i + 1) * B], B, 4 * U, Et, Et, 4 * U, 4 * U, bias=a.p("lstm/bias"))
-            self._decode_step(i, B, False, s_all[i])
-            self.gemm_sk(self.Hs[i + 1], a.p("time_distributed_nonlinear/kernel"), self.inter[:B], B, H, U, U, H, H,
-                    bias=a.p("time_distributed_nonlinear/bias"), act=ACT_LEAKY, slope=0.2)     # :621
-            self.gemm_sk(self.inter[:B], a.p("time_distributed_softmax/kernel"), probs[i], B, V, H, H, ldV, ldV,
-                    bias=a.p("time_distributed_softmax/bias"))                                # :623
-            be.softmax_cce(probs[i], None, probs[i], None, None, None, B, V, ldV, 0.0)
-            if _sample is None:
-                be.argmax_rows(probs[i], ids[i], B, V, ldV)                                    # :627
-            else:
-                be.sample_rows(probs[i], ids[i], B, V, ldV, _sample[0], False, self.seed, S_SAMPLE + i, _sample[1])
-            words = ids[i].view(B, 1)
+        # decode buffers are static per (B, max_len, return_s) so that the whole loop can be one captured hipGraph
+        # (encoder + max_len x {embed, project, attention, LSTM step, head, softmax, argmax}: ~8 launches per token)
+        key = (B, max_len, bool(return_s))
+        bufs = self.__dict__.setdefault("_dec_bufs", {})
+        if key not in bufs:
+            bufs[key] = (torch.zeros(B, 1, dtype=torch.int32, device=self.device),
+                         torch.zeros(max_len, B, ldV, dtype=torch.float32, device=self.device),
+                         torch.zeros(max_len, B, R, A, dtype=torch.float32, device=self.device) if return_s else None,
+                         torch.zeros(max_len, B, dtype=torch.int32, device=self.device))
+        start_buf, probs, s_all, ids = bufs[key]
+        start_buf.copy_(start.view(B, 1))
+
+        def run():
+            self._encode(B, False)
+            words = start_buf
+            for i in range(max_len):
+                text = self.text[i * B:(i + 1) * B]
+                be.embedding_fwd(a.p("emb_text/embeddings"), words, text, B, 1, Et, Et, V)        # :596,632
+                self.gemm_sk(text, Wl[D:], self.XZ[i * B:(i + 1) * B], B, 4 * U, Et, Et, 4 * U, 4 * U,
+                             bias=a.p("lstm/bias"))
+                self._decode_step(i, B, False, s_all[i] if return_s else None)
+                self.gemm_sk(self.Hs[i + 1], a.p("time_distributed_nonlinear/kernel"), self.inter[:B], B, H, U, U, H, H,
+                             bias=a.p("time_distributed_nonlinear/bias"), act=ACT_LEAKY, slope=0.2)     # :621
+                self.gemm_sk(self.inter[:B], a.p("time_distributed_softmax/kernel"), probs[i], B, V, H, H, ldV, ldV,
+                             bias=a.p("time_distributed_softmax/bias"))                                # :623
+                be.softmax_cce(probs[i], None, probs[i], None, None, None, B, V, ldV, 0.0)
+                if _sample is None:
+                    be.argmax_rows(probs[i], ids[i], B, V, ldV)                                    # :627
+                else:
+                    be.sample_rows(probs[i], ids[i], B, V, ldV, _sample[0], False, self.seed, S_SAMPLE + i, _sample[1])
+                words = ids[i].view(B, 1)
+        if _sample is None:
+            self._run_captured(("greedy",) + key, run)
+        else:                      # the sampling stream step is a launch argument: not captured
+            run()
         out_words = ids.t().contiguous().cpu().numpy().astype(np.int64)[:, :, None]
         out_probs = probs[:, :, :V].permute(1, 0, 2).contiguous().cpu().numpy()
-        return out_words, out_probs, self.alpha[:max_len].cpu().numpy()[..., None], s_all.cpu().numpy()
+        # s (the dropout-free tanh activations, 44 MB at the BASELINE shape) is part of the reference's return tuple but
+        # only analysis code reads it: return_s=False skips its device-to-host copy (eval_model does)
+        return out_words, out_probs, self.alpha[:max_len].cpu().numpy()[..., None], (s_all.cpu().numpy() if return_s else None)
 
     greedy_predict_attention = greedy_predict

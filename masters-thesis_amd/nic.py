@@ -420,32 +420,43 @@ class NIC(ModelBase):
         cap = torch.zeros(B, 1, dtype=torch.int32, device=self.device)
         self._stage_inputs((img_input, cap, a0, c0))
         N, U, E, V, ldV = self.N, self.U, self.E, self.V, self.ldV
-        self.gemm_sk(self.x, a.p("dense_img/kernel"), self.enc_y, B, E, N, self.ldx, E, E, bias=a.p("dense_img/bias"),
-                     pre=self.enc_pre, act=ACT_LEAKY, slope=0.2)
-        if self.norm == "batch":
-            be.batchnorm_fwd(self.enc_y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.mov_mean, self.mov_var,
-                             self.Xin, self.xhat, self.inv_std, B, E, E, False, BN_EPS, BN_MOMENTUM, self.work)
-        else:
-            be.layernorm_fwd(self.enc_y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.Xin, self.xhat,
-                             self.inv_std, B, E, E, BN_EPS)
-        Wl, bl, Ur = a.p("lstm/kernel"), a.p("lstm/bias"), a.p("lstm/recurrent_kernel")
-        xz, emb = self.XZ[:B], self.Xin[B:2 * B]
-        h = [self.Hs[0], self.Hs[1]]
-        c = [self.Cs[0], self.Cs[1]]
-        self.gemm_sk(self.Xin, Wl, xz, B, 4 * U, E, E, 4 * U, 4 * U, bias=bl)
-        be.lstm_step_fwd(xz, h[0], c[0], Ur, None, None, 0, None, 0, 0, None, h[1], c[1], None, self.gates[0], B, U)
-        cur = 1
-        words = start.clone().view(B, 1)
-        out = self.Out[0]
-        probs_all = torch.zeros(max_len, B, ldV, dtype=torch.float32, device=self.device)
-        for i in range(max_len):
-            be.embedding_fwd(a.p("emb_text/embeddings"), words, emb, B, 1, E, E, V)
-            self.gemm_sk(emb, Wl, xz, B, 4 * U, E, E, 4 * U, 4 * U, bias=bl)
-            be.lstm_step_fwd(xz, h[cur], c[cur], Ur, None, None, 0, words if i > 0 else None, 1, 0, None,
-                             h[1 - cur], c[1 - cur], out, self.gates[0], B, U)
-            cur = 1 - cur
-            self.gemm_sk(out, a.p("time_distributed_softmax/kernel"), probs_all[i], B, V, U, U, ldV, ldV,
-                    bias=a.p("time_distributed_softmax/bias"))
-            be.softmax_cce(probs_all[i], None, probs_all[i], None, None, None, B, V, ldV, 0.0)
-            be.argmax_rows(probs_all[i], words, B, V, ldV)
+        # static decode buffers per (B, max_len): the whole loop is one captured hipGraph
+        key = (B, max_len)
+        bufs = self.__dict__.setdefault("_dec_bufs", {})
+        if key not in bufs:
+            bufs[key] = (torch.zeros(B, 1, dtype=torch.int32, device=self.device),
+                         torch.zeros(B, 1, dtype=torch.int32, device=self.device),
+                         torch.zeros(max_len, B, ldV, dtype=torch.float32, device=self.device))
+        start_buf, words, probs_all = bufs[key]
+        start_buf.copy_(start.view(B, 1))
+
+        def run():
+            self.gemm_sk(self.x, a.p("dense_img/kernel"), self.enc_y, B, E, N, self.ldx, E, E, bias=a.p("dense_img/bias"),
+                         pre=self.enc_pre, act=ACT_LEAKY, slope=0.2)
+            if self.norm == "batch":
+                be.batchnorm_fwd(self.enc_y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.mov_mean, self.mov_var,
+                                 self.Xin, self.xhat, self.inv_std, B, E, E, False, BN_EPS, BN_MOMENTUM, self.work)
+            else:
+                be.layernorm_fwd(self.enc_y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.Xin, self.xhat,
+                                 self.inv_std, B, E, E, BN_EPS)
+            Wl, bl, Ur = a.p("lstm/kernel"), a.p("lstm/bias"), a.p("lstm/recurrent_kernel")
+            xz, emb = self.XZ[:B], self.Xin[B:2 * B]
+            h = [self.Hs[0], self.Hs[1]]
+            c = [self.Cs[0], self.Cs[1]]
+            self.gemm_sk(self.Xin, Wl, xz, B, 4 * U, E, E, 4 * U, 4 * U, bias=bl)
+            be.lstm_step_fwd(xz, h[0], c[0], Ur, None, None, 0, None, 0, 0, None, h[1], c[1], None, self.gates[0], B, U)
+            cur = 1
+            out = self.Out[0]
+            for i in range(max_len):
+                tok = start_buf if i == 0 else words
+                be.embedding_fwd(a.p("emb_text/embeddings"), tok, emb, B, 1, E, E, V)
+                self.gemm_sk(emb, Wl, xz, B, 4 * U, E, E, 4 * U, 4 * U, bias=bl)
+                be.lstm_step_fwd(xz, h[cur], c[cur], Ur, None, None, 0, words if i > 0 else None, 1, 0, None,
+                                 h[1 - cur], c[1 - cur], out, self.gates[0], B, U)
+                cur = 1 - cur
+                self.gemm_sk(out, a.p("time_distributed_softmax/kernel"), probs_all[i], B, V, U, U, ldV, ldV,
+                             bias=a.p("time_distributed_softmax/bias"))
+                be.softmax_cce(probs_all[i], None, probs_all[i], None, None, None, B, V, ldV, 0.0)
+                be.argmax_rows(probs_all[i], words, B, V, ldV)
+        self._run_captured(("greedy",) + key, run)
         return probs_all[:, :, :V].cpu().numpy()[:, :, None, :]

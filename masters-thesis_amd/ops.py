@@ -30,7 +30,9 @@ class HipBackend:
 
     @staticmethod
     def _s():
-        return torch.cuda.current_stream().cuda_stream
+        # raw handle of torch's current stream (also the capturing stream inside a hipGraph capture); the Stream-object
+        # route costs ~8 us per launch, which is most of an eager decode step
+        return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
     def bn_nchunk(self, rows):
         return self.lib.tnt_bn_nchunk(rows)
