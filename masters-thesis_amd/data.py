@@ -12,7 +12,6 @@ are assembled in pinned host memory and copied with non_blocking H2D on a side s
 double-buffered, so the copy of batch i+1 overlaps the step on batch i.
 """
 import json
-import re
 from collections import OrderedDict
 
 import numpy as np

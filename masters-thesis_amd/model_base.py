@@ -15,8 +15,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .arena import ParamArena
-from .optimizers import Adam, SGD
+from .optimizers import Adam
 
 # dropout site ids of the Philox stream (shared with oracle/models.py)
 S_IN, S_FEAT, S_TEXT, S_OUT = 1, 2, 3, 5

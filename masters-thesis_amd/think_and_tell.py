@@ -20,7 +20,7 @@ import torch
 
 from .arena import ParamArena
 from .model_base import ModelBase, Metrics, interleave_gates, deinterleave_gates, S_FEAT, S_OUT
-from .ops import ACT_NONE, ACT_RELU, ACT_TANH
+from .ops import ACT_RELU, ACT_TANH
 
 
 def _r4(n):
