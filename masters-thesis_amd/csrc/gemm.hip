@@ -119,6 +119,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // The bias is fetched up front: a load still pending in the epilogue makes the compiler put
+  // s_waitcnt vmcnt(0) in front of every guarded store there, which serialises the stores.
+  const int lrow = lane & 31, lk = lane >> 5;
+  float bcol[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = n0 + wn * WN + tn * 32 + lrow;
+    bcol[tn] = (g.bias != nullptr && g.splitk == 1 && col < g.N) ? g.bias[col] : 0.f;
+  }
+
   LA la; LB lb;
   if (nk > 0) {
     la.load(g.A, g.lda, m0, g.M, kbeg, kend, tid);
@@ -128,7 +138,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
   __syncthreads();
 
-  const int lrow = lane & 31, lk = lane >> 5;
   // per-lane LDS bases: every operand fetch below is base + compile-time offset
   const float* Abase = As + lk * LA::LDS_LD + wm * WM + lrow;
   const float* Bbase = Bs + lk * LB::LDS_LD + wn * WN + lrow;
@@ -160,28 +169,46 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // The mode is workgroup-uniform and chosen outside the element loops, so each mode is a run of stores.
+  const bool plain = g.pre == nullptr && !g.accumulate;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const int col = n0 + wn * WN + tn * 32 + lrow;
       if (col >= g.N) continue;
-      const float bcol = (g.bias != nullptr && g.splitk == 1) ? g.bias[col] : 0.f;
+      const int row0 = m0 + wm * WM + tm * 32 + 4 * lk;
+      if (g.splitk > 1) {
+        float* W = g.work + ((long)z * g.M + row0) * g.N + col;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row >= g.M) continue;
-        float v = acc[tm][tn][r];
-        if (g.splitk > 1) {
-          g.work[((long)z * g.M + row) * g.N + col] = v;
-        } else {
-          v += bcol;
-          const long o = (long)row * g.ldc + col;
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          if (row0 + dr < g.M) W[(long)dr * g.N] = acc[tm][tn][r];
+        }
+      } else if (plain) {
+        float* Cp = g.C + (long)row0 * g.ldc + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          if (row0 + dr < g.M) Cp[(long)dr * g.ldc] = tnt_act(acc[tm][tn][r] + bcol[tn], g.act, g.slope);
+        }
+      } else {
+        const long o0 = (long)row0 * g.ldc + col;
+        float cold[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          cold[r] = (g.accumulate && row0 + dr < g.M) ? g.C[o0 + (long)dr * g.ldc] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          if (row0 + dr >= g.M) continue;
+          const long o = o0 + (long)dr * g.ldc;
+          float v = acc[tm][tn][r] + bcol[tn];
           if (g.pre) g.pre[o] = v;
-          v = tnt_act(v, g.act, g.slope);
-          if (g.accumulate) v += g.C[o];
-          g.C[o] = v;
+          g.C[o] = tnt_act(v, g.act, g.slope) + cold[r];
         }
       }
     }
@@ -201,6 +228,196 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
     if (g.accumulate) v += g.C[o];
     g.C[o] = v;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One-round kernel.  The 64x64 tiles above quantise badly on the vocabulary head: 1185 tiles over 1024 resident
+// workgroup slots = a second, nearly empty round.  Here the workgroup tile is sized so that the whole output is
+// ONE round of at most 256 workgroups (one per CU, 16 waves): 160x128 covers logits[960x5001] in 240 tiles.
+// 16x16x4 FP32 MFMAs so that tile edges only need to be multiples of 16; each wave owns 80x16 (5 MFMA tiles).
+//   A (k-contiguous rows) sits in LDS as [m][k] rows of BK+2 floats: the 16 rows x 2 k-pairs of a 16-lane group
+//   fall on 32 distinct banks and one 8-byte read feeds two MFMAs (k = 8s+2g and 8s+2g+1, g = lane>>4);
+//   B (n-contiguous rows) sits as [k][n] with 2*LD = 16 mod 32, so lanes 0-15 (row k) and 16-31 (row k+2) of a
+//   32-lane group use disjoint banks.  Both operands use the same k permutation, so the sum is the same set
+//   of products in a different order from the 32x32x2 kernel (still one f32 fma chain per element).
+// Measured on the head (tools/probe/gemm1r_probe.hip, profiles/r01_gemm_design_probe.txt): 54.9 us vs 61.4 us.
+template <int BMN, int NT, bool KC>
+struct Tile1r {
+  static constexpr int QPR = BK / 4;
+  static constexpr int NF4 = BMN * BK / 4;
+  static constexpr int NV = (NF4 + NT - 1) / NT;
+  static constexpr int LD = KC ? (BK + 2) : (BMN + ((40 - BMN % 32) % 32));
+  static constexpr int SZ = ((KC ? BMN * LD : BK * LD) + 3) & ~3;
+  float4 r[NV];
+  __device__ __forceinline__ void load(const float* base, int ld, int mn0, int mn_lim, int k0, int k_lim, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * NT;
+      r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (NF4 % NT != 0 && f >= NF4) continue;
+      if (KC) {
+        const int mn = f / QPR, kq = (f % QPR) * 4;
+        const int valid = (mn0 + mn < mn_lim) ? (k_lim - (k0 + kq)) : 0;
+        r[i] = ldg4<true>(base + (long)(mn0 + mn) * ld + k0 + kq, valid);
+      } else {
+        const int kk = f / (BMN / 4), mn4 = (f % (BMN / 4)) * 4;
+        const int valid = (k0 + kk < k_lim) ? (mn_lim - (mn0 + mn4)) : 0;
+        r[i] = ldg4<true>(base + (long)(k0 + kk) * ld + mn0 + mn4, valid);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * NT;
+      if (NF4 % NT != 0 && f >= NF4) continue;
+      if (KC) {
+        const int mn = f / QPR, kq = (f % QPR) * 4;
+        *reinterpret_cast<float2*>(&lds[mn * LD + kq]) = make_float2(r[i].x, r[i].y);
+        *reinterpret_cast<float2*>(&lds[mn * LD + kq + 2]) = make_float2(r[i].z, r[i].w);
+      } else {
+        const int kk = f / (BMN / 4), mn4 = (f % (BMN / 4)) * 4;
+        *reinterpret_cast<float4*>(&lds[kk * LD + mn4]) = r[i];
+      }
+    }
+  }
+  static __device__ __forceinline__ float2 fetch(const float* lds, int mn, int s, int g) {
+    if (KC) return *reinterpret_cast<const float2*>(&lds[mn * LD + 8 * s + 2 * g]);
+    return make_float2(lds[(8 * s + 2 * g) * LD + mn], lds[(8 * s + 2 * g + 1) * LD + mn]);
+  }
+};
+
+template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm1r_kernel(GemmArgs g) {
+  constexpr int NT = 64 * WGM * WGN;
+  using OA = Tile1r<BM, NT, A_KC>;
+  using OB = Tile1r<BN, NT, B_KC>;
+  constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
+  static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile must be whole 16x16 MFMA tiles");
+  extern __shared__ __attribute__((aligned(16))) float lds1r[];
+  float* As = lds1r;
+  float* Bs = lds1r + 2 * OA::SZ;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int l16 = lane & 15, gq = lane >> 4;
+  const int MT = (g.M + BM - 1) / BM, NTl = (g.N + BN - 1) / BN;
+  const int nwg = MT * NTl, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;       // same XCD-contiguous remap as gemm_kernel
+  const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int m0 = (t % MT) * BM, n0 = (t / MT) * BN;
+  const int nk = (g.K + BK - 1) / BK;
+
+  floatx4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float bcol[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = n0 + wn * WN + tn * 16 + l16;
+    bcol[tn] = (g.bias != nullptr && col < g.N) ? g.bias[col] : 0.f;
+  }
+
+  OA oa; OB ob;
+  oa.load(g.A, g.lda, m0, g.M, 0, g.K, tid);
+  ob.load(g.B, g.ldb, n0, g.N, 0, g.K, tid);
+  oa.store(As, tid);
+  ob.store(Bs, tid);
+  __syncthreads();
+  for (int i = 0; i < nk; ++i) {
+    const int cur = i & 1;
+    if (i + 1 < nk) {
+      oa.load(g.A, g.lda, m0, g.M, (i + 1) * BK, g.K, tid);
+      ob.load(g.B, g.ldb, n0, g.N, (i + 1) * BK, g.K, tid);
+    }
+    const float* Ac = As + cur * OA::SZ;
+    const float* Bc = Bs + cur * OB::SZ;
+#pragma unroll
+    for (int s = 0; s < BK / 8; ++s) {
+      float2 av[TM], bv[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) av[tm] = OA::fetch(Ac, wm * WM + tm * 16 + l16, s, gq);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) bv[tn] = OB::fetch(Bc, wn * WN + tn * 16 + l16, s, gq);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tm].x, bv[tn].x, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tm].y, bv[tn].y, acc[tm][tn], 0, 0, 0);
+    }
+    if (i + 1 < nk) {
+      oa.store(As + (cur ^ 1) * OA::SZ, tid);
+      ob.store(Bs + (cur ^ 1) * OB::SZ, tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
+  const bool plain = g.pre == nullptr && !g.accumulate;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = n0 + wn * WN + tn * 16 + l16;
+    if (col >= g.N) continue;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row0 = m0 + wm * WM + tm * 16 + 4 * gq;
+      const long o0 = (long)row0 * g.ldc + col;
+      if (plain) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (row0 + r < g.M) g.C[o0 + (long)r * g.ldc] = tnt_act(acc[tm][tn][r] + bcol[tn], g.act, g.slope);
+      } else {
+        float cold[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cold[r] = (g.accumulate && row0 + r < g.M) ? g.C[o0 + (long)r * g.ldc] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (row0 + r >= g.M) continue;
+          const long o = o0 + (long)r * g.ldc;
+          const float v = acc[tm][tn][r] + bcol[tn];
+          if (g.pre) g.pre[o] = v;
+          g.C[o] = tnt_act(v, g.act, g.slope) + cold[r];
+        }
+      }
+    }
+  }
+}
+
+constexpr int R1_BM = 160, R1_BN = 128, R1_WGM = 2, R1_WGN = 8;
+
+// NN only (A rows k-contiguous, B rows n-contiguous): the gradient GEMMs of the same layers have no epilogue
+// and go through the vendor library (csrc/blas.hip).
+int32_t launch_one_round(const GemmArgs& g, hipStream_t s) {
+  using OA = Tile1r<R1_BM, 64 * R1_WGM * R1_WGN, true>;
+  using OB = Tile1r<R1_BN, 64 * R1_WGM * R1_WGN, false>;
+  constexpr int shmem = (2 * OA::SZ + 2 * OB::SZ) * (int)sizeof(float);
+  auto kern = gemm1r_kernel<R1_BM, R1_BN, R1_WGM, R1_WGN, true, false>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, shmem) != hipSuccess)
+      return TNT_BADARG(90);
+    attr_set = true;
+  }
+  const int tiles = ((g.M + R1_BM - 1) / R1_BM) * ((g.N + R1_BN - 1) / R1_BN);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * R1_WGM * R1_WGN), shmem, s, g);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+// One round pays when the 64x64 grid would need a second, mostly empty round and the 160x128 grid fills most CUs.
+bool one_round_fits(int M, int N, int K) {
+  const long tiles = (long)((M + R1_BM - 1) / R1_BM) * ((N + R1_BN - 1) / R1_BN);
+  const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+  if (tiles > 256 || tiles < 208 || K < 128) return false;
+  const double useful = (double)M * N / ((double)tiles * R1_BM * R1_BN);
+  return useful >= 0.9 && tiles64 > 1024;
 }
 
 template <int BM, int BN, bool TA, bool TB>
@@ -251,6 +468,11 @@ int32_t gemm_dispatch(const float* A, const float* B, float* C, const float* bia
     if (cand[c][0] == force_bm && cand[c][1] == force_bn) best = c;
   const bool vec = tnt_aligned16(A) && tnt_aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
   hipStream_t s = tnt_stream(stream);
+  if (force_bm == R1_BM && force_bn == R1_BN) {      // tests / tuning: the one-round kernel on any NN shape
+    if (transA || transB || splitk != 1 || !vec) return TNT_BADARG(91);
+    return launch_one_round(g, s);
+  }
+  if (!transA && !transB && splitk == 1 && vec && force_bm == 0 && one_round_fits(M, N, K)) return launch_one_round(g, s);
   int32_t rc;
   if (!transA && !transB) rc = launch_layout<false, false>(g, cand[best][0], cand[best][1], vec, s);
   else if (!transA && transB) rc = launch_layout<false, true>(g, cand[best][0], cand[best][1], vec, s);
@@ -277,7 +499,8 @@ extern "C" int32_t tnt_gemm_f32(const float* A, const float* B, float* C, const 
 }
 
 // tuning entry point: same as tnt_gemm_f32 with the workgroup tile forced to bm x bn
-// (bm, bn in {64,128}); used by tools/gemm_bench.py to calibrate the tile heuristic.
+// (bm, bn in {64,128}), or (160, 128) = the one-round kernel (NN, splitk 1, 16-byte aligned operands only);
+// used by tools/gemm_bench.py to calibrate the heuristics and by the tests to reach both kernels on any shape.
 extern "C" int32_t tnt_gemm_f32_tile(const float* A, const float* B, float* C, const float* bias, float* pre,
                                      int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc,
                                      int32_t transA, int32_t transB, int32_t act, float slope,

@@ -43,6 +43,14 @@ class HipBackend:
                                          int(transA), int(transB), act, slope, int(accumulate), splitk,
                                          _p(work), self._s()), "tnt_gemm_f32")
 
+    def gemm_tile(self, A, B, C, M, N, K, lda, ldb, ldc, bm, bn, transA=False, transB=False, bias=None, pre=None,
+                  act=ACT_NONE, slope=0.2, accumulate=False, splitk=1, work=None):
+        """tnt_gemm_f32 with the workgroup tile forced: (64|128, 64|128) = the tiled kernel, (160, 128) = the
+        one-round kernel (tests and tools/ only)."""
+        _lib.check(self.lib.tnt_gemm_f32_tile(_p(A), _p(B), _p(C), _p(bias), _p(pre), M, N, K, lda, ldb, ldc,
+                                              int(transA), int(transB), act, slope, int(accumulate), splitk,
+                                              _p(work), bm, bn, self._s()), "tnt_gemm_f32_tile")
+
     def dropout(self, x, y, rows, cols, ld, tmajor_B, lwidth, lcol0, rate, seed, site, step, step_dev=None,
                 rows_per_site=0):
         _lib.check(self.lib.tnt_dropout_f32(_p(x), _p(y), rows, cols, ld, tmajor_B, lwidth, lcol0, rows_per_site,

@@ -75,6 +75,42 @@ def test_gemm(be, M, N, K, tA, tB, pad):
     close(C2[:, :N], A @ Bm + 1.0)
 
 
+@pytest.mark.parametrize("M,N,K,pad,forced", [(960, 5001, 512, 3, False), (960, 5001, 256, 3, False),
+                                               (100, 70, 44, 2, True), (330, 257, 96, 3, True), (161, 129, 36, 3, True),
+                                               (16, 16, 8, 0, True), (480, 300, 1000, 0, True)])
+def test_gemm_one_round(be, M, N, K, pad, forced):
+    """The one-round 160x128 kernel (16x16x4 MFMAs, one workgroup per CU): picked by tnt_gemm_f32 itself on the
+    vocabulary-head shapes, forced through tnt_gemm_f32_tile on ragged ones (row / column / k tails, every epilogue
+    mode), against float64 numpy and against the tiled kernel."""
+    rng = np.random.default_rng(M * 11 + N * 5 + K)
+    A, Bm, bias = rng.standard_normal((M, K)), rng.standard_normal((K, N)), rng.standard_normal(N)
+    lda, ldb, ldc = K, N + pad, N + pad
+    assert ldb % 4 == 0 and lda % 4 == 0
+    Ad = dev(A)
+    Bd = torch.zeros(K, ldb, device="cuda"); Bd[:, :N] = dev(Bm)
+    run = (lambda *a, **k: be.gemm_tile(*a, 160, 128, **k)) if forced else be.gemm
+    Cd = torch.full((M, ldc), 7.0, device="cuda"); Pd = torch.zeros(M, ldc, device="cuda")
+    run(Ad, Bd, Cd, M, N, K, lda, ldb, ldc, bias=dev(bias), pre=Pd, act=1, slope=0.2)
+    pre = A @ Bm + bias
+    close(Pd[:, :N], pre)
+    close(Cd[:, :N], np.where(pre > 0, pre, 0.2 * pre))
+    if pad:
+        assert (Cd[:, N:] == 7.0).all() and (Pd[:, N:] == 0.0).all()
+    C1 = torch.full((M, ldc), 7.0, device="cuda")                  # plain mode: bias + activation, no pre
+    run(Ad, Bd, C1, M, N, K, lda, ldb, ldc, bias=dev(bias), act=2)
+    close(C1[:, :N], np.maximum(pre, 0.0))
+    if pad:
+        assert (C1[:, N:] == 7.0).all()
+    C2 = torch.ones(M, ldc, device="cuda")
+    run(Ad, Bd, C2, M, N, K, lda, ldb, ldc, accumulate=True)
+    close(C2[:, :N], A @ Bm + 1.0)
+    C3 = torch.zeros(M, ldc, device="cuda")                        # same products as the 64x64 tiled kernel
+    be.gemm_tile(Ad, Bd, C3, M, N, K, lda, ldb, ldc, 64, 64, bias=dev(bias))
+    C4 = torch.zeros(M, ldc, device="cuda")
+    run(Ad, Bd, C4, M, N, K, lda, ldb, ldc, bias=dev(bias))
+    assert (C3[:, :N] - C4[:, :N]).abs().max().item() <= 2e-5 * max(1.0, float(np.abs(pre).max()))
+
+
 def test_gemm_splitk(be):
     rng = np.random.default_rng(0)
     M, N, K = 64, 512, 20000
