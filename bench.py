@@ -25,9 +25,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 B, T, V, U, E, N_VOX = 64, 15, 5001, 512, 512, 20000
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak
-# vocabulary-head forward GEMM, measured HBM bytes per launch: 2 x FETCH_SIZE(16190 KiB) + WRITE_SIZE(19625 KiB)
-# (algorithmic: 31.4 MB -- A 1.97 + B 10.25 read, C 19.2 written)
-PMC_TRAFFIC_BYTES = int((2 * 16190.0 + 19625.1) * 1024)
+# vocabulary-head forward GEMM (one-round kernel), measured HBM bytes per launch: 2 x FETCH_SIZE(13029 KiB) +
+# WRITE_SIZE(18886 KiB), profiles/r01_gemm_head_pmc_v3.txt (algorithmic: 31.4 MB -- A 1.97 + B 10.25 read, C 19.2 written)
+PMC_TRAFFIC_BYTES = int((2 * 13029.1 + 18885.8) * 1024)
 
 
 def synth(rank, device):
@@ -118,14 +118,14 @@ def dominant_kernel_roofline(model, workload, steps=20):
         launch = lambda: be.gemm(model.Out, Wo, model.logits, Bt, V, U, U, ldV, ldV,
                                  bias=a.p("time_distributed_softmax/bias"))
         flops = 2.0 * Bt * V * U
-        name = "gemm_kernel<NN> logits = Out[960x512] @ Wo[512x5001]"
+        name = "gemm1r_kernel<160,128> logits = Out[960x512] @ Wo[512x5001]"
     else:
         a = model.arena
         Wo, ldV, H = a.p("time_distributed_softmax/kernel"), model.ldV, model.H
         launch = lambda: be.gemm(model.inter_d, Wo, model.logits, Bt, V, H, H, ldV, ldV,
                                  bias=a.p("time_distributed_softmax/bias"))
         flops = 2.0 * Bt * V * H
-        name = "gemm_kernel<NN> logits = inter[960x256] @ Wo[256x5001]"
+        name = "gemm1r_kernel<160,128> logits = inter[960x256] @ Wo[256x5001]"
     for _ in range(3):
         launch()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -142,7 +142,7 @@ def dominant_kernel_roofline(model, workload, steps=20):
     traffic = PMC_TRAFFIC_BYTES if workload == "dense" else None
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
             "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": traffic,
-            "traffic_source": "profiles/r01_gemm_head_pmc_traffic.txt" if traffic else None, "kernel": name,
+            "traffic_source": "profiles/r01_gemm_head_pmc_v3.txt" if traffic else None, "kernel": name,
             "avg_launch_us": round(dur_s * 1e6, 2), "flops_per_launch": flops}
 
 
