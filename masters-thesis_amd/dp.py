@@ -14,6 +14,8 @@ BatchNorm batch statistics, which stay per replica.  Mechanics:
 """
 import warnings
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -42,8 +44,8 @@ def make_grad_sync(world, bucket_elems=None):
 
 class PipelinedDenseSync:
     """DP schedule for the dense-encoder NIC (config 2), shaped for xGMI point-to-point links.
-    Five captured graphs; every collective is issued async right after the graph that produces its
-    operand and is waited for only by the graph that consumes it:
+    Six launch segments (hipGraphs or recorded launch plans, see ``eager`` below); every collective is issued async
+    right after the segment that produces its operand and is waited for only by the segment that consumes it:
 
       A  : forward + loss + vocabulary-head backward
              -> all-reduce head gradients (10 MB), all-gather the betas X (5 MB / rank)
@@ -51,8 +53,10 @@ class PipelinedDenseSync:
              -> all-reduce LSTM gradients (8 MB)
       B2 : dXin, embedding rows, BatchNorm / activation backward, encoder bias, dpre
              -> all-reduce {encoder bias, BN, embedding} (10 MB) + sparse-norm scalar, all-gather dpre
-      C1 : (waits X, dpre, head)   encoder dW = X_all^T dpre_all on every rank (K = G*B);
-           norms + clip + Adam of the encoder kernel and the head  (73 % of the arena)
+      C0 : (waits head)            step tick; norms + clip + Adam of the head -- runs while the all-gather of dpre,
+                                   the one small collective on the critical path, is in flight
+      C1 : (waits X, dpre)         encoder dW = X_all^T dpre_all on every rank (K = G*B);
+           norms + clip + Adam of the encoder kernel  (59 % of the arena)
       C2 : (waits LSTM, embedding) norms + clip + Adam of the rest, L2 metric
 
     The 41 MB encoder-kernel gradient -- 59 % of the arena and the LAST gradient backward produces --
@@ -63,6 +67,13 @@ class PipelinedDenseSync:
     work already queued on the compute stream; ``wait()`` makes the compute stream wait, not the host.
     """
     pipelined = True
+    # Segments replayed as recorded launch plans (ModelBase._run_planned: plain kernel launches re-issued from
+    # bound C-ABI calls) instead of hipGraphs.  Every hipGraphLaunch costs ~15-20 us of device idle time before
+    # its first kernel, and a step has six segments; only B1, the chain of 15 dependent LSTM steps, keeps its
+    # graph.  World-size-1 rehearsal (tools/host_overhead.py --dp): all graphs 0.905 ms/step, this choice 0.854
+    # with the host at 0.52 ms/step, all plans 0.847 with the host at 0.69.  The single-GPU step stays ONE graph
+    # (0.7195 ms vs 0.7142 as a plan: within noise, and the plan keeps the host 80 % busy).
+    eager = frozenset(os.environ.get("TNT_DP_EAGER", "A,B2,C0,C1,C2").split(","))
 
     def __init__(self, world):
         self.world = world
@@ -98,23 +109,25 @@ class PipelinedDenseSync:
         front0, lstm0, head0 = e["dense_img/bias"].off, e["lstm/kernel"].off, e["time_distributed_softmax/kernel"].off
         x_used = m.xd if m.r_in > 0 else m.x
 
-        m._run_captured(("dpA", B, T), lambda: (m._forward(B, T, True), m._loss_metrics(B, T, True),
-                                                m._bwd_head(B, T)))
+        cap = lambda key, fn: (m._run_planned if key[0][2:] in self.eager else m._run_captured)(key, fn)
+        cap(("dpA", B, T), lambda: (m._forward(B, T, True), m._loss_metrics(B, T, True), m._bwd_head(B, T)))
         w_head, w_x = self._ar(a.grad[head0:]), self._gather(x_all, x_used)
-        m._run_captured(("dpB1", B, T), lambda: (m._bwd_seq_lstm(B, T), m.join()))
+        cap(("dpB1", B, T), lambda: (m._bwd_seq_lstm(B, T), m.join()))
         w_lstm = self._ar(a.grad[lstm0:head0])
-        m._run_captured(("dpB2", B, T), lambda: (m._bwd_seq_front(B, T), m.join()))
+        cap(("dpB2", B, T), lambda: (m._bwd_seq_front(B, T), m.join()))
         # the 40-byte sparse-norm vector rides in the same launch as the last gradient bucket
         w_front = dist.all_reduce_coalesced([a.grad[front0:lstm0], a.sq_override], op=dist.ReduceOp.SUM, async_op=True)
         w_dpre = self._gather(dpre_all, m.dpre)
-        for w in (w_x, w_dpre, w_head):
+        # the head update needs only its own (long finished) all-reduce: it runs while the small, latency-bound
+        # all-gather of dpre -- the one collective on the critical path -- is in flight
+        w_head.wait()
+        cap(("dpC0", B, T), lambda: (m._tick(), m._update_slice(s_head)))
+        for w in (w_x, w_dpre):
             w.wait()
-        m._run_captured(("dpC1", B, T), lambda: (m._tick(), m._bwd_enc(B, T, x_all, dpre_all), m._update_slice(s_head),
-                                                 m._update_slice(s_enc)))
+        cap(("dpC1", B, T), lambda: (m._bwd_enc(B, T, x_all, dpre_all), m._update_slice(s_enc)))
         for w in (w_lstm, w_front):
             w.wait()
-        m._run_captured(("dpC2", B, T), lambda: (m._update_slice(s_mid),
-                                                 m.be.l2_total(a.wsq, a.seg_l2, a.nseg, m.met[2:3])))
+        cap(("dpC2", B, T), lambda: (m._update_slice(s_mid), m.be.l2_total(a.wsq, a.seg_l2, a.nseg, m.met[2:3])))
 
     def __call__(self, model):          # generic fallback (models without a pipelined schedule)
         make_grad_sync(self.world)(model)

@@ -28,6 +28,18 @@ class HipBackend:
         if not torch.cuda.is_available():
             raise _lib.KernelLibraryError("no GPU visible: the HIP backend needs an MI355X (there is no CPU fallback)")
 
+    _rec = None     # while a launch plan is being recorded: list of (c function, name, argument tuple)
+
+    def _call(self, fn, name, *args):
+        """Every C-ABI launch goes through here: checks the return code and, while a plan is being recorded
+        (ModelBase._run_planned), keeps the bound call so the same launch can be re-issued without the Python
+        argument plumbing."""
+        if self._rec is not None:
+            self._rec.append((fn, name, args))
+        rc = fn(*args)
+        if rc != 0:
+            raise _lib.KernelLibraryError(f"{name} failed with code {rc}")
+
     @staticmethod
     def _s():
         # raw handle of torch's current stream (also the capturing stream inside a hipGraph capture); the Stream-object
@@ -39,204 +51,187 @@ class HipBackend:
 
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, pre=None,
              act=ACT_NONE, slope=0.2, accumulate=False, splitk=1, work=None):
-        _lib.check(self.lib.tnt_gemm_f32(_p(A), _p(B), _p(C), _p(bias), _p(pre), M, N, K, lda, ldb, ldc,
+        self._call(self.lib.tnt_gemm_f32, "tnt_gemm_f32", _p(A), _p(B), _p(C), _p(bias), _p(pre), M, N, K, lda, ldb, ldc,
                                          int(transA), int(transB), act, slope, int(accumulate), splitk,
-                                         _p(work), self._s()), "tnt_gemm_f32")
+                                         _p(work), self._s())
 
     def gemm_tile(self, A, B, C, M, N, K, lda, ldb, ldc, bm, bn, transA=False, transB=False, bias=None, pre=None,
                   act=ACT_NONE, slope=0.2, accumulate=False, splitk=1, work=None):
         """tnt_gemm_f32 with the workgroup tile forced: (64|128, 64|128) = the tiled kernel, (160, 128) = the
         one-round kernel (tests and tools/ only)."""
-        _lib.check(self.lib.tnt_gemm_f32_tile(_p(A), _p(B), _p(C), _p(bias), _p(pre), M, N, K, lda, ldb, ldc,
+        self._call(self.lib.tnt_gemm_f32_tile, "tnt_gemm_f32_tile", _p(A), _p(B), _p(C), _p(bias), _p(pre), M, N, K, lda, ldb, ldc,
                                               int(transA), int(transB), act, slope, int(accumulate), splitk,
-                                              _p(work), bm, bn, self._s()), "tnt_gemm_f32_tile")
+                                              _p(work), bm, bn, self._s())
 
     def dropout(self, x, y, rows, cols, ld, tmajor_B, lwidth, lcol0, rate, seed, site, step, step_dev=None,
                 rows_per_site=0):
-        _lib.check(self.lib.tnt_dropout_f32(_p(x), _p(y), rows, cols, ld, tmajor_B, lwidth, lcol0, rows_per_site,
-                                            rate, seed, site, step, _p(step_dev), self._s()), "tnt_dropout_f32")
+        self._call(self.lib.tnt_dropout_f32, "tnt_dropout_f32", _p(x), _p(y), rows, cols, ld, tmajor_B, lwidth, lcol0, rows_per_site,
+                                            rate, seed, site, step, _p(step_dev), self._s())
 
     def act_bwd(self, pre, dy, dx, n, act, slope=0.2):
-        _lib.check(self.lib.tnt_act_bwd_f32(_p(pre), _p(dy), _p(dx), n, act, slope, self._s()), "tnt_act_bwd_f32")
+        self._call(self.lib.tnt_act_bwd_f32, "tnt_act_bwd_f32", _p(pre), _p(dy), _p(dx), n, act, slope, self._s())
 
     def batchnorm_fwd(self, x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, training, eps,
                       momentum, work):
-        _lib.check(self.lib.tnt_batchnorm_fwd_f32(_p(x), _p(gamma), _p(beta), _p(mov_mean), _p(mov_var), _p(y),
+        self._call(self.lib.tnt_batchnorm_fwd_f32, "tnt_batchnorm_fwd_f32", _p(x), _p(gamma), _p(beta), _p(mov_mean), _p(mov_var), _p(y),
                                                   _p(xhat), _p(inv_std), rows, C, ldy, int(training), eps, momentum,
-                                                  _p(work), self._s()), "tnt_batchnorm_fwd_f32")
+                                                  _p(work), self._s())
 
     def batchnorm_bwd(self, dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, training, work):
-        _lib.check(self.lib.tnt_batchnorm_bwd_f32(_p(dy), _p(xhat), _p(gamma), _p(inv_std), _p(dx), _p(dgamma),
-                                                  _p(dbeta), rows, C, lddy, int(training), _p(work), self._s()),
-                   "tnt_batchnorm_bwd_f32")
+        self._call(self.lib.tnt_batchnorm_bwd_f32, "tnt_batchnorm_bwd_f32", _p(dy), _p(xhat), _p(gamma), _p(inv_std), _p(dx), _p(dgamma),
+                                                  _p(dbeta), rows, C, lddy, int(training), _p(work), self._s())
 
     def layernorm_fwd(self, x, gamma, beta, y, xhat, inv_std, rows, C, ldy, eps):
-        _lib.check(self.lib.tnt_layernorm_fwd_f32(_p(x), _p(gamma), _p(beta), _p(y), _p(xhat), _p(inv_std), rows, C,
-                                                  ldy, eps, self._s()), "tnt_layernorm_fwd_f32")
+        self._call(self.lib.tnt_layernorm_fwd_f32, "tnt_layernorm_fwd_f32", _p(x), _p(gamma), _p(beta), _p(y), _p(xhat), _p(inv_std), rows, C,
+                                                  ldy, eps, self._s())
 
     def layernorm_bwd(self, dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, work):
-        _lib.check(self.lib.tnt_layernorm_bwd_f32(_p(dy), _p(xhat), _p(gamma), _p(inv_std), _p(dx), _p(dgamma),
-                                                  _p(dbeta), rows, C, lddy, _p(work), self._s()),
-                   "tnt_layernorm_bwd_f32")
+        self._call(self.lib.tnt_layernorm_bwd_f32, "tnt_layernorm_bwd_f32", _p(dy), _p(xhat), _p(gamma), _p(inv_std), _p(dx), _p(dgamma),
+                                                  _p(dbeta), rows, C, lddy, _p(work), self._s())
 
     def colsum(self, x, out, rows, C, ld, work):
-        _lib.check(self.lib.tnt_colsum_f32(_p(x), _p(out), rows, C, ld, _p(work), self._s()), "tnt_colsum_f32")
+        self._call(self.lib.tnt_colsum_f32, "tnt_colsum_f32", _p(x), _p(out), rows, C, ld, _p(work), self._s())
 
     def embedding_fwd(self, table, ids, out, B, T, E, ldo, V):
-        _lib.check(self.lib.tnt_embedding_fwd_f32(_p(table), _p(ids), _p(out), B, T, E, ldo, V, self._s()),
-                   "tnt_embedding_fwd_f32")
+        self._call(self.lib.tnt_embedding_fwd_f32, "tnt_embedding_fwd_f32", _p(table), _p(ids), _p(out), B, T, E, ldo, V, self._s())
 
     def embedding_fwd_drop(self, table, ids, out, out_drop, B, T, E, ldo, V, rate, seed, site, step, step_dev=None):
-        _lib.check(self.lib.tnt_embedding_fwd_drop_f32(_p(table), _p(ids), _p(out), _p(out_drop), B, T, E, ldo, V, rate,
-                                                       int(seed), int(site), int(step), _p(step_dev), self._s()),
-                   "tnt_embedding_fwd_drop_f32")
+        self._call(self.lib.tnt_embedding_fwd_drop_f32, "tnt_embedding_fwd_drop_f32", _p(table), _p(ids), _p(out), _p(out_drop), B, T, E, ldo, V, rate,
+                                                       int(seed), int(site), int(step), _p(step_dev), self._s())
 
     def embedding_bwd(self, drows, ids, dtable, sq_norm, rowsq_work, B, T, E, ldd, V):
-        _lib.check(self.lib.tnt_embedding_bwd_f32(_p(drows), _p(ids), _p(dtable), _p(sq_norm), _p(rowsq_work), B, T,
-                                                  E, ldd, V, self._s()), "tnt_embedding_bwd_f32")
+        self._call(self.lib.tnt_embedding_bwd_f32, "tnt_embedding_bwd_f32", _p(drows), _p(ids), _p(dtable), _p(sq_norm), _p(rowsq_work), B, T,
+                                                  E, ldd, V, self._s())
 
     def lstm_step_fwd(self, xz, h_prev, c_prev, Ur, ctx, Wc, D, mask_ids, mask_T, mask_t, out_prev, h, c, out,
                       gates, B, U, xz_bias=None):
-        _lib.check(self.lib.tnt_lstm_step_fwd_f32(_p(xz), _p(h_prev), _p(c_prev), _p(Ur), _p(ctx), _p(Wc), D,
+        self._call(self.lib.tnt_lstm_step_fwd_f32, "tnt_lstm_step_fwd_f32", _p(xz), _p(h_prev), _p(c_prev), _p(Ur), _p(ctx), _p(Wc), D,
                                                   _p(mask_ids), mask_T, mask_t, _p(out_prev), _p(h), _p(c), _p(out),
-                                                  _p(gates), B, U, _p(xz_bias), self._s()), "tnt_lstm_step_fwd_f32")
+                                                  _p(gates), B, U, _p(xz_bias), self._s())
 
     def lstm_step_bwd(self, dz_next, Ur, da_pass_in, dh_ext, dc_in, dout_in, dout_t, mask_ids, mask_T, mask_t,
                       gates, c, c_prev, dz, da_pass_out, dc_out, dout_out, B, U, Wc=None, D=0, dctx_part=None):
-        _lib.check(self.lib.tnt_lstm_step_bwd_f32(_p(dz_next), _p(Ur), _p(da_pass_in), _p(dh_ext), _p(dc_in),
+        self._call(self.lib.tnt_lstm_step_bwd_f32, "tnt_lstm_step_bwd_f32", _p(dz_next), _p(Ur), _p(da_pass_in), _p(dh_ext), _p(dc_in),
                                                   _p(dout_in), _p(dout_t), _p(mask_ids), mask_T, mask_t, _p(gates),
                                                   _p(c), _p(c_prev), _p(dz), _p(da_pass_out), _p(dc_out),
-                                                  _p(dout_out), B, U, _p(Wc), D, _p(dctx_part), self._s()),
-                   "tnt_lstm_step_bwd_f32")
+                                                  _p(dout_out), B, U, _p(Wc), D, _p(dctx_part), self._s())
 
     def gru_step_fwd(self, xz, h_prev, Uk, br, h, gates, B, U):
-        _lib.check(self.lib.tnt_gru_step_fwd_f32(_p(xz), _p(h_prev), _p(Uk), _p(br), _p(h), _p(gates), B, U, self._s()),
-                   "tnt_gru_step_fwd_f32")
+        self._call(self.lib.tnt_gru_step_fwd_f32, "tnt_gru_step_fwd_f32", _p(xz), _p(h_prev), _p(Uk), _p(br), _p(h), _p(gates), B, U, self._s())
 
     def gru_step_bwd(self, drec_next, Uk, dh_pass_in, dh_ext, gates, h_prev, dxz, drec, dh_pass_out, B, U):
-        _lib.check(self.lib.tnt_gru_step_bwd_f32(_p(drec_next), _p(Uk), _p(dh_pass_in), _p(dh_ext), _p(gates), _p(h_prev),
-                                                 _p(dxz), _p(drec), _p(dh_pass_out), B, U, self._s()),
-                   "tnt_gru_step_bwd_f32")
+        self._call(self.lib.tnt_gru_step_bwd_f32, "tnt_gru_step_bwd_f32", _p(drec_next), _p(Uk), _p(dh_pass_in), _p(dh_ext), _p(gates), _p(h_prev),
+                                                 _p(dxz), _p(drec), _p(dh_pass_out), B, U, self._s())
 
     def softmax_cce(self, logits, target, probs, loss_row, correct_row, dlogits, rows, V, ld, gscale,
                     from_logits=False, mask_zero=False):
-        _lib.check(self.lib.tnt_softmax_cce_f32(_p(logits), _p(target), _p(probs), _p(loss_row), _p(correct_row),
+        self._call(self.lib.tnt_softmax_cce_f32, "tnt_softmax_cce_f32", _p(logits), _p(target), _p(probs), _p(loss_row), _p(correct_row),
                                                 _p(dlogits), rows, V, ld, gscale, int(from_logits), int(mask_zero),
-                                                self._s()), "tnt_softmax_cce_f32")
+                                                self._s())
 
     def onehot_argmax(self, onehot, ids_tmajor, B, T, V):
-        _lib.check(self.lib.tnt_onehot_argmax_f32(_p(onehot), _p(ids_tmajor), B, T, V, self._s()),
-                   "tnt_onehot_argmax_f32")
+        self._call(self.lib.tnt_onehot_argmax_f32, "tnt_onehot_argmax_f32", _p(onehot), _p(ids_tmajor), B, T, V, self._s())
 
     def argmax_rows(self, x, out, rows, V, ld):
-        _lib.check(self.lib.tnt_argmax_rows_f32(_p(x), _p(out), rows, V, ld, self._s()), "tnt_argmax_rows_f32")
+        self._call(self.lib.tnt_argmax_rows_f32, "tnt_argmax_rows_f32", _p(x), _p(out), rows, V, ld, self._s())
 
     def enc_tail_fwd(self, y, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C, ldo, training, eps, momentum,
                      r_feat, r_lstm, seed, site_feat, site_lstm, step_dev=None):
-        _lib.check(self.lib.tnt_enc_tail_fwd_f32(_p(y), _p(gamma), _p(beta), _p(mov_mean), _p(mov_var), _p(out), _p(xhat),
+        self._call(self.lib.tnt_enc_tail_fwd_f32, "tnt_enc_tail_fwd_f32", _p(y), _p(gamma), _p(beta), _p(mov_mean), _p(mov_var), _p(out), _p(xhat),
                                                  _p(inv_std), rows, C, ldo, int(training), eps, momentum, r_feat, r_lstm,
-                                                 int(seed), int(site_feat), int(site_lstm), _p(step_dev), self._s()),
-                   "tnt_enc_tail_fwd_f32")
+                                                 int(seed), int(site_feat), int(site_lstm), _p(step_dev), self._s())
 
     def enc_tail_bwd(self, dout, xhat, gamma, inv_std, pre, dpre, dgamma, dbeta, dbias, rows, C, ldo, r_feat, r_lstm,
                      slope, seed, site_feat, site_lstm, step_dev=None):
-        _lib.check(self.lib.tnt_enc_tail_bwd_f32(_p(dout), _p(xhat), _p(gamma), _p(inv_std), _p(pre), _p(dpre), _p(dgamma),
+        self._call(self.lib.tnt_enc_tail_bwd_f32, "tnt_enc_tail_bwd_f32", _p(dout), _p(xhat), _p(gamma), _p(inv_std), _p(pre), _p(dpre), _p(dgamma),
                                                  _p(dbeta), _p(dbias), rows, C, ldo, r_feat, r_lstm, slope, int(seed),
-                                                 int(site_feat), int(site_lstm), _p(step_dev), self._s()),
-                   "tnt_enc_tail_bwd_f32")
+                                                 int(site_feat), int(site_lstm), _p(step_dev), self._s())
 
     def dense_dw_skinny(self, x, dpre, dw, N, E, Bk, ldx):
-        _lib.check(self.lib.tnt_dense_dw_skinny_f32(_p(x), _p(dpre), _p(dw), N, E, Bk, ldx, self._s()),
-                   "tnt_dense_dw_skinny_f32")
+        self._call(self.lib.tnt_dense_dw_skinny_f32, "tnt_dense_dw_skinny_f32", _p(x), _p(dpre), _p(dw), N, E, Bk, ldx, self._s())
 
     def gemm_blas(self, A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, accumulate=False):
-        _lib.check(self.lib.tnt_gemm_blas_f32(_p(A), _p(B), _p(C), M, N, K, lda, ldb, ldc, int(transA), int(transB),
-                                              int(accumulate), self._s()), "tnt_gemm_blas_f32")
+        self._call(self.lib.tnt_gemm_blas_f32, "tnt_gemm_blas_f32", _p(A), _p(B), _p(C), M, N, K, lda, ldb, ldc, int(transA), int(transB),
+                                              int(accumulate), self._s())
 
     def locally_dense_fwd_split(self, x, ldx, idx, vgoff, vreg, rfirst, NV, W, bias, pre, y, partial, B, R, D, slope=0.2,
                                 voxel_major=False):
-        _lib.check(self.lib.tnt_locally_dense_fwd_split_f32(_p(x), ldx, _p(idx), _p(vgoff), _p(vreg), _p(rfirst), NV, _p(W),
+        self._call(self.lib.tnt_locally_dense_fwd_split_f32, "tnt_locally_dense_fwd_split_f32", _p(x), ldx, _p(idx), _p(vgoff), _p(vreg), _p(rfirst), NV, _p(W),
                                                             _p(bias), _p(pre), _p(y), _p(partial), B, R, D, slope,
-                                                            int(voxel_major), self._s()), "tnt_locally_dense_fwd_split_f32")
+                                                            int(voxel_major), self._s())
 
     def locally_dense_bwd_split(self, x, ldx, idx, vgoff, vreg, vfirst, NV, dpre, dW, db, B, R, D, voxel_major=False):
-        _lib.check(self.lib.tnt_locally_dense_bwd_split_f32(_p(x), ldx, _p(idx), _p(vgoff), _p(vreg), _p(vfirst), NV,
-                                                            _p(dpre), _p(dW), _p(db), B, R, D, int(voxel_major), self._s()),
-                   "tnt_locally_dense_bwd_split_f32")
+        self._call(self.lib.tnt_locally_dense_bwd_split_f32, "tnt_locally_dense_bwd_split_f32", _p(x), ldx, _p(idx), _p(vgoff), _p(vreg), _p(vfirst), NV,
+                                                            _p(dpre), _p(dW), _p(db), B, R, D, int(voxel_major), self._s())
 
     def sum2(self, x0, out0, x1, out1, n, scale):
-        _lib.check(self.lib.tnt_sum2_f32(_p(x0), _p(out0), _p(x1), _p(out1), n, scale, self._s()), "tnt_sum2_f32")
+        self._call(self.lib.tnt_sum2_f32, "tnt_sum2_f32", _p(x0), _p(out0), _p(x1), _p(out1), n, scale, self._s())
 
     def stage_batch(self, x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U, xT_dst=None, ldt=0):
-        _lib.check(self.lib.tnt_stage_batch_f32(_p(x), _p(x_dst), _p(cap), _p(cap_dst), _p(tgt), _p(tgt_tmajor), _p(a0),
-                                                _p(h0), _p(c0), _p(c0_dst), B, T, N, ldx, U, _p(xT_dst), ldt, self._s()),
-                   "tnt_stage_batch_f32")
+        self._call(self.lib.tnt_stage_batch_f32, "tnt_stage_batch_f32", _p(x), _p(x_dst), _p(cap), _p(cap_dst), _p(tgt), _p(tgt_tmajor), _p(a0),
+                                                _p(h0), _p(c0), _p(c0_dst), B, T, N, ldx, U, _p(xT_dst), ldt, self._s())
 
     def sample_rows(self, x, out, rows, V, ld, temperature, from_logits, seed, site, step, step_dev=None):
-        _lib.check(self.lib.tnt_sample_rows_f32(_p(x), _p(out), rows, V, ld, float(temperature), int(from_logits),
-                                                int(seed), int(site), int(step), _p(step_dev), self._s()),
-                   "tnt_sample_rows_f32")
+        self._call(self.lib.tnt_sample_rows_f32, "tnt_sample_rows_f32", _p(x), _p(out), rows, V, ld, float(temperature), int(from_logits),
+                                                int(seed), int(site), int(step), _p(step_dev), self._s())
 
     def sum(self, x, out, n, scale):
-        _lib.check(self.lib.tnt_sum_f32(_p(x), _p(out), n, scale, self._s()), "tnt_sum_f32")
+        self._call(self.lib.tnt_sum_f32, "tnt_sum_f32", _p(x), _p(out), n, scale, self._s())
 
     def seg_sqnorm(self, theta, grad, span_seg, span_off, span_len, seg_first, seg_l2, partial, sq, wsq, l2_out,
                    nspan, nseg):
-        _lib.check(self.lib.tnt_seg_sqnorm_f32(_p(theta), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
+        self._call(self.lib.tnt_seg_sqnorm_f32, "tnt_seg_sqnorm_f32", _p(theta), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
                                                _p(seg_first), _p(seg_l2), _p(partial), _p(sq), _p(wsq), _p(l2_out),
-                                               nspan, nseg, self._s()), "tnt_seg_sqnorm_f32")
+                                               nspan, nseg, self._s())
 
     def l2_total(self, wsq, seg_l2, nseg, out):
-        _lib.check(self.lib.tnt_l2_total_f32(_p(wsq), _p(seg_l2), nseg, _p(out), self._s()), "tnt_l2_total_f32")
+        self._call(self.lib.tnt_l2_total_f32, "tnt_l2_total_f32", _p(wsq), _p(seg_l2), nseg, _p(out), self._s())
 
     def adam(self, theta, m, v, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr_t, lr_t_dev,
              beta1, beta2, eps, clipnorm):
-        _lib.check(self.lib.tnt_adam_f32(_p(theta), _p(m), _p(v), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
+        self._call(self.lib.tnt_adam_f32, "tnt_adam_f32", _p(theta), _p(m), _p(v), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
                                          _p(seg_l2), _p(sq), _p(sq_override), nspan, lr_t, _p(lr_t_dev), beta1,
-                                         beta2, eps, clipnorm, self._s()), "tnt_adam_f32")
+                                         beta2, eps, clipnorm, self._s())
 
     def sgd(self, theta, mom, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr, lr_dev,
             momentum, clipnorm):
-        _lib.check(self.lib.tnt_sgd_f32(_p(theta), _p(mom), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
+        self._call(self.lib.tnt_sgd_f32, "tnt_sgd_f32", _p(theta), _p(mom), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
                                         _p(seg_l2), _p(sq), _p(sq_override), nspan, lr, _p(lr_dev), momentum,
-                                        clipnorm, self._s()), "tnt_sgd_f32")
+                                        clipnorm, self._s())
 
     def sam(self, theta, grad, ew, span_seg, span_off, span_len, seg_l2, sq, nseg, nspan, rho, mode):
-        _lib.check(self.lib.tnt_sam_f32(_p(theta), _p(grad), _p(ew), _p(span_seg), _p(span_off), _p(span_len),
-                                        _p(seg_l2), _p(sq), nseg, nspan, rho, mode, self._s()), "tnt_sam_f32")
+        self._call(self.lib.tnt_sam_f32, "tnt_sam_f32", _p(theta), _p(grad), _p(ew), _p(span_seg), _p(span_off), _p(span_len),
+                                        _p(seg_l2), _p(sq), nseg, nspan, rho, mode, self._s())
 
     def step_tick(self, adam_t, drop_step, lr, lr_t, beta1, beta2):
-        _lib.check(self.lib.tnt_step_tick(_p(adam_t), _p(drop_step), _p(lr), _p(lr_t), beta1, beta2, self._s()),
-                   "tnt_step_tick")
+        self._call(self.lib.tnt_step_tick, "tnt_step_tick", _p(adam_t), _p(drop_step), _p(lr), _p(lr_t), beta1, beta2, self._s())
 
     def locally_dense_fwd(self, x, ldx, idx, goff, W, bias, pre, y, B, R, D, slope=0.2):
-        _lib.check(self.lib.tnt_locally_dense_fwd_f32(_p(x), ldx, _p(idx), _p(goff), _p(W), _p(bias), _p(pre), _p(y),
-                                                      B, R, D, slope, self._s()), "tnt_locally_dense_fwd_f32")
+        self._call(self.lib.tnt_locally_dense_fwd_f32, "tnt_locally_dense_fwd_f32", _p(x), ldx, _p(idx), _p(goff), _p(W), _p(bias), _p(pre), _p(y),
+                                                      B, R, D, slope, self._s())
 
     def locally_dense_bwd(self, x, ldx, idx, goff, dpre, dW, db, B, R, D):
-        _lib.check(self.lib.tnt_locally_dense_bwd_f32(_p(x), ldx, _p(idx), _p(goff), _p(dpre), _p(dW), _p(db), B, R,
-                                                      D, self._s()), "tnt_locally_dense_bwd_f32")
+        self._call(self.lib.tnt_locally_dense_bwd_f32, "tnt_locally_dense_bwd_f32", _p(x), ldx, _p(idx), _p(goff), _p(dpre), _p(dW), _p(db), B, R,
+                                                      D, self._s())
 
     def attention_step_fwd(self, h, F, P, W2, b2, v, bv, qpre, alpha, ctx, ctx_d, s_out, B, R, D, A, U, slope,
                            rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None):
-        _lib.check(self.lib.tnt_attention_step_fwd_f32(_p(h), _p(F), _p(P), _p(W2), _p(b2), _p(v), _p(bv), _p(qpre),
+        self._call(self.lib.tnt_attention_step_fwd_f32, "tnt_attention_step_fwd_f32", _p(h), _p(F), _p(P), _p(W2), _p(b2), _p(v), _p(bv), _p(qpre),
                                                        _p(alpha), _p(ctx), _p(ctx_d), _p(s_out), B, R, D, A, U, slope,
                                                        rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step,
-                                                       _p(step_dev), self._s()), "tnt_attention_step_fwd_f32")
+                                                       _p(step_dev), self._s())
 
     def attention_step_bwd(self, dctx_d, F, P, W2, v, qpre, alpha, dP, dF, dvb, dqpre, dh, B, R, D, A, U, slope,
                            rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None, dz=None,
                            Wc=None, dctx_part=None, nparts=0):
-        _lib.check(self.lib.tnt_attention_step_bwd_f32(_p(dctx_d), _p(F), _p(P), _p(W2), _p(v), _p(qpre), _p(alpha),
+        self._call(self.lib.tnt_attention_step_bwd_f32, "tnt_attention_step_bwd_f32", _p(dctx_d), _p(F), _p(P), _p(W2), _p(v), _p(qpre), _p(alpha),
                                                        _p(dP), _p(dF), _p(dvb), _p(dqpre), _p(dh), B, R, D, A, U,
                                                        slope, rate_attn, rate_in, in_lwidth, seed, site_attn, site_in,
                                                        step, _p(step_dev), _p(dz), _p(Wc), _p(dctx_part), nparts,
-                                                       self._s()),
-                   "tnt_attention_step_bwd_f32")
+                                                       self._s())
 
     def attention_metric(self, alpha, out, work, T, B, R, tstride=0):
-        _lib.check(self.lib.tnt_attention_metric_f32(_p(alpha), _p(out), _p(work), T, B, R, tstride, self._s()),
-                   "tnt_attention_metric_f32")
+        self._call(self.lib.tnt_attention_metric_f32, "tnt_attention_metric_f32", _p(alpha), _p(out), _p(work), T, B, R, tstride, self._s())
 
 
 _backend = None

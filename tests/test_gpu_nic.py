@@ -108,3 +108,62 @@ def test_full_size_properties():
         losses[use_graph] = ls
         assert np.abs(model.get_weight("batch_norm/moving_mean")).max() > 0
     assert np.allclose(losses[False], losses[True], rtol=1e-6)
+
+
+def _twin_models(rates=(0.1, 0.2, 0.2), dims=(8, 2000, 15, 501, 64, 64)):
+    from masters_thesis_amd.optimizers import Adam
+    rng = np.random.default_rng(77)
+    a, orc = build(rng, rates, dims)
+    b, _ = build(np.random.default_rng(77), rates, dims)
+    for k, v in orc.p.items():
+        b.set_weight(k, v)
+    for m in (a, b):
+        m.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    return a, b, dims
+
+
+def test_launch_plan_replay_equals_graph_replay():
+    """ModelBase._run_planned (the step re-issued from recorded C-ABI calls, used by the data-parallel schedule)
+    against the captured hipGraph: same launches, so weights, optimizer state and metrics stay bit-identical over
+    eager -> record/capture -> replay -> replay steps, dropout included."""
+    a, b, (B, N, T, V, U, E) = _twin_models()
+    b._run_captured = b._run_planned
+    rng = np.random.default_rng(5)
+    for step in range(5):
+        data, tgt = synth_batch(B, N, T, V, U, rng)
+        ra, rb = a.train_step((data, tgt)).as_floats(), b.train_step((data, tgt)).as_floats()
+        assert ra == rb, (step, ra, rb)
+    plans = [v for v in b._graphs.values() if isinstance(v, tuple)]
+    assert plans and len(plans[0][1]) > 40           # the step really was replayed from a recorded plan
+    torch.cuda.synchronize()
+    assert torch.equal(a.arena.theta, b.arena.theta)
+    assert torch.equal(a.opt_m, b.opt_m) and torch.equal(a.opt_v, b.opt_v)
+
+
+def test_pipelined_dp_schedule_world1_equals_single_gpu_step():
+    """The data-parallel schedule of config 2 (dp.PipelinedDenseSync: six segments, collectives between them, the
+    encoder weight gradient from gathered operands, the update in three arena slices) at world size 1 over RCCL must
+    train exactly like the single-GPU step."""
+    import socket
+    import torch.distributed as dist
+    from masters_thesis_amd import dp
+    a, b, (B, N, T, V, U, E) = _twin_models()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        dp.attach(b, 1)
+        assert isinstance(b.grad_sync, dp.PipelinedDenseSync)
+        rng = np.random.default_rng(6)
+        for step in range(5):
+            data, tgt = synth_batch(B, N, T, V, U, rng)
+            ra, rb = a.train_step((data, tgt)).as_floats(), b.train_step((data, tgt)).as_floats()
+            for k in ra:
+                assert abs(ra[k] - rb[k]) <= 1e-6 * max(1.0, abs(ra[k])), (step, k, ra, rb)
+        torch.cuda.synchronize()
+        d = (a.arena.theta - b.arena.theta).abs().max().item()
+        assert d <= 1e-7, d
+    finally:
+        dist.destroy_process_group()

@@ -1,10 +1,19 @@
 """Host-side cost of one train_step call (enqueue only) against the device time per step."""
-import sys, time
+import os, sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = torch.device("cuda", 0)
-model = bench.make_model("dense", dev, None)
+workload = "attention" if "--attention" in sys.argv else "dense"
+model = bench.make_model(workload, dev, None)
+if "--dp" in sys.argv:            # world-size-1 rehearsal of the data-parallel schedule (RCCL on one GPU)
+    import os
+    import torch.distributed as dist
+    from masters_thesis_amd import dp
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29547")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    dp.attach(model, 1)
 batch, _ = bench.synth(0, dev)
 for _ in range(30):
     model.train_step(batch)
@@ -26,3 +35,4 @@ for _ in range(200):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("tottime").print_stats(14)
