@@ -163,7 +163,11 @@ class ModelBase:
         concurrent branch, see ``side``).  Workspaces grow on demand during eager (warm-up) passes;
         growing one invalidates captured graphs, which are then re-captured."""
         plain = kw.get("bias") is None and kw.get("pre") is None and kw.get("act", 0) == 0
-        if plain and getattr(self, "use_blas", True) and hasattr(self.be, "gemm_blas"):
+        # One shape family where the vendor's pick is poor: NT with a narrow output and a very long K (config 3's
+        # head dX = dlogits[960x5001] @ Wo^T[5001x256]: 59 us = 42 TF, against 38 us for the tiled kernel with
+        # split-K 16; tools/c3_head_grad_probe.py).  At N = 512 the two are level and the library stays.
+        blas_poor = kw.get("transB", False) and not kw.get("transA", False) and N <= 256 and K >= 16 * N
+        if plain and not blas_poor and getattr(self, "use_blas", True) and hasattr(self.be, "gemm_blas"):
             # no fused epilogue (weight / input gradients): the vendor's stream-K sgemm (tnt_gemm_blas_f32) needs no
             # split-K pass + reduce launch on these skinny-output / long-K shapes
             self.be.gemm_blas(A, B, C, M, N, K, lda, ldb, ldc, transA=kw.get("transA", False),
