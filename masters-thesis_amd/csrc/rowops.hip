@@ -649,9 +649,37 @@ extern "C" int32_t tnt_layernorm_bwd_f32(const float* dy, const float* xhat, con
   return 0;
 }
 
+// Column sums of a short matrix (rows <= 2048: every bias gradient of a T*B-row activation) in ONE launch instead of
+// partial + finalize: 32 column lanes x 32 row lanes per workgroup, each thread's loads independent (8 in flight),
+// then a fixed-order sum over the row lanes through LDS.
+__global__ __launch_bounds__(1024) void col_sum_direct_kernel(const float* x, int ld, int rows, int C, float* out) {
+  __shared__ float sh[32][33];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float v = 0.f;
+  if (c < C) {
+#pragma unroll 8
+    for (int r = rl; r < rows; r += 32) v += x[(long)r * ld + c];
+  }
+  sh[rl][cl] = v;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) t += sh[j][cl];
+    out[c] = t;
+  }
+}
+
 extern "C" int32_t tnt_colsum_f32(const float* x, float* out, int32_t rows, int32_t C, int32_t ld, float* work,
                                   void* stream) {
   hipStream_t s = tnt_stream(stream);
+  if (rows <= 0 || C <= 0) return 0;
+  if (rows <= 2048) {
+    hipLaunchKernelGGL(col_sum_direct_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, x, ld, rows, C, out);
+    TNT_LAUNCH_CHECK();
+    return 0;
+  }
   const int nchunk = chunk_count(rows);
   launch_col_partial<2>(x, ld, nullptr, 0, rows, C, work, s);
   TNT_LAUNCH_CHECK();

@@ -233,6 +233,20 @@ def test_colsum_sum_actbwd(be):
     close(dx, np.where(pre > 0, dy, 0.2 * dy))
 
 
+@pytest.mark.parametrize("rows,C,pad", [(1, 1, 0), (15, 64, 0), (64, 33, 1), (960, 2048, 0), (2048, 37, 3), (2049, 37, 3),
+                                        (23040, 32, 0)])
+def test_colsum_short_and_long(be, rows, C, pad):
+    """tnt_colsum_f32: one direct launch up to 2048 rows, chunk partials + finalize beyond; padding columns ignored."""
+    rng = np.random.default_rng(rows * 3 + C)
+    x = rng.standard_normal((rows, C))
+    xd = torch.full((rows, C + pad), 1e6, device="cuda"); xd[:, :C] = dev(x)
+    out = torch.full((C + 2,), -5.0, device="cuda")
+    work = torch.zeros(max(1, C * be.bn_nchunk(rows)), device="cuda")
+    be.colsum(xd, out, rows, C, C + pad, work)
+    close(out[:C], x.sum(0))
+    assert (out[C:] == -5.0).all()
+
+
 # -------------------------------------------------------------------------- embedding
 @pytest.mark.parametrize("B,T,E,V", [(8, 5, 70, 23), (64, 15, 512, 5001), (9, 4, 36, 11)])
 def test_embedding(be, B, T, E, V):
