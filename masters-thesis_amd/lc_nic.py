@@ -285,8 +285,12 @@ class NIC(ModelBase):
         self.dZ = f(n, U, 4)
         self.dc, self.dh_att = f(B, U), f(B, U)
         self.dctx = f(B, D)
-        self.dP, self.dF = f(B * R, A), f(B, R, D)
-        self.dvb, self.dqpre = f(B, A + 1), f(T, B, A)
+        # the three accumulators of the attention backward sit in one allocation: one fill zeroes them per step
+        pad4 = lambda v: -(-v // 4) * 4                      # every piece starts 16-byte aligned
+        oF, ovb = pad4(B * R * A), pad4(B * R * A) + pad4(B * R * D)
+        self.datt = f(ovb + pad4(B * (A + 1)))
+        self.dP, self.dF = self.datt[:B * R * A].view(B * R, A), self.datt[oF:oF + B * R * D].view(B, R, D)
+        self.dvb, self.dqpre = self.datt[ovb:ovb + B * (A + 1)].view(B, A + 1), f(T, B, A)
         self.dtext = f(n, Et)
         self.dbn = f(B * R, D)
         nch = max(self.be.bn_nchunk(B * R), self.be.bn_nchunk(n))
@@ -376,9 +380,13 @@ class NIC(ModelBase):
         n = T * B
         sd, ds = self.seed, self.drop_step
         self._encode(B, training)
-        be.embedding_fwd(a.p("emb_text/embeddings"), self.cap, self.text, B, T, Et, Et, V)       # lc_NIC.py:233
-        if training and self.r_text > 0:
-            be.dropout(self.text, self.text, n, Et, Et, B, Et, 0, self.r_text, sd, S_TEXT, 0, ds)
+        if training and self.r_text > 0 and Et % 4 == 0:     # lc_NIC.py:233 + its Dropout in one launch
+            be.embedding_fwd_drop(a.p("emb_text/embeddings"), self.cap, None, self.text, B, T, Et, Et, V, self.r_text,
+                                  sd, S_TEXT, 0, ds)
+        else:
+            be.embedding_fwd(a.p("emb_text/embeddings"), self.cap, self.text, B, T, Et, Et, V)       # lc_NIC.py:233
+            if training and self.r_text > 0:
+                be.dropout(self.text, self.text, n, Et, Et, B, Et, 0, self.r_text, sd, S_TEXT, 0, ds)
         if training and self.r_lstm > 0:       # text half of the per-call LSTM input mask over (B,1,D+Et)
             be.dropout(self.text, self.text, n, Et, Et, 0, D + Et, D, self.r_lstm, sd, S_LSTM_IN, 0, ds,
                        rows_per_site=B)
@@ -443,7 +451,7 @@ class NIC(ModelBase):
         self.gemm_sk(self.dinter, a.p("time_distributed_nonlinear/kernel"), self.dHs, n, U, H, H, H, U, transB=True)
         if self.r_lstm > 0:
             be.dropout(self.dHs, self.dHs, n, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds, rows_per_site=B)
-        self.dP.zero_(); self.dF.zero_(); self.dvb.zero_()
+        self.datt.zero_()
         Wl, Ur = a.p("lstm/kernel"), a.p("lstm/recurrent_kernel")
         W2, v = a.p("attention/W2/kernel"), a.p("attention/V/kernel")
         for i in range(T - 1, -1, -1):
