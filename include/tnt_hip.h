@@ -76,6 +76,12 @@ int32_t tnt_gemm_f32_tile(const float* A, const float* B, float* C, const float*
  * the T per-timestep masks of lc_NIC.py:255-256.
  * The stream step is step + *step_dev (step_dev nullable): a device-resident counter
  * lets a captured hipGraph replay with a fresh mask each time (see tnt_step_tick). */
+/* Keep-masks only (no data pass): out[nsites][n/4] bytes, bit j of byte g of block k = element 4g+j of site site0+k is
+ * kept -- the same Philox stream (seed, site, step + *step_dev, element) as tnt_dropout_f32, n % 4 == 0.  One launch
+ * produces the attention-dropout masks of all T timesteps (attention.py:36, sites S_ATTN + t) off the serial chain;
+ * tnt_attention_step_{fwd,bwd}_f32 take them through `keep4`. */
+int32_t tnt_dropout_mask4_u8(uint8_t* out, int64_t n, int32_t nsites, float rate, uint64_t seed, uint32_t site0,
+                             uint32_t step, const uint32_t* step_dev, void* stream);
 int32_t tnt_dropout_f32(const float* x, float* y, int32_t rows, int32_t cols, int32_t ld,
                         int32_t tmajor_B, int32_t lwidth, int32_t lcol0, int32_t rows_per_site,
                         float rate, uint64_t seed, uint32_t site, uint32_t step,
@@ -325,7 +331,9 @@ int32_t tnt_locally_dense_bwd_f32(const float* x, int32_t ldx, const int32_t* id
  * P = LeakyReLU(F @ W1 + b1) is loop-invariant and computed once with tnt_gemm_f32.
  * fwd: q = LeakyReLU(h @ W2 + b2); s = tanh(P + q); dropout(s); e = s.v + bv;
  *      alpha = softmax_R(e); ctx = sum_R alpha*F; ctx_d = LSTM-input dropout of ctx.
- *      Saves qpre[B][A], alpha[B][R]. s_out (nullable) [B][R][A] post-dropout. */
+ *      Saves qpre[B][A], alpha[B][R]. s_out (nullable) [B][R][A] post-dropout.
+ *      keep4 (nullable, fwd and bwd): this step's [B*R*A/4] bytes of tnt_dropout_mask4_u8 for (seed, site_attn, step);
+ *      when given (A % 4 == 0) the kernels read the bits instead of running Philox -- bit-identical results. */
 int32_t tnt_attention_step_fwd_f32(const float* h, const float* F, const float* P,
                                    const float* W2, const float* b2, const float* v,
                                    const float* bv, float* qpre, float* alpha, float* ctx,
@@ -333,7 +341,7 @@ int32_t tnt_attention_step_fwd_f32(const float* h, const float* F, const float* 
                                    int32_t A, int32_t U, float slope, float rate_attn,
                                    float rate_in, int32_t in_lwidth, uint64_t seed,
                                    uint32_t site_attn, uint32_t site_in, uint32_t step,
-                                   const uint32_t* step_dev, void* stream);
+                                   const uint32_t* step_dev, const uint8_t* keep4, void* stream);
 /* bwd: given dctx_d (grad wrt the dropped ctx), accumulates dP[B][R][A] += , dF[B][R][D] +=,
  * dvb[B][A+1] += (per-sample partials of dV and dbV), writes dqpre[B][A] and
  * dh[B][U] = dqpre @ W2^T.  If dz != NULL the context gradient is computed in-kernel as
@@ -348,7 +356,8 @@ int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* F, const fl
                                    float rate_in, int32_t in_lwidth, uint64_t seed,
                                    uint32_t site_attn, uint32_t site_in, uint32_t step,
                                    const uint32_t* step_dev, const float* dz, const float* Wc,
-                                   const float* dctx_part, int32_t nparts, void* stream);
+                                   const float* dctx_part, int32_t nparts, const uint8_t* keep4,
+                                   void* stream);
 
 /* attention "coverage" metric (lc_NIC.py:365-367): mean over (T,R) of
  * (1 - sum_b alpha[t][b][r])^2.  alpha is [T][B][R]. */

@@ -20,6 +20,7 @@ I32, I64, U32, U64, F32 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_floa
 SIGNATURES = {
     "tnt_version": [],
     "tnt_gemm_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, F32, I32, I32, P, P],
+    "tnt_dropout_mask4_u8": [P, I64, I32, F32, U64, U32, U32, P, P],
     "tnt_dropout_f32": [P, P, I32, I32, I32, I32, I32, I32, I32, F32, U64, U32, U32, P, P],
     "tnt_act_bwd_f32": [P, P, P, I64, I32, F32, P],
     "tnt_bn_nchunk": [I32],
@@ -58,9 +59,9 @@ SIGNATURES = {
     "tnt_locally_dense_fwd_f32": [P, I32, P, P, P, P, P, P, I32, I32, I32, F32, P],
     "tnt_locally_dense_bwd_f32": [P, I32, P, P, P, P, P, I32, I32, I32, P],
     "tnt_attention_step_fwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, F32,
-                                   I32, U64, U32, U32, U32, P, P],
+                                   I32, U64, U32, U32, U32, P, P, P],
     "tnt_attention_step_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, F32,
-                                   I32, U64, U32, U32, U32, P, P, P, P, I32, P],
+                                   I32, U64, U32, U32, U32, P, P, P, P, I32, P, P],
     "tnt_attention_metric_f32": [P, P, P, I32, I32, I32, I64, P],
 }
 

@@ -51,6 +51,7 @@ struct AttArgs {
   int B, R, D, A, U, in_lwidth;
   float slope, rate_attn, rate_in;
   uint64_t seed; uint32_t site_attn, site_in, step; const uint32_t* step_dev;
+  const uint8_t* keep4;       // nullable: attention-dropout keep bits from tnt_dropout_mask4_u8 (wide kernels only)
 };
 
 // q[a] = LeakyReLU(sum_k h[k] W2[k][a] + b2[a]); threads = (a = tid % AP, part = tid / AP)
@@ -391,12 +392,15 @@ __global__ __launch_bounds__(WT) void attention_fwd_wide_kernel(AttArgs g) {
   // ---- scores e[r] = sum_a dropout(tanh(P + q)) v + bv
   {
     float4 pv[MAXP];
+    uint32_t mk[MAXP];
     const bool cok = c4 * 4 < A;
+    const bool stored = g.keep4 != nullptr && g.rate_attn > 0.f;
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
       const int r = p * RPP + rl;
       pv[p] = (cok && r < R) ? *reinterpret_cast<const float4*>(g.P + ((long)b * R + r) * A + c4 * 4)
                              : make_float4(0.f, 0.f, 0.f, 0.f);
+      mk[p] = (stored && cok && r < R) ? g.keep4[(((long)b * R + r) * A + c4 * 4) >> 2] : 0u;
     }
     const float4 q4 = cok ? *reinterpret_cast<const float4*>(&qs[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 v4 = cok ? *reinterpret_cast<const float4*>(g.v + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -410,7 +414,8 @@ __global__ __launch_bounds__(WT) void attention_fwd_wide_kernel(AttArgs g) {
         float s0 = tnt_tanh(pv[p].x + q4.x), s1 = tnt_tanh(pv[p].y + q4.y), s2 = tnt_tanh(pv[p].z + q4.z), s3 = tnt_tanh(pv[p].w + q4.w);
         if (g.rate_attn > 0.f) {
           bool k[4];
-          tnt_keep4((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step, k);
+          if (stored) { k[0] = mk[p] & 1u; k[1] = mk[p] & 2u; k[2] = mk[p] & 4u; k[3] = mk[p] & 8u; }
+          else tnt_keep4((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step, k);
           s0 = k[0] ? s0 * scale_a : 0.f; s1 = k[1] ? s1 * scale_a : 0.f;
           s2 = k[2] ? s2 * scale_a : 0.f; s3 = k[3] ? s3 * scale_a : 0.f;
         }
@@ -570,6 +575,8 @@ __global__ __launch_bounds__(WT) void attention_bwd_wide_kernel(AttArgs g) {
     const float4 v4 = cok ? *reinterpret_cast<const float4*>(g.v + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float scale_a = g.rate_attn > 0.f ? 1.f / (1.f - g.rate_attn) : 1.f;
     float4 pv[MAXP], dpv[MAXP];
+    uint32_t mk[MAXP];
+    const bool stored = g.keep4 != nullptr && g.rate_attn > 0.f;
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
       const int r = p * RPP + rl;
@@ -577,6 +584,7 @@ __global__ __launch_bounds__(WT) void attention_bwd_wide_kernel(AttArgs g) {
       const long e = ((long)b * R + r) * A + c4 * 4;
       pv[p] = ok ? *reinterpret_cast<const float4*>(g.P + e) : make_float4(0.f, 0.f, 0.f, 0.f);
       dpv[p] = ok ? *reinterpret_cast<const float4*>(g.dP + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      mk[p] = (stored && ok) ? g.keep4[e >> 2] : 0u;
     }
     float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), dq = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -586,7 +594,8 @@ __global__ __launch_bounds__(WT) void attention_bwd_wide_kernel(AttArgs g) {
       const long e = ((long)b * R + r) * A + c4 * 4;
       const float s0 = tnt_tanh(pv[p].x + q4.x), s1 = tnt_tanh(pv[p].y + q4.y), s2 = tnt_tanh(pv[p].z + q4.z), s3 = tnt_tanh(pv[p].w + q4.w);
       bool k[4] = {true, true, true, true};
-      if (g.rate_attn > 0.f) tnt_keep4((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step, k);
+      if (stored) { k[0] = mk[p] & 1u; k[1] = mk[p] & 2u; k[2] = mk[p] & 4u; k[3] = mk[p] & 8u; }
+      else if (g.rate_attn > 0.f) tnt_keep4((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step, k);
       const float k0 = k[0] ? scale_a : 0.f, k1 = k[1] ? scale_a : 0.f, k2 = k[2] ? scale_a : 0.f, k3 = k[3] ? scale_a : 0.f;
       const float de = als[r];
       dv.x += s0 * k0 * de; dv.y += s1 * k1 * de; dv.z += s2 * k2 * de; dv.w += s3 * k3 * de;
@@ -650,9 +659,11 @@ extern "C" int32_t tnt_attention_step_fwd_f32(const float* h, const float* F, co
                                               float* alpha, float* ctx, float* ctx_d, float* s_out, int32_t B, int32_t R,
                                               int32_t D, int32_t A, int32_t U, float slope, float rate_attn,
                                               float rate_in, int32_t in_lwidth, uint64_t seed, uint32_t site_attn,
-                                              uint32_t site_in, uint32_t step, const uint32_t* step_dev, void* stream) {
+                                              uint32_t site_in, uint32_t step, const uint32_t* step_dev,
+                                              const uint8_t* keep4, void* stream) {
   if (int32_t rc = check_dims(B, R, D, A, U)) return rc;
   AttArgs g{};
+  g.keep4 = keep4;
   g.h = h; g.F = F; g.P = P; g.W2 = W2; g.b2 = b2; g.v = v; g.bv = bv; g.qpre = qpre; g.alpha = alpha; g.ctx = ctx;
   g.ctx_d = ctx_d; g.s_out = s_out; g.B = B; g.R = R; g.D = D; g.A = A; g.U = U; g.in_lwidth = in_lwidth;
   g.slope = slope; g.rate_attn = rate_attn; g.rate_in = rate_in; g.seed = seed; g.site_attn = site_attn;
@@ -677,13 +688,14 @@ extern "C" int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* 
                                               int32_t A, int32_t U, float slope, float rate_attn, float rate_in,
                                               int32_t in_lwidth, uint64_t seed, uint32_t site_attn, uint32_t site_in,
                                               uint32_t step, const uint32_t* step_dev, const float* dz, const float* Wc,
-                                              const float* dctx_part, int32_t nparts, void* stream) {
+                                              const float* dctx_part, int32_t nparts, const uint8_t* keep4,
+                                              void* stream) {
   if (int32_t rc = check_dims(B, R, D, A, U)) return rc;
   if (dz != nullptr && (U % 16 != 0 || Wc == nullptr)) return TNT_BADARG(27);
   if (dz == nullptr && dctx_d == nullptr && dctx_part == nullptr) return TNT_BADARG(1);
   if (dctx_part != nullptr && (nparts <= 0 || nparts * D > 1024)) return TNT_BADARG(30);
   AttArgs g{};
-  g.dz = dz; g.Wc = Wc; g.dctx_part = dctx_part; g.nparts = nparts;
+  g.dz = dz; g.Wc = Wc; g.dctx_part = dctx_part; g.nparts = nparts; g.keep4 = keep4;
   g.dctx_d = dctx_d; g.F = F; g.P = P; g.W2 = W2; g.v = v; g.qpre_in = qpre; g.alpha_in = alpha; g.dP = dP; g.dF = dF;
   g.dvb = dvb; g.dqpre = dqpre; g.dh = dh; g.B = B; g.R = R; g.D = D; g.A = A; g.U = U; g.in_lwidth = in_lwidth;
   g.slope = slope; g.rate_attn = rate_attn; g.rate_in = rate_in; g.seed = seed; g.site_attn = site_attn;

@@ -63,6 +63,21 @@ __global__ __launch_bounds__(256) void dropout4_kernel(DropArgs a) {
   }
 }
 
+// Keep-masks only, one byte per 4 consecutive logical elements (bit j = element 4g + j kept), for `nsites`
+// consecutive sites of n4 groups each.  Philox4x32-10 is 40 quarter-rate integer multiplies per call: ~2 us inside each
+// of the per-timestep attention kernels, which run on B of the 256 CUs on the serial chain, but ~10 us for all T
+// timesteps at once when spread over the whole chip (and the backward reuses the bytes).
+__global__ __launch_bounds__(256) void dropout_mask4_kernel(uint8_t* out, long n4, long total, float rate, uint64_t seed,
+                                                            uint32_t site0, uint32_t step, const uint32_t* step_dev) {
+  const uint32_t st = step + (step_dev ? step_dev[0] : 0u);
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+    const long k = g / n4, gi = g - k * n4;
+    bool kp[4];
+    tnt_keep4((uint64_t)gi * 4u, rate, seed, site0 + (uint32_t)k, st, kp);
+    out[g] = (uint8_t)((kp[0] ? 1 : 0) | (kp[1] ? 2 : 0) | (kp[2] ? 4 : 0) | (kp[3] ? 8 : 0));
+  }
+}
+
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* pre, const float* dy, float* dx, long n, int act,
                                                       float slope) {
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256)
@@ -361,6 +376,19 @@ extern "C" int32_t tnt_dropout_f32(const float* x, float* y, int32_t rows, int32
     hipLaunchKernelGGL(dropout4_kernel, dim3(ew_blocks((long)rows * (cols / 4))), dim3(256), 0, tnt_stream(stream), a);
   else
     hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks((long)rows * cols)), dim3(256), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_dropout_mask4_u8(uint8_t* out, int64_t n, int32_t nsites, float rate, uint64_t seed,
+                                       uint32_t site0, uint32_t step, const uint32_t* step_dev, void* stream) {
+  if (n <= 0 || nsites <= 0) return 0;
+  if (n % 4 != 0) return TNT_BADARG(2);
+  const long n4 = n / 4, total = n4 * nsites;
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dropout_mask4_kernel, dim3((unsigned)blocks), dim3(256), 0, tnt_stream(stream), out, n4, total, rate,
+                     seed, site0, step, step_dev);
   TNT_LAUNCH_CHECK();
   return 0;
 }

@@ -291,6 +291,11 @@ class NIC(ModelBase):
         self.datt = f(ovb + pad4(B * (A + 1)))
         self.dP, self.dF = self.datt[:B * R * A].view(B * R, A), self.datt[oF:oF + B * R * D].view(B, R, D)
         self.dvb, self.dqpre = self.datt[ovb:ovb + B * (A + 1)].view(B, A + 1), f(T, B, A)
+        # attention-dropout keep bits of all T timesteps (4 per byte), produced by ONE chip-wide launch per step instead
+        # of Philox inside every per-timestep kernel on the serial chain (2 us forward + 2.4 us backward per timestep)
+        self._keep_stored = self.r_attn > 0 and A % 4 == 0
+        self.att_keep = (torch.zeros(T, B * R * A // 4, dtype=torch.uint8, device=self.device)
+                         if self._keep_stored else None)
         self.dtext = f(n, Et)
         self.dbn = f(B * R, D)
         nch = max(self.be.bn_nchunk(B * R), self.be.bn_nchunk(n))
@@ -369,7 +374,8 @@ class NIC(ModelBase):
                               a.p("attention/V/kernel"), a.p("attention/V/bias"), self.qpre[i], self.alpha[i],
                               self.ctx[i], self.ctx_d[i], s_out, B, R, D, A, U, 0.2,
                               self.r_attn if training else 0.0, self.r_lstm if training else 0.0, D + Et, self.seed,
-                              S_ATTN + i, S_LSTM_IN + i, 0, self.drop_step)
+                              S_ATTN + i, S_LSTM_IN + i, 0, self.drop_step,
+                              keep4=self.att_keep[i] if (training and self._keep_stored) else None)
         be.lstm_step_fwd(self.XZ[i * B:(i + 1) * B], self.Hs[i], self.Cs[i], a.p("lstm/recurrent_kernel"),
                          self.ctx_d[i], Wl[:D], D, None, 0, 0, None, self.Hs[i + 1], self.Cs[i + 1], None,
                          self.gates[i], B, U, xz_bias=xz_bias)
@@ -393,6 +399,8 @@ class NIC(ModelBase):
         Wl = a.p("lstm/kernel")
         # text half of the input projection for all T steps: one epilogue-free GEMM; bias added in the step kernel
         self.gemm_sk(self.text, Wl[D:], self.XZ, n, 4 * U, Et, Et, 4 * U, 4 * U)
+        if training and self._keep_stored:
+            be.dropout_mask4(self.att_keep, B * R * A, T, self.r_attn, sd, S_ATTN, 0, ds)
         for i in range(T):                                                                      # :244-256
             self._decode_step(i, B, training, xz_bias=a.p("lstm/bias"))
         hs = self.Hs[1:].view(n, U)
@@ -468,12 +476,12 @@ class NIC(ModelBase):
                 be.attention_step_bwd(None, self.F, self.P, W2, v, self.qpre[i], self.alpha[i], self.dP, self.dF,
                                       self.dvb, self.dqpre[i], self.dh_att, B, R, D, A, U, 0.2, self.r_attn, self.r_lstm,
                                       D + Et, sd, S_ATTN + i, S_LSTM_IN + i, 0, ds, dctx_part=self.dctx_part,
-                                      nparts=U // 16)
+                                      nparts=U // 16, keep4=self.att_keep[i] if self._keep_stored else None)
             else:
                 be.attention_step_bwd(None, self.F, self.P, W2, v, self.qpre[i], self.alpha[i], self.dP, self.dF,
                                       self.dvb, self.dqpre[i], self.dh_att, B, R, D, A, U, 0.2, self.r_attn, self.r_lstm,
                                       D + Et, sd, S_ATTN + i, S_LSTM_IN + i, 0, ds, dz=self.dZ[i * B:(i + 1) * B],
-                                      Wc=Wl[:D])
+                                      Wc=Wl[:D], keep4=self.att_keep[i] if self._keep_stored else None)
         hprev = self.Hs[:T].view(n, U)
         gWl = a.g("lstm/kernel")
         self.gemm_sk(hprev, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True)

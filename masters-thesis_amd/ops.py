@@ -68,6 +68,11 @@ class HipBackend:
         self._call(self.lib.tnt_dropout_f32, "tnt_dropout_f32", _p(x), _p(y), rows, cols, ld, tmajor_B, lwidth, lcol0, rows_per_site,
                                             rate, seed, site, step, _p(step_dev), self._s())
 
+    def dropout_mask4(self, out, n, nsites, rate, seed, site0, step, step_dev=None):
+        """uint8 keep-masks (4 elements per byte) of ``nsites`` consecutive dropout sites, no data pass."""
+        self._call(self.lib.tnt_dropout_mask4_u8, "tnt_dropout_mask4_u8", _p(out), n, nsites, rate, int(seed), int(site0), int(step), _p(step_dev),
+                   self._s())
+
     def act_bwd(self, pre, dy, dx, n, act, slope=0.2):
         self._call(self.lib.tnt_act_bwd_f32, "tnt_act_bwd_f32", _p(pre), _p(dy), _p(dx), n, act, slope, self._s())
 
@@ -215,20 +220,20 @@ class HipBackend:
                                                       D, self._s())
 
     def attention_step_fwd(self, h, F, P, W2, b2, v, bv, qpre, alpha, ctx, ctx_d, s_out, B, R, D, A, U, slope,
-                           rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None):
+                           rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None, keep4=None):
         self._call(self.lib.tnt_attention_step_fwd_f32, "tnt_attention_step_fwd_f32", _p(h), _p(F), _p(P), _p(W2), _p(b2), _p(v), _p(bv), _p(qpre),
                                                        _p(alpha), _p(ctx), _p(ctx_d), _p(s_out), B, R, D, A, U, slope,
                                                        rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step,
-                                                       _p(step_dev), self._s())
+                                                       _p(step_dev), _p(keep4), self._s())
 
     def attention_step_bwd(self, dctx_d, F, P, W2, v, qpre, alpha, dP, dF, dvb, dqpre, dh, B, R, D, A, U, slope,
                            rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None, dz=None,
-                           Wc=None, dctx_part=None, nparts=0):
+                           Wc=None, dctx_part=None, nparts=0, keep4=None):
         self._call(self.lib.tnt_attention_step_bwd_f32, "tnt_attention_step_bwd_f32", _p(dctx_d), _p(F), _p(P), _p(W2), _p(v), _p(qpre), _p(alpha),
                                                        _p(dP), _p(dF), _p(dvb), _p(dqpre), _p(dh), B, R, D, A, U,
                                                        slope, rate_attn, rate_in, in_lwidth, seed, site_attn, site_in,
                                                        step, _p(step_dev), _p(dz), _p(Wc), _p(dctx_part), nparts,
-                                                       self._s())
+                                                       _p(keep4), self._s())
 
     def attention_metric(self, alpha, out, work, T, B, R, tstride=0):
         self._call(self.lib.tnt_attention_metric_f32, "tnt_attention_metric_f32", _p(alpha), _p(out), _p(work), T, B, R, tstride, self._s())

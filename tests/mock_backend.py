@@ -80,6 +80,23 @@ class MockBackend:
         scale = np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
         ys[...] = np.where(k, xs * scale, np.float32(0))
 
+    def dropout_mask4(self, out, n, nsites, rate, seed, site0, step, step_dev=None):
+        if step_dev is not None:
+            step = (step + int(step_dev[0])) & 0xFFFFFFFF
+        o = out.view(-1).numpy()
+        for k in range(nsites):
+            bits = _keep(np.arange(n), rate, seed, site0 + k, step).reshape(n // 4, 4)
+            o[k * (n // 4):(k + 1) * (n // 4)] = (bits * np.array([1, 2, 4, 8])).sum(1).astype(np.uint8)
+
+    @staticmethod
+    def _check_keep4(keep4, keep, n):
+        """The stored bits handed to an attention step must be the Philox mask that step would have generated."""
+        if keep4 is None or keep is None:
+            return
+        by = keep4.view(-1).numpy()[:n // 4]
+        bits = ((by[:, None] >> np.arange(4)[None, :]) & 1).astype(bool).reshape(-1)
+        assert np.array_equal(bits, keep.reshape(-1)), "keep4 does not match the step's dropout stream"
+
     def act_bwd(self, pre, dy, dx, n, act, slope=0.2):
         flat(dx)[:n] = O.act_bwd(flat(pre)[:n].astype(np.float64), flat(dy)[:n].astype(np.float64), act, slope)
 
@@ -416,11 +433,12 @@ class MockBackend:
         mat(db, R, D, D)[...] = dp.sum(0)
 
     def attention_step_fwd(self, h, F, P, W2, b2, v, bv, qpre, alpha, ctx, ctx_d, s_out, B, R, D, A, U, slope,
-                           rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None):
+                           rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None, keep4=None):
         if step_dev is not None:
             step = (step + int(step_dev[0])) & 0xFFFFFFFF
         f64 = lambda t, *s: flat(t)[:int(np.prod(s))].reshape(*s).astype(np.float64)
         keep = _keep(np.arange(B * R * A).reshape(B, R, A), rate_attn, seed, site_attn, step) if rate_attn > 0 else None
+        self._check_keep4(keep4, keep, B * R * A)
         (cx, al, sd), cache = O.attention_step_fwd(f64(h, B, U), f64(F, B, R, D), f64(P, B, R, A), f64(W2, U, A),
                                                    f64(b2, A), f64(v, A)[:, None], f64(bv, 1), keep, rate_attn, slope)
         flat(qpre)[:B * A] = cache[1].reshape(-1)
@@ -434,11 +452,12 @@ class MockBackend:
 
     def attention_step_bwd(self, dctx_d, F, P, W2, v, qpre, alpha, dP, dF, dvb, dqpre, dh, B, R, D, A, U, slope,
                            rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None, dz=None,
-                           Wc=None, dctx_part=None, nparts=0):
+                           Wc=None, dctx_part=None, nparts=0, keep4=None):
         if step_dev is not None:
             step = (step + int(step_dev[0])) & 0xFFFFFFFF
         f64 = lambda t, *s: flat(t)[:int(np.prod(s))].reshape(*s).astype(np.float64)
         keep = _keep(np.arange(B * R * A).reshape(B, R, A), rate_attn, seed, site_attn, step) if rate_attn > 0 else None
+        self._check_keep4(keep4, keep, B * R * A)
         kin = _keep(np.arange(B)[:, None] * in_lwidth + np.arange(D)[None, :], rate_in, seed, site_in, step) if rate_in > 0 else None
         if dctx_part is not None:
             raw = f64(dctx_part, nparts, B, D).sum(0)

@@ -481,6 +481,49 @@ def test_attention_step(be, B, R, D, A, U, rate):
         close(dhd, dh2); close(dPd2, dsum2); close(dFd2, dF2)
 
 
+def test_dropout_mask4_bit_exact(be):
+    """tnt_dropout_mask4_u8: the stored keep bits are the Philox stream of tnt_dropout_f32 / oracle.philox, per site."""
+    n, nsites, rate, seed, site0, step = 64 * 90 * 32, 3, 0.2, 1234567890123, 16, 4
+    out = torch.zeros(nsites, n // 4, dtype=torch.uint8, device="cuda")
+    step_dev = torch.tensor([3], dtype=torch.int32, device="cuda")
+    be.dropout_mask4(out, n, nsites, rate, seed, site0, step, step_dev)
+    got = out.cpu().numpy()
+    for k in range(nsites):
+        want = keep_mask((n,), rate, seed, site0 + k, step + 3).reshape(n // 4, 4)
+        bits = ((got[k][:, None] >> np.arange(4)[None, :]) & 1).astype(bool)
+        assert np.array_equal(bits, want), k
+    assert abs(1.0 - np.unpackbits(got).sum() * 2 / (nsites * n) * 0.5 - rate) < 0.01     # ~rate of the bits are 0
+
+
+@pytest.mark.parametrize("B,R,D,A,U", [(64, 360, 32, 32, 512), (5, 100, 16, 24, 64), (3, 40, 64, 64, 128)])
+def test_attention_step_stored_mask_is_bit_identical(be, B, R, D, A, U):
+    """The attention step kernels fed with stored keep bits (keep4) against the same kernels running Philox
+    themselves: every output bit-identical, forward and backward."""
+    rng = np.random.default_rng(14)
+    f = lambda *s: torch.tensor(rng.standard_normal(s), dtype=torch.float32, device="cuda")
+    h, F, P, W2, b2, v, bv = f(B, U) * 0.5, f(B, R, D), f(B, R, A), f(U, A) * 0.05, f(A) * 0.1, f(A), f(1)
+    seed, site_a, site_i, step, lw, rate = 99, 16 + 7, 48 + 7, 2, D + 40, 0.2
+    step_dev = torch.tensor([5], dtype=torch.int32, device="cuda")
+    keep4 = torch.zeros(1, B * R * A // 4, dtype=torch.uint8, device="cuda")
+    be.dropout_mask4(keep4, B * R * A, 1, rate, seed, site_a, step, step_dev)
+    outs = []
+    for k4 in (None, keep4[0]):
+        qpre, al, cx, cxd, s_out = (torch.zeros(B, A, device="cuda"), torch.zeros(B, R, device="cuda"),
+                                    torch.zeros(B, D, device="cuda"), torch.zeros(B, D, device="cuda"),
+                                    torch.zeros(B, R, A, device="cuda"))
+        be.attention_step_fwd(h, F, P, W2, b2, v, bv, qpre, al, cx, cxd, s_out, B, R, D, A, U, 0.2, rate, rate, lw, seed,
+                              site_a, site_i, step, step_dev, keep4=k4)
+        dP, dF, dvb = torch.ones(B, R, A, device="cuda"), torch.ones(B, R, D, device="cuda"), torch.zeros(B, A + 1, device="cuda")
+        dq, dh = torch.zeros(B, A, device="cuda"), torch.zeros(B, U, device="cuda")
+        dctx_d = torch.tensor(np.random.default_rng(15).standard_normal((B, D)), dtype=torch.float32, device="cuda")
+        be.attention_step_bwd(dctx_d, F, P, W2, v, qpre, al, dP, dF, dvb, dq, dh, B, R, D, A, U, 0.2, rate, rate, lw, seed,
+                              site_a, site_i, step, step_dev, keep4=k4)
+        outs.append((qpre, al, cx, cxd, s_out, dP, dF, dvb, dq, dh))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert (outs[0][4] == 0).float().mean().item() > 0.1          # the mask really dropped something
+
+
 def test_attention_metric(be):
     rng = np.random.default_rng(13)
     T, B, R = 5, 8, 30
