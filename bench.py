@@ -28,6 +28,8 @@ MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak
 # vocabulary-head forward GEMM (one-round kernel), measured HBM bytes per launch: 2 x FETCH_SIZE(13029 KiB) +
 # WRITE_SIZE(18886 KiB), profiles/r01_gemm_head_pmc_v3.txt (algorithmic: 31.4 MB -- A 1.97 + B 10.25 read, C 19.2 written)
 PMC_TRAFFIC_BYTES = int((2 * 13029.1 + 18885.8) * 1024)
+# config 3's head GEMM (K = 256), profiles/r01_gemm_head_c3_pmc.txt
+PMC_TRAFFIC_BYTES_C3 = int((2 * 6575.1 + 18885.0) * 1024)
 
 
 def synth(rank, device):
@@ -139,10 +141,10 @@ def dominant_kernel_roofline(model, workload, steps=20):
     ach = flops / dur_s / 1e12
     # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     # separate runs, gfx950 correction of MI355X_MICROARCH.md applied): dense workload only.
-    traffic = PMC_TRAFFIC_BYTES if workload == "dense" else None
+    traffic = PMC_TRAFFIC_BYTES if workload == "dense" else PMC_TRAFFIC_BYTES_C3
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
             "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": traffic,
-            "traffic_source": "profiles/r01_gemm_head_pmc_v3.txt" if traffic else None, "kernel": name,
+            "traffic_source": "profiles/r01_gemm_head_pmc_v3.txt" if workload == "dense" else "profiles/r01_gemm_head_c3_pmc.txt", "kernel": name,
             "avg_launch_us": round(dur_s * 1e6, 2), "flops_per_launch": flops}
 
 

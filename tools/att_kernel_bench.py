@@ -4,7 +4,8 @@ import torch
 sys.path.insert(0, ".")
 import masters_thesis_amd.ops as ops
 be = ops.backend()
-B, R, D, A, U = 64, 360, 32, 32, 512
+import os
+B, R, D, A, U = int(os.environ.get("ATT_B", 64)), int(os.environ.get("ATT_R", 360)), 32, 32, 512
 f = lambda *s: torch.randn(*s, device="cuda")
 h, F, P, W2, b2, v, bv = f(B, U), f(B, R, D), f(B, R, A), f(U, A) * 0.05, f(A), f(A), f(1)
 qpre, alpha, ctx, ctx_d = f(B, A), f(B, R), f(B, D), f(B, D)
