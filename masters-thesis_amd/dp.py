@@ -133,16 +133,84 @@ class PipelinedDenseSync:
         make_grad_sync(self.world)(model)
 
 
+class PipelinedAttentionSync:
+    """DP schedule for the region-wise encoder + attention decoder (lc_nic.NIC, BASELINE config 4; also the
+    multi-subject model, whose S encoders simply widen the last bucket).  27 MB of gradients, all of them all-reduced
+    (no tensor dominates the way the dense encoder kernel does), in the four buckets backward finishes them in, each
+    issued ``async_op`` right behind the launch group that produces it and waited for only by the optimizer slice
+    that consumes it (the arena keeps the variables in reverse production order, so every bucket is one range):
+
+      A  : forward + loss + head backward             -> all-reduce head (nonlinear + softmax, 5.7 MB)
+      B1 : T-step chain backward + LSTM gradients     -> all-reduce LSTM (8.7 MB)
+      B2 : text branch, embedding scatter             -> all-reduce embedding (10.2 MB) + its sparse-norm scalar
+      B3 : attention parameters, BatchNorm, encoder   -> all-reduce {encoder, BatchNorm, attention} (2.7 MB)
+      C0 : (waits head, LSTM)        step tick; norms + clip + Adam of {LSTM, head}  (53 % of the arena)
+      C1 : (waits embedding, front)  norms + clip + Adam of the rest, L2 metric
+
+    The head bucket hides under the chain (B1, ~0.45 ms of a 1.12 ms step), the LSTM bucket under B2 + B3, the
+    embedding bucket under B3 + C0; only the small front bucket and the tail of the embedding one are exposed.
+    The generic schedule (one all-reduce of the whole arena between backward and update) exposes all 27 MB.
+    A and B1 -- the two serial T-step chains -- are hipGraphs, the short segments recorded launch plans (see
+    PipelinedDenseSync.eager; this model has ~270 launches a step, so the host cannot afford plans for the chains:
+    world-size-1 rehearsal, tools/host_overhead.py --dp --attention: 1.32 ms/step with the host at 0.81, against
+    1.35 / 0.85 with six graphs and 1.32 / 1.14 with A as a plan too; bench.py --force-dp --workload attention: 1.23 ms
+    against 1.12 for the single-graph step)."""
+    pipelined = True
+    eager = frozenset(os.environ.get("TNT_DP_EAGER", "B2,B3,C0,C1").split(","))
+
+    def __init__(self, world):
+        self.world = world
+        self._slices = None
+
+    def step(self, m, B, T):
+        a = m.arena
+        if self._slices is None:
+            e = a.entries
+            s_lstm = e["lstm/kernel"].seg
+            self._slices = (a.seg_slice(s_lstm, a.nseg), a.seg_slice(0, s_lstm))
+            self._offs = (e["emb_text/embeddings"].off, e["lstm/kernel"].off, e["time_distributed_nonlinear/kernel"].off)
+        sl_tail, sl_front = self._slices
+        emb0, lstm0, head0 = self._offs
+        ar = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+        cap = lambda key, fn: (m._run_planned if key[0][2:] in self.eager else m._run_captured)(key, fn)
+
+        cap(("dpA", B, T), lambda: (m._forward(B, T, True), m._loss_metrics(B, T, True), m._bwd_head(B, T)))
+        w_head = ar(a.grad[head0:])
+        cap(("dpB1", B, T), lambda: m._bwd_chain(B, T))
+        w_lstm = ar(a.grad[lstm0:head0])
+        cap(("dpB2", B, T), lambda: m._bwd_emb(B, T))
+        w_emb = dist.all_reduce_coalesced([a.grad[emb0:lstm0], a.sq_override], op=dist.ReduceOp.SUM, async_op=True)
+        cap(("dpB3", B, T), lambda: m._bwd_front(B, T))
+        w_front = ar(a.grad[:emb0])
+        for w in (w_head, w_lstm):
+            w.wait()
+        cap(("dpC0", B, T), lambda: (m._tick(), m._update_slice(sl_tail)))
+        for w in (w_emb, w_front):
+            w.wait()
+        cap(("dpC1", B, T), lambda: (m._update_slice(sl_front), m.be.l2_total(a.wsq, a.seg_l2, a.nseg, m.met[2:3])))
+
+    def __call__(self, model):          # not used by lc_nic.train_step (it calls step); kept for the generic protocol
+        make_grad_sync(self.world)(model)
+
+
 def attach(model, world=None, bucket_elems=None, pipelined=None):
-    """Make ``model`` data-parallel over the default process group.  The dense-encoder NIC gets the
-    pipelined schedule (PipelinedDenseSync) unless pipelined=False."""
+    """Make ``model`` data-parallel over the default process group.  The dense-encoder NIC and the attention NIC
+    (incl. its multi-subject form) get their pipelined schedules unless pipelined=False; every other model the
+    generic one (all-reduce of the whole arena between backward and update)."""
     world = dist.get_world_size() if world is None else world
     model.dp_world = world
     from .nic import NIC as DenseNIC
+    from .lc_nic import NIC as AttentionNIC
     dense = type(model) is DenseNIC          # subclasses (fc mode) have other variables -> generic schedule
+    att = isinstance(model, AttentionNIC) and hasattr(model, "_bwd_chain")
     if pipelined is None:
-        pipelined = dense
-    model.grad_sync = PipelinedDenseSync(world) if (pipelined and dense) else make_grad_sync(world, bucket_elems)
+        pipelined = dense or att
+    if pipelined and dense:
+        model.grad_sync = PipelinedDenseSync(world)
+    elif pipelined and att:
+        model.grad_sync = PipelinedAttentionSync(world)
+    else:
+        model.grad_sync = make_grad_sync(world, bucket_elems)
     model._graphs = {}
     broadcast_parameters(model)
     return model

@@ -443,8 +443,17 @@ class NIC(ModelBase):
 
     # ------------------------------------------------------------------ backward
     def _backward(self, B, T):
+        """tape.gradient (lc_NIC.py:386-387) as four launch groups, in the order the gradients become final -- the
+        data-parallel schedule (dp.PipelinedAttentionSync) issues one all-reduce bucket after each."""
+        self._bwd_head(B, T)
+        self._bwd_chain(B, T)
+        self._bwd_emb(B, T)
+        self._bwd_front(B, T)
+
+    def _bwd_head(self, B, T):
+        """vocabulary head: gradients of time_distributed_softmax / time_distributed_nonlinear, dHs."""
         be, a = self.be, self.arena
-        R, D, A, U, Et, V, H, ldV = self.R, self.D, self.A, self.U, self.Et, self.V, self.H, self.ldV
+        U, V, H, ldV = self.U, self.V, self.H, self.ldV
         n = T * B
         sd, ds = self.seed, self.drop_step
         dlog, inter, hs = self.logits, self._inter_used, self._hs_used
@@ -459,6 +468,13 @@ class NIC(ModelBase):
         self.gemm_sk(self.dinter, a.p("time_distributed_nonlinear/kernel"), self.dHs, n, U, H, H, H, U, transB=True)
         if self.r_lstm > 0:
             be.dropout(self.dHs, self.dHs, n, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds, rows_per_site=B)
+
+    def _bwd_chain(self, B, T):
+        """the T-step chain (LSTM step backward -> attention step backward) and the LSTM parameter gradients."""
+        be, a = self.be, self.arena
+        R, D, A, U, Et = self.R, self.D, self.A, self.U, self.Et
+        n = T * B
+        sd, ds = self.seed, self.drop_step
         self.datt.zero_()
         Wl, Ur = a.p("lstm/kernel"), a.p("lstm/recurrent_kernel")
         W2, v = a.p("attention/W2/kernel"), a.p("attention/V/kernel")
@@ -488,6 +504,14 @@ class NIC(ModelBase):
         self.gemm_sk(self.text, self.dZ, gWl[D:], Et, 4 * U, n, Et, 4 * U, 4 * U, transA=True)
         self.gemm_sk(self.ctx_d, self.dZ, gWl[:D], D, 4 * U, n, D, 4 * U, 4 * U, transA=True)
         be.colsum(self.dZ, a.g("lstm/bias"), n, 4 * U, 4 * U, self.work)
+
+    def _bwd_emb(self, B, T):
+        """text branch: dtext = dZ Wl_text^T, its dropouts, the embedding scatter (+ IndexedSlices norm)."""
+        be, a = self.be, self.arena
+        D, U, Et, V = self.D, self.U, self.Et, self.V
+        n = T * B
+        sd, ds = self.seed, self.drop_step
+        Wl = a.p("lstm/kernel")
         self.gemm_sk(self.dZ, Wl[D:], self.dtext, n, Et, 4 * U, 4 * U, 4 * U, Et, transB=True)
         if self.r_lstm > 0:
             be.dropout(self.dtext, self.dtext, n, Et, Et, 0, D + Et, D, self.r_lstm, sd, S_LSTM_IN, 0, ds,
@@ -496,6 +520,14 @@ class NIC(ModelBase):
             be.dropout(self.dtext, self.dtext, n, Et, Et, B, Et, 0, self.r_text, sd, S_TEXT, 0, ds)
         sqo = a.sq_override[self.emb_seg:self.emb_seg + 1]
         be.embedding_bwd(self.dtext, self.cap, a.g("emb_text/embeddings"), sqo, self.rowsq, B, T, Et, Et, V)
+
+    def _bwd_front(self, B, T):
+        """attention parameters, then BatchNorm / region-wise encoder backward."""
+        be, a = self.be, self.arena
+        R, D, A, U = self.R, self.D, self.A, self.U
+        n = T * B
+        sd, ds = self.seed, self.drop_step
+        hprev = self.Hs[:T].view(n, U)
         # attention parameters
         self.gemm_sk(hprev, self.dqpre, a.g("attention/W2/kernel"), U, A, n, U, A, A, transA=True)
         be.colsum(self.dqpre, a.g("attention/W2/bias"), n, A, A, self.work)
@@ -564,6 +596,8 @@ class NIC(ModelBase):
         self._sync_lr()
         if self.grad_sync is None:
             self._run_captured(("train", B, T), lambda: (self._train_graph(B, T), self._update_graph()))
+        elif getattr(self.grad_sync, "pipelined", False):
+            self.grad_sync.step(self, B, T)
         else:
             self._run_captured(("train_fb", B, T), lambda: self._train_graph(B, T))
             self.grad_sync(self)

@@ -35,6 +35,7 @@ def _worker(rank, world, port, kind, q):
         local = tuple(a[sl] for a in data)
         m = model.train_step((local, tgt[sl]))
         out.append({k: float(v) for k, v in dp.allreduce_metrics(m).items()})
+    out.append(type(model.grad_sync).__name__)
     q.put((rank, {k: v for k, v in model.get_weights_dict().items()}, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -74,6 +75,8 @@ def test_dp2_equals_single_process(kind):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    # both model families run their pipelined (bucket-per-launch-group) schedule, not the generic fallback
+    assert res[0][1][-1] == {"nic": "PipelinedDenseSync", "lcnic": "PipelinedAttentionSync"}[kind]
     # replicas identical
     for k in res[0][0]:
         assert np.array_equal(res[0][0][k], res[1][0][k]), k

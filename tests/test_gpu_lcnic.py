@@ -104,3 +104,41 @@ def test_full_size_properties():
         assert abs(ls[0] - np.log(V)) < 0.5 and ls[-1] < ls[0]
         losses[use_graph] = ls
     assert np.allclose(losses[False], losses[True], rtol=1e-6)
+
+
+def test_pipelined_dp_schedule_world1_equals_single_gpu_step():
+    """dp.PipelinedAttentionSync (four all-reduce buckets behind four backward launch groups, the update in four arena
+    slices, segments replayed as launch plans / one hipGraph) at world size 1 over RCCL trains exactly like the
+    single-GPU step, dropout and stored attention keep-masks included."""
+    import socket
+    import torch.distributed as dist
+    from masters_thesis_amd import dp
+    from masters_thesis_amd.optimizers import Adam
+    dims = DIMS[1]
+    rates = (0.1, 0.2, 0.2, 0.2, 0.2, 0.2)
+    B, N, R, D, A, U, Et, V, T = dims
+    a, orc = build(np.random.default_rng(77), rates, dims)
+    b, _ = build(np.random.default_rng(77), rates, dims)
+    for k, v in orc.p.items():
+        b.set_weight(k, v)
+    for m in (a, b):
+        m.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        dp.attach(b, 1)
+        assert isinstance(b.grad_sync, dp.PipelinedAttentionSync)
+        rng = np.random.default_rng(6)
+        for step in range(5):
+            data, tgt = synth_batch(B, N, T, V, U, rng)
+            ra, rb = a.train_step((data, tgt)).as_floats(), b.train_step((data, tgt)).as_floats()
+            for k in ra:
+                assert abs(ra[k] - rb[k]) <= 1e-6 * max(1.0, abs(ra[k])), (step, k, ra, rb)
+        torch.cuda.synchronize()
+        d = (a.arena.theta - b.arena.theta).abs().max().item()
+        assert d <= 1e-7, d
+    finally:
+        dist.destroy_process_group()
