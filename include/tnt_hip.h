@@ -273,6 +273,13 @@ int32_t tnt_stage_batch_f32(const float* x, float* x_dst, const int32_t* cap, in
                             const int32_t* tgt, int32_t* tgt_tmajor, const float* a0, float* h0,
                             const float* c0, float* c0_dst, int32_t B, int32_t T, int32_t N, int32_t ldx,
                             int32_t U, float* xT_dst, int32_t ldt, void* stream);
+/* Same staging for betas that crossed PCIe as IEEE half (x_half: (B,N) uint16 bit patterns, 8-byte aligned when
+ * N % 4 == 0): widened to float in the same pass.  Opt-in "fp16 on-wire" input of data.PinnedPrefetcher
+ * (at full-cortex width, N = 327 684, the 84 MB float batch is what bounds the step). */
+int32_t tnt_stage_batch_h16(const uint16_t* x_half, float* x_dst, const int32_t* cap, int32_t* cap_dst,
+                            const int32_t* tgt, int32_t* tgt_tmajor, const float* a0, float* h0,
+                            const float* c0, float* c0_dst, int32_t B, int32_t T, int32_t N, int32_t ldx,
+                            int32_t U, float* xT_dst, int32_t ldt, void* stream);
 
 /* ---- optimizer: per-variable clipnorm + Adam / SGD over a flat parameter arena --
  * (main.py:97,100-102; lc_NIC.py:389).  The arena is cut by the host into

@@ -4,6 +4,7 @@
 // LayerNormalization (layers.py:41), bias gradients of every Dense.
 // All reductions are fixed-order (no float atomics) so results are bitwise reproducible.
 #include "tnt_common.h"
+#include <hip/hip_fp16.h>
 #include "tnt_rng.h"
 
 namespace {
@@ -304,13 +305,26 @@ __global__ __launch_bounds__(1024) void sum2_kernel(const float* x0, float* out0
 
 // One launch for the per-step input staging of a batch that is already on the device
 // (data_generator_guse.py:156-171 tuple -> the static buffers of the captured step).
+// XT = float, or __half when the betas crossed PCIe as IEEE half ("fp16 on-wire", SURVEY 8f rank 1: at full-cortex
+// width the 84 MB float batch is what bounds the step); the widening to float happens here, in the same pass.
+template <typename XT>
 struct StageArgs {
-  const float* x; float* xd; const int* cap; int* capd; const int* tgt; int* tgtd;
+  const XT* x; float* xd; const int* cap; int* capd; const int* tgt; int* tgtd;
   const float* a0; float* h0; const float* c0; float* c0d;
   int B, T, N, ldx, U;
   float* xT; int ldt; int ncopy;      // optional voxel-major copy xT[N][ldt] (blocks >= ncopy transpose 64x64 tiles)
 };
-__global__ __launch_bounds__(256) void stage_batch_kernel(StageArgs a) {
+__device__ __forceinline__ float stage_ld(const float* p) { return *p; }
+__device__ __forceinline__ float stage_ld(const __half* p) { return __half2float(*p); }
+__device__ __forceinline__ float4 stage_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 stage_ld4(const __half* p) {          // 8-byte aligned: 4 halves
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  const __half2 lo = *reinterpret_cast<const __half2*>(&u.x), hi = *reinterpret_cast<const __half2*>(&u.y);
+  const float2 a = __half22float2(lo), b = __half22float2(hi);
+  return make_float4(a.x, a.y, b.x, b.y);
+}
+template <typename XT>
+__global__ __launch_bounds__(256) void stage_batch_kernel(StageArgs<XT> a) {
   if ((int)blockIdx.x >= a.ncopy) {
     // voxel-major copy for the region-wise encoder's gather: tile = 64 voxels x 64 batch rows through LDS
     __shared__ float tile[64][65];
@@ -320,7 +334,7 @@ __global__ __launch_bounds__(256) void stage_batch_kernel(StageArgs a) {
       __syncthreads();
       for (int e = threadIdx.x; e < 64 * 64; e += 256) {
         const int r = e >> 6, c = e & 63;
-        tile[r][c] = (r0 + r < a.B && c0 + c < a.N) ? a.x[(long)(r0 + r) * a.N + c0 + c] : 0.f;
+        tile[r][c] = (r0 + r < a.B && c0 + c < a.N) ? stage_ld(a.x + (long)(r0 + r) * a.N + c0 + c) : 0.f;
       }
       __syncthreads();
       for (int e = threadIdx.x; e < 64 * 64; e += 256) {
@@ -335,12 +349,12 @@ __global__ __launch_bounds__(256) void stage_batch_kernel(StageArgs a) {
     const int n4 = a.N / 4;
     for (long e = gid; e < (long)a.B * n4; e += gsz) {
       const int r = (int)(e / n4), c = (int)(e % n4) * 4;
-      *reinterpret_cast<float4*>(a.xd + (long)r * a.ldx + c) = *reinterpret_cast<const float4*>(a.x + (long)r * a.N + c);
+      *reinterpret_cast<float4*>(a.xd + (long)r * a.ldx + c) = stage_ld4(a.x + (long)r * a.N + c);
     }
   } else {
     for (long e = gid; e < (long)a.B * a.N; e += gsz) {
       const int r = (int)(e / a.N), c = (int)(e % a.N);
-      a.xd[(long)r * a.ldx + c] = a.x[e];
+      a.xd[(long)r * a.ldx + c] = stage_ld(a.x + e);
     }
   }
   const int bt = a.B * a.T, bu = a.B * a.U;
@@ -730,21 +744,40 @@ extern "C" int32_t tnt_sum2_f32(const float* x0, float* out0, const float* x1, f
   return 0;
 }
 
+namespace {
+template <typename XT>
+int32_t stage_batch_launch(const XT* x, float* x_dst, const int32_t* cap, int32_t* cap_dst, const int32_t* tgt,
+                           int32_t* tgt_tmajor, const float* a0, float* h0, const float* c0, float* c0_dst, int32_t B,
+                           int32_t T, int32_t N, int32_t ldx, int32_t U, float* xT_dst, int32_t ldt, void* stream) {
+  if (B <= 0 || T <= 0 || N <= 0 || ldx < N || U <= 0) return TNT_BADARG(11);
+  if (xT_dst && ldt < B) return TNT_BADARG(16);
+  const bool vec = (N % 4 == 0) && (ldx % 4 == 0);
+  const bool src_ok = sizeof(XT) == 4 ? tnt_aligned16(x) : ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
+  if (vec && (!src_ok || !tnt_aligned16(x_dst))) return TNT_BADARG(1);
+  StageArgs<XT> a{x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U, xT_dst, ldt, 0};
+  a.ncopy = ew_blocks((long)B * N / (vec ? 4 : 1));
+  int nt = 0;
+  if (xT_dst) { nt = ((N + 63) / 64) * ((B + 63) / 64); if (nt > 1024) nt = 1024; }
+  hipLaunchKernelGGL(stage_batch_kernel<XT>, dim3(a.ncopy + nt), dim3(256), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
+
 extern "C" int32_t tnt_stage_batch_f32(const float* x, float* x_dst, const int32_t* cap, int32_t* cap_dst,
                                        const int32_t* tgt, int32_t* tgt_tmajor, const float* a0, float* h0,
                                        const float* c0, float* c0_dst, int32_t B, int32_t T, int32_t N, int32_t ldx,
                                        int32_t U, float* xT_dst, int32_t ldt, void* stream) {
-  if (B <= 0 || T <= 0 || N <= 0 || ldx < N || U <= 0) return TNT_BADARG(11);
-  if (xT_dst && ldt < B) return TNT_BADARG(16);
-  const bool vec = (N % 4 == 0) && (ldx % 4 == 0);
-  if (vec && (!tnt_aligned16(x) || !tnt_aligned16(x_dst))) return TNT_BADARG(1);
-  StageArgs a{x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U, xT_dst, ldt, 0};
-  a.ncopy = ew_blocks((long)B * N / (vec ? 4 : 1));
-  int nt = 0;
-  if (xT_dst) { nt = ((N + 63) / 64) * ((B + 63) / 64); if (nt > 1024) nt = 1024; }
-  hipLaunchKernelGGL(stage_batch_kernel, dim3(a.ncopy + nt), dim3(256), 0, tnt_stream(stream), a);
-  TNT_LAUNCH_CHECK();
-  return 0;
+  return stage_batch_launch<float>(x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U, xT_dst,
+                                   ldt, stream);
 }
 
-extern "C" int32_t tnt_version(void) { return 102; }
+extern "C" int32_t tnt_stage_batch_h16(const uint16_t* x_half, float* x_dst, const int32_t* cap, int32_t* cap_dst,
+                                       const int32_t* tgt, int32_t* tgt_tmajor, const float* a0, float* h0,
+                                       const float* c0, float* c0_dst, int32_t B, int32_t T, int32_t N, int32_t ldx,
+                                       int32_t U, float* xT_dst, int32_t ldt, void* stream) {
+  return stage_batch_launch<__half>(reinterpret_cast<const __half*>(x_half), x_dst, cap, cap_dst, tgt, tgt_tmajor, a0,
+                                    h0, c0, c0_dst, B, T, N, ldx, U, xT_dst, ldt, stream);
+}
+
+extern "C" int32_t tnt_version(void) { return 103; }

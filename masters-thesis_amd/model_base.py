@@ -283,14 +283,16 @@ class ModelBase:
 
     def _stage_batch(self, inputs, target, n_cols):
         """(inputs, target) -> static buffers.  A batch that already sits on the model's device in the staged
-        dtypes (float32 betas / states, int32 ids, contiguous) goes through ONE launch (tnt_stage_batch_f32);
+        dtypes (float32 -- or float16 "on-wire" -- betas, float32 states, int32 ids, contiguous) goes through ONE launch
+        (tnt_stage_batch_f32 / _h16);
         anything else (numpy, one-hot targets, other dtypes) takes the general per-tensor path."""
         x, cap, a0, c0 = inputs[:4]
         ts = [x, cap, a0, c0] + ([target] if target is not None else [])
         dev = self.device
         same = lambda t: t.device.type == dev.type and (t.device.index or 0) == (dev.index or 0)
         ok = all(isinstance(t, torch.Tensor) and same(t) and t.is_contiguous() for t in ts)
-        ok = ok and x.dtype == a0.dtype == c0.dtype == torch.float32 and cap.dtype == torch.int32
+        ok = ok and x.dtype in (torch.float32, torch.float16) and a0.dtype == c0.dtype == torch.float32
+        ok = ok and cap.dtype == torch.int32
         ok = ok and x.dim() == 2 and cap.dim() == 2 and x.shape == (cap.shape[0], n_cols)
         ok = ok and (target is None or (target.dtype == torch.int32 and target.shape == cap.shape))
         if not ok:

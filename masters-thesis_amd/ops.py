@@ -173,7 +173,11 @@ class HipBackend:
         self._call(self.lib.tnt_sum2_f32, "tnt_sum2_f32", _p(x0), _p(out0), _p(x1), _p(out1), n, scale, self._s())
 
     def stage_batch(self, x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U, xT_dst=None, ldt=0):
-        self._call(self.lib.tnt_stage_batch_f32, "tnt_stage_batch_f32", _p(x), _p(x_dst), _p(cap), _p(cap_dst), _p(tgt), _p(tgt_tmajor), _p(a0),
+        """x: float32 betas, or float16 ("fp16 on-wire": widened to float by the staging kernel)."""
+        half = x.dtype == torch.float16
+        fn, name = (self.lib.tnt_stage_batch_h16, "tnt_stage_batch_h16") if half else \
+                   (self.lib.tnt_stage_batch_f32, "tnt_stage_batch_f32")
+        self._call(fn, name, _p(x), _p(x_dst), _p(cap), _p(cap_dst), _p(tgt), _p(tgt_tmajor), _p(a0),
                                                 _p(h0), _p(c0), _p(c0_dst), B, T, N, ldx, U, _p(xT_dst), ldt, self._s())
 
     def sample_rows(self, x, out, rows, V, ld, temperature, from_logits, seed, site, step, step_dev=None):

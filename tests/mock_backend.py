@@ -174,9 +174,10 @@ class MockBackend:
         self.sum(x1, out1, n, scale)
 
     def stage_batch(self, x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U, xT_dst=None, ldt=0):
-        mat(x_dst, B, N, ldx)[...] = flat(x)[:B * N].reshape(B, N)
+        xs = x.reshape(-1)[:B * N].float().numpy().reshape(B, N)          # float32 or float16 ("on-wire") betas
+        mat(x_dst, B, N, ldx)[...] = xs
         if xT_dst is not None:
-            mat(xT_dst, N, B, ldt)[...] = flat(x)[:B * N].reshape(B, N).T
+            mat(xT_dst, N, B, ldt)[...] = xs.T
         flat(cap_dst)[:B * T] = flat(cap)[:B * T]
         if tgt is not None:
             flat(tgt_tmajor)[:B * T] = flat(tgt)[:B * T].reshape(B, T).T.reshape(-1)

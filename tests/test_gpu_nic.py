@@ -167,3 +167,24 @@ def test_pipelined_dp_schedule_world1_equals_single_gpu_step():
         assert d <= 1e-7, d
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("betas_dtype", ["float32", "float16"])
+def test_pinned_prefetcher_feeds_the_step(betas_dtype):
+    """data.PinnedPrefetcher (pinned double-buffered H2D on a side stream; optionally float16 betas on the wire, widened
+    by tnt_stage_batch_h16) against feeding the same host batches directly: identical training, batch after batch."""
+    from masters_thesis_amd.data import SyntheticGenerator, PinnedPrefetcher
+    a, b, (B, N, T, V, U, E) = _twin_models(rates=(0.0, 0.2, 0.2))
+    gen = SyntheticGenerator(6, B, N, U, T, V, seed=3)
+    pre = PinnedPrefetcher(SyntheticGenerator(6, B, N, U, T, V, seed=3), "cuda", betas_dtype=betas_dtype)
+    for i in range(len(gen)):
+        (x, cap, a0, c0), tgt = gen[i]
+        if betas_dtype == "float16":
+            x = x.astype(np.float16).astype(np.float32)          # what the wire format keeps of the betas
+        ra = a.train_step(((x, cap, a0, c0), tgt)).as_floats()
+        item = pre[i]
+        assert item[0][0].is_cuda and item[0][0].dtype == (torch.float16 if betas_dtype == "float16" else torch.float32)
+        rb = b.train_step(item).as_floats()
+        assert ra == rb, (i, ra, rb)
+    torch.cuda.synchronize()
+    assert torch.equal(a.arena.theta, b.arena.theta)

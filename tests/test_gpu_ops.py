@@ -661,6 +661,16 @@ def test_embedding_fwd_drop_stage_sum2(be):
     x2 = dev(rng.standard_normal((B, 37))); xd2 = torch.zeros(B, 40, device="cuda")      # ragged width, padded rows
     be.stage_batch(x2, xd2, cap, capd, None, tgtd, a0, h0, c0, c0d, B, T, 37, 40, U)
     assert torch.equal(xd2[:, :37], x2) and float(xd2[:, 37:].abs().sum()) == 0.0
+    # --- the same staging from IEEE-half betas ("fp16 on-wire"): exactly the float widening of the half values
+    for (xs, width, ld, xTt) in ((x, N, N, True), (x2, 37, 40, False)):
+        xh = xs.half()
+        xd3 = torch.zeros(B, ld, device="cuda")
+        xT3 = torch.full((width, 8), 7.0, device="cuda") if xTt else None
+        be.stage_batch(xh, xd3, cap, capd, tgt, tgtd, a0, h0, c0, c0d, B, T, width, ld, U, xT3, 8 if xTt else 0)
+        assert torch.equal(xd3[:, :width], xh.float()) and float(xd3[:, width:].abs().sum()) == 0.0
+        if xTt:
+            assert torch.equal(xT3[:, :B], xh.float().t()) and float(xT3[:, B:].abs().sum()) == 0.0
+        assert torch.equal(capd, cap) and torch.equal(h0, a0) and torch.equal(tgtd.view(T, B), tgt.t())
     # --- two sums in one launch
     v0, v1 = dev(rng.standard_normal(960)), dev(rng.standard_normal(960))
     out = torch.zeros(2, device="cuda")

@@ -150,3 +150,23 @@ def test_device_resident_batch_is_staged_in_one_launch():
     assert r1 == r2
     for k in m1.keras_shapes:
         assert np.array_equal(m1.get_weight(k), m2.get_weight(k)), k
+
+
+def test_half_precision_betas_on_the_wire():
+    """float16 betas (data.PinnedPrefetcher(betas_dtype="float16")) are widened by the staging launch: the step equals
+    the step on the float32 image of the same half values."""
+    rng = np.random.default_rng(26)
+    B, N, T, V, U = 4, 20, 5, 11, 16
+    m1, _ = make_pair(rng, (0, 0, 0), B=B, N=N, T=T, V=V, U=U)
+    m2, _ = make_pair(np.random.default_rng(26), (0, 0, 0), B=B, N=N, T=T, V=V, U=U)
+    for m in (m1, m2):
+        m.compile(Adam(1e-3, clipnorm=0.1))
+    data, tgt = synth_batch(B, N, T, V, U, rng)
+    xh = torch.from_numpy(np.ascontiguousarray(data[0])).half()
+    rest = tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in data[1:])
+    tt = torch.from_numpy(tgt.astype(np.int32))
+    r1 = m1.train_step(((xh,) + rest, tt)).as_floats()
+    r2 = m2.train_step(((xh.float(),) + rest, tt)).as_floats()
+    assert r1 == r2
+    for k in m1.keras_shapes:
+        assert np.array_equal(m1.get_weight(k), m2.get_weight(k)), k
