@@ -191,6 +191,105 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1r(const float* A, const f
   }
 }
 
+// Direct-to-LDS variant (NN, K % 32 == 0, BK = 32, 1024 threads): global_load_lds_dwordx4 writes each wave's 1 KB
+// straight into LDS, so there is no VGPR staging and no ds_write.  A: slot (row, c) holds k-chunk c ^ ((row>>1)&7)
+// (conflict-free ds_read_b64 over 64 banks); B: slot (k, c) holds column chunk c ^ (((k>>1)&1)<<2).
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm1r_glds(const float* A, const float* B, float* C, const float* bias,
+                                                              int M, int N, int K, int lda, int ldb, int ldc) {
+  constexpr int BK = 32, NT = 64 * WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
+  constexpr int ASZ = BM * BK, BSZ = BK * BN;
+  constexpr int NA = (BM * BK / 4 + NT - 1) / NT, NB = (BK * BN / 4 + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds; float* Bs = lds + 2 * ASZ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int MT = (M + BM - 1) / BM, NTl = (N + BN - 1) / BN;
+  const int nwg = MT * NTl, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int m0 = (t % MT) * BM, n0 = (t / MT) * BN;
+  const int nk = K / BK;
+  const int l16 = lane & 15, g = lane >> 4;
+  floatx4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float bcol[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = n0 + wn * WN + tn * 16 + l16;
+    bcol[tn] = (bias && col < N) ? bias[col] : 0.f;
+  }
+  auto issue = [&](int buf, int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int f = tid + i * NT;
+      if (BM * BK / 4 % NT != 0 && (wave * 64 + i * NT) >= BM * BK / 4) continue;      // wave-uniform
+      const int row = f >> 3, c = f & 7;
+      const int grow = min(m0 + row, M - 1);
+      const float* src = A + (long)grow * lda + k0 + 4 * (c ^ ((row >> 1) & 7));
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(As + buf * ASZ + (wave * 64 + i * NT) * 4), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int f = tid + i * NT;
+      if (BK * BN / 4 % NT != 0 && (wave * 64 + i * NT) >= BK * BN / 4) continue;
+      const int kk = f / (BN / 4), c = f % (BN / 4);
+      const int gcol = min(n0 + 4 * (c ^ (((kk >> 1) & 1) << 2)), ldb - 4);
+      const float* src = B + (long)(k0 + kk) * ldb + gcol;
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(Bs + buf * BSZ + (wave * 64 + i * NT) * 4), 16, 0, 0);
+    }
+  };
+  issue(0, 0);
+  __syncthreads();
+  for (int i = 0; i < nk; ++i) {
+    const int cur = i & 1;
+    if (i + 1 < nk) issue(cur ^ 1, (i + 1) * BK);
+    const float* Ac = As + cur * ASZ; const float* Bc = Bs + cur * BSZ;
+#pragma unroll
+    for (int s = 0; s < BK / 8; ++s) {
+      float2 av[TM], bv[TN];
+      const int Q = 2 * s + (g >> 1);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int row = wm * WM + tm * 16 + l16;
+        av[tm] = *reinterpret_cast<const float2*>(&Ac[row * BK + ((Q ^ ((row >> 1) & 7)) << 2) + 2 * (g & 1)]);
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = wn * WN + tn * 16 + l16, k = 8 * s + 2 * g;
+        const int col = (((n >> 2) ^ (((k >> 1) & 1) << 2)) << 2) + (n & 3);          // k and k+1 share (k>>1)
+        bv[tn] = make_float2(Bc[k * BN + col], Bc[(k + 1) * BN + col]);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tm].x, bv[tn].x, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tm].y, bv[tn].y, acc[tm][tn], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = n0 + wn * WN + tn * 16 + l16;
+    if (col >= N) continue;
+    float* Cp = C + (long)(m0 + wm * WM + 4 * g) * ldc + col;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * WM + tm * 16 + 4 * g + r;
+        if (row < M) Cp[(long)(tm * 16 + r) * ldc] = acc[tm][tn][r] + bcol[tn];
+      }
+  }
+}
+
 __global__ void ref_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
                          int ldc, int a_kc, int b_kc) {
   const int col = blockIdx.x * 64 + threadIdx.x, row = blockIdx.y;
@@ -236,6 +335,35 @@ void run(const char* name, const float* A, const float* B, float* C, const float
          2.0 * M * N * K / us / 1e6, md, mx, e == hipSuccess ? "" : hipGetErrorString(e));
 }
 
+template <int BM, int BN, int WGM, int WGN>
+void rung(const char* name, const float* A, const float* B, float* C, const float* Cref, const float* bias, int M, int N, int K,
+          int lda, int ldb, int ldc) {
+  if (K % 32) return;
+  const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  constexpr int NT = 64 * WGM * WGN;
+  const int shmem = (2 * BM * 32 + 2 * 32 * BN) * 4;
+  auto kern = gemm1r_glds<BM, BN, WGM, WGN>;
+  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+  hipMemset(C, 0, (size_t)M * ldc * 4);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) kern<<<grid, NT, shmem>>>(A, B, C, bias, M, N, K, lda, ldb, ldc);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int i = 0; i < 20; ++i) kern<<<grid, NT, shmem>>>(A, B, C, bias, M, N, K, lda, ldb, ldc);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double us = ms * 1e3 / 20;
+  std::vector<float> h((size_t)M * ldc), hr((size_t)M * ldc);
+  hipMemcpy(h.data(), C, h.size() * 4, hipMemcpyDeviceToHost);
+  hipMemcpy(hr.data(), Cref, h.size() * 4, hipMemcpyDeviceToHost);
+  double md = 0;
+  for (int r = 0; r < M; ++r)
+    for (int c = 0; c < N; ++c) md = fmax(md, fabs((double)h[(size_t)r * ldc + c] - hr[(size_t)r * ldc + c]));
+  hipError_t e = hipGetLastError();
+  printf("  %-34s grid=%5d x%4d : %7.1f us  %6.1f TF   maxdiff %.2e %s\n", name, grid, NT, us, 2.0 * M * N * K / us / 1e6, md,
+         e == hipSuccess ? "" : hipGetErrorString(e));
+}
+
 int main() {
   struct Shape { const char* n; int M, N, K, a_kc, b_kc; } shapes[] = {
       {"head fwd NN", 960, 5001, 512, 1, 0}, {"c3 head fwd NN", 960, 5001, 256, 1, 0}, {"head dW TN", 512, 5001, 960, 0, 0},
@@ -264,6 +392,8 @@ int main() {
       RUN(128, 128, 2, 4, true, false);
       RUN(160, 128, 2, 4, true, false);
       RUN(160, 128, 2, 8, true, false);
+      rung<160, 128, 2, 8>("160x128 2x8 direct-to-LDS", A, B, C, Cr, bias, s.M, s.N, s.K, lda, ldb, ldc);
+      rung<160, 128, 2, 4>("160x128 2x4 direct-to-LDS", A, B, C, Cr, bias, s.M, s.N, s.K, lda, ldb, ldc);
 #define RUNA(WGN, ABL) run<160, 128, 2, WGN, true, false, ABL>("160x128 2x" #WGN " ablation " #ABL, A, B, C, Cr, bias, s.M, s.N, s.K, lda, ldb, ldc)
       RUNA(4, 1); RUNA(4, 3); RUNA(4, 7); RUNA(4, 15); RUNA(4, 8); RUNA(4, 4);
       run<160, 128, 2, 8, true, false, 0, 64>("160x128 2x8 bk64", A, B, C, Cr, bias, s.M, s.N, s.K, lda, ldb, ldc);
