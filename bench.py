@@ -229,6 +229,7 @@ def main():
         el = float(t.item())
     pct = step_percentiles(model, batch, min(args.steps, 200)) if args.steps >= 10 else None
     last = model.train_step(batch).as_floats()
+    model.check_device_errors()          # e.g. a barrier timeout of the persistent LSTM kernel would void the run
 
     if rank == 0:
         tokens = world * B * T * args.steps

@@ -201,6 +201,19 @@ int32_t tnt_lstm_step_fwd_f32(const float* xz, const float* h_prev, const float*
                               const int32_t* mask_ids, int32_t mask_T, int32_t mask_t,
                               const float* out_prev, float* h, float* c, float* out,
                               float* gates, int32_t B, int32_t U, const float* xz_bias, void* stream);
+/* Persistent form of the masked sequence forward of NIC.py:138-140: ONE launch runs the S dependent steps
+ * (step s reads hs[s], cs[s], xz[s] and writes hs[s+1], cs[s+1], gates[s]; steps s >= mask_s0 are masked by column
+ * s - mask_s0 of mask_ids[B][mask_T] and write the sequence output out[s - mask_s0]; mask_ids nullable = no mask,
+ * no output).  hs/cs: [S+1][B][U] with slab 0 = the initial state; xz: [S][B][U][4]; gates: [S][B][U][4];
+ * sync: 1025 uint32 of scratch owned by the caller, zero-initialised once and then left alone (flags and tickets carry
+ * over from launch to launch; word 1024 is sticky: != 0 = a barrier timed out at some point and results are invalid).  Same arithmetic as S calls of tnt_lstm_step_fwd_f32.  A step pays one XCD-local barrier instead of a
+ * dependent kernel launch and the recurrent weights stay in VGPRs; needs U == 512, B <= 128 and a 256-CU device on
+ * which a 256-workgroup launch places 32 workgroups on each of the 8 XCDs: tnt_lstm_seq_supported() tests exactly that
+ * (one synchronising probe launch per process, so call it outside any graph capture) and returns 1 or 0. */
+int32_t tnt_lstm_seq_supported(int32_t B, int32_t U);
+int32_t tnt_lstm_seq_fwd_f32(const float* xz, float* hs, float* cs, const float* Ur, const float* xz_bias,
+                             const int32_t* mask_ids, int32_t mask_T, int32_t mask_s0, float* out,
+                             float* gates, int32_t S, int32_t B, int32_t U, uint32_t* sync, void* stream);
 /* bwd of one step, fused with the recurrent matmul of the step after it:
  *   da = da_pass_in + dh_ext + (dz_next ? dz_next[B][U][4] @ Ur^T : 0)
  *   dout = dout_in + dout_t ; masked rows pass (da, dc, dout) through, dz = 0

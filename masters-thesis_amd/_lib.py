@@ -31,6 +31,8 @@ SIGNATURES = {
     "tnt_colsum_f32": [P, P, I32, I32, I32, P, P],
     "tnt_embedding_fwd_f32": [P, P, P, I32, I32, I32, I32, I32, P],
     "tnt_embedding_bwd_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, P],
+    "tnt_lstm_seq_supported": [I32, I32],
+    "tnt_lstm_seq_fwd_f32": [P, P, P, P, P, P, I32, I32, P, P, I32, I32, I32, P, P],
     "tnt_lstm_step_fwd_f32": [P, P, P, P, P, P, I32, P, I32, I32, P, P, P, P, P, I32, I32, P, P],
     "tnt_lstm_step_bwd_f32": [P, P, P, P, P, P, P, P, I32, I32, P, P, P, P, P, P, P, I32, I32, P, I32, P, P],
     "tnt_softmax_cce_f32": [P, P, P, P, P, P, I32, I32, I32, F32, I32, I32, P],

@@ -395,6 +395,159 @@ __global__ __launch_bounds__(64 * NWB) void lstm_bwd_lds_kernel(LstmBwdArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent sequence forward (the dense-encoder NIC's masked LSTM over S steps, NIC.py:138-140): ONE launch runs
+// all S dependent steps.  A dependent kernel launch costs ~3.1 us inside a captured graph; here a step pays one
+// XCD-local barrier instead (~1.8 us with the h exchange, tools/probe/xcdbar_probe.hip), and the recurrent weights
+// never leave the VGPRs.
+//   * Work split as in lstm_fwd_kernel<16, 8>: workgroup = 16 batch rows x 16 hidden units, 16 waves, wave w owns
+//     the 32 contraction rows k = 32w .. 32w+31; its weight fragments (8 x float4 per lane = the whole 128 KB slice
+//     over the workgroup) are loaded ONCE.
+//   * The 32 workgroups of one row block exchange h through global memory and must share an L2: a row block is
+//     pinned to one XCD.  256 workgroups are launched (one per CU: 1024 threads + 64 KB of LDS), each reads its
+//     XCC_ID, takes a ticket in that XCD (= its unit block) and works on row block XCC_ID; the other XCDs' workgroups exit.
+//     Plain stores + an explicit s_waitcnt vmcnt(0) publish a slice in the XCD's L2 (vector L1 is write-through), plain
+//     loads read it: every h slab is written once per launch and read only after its barrier.
+//   * Epilogue operands that the same thread produced a step earlier (c, h, previous output) are carried in registers.
+//   * Barriers spin a bounded number of times; on timeout (or a workgroup census that is not 32 per XCD) the error
+//     word is set and every wave leaves -- wrong results, never a hung grid.  tnt_lstm_seq_supported() checks the
+//     census once per process before a model opts in.
+struct LstmSeqArgs {
+  const float* xz; float* hs; float* cs; const float* Ur; const float* zbias;
+  const int* mask_ids; float* out; float* gates;
+  int S, B, U, mask_T, mask_s0;
+  unsigned* sync;        // [8][64] barrier flags (32 used per XCD), [8][64] tickets, then the error word; zero-initialised ONCE
+};
+
+__device__ __forceinline__ unsigned tnt_xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xfu;
+}
+
+constexpr unsigned SEQ_SPIN_LIMIT = 1u << 21;
+constexpr int SEQ_ERR = 2 * 8 * 64;
+
+__global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
+  constexpr int NWF = 16, SS = 8, CK = 32;
+  extern __shared__ float seq_lds[];                       // 64 KB requested: one workgroup per CU
+  float (*red)[4][16][17] = reinterpret_cast<float (*)[4][16][17]>(seq_lds);       // [NWF][4][16][17] = 69.6 KB
+  __shared__ unsigned s_ub;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kq = lane >> 4, lr = lane & 15;
+  const int U = a.U, B = a.B;
+  const unsigned xcc = tnt_xcc_id();
+  const int nrb = (B + 15) / 16;
+  if ((int)xcc >= nrb) return;                             // this XCD has no row block
+  unsigned* bar = a.sync + xcc * 64;
+  unsigned* err = a.sync + SEQ_ERR;
+  // Nothing in `sync` is reset between launches (a captured memset node proved unreliable in front of this kernel):
+  // tickets count on modulo 32 -- exactly 32 workgroups per XCD per launch, see tnt_lstm_seq_supported -- and the
+  // barrier flags only ever grow; a launch counts its barriers from the value its own flag had when it started
+  // (all flags of a row block end a launch at the same value).
+  if (tid == 0) s_ub = atomicAdd(a.sync + (8 + xcc) * 64, 1u) & 31u;
+  __syncthreads();
+  const int ub = (int)s_ub, rb = (int)xcc;
+  const unsigned base = __hip_atomic_load(bar + ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int arow = rb * 16 + lr, ucol = ub * 16 + lr;
+  // ---- this wave's weight fragments, resident for the whole sequence
+  float4 bv[SS];
+#pragma unroll
+  for (int s = 0; s < SS; ++s) bv[s] = ld4g(a.Ur + ((long)(w * CK + (s >> 2) * 16 + kq * 4 + (s & 3)) * U + ucol) * 4, true);
+  // ---- epilogue thread state
+  const int erow = tid >> 4, ecol = tid & 15;
+  const int eb = rb * 16 + erow, eu = ub * 16 + ecol;
+  const bool eok = tid < 256 && eb < B;
+  const long ee = (long)eb * U + eu;
+  const long BU = (long)B * U;
+  float4 zb = make_float4(0.f, 0.f, 0.f, 0.f);
+  float cp = 0.f, hp = 0.f, op = 0.f;
+  float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (eok) {
+    if (a.zbias) zb = *reinterpret_cast<const float4*>(a.zbias + (long)eu * 4);
+    cp = a.cs[ee]; hp = a.hs[ee];
+    x4 = *reinterpret_cast<const float4*>(a.xz + ee * 4);
+  }
+  for (int st = 0; st < a.S; ++st) {
+    // ---- A fragments: this row block's h of the previous step (own XCD's L2 after the barrier)
+    const float* hprev = a.hs + (long)st * BU;
+    float av[SS];
+#pragma unroll
+    for (int j = 0; j < SS / 4; ++j) {
+      const float4 t = ld4g(hprev + (long)arow * U + w * CK + j * 16 + kq * 4, arow < B);
+      av[4 * j + 0] = t.x; av[4 * j + 1] = t.y; av[4 * j + 2] = t.z; av[4 * j + 3] = t.w;
+    }
+    int mid = 1;
+    if (eok && a.mask_ids && st >= a.mask_s0) mid = a.mask_ids[eb * a.mask_T + (st - a.mask_s0)];
+    floatx4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < SS; ++s) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].w, acc[3], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][g][kq * 4 + r][lr] = acc[g][r];
+    __syncthreads();
+    if (eok) {
+      float z[4] = {x4.x + zb.x, x4.y + zb.y, x4.z + zb.z, x4.w + zb.w};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < NWF; ++k) sacc += red[k][g][erow][ecol];
+        z[g] += sacc;
+      }
+      const float gi = tnt_sigmoid_fast(z[0]), gf = tnt_sigmoid_fast(z[1]), gg = tnt_tanh(z[2]), go = tnt_sigmoid_fast(z[3]);
+      const float c2 = gf * cp + gi * gg;
+      const float h2 = go * tnt_tanh(c2);
+      const bool m = mid != 0;
+      const bool seq = st >= a.mask_s0;
+      const float hn = m ? h2 : hp, cn = m ? c2 : cp;
+      a.hs[(long)(st + 1) * BU + ee] = hn;
+      a.cs[(long)(st + 1) * BU + ee] = cn;
+      if (a.out && seq) { op = m ? h2 : op; a.out[(long)(st - a.mask_s0) * BU + ee] = op; }
+      *reinterpret_cast<float4*>(a.gates + ((long)st * BU + ee) * 4) = make_float4(gi, gf, gg, go);
+      hp = hn; cp = cn;
+      if (st + 1 < a.S) x4 = *reinterpret_cast<const float4*>(a.xz + ((long)(st + 1) * BU + ee) * 4);
+    }
+    if (st + 1 == a.S) break;
+    // ---- XCD-local barrier.  Slices are in L2 once vmcnt drains; every workgroup then raises its own flag word (the 32
+    // flags of a row block share one 128-byte line) and the first 32 lanes poll that line: no read-modify-write on a
+    // shared counter, which the L2 would serialise 32-fold.
+    // (a workgroup-scope release fence alone does not drain vmcnt: stores are already ordered within a CU)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (w == 0) {
+      const unsigned target = base + (unsigned)(st + 1);
+      if (lane == 0) __hip_atomic_store(bar + ub, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      for (;;) {
+        const unsigned v = lane < 32 ? __hip_atomic_load(bar + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+        if (__all((int)(v - target) >= 0)) break;
+        if (++spins > SEQ_SPIN_LIMIT) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
+// census of a 256 x 1024-thread launch: how many workgroups land on each XCC_ID
+__global__ __launch_bounds__(1024) void xcc_census_kernel(unsigned* hist) {
+  extern __shared__ float seq_lds[];
+  if (threadIdx.x == 0) { seq_lds[0] = 0.f; atomicAdd(&hist[tnt_xcc_id() & 15u], 1u); }
+}
+
+constexpr int SEQ_LDS_BYTES = 16 * 4 * 16 * 17 * 4;      // the reduction buffer; > 64 KB, so one workgroup per CU
+
 }  // namespace
 
 extern "C" int32_t tnt_lstm_step_fwd_f32(const float* xz, const float* h_prev, const float* c_prev, const float* Ur,
@@ -450,6 +603,48 @@ extern "C" int32_t tnt_lstm_step_bwd_f32(const float* dz_next, const float* Ur, 
   } else {
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3(U / 16, (B + 15) / 16), dim3(512), 0, tnt_stream(stream), a);
   }
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+/* see include/tnt_hip.h */
+extern "C" int32_t tnt_lstm_seq_supported(int32_t B, int32_t U) {
+  static int cached = -1;
+  if (U != 512 || B <= 0 || B > 128) return 0;
+  if (cached < 0) {
+    cached = 0;
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (prop.multiProcessorCount != 256) return 0;
+    if (hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_LDS_BYTES) != hipSuccess) return 0;
+    if (hipFuncSetAttribute((const void*)xcc_census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_LDS_BYTES) != hipSuccess) return 0;
+    unsigned* hist = nullptr;
+    if (hipMalloc(&hist, 64) != hipSuccess) return 0;
+    bool ok = true;
+    for (int rep = 0; rep < 3 && ok; ++rep) {
+      unsigned h[16];
+      ok = hipMemset(hist, 0, 64) == hipSuccess;
+      hipLaunchKernelGGL(xcc_census_kernel, dim3(256), dim3(1024), SEQ_LDS_BYTES, 0, hist);
+      ok = ok && hipDeviceSynchronize() == hipSuccess && hipMemcpy(h, hist, 64, hipMemcpyDeviceToHost) == hipSuccess;
+      for (int i = 0; i < 8 && ok; ++i) ok = h[i] == 32u;
+    }
+    (void)hipFree(hist);
+    cached = ok ? 1 : 0;
+  }
+  return cached;
+}
+
+extern "C" int32_t tnt_lstm_seq_fwd_f32(const float* xz, float* hs, float* cs, const float* Ur, const float* xz_bias,
+                                        const int32_t* mask_ids, int32_t mask_T, int32_t mask_s0, float* out,
+                                        float* gates, int32_t S, int32_t B, int32_t U, uint32_t* sync, void* stream) {
+  if (S <= 0 || sync == nullptr) return TNT_BADARG(11);
+  if (!tnt_lstm_seq_supported(B, U)) return TNT_BADARG(13);
+  if (mask_ids != nullptr && (mask_s0 < 0 || S - mask_s0 > mask_T)) return TNT_BADARG(7);
+  hipStream_t s = tnt_stream(stream);
+  LstmSeqArgs a;
+  a.xz = xz; a.hs = hs; a.cs = cs; a.Ur = Ur; a.zbias = xz_bias; a.mask_ids = mask_ids; a.out = out; a.gates = gates;
+  a.S = S; a.B = B; a.U = U; a.mask_T = mask_T; a.mask_s0 = mask_ids ? mask_s0 : S; a.sync = sync;
+  hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(256), dim3(1024), SEQ_LDS_BYTES, s, a);
   TNT_LAUNCH_CHECK();
   return 0;
 }

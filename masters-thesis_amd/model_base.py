@@ -323,6 +323,17 @@ class ModelBase:
             assert oh.shape == (B, T, self.V), f"target shape {tuple(oh.shape)}"
             self.be.onehot_argmax(oh, self.tgt, B, T, self.V)
 
+    def check_device_errors(self):
+        """Raises if a device-side guard tripped since the last check (synchronises): today only the barrier timeout of
+        the persistent LSTM kernel (tnt_lstm_seq_fwd_f32), whose results are invalid once its error word is set.
+        fit() calls it at every epoch end, bench.py and smoke() after their steps."""
+        sync = self.__dict__.get("seq_sync")
+        if sync is not None and int(sync[1024].item()) != 0:
+            code = int(sync[1024].item())
+            sync[1024] = 0
+            raise RuntimeError(f"persistent LSTM kernel: barrier timeout (code {code}); results since the last check "
+                               "are invalid.  Set model.use_seq_lstm = False before the first step to use the per-step kernels.")
+
     # ------------------------------------------------------------------ graph capture
     def _run_captured(self, key, fn):
         """Run ``fn`` (a fixed launch sequence over static buffers) through a hipGraph:
@@ -413,6 +424,7 @@ class ModelBase:
                       " - ".join(f"{k}: {v:.4f}" for k, v in elogs.items()))
             for k, v in elogs.items():
                 history.setdefault(k, []).append(v)
+            self.check_device_errors()
             _call(callbacks, "on_epoch_end", epoch, elogs)
             if hasattr(x, "on_epoch_end"):
                 x.on_epoch_end()

@@ -158,6 +158,10 @@ class NIC(ModelBase):
         self.Hs, self.Cs = f(T + 2, B, U), f(T + 2, B, U)
         self.gates = f(T + 1, B, U, 4)
         self.Out = f(T, B, U)
+        # persistent sequence kernel: opt-in per shape and per device (probe launch, so decided here, outside any capture)
+        self._seq_lstm = bool(getattr(self, "use_seq_lstm", True) and hasattr(self.be, "lstm_seq_supported")
+                              and self.be.lstm_seq_supported(B, U))
+        self.seq_sync = torch.zeros(1025, dtype=torch.int32, device=self.device) if self._seq_lstm else None
         self.logits = f(T * B, ldV)
         self.loss_row, self.corr_row = f(T * B), f(T * B)
         self.met = f(8)
@@ -240,14 +244,20 @@ class NIC(ModelBase):
         # input projection of all T+1 steps as ONE epilogue-free GEMM; the LSTM bias is added inside the step kernel
         self.gemm_sk(xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U)
         Ur, bl = a.p("lstm/recurrent_kernel"), a.p("lstm/bias")
-        # lstm call 1: the feature, one unmasked step (NIC.py:138)
-        be.lstm_step_fwd(self.XZ[:B], self.Hs[0], self.Cs[0], Ur, None, None, 0, None, 0, 0, None, self.Hs[1],
-                         self.Cs[1], None, self.gates[0], B, U, xz_bias=bl)
-        # lstm call 2: the text, masked by the Embedding mask (NIC.py:140)
-        for t in range(1, T + 1):
-            be.lstm_step_fwd(self.XZ[t * B:(t + 1) * B], self.Hs[t], self.Cs[t], Ur, None, None, 0, self.cap, T,
-                             t - 1, self.Out[t - 2] if t > 1 else None, self.Hs[t + 1], self.Cs[t + 1],
-                             self.Out[t - 1], self.gates[t], B, U, xz_bias=bl)
+        if self._seq_lstm:
+            # both LSTM calls (NIC.py:138,140) as ONE persistent launch: the T+1 dependent steps pay an XCD-local barrier
+            # each instead of a kernel launch, the recurrent weights stay in VGPRs (tnt_lstm_seq_fwd_f32)
+            be.lstm_seq_fwd(self.XZ, self.Hs, self.Cs, Ur, bl, self.cap, T, 1, self.Out, self.gates, T + 1, B, U,
+                            self.seq_sync)
+        else:
+            # lstm call 1: the feature, one unmasked step (NIC.py:138)
+            be.lstm_step_fwd(self.XZ[:B], self.Hs[0], self.Cs[0], Ur, None, None, 0, None, 0, 0, None, self.Hs[1],
+                             self.Cs[1], None, self.gates[0], B, U, xz_bias=bl)
+            # lstm call 2: the text, masked by the Embedding mask (NIC.py:140)
+            for t in range(1, T + 1):
+                be.lstm_step_fwd(self.XZ[t * B:(t + 1) * B], self.Hs[t], self.Cs[t], Ur, None, None, 0, self.cap, T,
+                                 t - 1, self.Out[t - 2] if t > 1 else None, self.Hs[t + 1], self.Cs[t + 1],
+                                 self.Out[t - 1], self.gates[t], B, U, xz_bias=bl)
         self.gemm_sk(self.Out, a.p("time_distributed_softmax/kernel"), self.logits, T * B, V, U, U, ldV, ldV,
                 bias=a.p("time_distributed_softmax/bias"))                         # NIC.py:143
 

@@ -114,6 +114,14 @@ class HipBackend:
                                                   _p(mask_ids), mask_T, mask_t, _p(out_prev), _p(h), _p(c), _p(out),
                                                   _p(gates), B, U, _p(xz_bias), self._s())
 
+    def lstm_seq_supported(self, B, U):
+        """1 when the persistent sequence kernel can run here (U == 512, 256 CUs, 32 workgroups per XCD); probes once."""
+        return bool(self.lib.tnt_lstm_seq_supported(int(B), int(U)))
+
+    def lstm_seq_fwd(self, xz, hs, cs, Ur, xz_bias, mask_ids, mask_T, mask_s0, out, gates, S, B, U, sync):
+        self._call(self.lib.tnt_lstm_seq_fwd_f32, "tnt_lstm_seq_fwd_f32", _p(xz), _p(hs), _p(cs), _p(Ur), _p(xz_bias),
+                   _p(mask_ids), mask_T, mask_s0, _p(out), _p(gates), S, B, U, _p(sync), self._s())
+
     def lstm_step_bwd(self, dz_next, Ur, da_pass_in, dh_ext, dc_in, dout_in, dout_t, mask_ids, mask_T, mask_t,
                       gates, c, c_prev, dz, da_pass_out, dc_out, dout_out, B, U, Wc=None, D=0, dctx_part=None):
         self._call(self.lib.tnt_lstm_step_bwd_f32, "tnt_lstm_step_bwd_f32", _p(dz_next), _p(Ur), _p(da_pass_in), _p(dh_ext), _p(dc_in),

@@ -106,3 +106,27 @@ def test_edge_shapes(kind, b, t):
     g = model.greedy_predict(data[0], z, z, np.ones(b, np.int64), 4, U, None)
     words = g[0] if isinstance(g, tuple) else g.argmax(-1)
     assert np.asarray(words).size == b * 4
+
+
+def test_persistent_lstm_forward_trains_like_the_step_kernels():
+    """Config 2 with the persistent sequence kernel (tnt_lstm_seq_fwd_f32: one launch for the T+1 dependent LSTM steps)
+    against the same model on the per-step kernels: same losses and weights over captured training steps (the two
+    kernels differ by float32 rounding in the gate math only), and no barrier timeout."""
+    rng = np.random.default_rng(9)
+    data, tgt = synth(rng)
+    a, b = make("dense"), make("dense")
+    b.use_seq_lstm = False
+    ha = [a.train_step((data, tgt)).as_floats() for _ in range(6)]
+    hb = [b.train_step((data, tgt)).as_floats() for _ in range(6)]
+    if not a._seq_lstm:
+        pytest.skip("persistent LSTM kernel not supported on this device")
+    assert not b._seq_lstm
+    a.check_device_errors()
+    for x, y in zip(ha, hb):
+        assert abs(x["loss"] - y["loss"]) <= 2e-5 * abs(y["loss"]), (x, y)
+        assert abs(x["accuracy"] - y["accuracy"]) <= 2.0 / (B * T)
+    wa, wb = a.get_weights_dict(), b.get_weights_dict()
+    for k in wa:
+        # Adam moves every weight by ~lr per step whatever the gradient scale, so rounding noise shows up as a small
+        # fraction of the 6 * lr = 6e-4 the weights travelled
+        assert np.abs(wa[k] - wb[k]).max() <= 3e-5, (k, np.abs(wa[k] - wb[k]).max())

@@ -524,6 +524,54 @@ def test_attention_step_stored_mask_is_bit_identical(be, B, R, D, A, U):
     assert (outs[0][4] == 0).float().mean().item() > 0.1          # the mask really dropped something
 
 
+@pytest.mark.parametrize("B,masked", [(64, True), (40, True), (64, False), (128, True)])
+def test_lstm_seq_fwd_equals_step_kernels(be, B, masked):
+    """tnt_lstm_seq_fwd_f32 (one persistent launch for the S dependent steps, XCD-local barriers) against S launches of
+    tnt_lstm_step_fwd_f32 driven the way nic.NIC drives them: same arithmetic (states, outputs and gates equal to a few
+    float32 ulps -- the two kernels are compiled separately, so fma contraction in the gate math differs), run-to-run
+    bit-identical, no barrier timeout."""
+    U, T = 512, 15
+    S = T + 1
+    if not be.lstm_seq_supported(B, U):
+        pytest.skip("persistent LSTM kernel not supported on this device (needs 256 CUs, 32 workgroups per XCD)")
+    rng = np.random.default_rng(B + masked)
+    f = lambda *s: torch.tensor(rng.standard_normal(s), dtype=torch.float32, device="cuda")
+    xz, Ur, bl = f(S, B, U, 4) * 0.5, f(U, U, 4) * 0.05, f(U, 4) * 0.1
+    cap = rng.integers(1, 50, (B, T)).astype(np.int32)
+    for b in range(B):
+        cap[b, rng.integers(3, T):] = 0                                  # padding tail: masked steps
+    capd = torch.tensor(cap, device="cuda")
+    h0, c0 = f(B, U) * 0.3, f(B, U) * 0.3
+
+    def alloc():
+        Hs, Cs = torch.zeros(S + 1, B, U, device="cuda"), torch.zeros(S + 1, B, U, device="cuda")
+        Hs[0], Cs[0] = h0, c0
+        return Hs, Cs, torch.full((T, B, U), 9.0, device="cuda"), torch.zeros(S, B, U, 4, device="cuda")
+
+    Hs, Cs, Out, G = alloc()
+    be.lstm_step_fwd(xz[0], Hs[0], Cs[0], Ur, None, None, 0, None, 0, 0, None, Hs[1], Cs[1], None, G[0], B, U, xz_bias=bl)
+    for t in range(1, S):
+        be.lstm_step_fwd(xz[t], Hs[t], Cs[t], Ur, None, None, 0, capd if masked else None, T, t - 1,
+                         Out[t - 2] if (t > 1 and masked) else None, Hs[t + 1], Cs[t + 1], Out[t - 1] if masked else None,
+                         G[t], B, U, xz_bias=bl)
+    Hs2, Cs2, Out2, G2 = alloc()
+    sync = torch.zeros(1025, dtype=torch.int32, device="cuda")
+    be.lstm_seq_fwd(xz, Hs2, Cs2, Ur, bl, capd if masked else None, T, 1, Out2 if masked else None, G2, S, B, U, sync)
+    torch.cuda.synchronize()
+    assert int(sync[1024]) == 0, "a barrier of the persistent kernel timed out"
+    for x, y in ((Hs, Hs2), (Cs, Cs2), (G, G2)) + (((Out, Out2),) if masked else ()):
+        assert (x - y).abs().max().item() <= 2e-6
+    if masked:
+        assert torch.equal(Out2 == 9.0, torch.zeros_like(Out2, dtype=torch.bool))     # every output row written
+        assert not torch.equal(Hs[S], Hs[S - 3])                        # the sequence really advanced
+        keep = torch.tensor(cap[:, -1] == 0, device="cuda")             # rows masked at the last step hold their state
+        assert torch.equal(Hs2[S][keep], Hs2[S - 1][keep]) and torch.equal(Out2[T - 1][keep], Out2[T - 2][keep])
+    Hs3, Cs3, Out3, G3 = alloc()
+    be.lstm_seq_fwd(xz, Hs3, Cs3, Ur, bl, capd if masked else None, T, 1, Out3 if masked else None, G3, S, B, U, sync)
+    torch.cuda.synchronize()
+    assert torch.equal(Hs2, Hs3) and torch.equal(Cs2, Cs3) and torch.equal(G2, G3)
+
+
 def test_attention_metric(be):
     rng = np.random.default_rng(13)
     T, B, R = 5, 8, 30
