@@ -59,3 +59,4 @@ sync = torch.zeros(1025, dtype=torch.int32, device="cuda")
 t_steps = timeit(steps)
 t_seq = timeit(lambda: be.lstm_seq_fwd(xz, Hs2, Cs2, Ur, bl, capd, T, 1, Out2, G2, S, B, U, sync))
 print(f"16 step launches: {t_steps:7.1f} us ({t_steps / S:.2f} us/step);  persistent: {t_seq:7.1f} us ({t_seq / S:.2f} us/step); err {int(sync[1024])}")
+
