@@ -334,6 +334,16 @@ class ModelBase:
             raise RuntimeError(f"persistent LSTM kernel: barrier timeout (code {code}); results since the last check "
                                "are invalid.  Set model.use_seq_lstm = False before the first step to use the per-step kernels.")
 
+    def disable_seq_lstm(self):
+        """Back to the per-step LSTM kernels (after a barrier timeout of the persistent one, or by choice): clears the
+        error word, drops captured graphs / launch plans and rebuilds the step buffers on the next call."""
+        self.use_seq_lstm = False
+        sync = self.__dict__.get("seq_sync")
+        if sync is not None:
+            sync[1024] = 0
+        self._seq_lstm = False
+        self._graphs = {}
+
     # ------------------------------------------------------------------ graph capture
     def _run_captured(self, key, fn):
         """Run ``fn`` (a fixed launch sequence over static buffers) through a hipGraph:
