@@ -488,18 +488,30 @@ __global__ __launch_bounds__(WT) void attention_bwd_wide_kernel(AttArgs g) {
   const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
   // ---- dctx (sum of the LSTM backward's per-unit-block partials, or fused dz Wc^T, or given), un-dropped
   if (g.dctx_part) {
-    // thread (p, d): one partial each, then a fixed-order sum over p through LDS (wred is free here: [WW][64] floats)
-    float* scratch = &wred[0][0];
+    // thread (p, d) holds one partial (np*D <= 1024 by the launch check).  Fixed-order tree: when a wave holds whole
+    // rows of D = 32 values, lanes l and l^32 are two parts of the same d and are added by a shuffle first, so each wave
+    // leaves D sums; a last pass of D threads adds the per-wave rows.  (Other D: per-part rows straight to LDS.)
+    float* scratch = &wred[0][0];                       // [WW][64] floats, free here
     const int np = g.nparts;
-    for (int d = tid; d < D; d += WT) dcs[d] = 0.f;
-    for (int e = tid; e < np * D; e += WT) scratch[e % (WW * 64)] = 0.f;     // (np*D <= 1024 by the launch check)
-    __syncthreads();
-    if (tid < np * D) scratch[tid] = g.dctx_part[((long)(tid / D) * g.B + b) * D + tid % D];
-    __syncthreads();
-    if (tid < D) {
-      float t = 0.f;
-      for (int p = 0; p < np; ++p) t += scratch[p * D + tid];
-      dcs[tid] = t;
+    float v = tid < np * D ? g.dctx_part[((long)(tid / D) * g.B + b) * D + tid % D] : 0.f;
+    if (D == 32) {
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 32) scratch[w * 32 + lane] = v;        // wave w covers parts 2w, 2w+1 (zero past np)
+      __syncthreads();
+      if (tid < 32) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < WW; ++k) t += scratch[k * 32 + tid];
+        dcs[tid] = t;
+      }
+    } else {
+      scratch[tid] = v;
+      __syncthreads();
+      if (tid < D) {
+        float t = 0.f;
+        for (int p = 0; p < np; ++p) t += scratch[p * D + tid];
+        dcs[tid] = t;
+      }
     }
   } else if (g.dz) {
     const int K4 = 4 * U;
