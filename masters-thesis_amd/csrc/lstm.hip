@@ -14,6 +14,7 @@
 // weight layout [k][U][4] puts i,f,g,o of one unit in one 16-byte load and in one lane's
 // four accumulators, so the gate math needs no cross-lane traffic.
 #include "tnt_common.h"
+#include "tnt_seq_sync.h"
 
 namespace {
 
@@ -419,15 +420,6 @@ struct LstmSeqArgs {
   unsigned* sync;        // [8][64] barrier flags (32 used per XCD), [8][64] tickets, then the error word; zero-initialised ONCE
 };
 
-__device__ __forceinline__ unsigned tnt_xcc_id() {
-  unsigned v;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-  return v & 0xfu;
-}
-
-constexpr unsigned SEQ_SPIN_LIMIT = 1u << 21;
-constexpr int SEQ_ERR = 2 * 8 * 64;
-
 __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   constexpr int NWF = 16, SS = 8, CK = 32;
   extern __shared__ float seq_lds[];                       // 64 KB requested: one workgroup per CU
@@ -440,14 +432,15 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   const int nrb = (B + 15) / 16;
   if ((int)xcc >= nrb) return;                             // this XCD has no row block
   unsigned* bar = a.sync + xcc * 64;
-  unsigned* err = a.sync + SEQ_ERR;
+  unsigned* err = a.sync + TNT_SEQ_ERR;
   // Nothing in `sync` is reset between launches (a captured memset node proved unreliable in front of this kernel):
   // tickets count on modulo 32 -- exactly 32 workgroups per XCD per launch, see tnt_lstm_seq_supported -- and the
   // barrier flags only ever grow; a launch counts its barriers from the value its own flag had when it started
   // (all flags of a row block end a launch at the same value).
   if (tid == 0) s_ub = atomicAdd(a.sync + (8 + xcc) * 64, 1u) & 31u;
   __syncthreads();
-  const int ub = (int)s_ub, rb = (int)xcc;
+  // (readfirstlane: the slot is workgroup-uniform, and the compiler should keep everything derived from it in SGPRs)
+  const int ub = __builtin_amdgcn_readfirstlane((int)s_ub), rb = __builtin_amdgcn_readfirstlane((int)xcc);
   const unsigned base = __hip_atomic_load(bar + ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int arow = rb * 16 + lr, ucol = ub * 16 + lr;
   // ---- this wave's weight fragments, resident for the whole sequence
@@ -517,26 +510,8 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
       if (st + 1 < a.S) x4 = *reinterpret_cast<const float4*>(a.xz + ((long)(st + 1) * BU + ee) * 4);
     }
     if (st + 1 == a.S) break;
-    // ---- XCD-local barrier.  Slices are in L2 once vmcnt drains; every workgroup then raises its own flag word (the 32
-    // flags of a row block share one 128-byte line) and the first 32 lanes poll that line: no read-modify-write on a
-    // shared counter, which the L2 would serialise 32-fold.
-    // (a workgroup-scope release fence alone does not drain vmcnt: stores are already ordered within a CU)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (w == 0) {
-      const unsigned target = base + (unsigned)(st + 1);
-      if (lane == 0) __hip_atomic_store(bar + ub, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned spins = 0;
-      for (;;) {
-        const unsigned v = lane < 32 ? __hip_atomic_load(bar + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-        if (__all((int)(v - target) >= 0)) break;
-        if (++spins > SEQ_SPIN_LIMIT) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-      }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- XCD-local barrier (tnt_seq_sync.h): slices are in L2 once vmcnt drains, one flag word per workgroup
+    tnt_seq_group_barrier(bar, ub, base + (unsigned)(st + 1), err);
   }
 }
 
