@@ -202,9 +202,9 @@ int32_t tnt_lstm_step_fwd_f32(const float* xz, const float* h_prev, const float*
                               const float* out_prev, float* h, float* c, float* out,
                               float* gates, int32_t B, int32_t U, const float* xz_bias, void* stream);
 /* Persistent form of the masked sequence forward of NIC.py:138-140: ONE launch runs the S dependent steps
- * (step s reads hs[s], cs[s], xz[s] and writes hs[s+1], cs[s+1], gates[s]; steps s >= mask_s0 are masked by column
- * s - mask_s0 of mask_ids[B][mask_T] and write the sequence output out[s - mask_s0]; mask_ids nullable = no mask,
- * no output).  hs/cs: [S+1][B][U] with slab 0 = the initial state; xz: [S][B][U][4]; gates: [S][B][U][4];
+ * (step s reads hs[s], cs[s], xz[s] and writes hs[s+1], cs[s+1], gates[s]; steps s >= mask_s0 write the sequence
+ * output out[s - mask_s0] (out nullable) and, if mask_ids[B][mask_T] is given, are masked by its column s - mask_s0;
+ * pass mask_s0 = S for neither).  hs/cs: [S+1][B][U] with slab 0 = the initial state; xz: [S][B][U][4]; gates: [S][B][U][4];
  * sync: 1025 uint32 of scratch owned by the caller, zero-initialised once and then left alone (flags and tickets carry
  * over from launch to launch; word 1024 is sticky: != 0 = a barrier timed out at some point and results are invalid).  Same arithmetic as S calls of tnt_lstm_step_fwd_f32.  A step pays one XCD-local barrier instead of a
  * dependent kernel launch and the recurrent weights stay in VGPRs; needs U == 512, B <= 128 and a 256-CU device on

@@ -614,11 +614,11 @@ extern "C" int32_t tnt_lstm_seq_fwd_f32(const float* xz, float* hs, float* cs, c
                                         float* gates, int32_t S, int32_t B, int32_t U, uint32_t* sync, void* stream) {
   if (S <= 0 || sync == nullptr) return TNT_BADARG(11);
   if (!tnt_lstm_seq_supported(B, U)) return TNT_BADARG(13);
-  if (mask_ids != nullptr && (mask_s0 < 0 || S - mask_s0 > mask_T)) return TNT_BADARG(7);
+  if (mask_s0 < 0 || mask_s0 > S || (mask_ids != nullptr && S - mask_s0 > mask_T)) return TNT_BADARG(7);
   hipStream_t s = tnt_stream(stream);
   LstmSeqArgs a;
   a.xz = xz; a.hs = hs; a.cs = cs; a.Ur = Ur; a.zbias = xz_bias; a.mask_ids = mask_ids; a.out = out; a.gates = gates;
-  a.S = S; a.B = B; a.U = U; a.mask_T = mask_T; a.mask_s0 = mask_ids ? mask_s0 : S; a.sync = sync;
+  a.S = S; a.B = B; a.U = U; a.mask_T = mask_T; a.mask_s0 = mask_s0; a.sync = sync;
   hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(256), dim3(1024), SEQ_LDS_BYTES, s, a);
   TNT_LAUNCH_CHECK();
   return 0;

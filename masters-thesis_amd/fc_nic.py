@@ -132,6 +132,7 @@ class NICfc(_DenseNIC):
         self.Hs, self.Cs = f(T + 2, B, U), f(T + 2, B, U)
         self.gates = f(T + 1, B, U, 4)
         self.Out = f(T, B, U)
+        self._init_seq_lstm(B, U)
         self.Out_d = f(T, B, U) if self.r_lstm > 0 else self.Out
         self.inter, self.ipre = f(n, H), f(n, H)
         self.inter_d = f(n, H) if self.r_out > 0 else self.inter
@@ -180,10 +181,13 @@ class NICfc(_DenseNIC):
             be.dropout(self.text, self.text, n, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
         self.gemm_sk(self.text, a.p("lstm/kernel"), self.XZ, n, 4 * U, E, E, 4 * U, 4 * U)   # bias: in the step kernel
         Ur, bl = a.p("lstm/recurrent_kernel"), a.p("lstm/bias")
-        for t in range(T):                                                                          # :318
-            be.lstm_step_fwd(self.XZ[t * B:(t + 1) * B], self.Hs[t], self.Cs[t], Ur, None, None, 0, self.cap, T, t,
-                             self.Out[t - 1] if t > 0 else None, self.Hs[t + 1], self.Cs[t + 1], self.Out[t],
-                             self.gates[t], B, U, xz_bias=bl)
+        if self._seq_lstm:       # the T masked steps (:318) as one persistent launch, see nic.NIC._forward
+            be.lstm_seq_fwd(self.XZ, self.Hs, self.Cs, Ur, bl, self.cap, T, 0, self.Out, self.gates, T, B, U, self.seq_sync)
+        else:
+            for t in range(T):                                                                      # :318
+                be.lstm_step_fwd(self.XZ[t * B:(t + 1) * B], self.Hs[t], self.Cs[t], Ur, None, None, 0, self.cap, T, t,
+                                 self.Out[t - 1] if t > 0 else None, self.Hs[t + 1], self.Cs[t + 1], self.Out[t],
+                                 self.gates[t], B, U, xz_bias=bl)
         out = self.Out
         if training and self.r_lstm > 0:                                                            # :321
             be.dropout(self.Out, self.Out_d, n, U, U, B, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds)

@@ -334,6 +334,16 @@ class ModelBase:
             raise RuntimeError(f"persistent LSTM kernel: barrier timeout (code {code}); results since the last check "
                                "are invalid.  Set model.use_seq_lstm = False before the first step to use the per-step kernels.")
 
+    def _init_seq_lstm(self, B, U):
+        """Opt in to the persistent sequence-forward kernel for this (B, U) on this device.  Probes once per process
+        (tnt_lstm_seq_supported synchronises), so it is called from _build, outside any capture."""
+        self._seq_lstm = bool(getattr(self, "use_seq_lstm", True) and hasattr(self.be, "lstm_seq_supported")
+                              and self.be.lstm_seq_supported(B, U))
+        if self._seq_lstm and self.__dict__.get("seq_sync") is None:
+            self.seq_sync = torch.zeros(1025, dtype=torch.int32, device=self.device)     # zeroed ONCE, never reset
+        elif not self._seq_lstm and "seq_sync" not in self.__dict__:
+            self.seq_sync = None
+
     def disable_seq_lstm(self):
         """Back to the per-step LSTM kernels (after a barrier timeout of the persistent one, or by choice): clears the
         error word, drops captured graphs / launch plans and rebuilds the step buffers on the next call."""

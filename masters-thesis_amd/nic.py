@@ -158,10 +158,7 @@ class NIC(ModelBase):
         self.Hs, self.Cs = f(T + 2, B, U), f(T + 2, B, U)
         self.gates = f(T + 1, B, U, 4)
         self.Out = f(T, B, U)
-        # persistent sequence kernel: opt-in per shape and per device (probe launch, so decided here, outside any capture)
-        self._seq_lstm = bool(getattr(self, "use_seq_lstm", True) and hasattr(self.be, "lstm_seq_supported")
-                              and self.be.lstm_seq_supported(B, U))
-        self.seq_sync = torch.zeros(1025, dtype=torch.int32, device=self.device) if self._seq_lstm else None
+        self._init_seq_lstm(B, U)        # persistent sequence kernel: opt-in per shape and per device
         self.logits = f(T * B, ldV)
         self.loss_row, self.corr_row = f(T * B), f(T * B)
         self.met = f(8)

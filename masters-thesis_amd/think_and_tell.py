@@ -146,6 +146,7 @@ class CaptionGenerator(ModelBase):
         self.Hs, self.Cs = f(T + 2, B, U), f(T + 2, B, U)
         self.gates = f(T + 1, B, U, 4)
         self.Out = f(R1, U)
+        self._init_seq_lstm(B, U)
         self.Hd = f(R1, U) if self.r_dec > 0 else self.Out
         self.mid = f(R1, U) if self.sat else None
         self.logits, self.dlogits = f(R1, ldV), f(R1, ldV)
@@ -199,9 +200,13 @@ class CaptionGenerator(ModelBase):
         self.gemm_sk(self.Xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U, bias=a.p("lstm/bias"))
         Ur = a.p("lstm/recurrent_kernel")
         mask = self.lenmask if self.sat else None
-        for t in range(T + 1):
-            be.lstm_step_fwd(self.XZ[t * B:(t + 1) * B], self.Hs[t], self.Cs[t], Ur, None, None, 0, mask, T + 1, t, None,
-                             self.Hs[t + 1], self.Cs[t + 1], self.Out[t * B:(t + 1) * B], self.gates[t], B, U)
+        if self._seq_lstm and mask is None:     # unmasked sequence: one persistent launch (tnt_lstm_seq_fwd_f32); the masked
+            # ShowAndTell form zeroes masked outputs instead of repeating them and stays on the step kernel
+            be.lstm_seq_fwd(self.XZ, self.Hs, self.Cs, Ur, None, None, 0, 0, self.Out, self.gates, T + 1, B, U, self.seq_sync)
+        else:
+            for t in range(T + 1):
+                be.lstm_step_fwd(self.XZ[t * B:(t + 1) * B], self.Hs[t], self.Cs[t], Ur, None, None, 0, mask, T + 1, t, None,
+                                 self.Hs[t + 1], self.Cs[t + 1], self.Out[t * B:(t + 1) * B], self.gates[t], B, U)
         hd = self.Out
         if training and self.r_dec > 0:
             be.dropout(self.Out, self.Hd, R1, U, U, B, U, 0, self.r_dec, sd, S_OUT, 0, ds)

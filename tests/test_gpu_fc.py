@@ -72,3 +72,32 @@ def test_forward_gradients_greedy(dims):
         g = model.get_gradient(k) + 2 * L2.get(k, 0.0) * w0[k]
         want_g = grads[k] if grads[k] is not None else np.zeros_like(w0[k])
         assert np.abs(g - want_g).max() <= 1e-4 * np.abs(want_g).max() + 1e-9, k
+
+
+def test_full_width_forward_and_persistent_lstm():
+    """call_fc at the BASELINE widths (B = 64, U = E = 512, V = 5001, T = 15; N shortened to 5000): eval probabilities
+    against the float64 oracle, and -- where the device supports it -- the persistent sequence kernel
+    (tnt_lstm_seq_fwd_f32, T masked steps in one launch) against the per-step kernels over captured training steps."""
+    from masters_thesis_amd.optimizers import Adam
+    dims = (64, 5000, 15, 5001, 512, 512)
+    B, N, T, V, U, E = dims
+    rng = np.random.default_rng(73)
+    a, orc = build(rng, (0, 0, 0, 0, 0), dims)
+    b, _ = build(np.random.default_rng(73), (0, 0, 0, 0, 0), dims)
+    for k, v in orc.p.items():
+        b.set_weight(k, v)
+    b.use_seq_lstm = False
+    for m in (a, b):
+        m.compile(Adam(learning_rate=1e-4, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    data, tgt = synth_batch(B, N, T, V, U, rng)
+    probs, cache = orc.forward(data, False)
+    p, _ = a(data, training=False)
+    assert np.abs(np.log(p.cpu().numpy()) - np.log(probs)).max() <= 1e-4 * np.abs(cache["logits"]).max()
+    for step in range(4):
+        ra, rb = a.train_step((data, tgt)).as_floats(), b.train_step((data, tgt)).as_floats()
+        assert abs(ra["loss"] - rb["loss"]) <= 2e-5 * abs(rb["loss"]), (step, ra, rb)
+    a.check_device_errors()
+    assert not b._seq_lstm
+    if a._seq_lstm:                       # rounding-level differences only
+        for k in orc.p:
+            assert np.abs(a.get_weight(k) - b.get_weight(k)).max() <= 3e-5, k
