@@ -2,6 +2,9 @@
 import sys
 import torch
 sys.path.insert(0, ".")
+import os
+from masters_thesis_amd import _lib
+if os.environ.get("TNT_LIB"): _lib.LIB_PATH = os.environ["TNT_LIB"]
 import masters_thesis_amd.ops as ops
 be = ops.backend()
 rows, V, ld = 960, 5001, 5004
