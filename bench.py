@@ -5,18 +5,25 @@
 
 One "step" = one full train_step (forward + backward + clip + Adam) of the hot path on one
 synthetic batch already resident in HBM.  Workload at N=1 is BASELINE config 2
-(20k-voxel dense encoder + 512-unit LSTM, B=64, T=15, V=5001); ``--workload attention`` runs
-config 3.  N>1: one process per GPU (torchrun), weak scaling (B=64 per GPU), gradient
-all-reduce of the flat arena over RCCL.  Rank 0 prints ONE JSON line.
+(20k-voxel dense encoder + 512-unit LSTM, B=64, T=15, V=5001); config 3 (region-wise encoder +
+attention) is timed in the same run and reported as the ``config3`` sub-object (``--workload
+attention`` makes it the headline instead).  N>1: one process per GPU, weak scaling (B=64 per
+GPU), gradient exchange over RCCL; when WORLD_SIZE is not set the script starts the N ranks itself
+(``python -m torch.distributed.run``, before anything touches the GPU) and relays rank 0's line.
+Rank 0 prints ONE JSON line.
+
+``roofline`` describes the C-ABI call group that takes the most device time per step, found live:
+one eager step is recorded (every launch goes through HipBackend._call), each distinct call is then
+timed back to back with HIP events on the launch stream, and its algorithmic work (SURVEY 8d
+formulas at the run's dims) is priced against the gfx950 peak that bounds it.  ``kernels`` lists the
+other groups, ``step_frac`` prices the whole step (30.3 GFLOP for config 2) against the FP32-MFMA peak.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -25,15 +32,23 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 B, T, V, U, E, N_VOX = 64, 15, 5001, 512, 512, 20000
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak
-# vocabulary-head forward GEMM (one-round kernel), measured HBM bytes per launch: 2 x FETCH_SIZE(13029 KiB) +
-# WRITE_SIZE(18886 KiB), profiles/r01_gemm_head_pmc_v3.txt (algorithmic: 31.4 MB -- A 1.97 + B 10.25 read, C 19.2 written)
-PMC_TRAFFIC_BYTES = int((2 * 13029.1 + 18885.8) * 1024)
-# config 3's head GEMM (K = 256), profiles/r01_gemm_head_c3_pmc.txt
-PMC_TRAFFIC_BYTES_C3 = int((2 * 6575.1 + 18885.0) * 1024)
+# HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes), by call
+# group; filled from the summaries committed under profiles/ (None = not collected for that kernel)
+PMC_TRAFFIC = {
+    "dense": {"tnt_gemm_f32 NN 960x5001x512": (int((2 * 13029.1 + 18885.8) * 1024), "profiles/r01_gemm_head_pmc_v3.txt")},
+    "attention": {"tnt_gemm_f32 NN 960x5001x256": (int((2 * 6575.1 + 18885.0) * 1024), "profiles/r01_gemm_head_c3_pmc.txt")},
+}
+STEP_GFLOP = {"dense": 30.3, "attention": 22.0}          # SURVEY 8d, whole training step
+WORKLOAD_NAME = {
+    "dense": "config 2: AttemptFour NIC.py dense 20000->512 encoder + BatchNorm + 512-unit LSTM, V=5001, T=15, B=64/GPU",
+    "attention": "config 3: lc_NIC locally-dense 20000->360x32 + additive attention + 512-unit LSTM, V=5001, T=15, B=64/GPU",
+}
 
 
 def synth(rank, device):
     """SURVEY 8d synthetic batch: betas ~ N(0,1); caption = <start>, 6..13 tokens, <end>, zero pad."""
+    import numpy as np
+    import torch
     rng = np.random.default_rng(42 + rank)
     x = rng.standard_normal((B, N_VOX)).astype(np.float32)
     cap = np.zeros((B, T), np.int32)
@@ -68,6 +83,7 @@ def make_model(workload, device, grad_sync=None):
 
 def cpu_baseline(workload, host_batch, budget_s=20.0):
     """The oracle (numpy float32 port of the reference path) timed on this host's cores."""
+    import numpy as np
     from oracle import models as M
     x, cap, z, tgt = host_batch
     rng = np.random.default_rng(0)
@@ -108,49 +124,106 @@ def cpu_baseline(workload, host_batch, budget_s=20.0):
     return out
 
 
-def dominant_kernel_roofline(model, workload, steps=20):
-    """Times the dominant kernel of the step live with HIP events on the launch stream.
-    Dense workload: the vocabulary-head GEMM family (3 of them: logits, dW, dX), FP32-MFMA bound.
-    achieved = algorithmic FLOPs (2*M*N*K) / average launch duration."""
+# ------------------------------------------------------------------------------------------ live per-kernel roofline
+def _work_model(name, a):
+    """(group key, algorithmic FLOPs, algorithmic HBM bytes) of one recorded C-ABI call (argument layouts: include/tnt_hip.h).
+    SURVEY 8d: a GEMM is 2*M*N*K FLOPs and reads A, B / writes C once; an LSTM step is 2*B*4U*U FLOPs; the optimizer
+    moves 7 words per parameter, the norm pass 2."""
+    if name in ("tnt_gemm_f32", "tnt_gemm_blas_f32", "tnt_gemm_acc_f32"):
+        if name == "tnt_gemm_f32":
+            M, N, K, tA, tB = a[5], a[6], a[7], a[11], a[12]
+        else:
+            M, N, K, tA, tB = a[3], a[4], a[5], a[9], a[10]
+        lay = ("T" if tA else "N") + ("T" if tB else "N")
+        return f"{name} {lay} {M}x{N}x{K}", 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N)
+    if name == "tnt_lstm_step_bwd_f32":
+        Bq, Uq = a[17], a[18]
+        if not a[0]:
+            return f"{name} (last step, no matmul)", 0.0, 0.0
+        return f"{name} B={Bq} U={Uq}", 2.0 * Bq * 4 * Uq * Uq, 0.0
+    if name == "tnt_lstm_step_fwd_f32":
+        Bq, Uq, D = a[15], a[16], a[6]
+        return f"{name} B={Bq} U={Uq} D={D}", 2.0 * Bq * 4 * Uq * (Uq + D), 0.0
+    if name in ("tnt_lstm_seq_fwd_f32", "tnt_lstm_seq_bwd_f32"):
+        S, Bq, Uq = (a[10], a[11], a[12]) if name.endswith("fwd_f32") else (a[-7], a[-6], a[-5])
+        return f"{name} S={S} B={Bq} U={Uq}", 2.0 * S * Bq * 4 * Uq * Uq, 0.0
+    if name == "tnt_dense_dw_skinny_f32":
+        Nq, Eq, Bk = a[3], a[4], a[5]
+        return f"{name} {Nq}x{Eq}x{Bk}", 2.0 * Nq * Eq * Bk, 4.0 * (Nq * Eq + Bk * Nq + Bk * Eq)
+    if name == "tnt_softmax_cce_f32":
+        rows, ld = a[6], a[8]
+        return f"{name} {rows}x{a[7]}", 0.0, 8.0 * rows * ld
+    return name, None, None
+
+
+def kernel_breakdown(model, batch, workload, reps=20):
+    """Records the launches of ONE eager training step, times every distinct C-ABI call back to back with HIP events
+    on the launch stream, and returns (dominant group's roofline dict, [other groups, largest first])."""
+    import torch
     be = model.be
-    Bt = B * T
-    if workload == "dense":
-        a = model.arena
-        Wo, ldV = a.p("time_distributed_softmax/kernel"), model.ldV
-        launch = lambda: be.gemm(model.Out, Wo, model.logits, Bt, V, U, U, ldV, ldV,
-                                 bias=a.p("time_distributed_softmax/bias"))
-        flops = 2.0 * Bt * V * U
-        name = "gemm1r_kernel<160,128> logits = Out[960x512] @ Wo[512x5001]"
-    else:
-        a = model.arena
-        Wo, ldV, H = a.p("time_distributed_softmax/kernel"), model.ldV, model.H
-        launch = lambda: be.gemm(model.inter_d, Wo, model.logits, Bt, V, H, H, ldV, ldV,
-                                 bias=a.p("time_distributed_softmax/bias"))
-        flops = 2.0 * Bt * V * H
-        name = "gemm1r_kernel<160,128> logits = inter[960x256] @ Wo[256x5001]"
-    for _ in range(3):
-        launch()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    saved_graphs = model._graphs
+    model._graphs = {}                          # next train_step runs its launch sequence eagerly
+    be._rec = rec = []
+    try:
+        model.train_step(batch)
+    finally:
+        be._rec = None
     torch.cuda.synchronize()
-    ev[0].record()
-    for _ in range(steps):
-        launch()
-    ev[1].record()
-    torch.cuda.synchronize()
-    dur_s = ev[0].elapsed_time(ev[1]) / 1e3 / steps
-    ach = flops / dur_s / 1e12
-    # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-    # separate runs, gfx950 correction of MI355X_MICROARCH.md applied): dense workload only.
-    traffic = PMC_TRAFFIC_BYTES if workload == "dense" else PMC_TRAFFIC_BYTES_C3
-    return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-            "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": traffic,
-            "traffic_source": "profiles/r01_gemm_head_pmc_v3.txt" if workload == "dense" else "profiles/r01_gemm_head_c3_pmc.txt", "kernel": name,
-            "avg_launch_us": round(dur_s * 1e6, 2), "flops_per_launch": flops}
+    model._graphs = saved_graphs
+    n_param = int(model.arena.total)
+    groups = {}
+    for fn, name, args in rec:
+        key, fl, by = _work_model(name, args)
+        if name == "tnt_adam_f32":
+            fl, by = 0.0, 28.0 * n_param
+        elif name == "tnt_seg_sqnorm_f32":
+            fl, by = 0.0, 8.0 * n_param
+        g = groups.setdefault(key, {"calls": 0, "fn": fn, "args": args, "flops": fl, "bytes": by})
+        g["calls"] += 1
+    out = []
+    for key, g in groups.items():
+        fn, args = g["fn"], g["args"]
+        for _ in range(2):
+            fn(*args)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(reps):
+            fn(*args)
+        ev1.record()
+        torch.cuda.synchronize()
+        us = ev0.elapsed_time(ev1) * 1e3 / reps
+        row = {"kernel": key, "calls_per_step": g["calls"], "avg_launch_us": round(us, 2),
+               "us_per_step": round(us * g["calls"], 1)}
+        fl, by = g["flops"], g["bytes"]
+        if fl is not None and (fl > 0 or by > 0):
+            t_f = fl / (MFMA_F32_PEAK_TF * 1e12)
+            t_b = by / (HBM_PEAK_GBS * 1e9)
+            if t_f >= t_b:
+                ach = fl / (us * 1e-6) / 1e12
+                row.update(bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                           frac=round(ach / MFMA_F32_PEAK_TF, 4), flops_per_launch=fl)
+            else:
+                ach = by / (us * 1e-6) / 1e9
+                row.update(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                           frac=round(ach / HBM_PEAK_GBS, 4), bytes_per_launch=by)
+            pmc = PMC_TRAFFIC.get(workload, {}).get(key)
+            row["traffic"] = pmc[0] if pmc else None
+            if pmc:
+                row["traffic_source"] = pmc[1]
+        out.append(row)
+    out.sort(key=lambda r: -r["us_per_step"])
+    priced = [r for r in out if "bound" in r]
+    dom = priced[0] if priced else {"kernel": out[0]["kernel"], "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": None, "traffic": None}
+    others = [r for r in out if r is not dom][:12]
+    total = round(sum(r["us_per_step"] for r in out), 1)
+    return dom, others, total
 
 
 def step_percentiles(model, batch, steps):
     """p10 / p50 / p90 of the per-step device time (HIP events between consecutive steps), measured in a
     separate loop after the timed region so the K timed steps stay undisturbed."""
+    import torch
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     torch.cuda.synchronize()
     ev[0].record()
@@ -163,6 +236,62 @@ def step_percentiles(model, batch, steps):
     return [pick(0.10), pick(0.50), pick(0.90)]
 
 
+def timed_steps(model, batch, steps, warmup, world=1, dist=None, device=None):
+    """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+    import torch
+    for _ in range(warmup):
+        model.train_step(batch)
+    torch.cuda.synchronize()
+    # The persistent LSTM kernel guards its barriers.  If the guard ever trips during the warm-up (it never has), every
+    # rank goes back to the per-step kernels together and warms up again, so the timed region measures valid steps.
+    sync = getattr(model, "seq_sync", None)
+    tripped = torch.tensor([1 if (sync is not None and int(sync[1024].item()) != 0) else 0], dtype=torch.int32, device=device)
+    if world > 1:
+        dist.all_reduce(tripped, op=dist.ReduceOp.MAX)
+    note = None
+    if int(tripped.item()):
+        model.disable_seq_lstm()
+        note = "persistent LSTM kernel disabled after a guard trip in warm-up; per-step kernels measured"
+        for _ in range(max(3, warmup)):
+            model.train_step(batch)
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.train_step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el, note
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start N ranks with torch.distributed.run as a CHILD process (this process has not
+    touched the GPU and never will) and relay rank 0's JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if p.returncode != 0 or not lines:
+        sys.stdout.write(p.stdout)
+        raise SystemExit(p.returncode or 1)
+    print(lines[-1], flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,20 +299,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="dense", choices=["dense", "attention"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config3", action="store_true", help="skip the config-3 sub-measurement of the default run")
     ap.add_argument("--host-inputs", action="store_true", help="feed numpy batches (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel schedule even at world size 1 (rehearsal)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torchrun with WORLD_SIZE={args.gpus} (got {world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    grad_sync = None
     use_dp = world > 1 or args.force_dp
-    saved_stdout = None
+    dist = None
     if use_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -198,7 +331,7 @@ def main():
     model = make_model(args.workload, device, None)
     if use_dp:
         from masters_thesis_amd import dp
-        dp.attach(model, world)
+        dp.attach(model, world, rank=rank)
         torch.cuda.synchronize()
         dist.barrier()
         sys.stdout.flush()
@@ -209,59 +342,46 @@ def main():
         x, cap, z, tgt = host_batch
         batch = ((x, cap, z, z), tgt)
 
-    for _ in range(args.warmup):
-        model.train_step(batch)
-    torch.cuda.synchronize()
-    # The persistent LSTM kernel guards its barriers with a timeout.  If that ever trips during the warm-up (it never has),
-    # every rank goes back to the per-step kernels together and warms up again, so the timed region measures valid steps.
-    sync = getattr(model, "seq_sync", None)
-    tripped = torch.tensor([1 if (sync is not None and int(sync[1024].item()) != 0) else 0], dtype=torch.int32, device=device)
-    if world > 1:
-        dist.all_reduce(tripped, op=dist.ReduceOp.MAX)
-    seq_note = None
-    if int(tripped.item()):
-        model.disable_seq_lstm()
-        seq_note = "persistent LSTM kernel disabled after a barrier timeout in warm-up; per-step kernels measured"
-        for _ in range(max(3, args.warmup)):
-            model.train_step(batch)
-        torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.train_step(batch)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    el, seq_note = timed_steps(model, batch, args.steps, args.warmup, world, dist, device)
     pct = step_percentiles(model, batch, min(args.steps, 200)) if args.steps >= 10 else None
     last = model.train_step(batch).as_floats()
-    model.check_device_errors()          # e.g. a barrier timeout of the persistent LSTM kernel would void the run
+    model.check_device_errors()          # a guard trip of the persistent LSTM kernel would void the run
 
     if rank == 0:
         tokens = world * B * T * args.steps
+        ms = el / args.steps * 1e3
         out = {
             "metric": "caption-tokens/sec training (20k-voxel enc, 512 LSTM, B=64)",
             "value": round(tokens / el, 1), "unit": "caption-tokens/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" + (" (host numpy batches, PCIe-inclusive)" if args.host_inputs else ""),
-            "config": {"workload": ("config 2: AttemptFour NIC.py dense 20000->512 encoder + BatchNorm + 512-unit LSTM, "
-                                    "V=5001, T=15, B=64/GPU" if args.workload == "dense" else
-                                    "config 3: lc_NIC locally-dense 20000->360x32 + additive attention + 512-unit LSTM, "
-                                    "V=5001, T=15, B=64/GPU"),
-                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
-                       "final_loss": round(last["loss"], 4), "step_ms_p10_p50_p90": pct},
+            "config": {"workload": WORKLOAD_NAME[args.workload], "global_batch": B * world, "seq_len": T,
+                       "parallelism": f"dp{world}", "final_loss": round(last["loss"], 4), "step_ms_p10_p50_p90": pct},
         }
         if seq_note:
             out["config"]["note"] = seq_note
-        out["roofline"] = dominant_kernel_roofline(model, args.workload)
+        if not use_dp:
+            dom, others, total = kernel_breakdown(model, batch, args.workload)
+            out["roofline"] = dom
+            out["kernels"] = others
+            out["kernel_us_per_step"] = total
+        gf = STEP_GFLOP[args.workload]
+        out["step_frac"] = {"gflop_per_step": gf, "achieved_tflops": round(gf / ms, 2), "peak": MFMA_F32_PEAK_TF,
+                            "frac": round(gf / ms / MFMA_F32_PEAK_TF, 4)}
+        if world == 1 and not use_dp and args.workload == "dense" and not args.no_config3:
+            del model
+            torch.cuda.empty_cache()
+            m3 = make_model("attention", device, None)
+            k3 = min(args.steps, 200)
+            el3, _ = timed_steps(m3, batch, k3, min(args.warmup, 20), 1, None, device)
+            ms3 = el3 / k3 * 1e3
+            dom3, others3, total3 = kernel_breakdown(m3, batch, "attention")
+            m3.check_device_errors()
+            out["config3"] = {"workload": WORKLOAD_NAME["attention"], "steps": k3, "ms_per_step": round(ms3, 4),
+                              "value": round(B * T * k3 / el3, 1), "unit": "caption-tokens/s", "roofline": dom3,
+                              "kernels": others3[:6], "kernel_us_per_step": total3,
+                              "step_frac": round(STEP_GFLOP["attention"] / ms3 / MFMA_F32_PEAK_TF, 4)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, host_batch)
         print(json.dumps(out), flush=True)

@@ -205,15 +205,20 @@ int32_t tnt_lstm_step_fwd_f32(const float* xz, const float* h_prev, const float*
  * (step s reads hs[s], cs[s], xz[s] and writes hs[s+1], cs[s+1], gates[s]; steps s >= mask_s0 write the sequence
  * output out[s - mask_s0] (out nullable) and, if mask_ids[B][mask_T] is given, are masked by its column s - mask_s0;
  * pass mask_s0 = S for neither).  hs/cs: [S+1][B][U] with slab 0 = the initial state; xz: [S][B][U][4]; gates: [S][B][U][4];
- * sync: 1025 uint32 of scratch owned by the caller, zero-initialised once and then left alone (flags and tickets carry
- * over from launch to launch; word 1024 is sticky: != 0 = a barrier timed out at some point and results are invalid).  Same arithmetic as S calls of tnt_lstm_step_fwd_f32.  A step pays one XCD-local barrier instead of a
+ * sync: 1025 uint32 of scratch owned by the caller, zeroed before first use and after an error, never in between (the
+ * kernel re-arms its own counters when it ends, so a captured launch replays without any reset node; protocol in
+ * csrc/tnt_seq_sync.h).  Word 1024 is the sticky error word: 1 = a barrier timed out, 2 = a launch did not place 32
+ * workgroups on each XCD; results are invalid from then on.  guard_out (nullable): one float the kernel sets to the error
+ * code when it sees the error word set (never cleared by the device), so the caller can carry the check along with
+ * the metrics it reads anyway; tnt_step_tick / tnt_adam_f32 / tnt_sgd_f32 take the error word as `guard` and leave the
+ * model state untouched when it is set.  S <= 64.  Same arithmetic as S calls of tnt_lstm_step_fwd_f32.  A step pays one XCD-local barrier instead of a
  * dependent kernel launch and the recurrent weights stay in VGPRs; needs U == 512, B <= 128 and a 256-CU device on
  * which a 256-workgroup launch places 32 workgroups on each of the 8 XCDs: tnt_lstm_seq_supported() tests exactly that
  * (one synchronising probe launch per process, so call it outside any graph capture) and returns 1 or 0. */
 int32_t tnt_lstm_seq_supported(int32_t B, int32_t U);
 int32_t tnt_lstm_seq_fwd_f32(const float* xz, float* hs, float* cs, const float* Ur, const float* xz_bias,
                              const int32_t* mask_ids, int32_t mask_T, int32_t mask_s0, float* out,
-                             float* gates, int32_t S, int32_t B, int32_t U, uint32_t* sync, void* stream);
+                             float* gates, int32_t S, int32_t B, int32_t U, uint32_t* sync, float* guard_out, void* stream);
 /* bwd of one step, fused with the recurrent matmul of the step after it:
  *   da = da_pass_in + dh_ext + (dz_next ? dz_next[B][U][4] @ Ur^T : 0)
  *   dout = dout_in + dout_t ; masked rows pass (da, dc, dout) through, dz = 0
@@ -317,11 +322,11 @@ int32_t tnt_adam_f32(float* theta, float* m, float* v, const float* grad,
                      const int32_t* span_seg, const int64_t* span_off, const int32_t* span_len,
                      const float* seg_l2, const float* sq, const float* sq_override,
                      int32_t nspan, float lr_t, const float* lr_t_dev, float beta1, float beta2,
-                     float eps, float clipnorm, void* stream);
+                     float eps, float clipnorm, const uint32_t* guard, void* stream);
 int32_t tnt_sgd_f32(float* theta, float* mom, const float* grad, const int32_t* span_seg,
                     const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
                     const float* sq, const float* sq_override, int32_t nspan, float lr,
-                    const float* lr_dev, float momentum, float clipnorm, void* stream);
+                    const float* lr_dev, float momentum, float clipnorm, const uint32_t* guard, void* stream);
 /* Sharpness-aware minimisation helper (CaptionGenerator.train_step_SAM, ThinkAndTell/model.py:166-233;
  * lc_NIC.train_step_sam, lc_NIC.py:713-838).  mode 0: e_w = (g + 2 lambda theta) * rho/(||g||+1e-12)
  * with ||g||^2 = sum_s sq[s] (from tnt_seg_sqnorm_f32); theta += e_w; e_w stored.  mode 1: theta -= e_w. */
@@ -329,9 +334,12 @@ int32_t tnt_sam_f32(float* theta, const float* grad, float* ew, const int32_t* s
                     const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
                     const float* sq, int32_t nseg, int32_t nspan, float rho, int32_t mode, void* stream);
 /* device-resident step state, advanced inside the (captured) step:
- * adam_t += 1; lr_t = lr[0]*sqrt(1-b2^t)/(1-b1^t); drop_step += 1.  Pointers nullable. */
+ * adam_t += 1; lr_t = lr[0]*sqrt(1-b2^t)/(1-b1^t); drop_step += 1.  Pointers nullable.
+ * guard (nullable): a device error word (tnt_lstm_seq_fwd_f32); when it is non-zero nothing is advanced, and
+ * tnt_adam_f32 / tnt_sgd_f32 given the same word skip their update: a step whose forward pass was invalid leaves
+ * weights, moments, t and the dropout stream exactly as they were, so the caller can redo it. */
 int32_t tnt_step_tick(int64_t* adam_t, uint32_t* drop_step, const float* lr, float* lr_t,
-                      float beta1, float beta2, void* stream);
+                      float beta1, float beta2, const uint32_t* guard, void* stream);
 
 /* ---- region-wise encoder: layers.LocallyDense.call (layers.py:43-48) ------------
  * CSR groups: idx[goff[r] .. goff[r+1]) are the voxel columns of group r; W is the

@@ -32,7 +32,7 @@ SIGNATURES = {
     "tnt_embedding_fwd_f32": [P, P, P, I32, I32, I32, I32, I32, P],
     "tnt_embedding_bwd_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, P],
     "tnt_lstm_seq_supported": [I32, I32],
-    "tnt_lstm_seq_fwd_f32": [P, P, P, P, P, P, I32, I32, P, P, I32, I32, I32, P, P],
+    "tnt_lstm_seq_fwd_f32": [P, P, P, P, P, P, I32, I32, P, P, I32, I32, I32, P, P, P],
     "tnt_lstm_step_fwd_f32": [P, P, P, P, P, P, I32, P, I32, I32, P, P, P, P, P, I32, I32, P, P],
     "tnt_lstm_step_bwd_f32": [P, P, P, P, P, P, P, P, I32, I32, P, P, P, P, P, P, P, I32, I32, P, I32, P, P],
     "tnt_softmax_cce_f32": [P, P, P, P, P, P, I32, I32, I32, F32, I32, I32, P],
@@ -54,9 +54,9 @@ SIGNATURES = {
     "tnt_sum_f32": [P, P, I32, F32, P],
     "tnt_l2_total_f32": [P, P, I32, P, P],
     "tnt_seg_sqnorm_f32": [P, P, P, P, P, P, P, P, P, P, P, I32, I32, P],
-    "tnt_adam_f32": [P, P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, F32, F32, P],
-    "tnt_sgd_f32": [P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, P],
-    "tnt_step_tick": [P, P, P, P, F32, F32, P],
+    "tnt_adam_f32": [P, P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, F32, F32, P, P],
+    "tnt_sgd_f32": [P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, P, P],
+    "tnt_step_tick": [P, P, P, P, F32, F32, P, P],
     "tnt_sam_f32": [P, P, P, P, P, P, P, P, I32, I32, F32, I32, P],
     "tnt_gemm_f32_tile": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, F32, I32, I32, P, I32, I32, P],
     "tnt_locally_dense_fwd_f32": [P, I32, P, P, P, P, P, P, I32, I32, I32, F32, P],

@@ -404,27 +404,29 @@ __global__ __launch_bounds__(64 * NWB) void lstm_bwd_lds_kernel(LstmBwdArgs a) {
 //   * Work split as in lstm_fwd_kernel<16, 8>: workgroup = 16 batch rows x 16 hidden units, 16 waves, wave w owns
 //     the 32 contraction rows k = 32w .. 32w+31; its weight fragments (8 x float4 per lane = the whole 128 KB slice
 //     over the workgroup) are loaded ONCE.
-//   * The 32 workgroups of one row block exchange h through global memory and must share an L2: a row block is
-//     pinned to one XCD.  256 workgroups are launched (one per CU: 1024 threads + 64 KB of LDS), each reads its
-//     XCC_ID, takes a ticket in that XCD (= its unit block) and works on row block XCC_ID; the other XCDs' workgroups exit.
-//     Plain stores + an explicit s_waitcnt vmcnt(0) publish a slice in the XCD's L2 (vector L1 is write-through), plain
-//     loads read it: every h slab is written once per launch and read only after its barrier.
+//   * The 32 workgroups of one row block exchange h through global memory and must share an L2: a workgroup reads the
+//     XCD it runs on (XCC_ID), takes a ticket in that XCD (= its unit block) and works on row block XCC_ID; 256
+//     workgroups are launched (one per CU: 1024 threads + 64 KB of LDS), the workgroups of XCDs without a row block exit.
+//     Hand-off per step (tnt_seq_sync.h): plain h stores, drained by every storing wave, one flag per workgroup; the
+//     consumers read the h slab with L1-bypassing (sc1) loads only, so no L1 invalidate is needed.
 //   * Epilogue operands that the same thread produced a step earlier (c, h, previous output) are carried in registers.
-//   * Barriers spin a bounded number of times; on timeout (or a workgroup census that is not 32 per XCD) the error
-//     word is set and every wave leaves -- wrong results, never a hung grid.  tnt_lstm_seq_supported() checks the
-//     census once per process before a model opts in.
+//   * Barriers spin a bounded number of times; on timeout, or on a ticket outside 0..31 (a launch that did not place
+//     exactly 32 workgroups on the XCD), the error word is set and every wave leaves -- wrong results, never a hung
+//     grid.  The last workgroup of a group to leave resets the group's counters and advances its epoch; barrier
+//     targets are epoch * 64 + step.  tnt_lstm_seq_supported() checks the census once per process before a model opts in.
 struct LstmSeqArgs {
   const float* xz; float* hs; float* cs; const float* Ur; const float* zbias;
   const int* mask_ids; float* out; float* gates;
   int S, B, U, mask_T, mask_s0;
-  unsigned* sync;        // [8][64] barrier flags (32 used per XCD), [8][64] tickets, then the error word; zero-initialised ONCE
+  unsigned* sync;        // TNT_SEQ_SYNC_WORDS words, layout and protocol in tnt_seq_sync.h
+  float* guard_out;      // nullable: set to the error code when the error word is seen set
 };
 
 __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   constexpr int NWF = 16, SS = 8, CK = 32;
-  extern __shared__ float seq_lds[];                       // 64 KB requested: one workgroup per CU
+  extern __shared__ __attribute__((aligned(16))) float seq_lds[];       // > 64 KB requested: one workgroup per CU
   float (*red)[4][16][17] = reinterpret_cast<float (*)[4][16][17]>(seq_lds);       // [NWF][4][16][17] = 69.6 KB
-  __shared__ unsigned s_ub;
+  unsigned* s_slot = reinterpret_cast<unsigned*>(seq_lds + NWF * 4 * 16 * 17);      // 2 words behind the reduction buffer
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
   const int U = a.U, B = a.B;
@@ -433,15 +435,13 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   if ((int)xcc >= nrb) return;                             // this XCD has no row block
   unsigned* bar = a.sync + xcc * 64;
   unsigned* err = a.sync + TNT_SEQ_ERR;
-  // Nothing in `sync` is reset between launches (a captured memset node proved unreliable in front of this kernel):
-  // tickets count on modulo 32 -- exactly 32 workgroups per XCD per launch, see tnt_lstm_seq_supported -- and the
-  // barrier flags only ever grow; a launch counts its barriers from the value its own flag had when it started
-  // (all flags of a row block end a launch at the same value).
-  if (tid == 0) s_ub = atomicAdd(a.sync + (8 + xcc) * 64, 1u) & 31u;
-  __syncthreads();
-  // (readfirstlane: the slot is workgroup-uniform, and the compiler should keep everything derived from it in SGPRs)
-  const int ub = __builtin_amdgcn_readfirstlane((int)s_ub), rb = __builtin_amdgcn_readfirstlane((int)xcc);
-  const unsigned base = __hip_atomic_load(bar + ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const TntSeqSlot slot = tnt_seq_enter(a.sync, xcc, s_slot);
+  if (slot.ub < 0) {                                       // error word set (tnt_seq_sync.h)
+    if (tid == 0 && a.guard_out) a.guard_out[0] = 2.f;
+    return;
+  }
+  const int ub = slot.ub, rb = __builtin_amdgcn_readfirstlane((int)xcc);
+  const __amdgpu_buffer_rsrc_t hs_rsrc = tnt_rsrc(a.hs, (unsigned)((long)(a.S + 1) * B * U * 4));
   const int arow = rb * 16 + lr, ucol = ub * 16 + lr;
   // ---- this wave's weight fragments, resident for the whole sequence
   float4 bv[SS];
@@ -463,11 +463,12 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   }
   for (int st = 0; st < a.S; ++st) {
     // ---- A fragments: this row block's h of the previous step (own XCD's L2 after the barrier)
-    const float* hprev = a.hs + (long)st * BU;
+    // (sc1 loads: the slab was stored by the other workgroups of this group one barrier ago)
     float av[SS];
 #pragma unroll
     for (int j = 0; j < SS / 4; ++j) {
-      const float4 t = ld4g(hprev + (long)arow * U + w * CK + j * 16 + kq * 4, arow < B);
+      const float4 t = arow < B ? tnt_ld4_l2(hs_rsrc, (unsigned)(((long)st * BU + (long)arow * U + w * CK + j * 16 + kq * 4) * 4))
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
       av[4 * j + 0] = t.x; av[4 * j + 1] = t.y; av[4 * j + 2] = t.z; av[4 * j + 3] = t.w;
     }
     int mid = 1;
@@ -511,8 +512,9 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
     }
     if (st + 1 == a.S) break;
     // ---- XCD-local barrier (tnt_seq_sync.h): slices are in L2 once vmcnt drains, one flag word per workgroup
-    tnt_seq_group_barrier(bar, ub, base + (unsigned)(st + 1), err);
+    tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, st + 1), err);
   }
+  tnt_seq_leave(a.sync, xcc, a.guard_out);
 }
 
 // census of a 256 x 1024-thread launch: how many workgroups land on each XCC_ID
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(1024) void xcc_census_kernel(unsigned* hist) {
   if (threadIdx.x == 0) { seq_lds[0] = 0.f; atomicAdd(&hist[tnt_xcc_id() & 15u], 1u); }
 }
 
-constexpr int SEQ_LDS_BYTES = 16 * 4 * 16 * 17 * 4;      // the reduction buffer; > 64 KB, so one workgroup per CU
+constexpr int SEQ_LDS_BYTES = 16 * 4 * 16 * 17 * 4 + 16;      // reduction buffer + slot words; > 64 KB, so one workgroup per CU
 
 }  // namespace
 
@@ -611,14 +613,16 @@ extern "C" int32_t tnt_lstm_seq_supported(int32_t B, int32_t U) {
 
 extern "C" int32_t tnt_lstm_seq_fwd_f32(const float* xz, float* hs, float* cs, const float* Ur, const float* xz_bias,
                                         const int32_t* mask_ids, int32_t mask_T, int32_t mask_s0, float* out,
-                                        float* gates, int32_t S, int32_t B, int32_t U, uint32_t* sync, void* stream) {
-  if (S <= 0 || sync == nullptr) return TNT_BADARG(11);
+                                        float* gates, int32_t S, int32_t B, int32_t U, uint32_t* sync, float* guard_out,
+                                        void* stream) {
+  if (S <= 0 || S - 1 > TNT_SEQ_MAX_BARRIERS || sync == nullptr) return TNT_BADARG(11);
   if (!tnt_lstm_seq_supported(B, U)) return TNT_BADARG(13);
+  if ((long)(S + 1) * B * U * 4 >= (1L << 32)) return TNT_BADARG(2);
   if (mask_s0 < 0 || mask_s0 > S || (mask_ids != nullptr && S - mask_s0 > mask_T)) return TNT_BADARG(7);
   hipStream_t s = tnt_stream(stream);
   LstmSeqArgs a;
   a.xz = xz; a.hs = hs; a.cs = cs; a.Ur = Ur; a.zbias = xz_bias; a.mask_ids = mask_ids; a.out = out; a.gates = gates;
-  a.S = S; a.B = B; a.U = U; a.mask_T = mask_T; a.mask_s0 = mask_s0; a.sync = sync;
+  a.S = S; a.B = B; a.U = U; a.mask_T = mask_T; a.mask_s0 = mask_s0; a.sync = sync; a.guard_out = guard_out;
   hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(256), dim3(1024), SEQ_LDS_BYTES, s, a);
   TNT_LAUNCH_CHECK();
   return 0;

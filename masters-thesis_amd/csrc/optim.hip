@@ -82,9 +82,10 @@ __device__ __forceinline__ float clip_scale(const float* sq, const float* sq_ove
 __global__ __launch_bounds__(256) void adam_kernel(float* theta, float* m, float* v, const float* grad, SpanTab t,
                                                    const float* sq, const float* sq_override, int nspan, float lr_t,
                                                    const float* lr_t_dev, float b1, float b2, float eps,
-                                                   float clipnorm) {
+                                                   float clipnorm, const uint32_t* guard) {
   const int sp = blockIdx.x;
   if (sp >= nspan) return;
+  if (guard && guard[0] != 0u) return;       // the step's forward pass was invalid: leave the model untouched
   if (lr_t_dev) lr_t = lr_t_dev[0];
   const long off = t.span_off[sp];
   const int len = t.span_len[sp];
@@ -122,9 +123,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* theta, float* m, float
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* theta, float* mom, const float* grad, SpanTab t,
                                                   const float* sq, const float* sq_override, int nspan, float lr,
-                                                  const float* lr_dev, float momentum, float clipnorm) {
+                                                  const float* lr_dev, float momentum, float clipnorm,
+                                                  const uint32_t* guard) {
   const int sp = blockIdx.x;
   if (sp >= nspan) return;
+  if (guard && guard[0] != 0u) return;
   if (lr_dev) lr = lr_dev[0];
   const long off = t.span_off[sp];
   const int len = t.span_len[sp];
@@ -172,8 +175,9 @@ __global__ __launch_bounds__(256) void sam_kernel(float* theta, const float* gra
 // advances the device-resident step state (so a captured hipGraph replays with fresh values):
 //   adam_t += 1; lr_t = lr * sqrt(1-b2^t)/(1-b1^t); drop_step += 1
 __global__ void step_tick_kernel(int64_t* adam_t, uint32_t* drop_step, const float* lr, float* lr_t, float b1,
-                                 float b2) {
+                                 float b2, const uint32_t* guard) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (guard && guard[0] != 0u) return;
   if (drop_step) drop_step[0] += 1u;
   if (adam_t) {
     const int64_t t = adam_t[0] + 1;
@@ -188,9 +192,9 @@ __global__ void step_tick_kernel(int64_t* adam_t, uint32_t* drop_step, const flo
 }  // namespace
 
 extern "C" int32_t tnt_step_tick(int64_t* adam_t, uint32_t* drop_step, const float* lr, float* lr_t, float beta1,
-                                 float beta2, void* stream) {
+                                 float beta2, const uint32_t* guard, void* stream) {
   hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, tnt_stream(stream), adam_t, drop_step, lr, lr_t, beta1,
-                     beta2);
+                     beta2, guard);
   TNT_LAUNCH_CHECK();
   return 0;
 }
@@ -223,11 +227,11 @@ extern "C" int32_t tnt_l2_total_f32(const float* wsq, const float* seg_l2, int32
 extern "C" int32_t tnt_adam_f32(float* theta, float* m, float* v, const float* grad, const int32_t* span_seg,
                                 const int64_t* span_off, const int32_t* span_len, const float* seg_l2, const float* sq,
                                 const float* sq_override, int32_t nspan, float lr_t, const float* lr_t_dev, float beta1,
-                                float beta2, float eps, float clipnorm, void* stream) {
+                                float beta2, float eps, float clipnorm, const uint32_t* guard, void* stream) {
   if (nspan <= 0) return 0;
   SpanTab t{span_seg, span_off, span_len, nullptr, seg_l2};
   hipLaunchKernelGGL(adam_kernel, dim3(nspan), dim3(256), 0, tnt_stream(stream), theta, m, v, grad, t, sq, sq_override,
-                     nspan, lr_t, lr_t_dev, beta1, beta2, eps, clipnorm);
+                     nspan, lr_t, lr_t_dev, beta1, beta2, eps, clipnorm, guard);
   TNT_LAUNCH_CHECK();
   return 0;
 }
@@ -235,11 +239,11 @@ extern "C" int32_t tnt_adam_f32(float* theta, float* m, float* v, const float* g
 extern "C" int32_t tnt_sgd_f32(float* theta, float* mom, const float* grad, const int32_t* span_seg,
                                const int64_t* span_off, const int32_t* span_len, const float* seg_l2, const float* sq,
                                const float* sq_override, int32_t nspan, float lr, const float* lr_dev, float momentum,
-                               float clipnorm, void* stream) {
+                               float clipnorm, const uint32_t* guard, void* stream) {
   if (nspan <= 0) return 0;
   SpanTab t{span_seg, span_off, span_len, nullptr, seg_l2};
   hipLaunchKernelGGL(sgd_kernel, dim3(nspan), dim3(256), 0, tnt_stream(stream), theta, mom, grad, t, sq, sq_override,
-                     nspan, lr, lr_dev, momentum, clipnorm);
+                     nspan, lr, lr_dev, momentum, clipnorm, guard);
   TNT_LAUNCH_CHECK();
   return 0;
 }

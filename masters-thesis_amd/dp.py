@@ -37,7 +37,7 @@ def make_grad_sync(world, bucket_elems=None):
                 lo = max(0, hi - bucket_elems)
                 dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM)
                 hi = lo
-        dist.all_reduce(model.arena.sq_override, op=dist.ReduceOp.SUM)
+        dist.all_reduce(_sparse_norm_slot(model), op=dist.ReduceOp.SUM)
     sync.world = world
     return sync
 
@@ -116,7 +116,7 @@ class PipelinedDenseSync:
         w_lstm = self._ar(a.grad[lstm0:head0])
         cap(("dpB2", B, T), lambda: (m._bwd_seq_front(B, T), m.join()))
         # the 40-byte sparse-norm vector rides in the same launch as the last gradient bucket
-        w_front = dist.all_reduce_coalesced([a.grad[front0:lstm0], a.sq_override], op=dist.ReduceOp.SUM, async_op=True)
+        w_front = dist.all_reduce_coalesced([a.grad[front0:lstm0], _sparse_norm_slot(m)], op=dist.ReduceOp.SUM, async_op=True)
         w_dpre = self._gather(dpre_all, m.dpre)
         # the head update needs only its own (long finished) all-reduce: it runs while the small, latency-bound
         # all-gather of dpre -- the one collective on the critical path -- is in flight
@@ -179,7 +179,7 @@ class PipelinedAttentionSync:
         cap(("dpB1", B, T), lambda: m._bwd_chain(B, T))
         w_lstm = ar(a.grad[lstm0:head0])
         cap(("dpB2", B, T), lambda: m._bwd_emb(B, T))
-        w_emb = dist.all_reduce_coalesced([a.grad[emb0:lstm0], a.sq_override], op=dist.ReduceOp.SUM, async_op=True)
+        w_emb = dist.all_reduce_coalesced([a.grad[emb0:lstm0], _sparse_norm_slot(m)], op=dist.ReduceOp.SUM, async_op=True)
         cap(("dpB3", B, T), lambda: m._bwd_front(B, T))
         w_front = ar(a.grad[:emb0])
         for w in (w_head, w_lstm):
@@ -193,12 +193,25 @@ class PipelinedAttentionSync:
         make_grad_sync(self.world)(model)
 
 
-def attach(model, world=None, bucket_elems=None, pipelined=None):
+def _sparse_norm_slot(model):
+    """The one slot of ``sq_override`` that carries data: the Embedding IndexedSlices squared norm (a per-rank partial
+    sum).  The other slots hold the -1 "not overridden" sentinel and must not take part in the SUM all-reduce."""
+    seg = model.emb_seg
+    return model.arena.sq_override[seg:seg + 1]
+
+
+def attach(model, world=None, bucket_elems=None, pipelined=None, rank=None):
     """Make ``model`` data-parallel over the default process group.  The dense-encoder NIC and the attention NIC
     (incl. its multi-subject form) get their pipelined schedules unless pipelined=False; every other model the
-    generic one (all-reduce of the whole arena between backward and update)."""
+    generic one (all-reduce of the whole arena between backward and update).
+    Each replica draws its own dropout masks: the Philox key is derived from (seed, rank), so G replicas see G
+    independent mask sets like G disjoint slices of one large batch would (rank 0 keeps the model's seed).  The
+    "G ranks x local batch == one rank on the concatenated batch" contract is exact for the deterministic part of
+    the step (tests/test_dp_gloo.py, dropout-free) and statistical for the masks."""
     world = dist.get_world_size() if world is None else world
+    rank = dist.get_rank() if rank is None else rank
     model.dp_world = world
+    model.seed = (int(model.seed) + 0x9E3779B1 * int(rank)) & 0x7FFFFFFFFFFFFFFF
     from .nic import NIC as DenseNIC
     from .lc_nic import NIC as AttentionNIC
     dense = type(model) is DenseNIC          # subclasses (fc mode) have other variables -> generic schedule

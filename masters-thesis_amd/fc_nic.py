@@ -182,7 +182,8 @@ class NICfc(_DenseNIC):
         self.gemm_sk(self.text, a.p("lstm/kernel"), self.XZ, n, 4 * U, E, E, 4 * U, 4 * U)   # bias: in the step kernel
         Ur, bl = a.p("lstm/recurrent_kernel"), a.p("lstm/bias")
         if self._seq_lstm:       # the T masked steps (:318) as one persistent launch, see nic.NIC._forward
-            be.lstm_seq_fwd(self.XZ, self.Hs, self.Cs, Ur, bl, self.cap, T, 0, self.Out, self.gates, T, B, U, self.seq_sync)
+            be.lstm_seq_fwd(self.XZ, self.Hs, self.Cs, Ur, bl, self.cap, T, 0, self.Out, self.gates, T, B, U, self.seq_sync,
+                            self._guard_out())
         else:
             for t in range(T):                                                                      # :318
                 be.lstm_step_fwd(self.XZ[t * B:(t + 1) * B], self.Hs[t], self.Cs[t], Ur, None, None, 0, self.cap, T, t,
@@ -262,14 +263,17 @@ class NICfc(_DenseNIC):
             self._run_captured(("train_up", B, T), self._update_graph)
         self.optimizer.iterations += 1
         m = self.met.clone()
-        return Metrics(loss=m[0], L2=m[2], accuracy=m[1], lr=self.lr_dev.clone()[0])
+        return self._metrics_from(m, loss=0, L2=2, accuracy=1, lr=self.lr_dev.clone()[0])
 
     def __call__(self, data, training=False):
         """lc_NIC.call_fc (lc_NIC.py:298-323): returns (probabilities (B,T,V), None)."""
         B, T = self._stage_inputs(data)
-        self._forward(B, T, training)
-        self.be.softmax_cce(self.logits, None, self.logits, None, None, None, T * B, self.V, self.ldV, 0.0)
-        return self.logits.view(T, B, self.ldV)[:, :, :self.V].permute(1, 0, 2).contiguous(), None
+
+        def run():
+            self._forward(B, T, training)
+            self.be.softmax_cce(self.logits, None, self.logits, None, None, None, T * B, self.V, self.ldV, 0.0)
+            return self.logits.view(T, B, self.ldV)[:, :, :self.V].permute(1, 0, 2).contiguous()
+        return self._guarded(run), None
 
     call = call_fc = __call__
 

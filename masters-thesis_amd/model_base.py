@@ -52,14 +52,31 @@ class _LayerView:
             self.model.set_weight(f"{self.name}/{w}", arr)
 
 
+class DeviceGuardError(RuntimeError):
+    """A device-side guard tripped (today: the barrier / census guard of the persistent LSTM kernel).  The step that
+    carried it left the model state untouched (the optimizer kernels skip on the error word) and the model has already
+    fallen back to the per-step kernels, so the caller may simply run the step again -- ``fit`` does."""
+
+
 class Metrics(dict):
-    """train_step/test_step result: values are 0-d device tensors (no host sync until read)."""
+    """train_step/test_step result: values are 0-d device tensors (no host sync until read).  The step's device guard
+    word (ModelBase.GUARD slot of ``met``, copied in the same clone as the metrics) rides along: reading the metrics
+    raises DeviceGuardError when it is set, so an invalid step cannot go unnoticed -- and costs no extra sync."""
+    _guard = _model = None
+
+    def guarded(self, model, word):
+        self._model, self._guard = model, word
+        return self
 
     def as_floats(self):
-        return {k: float(v) for k, v in self.items()}
+        out = {k: float(v) for k, v in self.items()}
+        if self._guard is not None and float(self._guard) != 0.0:
+            self._model._on_guard_trip(int(float(self._guard)))
+        return out
 
 
 class ModelBase:
+    GUARD = 7       # slot of ``met`` that carries the device guard word of the step (see Metrics)
     # subclasses fill: self.layers_spec = OrderedDict(layer -> [weight names]),
     # self.keras_shapes = {full name: keras shape}
     def __init__(self, device=None, seed=42, use_graph=True, grad_sync=None):
@@ -110,21 +127,22 @@ class ModelBase:
         """per-variable clipnorm + Adam/SGD (optimizer.apply_gradients, lc_NIC.py:389)."""
         be, a, sp, opt = self.be, self.arena, self.arena.spans, self.optimizer
         clip = opt.clipnorm if opt.clipnorm is not None else 0.0
+        gd = self._guard_word()
         if opt.kind == "adam":
-            be.step_tick(self.adam_t, self.drop_step, self.lr_dev, self.lr_t_dev, opt.beta_1, opt.beta_2)
+            be.step_tick(self.adam_t, self.drop_step, self.lr_dev, self.lr_t_dev, opt.beta_1, opt.beta_2, guard=gd)
             be.adam(a.theta, self.opt_m, self.opt_v, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq,
-                    a.sq_override, sp.nspan, 0.0, self.lr_t_dev, opt.beta_1, opt.beta_2, opt.epsilon, clip)
+                    a.sq_override, sp.nspan, 0.0, self.lr_t_dev, opt.beta_1, opt.beta_2, opt.epsilon, clip, guard=gd)
         else:
-            be.step_tick(self.adam_t, self.drop_step, self.lr_dev, None, 0.0, 0.0)
+            be.step_tick(self.adam_t, self.drop_step, self.lr_dev, None, 0.0, 0.0, guard=gd)
             be.sgd(a.theta, self.opt_m, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq, a.sq_override,
-                   sp.nspan, 0.0, self.lr_dev, opt.momentum, clip)
+                   sp.nspan, 0.0, self.lr_dev, opt.momentum, clip, guard=gd)
 
     def _tick(self):
-        opt = self.optimizer
+        opt, gd = self.optimizer, self._guard_word()
         if opt.kind == "adam":
-            self.be.step_tick(self.adam_t, self.drop_step, self.lr_dev, self.lr_t_dev, opt.beta_1, opt.beta_2)
+            self.be.step_tick(self.adam_t, self.drop_step, self.lr_dev, self.lr_t_dev, opt.beta_1, opt.beta_2, guard=gd)
         else:
-            self.be.step_tick(self.adam_t, self.drop_step, self.lr_dev, None, 0.0, 0.0)
+            self.be.step_tick(self.adam_t, self.drop_step, self.lr_dev, None, 0.0, 0.0, guard=gd)
 
     def _update_slice(self, sl):
         """norms + clip + optimizer on one contiguous range of variables (arena.seg_slice); the caller
@@ -133,12 +151,13 @@ class ModelBase:
         clip = opt.clipnorm if opt.clipnorm is not None else 0.0
         be.seg_sqnorm(a.theta, a.grad, sl.span_seg, sl.span_off, sl.span_len, sl.seg_first, a.seg_l2, sl.partial,
                       sl.sq, sl.wsq, None, sl.nspan, sl.nseg)
+        gd = self._guard_word()
         if opt.kind == "adam":
             be.adam(a.theta, self.opt_m, self.opt_v, a.grad, sl.span_seg, sl.span_off, sl.span_len, a.seg_l2, a.sq,
-                    a.sq_override, sl.nspan, 0.0, self.lr_t_dev, opt.beta_1, opt.beta_2, opt.epsilon, clip)
+                    a.sq_override, sl.nspan, 0.0, self.lr_t_dev, opt.beta_1, opt.beta_2, opt.epsilon, clip, guard=gd)
         else:
             be.sgd(a.theta, self.opt_m, a.grad, sl.span_seg, sl.span_off, sl.span_len, a.seg_l2, a.sq, a.sq_override,
-                   sl.nspan, 0.0, self.lr_dev, opt.momentum, clip)
+                   sl.nspan, 0.0, self.lr_dev, opt.momentum, clip, guard=gd)
 
     @staticmethod
     def pick_splitk(M, N, K):
@@ -240,6 +259,11 @@ class ModelBase:
             elif strict:
                 raise KeyError(n)
 
+    def get_optimizer_slot(self, name, slot):
+        """Adam first ('m') / second ('v') moment (SGD: 'm' = momentum) of one trainable, in the keras layout."""
+        buf = self.opt_m if slot == "m" else self.opt_v
+        return self._unpack(name, self.arena.slot(buf, name))
+
     def get_layer(self, name):
         if name not in self.layers_spec:
             raise ValueError(f"No such layer: {name}")
@@ -323,16 +347,46 @@ class ModelBase:
             assert oh.shape == (B, T, self.V), f"target shape {tuple(oh.shape)}"
             self.be.onehot_argmax(oh, self.tgt, B, T, self.V)
 
+    # ------------------------------------------------------------------ device guard (persistent LSTM kernel)
+    def _guard_word(self):
+        """The error word of the persistent kernel's sync state (uint32, device) while that kernel is in use, else None.
+        The optimizer kernels take it as ``guard`` and leave the model untouched when it is set."""
+        sync = self.__dict__.get("seq_sync")
+        return sync[1024:1025] if (sync is not None and self.__dict__.get("_seq_lstm")) else None
+
+    def _guard_out(self):
+        """Where the persistent kernel reports its error code for the host: slot GUARD of the metrics buffer."""
+        return self.met[self.GUARD:self.GUARD + 1]
+
+    def _metrics_from(self, m, **slots):
+        """Metrics from a clone ``m`` of the metrics buffer; the guard word of the same clone rides along."""
+        out = Metrics((k, m[i] if isinstance(i, int) else i) for k, i in slots.items())
+        return out.guarded(self, m[self.GUARD]) if self.__dict__.get("_seq_lstm") else out
+
+    def _on_guard_trip(self, code):
+        self.disable_seq_lstm()
+        what = {1: "a barrier timed out", 2: "a launch did not place 32 workgroups on every XCD"}.get(code, "unknown")
+        raise DeviceGuardError(
+            f"persistent LSTM kernel: device guard tripped (code {code}: {what}).  The results of that step are invalid; "
+            "its optimizer update was skipped, so weights, moments and step counters are unchanged.  The model now uses "
+            "the per-step LSTM kernels: run the step again.")
+
+    def _guarded(self, fn):
+        """Inference paths: run ``fn`` (which ends in a host read anyway), check the guard word, and on a trip fall back
+        to the per-step kernels and run it once more -- inference mutates no model state."""
+        out = fn()
+        if self._guard_word() is not None and float(self.met[self.GUARD]) != 0.0:
+            self.disable_seq_lstm()
+            out = fn()
+        return out
+
     def check_device_errors(self):
-        """Raises if a device-side guard tripped since the last check (synchronises): today only the barrier timeout of
-        the persistent LSTM kernel (tnt_lstm_seq_fwd_f32), whose results are invalid once its error word is set.
-        fit() calls it at every epoch end, bench.py and smoke() after their steps."""
+        """Raises DeviceGuardError if the persistent LSTM kernel's error word is set (synchronises).  train_step /
+        test_step results carry the same check with them (Metrics.as_floats), the inference paths check after their
+        own host read; this is the explicit form for loops that never read a metric."""
         sync = self.__dict__.get("seq_sync")
         if sync is not None and int(sync[1024].item()) != 0:
-            code = int(sync[1024].item())
-            sync[1024] = 0
-            raise RuntimeError(f"persistent LSTM kernel: barrier timeout (code {code}); results since the last check "
-                               "are invalid.  Set model.use_seq_lstm = False before the first step to use the per-step kernels.")
+            self._on_guard_trip(int(sync[1024].item()))
 
     def _init_seq_lstm(self, B, U):
         """Opt in to the persistent sequence-forward kernel for this (B, U) on this device.  Probes once per process
@@ -340,17 +394,19 @@ class ModelBase:
         self._seq_lstm = bool(getattr(self, "use_seq_lstm", True) and hasattr(self.be, "lstm_seq_supported")
                               and self.be.lstm_seq_supported(B, U))
         if self._seq_lstm and self.__dict__.get("seq_sync") is None:
-            self.seq_sync = torch.zeros(1025, dtype=torch.int32, device=self.device)     # zeroed ONCE, never reset
+            self.seq_sync = torch.zeros(1025, dtype=torch.int32, device=self.device)     # re-armed by the kernel itself
         elif not self._seq_lstm and "seq_sync" not in self.__dict__:
             self.seq_sync = None
 
     def disable_seq_lstm(self):
-        """Back to the per-step LSTM kernels (after a barrier timeout of the persistent one, or by choice): clears the
-        error word, drops captured graphs / launch plans and rebuilds the step buffers on the next call."""
+        """Back to the per-step LSTM kernels (after a guard trip of the persistent one, or by choice): zeroes the sync
+        state and the guard slot, drops captured graphs / launch plans; the step buffers are reused as they are."""
         self.use_seq_lstm = False
         sync = self.__dict__.get("seq_sync")
         if sync is not None:
-            sync[1024] = 0
+            sync.zero_()
+        if self.__dict__.get("met") is not None:
+            self.met[self.GUARD] = 0
         self._seq_lstm = False
         self._graphs = {}
 
@@ -425,7 +481,10 @@ class ModelBase:
             sums, t0 = {}, time.time()
             for b in range(n):
                 _call(callbacks, "on_train_batch_begin", b, {})
-                logs = self.train_step(x[b]).as_floats()
+                try:
+                    logs = self.train_step(x[b]).as_floats()
+                except DeviceGuardError:        # the step left the model untouched and the fallback is in place: redo it
+                    logs = self.train_step(x[b]).as_floats()
                 for k, v in logs.items():
                     sums[k] = sums.get(k, 0.0) + v
                 _call(callbacks, "on_train_batch_end", b, logs)
@@ -434,7 +493,10 @@ class ModelBase:
                 nv = len(validation_data) if validation_steps is None else validation_steps
                 vs = {}
                 for b in range(nv):
-                    logs = self.test_step(validation_data[b]).as_floats()
+                    try:
+                        logs = self.test_step(validation_data[b]).as_floats()
+                    except DeviceGuardError:
+                        logs = self.test_step(validation_data[b]).as_floats()
                     for k, v in logs.items():
                         vs[k] = vs.get(k, 0.0) + v
                     _call(callbacks, "on_test_batch_end", b, logs)

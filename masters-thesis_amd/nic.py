@@ -245,7 +245,7 @@ class NIC(ModelBase):
             # both LSTM calls (NIC.py:138,140) as ONE persistent launch: the T+1 dependent steps pay an XCD-local barrier
             # each instead of a kernel launch, the recurrent weights stay in VGPRs (tnt_lstm_seq_fwd_f32)
             be.lstm_seq_fwd(self.XZ, self.Hs, self.Cs, Ur, bl, self.cap, T, 1, self.Out, self.gates, T + 1, B, U,
-                            self.seq_sync)
+                            self.seq_sync, self._guard_out())
         else:
             # lstm call 1: the feature, one unmasked step (NIC.py:138)
             be.lstm_step_fwd(self.XZ[:B], self.Hs[0], self.Cs[0], Ur, None, None, 0, None, 0, 0, None, self.Hs[1],
@@ -395,7 +395,7 @@ class NIC(ModelBase):
             self._run_captured(("train_up", B, T), self._update_graph)
         self.optimizer.iterations += 1
         m = self.met.clone()
-        return Metrics(loss=m[0], L2=m[2], accuracy=m[1])
+        return self._metrics_from(m, loss=0, L2=2, accuracy=1)
 
     def test_step(self, data):
         """NIC.test_step (NIC.py:254-299)."""
@@ -407,14 +407,17 @@ class NIC(ModelBase):
             self._norms_and_l2(self.met[2:3])
         self._run_captured(("test", B, T), run)
         m = self.met.clone()
-        return Metrics(loss=m[0], L2=m[2], accuracy=m[1])
+        return self._metrics_from(m, loss=0, L2=2, accuracy=1)
 
     def __call__(self, data, training=False):
         """NIC.call (NIC.py:100-145): returns probabilities (B, T, V)."""
         B, T = self._stage_inputs(data)
-        self._forward(B, T, training)
-        self.be.softmax_cce(self.logits, None, self.logits, None, None, None, T * B, self.V, self.ldV, 0.0)
-        return self.logits.view(T, B, self.ldV)[:, :, :self.V].permute(1, 0, 2).contiguous()
+
+        def run():
+            self._forward(B, T, training)
+            self.be.softmax_cce(self.logits, None, self.logits, None, None, None, T * B, self.V, self.ldV, 0.0)
+            return self.logits.view(T, B, self.ldV)[:, :, :self.V].permute(1, 0, 2).contiguous()
+        return self._guarded(run)
 
     call = __call__
 

@@ -118,9 +118,9 @@ class HipBackend:
         """1 when the persistent sequence kernel can run here (U == 512, 256 CUs, 32 workgroups per XCD); probes once."""
         return bool(self.lib.tnt_lstm_seq_supported(int(B), int(U)))
 
-    def lstm_seq_fwd(self, xz, hs, cs, Ur, xz_bias, mask_ids, mask_T, mask_s0, out, gates, S, B, U, sync):
+    def lstm_seq_fwd(self, xz, hs, cs, Ur, xz_bias, mask_ids, mask_T, mask_s0, out, gates, S, B, U, sync, guard_out=None):
         self._call(self.lib.tnt_lstm_seq_fwd_f32, "tnt_lstm_seq_fwd_f32", _p(xz), _p(hs), _p(cs), _p(Ur), _p(xz_bias),
-                   _p(mask_ids), mask_T, mask_s0, _p(out), _p(gates), S, B, U, _p(sync), self._s())
+                   _p(mask_ids), mask_T, mask_s0, _p(out), _p(gates), S, B, U, _p(sync), _p(guard_out), self._s())
 
     def lstm_step_bwd(self, dz_next, Ur, da_pass_in, dh_ext, dc_in, dout_in, dout_t, mask_ids, mask_T, mask_t,
                       gates, c, c_prev, dz, da_pass_out, dc_out, dout_out, B, U, Wc=None, D=0, dctx_part=None):
@@ -205,23 +205,24 @@ class HipBackend:
         self._call(self.lib.tnt_l2_total_f32, "tnt_l2_total_f32", _p(wsq), _p(seg_l2), nseg, _p(out), self._s())
 
     def adam(self, theta, m, v, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr_t, lr_t_dev,
-             beta1, beta2, eps, clipnorm):
+             beta1, beta2, eps, clipnorm, guard=None):
         self._call(self.lib.tnt_adam_f32, "tnt_adam_f32", _p(theta), _p(m), _p(v), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
                                          _p(seg_l2), _p(sq), _p(sq_override), nspan, lr_t, _p(lr_t_dev), beta1,
-                                         beta2, eps, clipnorm, self._s())
+                                         beta2, eps, clipnorm, _p(guard), self._s())
 
     def sgd(self, theta, mom, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr, lr_dev,
-            momentum, clipnorm):
+            momentum, clipnorm, guard=None):
         self._call(self.lib.tnt_sgd_f32, "tnt_sgd_f32", _p(theta), _p(mom), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
                                         _p(seg_l2), _p(sq), _p(sq_override), nspan, lr, _p(lr_dev), momentum,
-                                        clipnorm, self._s())
+                                        clipnorm, _p(guard), self._s())
 
     def sam(self, theta, grad, ew, span_seg, span_off, span_len, seg_l2, sq, nseg, nspan, rho, mode):
         self._call(self.lib.tnt_sam_f32, "tnt_sam_f32", _p(theta), _p(grad), _p(ew), _p(span_seg), _p(span_off), _p(span_len),
                                         _p(seg_l2), _p(sq), nseg, nspan, rho, mode, self._s())
 
-    def step_tick(self, adam_t, drop_step, lr, lr_t, beta1, beta2):
-        self._call(self.lib.tnt_step_tick, "tnt_step_tick", _p(adam_t), _p(drop_step), _p(lr), _p(lr_t), beta1, beta2, self._s())
+    def step_tick(self, adam_t, drop_step, lr, lr_t, beta1, beta2, guard=None):
+        self._call(self.lib.tnt_step_tick, "tnt_step_tick", _p(adam_t), _p(drop_step), _p(lr), _p(lr_t), beta1, beta2, _p(guard),
+                   self._s())
 
     def locally_dense_fwd(self, x, ldx, idx, goff, W, bias, pre, y, B, R, D, slope=0.2):
         self._call(self.lib.tnt_locally_dense_fwd_f32, "tnt_locally_dense_fwd_f32", _p(x), ldx, _p(idx), _p(goff), _p(W), _p(bias), _p(pre), _p(y),

@@ -202,7 +202,8 @@ class CaptionGenerator(ModelBase):
         mask = self.lenmask if self.sat else None
         if self._seq_lstm and mask is None:     # unmasked sequence: one persistent launch (tnt_lstm_seq_fwd_f32); the masked
             # ShowAndTell form zeroes masked outputs instead of repeating them and stays on the step kernel
-            be.lstm_seq_fwd(self.XZ, self.Hs, self.Cs, Ur, None, None, 0, 0, self.Out, self.gates, T + 1, B, U, self.seq_sync)
+            be.lstm_seq_fwd(self.XZ, self.Hs, self.Cs, Ur, None, None, 0, 0, self.Out, self.gates, T + 1, B, U, self.seq_sync,
+                            self._guard_out())
         else:
             for t in range(T + 1):
                 be.lstm_step_fwd(self.XZ[t * B:(t + 1) * B], self.Hs[t], self.Cs[t], Ur, None, None, 0, mask, T + 1, t, None,
@@ -291,7 +292,8 @@ class CaptionGenerator(ModelBase):
         m = self.met.clone()
         if self.sat:
             return Metrics({"loss": m[0], "norm loss": m[1]})
-        return Metrics(scce=m[1], L2=m[2], loss=m[1] + m[2])
+        out = Metrics(scce=m[1], L2=m[2], loss=m[1] + m[2])
+        return out.guarded(self, m[self.GUARD]) if self._seq_lstm else out
 
     def train_step(self, data):
         if self.optimizer is None:
@@ -360,5 +362,8 @@ class CaptionGenerator(ModelBase):
         """decoder((target, features)) after the encoder: returns the (B, T+1, V) "logits" (model.py:84-114)."""
         img, target = self._unpack_batch(data) if isinstance(data, (tuple, list)) and len(data) >= 2 else data
         B, T = self._stage(img, target)
-        self._forward(B, T, training)
-        return self.logits.view(T + 1, B, self.ldV)[:, :, :self.V].permute(1, 0, 2).contiguous()
+
+        def run():
+            self._forward(B, T, training)
+            return self.logits.view(T + 1, B, self.ldV)[:, :, :self.V].permute(1, 0, 2).contiguous()
+        return self._guarded(run)

@@ -229,6 +229,7 @@ class NICDense:
         ce, acc = self.metrics(probs, y_ids)
         l2 = self.l2_loss()
         grads, sparse = self.backward(probs, cache, y_ids)
+        self.last_sparse = sparse          # IndexedSlices norms used by clip-by-norm (for tests that re-apply Adam)
         opt.apply(self.p, grads, sparse)
         self.p['batch_norm/moving_mean'] = cache['new_mm']
         self.p['batch_norm/moving_variance'] = cache['new_mv']
@@ -495,6 +496,7 @@ class LcNIC:
         ce, acc, al = self.metrics(probs, attn, y_ids)
         l2 = self.l2_loss()
         grads, sparse = self.backward(probs, cache, y_ids)
+        self.last_sparse = sparse          # IndexedSlices norms used by clip-by-norm (for tests that re-apply Adam)
         opt.apply(self.p, grads, sparse)
         self.p['input_bn/moving_mean'] = cache['enc']['new_mm']
         self.p['input_bn/moving_variance'] = cache['enc']['new_mv']

@@ -364,7 +364,9 @@ class MockBackend:
         return clipnorm / max(np.sqrt(q), clipnorm)
 
     def adam(self, theta, m, v, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr_t, lr_t_dev,
-             beta1, beta2, eps, clipnorm):
+             beta1, beta2, eps, clipnorm, guard=None):
+        if guard is not None and int(guard[0]) != 0:
+            return
         if lr_t_dev is not None:
             lr_t = float(flat(lr_t_dev)[0])
         th, mm, vv, gr, l2 = flat(theta), flat(m), flat(v), flat(grad), flat(seg_l2)
@@ -378,7 +380,9 @@ class MockBackend:
             vv[o:o + n] = v1
 
     def sgd(self, theta, mom, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr, lr_dev, momentum,
-            clipnorm):
+            clipnorm, guard=None):
+        if guard is not None and int(guard[0]) != 0:
+            return
         if lr_dev is not None:
             lr = float(flat(lr_dev)[0])
         th, mo, gr, l2 = flat(theta), flat(mom), flat(grad), flat(seg_l2)
@@ -400,7 +404,9 @@ class MockBackend:
                 e[o:o + n] = (gr[o:o + n].astype(np.float64) + 2 * float(l2[s]) * t) * scale
                 th[o:o + n] = t + e[o:o + n]
 
-    def step_tick(self, adam_t, drop_step, lr, lr_t, beta1, beta2):
+    def step_tick(self, adam_t, drop_step, lr, lr_t, beta1, beta2, guard=None):
+        if guard is not None and int(guard[0]) != 0:
+            return
         if drop_step is not None:
             drop_step += 1
         if adam_t is not None:

@@ -29,17 +29,29 @@ def synth(rng, b=B, t=T):
     return (x, cap, z, z.copy()), tgt
 
 
-def make(kind, seed=42, **kw):
+RATES = {"dense": (0.0, 0.2, 0.2), "attention": (0.0, 0.2, 0.2, 0.2, 0.2, 0.2)}       # AttemptFour/config.yaml:36-41
+
+
+def make(kind, seed=42, rates=None, **kw):
     from masters_thesis_amd.optimizers import Adam
+    rates = RATES[kind] if rates is None else rates
     if kind == "dense":
         from masters_thesis_amd.nic import NIC
-        m = NIC(N, U, E, V, T, 0.0, 0.2, 0.2, 0.01, 0.00003, 0.00001, seed=seed, **kw)
+        m = NIC(N, U, E, V, T, *rates, 0.01, 0.00003, 0.00001, seed=seed, **kw)
     else:
         from masters_thesis_amd.lc_nic import NIC, synthetic_groups
-        m = NIC(synthetic_groups(N, 360, 32, seed=42), U, 512, E, 32, V, T, 0.0, 0.2, 0.2, 0.2, 0.2, 0.2, 0.01, 0.001,
+        m = NIC(synthetic_groups(N, 360, 32, seed=42), U, 512, E, 32, V, T, *rates, 0.01, 0.001,
                 0.00003, 0.00001, seed=seed, **kw)
     m.compile(Adam(learning_rate=1e-4, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
     return m
+
+
+def make_oracle(kind, rates=None):
+    rates = RATES[kind] if rates is None else rates
+    if kind == "dense":
+        return M.NICDense(N, U, E, V, T, *rates, 0.01, 0.00003, 0.00001)
+    from masters_thesis_amd.lc_nic import synthetic_groups
+    return M.LcNIC(synthetic_groups(N, 360, 32, seed=42), U, 512, E, 32, V, T, *rates, 0.01, 0.001, 0.00003, 0.00001)
 
 
 @pytest.mark.parametrize("kind", ["dense", "attention"])
@@ -137,3 +149,147 @@ def test_persistent_lstm_forward_trains_like_the_step_kernels():
         assert abs(x["loss"] - y["loss"]) <= 5e-5 * abs(y["loss"]), (x, y)
     assert not a._seq_lstm
     a.check_device_errors()
+
+
+def _sync_oracle(model, orc, opt, step):
+    """The oracle starts the step from exactly the model's state: weights, BatchNorm statistics, Adam moments, t."""
+    orc.p = {k: v.astype(np.float64) for k, v in model.get_weights_dict().items()}
+    if step > 0:
+        for k in opt.m:
+            opt.m[k] = model.get_optimizer_slot(k, "m").astype(np.float64)
+            opt.v[k] = model.get_optimizer_slot(k, "v").astype(np.float64)
+    opt.t = step
+
+
+@pytest.mark.parametrize("kind", ["dense", "attention"])
+@pytest.mark.parametrize("dropout", [True, False])
+def test_train_step_matches_oracle_at_full_size(kind, dropout):
+    """ONE training step at BASELINE size against the float64 oracle, three times over (eager launch sequence, the
+    captured hipGraph's first replay, a later replay), each from the model's own state: loss / accuracy / L2
+    [/ attention], EVERY gradient (NIC.py:248-249, lc_NIC.py:386-387), the BatchNorm moving statistics and the
+    post-Adam weights (main.py:97, lc_NIC.py:389).  This is the only place where the kernels that exist only at full
+    size -- the persistent LSTM forward (U == 512), lstm_bwd_lds (4U % 1024 == 0), the one-round head GEMM, the skinny
+    encoder dW, the in-kernel-reduced gradient GEMMs -- run inside one oracle-checked step.
+    The weights are checked twice: loosely against the oracle's own update (Adam turns a 1e-4 gradient error on a
+    near-zero element into a fraction of lr), and tightly (1e-3 of one update) against the float64 Adam formulas
+    applied to the gradients the model itself produced, which pins clip-by-norm + Adam + the IndexedSlices norm."""
+    rng = np.random.default_rng(21)
+    rates = None if dropout else tuple(0.0 for _ in RATES[kind])
+    model = make(kind, rates=rates)
+    orc = make_oracle(kind, rates)
+    orc.p = {k: v.astype(np.float64) for k, v in model.get_weights_dict().items()}
+    names = [k for k in orc.p if "moving_" not in k]
+    lam = {k: model.arena.entries[k].l2 for k in names}
+    lr = 1e-4
+    opt = M.AdamState({k: orc.p[k] for k in names}, lr=lr, b1=0.9, b2=0.98, eps=1e-8, clipnorm=0.1)
+    for step in range(3):
+        data, tgt = synth(rng)
+        _sync_oracle(model, orc, opt, step)
+        w0 = {k: v.copy() for k, v in orc.p.items()}
+        m0 = {k: v.copy() for k, v in opt.m.items()}
+        v0 = {k: v.copy() for k, v in opt.v.items()}
+        res, grads, _ = orc.train_step(data, tgt, opt, M.DropCtx(seed=model.seed, step=step, training=True))
+        got = model.train_step((data, tgt)).as_floats()
+        model.check_device_errors()
+        for k in res:
+            if k == "lr":
+                continue
+            tol = 1e-6 if k == "accuracy" else 1e-4 * abs(res[k]) + 1e-7
+            assert abs(got[k] - res[k]) <= tol, (step, k, got[k], res[k])
+        gm = {}
+        for k in names:
+            gm[k] = model.get_gradient(k).astype(np.float64) + 2 * lam[k] * w0[k]
+            if grads.get(k) is None:
+                continue
+            scale = np.abs(grads[k]).max()
+            if k == "attention/V/bias":            # softmax is shift-invariant: the true gradient is 0
+                assert np.abs(gm[k]).max() < 1e-5
+                continue
+            err = np.abs(gm[k] - grads[k]).max()
+            assert err <= 1e-4 * scale + 1e-10, (step, k, err, scale)
+        # BatchNorm moving statistics
+        for k in orc.p:
+            if "moving_" in k:
+                w = model.get_weight(k)
+                assert np.abs(w - orc.p[k]).max() <= 1e-5 * max(1.0, np.abs(orc.p[k]).max()), (step, k)
+        # (a) against the oracle's own update
+        for k in names:
+            if k == "attention/V/bias":
+                continue
+            w, v = model.get_weight(k), orc.p[k]
+            noisy = np.abs(grads[k]) < 1e-2 * np.abs(grads[k]).max()
+            tol = 2e-2 * lr + 1e-6 * np.abs(v).max() + 2.2 * lr * noisy
+            assert (np.abs(w - v) <= tol).all(), (step, k, np.abs(w - v).max())
+        # (b) the float64 Adam formulas on the model's own gradients
+        sparse = orc.last_sparse
+        p2 = {k: w0[k].copy() for k in names}
+        opt2 = M.AdamState(p2, lr=lr, b1=0.9, b2=0.98, eps=1e-8, clipnorm=0.1)
+        opt2.m, opt2.v, opt2.t = m0, v0, step
+        opt2.apply(p2, gm, sparse)
+        for k in names:
+            if k == "attention/V/bias":
+                continue
+            w = model.get_weight(k)
+            tol = 1e-3 * lr + 3e-7 * np.abs(p2[k])
+            assert (np.abs(w - p2[k]) <= tol).all(), (step, k, np.abs(w - p2[k]).max())
+
+
+@pytest.mark.parametrize("kind", ["dense", "attention"])
+def test_test_step_matches_oracle_at_full_size(kind):
+    """NIC.test_step (NIC.py:254-299) / lc_NIC.test_step (lc_NIC.py:410-459) at BASELINE size: inference-mode forward
+    (BatchNorm on the moving statistics, no dropout), loss / accuracy / L2 [/ attention] against the oracle --
+    eager, captured, replayed -- after two training steps have moved the weights and the moving statistics."""
+    rng = np.random.default_rng(22)
+    model = make(kind)
+    orc = make_oracle(kind)
+    for _ in range(2):
+        model.train_step(synth(rng))
+    for rep in range(3):
+        data, tgt = synth(rng)
+        orc.p = {k: v.astype(np.float64) for k, v in model.get_weights_dict().items()}
+        want = orc.test_step(data, tgt)[0]
+        got = model.test_step((data, tgt)).as_floats()
+        assert set(got) == set(want), (sorted(got), sorted(want))
+        for k in want:
+            tol = 1e-6 if k == "accuracy" else 1e-4 * abs(want[k]) + 1e-7
+            assert abs(got[k] - want[k]) <= tol, (rep, k, got[k], want[k])
+    model.check_device_errors()
+
+
+def test_guard_trip_skips_the_update_and_falls_back():
+    """Fault injection (the persistent LSTM kernel's error word pre-set, as a barrier timeout would leave it): the
+    step's metrics raise DeviceGuardError, the optimizer kernels have skipped -- weights, Adam moments, t and the
+    dropout stream are bit-identical to before the step -- the model has fallen back to the per-step kernels, and
+    running the step again gives what a model that never used the persistent kernel gives."""
+    from masters_thesis_amd.model_base import DeviceGuardError
+    rng = np.random.default_rng(23)
+    data, tgt = synth(rng)
+    a, b = make("dense"), make("dense")
+    b.use_seq_lstm = False
+    for _ in range(3):                       # eager, capture, replay
+        a.train_step((data, tgt)).as_floats(); b.train_step((data, tgt)).as_floats()
+    if not a._seq_lstm:
+        pytest.skip("persistent LSTM kernel not supported on this device")
+    torch.cuda.synchronize()
+    before = (a.arena.theta.clone(), a.opt_m.clone(), a.opt_v.clone(), a.adam_t.clone(), a.drop_step.clone())
+    a.seq_sync[1024] = 1
+    res = a.train_step((data, tgt))
+    with pytest.raises(DeviceGuardError):
+        res.as_floats()
+    after = (a.arena.theta, a.opt_m, a.opt_v, a.adam_t, a.drop_step)
+    assert all(torch.equal(x, y) for x, y in zip(before, after)), "a guarded step must leave the model untouched"
+    assert not a._seq_lstm and int(a.seq_sync[1024]) == 0
+    ra, rb = a.train_step((data, tgt)).as_floats(), b.train_step((data, tgt)).as_floats()
+    assert abs(ra["loss"] - rb["loss"]) <= 5e-5 * abs(rb["loss"]), (ra, rb)
+    # fit() redoes the step by itself
+    c = make("dense")
+    c.train_step((data, tgt)).as_floats()
+    c.seq_sync[1024] = 1
+    hist = c.fit([(data, tgt)] * 2, epochs=1, verbose=0)
+    assert np.isfinite(hist["loss"][0]) and not c._seq_lstm
+    # inference paths check after their own host read and re-run on the per-step kernels
+    d = make("dense")
+    p0 = d(data, training=False)
+    d.seq_sync[1024] = 1
+    p1 = d(data, training=False)
+    assert not d._seq_lstm and (p0 - p1).abs().max().item() <= 1e-5

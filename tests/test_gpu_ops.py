@@ -572,6 +572,122 @@ def test_lstm_seq_fwd_equals_step_kernels(be, B, masked):
     assert torch.equal(Hs2, Hs3) and torch.equal(Cs2, Cs3) and torch.equal(G2, G3)
 
 
+@pytest.mark.parametrize("B,masked", [(64, True), (40, True), (128, False)])
+def test_lstm_seq_fwd_matches_oracle(be, B, masked):
+    """tnt_lstm_seq_fwd_f32 straight against the float64 oracle (keras LSTM over the feature step + the masked text
+    sequence, NIC.py:138-140): every state, every gate and the masked layer output of all T+1 steps."""
+    U, T = 512, 15
+    S = T + 1
+    if not be.lstm_seq_supported(B, U):
+        pytest.skip("persistent LSTM kernel not supported on this device (needs 256 CUs, 32 workgroups per XCD)")
+    rng = np.random.default_rng(100 + B)
+    xz = rng.standard_normal((S, B, 4 * U)) * 0.5
+    Ur = rng.standard_normal((U, 4 * U)) / np.sqrt(U)
+    bl = rng.standard_normal(4 * U) * 0.1
+    cap = rng.integers(1, 50, (B, T)).astype(np.int32)
+    for b in range(B):
+        cap[b, rng.integers(2, T):] = 0
+    cap[0, 0] = 0                                                       # a row masked from the first text step on
+    h, c = rng.standard_normal((B, U)) * 0.3, rng.standard_normal((B, U)) * 0.3
+    Hw, Cw, Gw, Ow = [h], [c], [], []
+    out = np.zeros((B, U))
+    for s in range(S):
+        h2, c2, cache = O.lstm_step_fwd(xz[s] + bl, Hw[-1], Cw[-1], Ur)
+        Gw.append(np.stack(cache[:4], axis=-1))
+        if masked and s >= 1:
+            m = (cap[:, s - 1] != 0)[:, None]
+            h2, c2 = np.where(m, h2, Hw[-1]), np.where(m, c2, Cw[-1])
+            out = np.where(m, h2, out)
+            Ow.append(out)
+        Hw.append(h2); Cw.append(c2)
+    Hs, Cs = torch.zeros(S + 1, B, U, device="cuda"), torch.zeros(S + 1, B, U, device="cuda")
+    Hs[0], Cs[0] = dev(h), dev(c)
+    Out, G = torch.full((T, B, U), 9.0, device="cuda"), torch.zeros(S, B, U, 4, device="cuda")
+    sync = torch.zeros(1025, dtype=torch.int32, device="cuda")
+    be.lstm_seq_fwd(dev(il(xz, U)), Hs, Cs, dev(il(Ur, U)), dev(il(bl, U)), dev(cap, torch.int32) if masked else None, T, 1,
+                    Out if masked else None, G, S, B, U, sync)
+    torch.cuda.synchronize()
+    assert int(sync[1024]) == 0, "a barrier of the persistent kernel timed out"
+    close(Hs, np.stack(Hw)); close(Cs, np.stack(Cw)); close(G, np.stack(Gw))
+    if masked:
+        close(Out, np.stack(Ow))
+
+
+def test_lstm_seq_sync_state_after_graph_replays(be):
+    """The persistent kernel re-arms its own sync state (csrc/tnt_seq_sync.h): after 250 replays of a captured launch
+    -- no reset node, frozen kernel arguments -- the error word is 0, every ticket / exit counter is back at 0, the
+    epoch of every XCD that owns a row block equals the number of launches, all 32 flags of such a group stand at the
+    last barrier target of the last launch, and the outputs are bit-identical to the first launch."""
+    B, U, T = 64, 512, 15
+    S = T + 1
+    if not be.lstm_seq_supported(B, U):
+        pytest.skip("persistent LSTM kernel not supported on this device")
+    rng = np.random.default_rng(5)
+    f = lambda *s: torch.tensor(rng.standard_normal(s), dtype=torch.float32, device="cuda")
+    xz, Ur, bl = f(S, B, U, 4) * 0.5, f(U, U, 4) * 0.05, f(U, 4) * 0.1
+    cap = torch.tensor(rng.integers(0, 3, (B, T)).astype(np.int32), device="cuda")
+    Hs, Cs = torch.zeros(S + 1, B, U, device="cuda"), torch.zeros(S + 1, B, U, device="cuda")
+    Hs[0], Cs[0] = f(B, U) * 0.3, f(B, U) * 0.3
+    Out, G = torch.zeros(T, B, U, device="cuda"), torch.zeros(S, B, U, 4, device="cuda")
+    sync = torch.zeros(1025, dtype=torch.int32, device="cuda")
+    guard = torch.zeros(1, device="cuda")
+    launch = lambda: be.lstm_seq_fwd(xz, Hs, Cs, Ur, bl, cap, T, 1, Out, G, S, B, U, sync, guard)
+    launch()
+    torch.cuda.synchronize()
+    first = (Hs.clone(), Cs.clone(), Out.clone(), G.clone())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        launch()
+    reps = 250
+    for _ in range(reps):
+        g.replay()
+    torch.cuda.synchronize()
+    st = sync.cpu().numpy().astype(np.int64)
+    assert st[1024] == 0 and float(guard) == 0.0
+    nrb = (B + 15) // 16
+    epochs = st[512 + 2:1024:64]
+    active = np.nonzero(epochs)[0]
+    assert len(active) == nrb and (epochs[active] == 1 + reps).all(), epochs
+    assert (st[512:1024:64] == 0).all() and (st[513:1024:64] == 0).all(), "ticket / exit counters not re-armed"
+    for x in active:
+        flags = st[x * 64:x * 64 + 32]
+        assert (flags == (epochs[x] - 1) * 64 + (S - 1)).all(), (x, flags)
+    for a, b in zip(first, (Hs, Cs, Out, G)):
+        assert torch.equal(a, b)
+
+
+def test_lstm_seq_guard_codes(be):
+    """Device guard of the persistent kernel: a pre-set error word is reported through guard_out and survives; a ticket
+    counter that is out of phase (what a launch with a wrong census would leave behind) yields code 2 -- loudly, with
+    every wave leaving the kernel -- and after the owner zeroes the state the kernel works again."""
+    B, U, T = 64, 512, 3
+    S = T + 1
+    if not be.lstm_seq_supported(B, U):
+        pytest.skip("persistent LSTM kernel not supported on this device")
+    rng = np.random.default_rng(6)
+    f = lambda *s: torch.tensor(rng.standard_normal(s), dtype=torch.float32, device="cuda")
+    xz, Ur = f(S, B, U, 4) * 0.5, f(U, U, 4) * 0.05
+    Hs, Cs = torch.zeros(S + 1, B, U, device="cuda"), torch.zeros(S + 1, B, U, device="cuda")
+    G = torch.zeros(S, B, U, 4, device="cuda")
+    sync = torch.zeros(1025, dtype=torch.int32, device="cuda")
+    guard = torch.zeros(1, device="cuda")
+    launch = lambda: be.lstm_seq_fwd(xz, Hs, Cs, Ur, None, None, 0, S, None, G, S, B, U, sync, guard)
+    launch(); torch.cuda.synchronize()
+    good = Hs.clone()
+    assert int(sync[1024]) == 0 and float(guard) == 0.0
+    sync[1024] = 1                                  # as left behind by an earlier barrier timeout
+    launch(); torch.cuda.synchronize()
+    assert int(sync[1024]) == 1 and float(guard) == 1.0
+    sync.zero_(); guard.zero_()
+    sync[512:1024:64] = 7                           # tickets out of phase on every XCD
+    launch(); torch.cuda.synchronize()
+    assert int(sync[1024]) in (1, 2) and float(guard) != 0.0
+    sync.zero_(); guard.zero_()
+    Hs[1:].zero_()
+    launch(); torch.cuda.synchronize()
+    assert int(sync[1024]) == 0 and float(guard) == 0.0 and torch.equal(Hs, good)
+
+
 def test_attention_metric(be):
     rng = np.random.default_rng(13)
     T, B, R = 5, 8, 30
