@@ -145,7 +145,7 @@ def _work_model(name, a):
         Bq, Uq, D = a[15], a[16], a[6]
         return f"{name} B={Bq} U={Uq} D={D}", 2.0 * Bq * 4 * Uq * (Uq + D), 0.0
     if name in ("tnt_lstm_seq_fwd_f32", "tnt_lstm_seq_bwd_f32"):
-        S, Bq, Uq = (a[10], a[11], a[12]) if name.endswith("fwd_f32") else (a[-7], a[-6], a[-5])
+        S, Bq, Uq = a[10], a[11], a[12]
         return f"{name} S={S} B={Bq} U={Uq}", 2.0 * S * Bq * 4 * Uq * Uq, 0.0
     if name == "tnt_dense_dw_skinny_f32":
         Nq, Eq, Bk = a[3], a[4], a[5]

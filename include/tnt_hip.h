@@ -219,6 +219,19 @@ int32_t tnt_lstm_seq_supported(int32_t B, int32_t U);
 int32_t tnt_lstm_seq_fwd_f32(const float* xz, float* hs, float* cs, const float* Ur, const float* xz_bias,
                              const int32_t* mask_ids, int32_t mask_T, int32_t mask_s0, float* out,
                              float* gates, int32_t S, int32_t B, int32_t U, uint32_t* sync, float* guard_out, void* stream);
+/* Persistent form of the BPTT chain of the same sequence (the S calls of tnt_lstm_step_bwd_f32 that nic.NIC makes, in
+ * ONE launch): step s = S-1 .. 0 reads gates[s], cs[s+1], cs[s] and writes dz[s] ([S][B][U][4]); steps s >= mask_s0
+ * add dout_seq[s - mask_s0] (gradient of the sequence output, nullable) and are masked by column s - mask_s0 of
+ * mask_ids (nullable) exactly like the per-step kernel (masked row: dz = 0, the carried da / dc / dout pass through);
+ * the carried output gradient is dropped below mask_s0 (NIC.py:138: the feature step's output is not part of the
+ * sequence).  Weights stay in registers, the recurrent product is "pushed" as partial tiles through `work`
+ * (tnt_lstm_seq_bwd_work_floats(B, U) floats, 16-byte aligned) inside one XCD per 16-row block; sync / guard_out and the
+ * device requirements as tnt_lstm_seq_fwd_f32 (same sync buffer, launches on one stream).  Deterministic. */
+int32_t tnt_lstm_seq_bwd_work_floats(int32_t B, int32_t U);
+int32_t tnt_lstm_seq_bwd_f32(const float* Ur, const float* dout_seq, const int32_t* mask_ids, int32_t mask_T,
+                             int32_t mask_s0, const float* gates, const float* cs, float* dz, float* work,
+                             int64_t work_floats, int32_t S, int32_t B, int32_t U, uint32_t* sync,
+                             float* guard_out, void* stream);
 /* bwd of one step, fused with the recurrent matmul of the step after it:
  *   da = da_pass_in + dh_ext + (dz_next ? dz_next[B][U][4] @ Ur^T : 0)
  *   dout = dout_in + dout_t ; masked rows pass (da, dc, dout) through, dz = 0

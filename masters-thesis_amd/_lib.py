@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libtnt_hip.so")
+# TNT_HIP_LIB: A/B builds of the same library for tools/ (e.g. a variant compiled with an experiment macro)
+LIB_PATH = os.environ.get("TNT_HIP_LIB") or os.path.join(_HERE, "csrc", "libtnt_hip.so")
 
 P = C.c_void_p          # any device pointer
 I32, I64, U32, U64, F32 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
@@ -33,6 +34,8 @@ SIGNATURES = {
     "tnt_embedding_bwd_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, P],
     "tnt_lstm_seq_supported": [I32, I32],
     "tnt_lstm_seq_fwd_f32": [P, P, P, P, P, P, I32, I32, P, P, I32, I32, I32, P, P, P],
+    "tnt_lstm_seq_bwd_work_floats": [I32, I32],
+    "tnt_lstm_seq_bwd_f32": [P, P, P, I32, I32, P, P, P, P, I64, I32, I32, I32, P, P, P],
     "tnt_lstm_step_fwd_f32": [P, P, P, P, P, P, I32, P, I32, I32, P, P, P, P, P, I32, I32, P, P],
     "tnt_lstm_step_bwd_f32": [P, P, P, P, P, P, P, P, I32, I32, P, P, P, P, P, P, P, I32, I32, P, I32, P, P],
     "tnt_softmax_cce_f32": [P, P, P, P, P, P, I32, I32, I32, F32, I32, I32, P],

@@ -517,6 +517,150 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   tnt_seq_leave(a.sync, xcc, a.guard_out);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Persistent sequence backward (BPTT over the S dependent steps of the same sequence, tape.gradient through the keras
+// LSTM of NIC.py:138-140 / lc_NIC.py:317-318): ONE launch, weights stationary, "push" formulation.
+//   da[b][u] = sum_k dz_next[b][k] * Ur[u][k]   (k = (unit', gate), 4U of them)  is what chains the steps.
+// The per-step kernel PULLS: workgroup (16 rows x 16 units u) reads its 16 rows of dz_next (128 KB) and its 16 rows of
+// Ur (128 KB) every step.  Here a workgroup keeps the 64 gate columns k it PRODUCES (its own dz tile, 16 x 64, in LDS)
+// and the matching Ur^T slice [64 k][512 u] (128 KB = 32 floats per lane over 1024 lanes, loaded ONCE), multiplies
+// them into a partial da[16 x 512] (its k-slice of the sum) and pushes one 16 x 16 tile (1 KB) to each of the 32
+// workgroups of its row block; after one XCD-local barrier every workgroup gathers the 32 partial tiles of its own
+// 16 x 16 block (32 KB, fixed summation order: deterministic) and runs the cell backward, which yields its next dz
+// tile.  Per step and workgroup: 32 KB out + 32 KB in through the XCD's L2 instead of 256 KB in.
+// Same placement / synchronisation scheme as lstm_seq_fwd_kernel (row block = XCC_ID, tickets, epoch targets,
+// tnt_seq_sync.h); the exchange buffer is double-buffered by step parity.
+struct LstmSeqBwdArgs {
+  const float* Ur; const float* dout_seq; const int* mask_ids; const float* gates; const float* cs;
+  float* dz; float* xch; unsigned* sync; float* guard_out;
+  int S, B, U, mask_T, mask_s0;
+};
+
+constexpr int SB_DZLD = 68;                                   // row stride of the dz tile in LDS (16-byte rows, 68 % 64 == 4)
+constexpr int SB_LDS_BYTES = 82 * 1024;      // uses 16*68 + 16*256 + 4 floats; > half of the CU's 160 KB requested: one workgroup per CU
+
+__global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
+  constexpr int NWB = 16, NTW = 2;                            // U = 512 = 16 waves x 2 column tiles x 16 units
+  extern __shared__ __attribute__((aligned(16))) float sb_lds[];
+  float* dzs = sb_lds;                                        // [16][SB_DZLD]: this workgroup's dz tile of the previous step
+  float* red = sb_lds + 16 * SB_DZLD;                         // [NWB][64][4]
+  unsigned* s_slot = reinterpret_cast<unsigned*>(red + NWB * 256);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kq = lane >> 4, lr = lane & 15;
+  const int U = a.U, B = a.B, S = a.S;
+  const unsigned xcc = tnt_xcc_id();
+  const int nrb = (B + 15) / 16;
+  if ((int)xcc >= nrb) return;
+  unsigned* bar = a.sync + xcc * 64;
+  unsigned* err = a.sync + TNT_SEQ_ERR;
+  const TntSeqSlot slot = tnt_seq_enter(a.sync, xcc, s_slot);
+  if (slot.ub < 0) {
+    if (tid == 0 && a.guard_out) a.guard_out[0] = 2.f;
+    return;
+  }
+  const int ub = slot.ub, rb = __builtin_amdgcn_readfirstlane((int)xcc);
+  const __amdgpu_buffer_rsrc_t x_rsrc = tnt_rsrc(a.xch, (unsigned)(2u * nrb * 32u * 32u * 1024u));
+  // ---- resident weights: B operand of the MFMAs, Ur^T[k][n] = Ur[n][ub*64 + k]; lane (kq, lr) of column tile j holds
+  // n = w*32 + j*16 + lr and the 16 contraction indices k = kq*16 + ks (a permutation of the MFMA's natural k order,
+  // applied to both operands: each lane's slice is 64 contiguous bytes in HBM and in LDS)
+  float bw[NTW][16];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const float* src = a.Ur + ((long)(w * 32 + j * 16 + lr) * U + ub * 16) * 4 + kq * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(src + 4 * q);
+      bw[j][4 * q + 0] = t.x; bw[j][4 * q + 1] = t.y; bw[j][4 * q + 2] = t.z; bw[j][4 * q + 3] = t.w;
+    }
+  }
+  for (int e = tid; e < 16 * SB_DZLD; e += 1024) dzs[e] = 0.f;           // rows past B stay zero
+  // ---- epilogue thread state (element (erow, ecol) of the 16 x 16 block), carried across the steps in registers
+  const int erow = tid >> 4, ecol = tid & 15;
+  const int eb = rb * 16 + erow, eu = ub * 16 + ecol;
+  const bool eok = tid < 256 && eb < B;
+  const long ee = (long)eb * U + eu;
+  const long BU = (long)B * U;
+  const int ridx = ((erow >> 2) * 16 + ecol) * 4 + (erow & 3);           // where the MFMA C layout keeps (erow, ecol)
+  float da_c = 0.f, dc_c = 0.f, dout_c = 0.f;
+  __syncthreads();
+  for (int s = S - 1; s >= 0; --s) {
+    // epilogue operands of this step do not depend on the chain: fetch them first
+    const bool seq = s >= a.mask_s0;
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cval = 0.f, cprev = 0.f, dout_t = 0.f;
+    int mid = 1;
+    if (eok) {
+      g4 = *reinterpret_cast<const float4*>(a.gates + ((long)s * BU + ee) * 4);
+      cval = a.cs[(long)(s + 1) * BU + ee]; cprev = a.cs[(long)s * BU + ee];
+      if (seq && a.dout_seq) dout_t = a.dout_seq[(long)(s - a.mask_s0) * BU + ee];
+      if (seq && a.mask_ids) mid = a.mask_ids[eb * a.mask_T + (s - a.mask_s0)];
+    }
+    float da = da_c;
+    if (s < S - 1) {
+      const int par = s & 1;
+      // ---- partial da = dz_tile[16 x 64] @ Ur^T slice[64 x 512]: this wave's 2 column tiles
+      float av[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(dzs + lr * SB_DZLD + kq * 16 + 4 * q);
+        av[4 * q + 0] = t.x; av[4 * q + 1] = t.y; av[4 * q + 2] = t.z; av[4 * q + 3] = t.w;
+      }
+      floatx4 acc[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bw[j][ks], acc[j], 0, 0, 0);
+      // ---- push: tile j belongs to workgroup (w*2 + j) of this row block; slot [dest][src = ub], lane-major 1 KB tiles
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        float* X = a.xch + ((((long)(par * nrb + rb) * 32 + (w * NTW + j)) * 32 + ub) * 256) + lane * 4;
+        *reinterpret_cast<float4*>(X) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+      }
+      tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, S - 1 - s), err);
+      // ---- gather the 32 partial tiles of this workgroup's block (sc1 loads: stored by other workgroups): wave w sums
+      // sources w and w + 16, the 16 wave sums are combined through LDS in fixed order
+      {
+        const unsigned base = (unsigned)((((par * nrb + rb) * 32 + ub) * 32) * 1024) + (unsigned)lane * 16u;
+        const float4 p0 = tnt_ld4_l2(x_rsrc, base + (unsigned)w * 1024u);
+        const float4 p1 = tnt_ld4_l2(x_rsrc, base + (unsigned)(w + 16) * 1024u);
+        *reinterpret_cast<float4*>(red + w * 256 + lane * 4) = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
+      }
+      __syncthreads();
+      if (eok) {
+#pragma unroll
+        for (int k = 0; k < NWB; ++k) da += red[k * 256 + ridx];
+      }
+    }
+    // ---- cell backward (same arithmetic as bwd_epilogue of the per-step kernel)
+    if (eok) {
+      const bool m = mid != 0;
+      const float dout = (seq ? dout_c : 0.f) + dout_t;
+      float4 dz4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m) {
+        const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
+        const float tc = tnt_tanh(cval);
+        const float dh = da + dout;
+        const float dgo = dh * tc;
+        const float dc = dc_c + dh * go * (1.f - tc * tc);
+        dz4.x = dc * gg * gi * (1.f - gi);
+        dz4.y = dc * cprev * gf * (1.f - gf);
+        dz4.z = dc * gi * (1.f - gg * gg);
+        dz4.w = dgo * go * (1.f - go);
+        dc_c = dc * gf; da_c = 0.f; dout_c = 0.f;
+      } else {
+        da_c = da; dout_c = dout;
+      }
+      *reinterpret_cast<float4*>(a.dz + ((long)s * BU + ee) * 4) = dz4;
+      *reinterpret_cast<float4*>(dzs + erow * SB_DZLD + ecol * 4) = dz4;
+    }
+    __syncthreads();          // the dz tile is complete before the next step's A fragments are read; `red` is free again
+  }
+  tnt_seq_leave(a.sync, xcc, a.guard_out);
+}
+
 // census of a 256 x 1024-thread launch: how many workgroups land on each XCC_ID
 __global__ __launch_bounds__(1024) void xcc_census_kernel(unsigned* hist) {
   extern __shared__ float seq_lds[];
@@ -584,6 +728,8 @@ extern "C" int32_t tnt_lstm_step_bwd_f32(const float* dz_next, const float* Ur, 
   return 0;
 }
 
+extern "C" int32_t tnt_lstm_seq_bwd_work_floats(int32_t B, int32_t U);
+
 /* see include/tnt_hip.h */
 extern "C" int32_t tnt_lstm_seq_supported(int32_t B, int32_t U) {
   static int cached = -1;
@@ -626,4 +772,32 @@ extern "C" int32_t tnt_lstm_seq_fwd_f32(const float* xz, float* hs, float* cs, c
   hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(256), dim3(1024), SEQ_LDS_BYTES, s, a);
   TNT_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int32_t tnt_lstm_seq_bwd_f32(const float* Ur, const float* dout_seq, const int32_t* mask_ids, int32_t mask_T,
+                                        int32_t mask_s0, const float* gates, const float* cs, float* dz, float* work,
+                                        int64_t work_floats, int32_t S, int32_t B, int32_t U, uint32_t* sync,
+                                        float* guard_out, void* stream) {
+  if (S <= 0 || S - 1 > TNT_SEQ_MAX_BARRIERS || sync == nullptr || work == nullptr) return TNT_BADARG(11);
+  if (!tnt_lstm_seq_supported(B, U)) return TNT_BADARG(13);
+  if (mask_s0 < 0 || mask_s0 > S || (mask_ids != nullptr && S - mask_s0 > mask_T)) return TNT_BADARG(5);
+  if (work_floats < (int64_t)tnt_lstm_seq_bwd_work_floats(B, U)) return TNT_BADARG(10);
+  if (!tnt_aligned16(work) || !tnt_aligned16(Ur) || !tnt_aligned16(gates) || !tnt_aligned16(dz)) return TNT_BADARG(1);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS_BYTES) != hipSuccess)
+      return TNT_BADARG(90);
+    attr_set = true;
+  }
+  LstmSeqBwdArgs a;
+  a.Ur = Ur; a.dout_seq = dout_seq; a.mask_ids = mask_ids; a.gates = gates; a.cs = cs; a.dz = dz; a.xch = work;
+  a.sync = sync; a.guard_out = guard_out; a.S = S; a.B = B; a.U = U; a.mask_T = mask_T; a.mask_s0 = mask_s0;
+  hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(256), dim3(1024), SB_LDS_BYTES, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_lstm_seq_bwd_work_floats(int32_t B, int32_t U) {
+  (void)U;
+  return 2 * ((B + 15) / 16) * 32 * 32 * 256;
 }

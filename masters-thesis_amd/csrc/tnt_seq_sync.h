@@ -97,7 +97,11 @@ __device__ __forceinline__ void tnt_seq_group_barrier(unsigned* flags, int ub, u
   __syncthreads();
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
+#ifdef TNT_SEQ_FLAG_PLAIN     // experiment: plain store (stays in the XCD's L2) instead of the write-through sc1 store
+    if (lane == 0) *reinterpret_cast<volatile unsigned*>(flags + ub) = target;
+#else
     if (lane == 0) __hip_atomic_store(flags + ub, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     unsigned spins = 0;
     for (;;) {
       const unsigned v = lane < 32 ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;

@@ -224,12 +224,17 @@ class NICfc(_DenseNIC):
             be.dropout(self.dOut, self.dOut, n, U, U, B, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds)
         Ur = a.p("lstm/recurrent_kernel")
         dOut = self.dOut.view(T, B, U)
-        for t in range(T - 1, -1, -1):
-            last = t == T - 1
-            be.lstm_step_bwd(None if last else self.dZ[(t + 1) * B:(t + 2) * B], Ur, None if last else self.da_pass,
-                             None, None if last else self.dc, None if last else self.dout, dOut[t], self.cap, T, t,
-                             self.gates[t], self.Cs[t + 1], self.Cs[t], self.dZ[t * B:(t + 1) * B], self.da_pass,
-                             self.dc, self.dout, B, U)
+        seqb = self._seq_lstm and self.seq_xch is not None
+        if seqb:       # BPTT as one persistent launch, see nic.NIC._bwd_seq_lstm
+            be.lstm_seq_bwd(Ur, dOut, self.cap, T, 0, self.gates, self.Cs, self.dZ, self.seq_xch, T, B, U, self.seq_sync,
+                            self._guard_out())
+        else:
+            for t in range(T - 1, -1, -1):
+                last = t == T - 1
+                be.lstm_step_bwd(None if last else self.dZ[(t + 1) * B:(t + 2) * B], Ur, None if last else self.da_pass,
+                                 None, None if last else self.dc, None if last else self.dout, dOut[t], self.cap, T, t,
+                                 self.gates[t], self.Cs[t + 1], self.Cs[t], self.dZ[t * B:(t + 1) * B], self.da_pass,
+                                 self.dc, self.dout, B, U)
         hprev = self.Hs[:T].view(n, U)
         self.gemm_sk(hprev, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True)
         self.gemm_sk(self.text, self.dZ, a.g("lstm/kernel"), E, 4 * U, n, E, 4 * U, 4 * U, transA=True)

@@ -397,6 +397,12 @@ class ModelBase:
             self.seq_sync = torch.zeros(1025, dtype=torch.int32, device=self.device)     # re-armed by the kernel itself
         elif not self._seq_lstm and "seq_sync" not in self.__dict__:
             self.seq_sync = None
+        if self._seq_lstm and hasattr(self.be, "lstm_seq_bwd") and getattr(self, "use_seq_lstm_bwd", True):
+            n = self.be.lstm_seq_bwd_work_floats(B, U)       # exchange buffer of the persistent BPTT chain
+            if self.__dict__.get("seq_xch") is None or self.seq_xch.numel() < n:
+                self.seq_xch = self._f(n)
+        else:
+            self.seq_xch = None
 
     def disable_seq_lstm(self):
         """Back to the per-step LSTM kernels (after a guard trip of the persistent one, or by choice): zeroes the sync

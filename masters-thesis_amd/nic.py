@@ -307,15 +307,21 @@ class NIC(ModelBase):
         sd, ds = self.seed, self.drop_step
         Ur = a.p("lstm/recurrent_kernel")
         dOut = self.dOut.view(T, B, U)
-        for t in range(T, 0, -1):
-            first = t == T
-            be.lstm_step_bwd(None if first else self.dZ[(t + 1) * B:(t + 2) * B], Ur,
-                             None if first else self.da_pass, None, None if first else self.dc,
-                             None if first else self.dout, dOut[t - 1], self.cap, T, t - 1, self.gates[t],
-                             self.Cs[t + 1], self.Cs[t], self.dZ[t * B:(t + 1) * B], self.da_pass, self.dc, self.dout,
-                             B, U)
-        be.lstm_step_bwd(self.dZ[B:2 * B], Ur, self.da_pass, None, self.dc, None, None, None, 0, 0, self.gates[0],
-                         self.Cs[1], self.Cs[0], self.dZ[:B], None, None, None, B, U)
+        if self._seq_lstm and self.seq_xch is not None:
+            # the T+1 dependent backward steps as ONE persistent launch (tnt_lstm_seq_bwd_f32): weights stationary, the
+            # recurrent product pushed as partial tiles through the XCD's L2
+            be.lstm_seq_bwd(Ur, dOut, self.cap, T, 1, self.gates, self.Cs, self.dZ, self.seq_xch, T + 1, B, U, self.seq_sync,
+                            self._guard_out())
+        else:
+            for t in range(T, 0, -1):
+                first = t == T
+                be.lstm_step_bwd(None if first else self.dZ[(t + 1) * B:(t + 2) * B], Ur,
+                                 None if first else self.da_pass, None, None if first else self.dc,
+                                 None if first else self.dout, dOut[t - 1], self.cap, T, t - 1, self.gates[t],
+                                 self.Cs[t + 1], self.Cs[t], self.dZ[t * B:(t + 1) * B], self.da_pass, self.dc, self.dout,
+                                 B, U)
+            be.lstm_step_bwd(self.dZ[B:2 * B], Ur, self.da_pass, None, self.dc, None, None, None, 0, 0, self.gates[0],
+                             self.Cs[1], self.Cs[0], self.dZ[:B], None, None, None, B, U)
         xin = self._xin_used
         with self.side(1):
             self.gemm_sk(self.Hs, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, R1, U, 4 * U, 4 * U, transA=True, ws=2)

@@ -122,6 +122,14 @@ class HipBackend:
         self._call(self.lib.tnt_lstm_seq_fwd_f32, "tnt_lstm_seq_fwd_f32", _p(xz), _p(hs), _p(cs), _p(Ur), _p(xz_bias),
                    _p(mask_ids), mask_T, mask_s0, _p(out), _p(gates), S, B, U, _p(sync), _p(guard_out), self._s())
 
+    def lstm_seq_bwd_work_floats(self, B, U):
+        return int(self.lib.tnt_lstm_seq_bwd_work_floats(int(B), int(U)))
+
+    def lstm_seq_bwd(self, Ur, dout_seq, mask_ids, mask_T, mask_s0, gates, cs, dz, work, S, B, U, sync, guard_out=None):
+        """BPTT over the S steps of one sequence in ONE persistent launch (tnt_lstm_seq_bwd_f32)."""
+        self._call(self.lib.tnt_lstm_seq_bwd_f32, "tnt_lstm_seq_bwd_f32", _p(Ur), _p(dout_seq), _p(mask_ids), mask_T, mask_s0,
+                   _p(gates), _p(cs), _p(dz), _p(work), work.numel(), S, B, U, _p(sync), _p(guard_out), self._s())
+
     def lstm_step_bwd(self, dz_next, Ur, da_pass_in, dh_ext, dc_in, dout_in, dout_t, mask_ids, mask_T, mask_t,
                       gates, c, c_prev, dz, da_pass_out, dc_out, dout_out, B, U, Wc=None, D=0, dctx_part=None):
         self._call(self.lib.tnt_lstm_step_bwd_f32, "tnt_lstm_step_bwd_f32", _p(dz_next), _p(Ur), _p(da_pass_in), _p(dh_ext), _p(dc_in),

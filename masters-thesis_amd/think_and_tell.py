@@ -256,12 +256,17 @@ class CaptionGenerator(ModelBase):
             be.dropout(self.dOut, self.dOut, R1, U, U, B, U, 0, self.r_dec, sd, S_OUT, 0, ds)
         Ur = a.p("lstm/recurrent_kernel")
         mask = self.lenmask if self.sat else None
-        for t in range(T, -1, -1):
-            first = t == T
-            be.lstm_step_bwd(None if first else self.dZ[(t + 1) * B:(t + 2) * B], Ur, None if first else self.da_pass,
-                             None, None if first else self.dc, None, self.dOut[t * B:(t + 1) * B], mask, T + 1, t,
-                             self.gates[t], self.Cs[t + 1], self.Cs[t], self.dZ[t * B:(t + 1) * B], self.da_pass,
-                             self.dc, None, B, U)
+        seqb = self._seq_lstm and mask is None and self.seq_xch is not None
+        if seqb:       # BPTT as one persistent launch (unmasked decoder), see nic.NIC._bwd_seq_lstm
+            be.lstm_seq_bwd(Ur, self.dOut, None, 0, 0, self.gates, self.Cs, self.dZ, self.seq_xch, T + 1, B, U, self.seq_sync,
+                            self._guard_out())
+        else:
+            for t in range(T, -1, -1):
+                first = t == T
+                be.lstm_step_bwd(None if first else self.dZ[(t + 1) * B:(t + 2) * B], Ur, None if first else self.da_pass,
+                                 None, None if first else self.dc, None, self.dOut[t * B:(t + 1) * B], mask, T + 1, t,
+                                 self.gates[t], self.Cs[t + 1], self.Cs[t], self.dZ[t * B:(t + 1) * B], self.da_pass,
+                                 self.dc, None, B, U)
         self.gemm_sk(self.Hs, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, R1, U, 4 * U, 4 * U, transA=True)
         self.gemm_sk(self.Xin, self.dZ, a.g("lstm/kernel"), E, 4 * U, R1, E, 4 * U, 4 * U, transA=True)
         be.colsum(self.dZ, a.g("lstm/bias"), R1, 4 * U, 4 * U, self.work)

@@ -613,6 +613,85 @@ def test_lstm_seq_fwd_matches_oracle(be, B, masked):
         close(Out, np.stack(Ow))
 
 
+@pytest.mark.parametrize("B,mode", [(64, "nic"), (40, "nic"), (64, "fc"), (128, "plain")])
+def test_lstm_seq_bwd_matches_oracle_and_step_kernels(be, B, mode):
+    """tnt_lstm_seq_bwd_f32 (the BPTT chain as one persistent launch, weights stationary, partial products pushed through
+    the XCD's L2) against (a) the float64 oracle chain of NIC.backward (oracle/models.py, NIC.py:248-249 through the
+    keras LSTM of NIC.py:138-140) and (b) the per-step kernel driven the way the models drive it.
+    mode nic: feature step + masked text steps (mask_s0 = 1); fc: every step masked (lc_NIC.py:317-318);
+    plain: no mask (ThinkAndTell decoder)."""
+    U, T = 512, 15
+    S = T + 1 if mode != "fc" else T
+    s0 = {"nic": 1, "fc": 0, "plain": 0}[mode]
+    if not be.lstm_seq_supported(B, U):
+        pytest.skip("persistent LSTM kernel not supported on this device")
+    rng = np.random.default_rng(200 + B)
+    xz = rng.standard_normal((S, B, 4 * U)) * 0.5
+    Ur = rng.standard_normal((U, 4 * U)) / np.sqrt(U)
+    nseq = S - s0
+    cap = rng.integers(1, 50, (B, nseq)).astype(np.int32)
+    for b in range(B):
+        cap[b, rng.integers(2, nseq):] = 0
+    cap[1, 0] = 0
+    masked = mode != "plain"
+    dOut = rng.standard_normal((nseq, B, U)) * 0.1
+    # ---- oracle forward + backward chain
+    h, c = np.zeros((B, U)), np.zeros((B, U))
+    caches, ms = [], []
+    for s in range(S):
+        h2, c2, cache = O.lstm_step_fwd(xz[s], h, c, Ur)
+        m = (cap[:, s - s0] != 0)[:, None] if (masked and s >= s0) else np.ones((B, 1), bool)
+        caches.append(cache); ms.append(m)
+        h, c = np.where(m, h2, h), np.where(m, c2, c)
+    da, dc, dout = np.zeros((B, U)), np.zeros((B, U)), np.zeros((B, U))
+    dzw = np.zeros((S, B, 4 * U))
+    for s in reversed(range(S)):
+        m = ms[s]
+        if s >= s0:
+            dout = dout + dOut[s - s0]
+        else:
+            dout = np.zeros((B, U))
+        dz, dh_prev, dc_prev = O.lstm_step_bwd(np.where(m, da + dout, 0), np.where(m, dc, 0), caches[s], Ur)
+        dzw[s] = dz
+        da = np.where(m, 0, da) + dh_prev
+        dc = np.where(m, 0, dc) + dc_prev
+        dout = np.where(m, 0, dout)
+    # ---- device forward (persistent kernel) to produce gates / cell states
+    Hs, Cs = torch.zeros(S + 1, B, U, device="cuda"), torch.zeros(S + 1, B, U, device="cuda")
+    Out, G = torch.zeros(nseq, B, U, device="cuda"), torch.zeros(S, B, U, 4, device="cuda")
+    sync = torch.zeros(1025, dtype=torch.int32, device="cuda")
+    guard = torch.zeros(1, device="cuda")
+    capd = dev(cap, torch.int32) if masked else None
+    Urd = dev(il(Ur, U))
+    be.lstm_seq_fwd(dev(il(xz, U)), Hs, Cs, Urd, None, capd, nseq, s0, Out, G, S, B, U, sync, guard)
+    dOutd = dev(dOut)
+    dZ = torch.full((S, B, U, 4), 7.0, device="cuda")
+    work = torch.zeros(be.lstm_seq_bwd_work_floats(B, U), device="cuda")
+    be.lstm_seq_bwd(Urd, dOutd, capd, nseq, s0, G, Cs, dZ, work, S, B, U, sync, guard)
+    torch.cuda.synchronize()
+    assert int(sync[1024]) == 0 and float(guard) == 0.0
+    close(unil(dZ.cpu().numpy()), dzw)
+    # ---- the per-step kernel, driven as nic.NIC._bwd_seq_lstm drives it
+    dZ2 = torch.zeros(S, B, U, 4, device="cuda")
+    z = lambda: torch.zeros(B, U, device="cuda")
+    dap, dcp, dop = z(), z(), z()
+    for s in range(S - 1, -1, -1):
+        first = s == S - 1
+        seq = s >= s0
+        be.lstm_step_bwd(None if first else dZ2[s + 1], Urd, None if first else dap, None, None if first else dcp,
+                         (None if first else dop) if seq else None, dOutd[s - s0] if seq else None,
+                         capd if (seq and masked) else None, nseq, s - s0 if seq else 0, G[s], Cs[s + 1], Cs[s], dZ2[s],
+                         dap, dcp, dop if seq else None, B, U)
+    torch.cuda.synchronize()
+    scale = dZ2.abs().max().item()
+    assert (dZ - dZ2).abs().max().item() <= 2e-6 * max(1.0, scale) + 1e-6 * scale
+    # run-to-run bit-identical (fixed summation order, no atomics)
+    dZ3 = torch.zeros_like(dZ)
+    be.lstm_seq_bwd(Urd, dOutd, capd, nseq, s0, G, Cs, dZ3, work, S, B, U, sync, guard)
+    torch.cuda.synchronize()
+    assert torch.equal(dZ, dZ3)
+
+
 def test_lstm_seq_sync_state_after_graph_replays(be):
     """The persistent kernel re-arms its own sync state (csrc/tnt_seq_sync.h): after 250 replays of a captured launch
     -- no reset node, frozen kernel arguments -- the error word is 0, every ticket / exit counter is back at 0, the

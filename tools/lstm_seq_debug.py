@@ -23,10 +23,10 @@ for t in range(1, S):
     be.lstm_step_fwd(xz[t], Hs[t], Cs[t], Ur, None, None, 0, capd, T, t - 1, Out[t - 2] if t > 1 else None, Hs[t + 1], Cs[t + 1], Out[t - 1], G[t], B, U, xz_bias=bl)
 for rep in range(3):
     Hs2, Cs2, Out2, G2 = alloc()
-    sync = torch.ones(1025, dtype=torch.int32, device="cuda")
+    sync = torch.zeros(1025, dtype=torch.int32, device="cuda")
     be.lstm_seq_fwd(xz, Hs2, Cs2, Ur, bl, capd, T, 1, Out2, G2, S, B, U, sync)
     torch.cuda.synchronize()
-    print("err", int(sync[1024]), "counters", sync[0:512:64].tolist(), "tickets", sync[512:1024:64].tolist())
+    print("err", int(sync[1024]), "flag0", sync[0:512:64].tolist(), "tickets", sync[512:1024:64].tolist(), "epochs", sync[514:1024:64].tolist())
     for s in range(S + 1):
         d = (Hs[s] - Hs2[s]).abs()
         print(s, "H maxdiff %.3e" % d.max().item(), "rows bad", (d.max(1).values > 0).sum().item(), "cols bad", (d.max(0).values > 0).sum().item(),
@@ -60,3 +60,25 @@ t_steps = timeit(steps)
 t_seq = timeit(lambda: be.lstm_seq_fwd(xz, Hs2, Cs2, Ur, bl, capd, T, 1, Out2, G2, S, B, U, sync))
 print(f"16 step launches: {t_steps:7.1f} us ({t_steps / S:.2f} us/step);  persistent: {t_seq:7.1f} us ({t_seq / S:.2f} us/step); err {int(sync[1024])}")
 
+
+# ---- backward chain: 16 per-step launches vs the persistent push kernel
+dOut = f(T, B, U) * 0.1
+dZ, dZ2 = torch.zeros(S, B, U, 4, device="cuda"), torch.zeros(S, B, U, 4, device="cuda")
+z = lambda: torch.zeros(B, U, device="cuda")
+dap, dcp, dop = z(), z(), z()
+work = torch.zeros(be.lstm_seq_bwd_work_floats(B, U), device="cuda")
+
+
+def bsteps():
+    for s in range(S - 1, -1, -1):
+        first, seq = s == S - 1, s >= 1
+        be.lstm_step_bwd(None if first else dZ[s + 1], Ur, None if first else dap, None, None if first else dcp,
+                         (None if first else dop) if seq else None, dOut[s - 1] if seq else None, capd if seq else None, T,
+                         s - 1 if seq else 0, G2[s], Cs2[s + 1], Cs2[s], dZ[s], dap, dcp, dop if seq else None, B, U)
+
+
+t_bsteps = timeit(bsteps)
+t_bseq = timeit(lambda: be.lstm_seq_bwd(Ur, dOut, capd, T, 1, G2, Cs2, dZ2, work, S, B, U, sync))
+torch.cuda.synchronize()
+print(f"backward: 16 step launches: {t_bsteps:7.1f} us ({t_bsteps / S:.2f} us/step);  persistent: {t_bseq:7.1f} us "
+      f"({t_bseq / S:.2f} us/step); err {int(sync[1024])}; max |dz diff| {(dZ - dZ2).abs().max().item():.3e}")
