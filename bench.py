@@ -129,13 +129,18 @@ def _work_model(name, a):
     """(group key, algorithmic FLOPs, algorithmic HBM bytes) of one recorded C-ABI call (argument layouts: include/tnt_hip.h).
     SURVEY 8d: a GEMM is 2*M*N*K FLOPs and reads A, B / writes C once; an LSTM step is 2*B*4U*U FLOPs; the optimizer
     moves 7 words per parameter, the norm pass 2."""
-    if name in ("tnt_gemm_f32", "tnt_gemm_blas_f32", "tnt_gemm_acc_f32"):
+    if name in ("tnt_gemm_f32", "tnt_gemm_blas_f32", "tnt_gemm_fused_f32"):
+        nb = 1
         if name == "tnt_gemm_f32":
             M, N, K, tA, tB = a[5], a[6], a[7], a[11], a[12]
+        elif name == "tnt_gemm_fused_f32":
+            M, N, K, tA, tB = a[7], a[8], a[9], a[13], a[14]
+            nb = 2 if a[5] else 1
         else:
             M, N, K, tA, tB = a[3], a[4], a[5], a[9], a[10]
         lay = ("T" if tA else "N") + ("T" if tB else "N")
-        return f"{name} {lay} {M}x{N}x{K}", 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N)
+        return (f"{name} {lay} {M}x{N}x{K}" + (" x2" if nb == 2 else ""), 2.0 * M * N * K * nb,
+                4.0 * (nb * M * K + K * N + nb * M * N))
     if name == "tnt_lstm_step_bwd_f32":
         Bq, Uq = a[17], a[18]
         if not a[0]:

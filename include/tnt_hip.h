@@ -57,6 +57,23 @@ int32_t tnt_gemm_blas_f32(const float* A, const float* B, float* C, int32_t M, i
                           int32_t lda, int32_t ldb, int32_t ldc, int32_t transA, int32_t transB,
                           int32_t accumulate, void* stream);
 
+/* One-round GEMM family for the products that carry no activation epilogue -- the weight / input gradients that
+ * tape.gradient derives from the Dense / LSTM layers (lc_NIC.py:386-387, NIC.py:248-249) and the LSTM input projection
+ * (NIC.py:138-140): C = op(A) op(B) (+ bias[N]), operand conventions of tnt_gemm_f32.  The workgroup tile is picked so
+ * that the whole output is ONE round of at most 256 workgroups (one per CU); FP32 MFMA 16x16x4, exact f32, a fixed
+ * summation order (bitwise reproducible).  Fused riders:
+ *   colsum (nullable; transA=1, transB=0 only): colsum[n] = sum_k B[k][n] -- the bias gradient of the layer whose
+ *     kernel gradient this product is (B = dY), computed from the B tiles the first row of workgroups loads anyway;
+ *   A2 / C2 (both or neither): a second product C2 = op(A2) op(B) with the same dims and strides in the same launch
+ *     (the LSTM's kernel and recurrent-kernel gradients share dZ).
+ * cfg = 0: automatic; > 0: force configuration `cfg` of the table in csrc/gemm.hip (tools/gemm_cfg_scan.py).
+ * Returns a negative code when no one-round configuration exists for the shape (the caller then uses tnt_gemm_f32). */
+int32_t tnt_gemm_fused_f32(const float* A, const float* B, float* C, const float* bias, float* colsum,
+                           const float* A2, float* C2, int32_t M, int32_t N, int32_t K, int32_t lda,
+                           int32_t ldb, int32_t ldc, int32_t transA, int32_t transB, int32_t cfg, void* stream);
+/* the configuration tnt_gemm_fused_f32 would pick (0 = none) */
+int32_t tnt_gemm_fused_cfg(int32_t M, int32_t N, int32_t K, int32_t transA, int32_t transB, int32_t batch);
+
 /* tuning entry point: tnt_gemm_f32 with the workgroup tile forced to bm x bn (each 64 or 128; anything else =
  * the library's own choice).  Used by tools/gemm_bench.py / gemm_scan.py to calibrate the tile heuristic. */
 int32_t tnt_gemm_f32_tile(const float* A, const float* B, float* C, const float* bias, float* pre,

@@ -21,6 +21,8 @@ I32, I64, U32, U64, F32 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_floa
 SIGNATURES = {
     "tnt_version": [],
     "tnt_gemm_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, F32, I32, I32, P, P],
+    "tnt_gemm_fused_f32": [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
+    "tnt_gemm_fused_cfg": [I32, I32, I32, I32, I32, I32],
     "tnt_dropout_mask4_u8": [P, I64, I32, F32, U64, U32, U32, P, P],
     "tnt_dropout_f32": [P, P, I32, I32, I32, I32, I32, I32, I32, F32, U64, U32, U32, P, P],
     "tnt_act_bwd_f32": [P, P, P, I64, I32, F32, P],

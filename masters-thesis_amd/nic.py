@@ -239,7 +239,10 @@ class NIC(ModelBase):
                 be.dropout(self.Xin[B:], self.Xin_d[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
         self._xin_used = xin
         # input projection of all T+1 steps as ONE epilogue-free GEMM; the LSTM bias is added inside the step kernel
-        self.gemm_sk(xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U)
+        if getattr(self, "fused_xproj", True) and hasattr(be, "gemm_fused") and be.gemm_fused_cfg(R1, 4 * U, E) > 0:
+            be.gemm_fused(xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U)
+        else:
+            self.gemm_sk(xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U)
         Ur, bl = a.p("lstm/recurrent_kernel"), a.p("lstm/bias")
         if self._seq_lstm:
             # both LSTM calls (NIC.py:138,140) as ONE persistent launch: the T+1 dependent steps pay an XCD-local barrier
@@ -284,10 +287,15 @@ class NIC(ModelBase):
         U, V, ldV = self.U, self.V, self.ldV
         dlog = self.logits
         Wo = a.p("time_distributed_softmax/kernel")
-        with self.side(0 if getattr(self, "side_head", True) else -1):
-            self.gemm_sk(self.Out, dlog, a.g("time_distributed_softmax/kernel"), U, V, T * B, U, ldV, ldV, transA=True,
-                         ws=1)
-            be.colsum(dlog, a.g("time_distributed_softmax/bias"), T * B, V, ldV, self.work2)
+        if getattr(self, "fused_head_grads", False) and hasattr(be, "gemm_fused") and \
+                be.gemm_fused_cfg(U, V, T * B, True, False, 1) > 0:
+            be.gemm_fused(self.Out, dlog, a.g("time_distributed_softmax/kernel"), U, V, T * B, U, ldV, ldV, transA=True,
+                          colsum=a.g("time_distributed_softmax/bias"))
+        else:
+            with self.side(0 if getattr(self, "side_head", True) else -1):
+                self.gemm_sk(self.Out, dlog, a.g("time_distributed_softmax/kernel"), U, V, T * B, U, ldV, ldV, transA=True,
+                             ws=1)
+                be.colsum(dlog, a.g("time_distributed_softmax/bias"), T * B, V, ldV, self.work2)
         self.gemm_sk(dlog, Wo, self.dOut, T * B, U, V, ldV, ldV, U, transB=True)
         if join:
             self.join()
@@ -323,6 +331,13 @@ class NIC(ModelBase):
             be.lstm_step_bwd(self.dZ[B:2 * B], Ur, self.da_pass, None, self.dc, None, None, None, 0, 0, self.gates[0],
                              self.Cs[1], self.Cs[0], self.dZ[:B], None, None, None, B, U)
         xin = self._xin_used
+        if getattr(self, "fused_lstm_grads", True) and E == U and hasattr(be, "gemm_fused") and \
+                be.gemm_fused_cfg(U, 4 * U, R1, True, False, 2) > 0:
+            # kernel, recurrent-kernel and bias gradients in ONE launch of the one-round GEMM family: the two products
+            # share dZ, the bias gradient (column sums of dZ) rides on the tiles the first row of workgroups loads anyway
+            be.gemm_fused(xin, self.dZ, a.g("lstm/kernel"), E, 4 * U, R1, E, 4 * U, 4 * U, transA=True,
+                          colsum=a.g("lstm/bias"), A2=self.Hs, C2=a.g("lstm/recurrent_kernel"))
+            return
         with self.side(1):
             self.gemm_sk(self.Hs, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, R1, U, 4 * U, 4 * U, transA=True, ws=2)
         with self.side(0):

@@ -55,6 +55,16 @@ class HipBackend:
                                          int(transA), int(transB), act, slope, int(accumulate), splitk,
                                          _p(work), self._s())
 
+    def gemm_fused_cfg(self, M, N, K, transA=False, transB=False, batch=1):
+        """configuration tnt_gemm_fused_f32 would pick for this shape (0 = none: use gemm with split-K)"""
+        return int(self.lib.tnt_gemm_fused_cfg(M, N, K, int(transA), int(transB), batch))
+
+    def gemm_fused(self, A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, colsum=None, A2=None,
+                   C2=None, cfg=0):
+        """one-round GEMM without an activation epilogue; riders: column sums of B (bias gradient), a second product"""
+        self._call(self.lib.tnt_gemm_fused_f32, "tnt_gemm_fused_f32", _p(A), _p(B), _p(C), _p(bias), _p(colsum), _p(A2), _p(C2),
+                   M, N, K, lda, ldb, ldc, int(transA), int(transB), cfg, self._s())
+
     def gemm_tile(self, A, B, C, M, N, K, lda, ldb, ldc, bm, bn, transA=False, transB=False, bias=None, pre=None,
                   act=ACT_NONE, slope=0.2, accumulate=False, splitk=1, work=None):
         """tnt_gemm_f32 with the workgroup tile forced: (64|128, 64|128) = the tiled kernel, (160, 128) = the
