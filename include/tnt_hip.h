@@ -357,6 +357,22 @@ int32_t tnt_sgd_f32(float* theta, float* mom, const float* grad, const int32_t* 
                     const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
                     const float* sq, const float* sq_override, int32_t nspan, float lr,
                     const float* lr_dev, float momentum, float clipnorm, const uint32_t* guard, void* stream);
+/* ---- adaptive gradient clipping, unit-wise (AttemptFour/Model/agc.py:20-38; call site lc_NIC.py:388) ----
+ * Applied in place to the flat gradient arena before the norms / clip-by-norm / Adam: per variable v (table entry:
+ * arena offset var_off, row stride var_ld, L2 lambda var_lam) and per unit = output column of a keras (in, out) kernel
+ * (vectors: one unit):  g <- g * max(||theta_u||, eps) * clip_factor / max(||g_u||, 1e-6)  where ||g_u|| is not below
+ * that bound; g = arena gradient + 2 lambda theta (what tape.gradient returns), written back minus the L2 term.
+ * item [nitem][6] = (var, c0, ncols <= 64, r0, r1, column block id), cb_first [ncb+1] = first item of each column
+ * block (items of a block are consecutive); partial: nitem*128 floats.  Embedding (IndexedSlices, agc.py:25-30):
+ * gsq_cols[E] = column sums of squares of the un-deduplicated row gradients (tnt_colsq_f32) replaces the dense
+ * gradient's for variable gsq_var, whose column blocks are gsq_cb0 .. gsq_cb0+gsq_ncb-1; sq_out[0] receives the squared
+ * norm of the clipped rows (for clip-by-norm's IndexedSlices norm), sq_part: gsq_ncb floats of scratch. */
+int32_t tnt_agc_f32(const float* theta, float* grad, const int64_t* var_off, const int32_t* var_ld,
+                    const float* var_lam, const int32_t* item, const int32_t* cb_first, int32_t nitem,
+                    float* partial, const float* gsq_cols, int32_t gsq_var, int32_t gsq_cb0, int32_t gsq_ncb,
+                    float* sq_part, float* sq_out, float clip_factor, float eps, void* stream);
+/* out[c] = sum_r x[r][c]^2 */
+int32_t tnt_colsq_f32(const float* x, float* out, int32_t rows, int32_t cols, int32_t ld, void* stream);
 /* Sharpness-aware minimisation helper (CaptionGenerator.train_step_SAM, ThinkAndTell/model.py:166-233;
  * lc_NIC.train_step_sam, lc_NIC.py:713-838).  mode 0: e_w = (g + 2 lambda theta) * rho/(||g||+1e-12)
  * with ||g||^2 = sum_s sq[s] (from tnt_seg_sqnorm_f32); theta += e_w; e_w stored.  mode 1: theta -= e_w. */

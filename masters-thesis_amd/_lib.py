@@ -61,6 +61,8 @@ SIGNATURES = {
     "tnt_seg_sqnorm_f32": [P, P, P, P, P, P, P, P, P, P, P, I32, I32, P],
     "tnt_adam_f32": [P, P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, F32, F32, P, P],
     "tnt_sgd_f32": [P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, P, P],
+    "tnt_agc_f32": [P, P, P, P, P, P, P, I32, P, P, I32, I32, I32, P, P, F32, F32, P],
+    "tnt_colsq_f32": [P, P, I32, I32, I32, P],
     "tnt_step_tick": [P, P, P, P, F32, F32, P, P],
     "tnt_sam_f32": [P, P, P, P, P, P, P, P, I32, I32, F32, I32, P],
     "tnt_gemm_f32_tile": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, F32, I32, I32, P, I32, I32, P],

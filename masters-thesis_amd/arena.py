@@ -121,3 +121,36 @@ class ParamArena:
     def slot(self, buf, name):
         e = self.entries[name]
         return buf[e.off:e.off + e.size].view(e.shape)
+
+
+class AgcTable:
+    """Work table of tnt_agc_f32 (adaptive gradient clipping, agc.py:20-38): every trainable cut into items of
+    <= 64 columns x <= ROWS rows.  ``shapes``: name -> keras shape (rank 1: one unit; rank 2: one unit per output
+    column; the storage may be wider than the keras shape -- zero padding never clips)."""
+    ROWS = 256
+
+    def __init__(self, arena, shapes, emb_name=None):
+        dev = arena.device
+        off, ld, lam, items, cb_first = [], [], [], [], [0]
+        self.emb = None
+        for v, (name, e) in enumerate(arena.entries.items()):
+            ks = tuple(shapes[name])
+            rows = int(ks[0]) if len(ks) >= 2 else e.size
+            cols = e.size // rows if len(ks) >= 2 else 1
+            assert rows * cols == e.size, (name, ks, e.shape)
+            off.append(e.off); ld.append(cols); lam.append(e.l2)
+            cb0 = len(cb_first) - 1
+            for c0 in range(0, cols, 64):
+                for r0 in range(0, rows, self.ROWS):
+                    items.append((v, c0, min(64, cols - c0), r0, min(rows, r0 + self.ROWS), len(cb_first) - 1))
+                cb_first.append(len(items))
+            if name == emb_name:
+                self.emb = (v, cb0, len(cb_first) - 1 - cb0)
+        self.nitem = len(items)
+        self.var_off = torch.tensor(off, dtype=torch.int64, device=dev)
+        self.var_ld = torch.tensor(ld, dtype=torch.int32, device=dev)
+        self.var_lam = torch.tensor(lam, dtype=torch.float32, device=dev)
+        self.item = torch.tensor(items, dtype=torch.int32, device=dev).contiguous()
+        self.cb_first = torch.tensor(cb_first, dtype=torch.int32, device=dev)
+        self.partial = torch.zeros(self.nitem * 128, dtype=torch.float32, device=dev)
+        self.sq_part = torch.zeros(max(1, self.emb[2] if self.emb else 1), dtype=torch.float32, device=dev)

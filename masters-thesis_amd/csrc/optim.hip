@@ -172,6 +172,107 @@ __global__ __launch_bounds__(256) void sam_kernel(float* theta, const float* gra
   }
 }
 
+
+// ---- adaptive gradient clipping (AttemptFour/Model/agc.py:20-38; call site lc_NIC.py:388), unit-wise:
+// for a kernel of keras shape (in, out) every output column is its own unit; vectors are one unit.
+//   p_norm = ||theta_col||, max_norm = max(p_norm, eps) * clip_factor, g_norm = ||g_col||
+//   g_col <- g_col * max_norm / max(g_norm, 1e-6)   where g_norm >= max_norm
+// g is the full gradient the tape sees (data gradient + 2 lambda theta); the arena keeps the data gradient, so the
+// kernel writes back  g_clipped - 2 lambda theta  and the optimizer's own "+ 2 lambda theta" restores g_clipped.
+// Work is cut into items = (variable, block of 64 columns, chunk of rows): pass 1 leaves per-item column partials,
+// pass 2 sums the partials of its column block in fixed order (deterministic) and rescales its rows.
+struct AgcTab {
+  const int64_t* var_off; const int32_t* var_ld; const float* var_lam;     // per variable
+  const int32_t* item;         // [nitem][6]: var, c0, ncols, r0, r1, colblock
+  const int32_t* cb_first;     // [ncb + 1] first item of each column block
+};
+
+__global__ __launch_bounds__(256) void agc_partial_kernel(const float* theta, const float* grad, AgcTab t, float* partial) {
+  __shared__ float sp[4][64], sg[4][64];
+  const int it = blockIdx.x;
+  const int32_t* d = t.item + it * 6;
+  const int var = d[0], c0 = d[1], ncols = d[2], r0 = d[3], r1 = d[4];
+  const long off = t.var_off[var];
+  const int ld = t.var_ld[var];
+  const float lam2 = 2.f * t.var_lam[var];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  float ps = 0.f, gs = 0.f;
+  if (c < ncols)
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const long e = off + (long)r * ld + c0 + c;
+      const float w = theta[e], g = grad[e] + lam2 * w;
+      ps += w * w; gs += g * g;
+    }
+  sp[rl][c] = ps; sg[rl][c] = gs;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    partial[(long)it * 128 + c] = sp[0][c] + sp[1][c] + sp[2][c] + sp[3][c];
+    partial[(long)it * 128 + 64 + c] = sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c];
+  }
+}
+
+// gsq_cols (nullable) + gsq_var: column sums of squares that replace the dense gradient's for ONE variable -- the
+// Embedding, whose gradient is an IndexedSlices in the reference: agc.py:25-30 takes the norm of its un-deduplicated
+// rows.  sq_part_out (nullable): per column block of that variable, sum_c scale_c^2 * gsq_cols[c] -- the squared
+// norm of the clipped un-deduplicated rows that clip-by-norm then uses.
+__global__ __launch_bounds__(256) void agc_apply_kernel(const float* theta, float* grad, AgcTab t, const float* partial,
+                                                        const float* gsq_cols, int gsq_var, float* sq_part_out,
+                                                        int gsq_cb0, float clip_factor, float eps) {
+  __shared__ float sscale[64];
+  __shared__ float ssq[64];
+  const int it = blockIdx.x;
+  const int32_t* d = t.item + it * 6;
+  const int var = d[0], c0 = d[1], ncols = d[2], r0 = d[3], r1 = d[4], cb = d[5];
+  const long off = t.var_off[var];
+  const int ld = t.var_ld[var];
+  const float lam2 = 2.f * t.var_lam[var];
+  if (threadIdx.x < 64) {
+    const int c = threadIdx.x;
+    float ps = 0.f, gs = 0.f;
+    for (int k = t.cb_first[cb]; k < t.cb_first[cb + 1]; ++k) { ps += partial[(long)k * 128 + c]; gs += partial[(long)k * 128 + 64 + c]; }
+    const bool ovr = gsq_cols != nullptr && var == gsq_var && c < ncols;
+    if (ovr) gs = gsq_cols[c0 + c];
+    const float max_norm = fmaxf(sqrtf(ps), eps) * clip_factor;
+    const float gn = sqrtf(gs);
+    const float sc = (c < ncols && !(gn < max_norm)) ? max_norm / fmaxf(gn, 1e-6f) : 1.f;
+    sscale[c] = sc;
+    ssq[c] = ovr ? sc * sc * gs : 0.f;
+  }
+  __syncthreads();
+  if (sq_part_out != nullptr && var == gsq_var && r0 == 0 && threadIdx.x == 0) {
+    float a = 0.f;
+    for (int c = 0; c < 64; ++c) a += ssq[c];
+    sq_part_out[cb - gsq_cb0] = a;
+  }
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const float sc = sscale[c];
+  if (c < ncols && sc != 1.f)
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const long e = off + (long)r * ld + c0 + c;
+      const float w = theta[e];
+      grad[e] = (grad[e] + lam2 * w) * sc - lam2 * w;
+    }
+}
+
+// column sums of squares of a row-major matrix (the Embedding's row gradients), one workgroup per 64 columns
+__global__ __launch_bounds__(256) void colsq_kernel(const float* x, int rows, int cols, int ld, float* out) {
+  __shared__ float s[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float a = 0.f;
+  if (c < cols)
+    for (int r = rl; r < rows; r += 4) { const float v = x[(long)r * ld + c]; a += v * v; }
+  s[rl][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < cols) out[c] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+}
+
+__global__ void agc_sq_total_kernel(const float* part, int n, float* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float a = 0.f;
+  for (int i = 0; i < n; ++i) a += part[i];
+  out[0] = a;
+}
+
 // advances the device-resident step state (so a captured hipGraph replays with fresh values):
 //   adam_t += 1; lr_t = lr * sqrt(1-b2^t)/(1-b1^t); drop_step += 1
 __global__ void step_tick_kernel(int64_t* adam_t, uint32_t* drop_step, const float* lr, float* lr_t, float b1,
@@ -255,6 +356,33 @@ extern "C" int32_t tnt_sam_f32(float* theta, const float* grad, float* ew, const
   SpanTab t{span_seg, span_off, span_len, nullptr, seg_l2};
   hipLaunchKernelGGL(sam_kernel, dim3(nspan), dim3(256), 0, tnt_stream(stream), theta, grad, ew, t, sq, nseg, nspan, rho,
                      mode);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_agc_f32(const float* theta, float* grad, const int64_t* var_off, const int32_t* var_ld,
+                               const float* var_lam, const int32_t* item, const int32_t* cb_first, int32_t nitem,
+                               float* partial, const float* gsq_cols, int32_t gsq_var, int32_t gsq_cb0, int32_t gsq_ncb,
+                               float* sq_part, float* sq_out, float clip_factor, float eps, void* stream) {
+  if (nitem <= 0) return 0;
+  if (gsq_cols != nullptr && (sq_part == nullptr || sq_out == nullptr || gsq_ncb <= 0)) return TNT_BADARG(12);
+  AgcTab t{var_off, var_ld, var_lam, item, cb_first};
+  hipStream_t s = tnt_stream(stream);
+  hipLaunchKernelGGL(agc_partial_kernel, dim3(nitem), dim3(256), 0, s, theta, grad, t, partial);
+  TNT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(agc_apply_kernel, dim3(nitem), dim3(256), 0, s, theta, grad, t, partial, gsq_cols, gsq_var,
+                     gsq_cols ? sq_part : nullptr, gsq_cb0, clip_factor, eps);
+  TNT_LAUNCH_CHECK();
+  if (gsq_cols != nullptr) {
+    hipLaunchKernelGGL(agc_sq_total_kernel, dim3(1), dim3(64), 0, s, sq_part, gsq_ncb, sq_out);
+    TNT_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int32_t tnt_colsq_f32(const float* x, float* out, int32_t rows, int32_t cols, int32_t ld, void* stream) {
+  if (rows <= 0 || cols <= 0) return TNT_BADARG(2);
+  hipLaunchKernelGGL(colsq_kernel, dim3((cols + 63) / 64), dim3(256), 0, tnt_stream(stream), x, rows, cols, ld, out);
   TNT_LAUNCH_CHECK();
   return 0;
 }

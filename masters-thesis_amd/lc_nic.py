@@ -519,6 +519,7 @@ class NIC(ModelBase):
         if self.r_text > 0:
             be.dropout(self.dtext, self.dtext, n, Et, Et, B, Et, 0, self.r_text, sd, S_TEXT, 0, ds)
         sqo = a.sq_override[self.emb_seg:self.emb_seg + 1]
+        self._emb_rows = (self.dtext, n, Et, Et, "emb_text/embeddings")
         be.embedding_bwd(self.dtext, self.cap, a.g("emb_text/embeddings"), sqo, self.rowsq, B, T, Et, Et, V)
 
     def _bwd_front(self, B, T):
@@ -572,6 +573,7 @@ class NIC(ModelBase):
         self._backward(B, T)
 
     def _update_graph(self):
+        self._apply_agc()
         self._norms_and_l2(self.met[2:3])
         self._apply_optimizer()
 

@@ -236,6 +236,36 @@ class ModelBase:
             main.wait_stream(self._side_streams[i])
         used.clear()
 
+    # ------------------------------------------------------------------ adaptive gradient clipping (agc.py)
+    def enable_agc(self, clip_factor=0.01, eps=1e-3):
+        """gradients = agc.adaptive_clip_grad(trainable_variables, gradients, clip_factor, eps) before
+        optimizer.apply_gradients -- the (commented-out) call of lc_NIC.py:388.  clip_factor=None switches it off."""
+        self.agc = None if clip_factor is None else (float(clip_factor), float(eps))
+        self._graphs = {}
+
+    def _emb_row_grads(self):
+        """(row-gradient matrix of the Embedding [n][E], n, E, ld, arena name) or None: the IndexedSlices values whose
+        un-deduplicated column norms agc.py:25-30 uses.  Set by the models that have an Embedding."""
+        return self.__dict__.get("_emb_rows")
+
+    def _apply_agc(self):
+        if not self.__dict__.get("agc"):
+            return
+        from .arena import AgcTable
+        a, er = self.arena, self._emb_row_grads()
+        tab = self.__dict__.get("_agc_tab")
+        if tab is None:
+            shapes = {n: self.keras_shapes[n] for n in a.entries}
+            tab = self._agc_tab = AgcTable(a, shapes, er[4] if er else None)
+            self._agc_colsq = self._f(er[2]) if er else None
+        if er is not None:
+            x, n, E, ld, name = er
+            self.be.colsq(x, self._agc_colsq, n, E, ld)
+            seg = a.entries[name].seg
+            self.be.agc(a.theta, a.grad, tab, self._agc_colsq, a.sq_override[seg:seg + 1], *self.agc)
+        else:
+            self.be.agc(a.theta, a.grad, tab, None, None, *self.agc)
+
     def _norms_and_l2(self, l2_out):
         a, sp = self.arena, self.arena.spans
         self.be.seg_sqnorm(a.theta, a.grad, sp.span_seg, sp.span_off, sp.span_len, sp.seg_first, a.seg_l2, a.partial,

@@ -357,6 +357,7 @@ class NIC(ModelBase):
                 be.dropout(self.dXin, self.dXin, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
             be.dropout(self.dXin[B:], self.dXin[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
         sqo = a.sq_override[self.emb_seg:self.emb_seg + 1]
+        self._emb_rows = (self.dXin[B:], T * B, E, E, "emb_text/embeddings")
         be.embedding_bwd(self.dXin[B:], self.cap, a.g("emb_text/embeddings"), sqo, self.rowsq, B, T, E, E, V)
         if fused:       # dropout' -> BatchNorm' -> dropout' -> LeakyReLU' -> dpre, encoder bias gradient: one launch
             be.enc_tail_bwd(self.dXin, self.xhat, a.p("batch_norm/gamma"), self.inv_std, self.enc_pre, self.dpre,
@@ -397,6 +398,7 @@ class NIC(ModelBase):
         self._backward(B, T)
 
     def _update_graph(self):
+        self._apply_agc()
         self._norms_and_l2(self.met[2:3])
         self._apply_optimizer()
 

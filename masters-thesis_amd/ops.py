@@ -238,6 +238,16 @@ class HipBackend:
         self._call(self.lib.tnt_sam_f32, "tnt_sam_f32", _p(theta), _p(grad), _p(ew), _p(span_seg), _p(span_off), _p(span_len),
                                         _p(seg_l2), _p(sq), nseg, nspan, rho, mode, self._s())
 
+    def agc(self, theta, grad, tab, gsq_cols=None, sq_out=None, clip_factor=0.01, eps=1e-3):
+        """unit-wise adaptive gradient clipping over the arena; ``tab`` = arena.AgcTable"""
+        emb = tab.emb if gsq_cols is not None else None
+        self._call(self.lib.tnt_agc_f32, "tnt_agc_f32", _p(theta), _p(grad), _p(tab.var_off), _p(tab.var_ld), _p(tab.var_lam),
+                   _p(tab.item), _p(tab.cb_first), tab.nitem, _p(tab.partial), _p(gsq_cols), emb[0] if emb else -1,
+                   emb[1] if emb else 0, emb[2] if emb else 0, _p(tab.sq_part), _p(sq_out), clip_factor, eps, self._s())
+
+    def colsq(self, x, out, rows, cols, ld):
+        self._call(self.lib.tnt_colsq_f32, "tnt_colsq_f32", _p(x), _p(out), rows, cols, ld, self._s())
+
     def step_tick(self, adam_t, drop_step, lr, lr_t, beta1, beta2, guard=None):
         self._call(self.lib.tnt_step_tick, "tnt_step_tick", _p(adam_t), _p(drop_step), _p(lr), _p(lr_t), beta1, beta2, _p(guard),
                    self._s())

@@ -36,6 +36,31 @@ def _l2(lam, W):
     return lam * (W * W).sum()
 
 
+def apply_agc(model, grads, sparse, emb='emb_text/embeddings'):
+    """gradients = agc.adaptive_clip_grad(trainable_variables, gradients, clip_factor, eps) -- the commented-out call
+    of lc_NIC.py:388 (agc.py:20-38), enabled by ``model.agc = (clip_factor, eps)``.  The Embedding gradient is an
+    IndexedSlices there: its rows are clipped with unit norms taken over the un-deduplicated rows, and the norm that
+    clip-by-norm uses afterwards is the norm of those clipped rows."""
+    if not getattr(model, 'agc', None):
+        return grads, sparse
+    cf, eps = model.agc
+    out = {}
+    sparse = dict(sparse or {})
+    for k, g in grads.items():
+        if g is None:
+            out[k] = None
+        elif k == emb and getattr(model, 'last_emb_rows', None) is not None:
+            rows, flat = model.last_emb_rows
+            rows2 = O.adaptive_clip_grad(model.p[k], rows, cf, eps)
+            dense = np.zeros_like(model.p[k])
+            np.add.at(dense, flat, rows2)
+            out[k] = dense
+            sparse[k] = np.sqrt((rows2 * rows2).sum())
+        else:
+            out[k] = O.adaptive_clip_grad(model.p[k], g, cf, eps)
+    return out, sparse
+
+
 class AdamState:
     """keras Adam(lr, b1, b2, eps, clipnorm) -- main.py:97.  clip=None disables clipping
     (TF<=2.3 behaviour, SURVEY 9.9 version hazard)."""
@@ -208,6 +233,7 @@ class NICDense:
         g['lstm/bias'] = dbl
         demb = O.dropout_bwd(demb_d, cache['k_l1'], self.r_lstm)
         rows, flat = O.embedding_bwd_rows(demb, cache['ids'])
+        self.last_emb_rows = (rows, flat)
         g['emb_text/embeddings'] = O.embedding_bwd_dense(demb, cache['ids'], self.V)
         sparse_norm = np.sqrt((rows * rows).sum())
         df = O.dropout_bwd(df_d[:, None, :], cache['k_l0'], self.r_lstm)[:, 0, :]
@@ -229,6 +255,7 @@ class NICDense:
         ce, acc = self.metrics(probs, y_ids)
         l2 = self.l2_loss()
         grads, sparse = self.backward(probs, cache, y_ids)
+        grads, sparse = apply_agc(self, grads, sparse)
         self.last_sparse = sparse          # IndexedSlices norms used by clip-by-norm (for tests that re-apply Adam)
         opt.apply(self.p, grads, sparse)
         self.p['batch_norm/moving_mean'] = cache['new_mm']
@@ -471,7 +498,8 @@ class LcNIC:
         g['attention/W1/kernel'] = dW1 + 2 * self.l2_attn * W1
         g['attention/W1/bias'] = db1
         demb = O.dropout_bwd(dtext, cache['k_text'], self.r_text)
-        rows, _ = O.embedding_bwd_rows(demb, cache['ids'])
+        rows, flat_ = O.embedding_bwd_rows(demb, cache['ids'])
+        self.last_emb_rows = (rows, flat_)
         g['emb_text/embeddings'] = O.embedding_bwd_dense(demb, cache['ids'], self.V)
         sparse = {'emb_text/embeddings': np.sqrt((rows * rows).sum())}
         return g, sparse, dF
@@ -496,6 +524,7 @@ class LcNIC:
         ce, acc, al = self.metrics(probs, attn, y_ids)
         l2 = self.l2_loss()
         grads, sparse = self.backward(probs, cache, y_ids)
+        grads, sparse = apply_agc(self, grads, sparse)
         self.last_sparse = sparse          # IndexedSlices norms used by clip-by-norm (for tests that re-apply Adam)
         opt.apply(self.p, grads, sparse)
         self.p['input_bn/moving_mean'] = cache['enc']['new_mm']

@@ -321,6 +321,27 @@ def clip_by_norm(g, clipnorm):
     return g * clipnorm / np.maximum(n, clipnorm)
 
 
+def unitwise_norm(x):
+    """agc.unitwise_norm (AttemptFour/Model/agc.py:6-18): scalars / vectors -> one norm; rank 2, 3 -> over axis 0
+    (one unit per output column), keepdims."""
+    x = np.asarray(x)
+    if x.ndim <= 1:
+        return np.sqrt((x * x).sum())
+    if x.ndim in (2, 3):
+        return np.sqrt((x * x).sum(axis=0, keepdims=True))
+    raise ValueError("unitwise_norm: rank must be <= 3 here")
+
+
+def adaptive_clip_grad(param, grad, clip_factor=0.01, eps=1e-3):
+    """agc.adaptive_clip_grad for ONE (parameter, gradient) pair (agc.py:20-38).  ``grad`` may be the values of an
+    IndexedSlices (rows gathered from an Embedding): its unit norms are then taken over those rows (agc.py:25-30)."""
+    p_norm = unitwise_norm(param)
+    max_norm = np.maximum(p_norm, eps) * clip_factor
+    grad_norm = unitwise_norm(grad)
+    clipped = grad * (max_norm / np.maximum(grad_norm, 1e-6))
+    return np.where(grad_norm < max_norm, grad, clipped)
+
+
 def adam_update(theta, m, v, g, t, lr=1e-4, b1=0.9, b2=0.98, eps=1e-8):
     """keras OptimizerV2 Adam (main.py:97; SURVEY 9.9): epsilon outside the bias correction;
     t starts at 1.  Returns (theta, m, v)."""

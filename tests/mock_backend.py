@@ -404,6 +404,36 @@ class MockBackend:
                 e[o:o + n] = (gr[o:o + n].astype(np.float64) + 2 * float(l2[s]) * t) * scale
                 th[o:o + n] = t + e[o:o + n]
 
+    def colsq(self, x, out, rows, cols, ld):
+        m = mat(x, rows, cols, ld).astype(np.float64)
+        flat(out)[:cols] = (m * m).sum(0)
+
+    def agc(self, theta, grad, tab, gsq_cols=None, sq_out=None, clip_factor=0.01, eps=1e-3):
+        """include/tnt_hip.h: tnt_agc_f32, straight from the definition (per variable and unit column)."""
+        th, gr = flat(theta), flat(grad)
+        items = tab.item.numpy().reshape(-1, 6)
+        off, ld, lam = tab.var_off.numpy(), tab.var_ld.numpy(), tab.var_lam.numpy()
+        sq_total = 0.0
+        for v in np.unique(items[:, 0]):
+            it = items[items[:, 0] == v]
+            rows, cols = int(it[:, 4].max()), int(ld[v])
+            o, l2 = int(off[v]), 2 * float(lam[v])
+            W = th[o:o + rows * cols].reshape(rows, cols).astype(np.float64)
+            G = gr[o:o + rows * cols].reshape(rows, cols).astype(np.float64) + l2 * W
+            pn = np.sqrt((W * W).sum(0))
+            gsq = (G * G).sum(0)
+            emb = gsq_cols is not None and tab.emb is not None and v == tab.emb[0]
+            if emb:
+                gsq = flat(gsq_cols)[:cols].astype(np.float64)
+            gn = np.sqrt(gsq)
+            mx = np.maximum(pn, eps) * clip_factor
+            sc = np.where(gn < mx, 1.0, mx / np.maximum(gn, 1e-6))
+            gr[o:o + rows * cols] = ((G * sc) - l2 * W).reshape(-1)
+            if emb:
+                sq_total = float((sc * sc * gsq).sum())
+        if gsq_cols is not None and sq_out is not None:
+            flat(sq_out)[0] = sq_total
+
     def step_tick(self, adam_t, drop_step, lr, lr_t, beta1, beta2, guard=None):
         if guard is not None and int(guard[0]) != 0:
             return

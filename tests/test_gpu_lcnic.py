@@ -49,6 +49,30 @@ def test_train_parity(dims, rates, norm):
 
 
 @pytest.mark.parametrize("dims", DIMS)
+def test_train_parity_with_adaptive_gradient_clipping(dims):
+    """lc_NIC with the agc call of lc_NIC.py:388 switched on (agc.py:20-38)."""
+    from masters_thesis_amd.optimizers import Adam
+    rng = np.random.default_rng(54)
+    B, N, R, D, A, U, Et, V, T = dims
+    model, orc = build(rng, (0.1, 0.2, 0.2, 0.2, 0.2, 0.2), dims)
+    model.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    model.enable_agc(0.02, 1e-3)
+    orc.agc = (0.02, 1e-3)
+    opt = M.AdamState(orc.p, lr=1e-3, clipnorm=0.1)
+    for step in range(3):
+        data, tgt = synth_batch(B, N, T, V, U, rng)
+        res, grads, _ = orc.train_step(data, tgt, opt, M.DropCtx(seed=11, step=step, training=True))
+        got = model.train_step((data, tgt)).as_floats()
+        for k in ("loss", "L2", "attention"):
+            assert abs(got[k] - res[k]) <= 1e-4 * abs(res[k]) + 1e-7, (step, k)
+        for k, v in orc.p.items():
+            if k == "attention/V/bias":
+                continue
+            w = model.get_weight(k)
+            assert np.abs(w - v).max() <= 2e-2 * 1e-3 + 1e-4 * np.abs(v).max(), (step, k, np.abs(w - v).max())
+
+
+@pytest.mark.parametrize("dims", DIMS)
 def test_forward_gradients_greedy(dims):
     from masters_thesis_amd.optimizers import Adam
     rng = np.random.default_rng(52)

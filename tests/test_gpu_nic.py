@@ -56,6 +56,38 @@ def test_train_parity(dims, rates, norm):
 
 
 @pytest.mark.parametrize("dims", DIMS)
+def test_train_parity_with_adaptive_gradient_clipping(dims):
+    """gradients = agc.adaptive_clip_grad(...) before apply_gradients (agc.py:20-38, lc_NIC.py:388) through
+    tnt_agc_f32 / tnt_colsq_f32: post-AGC gradients and post-Adam weights against the oracle, graph replay included."""
+    from masters_thesis_amd.optimizers import Adam
+    rng = np.random.default_rng(34)
+    B, N, T, V, U, E = dims
+    model, orc = build(rng, (0, 0.2, 0.2), dims)
+    model.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    model.enable_agc(0.02, 1e-3)
+    orc.agc = (0.02, 1e-3)
+    opt = M.AdamState(orc.p, lr=1e-3, clipnorm=0.1)
+    lam = {"dense_img/kernel": 0.01, "lstm/kernel": 3e-5, "time_distributed_softmax/kernel": 3e-5}
+    for step in range(3):
+        data, tgt = synth_batch(B, N, T, V, U, rng)
+        w0 = {k: v.copy() for k, v in orc.p.items()}
+        probs, cache = orc.forward(data, True, M.DropCtx(seed=11, step=step, training=True))
+        raw, _ = orc.backward(probs, cache, tgt)
+        res, grads, _ = orc.train_step(data, tgt, opt, M.DropCtx(seed=11, step=step, training=True))
+        got = model.train_step((data, tgt)).as_floats()
+        assert abs(got["loss"] - res["loss"]) <= 1e-4 * abs(res["loss"])
+        changed = 0
+        for k in orc.TRAINABLE:
+            g = model.get_gradient(k) + 2 * lam.get(k, 0.0) * w0[k]
+            assert np.abs(g - grads[k]).max() <= 2e-4 * np.abs(grads[k]).max() + 1e-9, (step, k)
+            changed += int(np.abs(raw[k] - grads[k]).max() > 1e-12)
+        assert changed > 0
+        for k, v in orc.p.items():
+            w = model.get_weight(k)
+            assert np.abs(w - v).max() <= 2e-2 * 1e-3 + 1e-4 * np.abs(v).max() + 1e-3 * (step + 1) * float((np.abs(grads.get(k, np.ones(1))) < 1e-8).any()), (step, k)
+
+
+@pytest.mark.parametrize("dims", DIMS)
 def test_forward_gradients_greedy(dims):
     from masters_thesis_amd.optimizers import Adam
     rng = np.random.default_rng(32)

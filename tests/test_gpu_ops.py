@@ -111,6 +111,35 @@ def test_gemm_one_round(be, M, N, K, pad, forced):
     assert (C3[:, :N] - C4[:, :N]).abs().max().item() <= 2e-5 * max(1.0, float(np.abs(pre).max()))
 
 
+@pytest.mark.parametrize("M,N,K,tA,tB,batch,cs,cfg", [
+    (1024, 2048, 512, 0, 0, 1, 0, 0), (512, 2048, 1024, 1, 0, 2, 1, 0), (512, 5001, 960, 1, 0, 1, 1, 26),
+    (960, 512, 256, 0, 1, 1, 0, 21), (37, 70, 50, 1, 0, 2, 1, 21), (130, 33, 77, 0, 0, 1, 0, 25), (65, 161, 40, 0, 1, 1, 0, 26),
+    (100, 200, 96, 1, 0, 1, 1, 24), (960, 5001, 512, 0, 0, 1, 0, 28), (161, 129, 33, 0, 0, 1, 0, 1), (70, 70, 70, 1, 0, 1, 1, 9)])
+def test_gemm_fused(be, M, N, K, tA, tB, batch, cs, cfg):
+    """tnt_gemm_fused_f32 (one-round family: gemm1r / gemm2) on every layout, with ragged edges, the fused column sums
+    of B (bias gradient) and the second product sharing B, against float64 numpy; padding columns hold garbage."""
+    rng = np.random.default_rng(M + N + K)
+    r4 = lambda n: (n + 3) // 4 * 4
+    lda, ldb, ldc = r4(M if tA else K), r4(K if tB else N), r4(N) + 4
+    A = rng.standard_normal(((K if tA else M), lda)); A2 = rng.standard_normal(A.shape)
+    Bm = rng.standard_normal(((N if tB else K), ldb))
+    opA = (A[:, :M].T if tA else A[:, :K]); opA2 = (A2[:, :M].T if tA else A2[:, :K])
+    opB = (Bm[:, :K].T if tB else Bm[:, :N])
+    bias = rng.standard_normal(N) if not cs else None
+    C, C2 = torch.full((M, ldc), 5.0, device="cuda"), torch.full((M, ldc), 5.0, device="cuda")
+    col = torch.full((ldc,), 5.0, device="cuda")
+    be.gemm_fused(dev(A), dev(Bm), C, M, N, K, lda, ldb, ldc, transA=bool(tA), transB=bool(tB),
+                  bias=dev(bias) if bias is not None else None, colsum=col if cs else None,
+                  A2=dev(A2) if batch == 2 else None, C2=C2 if batch == 2 else None, cfg=cfg)
+    close(C[:, :N], opA @ opB + (bias if bias is not None else 0))
+    assert torch.equal(C[:, N:], torch.full((M, ldc - N), 5.0, device="cuda")), "padding columns written"
+    if batch == 2:
+        close(C2[:, :N], opA2 @ opB)
+    if cs:
+        close(col[:N], opB.sum(0), atol=1e-4 * np.abs(opB).sum(0).max())
+        assert torch.equal(col[N:], torch.full((ldc - N,), 5.0, device="cuda"))
+
+
 def test_gemm_splitk(be):
     rng = np.random.default_rng(0)
     M, N, K = 64, 512, 20000

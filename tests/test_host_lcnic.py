@@ -138,3 +138,22 @@ def test_compact_groups_is_the_same_function_on_fewer_columns():
     p1, a1 = m1(data, training=False)
     p2, a2 = m2((data[0][:, used],) + tuple(data[1:]), training=False)
     assert np.array_equal(p1.numpy(), p2.numpy()) and np.array_equal(a1.numpy(), a2.numpy())
+
+
+def test_adaptive_gradient_clipping_matches_oracle():
+    """lc_NIC with gradients = agc.adaptive_clip_grad(...) switched on (lc_NIC.py:388, agc.py:20-38)."""
+    rng = np.random.default_rng(59)
+    model, orc, d = make_pair(rng, (0.1, 0.2, 0.2, 0.2, 0.2, 0.2))
+    model.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    model.enable_agc(0.02, 1e-3)
+    orc.agc = (0.02, 1e-3)
+    opt = M.AdamState(orc.p, lr=1e-3, clipnorm=0.1)
+    for step in range(3):
+        data, tgt = synth_batch(d["B"], d["N"], d["T"], d["V"], d["U"], rng)
+        res, grads, _ = orc.train_step(data, tgt, opt, M.DropCtx(seed=11, step=step, training=True))
+        got = model.train_step((data, tgt)).as_floats()
+        assert abs(got["loss"] - res["loss"]) < 2e-5 * max(1, abs(res["loss"]))
+        for k, v in orc.p.items():
+            if k == "attention/V/bias":
+                continue
+            assert np.allclose(model.get_weight(k), v, rtol=2e-4, atol=2e-6), (step, k, np.abs(model.get_weight(k) - v).max())

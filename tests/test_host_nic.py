@@ -170,3 +170,30 @@ def test_half_precision_betas_on_the_wire():
     assert r1 == r2
     for k in m1.keras_shapes:
         assert np.array_equal(m1.get_weight(k), m2.get_weight(k)), k
+
+
+def test_adaptive_gradient_clipping_matches_oracle():
+    """model.enable_agc == agc.adaptive_clip_grad before apply_gradients (agc.py:20-38, call site lc_NIC.py:388):
+    unit-wise norms per output column, the Embedding through its un-deduplicated IndexedSlices rows."""
+    rng = np.random.default_rng(29)
+    B, N, T, V, U = 5, 23, 6, 13, 16
+    model, orc = make_pair(rng, (0, 0.2, 0.2))
+    model.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    model.enable_agc(0.02, 1e-3)
+    orc.agc = (0.02, 1e-3)
+    opt = M.AdamState(orc.p, lr=1e-3, clipnorm=0.1)
+    lam = {"dense_img/kernel": 0.01, "lstm/kernel": 3e-5, "time_distributed_softmax/kernel": 3e-5}
+    for step in range(3):
+        data, tgt = synth_batch(B, N, T, V, U, rng)
+        w0 = {k: v.copy() for k, v in orc.p.items()}
+        raw, _ = orc.backward(*(lambda pc: (pc[0], pc[1], tgt))(orc.forward(data, True, M.DropCtx(seed=11, step=step, training=True))))
+        res, grads, _ = orc.train_step(data, tgt, opt, M.DropCtx(seed=11, step=step, training=True))
+        model.train_step((data, tgt)).as_floats()
+        changed = 0
+        for k in orc.TRAINABLE:
+            g = model.get_gradient(k) + 2 * lam.get(k, 0.0) * w0[k]
+            assert np.allclose(g, grads[k], rtol=2e-4, atol=1e-5 * np.abs(grads[k]).max() + 1e-9), (step, k)
+            changed += int(not np.allclose(raw[k], grads[k], rtol=1e-9, atol=0))
+        assert 0 < changed, "the clip never triggered: the test exercises nothing"
+        for k, v in orc.p.items():
+            assert np.allclose(model.get_weight(k), v, rtol=2e-4, atol=2e-6), (step, k)
