@@ -299,6 +299,14 @@ int32_t tnt_softmax_cce_f32(const float* logits, const int32_t* target, float* p
 int32_t tnt_onehot_argmax_f32(const float* onehot, int32_t* ids_tmajor, int32_t B, int32_t T,
                               int32_t V, void* stream);
 /* row argmax (first max wins), out int32[rows]. */
+/* Beam-search expansion (beam search is only sketched in the reference: lc_NIC.py:640-692,
+ * ThinkAndTell/evaluate.py:203-228).  Rows b*k .. b*k+k-1 of probs [B*k][ld] are the k beams of sample b; candidate
+ * (beam j, token v) scores score_in[j] + log(max(p, 1e-30)); a finished beam (fin_in != 0: it has emitted end_id)
+ * only continues with token 0 at its own score.  The k best become the new beams (ties: lower j*V + v):
+ * score_out, parent (global row of the extended beam), token, fin_out -- all [B*k].  k <= 16. */
+int32_t tnt_beam_topk_f32(const float* probs, const float* score_in, const int32_t* fin_in, int32_t B,
+                          int32_t V, int32_t ld, int32_t k, int32_t end_id, float* score_out,
+                          int32_t* parent, int32_t* token, int32_t* fin_out, void* stream);
 int32_t tnt_argmax_rows_f32(const float* x, int32_t* out, int32_t rows, int32_t V, int32_t ld,
                             void* stream);
 /* out[0] = scale * sum_i x[i]  (fixed-order, one workgroup). */
@@ -393,6 +401,12 @@ int32_t tnt_step_tick(int64_t* adam_t, uint32_t* drop_step, const float* lr, flo
  * Any B (processed in row blocks of 64, in order), D % 16 == 0, D <= 64.
  * fwd: pre/y[b][r][:] = LeakyReLU(x[b][idx_r] @ W_r + b_r)    (y,pre: [B][R][D])
  * bwd: dW_r = x[:,idx_r]^T @ dpre[:,r,:]; db_r = sum_b dpre[b][r][:]. */
+/* Input gradient of a stack of per-region Dense layers -- the deeper stages of deep_layers.LocallyDense
+ * (AttemptFour/Model/deep_layers.py:53-59), whose forward and weight gradients are tnt_locally_dense_*_f32 on the
+ * identity groups {r*D .. (r+1)*D-1}:  dx[b][r][k] = sum_n dpre[b][r][n] * W[r][k][n];  dpre [B][R][Dout],
+ * W [R][Din][Dout], dx [B][R][Din]; Din, Dout <= 64. */
+int32_t tnt_block_dense_dx_f32(const float* dpre, const float* W, float* dx, int32_t B, int32_t R,
+                               int32_t Din, int32_t Dout, void* stream);
 int32_t tnt_locally_dense_fwd_f32(const float* x, int32_t ldx, const int32_t* idx,
                                   const int32_t* goff, const float* W, const float* bias,
                                   float* pre, float* y, int32_t B, int32_t R, int32_t D,

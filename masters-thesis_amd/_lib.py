@@ -42,6 +42,7 @@ SIGNATURES = {
     "tnt_lstm_step_bwd_f32": [P, P, P, P, P, P, P, P, I32, I32, P, P, P, P, P, P, P, I32, I32, P, I32, P, P],
     "tnt_softmax_cce_f32": [P, P, P, P, P, P, I32, I32, I32, F32, I32, I32, P],
     "tnt_onehot_argmax_f32": [P, P, I32, I32, I32, P],
+    "tnt_beam_topk_f32": [P, P, P, I32, I32, I32, I32, I32, P, P, P, P, P],
     "tnt_argmax_rows_f32": [P, P, I32, I32, I32, P],
     "tnt_enc_tail_fwd_f32": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, F32, F32, F32, F32, U64, U32, U32, P, P],
     "tnt_enc_tail_bwd_f32": [P, P, P, P, P, P, P, P, P, I32, I32, I32, F32, F32, F32, U64, U32, U32, P, P],
@@ -66,6 +67,7 @@ SIGNATURES = {
     "tnt_step_tick": [P, P, P, P, F32, F32, P, P],
     "tnt_sam_f32": [P, P, P, P, P, P, P, P, I32, I32, F32, I32, P],
     "tnt_gemm_f32_tile": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, F32, I32, I32, P, I32, I32, P],
+    "tnt_block_dense_dx_f32": [P, P, P, I32, I32, I32, I32, P],
     "tnt_locally_dense_fwd_f32": [P, I32, P, P, P, P, P, P, I32, I32, I32, F32, P],
     "tnt_locally_dense_bwd_f32": [P, I32, P, P, P, P, P, I32, I32, I32, P],
     "tnt_attention_step_fwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, F32,

@@ -402,6 +402,31 @@ __global__ __launch_bounds__(512) void dense_dw_skinny_kernel(DwArgs a) {
   if (sprev >= 0) store_strip(outp, sprev);
 }
 
+
+// ---- input gradient of a stack of per-region Dense layers (the deeper stages of deep_layers.LocallyDense,
+// AttemptFour/Model/deep_layers.py:53-59: layer_r(x[:, r, :]) for every region r):
+//   dx[b][r][k] = sum_n dpre[b][r][n] * W_r[k][n],   W = [R][Din][Dout] (keras (in, out) kernels, concatenated)
+// One workgroup per region: W_r (<= 64 x 64) sits in LDS (odd row stride: the Din rows of a column group fall on
+// different banks), every thread owns output elements (b, k) strided over the batch.
+__global__ __launch_bounds__(256) void block_dense_dx_kernel(const float* dpre, const float* W, float* dx, int B, int R,
+                                                             int Din, int Dout) {
+  __shared__ float Ws[64 * 65];
+  __shared__ float ds[4][64];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  for (int e = tid; e < Din * Dout; e += 256) Ws[(e / Dout) * 65 + (e % Dout)] = W[(long)r * Din * Dout + e];
+  const int k = tid & 63, bl = tid >> 6;
+  for (int b0 = 0; b0 < B; b0 += 4) {
+    const int b = b0 + bl;
+    __syncthreads();
+    if (b < B && k < Dout) ds[bl][k] = dpre[((long)b * R + r) * Dout + k];
+    __syncthreads();
+    if (b < B && k < Din) {
+      float acc = 0.f;
+      for (int n = 0; n < Dout; ++n) acc += ds[bl][n] * Ws[k * 65 + n];
+      dx[((long)b * R + r) * Din + k] = acc;
+    }
+  }
+}
 }  // namespace
 
 extern "C" int32_t tnt_dense_dw_skinny_f32(const float* x, const float* dpre, float* dw, int32_t N, int32_t E,
@@ -418,6 +443,14 @@ extern "C" int32_t tnt_dense_dw_skinny_f32(const float* x, const float* dpre, fl
   if (tpw == 1) hipLaunchKernelGGL(dense_dw_skinny_kernel<1>, g, dim3(512), 0, tnt_stream(stream), a);
   else if (tpw == 2) hipLaunchKernelGGL(dense_dw_skinny_kernel<2>, g, dim3(512), 0, tnt_stream(stream), a);
   else hipLaunchKernelGGL(dense_dw_skinny_kernel<4>, g, dim3(512), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_block_dense_dx_f32(const float* dpre, const float* W, float* dx, int32_t B, int32_t R,
+                                          int32_t Din, int32_t Dout, void* stream) {
+  if (B <= 0 || R <= 0 || Din <= 0 || Dout <= 0 || Din > 64 || Dout > 64) return TNT_BADARG(5);
+  hipLaunchKernelGGL(block_dense_dx_kernel, dim3(R), dim3(256), 0, tnt_stream(stream), dpre, W, dx, B, R, Din, Dout);
   TNT_LAUNCH_CHECK();
   return 0;
 }

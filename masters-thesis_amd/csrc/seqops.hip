@@ -369,6 +369,50 @@ __global__ __launch_bounds__(256) void onehot_argmax_kernel(const float* onehot,
   if (threadIdx.x == 0) ids[t * B + b] = am.i == 0x7fffffff ? 0 : am.i;
 }
 
+
+// Beam-search expansion, one workgroup per sample (the reference only sketches beam search: lc_NIC.py:640-692,
+// ThinkAndTell/evaluate.py:203-228; the definition below is this library's, restated by oracle LcNIC.beam_search):
+// the k beams of a sample are rows b*k .. b*k+k-1 of probs; candidate (j, v) scores  score[j] + log(max(p[j][v], 1e-30));
+// a finished beam (it has emitted end_id) has ONE candidate: token 0 (padding) at its own score.  The k best
+// candidates become the new beams, ties -> the lower flat index j*V + v (the first-maximum rule of np.argmax).
+// out: score_out[b*k + r], parent[b*k + r] = global row of the beam it extends, token[b*k + r], fin_out.
+__global__ __launch_bounds__(256) void beam_topk_kernel(const float* probs, const float* score_in, const int* fin_in,
+                                                        int V, int ld, int k, int end_id, float* score_out,
+                                                        int* parent, int* token, int* fin_out) {
+  __shared__ ArgMax sha[4];
+  __shared__ int taken[16];
+  __shared__ float sc[16];
+  __shared__ int fn[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < k) { sc[tid] = score_in[b * k + tid]; fn[tid] = fin_in[b * k + tid]; }
+  __syncthreads();
+  const int ncand = k * V;
+  for (int r = 0; r < k; ++r) {
+    ArgMax am; am.v = -INFINITY; am.i = 0x7fffffff;
+    for (int cnd = tid; cnd < ncand; cnd += 256) {
+      const int j = cnd / V, v = cnd - j * V;
+      bool skip = false;
+      for (int q = 0; q < r; ++q) skip |= taken[q] == cnd;
+      if (skip) continue;
+      float val;
+      if (fn[j]) val = v == 0 ? sc[j] : -INFINITY;
+      else val = sc[j] + logf(fmaxf(probs[(long)(b * k + j) * ld + v], 1e-30f));
+      if (val > am.v) { am.v = val; am.i = cnd; }
+    }
+    am = block_argmax(am, sha);
+    if (tid == 0) {
+      const int cnd = am.i == 0x7fffffff ? 0 : am.i;
+      const int j = cnd / V, v = cnd - j * V;
+      taken[r] = cnd;
+      score_out[b * k + r] = am.v;
+      parent[b * k + r] = b * k + j;
+      token[b * k + r] = v;
+      fin_out[b * k + r] = (fn[j] || v == end_id) ? 1 : 0;
+    }
+    __syncthreads();
+  }
+}
+
 // Categorical sampling, one workgroup per row (tf.random.categorical(logits / temperature, 1),
 // ThinkAndTell/evaluate.py:223,278; lc_NIC.sample_choice, lc_NIC.py:571-575).  Inverse CDF in a fixed
 // order with one Philox uniform per row, so the CPU oracle can restate it:
@@ -515,6 +559,17 @@ extern "C" int32_t tnt_onehot_argmax_f32(const float* onehot, int32_t* ids_tmajo
 
 extern "C" int32_t tnt_argmax_rows_f32(const float* x, int32_t* out, int32_t rows, int32_t V, int32_t ld, void* stream) {
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, tnt_stream(stream), x, out, rows, V, ld);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_beam_topk_f32(const float* probs, const float* score_in, const int32_t* fin_in, int32_t B,
+                                     int32_t V, int32_t ld, int32_t k, int32_t end_id, float* score_out,
+                                     int32_t* parent, int32_t* token, int32_t* fin_out, void* stream) {
+  if (B <= 0 || V <= 0 || k <= 0 || k > 16) return TNT_BADARG(7);
+  if (score_out == score_in || fin_out == fin_in) return TNT_BADARG(9);
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(B), dim3(256), 0, tnt_stream(stream), probs, score_in, fin_in, V, ld, k,
+                     end_id, score_out, parent, token, fin_out);
   TNT_LAUNCH_CHECK();
   return 0;
 }

@@ -27,6 +27,7 @@ from .model_base import (ModelBase, Metrics, interleave_gates, deinterleave_gate
 
 SUBJ_SITE = 1000      # dropout-site offset per subject (multi-subject model)
 S_FEAT2 = 4           # second application of the feature dropout (ms2_NIC.py:214)
+S_DEEP = 6            # + i: feature dropout behind deep stage i of the depth-n encoder (deep_layers.py:58)
 from .ops import ACT_LEAKY
 
 
@@ -71,8 +72,15 @@ class NIC(ModelBase):
 
     def __init__(self, groups, units, embedding_features, embedding_text, attn_units, vocab_size, max_length,
                  dropout_input, dropout_features, dropout_text, dropout_attn, dropout_lstm, dropout_out, input_reg,
-                 attn_reg, lstm_reg, output_reg, norm="batch", n_subjects=1, **kw):
+                 attn_reg, lstm_reg, output_reg, norm="batch", n_subjects=1, depth=0, **kw):
         super().__init__(**kw)
+        # depth > 0: deep_layers.LocallyDense(groups, dropout, depth=n) (AttemptFour/Model/deep_layers.py:15-75) in place
+        # of layers.LocallyDense -- n more stages of {per-region Dense(D -> D), BatchNorm, Dropout} behind the first one
+        self.depth = int(depth)
+        if self.depth and int(n_subjects) != 1:
+            raise ValueError("the depth-n encoder is a single-subject variant")
+        if not 0 <= self.depth < 10:
+            raise ValueError("encoder depth must be in 0..9")
         # n_subjects > 1: AttemptFour/Model/ms2_NIC.py generalised to S subjects -- one region-wise
         # encoder (+ its own BatchNorm) per subject on S equal batch slices, shared decoder.
         self.S = int(n_subjects)
@@ -126,6 +134,13 @@ class NIC(ModelBase):
             ls[bn] = ["gamma", "beta", "moving_mean", "moving_variance"]
             for w in ls[bn]:
                 ks[f"{bn}/{w}"] = (D,)
+        for i in range(self.depth):
+            for r in range(self.R):
+                ls[f"dense_in/deep{i}/{r}"] = ["kernel", "bias"]
+                ks[f"dense_in/deep{i}/{r}/kernel"], ks[f"dense_in/deep{i}/{r}/bias"] = (D, D), (D,)
+            ls[f"input_bn/deep{i}"] = ["gamma", "beta", "moving_mean", "moving_variance"]
+            for w in ls[f"input_bn/deep{i}"]:
+                ks[f"input_bn/deep{i}/{w}"] = (D,)
         for nm, shp in (("attention/W1", (D, A)), ("attention/W2", (U, A)), ("attention/V", (A, 1))):
             ls[nm] = ["kernel", "bias"]
             ks[f"{nm}/kernel"] = shp
@@ -153,6 +168,17 @@ class NIC(ModelBase):
             enc_off.append((w_off, a.entries[f"{en}/0/bias"].off))
             a.total = (a.total + 63) // 64 * 64
             a.add(f"{bn}/gamma", (D,)); a.add(f"{bn}/beta", (D,))
+        deep_off = []
+        for i in range(self.depth):
+            for r in range(R):
+                a.add(f"dense_in/deep{i}/{r}/kernel", (D, D), self.l2_in, align=4)
+            w_off = a.entries[f"dense_in/deep{i}/0/kernel"].off
+            a.total = (a.total + 63) // 64 * 64
+            for r in range(R):
+                a.add(f"dense_in/deep{i}/{r}/bias", (D,), align=4)
+            deep_off.append((w_off, a.entries[f"dense_in/deep{i}/0/bias"].off))
+            a.total = (a.total + 63) // 64 * 64
+            a.add(f"input_bn/deep{i}/gamma", (D,)); a.add(f"input_bn/deep{i}/beta", (D,))
         a.add("attention/W1/kernel", (D, A), self.l2_attn); a.add("attention/W1/bias", (A,))
         a.add("attention/W2/kernel", (U, A), self.l2_attn); a.add("attention/W2/bias", (A,))
         a.add("attention/V/kernel", (A,)); a.add("attention/V/bias", (1,))
@@ -168,8 +194,15 @@ class NIC(ModelBase):
         self.encWg = [a.grad[w:w + nW] for w, _ in enc_off]
         self.encB = [a.theta[b:b + R * D] for _, b in enc_off]
         self.encBg = [a.grad[b:b + R * D] for _, b in enc_off]
-        self.mov_mean = [self._f(D) for _ in range(self.S)]
-        self.mov_var = [torch.ones(D, dtype=torch.float32, device=self.device) for _ in range(self.S)]
+        self.deepW = [a.theta[w:w + R * D * D] for w, _ in deep_off]
+        self.deepWg = [a.grad[w:w + R * D * D] for w, _ in deep_off]
+        self.deepB = [a.theta[b:b + R * D] for _, b in deep_off]
+        self.deepBg = [a.grad[b:b + R * D] for _, b in deep_off]
+        self.deep_idx = torch.arange(R * D, dtype=torch.int32, device=self.device)
+        self.deep_goff = torch.arange(0, (R + 1) * D, D, dtype=torch.int32, device=self.device)
+        # moving statistics: one pair per subject encoder, then one pair per deep stage
+        self.mov_mean = [self._f(D) for _ in range(self.S + self.depth)]
+        self.mov_var = [torch.ones(D, dtype=torch.float32, device=self.device) for _ in range(self.S + self.depth)]
         self.drop_step = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._init_weights(np.random.default_rng(self.seed))
         self._shape = None
@@ -183,6 +216,10 @@ class NIC(ModelBase):
             for r, g in enumerate(self.groups):
                 self.set_weight(f"{self.enc_name(q)}/{r}/kernel", tn((len(g), D), np.sqrt(2.0 / max(len(g), 1))))  # he_normal
             self.set_weight(f"{self.bn_name(q)}/gamma", np.ones(D))
+        for i in range(self.depth):
+            for r in range(self.R):
+                self.set_weight(f"dense_in/deep{i}/{r}/kernel", tn((D, D), np.sqrt(2.0 / D)))
+            self.set_weight(f"input_bn/deep{i}/gamma", np.ones(D))
         self.set_weight("attention/W1/kernel", tn((D, A), np.sqrt(2.0 / D)))
         self.set_weight("attention/W2/kernel", tn((U, A), np.sqrt(2.0 / U)))
         lim = np.sqrt(6.0 / (A + 1))
@@ -200,10 +237,10 @@ class NIC(ModelBase):
     def set_weight(self, name, arr):
         arr = np.asarray(arr, dtype=np.float32)
         assert tuple(arr.shape) == tuple(self.keras_shapes[name]), (name, arr.shape, self.keras_shapes[name])
-        for q in range(self.S):
-            if name == f"{self.bn_name(q)}/moving_mean":
+        for q, bn in self._bn_slots():
+            if name == f"{bn}/moving_mean":
                 self.mov_mean[q].copy_(torch.from_numpy(arr)); return
-            if name == f"{self.bn_name(q)}/moving_variance":
+            if name == f"{bn}/moving_variance":
                 self.mov_var[q].copy_(torch.from_numpy(arr)); return
         dst = self.arena.p(name)
         if name.startswith("lstm/"):
@@ -224,11 +261,15 @@ class NIC(ModelBase):
             return np.ascontiguousarray(arr[:self.V])
         return arr.reshape(self.keras_shapes[name]).copy()
 
+    def _bn_slots(self):
+        """(slot of mov_mean / mov_var, keras layer name) of every BatchNormalization of the encoder"""
+        return [(q, self.bn_name(q)) for q in range(self.S)] + [(self.S + i, f"input_bn/deep{i}") for i in range(self.depth)]
+
     def get_weight(self, name):
-        for q in range(self.S):
-            if name == f"{self.bn_name(q)}/moving_mean":
+        for q, bn in self._bn_slots():
+            if name == f"{bn}/moving_mean":
                 return self.mov_mean[q].cpu().numpy().copy()
-            if name == f"{self.bn_name(q)}/moving_variance":
+            if name == f"{bn}/moving_variance":
                 return self.mov_var[q].cpu().numpy().copy()
         return self._unpack(name, self.arena.p(name))
 
@@ -265,7 +306,14 @@ class NIC(ModelBase):
         # dropout, whose mask is defined on the batch-major tensor
         self.xT = f(self.n_in, (B + 3) // 4 * 4) if (self.r_in == 0 and self.ldx == self.n_in) else None
         self.xhat, self.inv_std = f(B * R, D), f(self.S, max(B * R, D))
-        self.F = f(B, R, D)
+        # depth-n encoder: stage i reads Fs[i] and writes Fs[i + 1]; the attention reads the last one
+        self.Fs = [f(B, R, D) for _ in range(self.depth + 1)]
+        self.F = self.Fs[-1]
+        self.deep_pre = [f(B, R, D) for _ in range(self.depth)]
+        self.deep_y = [f(B, R, D) for _ in range(self.depth)]
+        self.deep_xhat = [f(B * R, D) for _ in range(self.depth)]
+        self.deep_istd = [f(max(B * R, D)) for _ in range(self.depth)]
+        self.dFd = f(B, R, D) if self.depth else None
         self.text = f(n, Et)
         self.XZ = f(n, U, 4)
         self.P, self.Ppre = f(B * R, A), f(B * R, A)
@@ -350,7 +398,7 @@ class NIC(ModelBase):
                 be.locally_dense_fwd(x, self.ldx, self.idx, self.goff, self.encW[q], self.encB[q],
                                      self.enc_pre[r0:r1], self.enc_y[r0:r1], Bs, R, D, 0.2)
             bn = self.bn_name(q)
-            Fq, xh = self.F[r0:r1], self.xhat[r0 * R:r1 * R]
+            Fq, xh = self.Fs[0][r0:r1], self.xhat[r0 * R:r1 * R]
             if self.norm == "batch":
                 be.batchnorm_fwd(self.enc_y[r0:r1], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), self.mov_mean[q],
                                  self.mov_var[q], Fq, xh, self.inv_std[q], Bs * R, D, D, training, BN_EPS, BN_MOMENTUM,
@@ -362,6 +410,19 @@ class NIC(ModelBase):
                 be.dropout(Fq, Fq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT + off, 0, ds)        # layers.py:51
                 if S > 1:                        # ms2_NIC.py:214,257: the feature Dropout is applied a second time
                     be.dropout(Fq, Fq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT2 + off, 0, ds)
+        for i in range(self.depth):              # deep_layers.one_layer (deep_layers.py:53-59): Dense_r(x[:, r, :]), BN, Dropout
+            xin, out = self.Fs[i], self.Fs[i + 1]
+            be.locally_dense_fwd(xin, R * D, self.deep_idx, self.deep_goff, self.deepW[i], self.deepB[i], self.deep_pre[i],
+                                 self.deep_y[i], B, R, D, 0.2)
+            bn, q = f"input_bn/deep{i}", self.S + i
+            if self.norm == "batch":
+                be.batchnorm_fwd(self.deep_y[i], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), self.mov_mean[q], self.mov_var[q], out,
+                                 self.deep_xhat[i], self.deep_istd[i], B * R, D, D, training, BN_EPS, BN_MOMENTUM, self.work)
+            else:
+                be.layernorm_fwd(self.deep_y[i], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), out, self.deep_xhat[i],
+                                 self.deep_istd[i], B * R, D, D, BN_EPS)
+            if training and self.r_feat > 0:
+                be.dropout(out, out, B * R, D, D, 0, D, 0, self.r_feat, sd, S_DEEP + i, 0, ds)
         self.gemm_sk(self.F, a.p("attention/W1/kernel"), self.P, B * R, self.A, D, D, self.A, self.A,
                 bias=a.p("attention/W1/bias"), pre=self.Ppre, act=ACT_LEAKY, slope=0.2)      # attention.py:32 (hoisted)
 
@@ -541,10 +602,26 @@ class NIC(ModelBase):
         # encoder
         S = self.S
         Bs = B // S
+        dF_enc = self.dF
+        for i in range(self.depth - 1, -1, -1):          # the deep stages, last first; dF_enc: gradient wrt Fs[i + 1]
+            bn = f"input_bn/deep{i}"
+            if self.r_feat > 0:
+                be.dropout(dF_enc, dF_enc, B * R, D, D, 0, D, 0, self.r_feat, sd, S_DEEP + i, 0, ds)
+            if self.norm == "batch":
+                be.batchnorm_bwd(dF_enc, self.deep_xhat[i], a.p(f"{bn}/gamma"), self.deep_istd[i], self.dbn,
+                                 a.g(f"{bn}/gamma"), a.g(f"{bn}/beta"), B * R, D, D, True, self.work)
+            else:
+                be.layernorm_bwd(dF_enc, self.deep_xhat[i], a.p(f"{bn}/gamma"), self.deep_istd[i], self.dbn,
+                                 a.g(f"{bn}/gamma"), a.g(f"{bn}/beta"), B * R, D, D, self.work)
+            be.act_bwd(self.deep_pre[i], self.dbn, self.dbn, B * R * D, ACT_LEAKY, 0.2)
+            be.locally_dense_bwd(self.Fs[i], R * D, self.deep_idx, self.deep_goff, self.dbn, self.deepWg[i], self.deepBg[i],
+                                 B, R, D)
+            be.block_dense_dx(self.dbn, self.deepW[i], self.dFd, B, R, D, D)
+            dF_enc = self.dFd
         for q in range(S):
             off = SUBJ_SITE * (q + 1) if S > 1 else 0
             r0, r1 = q * Bs, (q + 1) * Bs
-            dFq, xh, dbn = self.dF[r0:r1], self.xhat[r0 * R:r1 * R], self.dbn[r0 * R:r1 * R]
+            dFq, xh, dbn = dF_enc[r0:r1], self.xhat[r0 * R:r1 * R], self.dbn[r0 * R:r1 * R]
             if self.r_feat > 0:
                 if S > 1:
                     be.dropout(dFq, dFq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT2 + off, 0, ds)
@@ -697,3 +774,62 @@ class NIC(ModelBase):
         return out_words, out_probs, self.alpha[:max_len].cpu().numpy()[..., None], (s_all.cpu().numpy() if return_s else None)
 
     greedy_predict_attention = greedy_predict
+
+    def beam_search(self, img_input, a0, c0, start_seq, max_len, beam_width=5, end_id=-1, units=None, tokenizer=None):
+        """Beam search over the attention decoder.  The reference only sketches it (lc_NIC.beam_search / _beam_search,
+        lc_NIC.py:640-692, recurse without returning; ThinkAndTell/evaluate.py:203-228 stops after one expansion), so
+        the definition is this library's: standard log-probability beam search of width ``beam_width`` with the greedy
+        decoder's step (lc_NIC.py:596-632), no length normalisation; a beam that emits ``end_id`` (the tokenizer's
+        '<end>' index; -1 = never) is finished and pads with 0.  Returns (sequences (B, k, max_len) int64, best first;
+        scores (B, k) float32 = sum of log-probabilities).  The whole search runs on the device: per token one
+        expansion launch (tnt_beam_topk_f32) and row gathers of the LSTM state by parent beam; the paths are
+        back-tracked on the host at the end.  Restated by oracle.models.LcNIC.beam_search."""
+        be, a = self.be, self.arena
+        k = int(beam_width)
+        start = np.asarray(start_seq).reshape(-1)
+        B = start.shape[0]
+        Bk = B * k
+        rep = lambda t: np.repeat(np.asarray(t), k, axis=0)
+        x = img_input.cpu().numpy() if isinstance(img_input, torch.Tensor) else np.asarray(img_input)
+        self._stage_inputs((rep(x), torch.zeros(Bk, max_len, dtype=torch.int32), rep(np.asarray(a0)), rep(np.asarray(c0))))
+        R, D, A, U, Et, V, H, ldV = self.R, self.D, self.A, self.U, self.Et, self.V, self.H, self.ldV
+        Wl = a.p("lstm/kernel")
+        dev, i32 = self.device, torch.int32
+        words0 = torch.as_tensor(rep(start).astype(np.int32)).to(dev).view(Bk, 1)
+        score = [torch.zeros(Bk, device=dev), torch.zeros(Bk, device=dev)]
+        score[0].view(B, k)[:, 1:] = -1e30            # step 0: the k beams of a sample are copies, only beam 0 counts
+        fin = [torch.zeros(Bk, dtype=i32, device=dev), torch.zeros(Bk, dtype=i32, device=dev)]
+        parents = torch.zeros(max_len, Bk, dtype=i32, device=dev)
+        tokens = torch.zeros(max_len, Bk, dtype=i32, device=dev)
+        probs = self.logits[:Bk]
+        hg, cg = self._f(Bk, U), self._f(Bk, U)
+        self._encode(Bk, False)
+        words = words0
+        for i in range(max_len):
+            text = self.text[i * Bk:(i + 1) * Bk]
+            be.embedding_fwd(a.p("emb_text/embeddings"), words, text, Bk, 1, Et, Et, V)
+            self.gemm_sk(text, Wl[D:], self.XZ[i * Bk:(i + 1) * Bk], Bk, 4 * U, Et, Et, 4 * U, 4 * U, bias=a.p("lstm/bias"))
+            self._decode_step(i, Bk, False, None)
+            self.gemm_sk(self.Hs[i + 1], a.p("time_distributed_nonlinear/kernel"), self.inter[:Bk], Bk, H, U, U, H, H,
+                         bias=a.p("time_distributed_nonlinear/bias"), act=ACT_LEAKY, slope=0.2)
+            self.gemm_sk(self.inter[:Bk], a.p("time_distributed_softmax/kernel"), probs, Bk, V, H, H, ldV, ldV,
+                         bias=a.p("time_distributed_softmax/bias"))
+            be.softmax_cce(probs, None, probs, None, None, None, Bk, V, ldV, 0.0)
+            cur, nxt = i & 1, (i & 1) ^ 1
+            be.beam_topk(probs, score[cur], fin[cur], B, V, ldV, k, int(end_id), score[nxt], parents[i], tokens[i], fin[nxt])
+            # the surviving beams continue from their parents' LSTM state (row gather by parent)
+            be.embedding_fwd(self.Hs[i + 1], parents[i].view(Bk, 1), hg, Bk, 1, U, U, Bk)
+            be.embedding_fwd(self.Cs[i + 1], parents[i].view(Bk, 1), cg, Bk, 1, U, U, Bk)
+            self.Hs[i + 1].copy_(hg)
+            self.Cs[i + 1].copy_(cg)
+            words = tokens[i].view(Bk, 1)
+        final = score[max_len & 1].cpu().numpy().reshape(B, k)
+        par, tok = parents.cpu().numpy(), tokens.cpu().numpy()
+        seqs = np.zeros((B, k, max_len), np.int64)
+        for b in range(B):
+            for r in range(k):
+                row = b * k + r
+                for i in range(max_len - 1, -1, -1):
+                    seqs[b, r, i] = tok[i, row]
+                    row = par[i, row]
+        return seqs, final

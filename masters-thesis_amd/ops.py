@@ -248,9 +248,16 @@ class HipBackend:
     def colsq(self, x, out, rows, cols, ld):
         self._call(self.lib.tnt_colsq_f32, "tnt_colsq_f32", _p(x), _p(out), rows, cols, ld, self._s())
 
+    def beam_topk(self, probs, score_in, fin_in, B, V, ld, k, end_id, score_out, parent, token, fin_out):
+        self._call(self.lib.tnt_beam_topk_f32, "tnt_beam_topk_f32", _p(probs), _p(score_in), _p(fin_in), B, V, ld, k, end_id,
+                   _p(score_out), _p(parent), _p(token), _p(fin_out), self._s())
+
     def step_tick(self, adam_t, drop_step, lr, lr_t, beta1, beta2, guard=None):
         self._call(self.lib.tnt_step_tick, "tnt_step_tick", _p(adam_t), _p(drop_step), _p(lr), _p(lr_t), beta1, beta2, _p(guard),
                    self._s())
+
+    def block_dense_dx(self, dpre, W, dx, B, R, Din, Dout):
+        self._call(self.lib.tnt_block_dense_dx_f32, "tnt_block_dense_dx_f32", _p(dpre), _p(W), _p(dx), B, R, Din, Dout, self._s())
 
     def locally_dense_fwd(self, x, ldx, idx, goff, W, bias, pre, y, B, R, D, slope=0.2):
         self._call(self.lib.tnt_locally_dense_fwd_f32, "tnt_locally_dense_fwd_f32", _p(x), ldx, _p(idx), _p(goff), _p(W), _p(bias), _p(pre), _p(y),

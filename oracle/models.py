@@ -18,6 +18,7 @@ from .philox import keep_mask
 S_IN, S_FEAT, S_TEXT, S_OUT = 1, 2, 3, 5
 S_ATTN, S_LSTM_IN, S_LSTM_OUT = 16, 48, 80
 S_SAMPLE = 112          # + decode position: the categorical-sampling stream of sample_predict
+S_DEEP = 6              # + layer index (< 10): feature dropout after deep layer i of the depth-n encoder
 
 
 class DropCtx:
@@ -306,7 +307,8 @@ class LcNIC:
 
     def __init__(self, groups, units, embedding_features, embedding_text, attn_units, vocab_size,
                  max_length, dropout_input, dropout_features, dropout_text, dropout_attn,
-                 dropout_lstm, dropout_out, input_reg, attn_reg, lstm_reg, output_reg, norm='batch'):
+                 dropout_lstm, dropout_out, input_reg, attn_reg, lstm_reg, output_reg, norm='batch', depth=0):
+        self.depth = int(depth)       # deep_layers.LocallyDense(depth=n): n more per-region Dense + BN + Dropout stages
         self.groups = [np.asarray(gi, dtype=np.int64) for gi in groups[0]]
         self.D = int(groups[1][0])
         assert all(int(d) == self.D for d in groups[1])
@@ -331,6 +333,14 @@ class LcNIC:
         p['input_bn/beta'] = (0.1 * rng.standard_normal(D)).astype(dtype)
         p['input_bn/moving_mean'] = np.zeros(D, dtype)
         p['input_bn/moving_variance'] = np.ones(D, dtype)
+        for i in range(self.depth):                                                    # deep_layers.py:42-51
+            for r in range(self.R):
+                p[f'dense_in/deep{i}/{r}/kernel'] = (rng.standard_normal((D, D)) * np.sqrt(2.0 / D)).astype(dtype)
+                p[f'dense_in/deep{i}/{r}/bias'] = (0.01 * rng.standard_normal(D)).astype(dtype)
+            p[f'input_bn/deep{i}/gamma'] = (1 + 0.1 * rng.standard_normal(D)).astype(dtype)
+            p[f'input_bn/deep{i}/beta'] = (0.1 * rng.standard_normal(D)).astype(dtype)
+            p[f'input_bn/deep{i}/moving_mean'] = np.zeros(D, dtype)
+            p[f'input_bn/deep{i}/moving_variance'] = np.ones(D, dtype)
         p['attention/W1/kernel'] = (rng.standard_normal((D, A)) * np.sqrt(2.0 / D)).astype(dtype)
         p['attention/W1/bias'] = (0.01 * rng.standard_normal(A)).astype(dtype)
         p['attention/W2/kernel'] = (rng.standard_normal((U, A)) * np.sqrt(2.0 / U)).astype(dtype)
@@ -367,7 +377,25 @@ class LcNIC:
             mm, mv = p['input_bn/moving_mean'], p['input_bn/moving_variance']
         k_feat = drop.mask(bn.shape, self.r_feat, S_FEAT)
         F = O.dropout_fwd(bn, k_feat, self.r_feat)                                  # layers.py:51
-        return F, dict(xd=xd, pre=pre, bn=bn_cache, k_feat=k_feat, new_mm=mm, new_mv=mv)
+        deep = []
+        B, R, D = F.shape
+        for i in range(self.depth):                                                 # deep_layers.one_layer (:53-59)
+            Wd = [p[f'dense_in/deep{i}/{r}/kernel'] for r in range(R)]
+            bd = [p[f'dense_in/deep{i}/{r}/bias'] for r in range(R)]
+            idg = [np.arange(r * D, (r + 1) * D) for r in range(R)]                 # layer(x[:, region, :])
+            xin = F.reshape(B, R * D)
+            y2, pre2 = O.locally_dense_fwd(xin, idg, Wd, bd)
+            if self.norm == 'batch':
+                bn2, c2, mm2, mv2 = O.batchnorm_fwd(y2, p[f'input_bn/deep{i}/gamma'], p[f'input_bn/deep{i}/beta'],
+                                                     p[f'input_bn/deep{i}/moving_mean'],
+                                                     p[f'input_bn/deep{i}/moving_variance'], training)
+            else:
+                bn2, c2 = O.layernorm_fwd(y2, p[f'input_bn/deep{i}/gamma'], p[f'input_bn/deep{i}/beta'])
+                mm2, mv2 = p[f'input_bn/deep{i}/moving_mean'], p[f'input_bn/deep{i}/moving_variance']
+            k2 = drop.mask(bn2.shape, self.r_feat, S_DEEP + i)
+            F = O.dropout_fwd(bn2, k2, self.r_feat)
+            deep.append(dict(xin=xin, idg=idg, pre=pre2, bn=c2, k=k2, new_mm=mm2, new_mv=mv2))
+        return F, dict(xd=xd, pre=pre, bn=bn_cache, k_feat=k_feat, new_mm=mm, new_mv=mv, deep=deep)
 
     # ---- lc_NIC.call_attention (lc_NIC.py:223-263)
     def forward(self, data, training=False, drop=None):
@@ -422,6 +450,7 @@ class LcNIC:
     def l2_loss(self):
         p = self.p
         s = sum(_l2(self.l2_in, p[f'dense_in/{r}/kernel']) for r in range(self.R))
+        s += sum(_l2(self.l2_in, p[f'dense_in/deep{i}/{r}/kernel']) for i in range(self.depth) for r in range(self.R))
         s += _l2(self.l2_attn, p['attention/W1/kernel']) + _l2(self.l2_attn, p['attention/W2/kernel'])
         s += _l2(self.l2_lstm, p['lstm/kernel'])
         s += _l2(self.l2_out, p['time_distributed_nonlinear/kernel'])
@@ -506,6 +535,23 @@ class LcNIC:
 
     def _encode_bwd(self, dF, enc, g, prefix=''):
         p = self.p
+        B, R, D = dF.shape
+        for i in reversed(range(self.depth)):
+            dc = enc['deep'][i]
+            d2 = O.dropout_bwd(dF, dc['k'], self.r_feat)
+            if self.norm == 'batch':
+                dy2, dgam, dbet = O.batchnorm_bwd(d2, p[f'input_bn/deep{i}/gamma'], dc['bn'])
+            else:
+                dy2, dgam, dbet = O.layernorm_bwd(d2, p[f'input_bn/deep{i}/gamma'], dc['bn'])
+            g[f'input_bn/deep{i}/gamma'], g[f'input_bn/deep{i}/beta'] = dgam, dbet
+            dWs, dbs = O.locally_dense_bwd(dc['xin'], dc['idg'], dc['pre'], dy2)
+            dpre = O.act_bwd(dc['pre'], dy2, O.ACT_LEAKY, 0.2)
+            dF = np.empty_like(dF)
+            for r in range(R):
+                W = p[f'dense_in/deep{i}/{r}/kernel']
+                g[f'dense_in/deep{i}/{r}/kernel'] = dWs[r] + 2 * self.l2_in * W
+                g[f'dense_in/deep{i}/{r}/bias'] = dbs[r]
+                dF[:, r, :] = dpre[:, r, :] @ W.T
         dbn = O.dropout_bwd(dF, enc['k_feat'], self.r_feat)
         if self.norm == 'batch':
             dy, dgam, dbet = O.batchnorm_bwd(dbn, p['input_bn/gamma'], enc['bn'])
@@ -529,6 +575,8 @@ class LcNIC:
         opt.apply(self.p, grads, sparse)
         self.p['input_bn/moving_mean'] = cache['enc']['new_mm']
         self.p['input_bn/moving_variance'] = cache['enc']['new_mv']
+        for i, dc in enumerate(cache['enc'].get('deep', [])):
+            self.p[f'input_bn/deep{i}/moving_mean'], self.p[f'input_bn/deep{i}/moving_variance'] = dc['new_mm'], dc['new_mv']
         return {'loss': ce, 'L2': l2, 'accuracy': acc, 'attention': al, 'lr': opt.lr}, grads, (probs, attn)
 
     def test_step(self, data, y_ids):
@@ -565,3 +613,49 @@ class LcNIC:
             ss.append(s)
         return (np.stack(words, axis=1).astype(np.int64), np.stack(raws, axis=1),
                 np.stack(alphas, axis=0), np.stack(ss, axis=0))
+
+    def beam_search(self, x, a0, c0, start_seq, max_len, k=5, end_id=-1):
+        """Log-probability beam search of width k with the greedy decoder's step (lc_NIC.py:596-632).  The reference
+        only sketches beam search (lc_NIC.py:640-692; ThinkAndTell/evaluate.py:203-228); this is the definition the
+        product implements (include/tnt_hip.h: tnt_beam_topk_f32).  Returns (sequences (B,k,max_len), scores (B,k),
+        margin (B,) = the smallest gap between the k-th kept and the best dropped candidate over all steps)."""
+        p = self.p
+        dt = p['lstm/kernel'].dtype
+        B = x.shape[0]
+        F, _ = self._encode(x.astype(dt), False, DropCtx(training=False))
+        P, _ = O.attention_proj_fwd(F, p['attention/W1/kernel'], p['attention/W1/bias'])
+        rep = lambda t: np.repeat(t, k, axis=0)
+        F, P = rep(F), rep(P)
+        a, c = rep(a0.astype(dt)), rep(c0.astype(dt))
+        word = rep(np.asarray(start_seq).reshape(-1))
+        score = np.zeros((B, k)); score[:, 1:] = -1e30
+        fin = np.zeros((B, k), bool)
+        seqs = np.zeros((B, k, 0), np.int64)
+        margin = np.full(B, np.inf)
+        V = self.V
+        for _ in range(max_len):
+            text = p['emb_text/embeddings'][word]
+            (ctx, alpha, s), _ = O.attention_step_fwd(a, F, P, p['attention/W2/kernel'], p['attention/W2/bias'],
+                                                      p['attention/V/kernel'], p['attention/V/bias'])
+            a, c, _ = O.lstm_step_fwd(np.concatenate([ctx, text], axis=1) @ p['lstm/kernel'] + p['lstm/bias'], a, c,
+                                      p['lstm/recurrent_kernel'])
+            inter, _ = O.dense_fwd(a, p['time_distributed_nonlinear/kernel'], p['time_distributed_nonlinear/bias'], O.ACT_LEAKY)
+            probs = O.softmax(inter @ p['time_distributed_softmax/kernel'] + p['time_distributed_softmax/bias'])
+            cand = score[:, :, None] + np.log(np.maximum(probs, 1e-30)).reshape(B, k, V)
+            frozen = np.full((B, k, V), -np.inf); frozen[:, :, 0] = score
+            cand = np.where(fin[:, :, None], frozen, cand).reshape(B, k * V)
+            order = np.argsort(-cand, axis=1, kind='stable')          # ties: lower flat index first
+            top = order[:, :k]
+            best = np.take_along_axis(cand, top, axis=1)
+            nxt = np.take_along_axis(cand, order[:, k:k + 1], axis=1)[:, 0]
+            margin = np.minimum(margin, np.min(best[:, :-1] - best[:, 1:], axis=1) if k > 1 else np.inf)
+            margin = np.minimum(margin, best[:, -1] - nxt)
+            pj, tv = top // V, top % V
+            rows = (np.arange(B)[:, None] * k + pj).reshape(-1)
+            a, c = a[rows], c[rows]
+            seqs = np.concatenate([np.take_along_axis(seqs, pj[:, :, None], axis=1) if seqs.shape[2] else seqs,
+                                   tv[:, :, None]], axis=2)
+            fin = np.take_along_axis(fin, pj, axis=1) | (tv == end_id)
+            score = best
+            word = tv.reshape(-1)
+        return seqs, score, margin

@@ -404,6 +404,29 @@ class MockBackend:
                 e[o:o + n] = (gr[o:o + n].astype(np.float64) + 2 * float(l2[s]) * t) * scale
                 th[o:o + n] = t + e[o:o + n]
 
+    def beam_topk(self, probs, score_in, fin_in, B, V, ld, k, end_id, score_out, parent, token, fin_out):
+        """include/tnt_hip.h: tnt_beam_topk_f32, from its definition (float32 scores like the kernel)."""
+        P = mat(probs, B * k, V, ld)
+        sc, fn = flat(score_in)[:B * k].reshape(B, k), flat(fin_in)[:B * k].reshape(B, k)
+        so, pa, to, fo = flat(score_out), flat(parent), flat(token), flat(fin_out)
+        for b in range(B):
+            cand = np.empty((k, V), np.float32)
+            for j in range(k):
+                if fn[b, j]:
+                    cand[j] = -np.inf; cand[j, 0] = sc[b, j]
+                else:
+                    cand[j] = np.float32(sc[b, j]) + np.log(np.maximum(P[b * k + j], np.float32(1e-30))).astype(np.float32)
+            order = np.argsort(-cand.reshape(-1), kind="stable")[:k]
+            for r, cnd in enumerate(order):
+                j, v = divmod(int(cnd), V)
+                so[b * k + r] = cand[j, v]; pa[b * k + r] = b * k + j; to[b * k + r] = v
+                fo[b * k + r] = 1 if (fn[b, j] or v == end_id) else 0
+
+    def block_dense_dx(self, dpre, W, dx, B, R, Din, Dout):
+        d = flat(dpre)[:B * R * Dout].reshape(B, R, Dout).astype(np.float64)
+        w = flat(W)[:R * Din * Dout].reshape(R, Din, Dout).astype(np.float64)
+        flat(dx)[:B * R * Din] = np.einsum("brn,rkn->brk", d, w).reshape(-1)
+
     def colsq(self, x, out, rows, cols, ld):
         m = mat(x, rows, cols, ld).astype(np.float64)
         flat(out)[:cols] = (m * m).sum(0)

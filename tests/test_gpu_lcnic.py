@@ -13,12 +13,12 @@ pytestmark = pytest.mark.gpu
 DIMS = [(3, 37, 4, 16, 3, 16, 6, 11, 4), (8, 2000, 36, 32, 32, 64, 64, 501, 15)]
 
 
-def build(rng, rates, dims, norm="batch", use_graph=True):
+def build(rng, rates, dims, norm="batch", use_graph=True, depth=0):
     from masters_thesis_amd.lc_nic import NIC
     B, N, R, D, A, U, Et, V, T = dims
     g = (tiny_groups(N, R, rng), [D] * R)
-    model = NIC(g, U, 512, Et, A, V, T, *rates, 0.01, 0.001, 3e-5, 1e-5, norm=norm, seed=11, use_graph=use_graph)
-    orc = M.LcNIC(g, U, 512, Et, A, V, T, *rates, 0.01, 0.001, 3e-5, 1e-5, norm=norm).init_params(rng)
+    model = NIC(g, U, 512, Et, A, V, T, *rates, 0.01, 0.001, 3e-5, 1e-5, norm=norm, seed=11, use_graph=use_graph, depth=depth)
+    orc = M.LcNIC(g, U, 512, Et, A, V, T, *rates, 0.01, 0.001, 3e-5, 1e-5, norm=norm, depth=depth).init_params(rng)
     for k, v in orc.p.items():
         model.set_weight(k, v)
     return model, orc
@@ -107,6 +107,61 @@ def test_forward_gradients_greedy(dims):
     assert np.array_equal(gw, ww)                                  # identical greedy captions
     assert np.abs(gp - wp).max() <= 1e-4 and np.abs(ga - wa).max() <= 1e-4 * wa.max()
     assert np.abs(gs - ws).max() <= 1e-4
+
+
+@pytest.mark.parametrize("dims", DIMS)
+@pytest.mark.parametrize("depth", [1, 2])
+def test_depth_n_encoder_train_parity(dims, depth):
+    """deep_layers.LocallyDense(depth=n) (deep_layers.py:15-75): forward, every gradient through the deep stages
+    (tnt_block_dense_dx_f32 for the per-region input gradients) and the Adam update against the oracle."""
+    from masters_thesis_amd.optimizers import Adam
+    rng = np.random.default_rng(56)
+    B, N, R, D, A, U, Et, V, T = dims
+    model, orc = build(rng, (0.1, 0.2, 0.2, 0.2, 0.2, 0.2), dims, depth=depth)
+    model.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    opt = M.AdamState(orc.p, lr=1e-3, clipnorm=0.1)
+    lam = lambda k: model.arena.entries[k].l2
+    for step in range(3):
+        data, tgt = synth_batch(B, N, T, V, U, rng)
+        w0 = {k: v.copy() for k, v in orc.p.items()}
+        res, grads, _ = orc.train_step(data, tgt, opt, M.DropCtx(seed=11, step=step, training=True))
+        got = model.train_step((data, tgt)).as_floats()
+        for k in ("loss", "L2", "attention"):
+            assert abs(got[k] - res[k]) <= 1e-4 * abs(res[k]) + 1e-7, (step, k, got[k], res[k])
+        for k in orc.trainable():
+            if k == "attention/V/bias" or "deep" not in k and step > 0:
+                continue
+            g = model.get_gradient(k) + 2 * lam(k) * w0[k]
+            assert np.abs(g - grads[k]).max() <= 3e-4 * np.abs(grads[k]).max() + 1e-9, (step, k)
+        for k, v in orc.p.items():
+            if k == "attention/V/bias":
+                continue
+            w = model.get_weight(k)
+            assert np.abs(w - v).max() <= 2e-2 * 1e-3 + 1e-4 * np.abs(v).max(), (step, k, np.abs(w - v).max())
+
+
+@pytest.mark.parametrize("dims", DIMS)
+def test_beam_search_matches_oracle(dims):
+    """tnt_beam_topk_f32 + the row gathers of the LSTM state driven by NIC.beam_search against oracle
+    LcNIC.beam_search (sequences identical wherever float32 cannot reorder the candidates, scores to 1e-4); width 1
+    without an end token reproduces the greedy caption."""
+    rng = np.random.default_rng(55)
+    B, N, R, D, A, U, Et, V, T = dims
+    model, orc = build(rng, (0,) * 6, dims, use_graph=False)
+    data, _ = synth_batch(B, N, T, V, U, rng)
+    z = np.zeros((B, U), np.float32)
+    start = np.ones(B, np.int64)
+    gw = model.greedy_predict(data[0], z, z, start, T, U, None)[0]
+    s1, _ = model.beam_search(data[0], z, z, start, T, beam_width=1)
+    assert np.array_equal(s1[:, 0, :], gw[:, :, 0])
+    end_id = int(gw[0, 1, 0])
+    for k, eid in ((3, -1), (5, end_id)):
+        want, wscore, margin = orc.beam_search(data[0], z, z, start, T, k=k, end_id=eid)
+        got, gscore = model.beam_search(data[0], z, z, start, T, beam_width=k, end_id=eid)
+        ok = margin > 2e-4
+        assert ok.any(), margin
+        assert np.array_equal(got[ok], want[ok]), (k, eid)
+        assert np.abs(gscore[ok] - wscore[ok]).max() <= 1e-4 * max(1.0, np.abs(wscore).max())
 
 
 def test_full_size_properties():

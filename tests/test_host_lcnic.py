@@ -22,14 +22,14 @@ def mock_backend():
 ARGS = dict(B=4, N=41, R=5, D=16, A=6, U=16, Et=12, V=13, T=5)
 
 
-def make_pair(rng, rates, norm="batch", seed=11, **d):
+def make_pair(rng, rates, norm="batch", seed=11, depth=0, **d):
     d = {**ARGS, **d}
     groups = tiny_groups(d["N"], d["R"], rng)
     g = (groups, [d["D"]] * d["R"])
     model = NIC(g, d["U"], 512, d["Et"], d["A"], d["V"], d["T"], *rates, 0.01, 0.001, 3e-5, 1e-5, norm=norm,
-                device="cpu", seed=seed)
+                device="cpu", seed=seed, depth=depth)
     orc = M.LcNIC(g, d["U"], 512, d["Et"], d["A"], d["V"], d["T"], *rates, 0.01, 0.001, 3e-5, 1e-5,
-                  norm=norm).init_params(rng)
+                  norm=norm, depth=depth).init_params(rng)
     for k, v in orc.p.items():
         model.set_weight(k, v)
         assert np.allclose(model.get_weight(k), v, atol=1e-6)
@@ -157,3 +157,49 @@ def test_adaptive_gradient_clipping_matches_oracle():
             if k == "attention/V/bias":
                 continue
             assert np.allclose(model.get_weight(k), v, rtol=2e-4, atol=2e-6), (step, k, np.abs(model.get_weight(k) - v).max())
+
+
+def test_beam_search_matches_oracle():
+    """NIC.beam_search (width k, log-probability sums, finished beams pad with 0) against oracle LcNIC.beam_search;
+    k = 1 without an end token is the greedy caption."""
+    rng = np.random.default_rng(61)
+    model, orc, d = make_pair(rng, (0,) * 6)
+    B, U, T = d["B"], d["U"], d["T"]
+    data, _ = synth_batch(B, d["N"], T, d["V"], U, rng)
+    z = np.zeros((B, U), np.float32)
+    start = np.ones(B, np.int64)
+    gw = model.greedy_predict(data[0], z, z, start, T, U, None)[0]
+    s1, _ = model.beam_search(data[0], z, z, start, T, beam_width=1)
+    assert np.array_equal(s1[:, 0, :], gw[:, :, 0])
+    end_id = int(gw[0, 1, 0])                       # a token the decoder really emits: exercises the finished-beam rule
+    for k, eid in ((3, -1), (4, end_id)):
+        want, wscore, margin = orc.beam_search(data[0], z, z, start, T, k=k, end_id=eid)
+        got, gscore = model.beam_search(data[0], z, z, start, T, beam_width=k, end_id=eid)
+        ok = margin > 1e-5                          # samples where float32 cannot reorder the candidates
+        assert ok.any()
+        assert np.array_equal(got[ok], want[ok]), (k, eid)
+        assert np.allclose(gscore[ok], wscore[ok], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("depth,norm", [(1, "batch"), (2, "batch"), (2, "layer")])
+def test_depth_n_encoder_matches_oracle(depth, norm):
+    """deep_layers.LocallyDense(depth=n) (deep_layers.py:15-75) in place of layers.LocallyDense: n more stages of
+    per-region Dense + BatchNorm + Dropout -- three training steps (every gradient through the stages, their moving
+    statistics) and the inference call against the oracle."""
+    rng = np.random.default_rng(62)
+    model, orc, d = make_pair(rng, (0.1, 0.2, 0.2, 0.2, 0.2, 0.2), norm=norm, depth=depth)
+    model.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    opt = M.AdamState(orc.p, lr=1e-3, clipnorm=0.1)
+    for step in range(3):
+        data, tgt = synth_batch(d["B"], d["N"], d["T"], d["V"], d["U"], rng)
+        res, grads, _ = orc.train_step(data, tgt, opt, M.DropCtx(seed=11, step=step, training=True))
+        got = model.train_step((data, tgt)).as_floats()
+        for k in ("loss", "L2", "attention"):
+            assert abs(got[k] - res[k]) < 2e-5 * max(1, abs(res[k])), (step, k, got[k], res[k])
+        for k, v in orc.p.items():
+            if k == "attention/V/bias":
+                continue
+            assert np.allclose(model.get_weight(k), v, rtol=2e-4, atol=3e-6), (step, k, np.abs(model.get_weight(k) - v).max())
+    (probs, attn), _ = orc.forward(data, False)
+    p, al = model(data, training=False)
+    assert np.allclose(p.numpy(), probs, rtol=1e-4, atol=1e-7) and np.allclose(al.numpy(), attn, rtol=1e-4, atol=1e-7)
