@@ -317,6 +317,8 @@ int32_t tnt_argmax_rows_f32(const float* x, int32_t* out, int32_t rows, int32_t 
 int32_t tnt_sample_rows_f32(const float* x, int32_t* out, int32_t rows, int32_t V, int32_t ld,
                             float temperature, int32_t from_logits, uint64_t seed, uint32_t site,
                             uint32_t step, const uint32_t* step_dev, void* stream);
+/* out[0] = mean_i (c - x[i])^2 (MeanSquaredError against a constant target, lc_NIC.py:813-814) */
+int32_t tnt_sqdiff_mean_f32(const float* x, float* out, int64_t n, float c, void* stream);
 int32_t tnt_sum_f32(const float* x, float* out, int32_t n, float scale, void* stream);
 /* two of them in one launch: out0[0] = scale*sum(x0[0..n)), out1[0] = scale*sum(x1[0..n))  (loss + accuracy) */
 int32_t tnt_sum2_f32(const float* x0, float* out0, const float* x1, float* out1, int32_t n, float scale,
@@ -383,10 +385,13 @@ int32_t tnt_agc_f32(const float* theta, float* grad, const int64_t* var_off, con
 int32_t tnt_colsq_f32(const float* x, float* out, int32_t rows, int32_t cols, int32_t ld, void* stream);
 /* Sharpness-aware minimisation helper (CaptionGenerator.train_step_SAM, ThinkAndTell/model.py:166-233;
  * lc_NIC.train_step_sam, lc_NIC.py:713-838).  mode 0: e_w = (g + 2 lambda theta) * rho/(||g||+1e-12)
- * with ||g||^2 = sum_s sq[s] (from tnt_seg_sqnorm_f32); theta += e_w; e_w stored.  mode 1: theta -= e_w. */
-int32_t tnt_sam_f32(float* theta, const float* grad, float* ew, const int32_t* span_seg,
+ * with ||g||^2 = sum_s sq[s] (from tnt_seg_sqnorm_f32; sq_override[s] >= 0 replaces sq[s]: tf.linalg.global_norm takes an
+ * IndexedSlices gradient by its un-deduplicated values, nullable); theta += e_w; e_w stored.  mode 1: theta -= e_w, and
+ * grad += 2 lambda e_w: the gradient the tape took at theta + e_w carries the L2 term of the PERTURBED weights, while the
+ * optimizer kernels add 2 lambda theta at the restored ones. */
+int32_t tnt_sam_f32(float* theta, float* grad, float* ew, const int32_t* span_seg,
                     const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
-                    const float* sq, int32_t nseg, int32_t nspan, float rho, int32_t mode, void* stream);
+                    const float* sq, const float* sq_override, int32_t nseg, int32_t nspan, float rho, int32_t mode, void* stream);
 /* device-resident step state, advanced inside the (captured) step:
  * adam_t += 1; lr_t = lr[0]*sqrt(1-b2^t)/(1-b1^t); drop_step += 1.  Pointers nullable.
  * guard (nullable): a device error word (tnt_lstm_seq_fwd_f32); when it is non-zero nothing is advanced, and
@@ -436,6 +441,8 @@ int32_t tnt_attention_step_fwd_f32(const float* h, const float* F, const float* 
  * dctx_d[b][d] = sum_n dz[b][n] * Wc[d][n] (dz: this step's LSTM dz [B][4U]; Wc: the context
  * rows of the LSTM kernel [D][4U]) and the dctx_d argument is ignored.  If dctx_part is non-null ([nparts][B][D], written
  * by tnt_lstm_step_bwd_f32; nparts*D <= 1024) the context gradient is the sum of the parts and dctx_d / dz are ignored. */
+/* alpha_mse_coef: dalpha[b][r] += alpha_mse_coef * (alpha[b][r] - 1) before the softmax backward -- the gradient of
+ * c * sum (1 - alpha)^2 with alpha_mse_coef = 2c (lc_NIC.train_step_sam's attention term, lc_NIC.py:751-752); 0 = none. */
 int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* F, const float* P,
                                    const float* W2, const float* v, const float* qpre,
                                    const float* alpha, float* dP, float* dF, float* dvb,
@@ -445,7 +452,7 @@ int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* F, const fl
                                    uint32_t site_attn, uint32_t site_in, uint32_t step,
                                    const uint32_t* step_dev, const float* dz, const float* Wc,
                                    const float* dctx_part, int32_t nparts, const uint8_t* keep4,
-                                   void* stream);
+                                   float alpha_mse_coef, void* stream);
 
 /* attention "coverage" metric (lc_NIC.py:365-367): mean over (T,R) of
  * (1 - sum_b alpha[t][b][r])^2.  alpha is [T][B][R]. */

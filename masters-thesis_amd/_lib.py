@@ -57,6 +57,7 @@ SIGNATURES = {
     "tnt_stage_batch_f32": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, I32, P],
     "tnt_stage_batch_h16": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, I32, P],
     "tnt_sample_rows_f32": [P, P, I32, I32, I32, F32, I32, U64, U32, U32, P, P],
+    "tnt_sqdiff_mean_f32": [P, P, I64, F32, P],
     "tnt_sum_f32": [P, P, I32, F32, P],
     "tnt_l2_total_f32": [P, P, I32, P, P],
     "tnt_seg_sqnorm_f32": [P, P, P, P, P, P, P, P, P, P, P, I32, I32, P],
@@ -65,7 +66,7 @@ SIGNATURES = {
     "tnt_agc_f32": [P, P, P, P, P, P, P, I32, P, P, I32, I32, I32, P, P, F32, F32, P],
     "tnt_colsq_f32": [P, P, I32, I32, I32, P],
     "tnt_step_tick": [P, P, P, P, F32, F32, P, P],
-    "tnt_sam_f32": [P, P, P, P, P, P, P, P, I32, I32, F32, I32, P],
+    "tnt_sam_f32": [P, P, P, P, P, P, P, P, P, I32, I32, F32, I32, P],
     "tnt_gemm_f32_tile": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, F32, I32, I32, P, I32, I32, P],
     "tnt_block_dense_dx_f32": [P, P, P, I32, I32, I32, I32, P],
     "tnt_locally_dense_fwd_f32": [P, I32, P, P, P, P, P, P, I32, I32, I32, F32, P],
@@ -73,7 +74,7 @@ SIGNATURES = {
     "tnt_attention_step_fwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, F32,
                                    I32, U64, U32, U32, U32, P, P, P],
     "tnt_attention_step_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, F32,
-                                   I32, U64, U32, U32, U32, P, P, P, P, I32, P, P],
+                                   I32, U64, U32, U32, U32, P, P, P, P, I32, P, F32, P],
     "tnt_attention_metric_f32": [P, P, P, I32, I32, I32, I64, P],
 }
 

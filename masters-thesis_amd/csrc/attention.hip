@@ -52,6 +52,9 @@ struct AttArgs {
   float slope, rate_attn, rate_in;
   uint64_t seed; uint32_t site_attn, site_in, step; const uint32_t* step_dev;
   const uint8_t* keep4;       // nullable: attention-dropout keep bits from tnt_dropout_mask4_u8 (wide kernels only)
+  // backward only: dalpha[r] += alpha_mse * (alpha[r] - 1) -- the gradient of c * sum (1 - alpha)^2 with alpha_mse = 2c
+  // (lc_NIC.train_step_sam adds MSE(ones, attention_scores) to the loss of its first pass, lc_NIC.py:751-752,766)
+  float alpha_mse;
 };
 
 // q[a] = LeakyReLU(sum_k h[k] W2[k][a] + b2[a]); threads = (a = tid % AP, part = tid / AP)
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttArgs g) {
         g.dF[e] = dfv[u] + als[r] * dcs[d];
       }
       t = group_sum<AP>(t);
-      if (d == 0 && r < g.R) das[r] = t;
+      if (d == 0 && r < g.R) das[r] = t + g.alpha_mse * (als[r] - 1.f);
     }
   }
   __syncthreads();
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(WT) void attention_bwd_wide_kernel(AttArgs g) {
                                                            dfv[p].z + al * dc4.z, dfv[p].w + al * dc4.w);
       }
       t = adj_sum<G4>(t);
-      if (c4 == 0 && r < R) das[r] = t;
+      if (c4 == 0 && r < R) das[r] = t + g.alpha_mse * (als[r] - 1.f);
     }
     __syncthreads();
   }
@@ -701,13 +704,13 @@ extern "C" int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* 
                                               int32_t in_lwidth, uint64_t seed, uint32_t site_attn, uint32_t site_in,
                                               uint32_t step, const uint32_t* step_dev, const float* dz, const float* Wc,
                                               const float* dctx_part, int32_t nparts, const uint8_t* keep4,
-                                              void* stream) {
+                                              float alpha_mse_coef, void* stream) {
   if (int32_t rc = check_dims(B, R, D, A, U)) return rc;
   if (dz != nullptr && (U % 16 != 0 || Wc == nullptr)) return TNT_BADARG(27);
   if (dz == nullptr && dctx_d == nullptr && dctx_part == nullptr) return TNT_BADARG(1);
   if (dctx_part != nullptr && (nparts <= 0 || nparts * D > 1024)) return TNT_BADARG(30);
   AttArgs g{};
-  g.dz = dz; g.Wc = Wc; g.dctx_part = dctx_part; g.nparts = nparts; g.keep4 = keep4;
+  g.dz = dz; g.Wc = Wc; g.dctx_part = dctx_part; g.nparts = nparts; g.keep4 = keep4; g.alpha_mse = alpha_mse_coef;
   g.dctx_d = dctx_d; g.F = F; g.P = P; g.W2 = W2; g.v = v; g.qpre_in = qpre; g.alpha_in = alpha; g.dP = dP; g.dF = dF;
   g.dvb = dvb; g.dqpre = dqpre; g.dh = dh; g.B = B; g.R = R; g.D = D; g.A = A; g.U = U; g.in_lwidth = in_lwidth;
   g.slope = slope; g.rate_attn = rate_attn; g.rate_in = rate_in; g.seed = seed; g.site_attn = site_attn;

@@ -146,19 +146,27 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* theta, float* mom, cons
 // Sharpness-aware minimisation helper (CaptionGenerator.train_step_SAM, ThinkAndTell/model.py:166-233):
 // mode 0: e_w = (g + 2 lambda theta) * rho / (||g_total|| + 1e-12); theta += e_w; e_w is kept
 // mode 1: theta -= e_w (restore).  ||g_total||^2 = sum of the per-segment squared norms sq[].
-__global__ __launch_bounds__(256) void sam_kernel(float* theta, const float* grad, float* ew, SpanTab t, const float* sq,
-                                                  int nseg, int nspan, float rho, int mode) {
+__global__ __launch_bounds__(256) void sam_kernel(float* theta, float* grad_rw, float* ew, SpanTab t, const float* sq,
+                                                  const float* sq_override, int nseg, int nspan, float rho, int mode) {
   __shared__ float sw[4];
   const int sp = blockIdx.x;
   if (sp >= nspan) return;
   const long off = t.span_off[sp];
   const int len = t.span_len[sp];
   if (mode == 1) {
-    for (int i = threadIdx.x; i < len; i += 256) theta[off + i] -= ew[off + i];
+    // restore; the second gradient was taken at theta + e_w, L2 term included (2 lambda (theta + e_w)): the optimizer
+    // adds 2 lambda theta at the RESTORED weights, so the difference 2 lambda e_w goes into the stored data gradient
+    const float lam2r = 2.f * t.seg_l2[t.span_seg[sp]];
+    for (int i = threadIdx.x; i < len; i += 256) {
+      const float e = ew[off + i];
+      theta[off + i] -= e;
+      if (lam2r != 0.f) grad_rw[off + i] += lam2r * e;
+    }
     return;
   }
   float a = 0.f;
-  for (int s = threadIdx.x; s < nseg; s += 256) a += sq[s];
+  // tf.linalg.global_norm takes an IndexedSlices gradient by its un-deduplicated values: sq_override where given
+  for (int s = threadIdx.x; s < nseg; s += 256) a += (sq_override && sq_override[s] >= 0.f) ? sq_override[s] : sq[s];
   a = tnt_wave_sum(a);
   if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = a;
   __syncthreads();
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(256) void sam_kernel(float* theta, const float* gra
   const float lam2 = 2.f * t.seg_l2[t.span_seg[sp]];
   for (int i = threadIdx.x; i < len; i += 256) {
     const float w = theta[off + i];
-    const float e = (grad[off + i] + lam2 * w) * scale;
+    const float e = (grad_rw[off + i] + lam2 * w) * scale;
     ew[off + i] = e;
     theta[off + i] = w + e;
   }
@@ -349,13 +357,14 @@ extern "C" int32_t tnt_sgd_f32(float* theta, float* mom, const float* grad, cons
   return 0;
 }
 
-extern "C" int32_t tnt_sam_f32(float* theta, const float* grad, float* ew, const int32_t* span_seg,
+extern "C" int32_t tnt_sam_f32(float* theta, float* grad, float* ew, const int32_t* span_seg,
                                const int64_t* span_off, const int32_t* span_len, const float* seg_l2, const float* sq,
-                               int32_t nseg, int32_t nspan, float rho, int32_t mode, void* stream) {
+                               const float* sq_override, int32_t nseg, int32_t nspan, float rho, int32_t mode,
+                               void* stream) {
   if (nspan <= 0) return 0;
   SpanTab t{span_seg, span_off, span_len, nullptr, seg_l2};
-  hipLaunchKernelGGL(sam_kernel, dim3(nspan), dim3(256), 0, tnt_stream(stream), theta, grad, ew, t, sq, nseg, nspan, rho,
-                     mode);
+  hipLaunchKernelGGL(sam_kernel, dim3(nspan), dim3(256), 0, tnt_stream(stream), theta, grad, ew, t, sq, sq_override, nseg, nspan,
+                     rho, mode);
   TNT_LAUNCH_CHECK();
   return 0;
 }

@@ -413,6 +413,22 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* probs, cons
   }
 }
 
+// out[0] = mean_i (c - x[i])^2, fixed reduction order (one workgroup): tf.keras.losses.MeanSquaredError()(c, x) for a
+// constant target -- the 'attention' entry lc_NIC.train_step_sam returns (lc_NIC.py:813-814,838)
+__global__ __launch_bounds__(1024) void sqdiff_mean_kernel(const float* x, long n, float c, float* out) {
+  __shared__ float s[16];
+  float a = 0.f;
+  for (long i = threadIdx.x; i < n; i += 1024) { const float d = c - x[i]; a += d * d; }
+  a = tnt_wave_sum(a);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += s[w];
+    out[0] = t / (float)n;
+  }
+}
+
 // Categorical sampling, one workgroup per row (tf.random.categorical(logits / temperature, 1),
 // ThinkAndTell/evaluate.py:223,278; lc_NIC.sample_choice, lc_NIC.py:571-575).  Inverse CDF in a fixed
 // order with one Philox uniform per row, so the CPU oracle can restate it:
@@ -570,6 +586,13 @@ extern "C" int32_t tnt_beam_topk_f32(const float* probs, const float* score_in, 
   if (score_out == score_in || fin_out == fin_in) return TNT_BADARG(9);
   hipLaunchKernelGGL(beam_topk_kernel, dim3(B), dim3(256), 0, tnt_stream(stream), probs, score_in, fin_in, V, ld, k,
                      end_id, score_out, parent, token, fin_out);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_sqdiff_mean_f32(const float* x, float* out, int64_t n, float c, void* stream) {
+  if (n <= 0) return TNT_BADARG(3);
+  hipLaunchKernelGGL(sqdiff_mean_kernel, dim3(1), dim3(1024), 0, tnt_stream(stream), x, (long)n, c, out);
   TNT_LAUNCH_CHECK();
   return 0;
 }

@@ -553,12 +553,14 @@ class NIC(ModelBase):
                 be.attention_step_bwd(None, self.F, self.P, W2, v, self.qpre[i], self.alpha[i], self.dP, self.dF,
                                       self.dvb, self.dqpre[i], self.dh_att, B, R, D, A, U, 0.2, self.r_attn, self.r_lstm,
                                       D + Et, sd, S_ATTN + i, S_LSTM_IN + i, 0, ds, dctx_part=self.dctx_part,
-                                      nparts=U // 16, keep4=self.att_keep[i] if self._keep_stored else None)
+                                      nparts=U // 16, keep4=self.att_keep[i] if self._keep_stored else None,
+                                      alpha_mse=self._alpha_mse)
             else:
                 be.attention_step_bwd(None, self.F, self.P, W2, v, self.qpre[i], self.alpha[i], self.dP, self.dF,
                                       self.dvb, self.dqpre[i], self.dh_att, B, R, D, A, U, 0.2, self.r_attn, self.r_lstm,
                                       D + Et, sd, S_ATTN + i, S_LSTM_IN + i, 0, ds, dz=self.dZ[i * B:(i + 1) * B],
-                                      Wc=Wl[:D], keep4=self.att_keep[i] if self._keep_stored else None)
+                                      Wc=Wl[:D], keep4=self.att_keep[i] if self._keep_stored else None,
+                                      alpha_mse=self._alpha_mse)
         hprev = self.Hs[:T].view(n, U)
         gWl = a.g("lstm/kernel")
         self.gemm_sk(hprev, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True)
@@ -681,6 +683,50 @@ class NIC(ModelBase):
             self._run_captured(("train_fb", B, T), lambda: self._train_graph(B, T))
             self.grad_sync(self)
             self._run_captured(("train_up", B, T), self._update_graph)
+        self.optimizer.iterations += 1
+        return self._metrics(True)
+
+    _alpha_mse = 0.0        # coefficient of the attention-MSE gradient in the backward chain (train_step_sam's first pass)
+
+    def train_step_sam(self, data, rho=0.05):
+        """lc_NIC.train_step_sam (lc_NIC.py:713-838): sharpness-aware step.  Pass 1 differentiates
+        CE + L2 + MSE(ones, attention_scores) (:751-766), the weights move by e_w = g * rho / (global_norm(g) + 1e-12)
+        (:768-786; the Embedding's IndexedSlices enter the norm by their un-deduplicated values), pass 2 differentiates
+        CE + L2 there (:800-830), the weights are restored and the optimizer applies the second gradient (:833-836).
+        Returns {loss, L2, accuracy, attention = MSE(ones, alpha), lr} of the second pass (:838).  Both passes draw the
+        same dropout masks.  One captured launch sequence: two forward / backward passes and the update."""
+        if self.optimizer is None:
+            raise RuntimeError("compile() the model before train_step_sam")
+        if self.S != 1:
+            raise NotImplementedError("train_step_sam is a single-subject step (lc_NIC.py)")
+        B, T = self._stage_batch(data[0], data[1], self.n_in)
+        self._sync_lr()
+        be, a, sp = self.be, self.arena, self.arena.spans
+        if self.__dict__.get("ew") is None:
+            self.ew = torch.zeros_like(a.theta)
+        n_alpha = T * B * self.R
+
+        def run():
+            self._forward(B, T, True)
+            self._loss_metrics(B, T, True)
+            self._alpha_mse = 2.0 / n_alpha
+            try:
+                self._backward(B, T)
+            finally:
+                self._alpha_mse = 0.0
+            self._norms_and_l2(None)
+            be.sam(a.theta, a.grad, self.ew, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq, a.nseg, sp.nspan, rho, 0,
+                   sq_override=a.sq_override)
+            self._forward(B, T, True)
+            self._loss_metrics(B, T, True)
+            be.sqdiff_mean(self.alpha, self.met[3:4], n_alpha, 1.0)
+            self._backward(B, T)
+            self._norms_and_l2(self.met[2:3])          # L2 as the reference reports it: at the perturbed weights
+            be.sam(a.theta, a.grad, self.ew, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq, a.nseg, sp.nspan, rho, 1)
+            self._apply_agc()
+            self._norms_and_l2(None)                   # clip norms of the second gradient at the restored weights
+            self._apply_optimizer()
+        self._run_captured(("sam", B, T, float(rho)), run)
         self.optimizer.iterations += 1
         return self._metrics(True)
 

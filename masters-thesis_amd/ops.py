@@ -234,9 +234,12 @@ class HipBackend:
                                         _p(seg_l2), _p(sq), _p(sq_override), nspan, lr, _p(lr_dev), momentum,
                                         clipnorm, _p(guard), self._s())
 
-    def sam(self, theta, grad, ew, span_seg, span_off, span_len, seg_l2, sq, nseg, nspan, rho, mode):
+    def sam(self, theta, grad, ew, span_seg, span_off, span_len, seg_l2, sq, nseg, nspan, rho, mode, sq_override=None):
         self._call(self.lib.tnt_sam_f32, "tnt_sam_f32", _p(theta), _p(grad), _p(ew), _p(span_seg), _p(span_off), _p(span_len),
-                                        _p(seg_l2), _p(sq), nseg, nspan, rho, mode, self._s())
+                                        _p(seg_l2), _p(sq), _p(sq_override), nseg, nspan, rho, mode, self._s())
+
+    def sqdiff_mean(self, x, out, n, c):
+        self._call(self.lib.tnt_sqdiff_mean_f32, "tnt_sqdiff_mean_f32", _p(x), _p(out), n, float(c), self._s())
 
     def agc(self, theta, grad, tab, gsq_cols=None, sq_out=None, clip_factor=0.01, eps=1e-3):
         """unit-wise adaptive gradient clipping over the arena; ``tab`` = arena.AgcTable"""
@@ -276,12 +279,12 @@ class HipBackend:
 
     def attention_step_bwd(self, dctx_d, F, P, W2, v, qpre, alpha, dP, dF, dvb, dqpre, dh, B, R, D, A, U, slope,
                            rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None, dz=None,
-                           Wc=None, dctx_part=None, nparts=0, keep4=None):
+                           Wc=None, dctx_part=None, nparts=0, keep4=None, alpha_mse=0.0):
         self._call(self.lib.tnt_attention_step_bwd_f32, "tnt_attention_step_bwd_f32", _p(dctx_d), _p(F), _p(P), _p(W2), _p(v), _p(qpre), _p(alpha),
                                                        _p(dP), _p(dF), _p(dvb), _p(dqpre), _p(dh), B, R, D, A, U,
                                                        slope, rate_attn, rate_in, in_lwidth, seed, site_attn, site_in,
                                                        step, _p(step_dev), _p(dz), _p(Wc), _p(dctx_part), nparts,
-                                                       _p(keep4), self._s())
+                                                       _p(keep4), float(alpha_mse), self._s())
 
     def attention_metric(self, alpha, out, work, T, B, R, tstride=0):
         self._call(self.lib.tnt_attention_metric_f32, "tnt_attention_metric_f32", _p(alpha), _p(out), _p(work), T, B, R, tstride, self._s())

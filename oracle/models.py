@@ -508,7 +508,9 @@ class LcNIC:
             dbl += dz.sum(axis=0)
             dsample = O.dropout_bwd((dz @ Wl.T)[:, None, :], st['k_li'], self.r_lstm)[:, 0]
             dctx, dtext[:, i] = dsample[:, :D], dsample[:, D:]
-            dh_att, dF_i, dsum, dW2_i, db2_i, dv_i, dbv_i = O.attention_step_bwd(dctx, F, W2, v, st['acache'])
+            am = getattr(self, '_alpha_mse', 0.0)       # train_step_sam, first pass: d/dalpha of mean (1 - alpha)^2
+            dh_att, dF_i, dsum, dW2_i, db2_i, dv_i, dbv_i = O.attention_step_bwd(
+                dctx, F, W2, v, st['acache'], dalpha_ext=(am * (st['acache'][4] - 1.0)) if am else None)
             dF += dF_i
             dP += dsum
             dW2 += dW2_i
@@ -578,6 +580,40 @@ class LcNIC:
         for i, dc in enumerate(cache['enc'].get('deep', [])):
             self.p[f'input_bn/deep{i}/moving_mean'], self.p[f'input_bn/deep{i}/moving_variance'] = dc['new_mm'], dc['new_mv']
         return {'loss': ce, 'L2': l2, 'accuracy': acc, 'attention': al, 'lr': opt.lr}, grads, (probs, attn)
+
+    def train_step_sam(self, data, y_ids, opt, drop=None, rho=0.05):
+        """lc_NIC.train_step_sam (lc_NIC.py:713-838): gradient of CE + L2 + MSE(ones, attention_scores) -> ascent step
+        e_w = g * rho / (global_norm(g) + 1e-12), the Embedding's IndexedSlices counted by its un-deduplicated values
+        (:768-786) -> gradient of CE + L2 at the perturbed weights (:800-830) -> restore -> apply_gradients (:833-836).
+        Returns the second pass's CE, L2 (at the perturbed weights), accuracy and 'attention' = MSE(ones, alpha) (:838).
+        Both passes draw the same dropout masks (TF would draw fresh ones; this library's stream is keyed by the step)."""
+        drop = drop or DropCtx(training=True)
+        (probs, attn), cache = self.forward(data, training=True, drop=drop)
+        self._alpha_mse = 2.0 / attn.size
+        g1, sp1 = self.backward(probs, cache, y_ids)
+        self._alpha_mse = 0.0
+        sq = sum(((sp1[k] ** 2) if k in sp1 else (g * g).sum()) for k, g in g1.items())
+        scale = rho / (np.sqrt(sq) + 1e-12)
+        e_ws = {k: g * scale for k, g in g1.items()}
+        for k, e in e_ws.items():
+            self.p[k] = self.p[k] + e
+        bn1 = cache['enc']
+        self.p['input_bn/moving_mean'], self.p['input_bn/moving_variance'] = bn1['new_mm'], bn1['new_mv']
+        for i, dc in enumerate(bn1.get('deep', [])):
+            self.p[f'input_bn/deep{i}/moving_mean'], self.p[f'input_bn/deep{i}/moving_variance'] = dc['new_mm'], dc['new_mv']
+        (probs, attn), cache = self.forward(data, training=True, drop=drop)
+        ce, acc, _ = self.metrics(probs, attn, y_ids)
+        l2 = self.l2_loss()
+        al = ((1.0 - attn) ** 2).mean()
+        g2, sparse = self.backward(probs, cache, y_ids)
+        for k, e in e_ws.items():
+            self.p[k] = self.p[k] - e
+        opt.apply(self.p, g2, sparse)
+        self.p['input_bn/moving_mean'] = cache['enc']['new_mm']
+        self.p['input_bn/moving_variance'] = cache['enc']['new_mv']
+        for i, dc in enumerate(cache['enc'].get('deep', [])):
+            self.p[f'input_bn/deep{i}/moving_mean'], self.p[f'input_bn/deep{i}/moving_variance'] = dc['new_mm'], dc['new_mv']
+        return {'loss': ce, 'L2': l2, 'accuracy': acc, 'attention': al, 'lr': opt.lr}, g2
 
     def test_step(self, data, y_ids):
         """lc_NIC.test_step (lc_NIC.py:410-459)."""

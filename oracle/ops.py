@@ -199,10 +199,13 @@ def attention_step_fwd(h, F, P, W2, b2, v, bv, keep=None, rate=0.0, slope=0.2):
     return (ctx, alpha, sd), (h, qpre, s, sd, alpha, keep, rate)
 
 
-def attention_step_bwd(dctx, F, W2, v, cache, slope=0.2):
-    """Returns dh, dF(step part, excluding the W1 path), dPsum (B,R,A), dW2, db2, dv, dbv."""
+def attention_step_bwd(dctx, F, W2, v, cache, slope=0.2, dalpha_ext=None):
+    """Returns dh, dF(step part, excluding the W1 path), dPsum (B,R,A), dW2, db2, dv, dbv.
+    dalpha_ext (B,R): a gradient that reaches the attention weights directly (lc_NIC.train_step_sam's MSE term)."""
     h, qpre, s, sd, alpha, keep, rate = cache
     dalpha = (dctx[:, None, :] * F).sum(axis=2)                 # (B,R)
+    if dalpha_ext is not None:
+        dalpha = dalpha + dalpha_ext
     dF = alpha[:, :, None] * dctx[:, None, :]
     de = alpha * (dalpha - (alpha * dalpha).sum(axis=1, keepdims=True))
     dv = (sd * de[:, :, None]).sum(axis=(0, 1))[:, None]

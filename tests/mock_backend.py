@@ -393,12 +393,20 @@ class MockBackend:
             mo[o:o + n] = mv
             th[o:o + n] = t + mv
 
-    def sam(self, theta, grad, ew, span_seg, span_off, span_len, seg_l2, sq, nseg, nspan, rho, mode):
+    def sqdiff_mean(self, x, out, n, c):
+        flat(out)[0] = ((c - flat(x)[:n].astype(np.float64)) ** 2).mean()
+
+    def sam(self, theta, grad, ew, span_seg, span_off, span_len, seg_l2, sq, nseg, nspan, rho, mode, sq_override=None):
         th, gr, e, l2 = flat(theta), flat(grad), flat(ew), flat(seg_l2)
-        scale = rho / (np.sqrt(flat(sq)[:nseg].astype(np.float64).sum()) + 1e-12)
+        q = flat(sq)[:nseg].astype(np.float64).copy()
+        if sq_override is not None:
+            o = flat(sq_override)[:nseg].astype(np.float64)
+            q = np.where(o >= 0, o, q)
+        scale = rho / (np.sqrt(q.sum()) + 1e-12)
         for s, o, n in self._segs(span_seg, span_off, span_len, nspan):
             if mode == 1:
                 th[o:o + n] -= e[o:o + n]
+                gr[o:o + n] += 2 * float(l2[s]) * e[o:o + n]
             else:
                 t = th[o:o + n].astype(np.float64)
                 e[o:o + n] = (gr[o:o + n].astype(np.float64) + 2 * float(l2[s]) * t) * scale
@@ -512,7 +520,7 @@ class MockBackend:
 
     def attention_step_bwd(self, dctx_d, F, P, W2, v, qpre, alpha, dP, dF, dvb, dqpre, dh, B, R, D, A, U, slope,
                            rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None, dz=None,
-                           Wc=None, dctx_part=None, nparts=0, keep4=None):
+                           Wc=None, dctx_part=None, nparts=0, keep4=None, alpha_mse=0.0):
         if step_dev is not None:
             step = (step + int(step_dev[0])) & 0xFFFFFFFF
         f64 = lambda t, *s: flat(t)[:int(np.prod(s))].reshape(*s).astype(np.float64)
@@ -529,7 +537,7 @@ class MockBackend:
         s = np.tanh(Pm + q[:, None, :])
         sd = O.dropout_fwd(s, keep, rate_attn)
         cache = (None, qp, s, sd, al, keep, rate_attn)
-        dalpha = (dctx[:, None, :] * Fm).sum(2)
+        dalpha = (dctx[:, None, :] * Fm).sum(2) + alpha_mse * (al - 1.0)
         dFv = al[:, :, None] * dctx[:, None, :]
         de = al * (dalpha - (al * dalpha).sum(1, keepdims=True))
         dv = (sd * de[:, :, None]).sum(1)                     # per-sample (B,A)

@@ -141,6 +141,31 @@ def test_depth_n_encoder_train_parity(dims, depth):
 
 
 @pytest.mark.parametrize("dims", DIMS)
+def test_train_step_sam_parity(dims):
+    """lc_NIC.train_step_sam (lc_NIC.py:713-838) on the GPU: the attention-MSE gradient through the attention backward
+    (alpha_mse_coef), the ascent step with the IndexedSlices global norm (tnt_sam_f32 sq_override), the second pass and
+    the update, hipGraph replay included."""
+    from masters_thesis_amd.optimizers import Adam
+    rng = np.random.default_rng(57)
+    B, N, R, D, A, U, Et, V, T = dims
+    model, orc = build(rng, (0.1, 0.2, 0.2, 0.2, 0.2, 0.2), dims)
+    model.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    opt = M.AdamState(orc.p, lr=1e-3, clipnorm=0.1)
+    for step in range(4):
+        data, tgt = synth_batch(B, N, T, V, U, rng)
+        res, g2 = orc.train_step_sam(data, tgt, opt, M.DropCtx(seed=11, step=step, training=True), rho=0.05)
+        got = model.train_step_sam((data, tgt), rho=0.05).as_floats()
+        for k in ("loss", "L2", "attention"):
+            assert abs(got[k] - res[k]) <= 1e-4 * abs(res[k]) + 1e-7, (step, k, got[k], res[k])
+        assert abs(got["accuracy"] - res["accuracy"]) < 1e-6
+        for k, v in orc.p.items():
+            if k == "attention/V/bias":
+                continue
+            w = model.get_weight(k)
+            assert np.abs(w - v).max() <= 2e-2 * 1e-3 + 1e-4 * np.abs(v).max(), (step, k, np.abs(w - v).max())
+
+
+@pytest.mark.parametrize("dims", DIMS)
 def test_beam_search_matches_oracle(dims):
     """tnt_beam_topk_f32 + the row gathers of the LSTM state driven by NIC.beam_search against oracle
     LcNIC.beam_search (sequences identical wherever float32 cannot reorder the candidates, scores to 1e-4); width 1

@@ -203,3 +203,24 @@ def test_depth_n_encoder_matches_oracle(depth, norm):
     (probs, attn), _ = orc.forward(data, False)
     p, al = model(data, training=False)
     assert np.allclose(p.numpy(), probs, rtol=1e-4, atol=1e-7) and np.allclose(al.numpy(), attn, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("depth", [0, 1])
+def test_train_step_sam_matches_oracle(depth):
+    """lc_NIC.train_step_sam (lc_NIC.py:713-838): first gradient incl. the attention-MSE term, ascent step with the
+    IndexedSlices global norm, second gradient at the perturbed weights, restore, Adam; metrics of the second pass."""
+    rng = np.random.default_rng(63)
+    model, orc, d = make_pair(rng, (0.1, 0.2, 0.2, 0.2, 0.2, 0.2), depth=depth)
+    model.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    opt = M.AdamState(orc.p, lr=1e-3, clipnorm=0.1)
+    for step in range(3):
+        data, tgt = synth_batch(d["B"], d["N"], d["T"], d["V"], d["U"], rng)
+        res, g2 = orc.train_step_sam(data, tgt, opt, M.DropCtx(seed=11, step=step, training=True), rho=0.05)
+        got = model.train_step_sam((data, tgt), rho=0.05).as_floats()
+        for k in ("loss", "L2", "attention", "accuracy"):
+            assert abs(got[k] - res[k]) < 3e-5 * max(1, abs(res[k])), (step, k, got[k], res[k])
+        for k, v in orc.p.items():
+            if k == "attention/V/bias":
+                continue
+            # atol: 2 % of one Adam update (lr = 1e-3)
+            assert np.allclose(model.get_weight(k), v, rtol=2e-4, atol=2e-5), (step, k, np.abs(model.get_weight(k) - v).max())
