@@ -185,50 +185,94 @@ class SyntheticGenerator:
 
 
 class PinnedPrefetcher:
-    """Double-buffered host->device staging for wide batches: wraps any generator; batch i+1 is
-    copied H2D from pinned memory on a side stream while the model steps on batch i.
+    """Double-buffered host->device staging for wide batches: wraps any generator; batch i+1 is fetched from the
+    generator and copied H2D on a side stream BY A WORKER THREAD while the model steps on batch i (at full-cortex width
+    moving an 84 MB batch takes longer than the GPU step, so none of it may sit on the launching thread).
+    Arrays the generator hands over in pinned memory (torch pinned tensors or numpy views of them) are DMA-ed
+    asynchronously from where they are -- a generator that does so must not rewrite such an array before two more
+    batches have been requested; pageable arrays go through the runtime's own staged copy, on the worker thread
+    (measured on MI355X, tools/full_cortex_bench.py: a private pageable->pinned memcpy is 5x slower than that).
     ``betas_dtype="float16"``: the betas cross PCIe as IEEE half (half the bytes of the tensor that dominates the
-    transfer: 84 MB per batch at full-cortex width) and are widened by the staging kernel (tnt_stage_batch_h16);
-    an opt-in approximation (10-bit mantissa on z-scored betas), off by default so that results match the reference."""
+    transfer) and are widened by the staging kernel (tnt_stage_batch_h16); an opt-in approximation (10-bit mantissa on
+    z-scored betas), off by default so that results match the reference.  It pays when the generator already yields
+    float16 (a dataset stored that way); a float32 source is converted on the worker thread, which costs more than
+    the bytes save."""
 
-    def __init__(self, generator, device, betas_dtype="float32"):
+    def __init__(self, generator, device, betas_dtype="float32", threaded=True):
         assert betas_dtype in ("float32", "float16")
         self.betas_dtype = np.float16 if betas_dtype == "float16" else np.float32
         self.gen, self.device = generator, torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._next = None
-        self._pinned = [None, None]
+        # two slots of persistent device buffers.  Batch i lives in slot i & 1 from its copy until batch i + 2 is staged:
+        # a slot is overwritten only after the compute stream has consumed the batch it held (an event recorded on the
+        # compute stream when the NEXT batch is requested); the host keeps the source arrays of a slot alive until the
+        # slot's asynchronous copy has completed.
+        self._dev = [None, None]
+        self._h2d = [None, None]
+        self._src = [None, None]
+        self._pool = None
+        if threaded and self.stream is not None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="tnt-prefetch")
 
     def __len__(self):
         return len(self.gen)
 
     def on_epoch_end(self):
+        self._drain()
         self.gen.on_epoch_end()
         self._next = None
 
-    def _stage(self, index, slot):
+    def _drain(self):
+        if self._next is not None and hasattr(self._next[1], "result"):
+            self._next[1].result()
+
+    def _stage(self, index, slot, consumed=None):
         (x, cap, a0, c0), tgt = self.gen[index][:2]
-        arrs = [np.ascontiguousarray(a) for a in (x, cap, a0, c0, tgt)]
-        arrs[0] = arrs[0].astype(self.betas_dtype, copy=False)
+        ts = [a if isinstance(a, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(a)) for a in (x, cap, a0, c0, tgt)]
+        want0 = torch.float16 if self.betas_dtype is np.float16 else torch.float32
+        if ts[0].dtype != want0:
+            ts[0] = ts[0].to(want0)
         if self.stream is None:
-            return tuple(torch.as_tensor(a) for a in arrs), None
-        if self._pinned[slot] is None or any(p.shape != a.shape for p, a in zip(self._pinned[slot], arrs)):
-            self._pinned[slot] = [torch.empty(a.shape, dtype=torch.as_tensor(a).dtype).pin_memory() for a in arrs]
+            return tuple(ts), None
+        torch.cuda.set_device(self.device)
+        if self._h2d[slot] is not None:
+            self._h2d[slot].synchronize()            # the previous copy into this slot is done: its sources may go
+        if self._dev[slot] is None or any(d.shape != t.shape or d.dtype != t.dtype for d, t in zip(self._dev[slot], ts)):
+            self._dev[slot] = [torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in ts]
         with torch.cuda.stream(self.stream):
-            outs = []
-            for p, a in zip(self._pinned[slot], arrs):
-                p.copy_(torch.as_tensor(a))
-                outs.append(p.to(self.device, non_blocking=True))
+            if consumed is not None:
+                self.stream.wait_event(consumed)     # the batch this slot held has been read by the compute stream
+            for src, dv in zip(ts, self._dev[slot]):
+                dv.copy_(src, non_blocking=True)     # pinned source: asynchronous DMA; pageable: the runtime's staged copy
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        return tuple(outs), ev
+        self._h2d[slot], self._src[slot] = ev, ts
+        return tuple(self._dev[slot]), ev
+
+    def _submit(self, index, consumed):
+        if self._pool is None:
+            return self._stage(index, index & 1, consumed)
+        return self._pool.submit(self._stage, index, index & 1, consumed)
 
     def __getitem__(self, index):
+        consumed = None
+        if self.stream is not None:
+            # everything the compute stream has been given so far -- the step on the previous batch included -- precedes this
+            consumed = torch.cuda.Event()
+            consumed.record(torch.cuda.current_stream())
         if self._next is None or self._next[0] != index:
-            self._next = (index, self._stage(index, index & 1))
-        (x, cap, a0, c0, tgt), ev = self._next[1]
+            self._drain()
+            self._next = (index, self._submit(index, consumed))
+        staged = self._next[1]
+        if hasattr(staged, "result"):
+            staged = staged.result()
+        (x, cap, a0, c0, tgt), ev = staged
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
         nxt = index + 1
-        self._next = (nxt, self._stage(nxt, nxt & 1)) if nxt < len(self.gen) else None
+        self._next = (nxt, self._submit(nxt, consumed)) if nxt < len(self.gen) else None
         return ((x, cap, a0, c0), tgt)

@@ -220,3 +220,64 @@ def test_pinned_prefetcher_feeds_the_step(betas_dtype):
         assert ra == rb, (i, ra, rb)
     torch.cuda.synchronize()
     assert torch.equal(a.arena.theta, b.arena.theta)
+
+
+def test_pinned_prefetcher_without_host_syncs():
+    """The prefetcher's point is a host that runs ahead of the device: 12 steps over 6 wide batches x 2 epochs with
+    NO host read in between (metrics left on the device), against the same batches fed one by one with a
+    synchronisation after each.  Bit-identical weights: no batch was torn by a reused pinned or device slot."""
+    from masters_thesis_amd.data import SyntheticGenerator, PinnedPrefetcher
+    a, b, (B, N, T, V, U, E) = _twin_models(rates=(0.0, 0.2, 0.2))
+    gen = SyntheticGenerator(6, B, N, U, T, V, seed=4)
+    pre = PinnedPrefetcher(SyntheticGenerator(6, B, N, U, T, V, seed=4), "cuda")
+    for epoch in range(2):
+        for i in range(len(gen)):
+            a.train_step(gen[i])
+            torch.cuda.synchronize()
+        for i in range(len(pre)):
+            b.train_step(pre[i])                      # no .as_floats(), no synchronize
+        pre.on_epoch_end()
+    torch.cuda.synchronize()
+    assert torch.equal(a.arena.theta, b.arena.theta)
+
+
+def test_full_cortex_width_through_the_prefetcher():
+    """the reference's generator yields betas of width 327 684 (data_generator_guse.py:129-171; 84 MB per
+    batch of 64 in float32).  The region-wise model over that width (360 regions that together reference a subset of
+    the cortex, as the Glasser groups do) trained through PinnedPrefetcher with float32 and with float16 on-wire betas
+    and through compact_groups (only the referenced voxels cross PCIe): same losses as feeding the host batch directly."""
+    from masters_thesis_amd.data import PinnedPrefetcher
+    from masters_thesis_amd.lc_nic import NIC, synthetic_groups, compact_groups
+    from masters_thesis_amd.optimizers import Adam
+    N, R, D, B, T, V, U = 327684, 360, 32, 64, 15, 5001, 512
+    rng = np.random.default_rng(12)
+    groups = synthetic_groups(62756, R, D, seed=42)                        # the visual-cortex subset (62 756 voxels) ...
+    perm = np.sort(rng.choice(N, 62756, replace=False))
+    groups = ([perm[np.asarray(g)] for g in groups[0]], groups[1])         # ... scattered over the full cortex
+
+    class Gen:
+        def __len__(self): return 3
+        def on_epoch_end(self): pass
+        def __getitem__(self, i):
+            r = np.random.default_rng(100 + i)
+            x = r.standard_normal((B, N)).astype(np.float32)
+            data, tgt = synth_batch(B, 4, T, V, U, r)
+            return ((x, data[1], data[2], data[3]), tgt)
+    gen = Gen()
+    mk = lambda g: NIC(g, U, 512, 512, 32, V, T, 0, 0.2, 0.2, 0.2, 0.2, 0.2, 0.01, 0.001, 3e-5, 1e-5, seed=5)
+    a, b = mk(groups), mk(groups)
+    for m in (a, b):
+        m.compile(Adam(1e-4, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    pre = PinnedPrefetcher(gen, "cuda")
+    la = [a.train_step(gen[i]).as_floats()["loss"] for i in range(3)]
+    lb = [b.train_step(pre[i]).as_floats()["loss"] for i in range(3)]
+    assert la == lb and np.isfinite(la).all()
+    # compact_groups: the same function on the referenced columns only (62 756 of 327 684: 16 MB instead of 84 MB per batch)
+    cols, cg = compact_groups(groups)
+    c = mk(cg)
+    c.compile(Adam(1e-4, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    lc = []
+    for i in range(3):
+        (x, cap, a0, c0), tgt = gen[i]
+        lc.append(c.train_step(((np.ascontiguousarray(x[:, cols]), cap, a0, c0), tgt)).as_floats()["loss"])
+    assert np.allclose(lc, la, rtol=1e-5)
