@@ -300,24 +300,50 @@ class ModelBase:
         return _LayerView(self, name, self.layers_spec[name])
 
     def save_weights(self, path):
-        """ModelCheckpoint(save_weights_only=True) target (main.py:168-190).  Written as .npz with
-        keras layer/weight names and keras layouts (h5py is not available offline)."""
+        """ModelCheckpoint(save_weights_only=True) target (main.py:168-190).  ``*.h5`` / ``*.hdf5``: a Keras weight file
+        (layer_names / weight_names attributes, one float32 dataset per weight, keras layouts), written by the
+        pure-Python h5lite module -- readable by h5py / Keras ``load_weights(by_name=True)`` wherever the layer names
+        agree.  Anything else: ``.npz`` with the same names and layouts."""
+        path = str(path)
+        if path.endswith((".h5", ".hdf5")):
+            from . import h5lite
+            layers = OrderedDict((layer, [(f"{layer}/{w}:0", self.get_weight(f"{layer}/{w}")) for w in ws])
+                                 for layer, ws in self.layers_spec.items())
+            h5lite.write_keras_weights(path, layers)
+            return
         arrs = {k.replace("/", "__"): v for k, v in self.get_weights_dict().items()}
         with open(path, "wb") as f:
             np.savez(f, **arrs)
 
-    def load_weights(self, path, by_name=True, skip_mismatch=False):
-        """model.load_weights(path, by_name=True, skip_mismatch=True) -- eval.py:140."""
-        with np.load(path, allow_pickle=False) as z:
-            for k in z.files:
-                n = k.replace("__", "/")
-                if n not in self.keras_shapes:
+    def load_weights(self, path, by_name=True, skip_mismatch=False, name_map=None):
+        """model.load_weights(path, by_name=True, skip_mismatch=True) -- eval.py:140.  Reads ``.npz`` (this library) and
+        Keras ``.h5`` weight files (h5lite: contiguous float datasets, old-style groups -- what Keras / h5py write).
+        Weights are matched BY NAME: ``<layer>/<weight>`` of ``model.layers_spec``; ``name_map`` ({file layer name: model
+        layer name}) renames layers of a file whose auto-generated Keras names differ (the reference's checkpoints are
+        not available here, so their exact layer names are unpinned).  Unknown layers are ignored (by_name semantics);
+        a shape mismatch raises unless ``skip_mismatch``."""
+        path = str(path)
+        name_map = name_map or {}
+        items = []
+        if path.endswith((".h5", ".hdf5")):
+            from . import h5lite
+            _, layers = h5lite.read_keras_weights(path)
+            for ln, ws in layers.items():
+                tgt = name_map.get(ln, ln)
+                for wn, arr in ws:
+                    w = wn.split("/")[-1].split(":")[0]
+                    items.append((f"{tgt}/{w}", arr))
+        else:
+            with np.load(path, allow_pickle=False) as z:
+                items = [(name_map.get(k.replace("__", "/"), k.replace("__", "/")), z[k]) for k in z.files]
+        for n, arr in items:
+            if n not in self.keras_shapes:
+                continue
+            if tuple(arr.shape) != tuple(self.keras_shapes[n]):
+                if skip_mismatch:
                     continue
-                if tuple(z[k].shape) != tuple(self.keras_shapes[n]):
-                    if skip_mismatch:
-                        continue
-                    raise ValueError(f"shape mismatch for {n}: {z[k].shape} vs {self.keras_shapes[n]}")
-                self.set_weight(n, z[k])
+                raise ValueError(f"shape mismatch for {n}: {arr.shape} vs {self.keras_shapes[n]}")
+            self.set_weight(n, arr)
 
     def count_params(self):
         return int(sum(np.prod(s) for s in self.keras_shapes.values()))
@@ -495,13 +521,31 @@ class ModelBase:
             if f(*args) != 0:
                 raise RuntimeError(f"{name} failed while replaying launch plan {key}")
 
+    def _dp_mean_logs(self, logs):
+        """epoch logs averaged over the data-parallel ranks (same keys on every rank, sorted)"""
+        import torch.distributed as dist
+        keys = sorted(logs)
+        vals = _dp_reduce([logs[k] for k in keys], dist.ReduceOp.SUM)
+        return {k: v / self.dp_world for k, v in zip(keys, vals)}
+
+    def _dp_any(self, flag):
+        import torch.distributed as dist
+        return _dp_reduce([1.0 if flag else 0.0], dist.ReduceOp.MAX)[0] > 0
+
     # ------------------------------------------------------------------ fit loop
     def fit(self, x=None, epochs=1, steps_per_epoch=None, batch_size=None, callbacks=None, validation_data=None,
-            validation_steps=None, initial_epoch=0, verbose=1, **kw):
+            validation_steps=None, initial_epoch=0, verbose=1, keras_last_batch_logs=False, **kw):
         """model.fit(generator, epochs, steps_per_epoch, batch_size, callbacks, validation_data,
         validation_steps, initial_epoch) -- main.py:269-281.  Honours the keras callback protocol
         (on_train_begin, on_epoch_begin, on_train_batch_end, on_test_batch_end, on_epoch_end,
-        on_train_end; Callbacks/EpochLoss.py:21-52)."""
+        on_train_end; Callbacks/EpochLoss.py:21-52).
+        Epoch logs: the MEAN of the per-batch logs (what keras' compiled metrics report).  The reference's models
+        override train_step / test_step and return plain tensors, for which Keras 2.4 hands ``on_epoch_end`` the
+        LAST batch's values -- ``keras_last_batch_logs=True`` reproduces that (it matters to
+        ModelCheckpoint(save_best_only) / EarlyStopping on ``val_loss``); the mean is the default because it is
+        what those callbacks are meant to see.
+        Data parallel: the epoch logs are averaged over the ranks and ``stop_training`` is OR-ed before the
+        callbacks' decision takes effect, so every rank leaves the loop in the same epoch."""
         callbacks = list(callbacks or [])
         for cb in callbacks:
             if hasattr(cb, "set_model"):
@@ -514,7 +558,7 @@ class ModelBase:
         for epoch in range(initial_epoch, epochs):
             _call(callbacks, "on_epoch_begin", epoch, {})
             n = len(x) if steps_per_epoch is None else steps_per_epoch
-            sums, t0 = {}, time.time()
+            sums, last, t0 = {}, {}, time.time()
             for b in range(n):
                 _call(callbacks, "on_train_batch_begin", b, {})
                 try:
@@ -523,11 +567,12 @@ class ModelBase:
                     logs = self.train_step(x[b]).as_floats()
                 for k, v in logs.items():
                     sums[k] = sums.get(k, 0.0) + v
+                last = logs
                 _call(callbacks, "on_train_batch_end", b, logs)
-            elogs = {k: v / max(n, 1) for k, v in sums.items()}
+            elogs = dict(last) if keras_last_batch_logs else {k: v / max(n, 1) for k, v in sums.items()}
             if validation_data is not None:
                 nv = len(validation_data) if validation_steps is None else validation_steps
-                vs = {}
+                vs, vlast = {}, {}
                 for b in range(nv):
                     try:
                         logs = self.test_step(validation_data[b]).as_floats()
@@ -535,8 +580,12 @@ class ModelBase:
                         logs = self.test_step(validation_data[b]).as_floats()
                     for k, v in logs.items():
                         vs[k] = vs.get(k, 0.0) + v
+                    vlast = logs
                     _call(callbacks, "on_test_batch_end", b, logs)
-                elogs.update({f"val_{k}": v / max(nv, 1) for k, v in vs.items()})
+                elogs.update({f"val_{k}": v for k, v in vlast.items()} if keras_last_batch_logs else
+                             {f"val_{k}": v / max(nv, 1) for k, v in vs.items()})
+            if self.dp_world > 1:
+                elogs = self._dp_mean_logs(elogs)
             if verbose:
                 print(f"epoch {epoch + 1}/{epochs} - {time.time() - t0:.1f}s - " +
                       " - ".join(f"{k}: {v:.4f}" for k, v in elogs.items()))
@@ -546,10 +595,20 @@ class ModelBase:
             _call(callbacks, "on_epoch_end", epoch, elogs)
             if hasattr(x, "on_epoch_end"):
                 x.on_epoch_end()
+            if self.dp_world > 1:
+                self.stop_training = self._dp_any(self.stop_training)
             if self.stop_training:
                 break
         _call(callbacks, "on_train_end", {})
         return history
+
+
+def _dp_reduce(values, op):
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor(values, dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=op)
+    return t.cpu().tolist()
 
 
 def _call(callbacks, name, *args):

@@ -152,3 +152,54 @@ def test_dp2_batchnorm_stats_are_per_replica_and_averaged_at_checkpoint(tmp_path
     assert np.array_equal(res[0][2], res[1][2])                       # trainables stay identical
     with np.load(os.path.join(str(tmp_path), "w.npz")) as z:          # written once, by rank 0
         assert np.allclose(z["batch_norm__moving_mean"], want, atol=1e-7)
+
+
+def _fit_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import masters_thesis_amd.ops as ops
+    from masters_thesis_amd import dp
+    from masters_thesis_amd.optimizers import Adam
+    from masters_thesis_amd.callbacks import Callback
+    from mock_backend import MockBackend
+    ops.set_backend(MockBackend())
+    model = _make("nic", seed=100 + rank)
+    model.compile(Adam(1e-3, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    dp.attach(model)
+    rng = np.random.default_rng(50 + rank)           # rank-local batches: rank-local losses
+    d = DIMS
+    from helpers import synth_batch
+    batches = [synth_batch(d["B"], d["N"], d["T"], d["V"], d["U"], rng) for _ in range(2)]
+    seen = []
+
+    class StopOnRank1(Callback):                     # a rank-local decision (what EarlyStopping on a rank-local val_loss is)
+        def on_epoch_end(self, epoch, logs=None):
+            seen.append(dict(logs))
+            if rank == 1 and epoch == 1:
+                self.model.stop_training = True
+    hist = model.fit(batches, epochs=5, callbacks=[StopOnRank1()], verbose=0)
+    q.put((rank, len(hist["loss"]), seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fit_logs_and_stop_flag_agree_across_ranks():
+    """fit() under data parallel: the epoch logs the callbacks see are the mean over the ranks (identical everywhere) and
+    a stop_training raised on ONE rank ends the loop on every rank in the same epoch (no rank is left in a collective)."""
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fit_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, n, seen = q.get(timeout=120)
+        res[r] = (n, seen)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0] == 2, (res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert a.keys() == b.keys() and all(abs(a[k] - b[k]) < 1e-12 for k in a)
