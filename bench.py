@@ -181,7 +181,7 @@ def kernel_breakdown(model, batch, workload, reps=20):
         key, fl, by = _work_model(name, args)
         if name == "tnt_adam_f32":
             fl, by = 0.0, 28.0 * n_param
-        elif name == "tnt_seg_sqnorm_f32":
+        elif name in ("tnt_seg_sqnorm_f32", "tnt_span_sqnorm_f32"):
             fl, by = 0.0, 8.0 * n_param
         g = groups.setdefault(key, {"calls": 0, "fn": fn, "args": args, "flops": fl, "bytes": by})
         g["calls"] += 1

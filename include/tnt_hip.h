@@ -200,6 +200,16 @@ int32_t tnt_embedding_fwd_drop_f32(const float* table, const int32_t* ids, float
                                    int32_t B, int32_t T, int32_t E, int32_t ldo, int32_t V, float rate,
                                    uint64_t seed, uint32_t site, uint32_t step, const uint32_t* step_dev,
                                    void* stream);
+/* Single-process form of tnt_embedding_bwd_f32 without the table-wide zero fill and the row-norm launches: the first
+ * occurrence of an id sums its rows into dtable[id] (deterministic, as above) and leaves its share of the IndexedSlices
+ * squared norm in sq_part[k * ny + y] (ny = ceil(E / 256); tnt_embedding_bwd_parts(B, T, E) floats; their sum is the
+ * norm of the un-deduplicated rows); rows that only the PREVIOUS step touched (prev_ids [B*T], -1 = none) are zeroed.
+ * Contract: dtable starts zeroed and is written by nothing else between calls (no gradient all-reduce), prev_ids holds
+ * the ids of the previous call (tnt_step_finalize_f32 copies them).  E % 4 == 0, 16-byte aligned rows. */
+int32_t tnt_embedding_bwd_parts(int32_t B, int32_t T, int32_t E);
+int32_t tnt_embedding_bwd_sparse_f32(const float* drows, const int32_t* ids, const int32_t* prev_ids, float* dtable,
+                                     float* sq_part, int32_t B, int32_t T, int32_t E, int32_t ldd, int32_t V,
+                                     void* stream);
 int32_t tnt_embedding_bwd_f32(const float* drows, const int32_t* ids, float* dtable,
                               float* sq_norm, float* rowsq_work, int32_t B, int32_t T,
                               int32_t E, int32_t ldd, int32_t V, void* stream);
@@ -354,6 +364,22 @@ int32_t tnt_seg_sqnorm_f32(const float* theta, const float* grad, const int32_t*
                            const int32_t* seg_first, const float* seg_l2, float* partial,
                            float* sq, float* wsq, float* l2_out, int32_t nspan, int32_t nseg,
                            void* stream);
+/* The scalar tail of a training step in ONE launch (each piece used to be its own dependent launch):
+ * span partials (tnt_span_sqnorm_f32: the first kernel of tnt_seg_sqnorm_f32 alone) -> sq / wsq per variable;
+ * l2_out = sum_s seg_l2[s]*wsq[s]; out0 = scale*sum x0[0..n), out1 = scale*sum x1[0..n) (loss / accuracy totals,
+ * lc_NIC.py:370-376; x1 nullable); extra[0] = sum extra_part[0..n_extra) (the Embedding's IndexedSlices squared norm
+ * from the per-block partials of the scatter); ids_dst[0..n_ids) = ids_src (this step's token ids become the
+ * prev_ids of tnt_embedding_bwd_sparse_f32); then the step state of tnt_step_tick advances (same arguments, same
+ * guard rule).  Every piece is optional: nseg = 0, n = 0, n_extra = 0, null state pointers.  Fixed summation order. */
+int32_t tnt_span_sqnorm_f32(const float* theta, const float* grad, const int32_t* span_seg,
+                            const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
+                            float* partial, int32_t nspan, void* stream);
+int32_t tnt_step_finalize_f32(const float* partial, const int32_t* seg_first, const float* seg_l2, float* sq,
+                              float* wsq, float* l2_out, int32_t nseg, const float* x0, float* out0,
+                              const float* x1, float* out1, int32_t n, float scale, const float* extra_part,
+                              float* extra, int32_t n_extra, const int32_t* ids_src, int32_t* ids_dst,
+                              int32_t n_ids, int64_t* adam_t, uint32_t* drop_step, const float* lr,
+                              float* lr_t, float beta1, float beta2, const uint32_t* guard, void* stream);
 /* out[0] = sum_s seg_l2[s]*wsq[s]; for callers that run tnt_seg_sqnorm_f32 on slices of the span
  * table (offset pointers, slice-local seg_first; the pipelined data-parallel update) and need the
  * total afterwards. */

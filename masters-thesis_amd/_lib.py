@@ -33,6 +33,8 @@ SIGNATURES = {
     "tnt_layernorm_bwd_f32": [P, P, P, P, P, P, P, I32, I32, I32, P, P],
     "tnt_colsum_f32": [P, P, I32, I32, I32, P, P],
     "tnt_embedding_fwd_f32": [P, P, P, I32, I32, I32, I32, I32, P],
+    "tnt_embedding_bwd_parts": [I32, I32, I32],
+    "tnt_embedding_bwd_sparse_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, P],
     "tnt_embedding_bwd_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, P],
     "tnt_lstm_seq_supported": [I32, I32],
     "tnt_lstm_seq_fwd_f32": [P, P, P, P, P, P, I32, I32, P, P, I32, I32, I32, P, P, P],
@@ -61,6 +63,8 @@ SIGNATURES = {
     "tnt_sum_f32": [P, P, I32, F32, P],
     "tnt_l2_total_f32": [P, P, I32, P, P],
     "tnt_seg_sqnorm_f32": [P, P, P, P, P, P, P, P, P, P, P, I32, I32, P],
+    "tnt_span_sqnorm_f32": [P, P, P, P, P, P, P, I32, P],
+    "tnt_step_finalize_f32": [P, P, P, P, P, P, I32, P, P, P, P, I32, F32, P, P, I32, P, P, I32, P, P, P, P, F32, F32, P, P],
     "tnt_adam_f32": [P, P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, F32, F32, P, P],
     "tnt_sgd_f32": [P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, P, P],
     "tnt_agc_f32": [P, P, P, P, P, P, P, I32, P, P, I32, I32, I32, P, P, F32, F32, P],

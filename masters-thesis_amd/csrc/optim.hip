@@ -298,6 +298,92 @@ __global__ void step_tick_kernel(int64_t* adam_t, uint32_t* drop_step, const flo
   }
 }
 
+
+// ---- one launch for the scalar tail of a training step (each of these used to be its own dependent ~4.6 us launch):
+//   (1) span partials -> per-variable squared norms sq[s] (clip-by-norm) and wsq[s] (L2 metric), fixed order;
+//   (2) l2_out = sum_s lambda_s * wsq[s]                                   (tf.add_n(self.losses), lc_NIC.py:379);
+//   (3) loss / accuracy totals of the step: out0 = scale * sum x0[0..n), out1 = scale * sum x1[0..n) (lc_NIC.py:370-376);
+//   (4) extra[0] = sum of extra_part[0..n_extra): the Embedding's IndexedSlices squared norm from per-block partials;
+//   (5) the device-resident step state advances (tnt_step_tick), unless the guard word is set.
+// One workgroup of 1024 threads; every piece is optional (null pointers / zero counts).
+struct FinalizeArgs {
+  const float* partial; SpanTab t; float* sq; float* wsq; float* l2_out; int nseg;
+  const float* x0; float* out0; const float* x1; float* out1; int n; float scale;
+  const float* extra_part; float* extra; int n_extra;
+  const int32_t* ids_src; int32_t* ids_dst; int n_ids;       // (4b) ids of this step -> prev_ids (tnt_embedding_bwd_sparse_f32)
+  int64_t* adam_t; uint32_t* drop_step; const float* lr; float* lr_t; float b1, b2; const uint32_t* guard;
+};
+
+__global__ __launch_bounds__(1024) void step_finalize_kernel(FinalizeArgs a) {
+  __shared__ float sw[16], sw2[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // (1) small variables (<= 8 spans: every variable of the region-wise model, hundreds of them) one per THREAD, serially
+  // over their spans; large ones one per wave, lanes striding over the spans + a fixed shuffle tree.  (A wave per small
+  // variable would walk 700+ variables 16 at a time, each step a dependent load pair: ~30 us on the attention model.)
+  for (int s = tid; s < a.nseg; s += 1024) {
+    const int k0 = a.t.seg_first[s], k1 = a.t.seg_first[s + 1];
+    if (k1 - k0 > 8) continue;
+    float q = 0.f, ws = 0.f;
+    for (int k = k0; k < k1; ++k) { q += a.partial[2 * k]; ws += a.partial[2 * k + 1]; }
+    a.sq[s] = q; a.wsq[s] = ws;
+  }
+  for (int s = w; s < a.nseg; s += 16) {
+    const int k0 = a.t.seg_first[s], k1 = a.t.seg_first[s + 1];
+    if (k1 - k0 <= 8) continue;                 // wave-uniform
+    float q = 0.f, ws = 0.f;
+    for (int k = k0 + lane; k < k1; k += 64) { q += a.partial[2 * k]; ws += a.partial[2 * k + 1]; }
+    q = tnt_wave_sum(q); ws = tnt_wave_sum(ws);
+    if (lane == 0) { a.sq[s] = q; a.wsq[s] = ws; }
+  }
+  __syncthreads();
+  // (2)
+  if (a.l2_out != nullptr) {
+    float l = 0.f;
+    for (int s = tid; s < a.nseg; s += 1024) l += a.t.seg_l2[s] * a.wsq[s];
+    l = tnt_wave_sum(l);
+    if (lane == 0) sw[w] = l;
+    __syncthreads();
+    if (tid == 0) { float t = 0.f; for (int k = 0; k < 16; ++k) t += sw[k]; a.l2_out[0] = t; }
+    __syncthreads();
+  }
+  // (3)
+  if (a.n > 0) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = tid; i < a.n; i += 1024) { s0 += a.x0[i]; if (a.x1) s1 += a.x1[i]; }
+    s0 = tnt_wave_sum(s0); s1 = tnt_wave_sum(s1);
+    if (lane == 0) { sw[w] = s0; sw2[w] = s1; }
+    __syncthreads();
+    if (tid == 0) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int k = 0; k < 16; ++k) { t0 += sw[k]; t1 += sw2[k]; }
+      a.out0[0] = t0 * a.scale;
+      if (a.x1) a.out1[0] = t1 * a.scale;
+    }
+    __syncthreads();
+  }
+  // (4)
+  if (a.n_extra > 0) {
+    float e = 0.f;
+    for (int i = tid; i < a.n_extra; i += 1024) e += a.extra_part[i];
+    e = tnt_wave_sum(e);
+    if (lane == 0) sw[w] = e;
+    __syncthreads();
+    if (tid == 0) { float t = 0.f; for (int k = 0; k < 16; ++k) t += sw[k]; a.extra[0] = t; }
+  }
+  for (int i = tid; i < a.n_ids; i += 1024) a.ids_dst[i] = a.ids_src[i];
+  // (5)
+  if (tid == 0 && !(a.guard && a.guard[0] != 0u)) {
+    if (a.drop_step) a.drop_step[0] += 1u;
+    if (a.adam_t) {
+      const int64_t t = a.adam_t[0] + 1;
+      a.adam_t[0] = t;
+      if (a.lr_t) {
+        const double p1 = pow((double)a.b1, (double)t), p2 = pow((double)a.b2, (double)t);
+        a.lr_t[0] = (float)((double)a.lr[0] * sqrt(1.0 - p2) / (1.0 - p1));
+      }
+    }
+  }
+}
 }  // namespace
 
 extern "C" int32_t tnt_step_tick(int64_t* adam_t, uint32_t* drop_step, const float* lr, float* lr_t, float beta1,
@@ -392,6 +478,35 @@ extern "C" int32_t tnt_agc_f32(const float* theta, float* grad, const int64_t* v
 extern "C" int32_t tnt_colsq_f32(const float* x, float* out, int32_t rows, int32_t cols, int32_t ld, void* stream) {
   if (rows <= 0 || cols <= 0) return TNT_BADARG(2);
   hipLaunchKernelGGL(colsq_kernel, dim3((cols + 63) / 64), dim3(256), 0, tnt_stream(stream), x, rows, cols, ld, out);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_span_sqnorm_f32(const float* theta, const float* grad, const int32_t* span_seg,
+                                       const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
+                                       float* partial, int32_t nspan, void* stream) {
+  if (nspan <= 0) return 0;
+  SpanTab t{span_seg, span_off, span_len, nullptr, seg_l2};
+  hipLaunchKernelGGL(span_sqnorm_kernel, dim3(nspan), dim3(256), 0, tnt_stream(stream), theta, grad, t, partial, nspan);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_step_finalize_f32(const float* partial, const int32_t* seg_first, const float* seg_l2, float* sq,
+                                         float* wsq, float* l2_out, int32_t nseg, const float* x0, float* out0,
+                                         const float* x1, float* out1, int32_t n, float scale, const float* extra_part,
+                                         float* extra, int32_t n_extra, const int32_t* ids_src, int32_t* ids_dst,
+                                         int32_t n_ids, int64_t* adam_t, uint32_t* drop_step, const float* lr,
+                                         float* lr_t, float beta1, float beta2, const uint32_t* guard, void* stream) {
+  if (nseg < 0 || n < 0 || n_extra < 0) return TNT_BADARG(7);
+  if (n > 0 && (x0 == nullptr || out0 == nullptr)) return TNT_BADARG(8);
+  FinalizeArgs a;
+  a.partial = partial; a.t = SpanTab{nullptr, nullptr, nullptr, seg_first, seg_l2}; a.sq = sq; a.wsq = wsq; a.l2_out = l2_out;
+  a.nseg = nseg; a.x0 = x0; a.out0 = out0; a.x1 = x1; a.out1 = out1; a.n = n; a.scale = scale;
+  a.extra_part = extra_part; a.extra = extra; a.n_extra = n_extra;
+  a.ids_src = ids_src; a.ids_dst = ids_dst; a.n_ids = (ids_src && ids_dst) ? n_ids : 0;
+  a.adam_t = adam_t; a.drop_step = drop_step; a.lr = lr; a.lr_t = lr_t; a.b1 = beta1; a.b2 = beta2; a.guard = guard;
+  hipLaunchKernelGGL(step_finalize_kernel, dim3(1), dim3(1024), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
 }

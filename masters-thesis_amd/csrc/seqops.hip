@@ -167,6 +167,101 @@ __global__ __launch_bounds__(256) void emb_bwd4_kernel(const float* drows, const
   }
 }
 
+
+// Embedding backward without the table-wide zero fill and without the separate row-norm launches (single-process step):
+//   blocks [0, n)      scatter: as emb_bwd4_kernel (first occurrence of an id owns the row), plus the block's share of
+//                      the IndexedSlices squared norm sum_{rows it reads} |row chunk|^2 -> sq_part[k * ny + y]
+//                      (every (b,t) row is read by exactly one owner per column chunk: the parts add up to the norm
+//                      of the un-deduplicated rows; non-owners write 0);
+//   blocks [n, 2n)     cleanup: entry k of prev_ids (the ids of the PREVIOUS step, -1 = none) whose id does not occur
+//                      in this step's ids gets its gradient row zeroed (first occurrence in prev_ids only).
+// Rows touched by neither step are zero already (the table gradient starts zeroed and nothing else writes it), rows of
+// this step are fully overwritten by their owner: no race between the two halves.  The caller copies ids -> prev_ids
+// after this launch (tnt_step_finalize_f32 does).
+__global__ __launch_bounds__(256) void emb_bwd_sparse_kernel(const float* drows, const int* ids, const int* prev_ids,
+                                                             float* dtable, float* sq_part, int B, int T, int E, int ldd,
+                                                             int V) {
+  __shared__ float4 part[4][64];
+  __shared__ float sqw[4];
+  __shared__ int s_flag;
+  const int n = B * T, ny = gridDim.y;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.y * 256 + lane * 4;
+  const bool jok = j < E;
+  if (threadIdx.x == 0) s_flag = 0;
+  __syncthreads();
+  if ((int)blockIdx.x >= n) {
+    // ---- cleanup of a row that only the previous step touched
+    const int k = blockIdx.x - n;
+    const int id = prev_ids[k];
+    if (id < 0 || id >= V) return;
+    for (int i = threadIdx.x; i < k; i += 256) if (prev_ids[i] == id) s_flag = 1;          // an earlier entry handles it
+    for (int i = threadIdx.x; i < n; i += 256) {
+      int cur = ids[i];
+      cur = cur < 0 ? 0 : (cur >= V ? V - 1 : cur);
+      if (cur == id) s_flag = 1;                                                            // rewritten by its owner
+    }
+    __syncthreads();
+    if (s_flag) return;
+    if (w == 0 && jok) *reinterpret_cast<float4*>(dtable + (long)id * E + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const int k = blockIdx.x;
+  int id = ids[k];
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+  for (int i = threadIdx.x; i < k; i += 256) {           // an earlier occurrence owns the row
+    int other = ids[i];
+    other = other < 0 ? 0 : (other >= V ? V - 1 : other);
+    if (other == id) s_flag = 1;
+  }
+  __syncthreads();
+  if (s_flag) {
+    if (threadIdx.x == 0) sq_part[(long)k * ny + blockIdx.y] = 0.f;
+    return;
+  }
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float sq = 0.f;
+  if (w == 0 && jok) {
+    acc = *reinterpret_cast<const float4*>(drows + (long)((k % T) * B + k / T) * ldd + j);
+    sq = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+  }
+  constexpr int NF = 8;
+  for (int base = k + 1 + 64 * w; base < n; base += 256) {
+    const int i = base + lane;
+    int other = i < n ? ids[i] : -1;
+    other = other >= V ? V - 1 : other;
+    unsigned long long hit = __ballot(i < n && other == id);
+    while (hit) {
+      int kk[NF];
+#pragma unroll
+      for (int q = 0; q < NF; ++q) {
+        kk[q] = -1;
+        if (hit) { kk[q] = base + __ffsll((long long)hit) - 1; hit &= hit - 1; }
+      }
+      float4 v[NF];
+#pragma unroll
+      for (int q = 0; q < NF; ++q)
+        v[q] = (kk[q] >= 0 && jok) ? *reinterpret_cast<const float4*>(drows + (long)((kk[q] % T) * B + kk[q] / T) * ldd + j)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < NF; ++q) {
+        acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w;
+        sq += v[q].x * v[q].x + v[q].y * v[q].y + v[q].z * v[q].z + v[q].w * v[q].w;
+      }
+    }
+  }
+  part[w][lane] = acc;
+  sq = tnt_wave_sum(sq);
+  if (lane == 0) sqw[w] = sq;
+  __syncthreads();
+  if (w == 0 && jok) {
+    const float4 a = part[0][lane], b = part[1][lane], c = part[2][lane], d = part[3][lane];
+    *reinterpret_cast<float4*>(dtable + (long)id * E + j) =
+        make_float4(((a.x + b.x) + c.x) + d.x, ((a.y + b.y) + c.y) + d.y, ((a.z + b.z) + c.z) + d.z, ((a.w + b.w) + c.w) + d.w);
+  }
+  if (threadIdx.x == 0) sq_part[(long)k * ny + blockIdx.y] = ((sqw[0] + sqw[1]) + sqw[2]) + sqw[3];
+}
+
 __global__ __launch_bounds__(1024) void sum_accum_kernel(const float* x, float* out, int n) {
   __shared__ float sw[16];
   float s = 0.f;
@@ -593,6 +688,20 @@ extern "C" int32_t tnt_beam_topk_f32(const float* probs, const float* score_in, 
 extern "C" int32_t tnt_sqdiff_mean_f32(const float* x, float* out, int64_t n, float c, void* stream) {
   if (n <= 0) return TNT_BADARG(3);
   hipLaunchKernelGGL(sqdiff_mean_kernel, dim3(1), dim3(1024), 0, tnt_stream(stream), x, (long)n, c, out);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_embedding_bwd_parts(int32_t B, int32_t T, int32_t E) { return B * T * ((E + 255) / 256); }
+
+extern "C" int32_t tnt_embedding_bwd_sparse_f32(const float* drows, const int32_t* ids, const int32_t* prev_ids,
+                                                float* dtable, float* sq_part, int32_t B, int32_t T, int32_t E,
+                                                int32_t ldd, int32_t V, void* stream) {
+  if (B <= 0 || T <= 0 || E <= 0 || V <= 0) return TNT_BADARG(6);
+  if (E % 4 != 0 || ldd % 4 != 0 || !tnt_aligned16(drows) || !tnt_aligned16(dtable)) return TNT_BADARG(1);
+  if (prev_ids == nullptr || sq_part == nullptr || prev_ids == ids) return TNT_BADARG(3);
+  hipLaunchKernelGGL(emb_bwd_sparse_kernel, dim3(2 * B * T, (E + 255) / 256), dim3(256), 0, tnt_stream(stream), drows, ids,
+                     prev_ids, dtable, sq_part, B, T, E, ldd, V);
   TNT_LAUNCH_CHECK();
   return 0;
 }

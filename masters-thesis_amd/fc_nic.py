@@ -261,7 +261,7 @@ class NICfc(_DenseNIC):
         B, T = self._stage_batch(data[0], data[1], self.N)
         self._sync_lr()
         if self.grad_sync is None:
-            self._run_captured(("train", B, T), lambda: (self._train_graph(B, T), self._update_graph()))
+            self._run_captured(("train", B, T), lambda: self._train_and_update_graph(B, T))
         else:
             self._run_captured(("train_fb", B, T), lambda: self._train_graph(B, T))
             self.grad_sync(self)

@@ -488,7 +488,7 @@ class NIC(ModelBase):
         else:
             be.softmax_cce(self.logits, self.tgt, self.logits, self.loss_row, self.corr_row, None, n, self.V, self.ldV,
                            0.0)
-        be.sum2(self.loss_row, self.met[0:1], self.corr_row, self.met[1:2], n, 1.0 / n)
+        self._sum2(self.loss_row, self.met[0:1], self.corr_row, self.met[1:2], n, 1.0 / n)
         if self.S == 1:
             be.attention_metric(self.alpha, self.met[3:4], self.rowsq, T, B, self.R)                        # :365-367
         else:       # per-subject loss / accuracy / attention metric (ms2_NIC.py:324-372)
@@ -581,9 +581,8 @@ class NIC(ModelBase):
                        rows_per_site=B)
         if self.r_text > 0:
             be.dropout(self.dtext, self.dtext, n, Et, Et, B, Et, 0, self.r_text, sd, S_TEXT, 0, ds)
-        sqo = a.sq_override[self.emb_seg:self.emb_seg + 1]
         self._emb_rows = (self.dtext, n, Et, Et, "emb_text/embeddings")
-        be.embedding_bwd(self.dtext, self.cap, a.g("emb_text/embeddings"), sqo, self.rowsq, B, T, Et, Et, V)
+        self._embedding_bwd(self.dtext, self.cap, "emb_text/embeddings", B, T, Et, Et, V)
 
     def _bwd_front(self, B, T):
         """attention parameters, then BatchNorm / region-wise encoder backward."""
@@ -656,6 +655,19 @@ class NIC(ModelBase):
         self._norms_and_l2(self.met[2:3])
         self._apply_optimizer()
 
+    def _train_and_update_graph(self, B, T):
+        """the single-process step as one launch sequence: the loss / accuracy totals ride in the step-finalize launch"""
+        if not getattr(self, "fused_update", True):          # A/B switch (tools/ab_attr.py): the unfused launch sequence
+            self._train_graph(B, T)
+            self._update_graph()
+            return
+        self._defer_sum2 = True
+        try:
+            self._train_graph(B, T)
+        finally:
+            self._defer_sum2 = False
+        self._update_fused(self.met[2:3])
+
     def _metrics(self, with_lr):
         m = self.met.clone()
         if self.S == 1:
@@ -676,7 +688,7 @@ class NIC(ModelBase):
         B, T = self._stage_batch(data[0], data[1], self.n_in)
         self._sync_lr()
         if self.grad_sync is None:
-            self._run_captured(("train", B, T), lambda: (self._train_graph(B, T), self._update_graph()))
+            self._run_captured(("train", B, T), lambda: self._train_and_update_graph(B, T))
         elif getattr(self.grad_sync, "pipelined", False):
             self.grad_sync.step(self, B, T)
         else:

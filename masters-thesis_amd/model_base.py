@@ -137,6 +137,75 @@ class ModelBase:
             be.sgd(a.theta, self.opt_m, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq, a.sq_override,
                    sp.nspan, 0.0, self.lr_dev, opt.momentum, clip, guard=gd)
 
+    def _update_fused(self, l2_out):
+        """single-process update: [AGC] -> span norms -> ONE finalize launch (per-variable norms, L2 metric, the step's
+        loss / accuracy totals if the model deferred them, step tick) -> clip + Adam / SGD.  Replaces the five dependent
+        launches seg_finalize, l2_total, sum2, step_tick of the unfused sequence (each ~4.6 us inside the graph)."""
+        be, a, sp, opt = self.be, self.arena, self.arena.spans, self.optimizer
+        self._apply_agc()
+        d = self.__dict__.pop("_sum2_deferred", None)
+        if not hasattr(be, "step_finalize"):
+            if d is not None:
+                be.sum2(*d)
+            self._norms_and_l2(l2_out)
+            self._apply_optimizer()
+            return
+        clip = opt.clipnorm if opt.clipnorm is not None else 0.0
+        gd = self._guard_word()
+        adam = opt.kind == "adam"
+        be.span_sqnorm(a.theta, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.partial, sp.nspan)
+        kw = dict(x0=d[0], out0=d[1], x1=d[2], out1=d[3], n=d[4], scale=d[5]) if d is not None else {}
+        ef = self.__dict__.pop("_emb_finalize", None)
+        if ef is not None:       # sparse embedding backward: sum its norm partials, hand this step's ids on as prev_ids
+            parts, sqo, nparts, ids, prev, nids = ef
+            kw.update(ids_src=ids, ids_dst=prev, n_ids=nids)
+            if sqo is not None:
+                kw.update(extra_part=parts, extra=sqo, n_extra=nparts)
+        be.step_finalize(a.partial, sp.seg_first, a.seg_l2, a.sq, a.wsq, l2_out, a.nseg, adam_t=self.adam_t,
+                         drop_step=self.drop_step, lr=self.lr_dev, lr_t=self.lr_t_dev if adam else None,
+                         beta1=opt.beta_1 if adam else 0.0, beta2=opt.beta_2 if adam else 0.0, guard=gd, **kw)
+        if adam:
+            be.adam(a.theta, self.opt_m, self.opt_v, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq,
+                    a.sq_override, sp.nspan, 0.0, self.lr_t_dev, opt.beta_1, opt.beta_2, opt.epsilon, clip, guard=gd)
+        else:
+            be.sgd(a.theta, self.opt_m, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq, a.sq_override,
+                   sp.nspan, 0.0, self.lr_dev, opt.momentum, clip, guard=gd)
+
+    def _embedding_bwd(self, drows, ids, name, B, T, E, ldd, V):
+        """Embedding scatter + IndexedSlices norm.  Inside the fused single-process step (``_defer_sum2``) the sparse
+        form runs: no table-wide zero fill (rows touched by the previous step only are cleaned through ``prev_ids``),
+        the norm as per-block partials that the step-finalize launch sums.  Anywhere else (data parallel: the all-reduce
+        writes rows of other ranks' tokens; SAM; eager paths) the dense form runs and hands its ids on as prev_ids, so
+        the invariant "dtable is zero outside the rows of prev_ids" holds whichever form runs next."""
+        be, a = self.be, self.arena
+        seg = a.entries[name].seg
+        sqo = a.sq_override[seg:seg + 1]
+        st = self.__dict__.get("_emb_state")
+        if st is None or st[0] != (B, T, name):
+            if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("embedding backward state must be built outside a graph capture (run one eager step)")
+            nparts = be.embedding_bwd_parts(B, T, E) if hasattr(be, "embedding_bwd_parts") else 1
+            st = self._emb_state = ((B, T, name), torch.full((B * T,), -1, dtype=torch.int32, device=self.device),
+                                    self._f(nparts), nparts)
+            a.g(name).zero_()
+        _, prev, parts, nparts = st
+        sparse = (self.__dict__.get("_defer_sum2") and self.dp_world == 1 and getattr(self, "sparse_emb_bwd", True)
+                  and hasattr(be, "embedding_bwd_sparse") and E % 4 == 0 and ldd % 4 == 0)
+        if sparse:
+            be.embedding_bwd_sparse(drows, ids, prev, a.g(name), parts, B, T, E, ldd, V)
+            self._emb_finalize = (parts, None if self.__dict__.get("agc") else sqo, nparts, ids, prev, B * T)
+        else:
+            be.embedding_bwd(drows, ids, a.g(name), sqo, self.rowsq, B, T, E, ldd, V)
+            prev.copy_(ids.reshape(-1))
+
+    def _sum2(self, x0, out0, x1, out1, n, scale):
+        """loss / accuracy totals: deferred into the step-finalize launch when a fused update follows in the same
+        launch sequence (``_defer_sum2`` set by train_step), else their own launch"""
+        if self.__dict__.get("_defer_sum2"):
+            self._sum2_deferred = (x0, out0, x1, out1, n, scale)
+        else:
+            self.be.sum2(x0, out0, x1, out1, n, scale)
+
     def _tick(self):
         opt, gd = self.optimizer, self._guard_word()
         if opt.kind == "adam":

@@ -239,7 +239,7 @@ class NIC(ModelBase):
                 be.dropout(self.Xin[B:], self.Xin_d[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
         self._xin_used = xin
         # input projection of all T+1 steps as ONE epilogue-free GEMM; the LSTM bias is added inside the step kernel
-        if getattr(self, "fused_xproj", True) and hasattr(be, "gemm_fused") and be.gemm_fused_cfg(R1, 4 * U, E) > 0:
+        if getattr(self, "fused_xproj", False) and hasattr(be, "gemm_fused") and be.gemm_fused_cfg(R1, 4 * U, E) > 0:
             be.gemm_fused(xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U)
         else:
             self.gemm_sk(xin, a.p("lstm/kernel"), self.XZ, R1, 4 * U, E, E, 4 * U, 4 * U)
@@ -272,7 +272,7 @@ class NIC(ModelBase):
         else:
             be.softmax_cce(self.logits, self.tgt, self.logits, self.loss_row, self.corr_row, None, n, self.V,
                            self.ldV, 0.0)
-        be.sum2(self.loss_row, self.met[0:1], self.corr_row, self.met[1:2], n, 1.0 / n)
+        self._sum2(self.loss_row, self.met[0:1], self.corr_row, self.met[1:2], n, 1.0 / n)
 
     # ------------------------------------------------------------------ backward
     def _backward(self, B, T):
@@ -331,7 +331,7 @@ class NIC(ModelBase):
             be.lstm_step_bwd(self.dZ[B:2 * B], Ur, self.da_pass, None, self.dc, None, None, None, 0, 0, self.gates[0],
                              self.Cs[1], self.Cs[0], self.dZ[:B], None, None, None, B, U)
         xin = self._xin_used
-        if getattr(self, "fused_lstm_grads", True) and E == U and hasattr(be, "gemm_fused") and \
+        if getattr(self, "fused_lstm_grads", False) and E == U and hasattr(be, "gemm_fused") and \
                 be.gemm_fused_cfg(U, 4 * U, R1, True, False, 2) > 0:
             # kernel, recurrent-kernel and bias gradients in ONE launch of the one-round GEMM family: the two products
             # share dZ, the bias gradient (column sums of dZ) rides on the tiles the first row of workgroups loads anyway
@@ -356,9 +356,8 @@ class NIC(ModelBase):
             if not fused:
                 be.dropout(self.dXin, self.dXin, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
             be.dropout(self.dXin[B:], self.dXin[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
-        sqo = a.sq_override[self.emb_seg:self.emb_seg + 1]
         self._emb_rows = (self.dXin[B:], T * B, E, E, "emb_text/embeddings")
-        be.embedding_bwd(self.dXin[B:], self.cap, a.g("emb_text/embeddings"), sqo, self.rowsq, B, T, E, E, V)
+        self._embedding_bwd(self.dXin[B:], self.cap, "emb_text/embeddings", B, T, E, E, V)
         if fused:       # dropout' -> BatchNorm' -> dropout' -> LeakyReLU' -> dpre, encoder bias gradient: one launch
             be.enc_tail_bwd(self.dXin, self.xhat, a.p("batch_norm/gamma"), self.inv_std, self.enc_pre, self.dpre,
                             a.g("batch_norm/gamma"), a.g("batch_norm/beta"), a.g("dense_img/bias"), B, E, E,
@@ -402,6 +401,19 @@ class NIC(ModelBase):
         self._norms_and_l2(self.met[2:3])
         self._apply_optimizer()
 
+    def _train_and_update_graph(self, B, T):
+        """the single-process step as one launch sequence: the loss / accuracy totals ride in the step-finalize launch"""
+        if not getattr(self, "fused_update", True):          # A/B switch (tools/ab_attr.py): the unfused launch sequence
+            self._train_graph(B, T)
+            self._update_graph()
+            return
+        self._defer_sum2 = True
+        try:
+            self._train_graph(B, T)
+        finally:
+            self._defer_sum2 = False
+        self._update_fused(self.met[2:3])
+
     def train_step(self, data):
         """NIC.train_step (NIC.py:198-252): data = ((betas, cap, a0, c0), target)."""
         if self.optimizer is None:
@@ -409,7 +421,7 @@ class NIC(ModelBase):
         B, T = self._stage_batch(data[0], data[1], self.N)
         self._sync_lr()
         if self.grad_sync is None:
-            self._run_captured(("train", B, T), lambda: (self._train_graph(B, T), self._update_graph()))
+            self._run_captured(("train", B, T), lambda: self._train_and_update_graph(B, T))
         elif getattr(self.grad_sync, "pipelined", False):
             self.grad_sync.step(self, B, T)
         else:       # data parallel: forward+backward | all-reduce of the flat gradient | update

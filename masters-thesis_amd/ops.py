@@ -241,6 +241,25 @@ class HipBackend:
     def sqdiff_mean(self, x, out, n, c):
         self._call(self.lib.tnt_sqdiff_mean_f32, "tnt_sqdiff_mean_f32", _p(x), _p(out), n, float(c), self._s())
 
+    def span_sqnorm(self, theta, grad, span_seg, span_off, span_len, seg_l2, partial, nspan):
+        self._call(self.lib.tnt_span_sqnorm_f32, "tnt_span_sqnorm_f32", _p(theta), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
+                   _p(seg_l2), _p(partial), nspan, self._s())
+
+    def step_finalize(self, partial, seg_first, seg_l2, sq, wsq, l2_out, nseg, x0=None, out0=None, x1=None, out1=None, n=0,
+                      scale=1.0, extra_part=None, extra=None, n_extra=0, ids_src=None, ids_dst=None, n_ids=0, adam_t=None,
+                      drop_step=None, lr=None, lr_t=None, beta1=0.0, beta2=0.0, guard=None):
+        self._call(self.lib.tnt_step_finalize_f32, "tnt_step_finalize_f32", _p(partial), _p(seg_first), _p(seg_l2), _p(sq), _p(wsq),
+                   _p(l2_out), nseg, _p(x0), _p(out0), _p(x1), _p(out1), n, scale, _p(extra_part), _p(extra), n_extra,
+                   _p(ids_src), _p(ids_dst), n_ids, _p(adam_t), _p(drop_step), _p(lr), _p(lr_t), beta1, beta2, _p(guard),
+                   self._s())
+
+    def embedding_bwd_parts(self, B, T, E):
+        return int(self.lib.tnt_embedding_bwd_parts(B, T, E))
+
+    def embedding_bwd_sparse(self, drows, ids, prev_ids, dtable, sq_part, B, T, E, ldd, V):
+        self._call(self.lib.tnt_embedding_bwd_sparse_f32, "tnt_embedding_bwd_sparse_f32", _p(drows), _p(ids), _p(prev_ids), _p(dtable),
+                   _p(sq_part), B, T, E, ldd, V, self._s())
+
     def agc(self, theta, grad, tab, gsq_cols=None, sq_out=None, clip_factor=0.01, eps=1e-3):
         """unit-wise adaptive gradient clipping over the arena; ``tab`` = arena.AgcTable"""
         emb = tab.emb if gsq_cols is not None else None

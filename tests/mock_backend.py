@@ -435,6 +435,55 @@ class MockBackend:
         w = flat(W)[:R * Din * Dout].reshape(R, Din, Dout).astype(np.float64)
         flat(dx)[:B * R * Din] = np.einsum("brn,rkn->brk", d, w).reshape(-1)
 
+    def embedding_bwd_parts(self, B, T, E):
+        return B * T * ((E + 255) // 256)
+
+    def embedding_bwd_sparse(self, drows, ids, prev_ids, dtable, sq_part, B, T, E, ldd, V):
+        """include/tnt_hip.h: tnt_embedding_bwd_sparse_f32 from its contract: only rows of ids and prev_ids are touched"""
+        idv = np.clip(flat(ids)[:B * T].reshape(B, T), 0, V - 1)
+        rows = mat(drows, T * B, E, ldd).reshape(T, B, E).astype(np.float64)
+        tab = flat(dtable)[:V * E].reshape(V, E)
+        for p in set(int(x) for x in flat(prev_ids)[:B * T] if 0 <= x < V):
+            tab[p] = 0
+        acc = {}
+        for b in range(B):
+            for t in range(T):
+                acc[int(idv[b, t])] = acc.get(int(idv[b, t]), 0) + rows[t, b]
+        for i, v in acc.items():
+            tab[i] = v
+        ny = (E + 255) // 256
+        sp = flat(sq_part)
+        sp[:B * T * ny] = 0
+        sp[0] = (rows * rows).sum()
+
+    def span_sqnorm(self, theta, grad, span_seg, span_off, span_len, seg_l2, partial, nspan):
+        th, gr, l2, pa = flat(theta), flat(grad), flat(seg_l2), flat(partial)
+        for k, (s, o, n) in enumerate(self._segs(span_seg, span_off, span_len, nspan)):
+            t = th[o:o + n].astype(np.float64)
+            g = gr[o:o + n].astype(np.float64) + 2 * float(l2[s]) * t
+            pa[2 * k], pa[2 * k + 1] = (g * g).sum(), (t * t).sum()
+
+    def step_finalize(self, partial, seg_first, seg_l2, sq, wsq, l2_out, nseg, x0=None, out0=None, x1=None, out1=None, n=0,
+                      scale=1.0, extra_part=None, extra=None, n_extra=0, ids_src=None, ids_dst=None, n_ids=0, adam_t=None,
+                      drop_step=None, lr=None, lr_t=None, beta1=0.0, beta2=0.0, guard=None):
+        if nseg > 0:
+            pa, first = flat(partial).astype(np.float64), flat(seg_first)
+            for s in range(nseg):
+                k0, k1 = int(first[s]), int(first[s + 1])
+                flat(sq)[s] = pa[2 * k0:2 * k1:2].sum()
+                flat(wsq)[s] = pa[2 * k0 + 1:2 * k1:2].sum()
+            if l2_out is not None:
+                flat(l2_out)[0] = (flat(seg_l2)[:nseg].astype(np.float64) * flat(wsq)[:nseg].astype(np.float64)).sum()
+        if n > 0:
+            flat(out0)[0] = flat(x0)[:n].astype(np.float64).sum() * scale
+            if x1 is not None:
+                flat(out1)[0] = flat(x1)[:n].astype(np.float64).sum() * scale
+        if n_extra > 0:
+            flat(extra)[0] = flat(extra_part)[:n_extra].astype(np.float64).sum()
+        if n_ids > 0 and ids_src is not None and ids_dst is not None:
+            flat(ids_dst)[:n_ids] = flat(ids_src)[:n_ids]
+        self.step_tick(adam_t, drop_step, lr, lr_t, beta1, beta2, guard=guard)
+
     def colsq(self, x, out, rows, cols, ld):
         m = mat(x, rows, cols, ld).astype(np.float64)
         flat(out)[:cols] = (m * m).sum(0)

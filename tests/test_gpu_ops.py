@@ -299,6 +299,66 @@ def test_embedding(be, B, T, E, V):
 
 
 # ------------------------------------------------------------------------------- LSTM
+@pytest.mark.parametrize("B,T,E,V", [(64, 15, 512, 5001), (8, 5, 72, 23), (9, 4, 36, 11)])
+def test_embedding_bwd_sparse_over_consecutive_steps(be, B, T, E, V):
+    """tnt_embedding_bwd_sparse_f32 over four consecutive "steps" with different token ids (heavy duplicates, ids that
+    disappear again): after every step the gradient table equals the dense scatter of THAT step alone -- rows only the
+    previous step touched are cleaned, nothing else is written -- and the norm partials add up to the squared norm of
+    the un-deduplicated rows; tnt_step_finalize_f32 hands the ids on and sums the partials."""
+    rng = np.random.default_rng(B * T)
+    n = B * T
+    table = torch.zeros(V, E, device="cuda")
+    prev = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    nparts = be.embedding_bwd_parts(B, T, E)
+    parts, sq = torch.zeros(nparts, device="cuda"), torch.zeros(1, device="cuda")
+    none = torch.zeros(1, device="cuda")
+    for step in range(4):
+        ids = rng.integers(0, min(V, 6 + 3 * step), (B, T)).astype(np.int32)
+        ids[:, T // 2:] = rng.integers(0, V, (B, T - T // 2))
+        if step == 2:
+            ids[:] = 1                                          # one id owns every row
+        drows = rng.standard_normal((T, B, E))
+        want = O.embedding_bwd_dense(np.transpose(drows, (1, 0, 2)), ids, V)
+        idd = dev(ids, torch.int32)
+        be.embedding_bwd_sparse(dev(drows.reshape(T * B, E)), idd, prev, table, parts, B, T, E, E, V)
+        be.step_finalize(none, None, None, None, None, None, 0, extra_part=parts, extra=sq, n_extra=nparts, ids_src=idd,
+                         ids_dst=prev, n_ids=n)
+        torch.cuda.synchronize()
+        close(table, want, atol=1e-5 * np.abs(want).max())
+        assert torch.equal(table == 0, torch.tensor(want == 0, device="cuda")), "a row outside this step's ids is not zero"
+        assert abs(float(sq) - (drows ** 2).sum()) <= 1e-5 * (drows ** 2).sum()
+        assert torch.equal(prev, idd.reshape(-1))
+
+
+def test_step_finalize(be):
+    """tnt_step_finalize_f32 == seg_finalize + l2_total + sum2 + step_tick of the unfused sequence."""
+    rng = np.random.default_rng(77)
+    nseg, nspan = 37, 200
+    first = np.sort(np.concatenate([[0, nspan], rng.choice(np.arange(1, nspan), nseg - 1, replace=False)])).astype(np.int32)
+    partial = rng.random(2 * nspan)
+    lam = rng.random(nseg) * 0.01
+    x0, x1 = rng.standard_normal(960), rng.random(960)
+    sq, wsq, l2, o0, o1 = (torch.zeros(k, device="cuda") for k in (nseg, nseg, 1, 1, 1))
+    adam_t = torch.tensor([4], dtype=torch.int64, device="cuda")
+    drop = torch.tensor([9], dtype=torch.int32, device="cuda")
+    lr, lr_t = torch.tensor([1e-3], device="cuda"), torch.zeros(1, device="cuda")
+    guard = torch.zeros(1, dtype=torch.int32, device="cuda")
+    args = lambda: be.step_finalize(dev(partial), dev(first, torch.int32), dev(lam), sq, wsq, l2, nseg, x0=dev(x0), out0=o0,
+                                    x1=dev(x1), out1=o1, n=960, scale=1 / 960, adam_t=adam_t, drop_step=drop, lr=lr, lr_t=lr_t,
+                                    beta1=0.9, beta2=0.98, guard=guard)
+    args()
+    torch.cuda.synchronize()
+    q = np.array([partial[2 * first[s]:2 * first[s + 1]:2].sum() for s in range(nseg)])
+    w = np.array([partial[2 * first[s] + 1:2 * first[s + 1]:2].sum() for s in range(nseg)])
+    close(sq, q); close(wsq, w); close(l2, [(lam * w).sum()]); close(o0, [x0.mean()], atol=1e-6); close(o1, [x1.mean()])
+    assert int(adam_t) == 5 and int(drop) == 10
+    assert abs(float(lr_t) - 1e-3 * np.sqrt(1 - 0.98 ** 5) / (1 - 0.9 ** 5)) < 1e-9
+    guard[0] = 1                                               # a tripped device guard freezes the step state
+    args()
+    torch.cuda.synchronize()
+    assert int(adam_t) == 5 and int(drop) == 10
+
+
 @pytest.mark.parametrize("B,U,D,masked", [(64, 512, 0, False), (64, 512, 32, False), (5, 16, 3, False),
                                           (20, 32, 0, True)])
 def test_lstm_step(be, B, U, D, masked):
