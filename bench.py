@@ -35,7 +35,9 @@ MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak
 # HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes), by call
 # group; filled from the summaries committed under profiles/ (None = not collected for that kernel)
 PMC_TRAFFIC = {
-    "dense": {"tnt_gemm_f32 NN 960x5001x512": (int((2 * 13029.1 + 18885.8) * 1024), "profiles/r01_gemm_head_pmc_v3.txt")},
+    "dense": {"tnt_gemm_f32 NN 960x5001x512": (int((2 * 13029.1 + 18885.8) * 1024), "profiles/r01_gemm_head_pmc_v3.txt"),
+              "tnt_lstm_seq_fwd_f32 S=16 B=64 U=512": (int((2 * 13424.4 + 14276.4) * 1024), "profiles/r02_lstm_seq_pmc.txt"),
+              "tnt_lstm_seq_bwd_f32 S=16 B=64 U=512": (int((2 * 18487.1 + 56852.5) * 1024), "profiles/r02_lstm_seq_pmc.txt")},
     "attention": {"tnt_gemm_f32 NN 960x5001x256": (int((2 * 6575.1 + 18885.0) * 1024), "profiles/r01_gemm_head_c3_pmc.txt")},
 }
 STEP_GFLOP = {"dense": 30.3, "attention": 22.0}          # SURVEY 8d, whole training step

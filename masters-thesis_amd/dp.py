@@ -42,6 +42,38 @@ def make_grad_sync(world, bucket_elems=None):
     return sync
 
 
+def _whole_step_graph(sync, m, key, body):
+    """ONE hipGraph for the whole data-parallel step, collectives included.  Under capture ProcessGroupNCCL enqueues
+    each ``async_op`` collective on its own stream behind an event of the capturing stream -- a forked branch of the
+    graph -- and ``work.wait()`` joins the branch, so the captured graph has exactly the overlap structure of the
+    segmented schedule without its six launch boundaries (each graph launch costs 15-20 us of device idle time, a
+    launch plan ~6 us of host time per kernel).  Tried once per (model, key): if the runtime refuses the capture the
+    segmented schedule takes over for good.  Off with TNT_DP_ONE_GRAPH=0; gloo (CPU tests) always runs segmented."""
+    if sync.one_graph is False or m.device.type != "cuda" or not m.use_graph or dist.get_backend() != "nccl":
+        return False
+    st = m._graphs.get(key)
+    if st is None:                       # first call: eager warm-up through the segmented path (creates buffers, comms)
+        m._graphs[key] = "pending"
+        return False
+    if st == "pending":
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                body()
+        except Exception as ex:          # noqa: BLE001 -- any capture failure means: not supported here
+            sync.one_graph = False
+            m._graphs.pop(key, None)
+            sync.capture_error = repr(ex)
+            torch.cuda.synchronize()
+            return False
+        m._graphs[key] = g
+        g.replay()
+        return True
+    st.replay()
+    return True
+
+
 class PipelinedDenseSync:
     """DP schedule for the dense-encoder NIC (config 2), shaped for xGMI point-to-point links.
     Six launch segments (hipGraphs or recorded launch plans, see ``eager`` below); every collective is issued async
@@ -79,6 +111,8 @@ class PipelinedDenseSync:
         self.world = world
         self._bufs = {}
         self._slices = None
+        self.one_graph = os.environ.get("TNT_DP_ONE_GRAPH", "1") != "0"
+        self.capture_error = None
 
     def _gather(self, out, t):
         if dist.get_backend() == "gloo":
@@ -108,6 +142,23 @@ class PipelinedDenseSync:
         s_enc, s_head, s_mid = self._slices
         front0, lstm0, head0 = e["dense_img/bias"].off, e["lstm/kernel"].off, e["time_distributed_softmax/kernel"].off
         x_used = m.xd if m.r_in > 0 else m.x
+
+        def body():
+            m._forward(B, T, True); m._loss_metrics(B, T, True); m._bwd_head(B, T)
+            w_head, w_x = self._ar(a.grad[head0:]), self._gather(x_all, x_used)
+            m._bwd_seq_lstm(B, T)
+            w_lstm = self._ar(a.grad[lstm0:head0])
+            m._bwd_seq_front(B, T)
+            w_front = dist.all_reduce_coalesced([a.grad[front0:lstm0], _sparse_norm_slot(m)], op=dist.ReduceOp.SUM, async_op=True)
+            w_dpre = self._gather(dpre_all, m.dpre)
+            w_head.wait()
+            m._tick(); m._update_slice(s_head)
+            w_x.wait(); w_dpre.wait()
+            m._bwd_enc(B, T, x_all, dpre_all); m._update_slice(s_enc)
+            w_lstm.wait(); w_front.wait()
+            m._update_slice(s_mid); m.be.l2_total(a.wsq, a.seg_l2, a.nseg, m.met[2:3])
+        if _whole_step_graph(self, m, ("dpall", B, T), body):
+            return
 
         cap = lambda key, fn: (m._run_planned if key[0][2:] in self.eager else m._run_captured)(key, fn)
         cap(("dpA", B, T), lambda: (m._forward(B, T, True), m._loss_metrics(B, T, True), m._bwd_head(B, T)))
@@ -161,6 +212,8 @@ class PipelinedAttentionSync:
     def __init__(self, world):
         self.world = world
         self._slices = None
+        self.one_graph = os.environ.get("TNT_DP_ONE_GRAPH", "1") != "0"
+        self.capture_error = None
 
     def step(self, m, B, T):
         a = m.arena
@@ -172,6 +225,22 @@ class PipelinedAttentionSync:
         sl_tail, sl_front = self._slices
         emb0, lstm0, head0 = self._offs
         ar = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+        def body():
+            m._forward(B, T, True); m._loss_metrics(B, T, True); m._bwd_head(B, T)
+            w_head = ar(a.grad[head0:])
+            m._bwd_chain(B, T)
+            w_lstm = ar(a.grad[lstm0:head0])
+            m._bwd_emb(B, T)
+            w_emb = dist.all_reduce_coalesced([a.grad[emb0:lstm0], _sparse_norm_slot(m)], op=dist.ReduceOp.SUM, async_op=True)
+            m._bwd_front(B, T)
+            w_front = ar(a.grad[:emb0])
+            w_head.wait(); w_lstm.wait()
+            m._tick(); m._update_slice(sl_tail)
+            w_emb.wait(); w_front.wait()
+            m._update_slice(sl_front); m.be.l2_total(a.wsq, a.seg_l2, a.nseg, m.met[2:3])
+        if _whole_step_graph(self, m, ("dpall", B, T), body):
+            return
         cap = lambda key, fn: (m._run_planned if key[0][2:] in self.eager else m._run_captured)(key, fn)
 
         cap(("dpA", B, T), lambda: (m._forward(B, T, True), m._loss_metrics(B, T, True), m._bwd_head(B, T)))
