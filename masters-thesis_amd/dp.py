@@ -48,7 +48,14 @@ def _whole_step_graph(sync, m, key, body):
     graph -- and ``work.wait()`` joins the branch, so the captured graph has exactly the overlap structure of the
     segmented schedule without its six launch boundaries (each graph launch costs 15-20 us of device idle time, a
     launch plan ~6 us of host time per kernel).  Tried once per (model, key): if the runtime refuses the capture the
-    segmented schedule takes over for good.  Off with TNT_DP_ONE_GRAPH=0; gloo (CPU tests) always runs segmented."""
+    segmented schedule takes over for good.  OPT-IN (TNT_DP_ONE_GRAPH=1); gloo (CPU tests) always runs segmented.
+    Measured at world size 1 over RCCL (tools/dp_rehearsal.py, profiles/r02_dp_onegraph_world1_trace.txt): the captured
+    graph replays correctly (bit-identical weights for the dense model), but as soon as a collective puts a second
+    stream into the graph (at world size 1: the all-gathers, which become copy kernels) every node behind the fork
+    runs in the runtime's slower cross-stream dependency mode -- small kernels 4.7 -> 11 us each -- and the dense
+    step is 0.815 ms against 0.763 for the segmented schedule and 0.641 for the single-GPU graph.  The attention
+    schedule (all-reduces only, which launch nothing at world size 1) replays at 1.135 ms against 1.309 segmented
+    and 1.110 single-GPU, but that says nothing about world sizes where the all-reduce is a real kernel."""
     if sync.one_graph is False or m.device.type != "cuda" or not m.use_graph or dist.get_backend() != "nccl":
         return False
     st = m._graphs.get(key)
@@ -111,7 +118,7 @@ class PipelinedDenseSync:
         self.world = world
         self._bufs = {}
         self._slices = None
-        self.one_graph = os.environ.get("TNT_DP_ONE_GRAPH", "1") != "0"
+        self.one_graph = os.environ.get("TNT_DP_ONE_GRAPH", "0") == "1"
         self.capture_error = None
 
     def _gather(self, out, t):
@@ -212,7 +219,7 @@ class PipelinedAttentionSync:
     def __init__(self, world):
         self.world = world
         self._slices = None
-        self.one_graph = os.environ.get("TNT_DP_ONE_GRAPH", "1") != "0"
+        self.one_graph = os.environ.get("TNT_DP_ONE_GRAPH", "0") == "1"
         self.capture_error = None
 
     def step(self, m, B, T):
