@@ -228,6 +228,22 @@ int32_t tnt_lstm_step_fwd_f32(const float* xz, const float* h_prev, const float*
                               const int32_t* mask_ids, int32_t mask_T, int32_t mask_t,
                               const float* out_prev, float* h, float* c, float* out,
                               float* gates, int32_t B, int32_t U, const float* xz_bias, void* stream);
+/* ---- LayerNormLSTMCell (tensorflow_addons 0.15 rnn.LayerNormLSTMCell; the use_layer_norm branch of lc_NIC.py:126-136):
+ *   z = LN_kernel(x W) + LN_recurrent(h U) + b;  c' = LN_state(sig(f) c + sig(i) tanh(c~));  h' = sig(o) tanh(c')
+ * The two 4U-wide LayerNorms are tnt_layernorm_fwd/bwd_f32 launches (dgamma = dbeta = NULL there: input gradient only)
+ * around the matmuls; these two entry points are the cell: gate math + the state LayerNorm over U, and the reverse.
+ * Gate-interleaved tensors [B][U][4] (zk, zr, gates, dz; bias [U][4]); chat = the normalised pre-affine state, istd [B].
+ * bwd: dh = dh_a + dh_b + dh_c (each nullable), dcn_in (nullable) = gradient wrt the normalised state carried to the
+ * next step; writes dz, dc_prev (gradient wrt the previous step's normalised state; may alias dcn_in) and dcnt = the
+ * total gradient at the normalised state (its products with chat / its column sums over all steps are the state
+ * norm's gamma / beta gradients).  U <= 4096. */
+int32_t tnt_ln_lstm_cell_fwd_f32(const float* zk, const float* zr, const float* bias, const float* c_prev,
+                                 const float* gamma_s, const float* beta_s, float* gates, float* chat,
+                                 float* istd, float* c, float* h, int32_t B, int32_t U, float eps, void* stream);
+int32_t tnt_ln_lstm_cell_bwd_f32(const float* dh_a, const float* dh_b, const float* dh_c, const float* dcn_in,
+                                 const float* gates, const float* c_prev, const float* c, const float* chat,
+                                 const float* istd, const float* gamma_s, float* dz, float* dc_prev,
+                                 float* dcnt, int32_t B, int32_t U, void* stream);
 /* Persistent form of the masked sequence forward of NIC.py:138-140: ONE launch runs the S dependent steps
  * (step s reads hs[s], cs[s], xz[s] and writes hs[s+1], cs[s+1], gates[s]; steps s >= mask_s0 write the sequence
  * output out[s - mask_s0] (out nullable) and, if mask_ids[B][mask_T] is given, are masked by its column s - mask_s0;

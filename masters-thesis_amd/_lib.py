@@ -41,6 +41,8 @@ SIGNATURES = {
     "tnt_lstm_seq_bwd_work_floats": [I32, I32],
     "tnt_lstm_seq_bwd_f32": [P, P, P, I32, I32, P, P, P, P, I64, I32, I32, I32, P, P, P],
     "tnt_lstm_step_fwd_f32": [P, P, P, P, P, P, I32, P, I32, I32, P, P, P, P, P, I32, I32, P, P],
+    "tnt_ln_lstm_cell_fwd_f32": [P, P, P, P, P, P, P, P, P, P, P, I32, I32, F32, P],
+    "tnt_ln_lstm_cell_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, P],
     "tnt_lstm_step_bwd_f32": [P, P, P, P, P, P, P, P, I32, I32, P, P, P, P, P, P, P, I32, I32, P, I32, P, P],
     "tnt_softmax_cce_f32": [P, P, P, P, P, P, I32, I32, I32, F32, I32, I32, P],
     "tnt_onehot_argmax_f32": [P, P, I32, I32, I32, P],

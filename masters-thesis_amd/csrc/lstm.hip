@@ -661,6 +661,119 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
   tnt_seq_leave(a.sync, xcc, a.guard_out);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNormLSTMCell (tensorflow_addons.rnn.LayerNormLSTMCell, the use_layer_norm branch of lc_NIC.py:126-136):
+//   z = LN_kernel(x W) + LN_recurrent(h U) + b;  c' = LN_state(sig(f) c + sig(i) tanh(g));  h' = sig(o) tanh(c')
+// The two 4U-wide LayerNorms are tnt_layernorm_*_f32 launches around the matmuls; this pair of kernels is the cell
+// itself: gate math + the state LayerNorm (a row reduction over U) forward, and its exact reverse.  One workgroup per
+// batch row, the row lives in registers (U <= 4096).  Tensors gate-interleaved [B][U][4] like the plain cell.
+struct LnCellArgs {
+  const float* zk; const float* zr; const float* bias; const float* c_prev; const float* gs; const float* bs;
+  float* gates; float* chat; float* istd; float* c; float* h;
+  // backward
+  const float* dh_a; const float* dh_b; const float* dh_c; const float* dcn_in; const float* c_in;
+  float* dz; float* dc_prev; float* dcnt;
+  int B, U; float eps;
+};
+
+constexpr int LN_MAXU_PER_THREAD = 16;
+
+__device__ __forceinline__ float ln_block_sum(float v, float* sh) {
+  v = tnt_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void ln_lstm_cell_fwd_kernel(LnCellArgs a) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x, U = a.U;
+  float craw[LN_MAXU_PER_THREAD], og[LN_MAXU_PER_THREAD];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < LN_MAXU_PER_THREAD; ++q) {
+    const int u = threadIdx.x + q * 256;
+    craw[q] = 0.f; og[q] = 0.f;
+    if (u < U) {
+      const long e = (long)b * U + u;
+      const float4 k4 = *reinterpret_cast<const float4*>(a.zk + e * 4), r4 = *reinterpret_cast<const float4*>(a.zr + e * 4);
+      const float4 b4 = *reinterpret_cast<const float4*>(a.bias + (long)u * 4);
+      const float gi = tnt_sigmoid(k4.x + r4.x + b4.x), gf = tnt_sigmoid(k4.y + r4.y + b4.y);
+      const float gg = tanhf(k4.z + r4.z + b4.z), go = tnt_sigmoid(k4.w + r4.w + b4.w);
+      *reinterpret_cast<float4*>(a.gates + e * 4) = make_float4(gi, gf, gg, go);
+      craw[q] = gf * a.c_prev[e] + gi * gg;
+      og[q] = go;
+      s += craw[q];
+    }
+  }
+  const float mean = ln_block_sum(s, sh) / (float)U;
+  float v = 0.f;
+#pragma unroll
+  for (int q = 0; q < LN_MAXU_PER_THREAD; ++q) {
+    const int u = threadIdx.x + q * 256;
+    if (u < U) { const float d = craw[q] - mean; v += d * d; }
+  }
+  const float inv = rsqrtf(ln_block_sum(v, sh) / (float)U + a.eps);
+  if (threadIdx.x == 0) a.istd[b] = inv;
+#pragma unroll
+  for (int q = 0; q < LN_MAXU_PER_THREAD; ++q) {
+    const int u = threadIdx.x + q * 256;
+    if (u < U) {
+      const long e = (long)b * U + u;
+      const float xh = (craw[q] - mean) * inv;
+      const float cn = xh * a.gs[u] + a.bs[u];
+      a.chat[e] = xh;
+      a.c[e] = cn;
+      a.h[e] = og[q] * tanhf(cn);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_lstm_cell_bwd_kernel(LnCellArgs a) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x, U = a.U;
+  float dxh[LN_MAXU_PER_THREAD], xh[LN_MAXU_PER_THREAD], dgo[LN_MAXU_PER_THREAD];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < LN_MAXU_PER_THREAD; ++q) {
+    const int u = threadIdx.x + q * 256;
+    dxh[q] = 0.f; xh[q] = 0.f; dgo[q] = 0.f;
+    if (u < U) {
+      const long e = (long)b * U + u;
+      float dh = 0.f;
+      if (a.dh_a) dh += a.dh_a[e];
+      if (a.dh_b) dh += a.dh_b[e];
+      if (a.dh_c) dh += a.dh_c[e];
+      const float go = a.gates[e * 4 + 3];
+      const float tc = tanhf(a.c_in[e]);
+      dgo[q] = dh * tc * go * (1.f - go);
+      const float dcn = (a.dcn_in ? a.dcn_in[e] : 0.f) + dh * go * (1.f - tc * tc);
+      a.dcnt[e] = dcn;
+      xh[q] = a.chat[e];
+      dxh[q] = dcn * a.gs[u];
+      s1 += dxh[q];
+      s2 += dxh[q] * xh[q];
+    }
+  }
+  const float t1 = ln_block_sum(s1, sh), t2 = ln_block_sum(s2, sh);
+  const float inv = a.istd[b], n = (float)U;
+#pragma unroll
+  for (int q = 0; q < LN_MAXU_PER_THREAD; ++q) {
+    const int u = threadIdx.x + q * 256;
+    if (u < U) {
+      const long e = (long)b * U + u;
+      const float dcr = inv / n * (n * dxh[q] - t1 - xh[q] * t2);
+      const float4 g4 = *reinterpret_cast<const float4*>(a.gates + e * 4);
+      const float gi = g4.x, gf = g4.y, gg = g4.z;
+      *reinterpret_cast<float4*>(a.dz + e * 4) = make_float4(dcr * gg * gi * (1.f - gi), dcr * a.c_prev[e] * gf * (1.f - gf),
+                                                             dcr * gi * (1.f - gg * gg), dgo[q]);
+      a.dc_prev[e] = dcr * gf;
+    }
+  }
+}
+
 // census of a 256 x 1024-thread launch: how many workgroups land on each XCC_ID
 __global__ __launch_bounds__(1024) void xcc_census_kernel(unsigned* hist) {
   extern __shared__ float seq_lds[];
@@ -800,4 +913,33 @@ extern "C" int32_t tnt_lstm_seq_bwd_f32(const float* Ur, const float* dout_seq, 
 extern "C" int32_t tnt_lstm_seq_bwd_work_floats(int32_t B, int32_t U) {
   (void)U;
   return 2 * ((B + 15) / 16) * 32 * 32 * 256;
+}
+
+extern "C" int32_t tnt_ln_lstm_cell_fwd_f32(const float* zk, const float* zr, const float* bias, const float* c_prev,
+                                            const float* gamma_s, const float* beta_s, float* gates, float* chat,
+                                            float* istd, float* c, float* h, int32_t B, int32_t U, float eps, void* stream) {
+  if (B <= 0 || U <= 0 || U > 256 * LN_MAXU_PER_THREAD) return TNT_BADARG(12);
+  if (!tnt_aligned16(zk) || !tnt_aligned16(zr) || !tnt_aligned16(bias) || !tnt_aligned16(gates)) return TNT_BADARG(1);
+  LnCellArgs a{};
+  a.zk = zk; a.zr = zr; a.bias = bias; a.c_prev = c_prev; a.gs = gamma_s; a.bs = beta_s; a.gates = gates; a.chat = chat;
+  a.istd = istd; a.c = c; a.h = h; a.B = B; a.U = U; a.eps = eps;
+  hipLaunchKernelGGL(ln_lstm_cell_fwd_kernel, dim3(B), dim3(256), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_ln_lstm_cell_bwd_f32(const float* dh_a, const float* dh_b, const float* dh_c, const float* dcn_in,
+                                            const float* gates, const float* c_prev, const float* c, const float* chat,
+                                            const float* istd, const float* gamma_s, float* dz, float* dc_prev,
+                                            float* dcnt, int32_t B, int32_t U, void* stream) {
+  if (B <= 0 || U <= 0 || U > 256 * LN_MAXU_PER_THREAD) return TNT_BADARG(14);
+  if (!tnt_aligned16(gates) || !tnt_aligned16(dz)) return TNT_BADARG(1);
+  if (dc_prev == dcn_in && dcn_in != nullptr) { /* in place is fine: every element is read before it is written by its own thread */ }
+  LnCellArgs a{};
+  a.dh_a = dh_a; a.dh_b = dh_b; a.dh_c = dh_c; a.dcn_in = dcn_in; a.gates = const_cast<float*>(gates); a.c_prev = c_prev;
+  a.c_in = c; a.chat = const_cast<float*>(chat); a.istd = const_cast<float*>(istd); a.gs = gamma_s; a.dz = dz;
+  a.dc_prev = dc_prev; a.dcnt = dcnt; a.B = B; a.U = U;
+  hipLaunchKernelGGL(ln_lstm_cell_bwd_kernel, dim3(B), dim3(256), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
 }

@@ -652,12 +652,15 @@ extern "C" int32_t tnt_batchnorm_bwd_f32(const float* dy, const float* xhat, con
                                          float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, int32_t lddy,
                                          int32_t training, float* work, void* stream) {
   hipStream_t s = tnt_stream(stream);
-  const int nchunk = chunk_count(rows);
-  float* part = work + C;
-  launch_col_partial<1>(dy, lddy, xhat, C, rows, C, part, s);
-  TNT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_finalize_kernel<true>, dim3((C + 63) / 64), dim3(64), 0, s, part, C, nchunk, dbeta, dgamma);
-  TNT_LAUNCH_CHECK();
+  if (dgamma != nullptr || dbeta != nullptr) {        // both null: input gradient only (per-step use inside a T-step chain)
+    if (dgamma == nullptr || dbeta == nullptr || work == nullptr) return TNT_BADARG(6);
+    const int nchunk = chunk_count(rows);
+    float* part = work + C;
+    launch_col_partial<1>(dy, lddy, xhat, C, rows, C, part, s);
+    TNT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(col_finalize_kernel<true>, dim3((C + 63) / 64), dim3(64), 0, s, part, C, nchunk, dbeta, dgamma);
+    TNT_LAUNCH_CHECK();
+  }
   if (dx) {
     hipLaunchKernelGGL(bn_dx_kernel, dim3(ew_blocks((long)rows * C)), dim3(256), 0, s, dy, lddy, xhat, gamma, inv_std,
                        dgamma, dbeta, dx, rows, C, training);
@@ -678,12 +681,15 @@ extern "C" int32_t tnt_layernorm_bwd_f32(const float* dy, const float* xhat, con
                                          float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, int32_t lddy,
                                          float* work, void* stream) {
   hipStream_t s = tnt_stream(stream);
-  const int nchunk = chunk_count(rows);
-  float* part = work + C;
-  launch_col_partial<1>(dy, lddy, xhat, C, rows, C, part, s);
-  TNT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_finalize_kernel<true>, dim3((C + 63) / 64), dim3(64), 0, s, part, C, nchunk, dbeta, dgamma);
-  TNT_LAUNCH_CHECK();
+  if (dgamma != nullptr || dbeta != nullptr) {        // both null: input gradient only (per-step use inside a T-step chain)
+    if (dgamma == nullptr || dbeta == nullptr || work == nullptr) return TNT_BADARG(6);
+    const int nchunk = chunk_count(rows);
+    float* part = work + C;
+    launch_col_partial<1>(dy, lddy, xhat, C, rows, C, part, s);
+    TNT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(col_finalize_kernel<true>, dim3((C + 63) / 64), dim3(64), 0, s, part, C, nchunk, dbeta, dgamma);
+    TNT_LAUNCH_CHECK();
+  }
   if (dx) {
     hipLaunchKernelGGL(ln_dx_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dy, lddy, xhat, gamma, inv_std, dx, rows, C);
     TNT_LAUNCH_CHECK();

@@ -72,8 +72,11 @@ class NIC(ModelBase):
 
     def __init__(self, groups, units, embedding_features, embedding_text, attn_units, vocab_size, max_length,
                  dropout_input, dropout_features, dropout_text, dropout_attn, dropout_lstm, dropout_out, input_reg,
-                 attn_reg, lstm_reg, output_reg, norm="batch", n_subjects=1, depth=0, **kw):
+                 attn_reg, lstm_reg, output_reg, norm="batch", n_subjects=1, depth=0, use_layer_norm=False, **kw):
         super().__init__(**kw)
+        # use_layer_norm: the decoder cell is tensorflow_addons' LayerNormLSTMCell (lc_NIC.py:115,126-136; hard-wired off in
+        # the reference): LayerNorm on x W, on h U and on the new cell state, no dropout inside the cell
+        self.use_layer_norm = bool(use_layer_norm)
         # depth > 0: deep_layers.LocallyDense(groups, dropout, depth=n) (AttemptFour/Model/deep_layers.py:15-75) in place
         # of layers.LocallyDense -- n more stages of {per-region Dense(D -> D), BatchNorm, Dropout} behind the first one
         self.depth = int(depth)
@@ -149,6 +152,10 @@ class NIC(ModelBase):
         ks["emb_text/embeddings"] = (V, Et)
         ls["lstm"] = ["kernel", "recurrent_kernel", "bias"]
         ks["lstm/kernel"], ks["lstm/recurrent_kernel"], ks["lstm/bias"] = (D + Et, 4 * U), (U, 4 * U), (4 * U,)
+        if self.use_layer_norm:
+            for nm, n in (("kernel_norm", 4 * U), ("recurrent_norm", 4 * U), ("state_norm", U)):
+                ls[f"lstm/{nm}"] = ["gamma", "beta"]
+                ks[f"lstm/{nm}/gamma"], ks[f"lstm/{nm}/beta"] = (n,), (n,)
         ls["time_distributed_nonlinear"] = ["kernel", "bias"]
         ks["time_distributed_nonlinear/kernel"], ks["time_distributed_nonlinear/bias"] = (U, H), (H,)
         ls["time_distributed_softmax"] = ["kernel", "bias"]
@@ -185,6 +192,10 @@ class NIC(ModelBase):
         a.add("emb_text/embeddings", (V, Et))
         a.add("lstm/kernel", (D + Et, U, 4), self.l2_lstm)
         a.add("lstm/recurrent_kernel", (U, U, 4)); a.add("lstm/bias", (U, 4))
+        if self.use_layer_norm:
+            for nm in ("kernel_norm", "recurrent_norm"):
+                a.add(f"lstm/{nm}/gamma", (U, 4)); a.add(f"lstm/{nm}/beta", (U, 4))
+            a.add("lstm/state_norm/gamma", (U,)); a.add("lstm/state_norm/beta", (U,))
         a.add("time_distributed_nonlinear/kernel", (U, H), self.l2_out); a.add("time_distributed_nonlinear/bias", (H,))
         a.add("time_distributed_softmax/kernel", (H, self.ldV), self.l2_out)
         a.add("time_distributed_softmax/bias", (self.ldV,))
@@ -231,6 +242,9 @@ class NIC(ModelBase):
         self.set_weight("lstm/recurrent_kernel", q)
         b = np.zeros(4 * U); b[U:2 * U] = 1.0
         self.set_weight("lstm/bias", b)
+        if self.use_layer_norm:
+            for nm, n in (("kernel_norm", 4 * U), ("recurrent_norm", 4 * U), ("state_norm", U)):
+                self.set_weight(f"lstm/{nm}/gamma", np.ones(n))
         self.set_weight("time_distributed_nonlinear/kernel", tn((U, H), np.sqrt(2.0 / (U + H))))
         self.set_weight("time_distributed_softmax/kernel", tn((H, V), np.sqrt(2.0 / (H + V))))
 
@@ -243,7 +257,7 @@ class NIC(ModelBase):
             if name == f"{bn}/moving_variance":
                 self.mov_var[q].copy_(torch.from_numpy(arr)); return
         dst = self.arena.p(name)
-        if name.startswith("lstm/"):
+        if name.startswith("lstm/") and arr.shape[-1] == 4 * self.U:
             arr = interleave_gates(arr, self.U)
         elif name == "time_distributed_softmax/kernel":
             pad = np.zeros((self.H, self.ldV), np.float32); pad[:, :self.V] = arr; arr = pad
@@ -253,7 +267,7 @@ class NIC(ModelBase):
 
     def _unpack(self, name, t):
         arr = t.detach().cpu().numpy()
-        if name.startswith("lstm/"):
+        if name.startswith("lstm/") and not name.startswith("lstm/state_norm"):
             return deinterleave_gates(arr)
         if name == "time_distributed_softmax/kernel":
             return np.ascontiguousarray(arr[:, :self.V])
@@ -322,6 +336,13 @@ class NIC(ModelBase):
         self.qpre, self.alpha = f(T, B, A), f(T, B, R)
         self.ctx, self.ctx_d = f(T, B, D), f(T, B, D)
         self.Hd = f(n, U) if self.r_lstm > 0 else None
+        if self.use_layer_norm:       # LayerNormLSTMCell: normalised projections, LayerNorm caches, per-step gradients
+            self.ZK, self.ZR, self.ZRn = f(n, U, 4), f(n, U, 4), f(n, U, 4)
+            self.xh_k, self.xh_r = f(n, 4 * U), f(n, 4 * U)
+            self.is_k, self.is_r, self.is_s = f(T, max(B, 4 * U)), f(T, max(B, 4 * U)), f(T, B)
+            self.chat, self.dcnt = f(n, U), f(n, U)
+            self.dZK, self.dZR = f(n, U, 4), f(n, U, 4)
+            self.dh_rec = f(B, U)
         self.ipre, self.inter = f(n, H), f(n, H)
         self.inter_d = f(n, H) if self.r_out > 0 else self.inter
         self.logits = f(n, ldV)
@@ -431,12 +452,27 @@ class NIC(ModelBase):
         be, a = self.be, self.arena
         R, D, A, U, Et = self.R, self.D, self.A, self.U, self.Et
         Wl = a.p("lstm/kernel")
+        r_in = self.r_lstm if (training and not self.use_layer_norm) else 0.0      # the LayerNorm cell has no input dropout
         be.attention_step_fwd(self.Hs[i], self.F, self.P, a.p("attention/W2/kernel"), a.p("attention/W2/bias"),
                               a.p("attention/V/kernel"), a.p("attention/V/bias"), self.qpre[i], self.alpha[i],
                               self.ctx[i], self.ctx_d[i], s_out, B, R, D, A, U, 0.2,
-                              self.r_attn if training else 0.0, self.r_lstm if training else 0.0, D + Et, self.seed,
+                              self.r_attn if training else 0.0, r_in, D + Et, self.seed,
                               S_ATTN + i, S_LSTM_IN + i, 0, self.drop_step,
                               keep4=self.att_keep[i] if (training and self._keep_stored) else None)
+        if self.use_layer_norm:
+            # LayerNormLSTMCell.call: z = LN_kernel([ctx, text] W) + LN_recurrent(h U) + b, state LayerNorm inside the cell
+            rows = slice(i * B, (i + 1) * B)
+            xz = self.XZ[rows]                       # text part of x W (all T steps in one GEMM, no bias) ...
+            self.gemm_sk(self.ctx_d[i], Wl[:D], xz, B, 4 * U, D, D, 4 * U, 4 * U, accumulate=True)       # ... + ctx W_ctx
+            be.layernorm_fwd(xz, a.p("lstm/kernel_norm/gamma"), a.p("lstm/kernel_norm/beta"), self.ZK[rows], self.xh_k[rows],
+                             self.is_k[i], B, 4 * U, 4 * U, BN_EPS)
+            self.gemm_sk(self.Hs[i], a.p("lstm/recurrent_kernel"), self.ZR[rows], B, 4 * U, U, U, 4 * U, 4 * U)
+            be.layernorm_fwd(self.ZR[rows], a.p("lstm/recurrent_norm/gamma"), a.p("lstm/recurrent_norm/beta"), self.ZRn[rows],
+                             self.xh_r[rows], self.is_r[i], B, 4 * U, 4 * U, BN_EPS)
+            be.ln_lstm_cell_fwd(self.ZK[rows], self.ZRn[rows], a.p("lstm/bias"), self.Cs[i], a.p("lstm/state_norm/gamma"),
+                                a.p("lstm/state_norm/beta"), self.gates[i], self.chat[rows], self.is_s[i], self.Cs[i + 1],
+                                self.Hs[i + 1], B, U, BN_EPS)
+            return
         be.lstm_step_fwd(self.XZ[i * B:(i + 1) * B], self.Hs[i], self.Cs[i], a.p("lstm/recurrent_kernel"),
                          self.ctx_d[i], Wl[:D], D, None, 0, 0, None, self.Hs[i + 1], self.Cs[i + 1], None,
                          self.gates[i], B, U, xz_bias=xz_bias)
@@ -454,7 +490,7 @@ class NIC(ModelBase):
             be.embedding_fwd(a.p("emb_text/embeddings"), self.cap, self.text, B, T, Et, Et, V)       # lc_NIC.py:233
             if training and self.r_text > 0:
                 be.dropout(self.text, self.text, n, Et, Et, B, Et, 0, self.r_text, sd, S_TEXT, 0, ds)
-        if training and self.r_lstm > 0:       # text half of the per-call LSTM input mask over (B,1,D+Et)
+        if training and self.r_lstm > 0 and not self.use_layer_norm:       # text half of the per-call LSTM input mask over (B,1,D+Et)
             be.dropout(self.text, self.text, n, Et, Et, 0, D + Et, D, self.r_lstm, sd, S_LSTM_IN, 0, ds,
                        rows_per_site=B)
         Wl = a.p("lstm/kernel")
@@ -539,6 +575,8 @@ class NIC(ModelBase):
         self.datt.zero_()
         Wl, Ur = a.p("lstm/kernel"), a.p("lstm/recurrent_kernel")
         W2, v = a.p("attention/W2/kernel"), a.p("attention/V/kernel")
+        if self.use_layer_norm:
+            return self._bwd_chain_ln(B, T)
         for i in range(T - 1, -1, -1):
             last = i == T - 1
             # dctx_i = dZ_i @ Wc^T: every LSTM-backward workgroup leaves the partial of its 16 units, the attention
@@ -568,6 +606,46 @@ class NIC(ModelBase):
         self.gemm_sk(self.ctx_d, self.dZ, gWl[:D], D, 4 * U, n, D, 4 * U, 4 * U, transA=True)
         be.colsum(self.dZ, a.g("lstm/bias"), n, 4 * U, 4 * U, self.work)
 
+    def _bwd_chain_ln(self, B, T):
+        """The T-step chain with the LayerNormLSTMCell (reverse of _decode_step's LayerNorm branch).  Per step: cell
+        backward (gate math + state LayerNorm) -> input gradients of the two 4U-wide LayerNorms -> dh of the previous
+        step through U^T -> attention step backward (context gradient from dZK).  The parameter gradients of the three
+        LayerNorms and of W / U / b are batched over all T steps behind the chain."""
+        be, a = self.be, self.arena
+        R, D, A, U, Et = self.R, self.D, self.A, self.U, self.Et
+        n = T * B
+        sd, ds = self.seed, self.drop_step
+        Wl, Ur = a.p("lstm/kernel"), a.p("lstm/recurrent_kernel")
+        W2, v = a.p("attention/W2/kernel"), a.p("attention/V/kernel")
+        gk, gr, gs = a.p("lstm/kernel_norm/gamma"), a.p("lstm/recurrent_norm/gamma"), a.p("lstm/state_norm/gamma")
+        for i in range(T - 1, -1, -1):
+            last = i == T - 1
+            rows = slice(i * B, (i + 1) * B)
+            be.ln_lstm_cell_bwd(self.dHs[rows], None if last else self.dh_att, None if last else self.dh_rec,
+                                None if last else self.dc, self.gates[i], self.Cs[i], self.Cs[i + 1], self.chat[rows],
+                                self.is_s[i], gs, self.dZ[rows], self.dc, self.dcnt[rows], B, U)
+            be.layernorm_bwd(self.dZ[rows], self.xh_k[rows], gk, self.is_k[i], self.dZK[rows], None, None, B, 4 * U, 4 * U, None)
+            be.layernorm_bwd(self.dZ[rows], self.xh_r[rows], gr, self.is_r[i], self.dZR[rows], None, None, B, 4 * U, 4 * U, None)
+            self.gemm_sk(self.dZR[rows], Ur, self.dh_rec, B, U, 4 * U, 4 * U, 4 * U, U, transB=True)
+            be.attention_step_bwd(None, self.F, self.P, W2, v, self.qpre[i], self.alpha[i], self.dP, self.dF,
+                                  self.dvb, self.dqpre[i], self.dh_att, B, R, D, A, U, 0.2, self.r_attn, 0.0,
+                                  D + Et, sd, S_ATTN + i, S_LSTM_IN + i, 0, ds, dz=self.dZK[rows],
+                                  Wc=Wl[:D], keep4=self.att_keep[i] if self._keep_stored else None,
+                                  alpha_mse=self._alpha_mse)
+        hprev = self.Hs[:T].view(n, U)
+        gWl = a.g("lstm/kernel")
+        self.gemm_sk(hprev, self.dZR, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True)
+        self.gemm_sk(self.text, self.dZK, gWl[D:], Et, 4 * U, n, Et, 4 * U, 4 * U, transA=True)
+        self.gemm_sk(self.ctx_d, self.dZK, gWl[:D], D, 4 * U, n, D, 4 * U, 4 * U, transA=True)
+        # gamma / beta of the three LayerNorms, summed over all T*B rows: dgamma = sum dy * xhat, dbeta = sum dy
+        be.layernorm_bwd(self.dZ, self.xh_k, gk, self.is_k, None, a.g("lstm/kernel_norm/gamma"), a.g("lstm/kernel_norm/beta"),
+                         n, 4 * U, 4 * U, self.work)
+        be.layernorm_bwd(self.dZ, self.xh_r, gr, self.is_r, None, a.g("lstm/recurrent_norm/gamma"),
+                         a.g("lstm/recurrent_norm/beta"), n, 4 * U, 4 * U, self.work)
+        be.layernorm_bwd(self.dcnt, self.chat, gs, self.is_s, None, a.g("lstm/state_norm/gamma"), a.g("lstm/state_norm/beta"),
+                         n, U, U, self.work)
+        be.colsum(self.dZ, a.g("lstm/bias"), n, 4 * U, 4 * U, self.work)
+
     def _bwd_emb(self, B, T):
         """text branch: dtext = dZ Wl_text^T, its dropouts, the embedding scatter (+ IndexedSlices norm)."""
         be, a = self.be, self.arena
@@ -575,8 +653,8 @@ class NIC(ModelBase):
         n = T * B
         sd, ds = self.seed, self.drop_step
         Wl = a.p("lstm/kernel")
-        self.gemm_sk(self.dZ, Wl[D:], self.dtext, n, Et, 4 * U, 4 * U, 4 * U, Et, transB=True)
-        if self.r_lstm > 0:
+        self.gemm_sk(self.dZK if self.use_layer_norm else self.dZ, Wl[D:], self.dtext, n, Et, 4 * U, 4 * U, 4 * U, Et, transB=True)
+        if self.r_lstm > 0 and not self.use_layer_norm:
             be.dropout(self.dtext, self.dtext, n, Et, Et, 0, D + Et, D, self.r_lstm, sd, S_LSTM_IN, 0, ds,
                        rows_per_site=B)
         if self.r_text > 0:
@@ -809,7 +887,7 @@ class NIC(ModelBase):
                 text = self.text[i * B:(i + 1) * B]
                 be.embedding_fwd(a.p("emb_text/embeddings"), words, text, B, 1, Et, Et, V)        # :596,632
                 self.gemm_sk(text, Wl[D:], self.XZ[i * B:(i + 1) * B], B, 4 * U, Et, Et, 4 * U, 4 * U,
-                             bias=a.p("lstm/bias"))
+                             bias=None if self.use_layer_norm else a.p("lstm/bias"))      # LN cell: bias behind the norms
                 self._decode_step(i, B, False, s_all[i] if return_s else None)
                 self.gemm_sk(self.Hs[i + 1], a.p("time_distributed_nonlinear/kernel"), self.inter[:B], B, H, U, U, H, H,
                              bias=a.p("time_distributed_nonlinear/bias"), act=ACT_LEAKY, slope=0.2)     # :621
@@ -866,7 +944,8 @@ class NIC(ModelBase):
         for i in range(max_len):
             text = self.text[i * Bk:(i + 1) * Bk]
             be.embedding_fwd(a.p("emb_text/embeddings"), words, text, Bk, 1, Et, Et, V)
-            self.gemm_sk(text, Wl[D:], self.XZ[i * Bk:(i + 1) * Bk], Bk, 4 * U, Et, Et, 4 * U, 4 * U, bias=a.p("lstm/bias"))
+            self.gemm_sk(text, Wl[D:], self.XZ[i * Bk:(i + 1) * Bk], Bk, 4 * U, Et, Et, 4 * U, 4 * U,
+                         bias=None if self.use_layer_norm else a.p("lstm/bias"))
             self._decode_step(i, Bk, False, None)
             self.gemm_sk(self.Hs[i + 1], a.p("time_distributed_nonlinear/kernel"), self.inter[:Bk], Bk, H, U, U, H, H,
                          bias=a.p("time_distributed_nonlinear/bias"), act=ACT_LEAKY, slope=0.2)

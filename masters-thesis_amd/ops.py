@@ -132,6 +132,14 @@ class HipBackend:
         self._call(self.lib.tnt_lstm_seq_fwd_f32, "tnt_lstm_seq_fwd_f32", _p(xz), _p(hs), _p(cs), _p(Ur), _p(xz_bias),
                    _p(mask_ids), mask_T, mask_s0, _p(out), _p(gates), S, B, U, _p(sync), _p(guard_out), self._s())
 
+    def ln_lstm_cell_fwd(self, zk, zr, bias, c_prev, gamma_s, beta_s, gates, chat, istd, c, h, B, U, eps):
+        self._call(self.lib.tnt_ln_lstm_cell_fwd_f32, "tnt_ln_lstm_cell_fwd_f32", _p(zk), _p(zr), _p(bias), _p(c_prev), _p(gamma_s),
+                   _p(beta_s), _p(gates), _p(chat), _p(istd), _p(c), _p(h), B, U, eps, self._s())
+
+    def ln_lstm_cell_bwd(self, dh_a, dh_b, dh_c, dcn_in, gates, c_prev, c, chat, istd, gamma_s, dz, dc_prev, dcnt, B, U):
+        self._call(self.lib.tnt_ln_lstm_cell_bwd_f32, "tnt_ln_lstm_cell_bwd_f32", _p(dh_a), _p(dh_b), _p(dh_c), _p(dcn_in), _p(gates),
+                   _p(c_prev), _p(c), _p(chat), _p(istd), _p(gamma_s), _p(dz), _p(dc_prev), _p(dcnt), B, U, self._s())
+
     def lstm_seq_bwd_work_floats(self, B, U):
         return int(self.lib.tnt_lstm_seq_bwd_work_floats(int(B), int(U)))
 

@@ -307,7 +307,8 @@ class LcNIC:
 
     def __init__(self, groups, units, embedding_features, embedding_text, attn_units, vocab_size,
                  max_length, dropout_input, dropout_features, dropout_text, dropout_attn,
-                 dropout_lstm, dropout_out, input_reg, attn_reg, lstm_reg, output_reg, norm='batch', depth=0):
+                 dropout_lstm, dropout_out, input_reg, attn_reg, lstm_reg, output_reg, norm='batch', depth=0, use_layer_norm=False):
+        self.use_layer_norm = bool(use_layer_norm)      # lc_NIC.py:115,126-136: tfa LayerNormLSTMCell as the decoder cell
         self.depth = int(depth)       # deep_layers.LocallyDense(depth=n): n more per-region Dense + BN + Dropout stages
         self.groups = [np.asarray(gi, dtype=np.int64) for gi in groups[0]]
         self.D = int(groups[1][0])
@@ -354,6 +355,10 @@ class LcNIC:
         b = 0.01 * rng.standard_normal(4 * U)
         b[U:2 * U] += 1.0
         p['lstm/bias'] = b.astype(dtype)
+        if self.use_layer_norm:
+            for nm, n in (('kernel_norm', 4 * U), ('recurrent_norm', 4 * U), ('state_norm', U)):
+                p[f'lstm/{nm}/gamma'] = (1 + 0.1 * rng.standard_normal(n)).astype(dtype)
+                p[f'lstm/{nm}/beta'] = (0.1 * rng.standard_normal(n)).astype(dtype)
         p['time_distributed_nonlinear/kernel'] = (rng.standard_normal((U, H)) * np.sqrt(2.0 / (U + H))).astype(dtype)
         p['time_distributed_nonlinear/bias'] = (0.01 * rng.standard_normal(H)).astype(dtype)
         p['time_distributed_softmax/kernel'] = (rng.standard_normal((H, V)) * np.sqrt(2.0 / (H + V))).astype(dtype)
@@ -428,9 +433,14 @@ class LcNIC:
                 a, F, P, p['attention/W2/kernel'], p['attention/W2/bias'],
                 p['attention/V/kernel'], p['attention/V/bias'], k_at, self.r_attn)
             sample = np.concatenate([ctx, text[:, i]], axis=1)                      # :253
-            k_li = drop.mask((B, 1, sample.shape[1]), self.r_lstm, S_LSTM_IN + i)
-            sample_d = O.dropout_fwd(sample[:, None, :], k_li, self.r_lstm)[:, 0]
-            a, c, lcache = O.lstm_step_fwd(sample_d @ Wl + bl, a, c, Ul)            # :255
+            if self.use_layer_norm:          # LayerNormLSTMCell(units, kernel_regularizer): no dropout inside the cell
+                k_li, sample_d = None, sample
+                a, c, lcache = O.ln_lstm_step_fwd(sample, a, c, Wl, Ul, bl, *[p[f'lstm/{n}/{w}'] for n in
+                                                  ('kernel_norm', 'recurrent_norm', 'state_norm') for w in ('gamma', 'beta')])
+            else:
+                k_li = drop.mask((B, 1, sample.shape[1]), self.r_lstm, S_LSTM_IN + i)
+                sample_d = O.dropout_fwd(sample[:, None, :], k_li, self.r_lstm)[:, 0]
+                a, c, lcache = O.lstm_step_fwd(sample_d @ Wl + bl, a, c, Ul)        # :255
             k_lo = drop.mask((B, self.U), self.r_lstm, S_LSTM_OUT + i)
             outs.append(O.dropout_fwd(a, k_lo, self.r_lstm))                        # :256
             alphas.append(alpha)
@@ -446,6 +456,17 @@ class LcNIC:
         cache = dict(F=F, P=P, Ppre=Ppre, k_text=k_text, steps=steps, Hs=Hs, ipre=ipre,
                      k_out=k_out, inter_d=inter_d, ids=ids, logits=logits)
         return (probs, attn), cache
+
+    def _cell(self, sample, a, c):
+        """one inference step of the decoder cell: keras LSTM, or tfa LayerNormLSTMCell with use_layer_norm"""
+        p = self.p
+        if self.use_layer_norm:
+            h2, c2, _ = O.ln_lstm_step_fwd(sample, a, c, p['lstm/kernel'], p['lstm/recurrent_kernel'], p['lstm/bias'],
+                                           *[p[f'lstm/{n}/{w}'] for n in ('kernel_norm', 'recurrent_norm', 'state_norm')
+                                             for w in ('gamma', 'beta')])
+            return h2, c2
+        h2, c2, _ = O.lstm_step_fwd(sample @ p['lstm/kernel'] + p['lstm/bias'], a, c, p['lstm/recurrent_kernel'])
+        return h2, c2
 
     def l2_loss(self):
         p = self.p
@@ -498,15 +519,24 @@ class LcNIC:
         dtext = np.zeros((B, T, self.Et), probs.dtype)
         da = np.zeros((B, U), probs.dtype)
         dc = np.zeros((B, U), probs.dtype)
+        dln = {}
         for i in reversed(range(T)):
             st = cache['steps'][i]
             dh2 = da + O.dropout_bwd(dHs[:, i], st['k_lo'], self.r_lstm)
-            dz, dh_prev, dc = O.lstm_step_bwd(dh2, dc, st['lcache'], Ul)
-            h_prev = st['lcache'][6]
-            dWl += st['sample_d'].T @ dz
-            dUl += h_prev.T @ dz
-            dbl += dz.sum(axis=0)
-            dsample = O.dropout_bwd((dz @ Wl.T)[:, None, :], st['k_li'], self.r_lstm)[:, 0]
+            if self.use_layer_norm:
+                dsample, dh_prev, dc, gl = O.ln_lstm_step_bwd(dh2, dc, st['lcache'], Wl, Ul, p['lstm/kernel_norm/gamma'],
+                                                              p['lstm/recurrent_norm/gamma'], p['lstm/state_norm/gamma'])
+                dWl += gl['W']; dUl += gl['U']; dbl += gl['b']
+                for nm, kk in (('kernel_norm', 'k'), ('recurrent_norm', 'r'), ('state_norm', 's')):
+                    dln[f'lstm/{nm}/gamma'] = dln.get(f'lstm/{nm}/gamma', 0) + gl['g' + kk]
+                    dln[f'lstm/{nm}/beta'] = dln.get(f'lstm/{nm}/beta', 0) + gl['b' + kk]
+            else:
+                dz, dh_prev, dc = O.lstm_step_bwd(dh2, dc, st['lcache'], Ul)
+                h_prev = st['lcache'][6]
+                dWl += st['sample_d'].T @ dz
+                dUl += h_prev.T @ dz
+                dbl += dz.sum(axis=0)
+                dsample = O.dropout_bwd((dz @ Wl.T)[:, None, :], st['k_li'], self.r_lstm)[:, 0]
             dctx, dtext[:, i] = dsample[:, :D], dsample[:, D:]
             am = getattr(self, '_alpha_mse', 0.0)       # train_step_sam, first pass: d/dalpha of mean (1 - alpha)^2
             dh_att, dF_i, dsum, dW2_i, db2_i, dv_i, dbv_i = O.attention_step_bwd(
@@ -520,6 +550,7 @@ class LcNIC:
             da = dh_prev + dh_att
         g['lstm/kernel'] = dWl + 2 * self.l2_lstm * Wl
         g['lstm/recurrent_kernel'], g['lstm/bias'] = dUl, dbl
+        g.update(dln)
         g['attention/W2/kernel'] = dW2 + 2 * self.l2_attn * W2
         g['attention/W2/bias'] = db2
         g['attention/V/kernel'], g['attention/V/bias'] = dv, dbv
@@ -638,7 +669,7 @@ class LcNIC:
             (ctx, alpha, s), _ = O.attention_step_fwd(a, F, P, p['attention/W2/kernel'], p['attention/W2/bias'],
                                                       p['attention/V/kernel'], p['attention/V/bias'])
             sample = np.concatenate([ctx, text], axis=1)
-            a, c, _ = O.lstm_step_fwd(sample @ p['lstm/kernel'] + p['lstm/bias'], a, c, p['lstm/recurrent_kernel'])
+            a, c = self._cell(sample, a, c)
             inter, _ = O.dense_fwd(a, p['time_distributed_nonlinear/kernel'],
                                    p['time_distributed_nonlinear/bias'], O.ACT_LEAKY)
             probs = O.softmax(inter @ p['time_distributed_softmax/kernel'] + p['time_distributed_softmax/bias'])
@@ -673,8 +704,7 @@ class LcNIC:
             text = p['emb_text/embeddings'][word]
             (ctx, alpha, s), _ = O.attention_step_fwd(a, F, P, p['attention/W2/kernel'], p['attention/W2/bias'],
                                                       p['attention/V/kernel'], p['attention/V/bias'])
-            a, c, _ = O.lstm_step_fwd(np.concatenate([ctx, text], axis=1) @ p['lstm/kernel'] + p['lstm/bias'], a, c,
-                                      p['lstm/recurrent_kernel'])
+            a, c = self._cell(np.concatenate([ctx, text], axis=1), a, c)
             inter, _ = O.dense_fwd(a, p['time_distributed_nonlinear/kernel'], p['time_distributed_nonlinear/bias'], O.ACT_LEAKY)
             probs = O.softmax(inter @ p['time_distributed_softmax/kernel'] + p['time_distributed_softmax/bias'])
             cand = score[:, :, None] + np.log(np.maximum(probs, 1e-30)).reshape(B, k, V)

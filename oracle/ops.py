@@ -254,6 +254,39 @@ def lstm_step_bwd(dh2, dc2, cache, U):
 
 
 # ----------------------------------------------------------- softmax + losses
+def ln_lstm_step_fwd(x, h, c, W, U, b, gk, bk, gr, br, gs, bs, eps=BN_EPS):
+    """tensorflow_addons.rnn.LayerNormLSTMCell.call (tfa 0.15; the use_layer_norm branch of lc_NIC.py:126-136):
+        z = LN_kernel(x @ W) + LN_recurrent(h @ U) + b;  i, f, c~, o = split(z)
+        c' = LN_state(sigmoid(f) * c + sigmoid(i) * tanh(c~));  h' = sigmoid(o) * tanh(c')
+    three keras LayerNormalization(epsilon = norm_epsilon = 1e-3) layers over the last axis; no dropout inside the
+    cell.  The NORMALISED c' is the state that is carried.  Restated from the published tfa source (the package is
+    not installable here): parity unpinned.  Returns (h', c', cache)."""
+    Un = h.shape[1]
+    zk, ck = layernorm_fwd(x @ W, gk, bk, eps)
+    zr, cr = layernorm_fwd(h @ U, gr, br, eps)
+    z = zk + zr + b
+    i, f = sigmoid(z[:, :Un]), sigmoid(z[:, Un:2 * Un])
+    g, o = np.tanh(z[:, 2 * Un:3 * Un]), sigmoid(z[:, 3 * Un:])
+    c_raw = f * c + i * g
+    cn, cs = layernorm_fwd(c_raw, gs, bs, eps)
+    tc = np.tanh(cn)
+    return o * tc, cn, (x, h, c, i, f, g, o, tc, ck, cr, cs)
+
+
+def ln_lstm_step_bwd(dh2, dcn, cache, W, U, gk, gr, gs):
+    """Returns (dx, dh_prev, dc_prev, grads) with grads = dict(W, U, b, gk, bk, gr, br, gs, bs)."""
+    x, h, c, i, f, g, o, tc, ck, cr, cs = cache
+    do = dh2 * tc
+    dcn_t = dcn + dh2 * o * (1 - tc * tc)
+    dc_raw, dgs, dbs = layernorm_bwd(dcn_t, gs, cs)
+    dz = np.concatenate([dc_raw * g * i * (1 - i), dc_raw * c * f * (1 - f), dc_raw * i * (1 - g * g),
+                         do * o * (1 - o)], axis=1)
+    dzk, dgk, dbk = layernorm_bwd(dz, gk, ck)
+    dzr, dgr, dbr = layernorm_bwd(dz, gr, cr)
+    grads = dict(W=x.T @ dzk, U=h.T @ dzr, b=dz.sum(axis=0), gk=dgk, bk=dbk, gr=dgr, br=dbr, gs=dgs, bs=dbs)
+    return dzk @ W.T, dzr @ U.T, dc_raw * f, grads
+
+
 def gru_step_fwd(xz, h, Uk, br):
     """keras GRU cell, reset_after=True (the TF2 default; ThinkAndTell/att_model.py:84-93): xz = x@W + b_i (B,3U)
     in keras gate order [z, r, h]; Uk (U,3U); br (3U,) the recurrent bias."""

@@ -119,8 +119,33 @@ class MockBackend:
         dxo, dg, db = O.batchnorm_bwd(mat(dy, rows, C, lddy).astype(np.float64), flat(gamma)[:C].astype(np.float64), cache)
         if dx is not None:
             mat(dx, rows, C, C)[...] = dxo
-        flat(dgamma)[:C] = dg
-        flat(dbeta)[:C] = db
+        if dgamma is not None:
+            flat(dgamma)[:C] = dg
+            flat(dbeta)[:C] = db
+
+    def ln_lstm_cell_fwd(self, zk, zr, bias, c_prev, gamma_s, beta_s, gates, chat, istd, c, h, B, U, eps):
+        """include/tnt_hip.h: tnt_ln_lstm_cell_fwd_f32 (gate-interleaved [B][U][4] tensors)"""
+        z = (flat(zk)[:B * U * 4].astype(np.float64) + flat(zr)[:B * U * 4]).reshape(B, U, 4) + flat(bias)[:U * 4].astype(np.float64).reshape(1, U, 4)
+        gi, gf, gg, go = O.sigmoid(z[..., 0]), O.sigmoid(z[..., 1]), np.tanh(z[..., 2]), O.sigmoid(z[..., 3])
+        craw = gf * flat(c_prev)[:B * U].astype(np.float64).reshape(B, U) + gi * gg
+        cn, (xh, inv) = O.layernorm_fwd(craw, flat(gamma_s)[:U].astype(np.float64), flat(beta_s)[:U].astype(np.float64), eps)
+        flat(gates)[:B * U * 4] = np.stack([gi, gf, gg, go], -1).reshape(-1)
+        flat(chat)[:B * U] = xh.reshape(-1); flat(istd)[:B] = inv.reshape(-1)
+        flat(c)[:B * U] = cn.reshape(-1); flat(h)[:B * U] = (go * np.tanh(cn)).reshape(-1)
+
+    def ln_lstm_cell_bwd(self, dh_a, dh_b, dh_c, dcn_in, gates, c_prev, c, chat, istd, gamma_s, dz, dc_prev, dcnt, B, U):
+        f64 = lambda t, *sh: flat(t)[:int(np.prod(sh))].astype(np.float64).reshape(*sh)
+        dh = sum(f64(t, B, U) for t in (dh_a, dh_b, dh_c) if t is not None)
+        g4 = f64(gates, B, U, 4)
+        gi, gf, gg, go = g4[..., 0], g4[..., 1], g4[..., 2], g4[..., 3]
+        tc = np.tanh(f64(c, B, U))
+        dcn = (f64(dcn_in, B, U) if dcn_in is not None else 0) + dh * go * (1 - tc * tc)
+        dcr, _, _ = O.layernorm_bwd(dcn, f64(gamma_s, U), (f64(chat, B, U), f64(istd, B)[:, None]))
+        cp = f64(c_prev, B, U)
+        out = np.stack([dcr * gg * gi * (1 - gi), dcr * cp * gf * (1 - gf), dcr * gi * (1 - gg * gg), dh * tc * go * (1 - go)], -1)
+        flat(dcnt)[:B * U] = dcn.reshape(-1)
+        flat(dz)[:B * U * 4] = out.reshape(-1)
+        flat(dc_prev)[:B * U] = (dcr * gf).reshape(-1)
 
     def enc_tail_fwd(self, y, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C, ldo, training, eps, momentum,
                      r_feat, r_lstm, seed, site_feat, site_lstm, step_dev=None):
@@ -159,8 +184,33 @@ class MockBackend:
         dxo, dg, db = O.layernorm_bwd(mat(dy, rows, C, lddy).astype(np.float64), flat(gamma)[:C].astype(np.float64), cache)
         if dx is not None:
             mat(dx, rows, C, C)[...] = dxo
-        flat(dgamma)[:C] = dg
-        flat(dbeta)[:C] = db
+        if dgamma is not None:
+            flat(dgamma)[:C] = dg
+            flat(dbeta)[:C] = db
+
+    def ln_lstm_cell_fwd(self, zk, zr, bias, c_prev, gamma_s, beta_s, gates, chat, istd, c, h, B, U, eps):
+        """include/tnt_hip.h: tnt_ln_lstm_cell_fwd_f32 (gate-interleaved [B][U][4] tensors)"""
+        z = (flat(zk)[:B * U * 4].astype(np.float64) + flat(zr)[:B * U * 4]).reshape(B, U, 4) + flat(bias)[:U * 4].astype(np.float64).reshape(1, U, 4)
+        gi, gf, gg, go = O.sigmoid(z[..., 0]), O.sigmoid(z[..., 1]), np.tanh(z[..., 2]), O.sigmoid(z[..., 3])
+        craw = gf * flat(c_prev)[:B * U].astype(np.float64).reshape(B, U) + gi * gg
+        cn, (xh, inv) = O.layernorm_fwd(craw, flat(gamma_s)[:U].astype(np.float64), flat(beta_s)[:U].astype(np.float64), eps)
+        flat(gates)[:B * U * 4] = np.stack([gi, gf, gg, go], -1).reshape(-1)
+        flat(chat)[:B * U] = xh.reshape(-1); flat(istd)[:B] = inv.reshape(-1)
+        flat(c)[:B * U] = cn.reshape(-1); flat(h)[:B * U] = (go * np.tanh(cn)).reshape(-1)
+
+    def ln_lstm_cell_bwd(self, dh_a, dh_b, dh_c, dcn_in, gates, c_prev, c, chat, istd, gamma_s, dz, dc_prev, dcnt, B, U):
+        f64 = lambda t, *sh: flat(t)[:int(np.prod(sh))].astype(np.float64).reshape(*sh)
+        dh = sum(f64(t, B, U) for t in (dh_a, dh_b, dh_c) if t is not None)
+        g4 = f64(gates, B, U, 4)
+        gi, gf, gg, go = g4[..., 0], g4[..., 1], g4[..., 2], g4[..., 3]
+        tc = np.tanh(f64(c, B, U))
+        dcn = (f64(dcn_in, B, U) if dcn_in is not None else 0) + dh * go * (1 - tc * tc)
+        dcr, _, _ = O.layernorm_bwd(dcn, f64(gamma_s, U), (f64(chat, B, U), f64(istd, B)[:, None]))
+        cp = f64(c_prev, B, U)
+        out = np.stack([dcr * gg * gi * (1 - gi), dcr * cp * gf * (1 - gf), dcr * gi * (1 - gg * gg), dh * tc * go * (1 - go)], -1)
+        flat(dcnt)[:B * U] = dcn.reshape(-1)
+        flat(dz)[:B * U * 4] = out.reshape(-1)
+        flat(dc_prev)[:B * U] = (dcr * gf).reshape(-1)
 
     def colsum(self, x, out, rows, C, ld, work):
         flat(out)[:C] = mat(x, rows, C, ld).astype(np.float64).sum(0)

@@ -13,12 +13,14 @@ pytestmark = pytest.mark.gpu
 DIMS = [(3, 37, 4, 16, 3, 16, 6, 11, 4), (8, 2000, 36, 32, 32, 64, 64, 501, 15)]
 
 
-def build(rng, rates, dims, norm="batch", use_graph=True, depth=0):
+def build(rng, rates, dims, norm="batch", use_graph=True, depth=0, use_layer_norm=False):
     from masters_thesis_amd.lc_nic import NIC
     B, N, R, D, A, U, Et, V, T = dims
     g = (tiny_groups(N, R, rng), [D] * R)
-    model = NIC(g, U, 512, Et, A, V, T, *rates, 0.01, 0.001, 3e-5, 1e-5, norm=norm, seed=11, use_graph=use_graph, depth=depth)
-    orc = M.LcNIC(g, U, 512, Et, A, V, T, *rates, 0.01, 0.001, 3e-5, 1e-5, norm=norm, depth=depth).init_params(rng)
+    model = NIC(g, U, 512, Et, A, V, T, *rates, 0.01, 0.001, 3e-5, 1e-5, norm=norm, seed=11, use_graph=use_graph, depth=depth,
+                use_layer_norm=use_layer_norm)
+    orc = M.LcNIC(g, U, 512, Et, A, V, T, *rates, 0.01, 0.001, 3e-5, 1e-5, norm=norm, depth=depth,
+                  use_layer_norm=use_layer_norm).init_params(rng)
     for k, v in orc.p.items():
         model.set_weight(k, v)
     return model, orc
@@ -163,6 +165,45 @@ def test_train_step_sam_parity(dims):
                 continue
             w = model.get_weight(k)
             assert np.abs(w - v).max() <= 2e-2 * 1e-3 + 1e-4 * np.abs(v).max(), (step, k, np.abs(w - v).max())
+
+
+@pytest.mark.parametrize("dims", DIMS)
+def test_layer_norm_lstm_cell_parity(dims):
+    """use_layer_norm=True (lc_NIC.py:115,126-136: tensorflow_addons LayerNormLSTMCell as the decoder cell): training
+    steps incl. hipGraph replay, step-0 gradients of every variable, test_step, greedy captions."""
+    from masters_thesis_amd.optimizers import Adam
+    rng = np.random.default_rng(58)
+    B, N, R, D, A, U, Et, V, T = dims
+    model, orc = build(rng, (0.1, 0.2, 0.2, 0.2, 0.2, 0.2), dims, use_layer_norm=True)
+    model.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    opt = M.AdamState(orc.p, lr=1e-3, clipnorm=0.1)
+    for step in range(4):
+        data, tgt = synth_batch(B, N, T, V, U, rng)
+        w0 = {k: v.copy() for k, v in orc.p.items()}
+        res, grads, _ = orc.train_step(data, tgt, opt, M.DropCtx(seed=11, step=step, training=True))
+        got = model.train_step((data, tgt)).as_floats()
+        for k in ("loss", "L2", "attention"):
+            assert abs(got[k] - res[k]) <= 1e-4 * abs(res[k]) + 1e-7, (step, k, got[k], res[k])
+        if step == 0:
+            for k in orc.trainable():
+                if k == "attention/V/bias":
+                    continue
+                g = model.get_gradient(k) + 2 * model.arena.entries[k].l2 * w0[k]
+                assert np.abs(g - grads[k]).max() <= 3e-4 * np.abs(grads[k]).max() + 1e-9, (k, np.abs(g - grads[k]).max())
+        for k, v in orc.p.items():
+            if k == "attention/V/bias":
+                continue
+            w = model.get_weight(k)
+            assert np.abs(w - v).max() <= 2e-2 * 1e-3 + 1e-4 * np.abs(v).max(), (step, k, np.abs(w - v).max())
+    want = orc.test_step(data, tgt)[0]
+    got = model.test_step((data, tgt)).as_floats()
+    for k in want:
+        assert abs(got[k] - want[k]) <= 1e-4 * abs(want[k]) + 1e-6, (k, got[k], want[k])
+    orc.p = {k: v.astype(np.float64) for k, v in model.get_weights_dict().items()}
+    z = np.zeros((B, U), np.float32)
+    ww, wp, _, _ = orc.greedy_predict(data[0], z, z, np.ones(B, np.int64), T)
+    gw, gp, _, _ = model.greedy_predict(data[0], z, z, np.ones(B, np.int64), T, U, None)
+    assert np.array_equal(gw, ww) and np.abs(gp - wp).max() <= 1e-4
 
 
 @pytest.mark.parametrize("dims", DIMS)

@@ -359,6 +359,42 @@ def test_step_finalize(be):
     assert int(adam_t) == 5 and int(drop) == 10
 
 
+@pytest.mark.parametrize("B,U", [(64, 512), (5, 16), (7, 1040)])
+def test_ln_lstm_cell(be, B, U):
+    """tnt_ln_lstm_cell_fwd/bwd_f32 + the two 4U-wide tnt_layernorm launches against oracle ln_lstm_step_fwd/bwd
+    (tensorflow_addons LayerNormLSTMCell, lc_NIC.py:126-136): states, gates, every input gradient."""
+    rng = np.random.default_rng(B + U)
+    Din = 24
+    x, h, c = rng.standard_normal((B, Din)), rng.standard_normal((B, U)) * 0.5, rng.standard_normal((B, U)) * 0.5
+    W, Ur = rng.standard_normal((Din, 4 * U)) / np.sqrt(Din), rng.standard_normal((U, 4 * U)) / np.sqrt(U)
+    b = rng.standard_normal(4 * U) * 0.1
+    gk, bk, gr, br = (1 + 0.1 * rng.standard_normal(4 * U), 0.1 * rng.standard_normal(4 * U),
+                      1 + 0.1 * rng.standard_normal(4 * U), 0.1 * rng.standard_normal(4 * U))
+    gs, bs = 1 + 0.1 * rng.standard_normal(U), 0.1 * rng.standard_normal(U)
+    h2, c2, cache = O.ln_lstm_step_fwd(x, h, c, W, Ur, b, gk, bk, gr, br, gs, bs)
+    f = lambda *sh: torch.zeros(*sh, device="cuda")
+    zk, zr, xhk, xhr, isk, isr = f(B, U, 4), f(B, U, 4), f(B, 4 * U), f(B, 4 * U), f(max(B, 4 * U)), f(max(B, 4 * U))
+    be.layernorm_fwd(dev(il(x @ W, U)), dev(il(gk, U)), dev(il(bk, U)), zk, xhk, isk, B, 4 * U, 4 * U, 1e-3)
+    be.layernorm_fwd(dev(il(h @ Ur, U)), dev(il(gr, U)), dev(il(br, U)), zr, xhr, isr, B, 4 * U, 4 * U, 1e-3)
+    gates, chat, iss, cn, hn = f(B, U, 4), f(B, U), f(B), f(B, U), f(B, U)
+    be.ln_lstm_cell_fwd(zk, zr, dev(il(b, U)), dev(c), dev(gs), dev(bs), gates, chat, iss, cn, hn, B, U, 1e-3)
+    close(hn, h2); close(cn, c2)
+    close(gates, np.stack(cache[3:7], axis=-1))
+    dh2, dcn = rng.standard_normal((B, U)), rng.standard_normal((B, U))
+    dx, dh, dc, gl = O.ln_lstm_step_bwd(dh2, dcn, cache, W, Ur, gk, gr, gs)
+    dz, dcp, dcnt = f(B, U, 4), f(B, U), f(B, U)
+    half = dev(dh2 * 0.5)
+    be.ln_lstm_cell_bwd(half, half, None, dev(dcn), gates, dev(c), cn, chat, iss, dev(gs), dz, dcp, dcnt, B, U)
+    close(dcp, dc)
+    dzk, dzr = f(B, 4 * U), f(B, 4 * U)
+    be.layernorm_bwd(dz, xhk, dev(il(gk, U)), isk, dzk, None, None, B, 4 * U, 4 * U, None)
+    be.layernorm_bwd(dz, xhr, dev(il(gr, U)), isr, dzr, None, None, B, 4 * U, 4 * U, None)
+    close(unil(dzk.view(B, U, 4).cpu().numpy()) @ W.T, dx)
+    close(unil(dzr.view(B, U, 4).cpu().numpy()) @ Ur.T, dh)
+    close(unil(dz.cpu().numpy()).sum(0), gl["b"])
+    close((dcnt.cpu().numpy().astype(np.float64) * chat.cpu().numpy()).sum(0), gl["gs"], atol=1e-4 * np.abs(gl["gs"]).max())
+
+
 @pytest.mark.parametrize("B,U,D,masked", [(64, 512, 0, False), (64, 512, 32, False), (5, 16, 3, False),
                                           (20, 32, 0, True)])
 def test_lstm_step(be, B, U, D, masked):

@@ -22,14 +22,14 @@ def mock_backend():
 ARGS = dict(B=4, N=41, R=5, D=16, A=6, U=16, Et=12, V=13, T=5)
 
 
-def make_pair(rng, rates, norm="batch", seed=11, depth=0, **d):
+def make_pair(rng, rates, norm="batch", seed=11, depth=0, use_layer_norm=False, **d):
     d = {**ARGS, **d}
     groups = tiny_groups(d["N"], d["R"], rng)
     g = (groups, [d["D"]] * d["R"])
     model = NIC(g, d["U"], 512, d["Et"], d["A"], d["V"], d["T"], *rates, 0.01, 0.001, 3e-5, 1e-5, norm=norm,
-                device="cpu", seed=seed, depth=depth)
+                device="cpu", seed=seed, depth=depth, use_layer_norm=use_layer_norm)
     orc = M.LcNIC(g, d["U"], 512, d["Et"], d["A"], d["V"], d["T"], *rates, 0.01, 0.001, 3e-5, 1e-5,
-                  norm=norm, depth=depth).init_params(rng)
+                  norm=norm, depth=depth, use_layer_norm=use_layer_norm).init_params(rng)
     for k, v in orc.p.items():
         model.set_weight(k, v)
         assert np.allclose(model.get_weight(k), v, atol=1e-6)
@@ -224,3 +224,42 @@ def test_train_step_sam_matches_oracle(depth):
                 continue
             # atol: 2 % of one Adam update (lr = 1e-3)
             assert np.allclose(model.get_weight(k), v, rtol=2e-4, atol=2e-5), (step, k, np.abs(model.get_weight(k) - v).max())
+
+
+def test_layer_norm_lstm_cell_matches_oracle():
+    """use_layer_norm=True: tfa LayerNormLSTMCell as the decoder cell (lc_NIC.py:115,126-136) -- training steps (every
+    gradient incl. the three LayerNorms', via the post-Adam weights), test_step, greedy captions and beam search."""
+    rng = np.random.default_rng(64)
+    model, orc, d = make_pair(rng, (0.1, 0.2, 0.2, 0.2, 0.2, 0.2), use_layer_norm=True)
+    model.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    opt = M.AdamState(orc.p, lr=1e-3, clipnorm=0.1)
+    B, U, T = d["B"], d["U"], d["T"]
+    for step in range(3):
+        data, tgt = synth_batch(B, d["N"], T, d["V"], U, rng)
+        w0 = {k: v.copy() for k, v in orc.p.items()}
+        res, grads, _ = orc.train_step(data, tgt, opt, M.DropCtx(seed=11, step=step, training=True))
+        got = model.train_step((data, tgt)).as_floats()
+        for k in ("loss", "L2", "attention", "accuracy"):
+            assert abs(got[k] - res[k]) < 3e-5 * max(1, abs(res[k])), (step, k, got[k], res[k])
+        if step == 0:
+            for k in orc.trainable():
+                if k == "attention/V/bias":
+                    continue
+                g = model.get_gradient(k) + 2 * model.arena.entries[k].l2 * w0[k]
+                assert np.allclose(g, grads[k], rtol=2e-4, atol=1e-5 * np.abs(grads[k]).max() + 1e-9), k
+        for k, v in orc.p.items():
+            if k == "attention/V/bias":
+                continue
+            assert np.allclose(model.get_weight(k), v, rtol=2e-4, atol=2e-5), (step, k, np.abs(model.get_weight(k) - v).max())
+    want = orc.test_step(data, tgt)[0]
+    got = model.test_step((data, tgt)).as_floats()
+    for k in want:
+        assert abs(got[k] - want[k]) < 3e-5 * max(1, abs(want[k])), (k, got[k], want[k])
+    z = np.zeros((B, U), np.float32)
+    ww, wp, _, _ = orc.greedy_predict(data[0], z, z, np.ones(B, np.int64), T)
+    gw, gp, _, _ = model.greedy_predict(data[0], z, z, np.ones(B, np.int64), T, U, None)
+    assert np.array_equal(gw, ww) and np.abs(gp - wp).max() < 1e-5
+    bs, _, margin = orc.beam_search(data[0], z, z, np.ones(B, np.int64), T, k=3)
+    gb, _ = model.beam_search(data[0], z, z, np.ones(B, np.int64), T, beam_width=3)
+    ok = margin > 1e-5
+    assert np.array_equal(gb[ok], bs[ok])
