@@ -144,6 +144,13 @@ int32_t tnt_locally_dense_bwd_split_f32(const float* x, int32_t ldx, const int32
                                         const float* dpre, float* dW, float* db, int32_t B, int32_t R,
                                         int32_t D, int32_t x_voxel_major, void* stream);
 
+/* ---- forward of the dense voxel encoder at small batch, as K-split partials ---------------------------
+ * part[s][B][E] = x[B][K slice s] @ w[K slice s][E], s < nsplit; x [B][ldx] (K % 4 == 0, ldx % 4 == 0), w [K][ldw]
+ * keras (in, out) kernel, E % 32 == 0, nsplit <= 64, all 16-byte aligned.  (NIC.py:64-69,125; ThinkAndTell
+ * model.py:22-33.)  The sum over s (+ bias + LeakyReLU) is taken by tnt_enc_tail_fwd_sk_f32. */
+int32_t tnt_dense_fwd_stream_f32(const float* x, const float* w, float* part, int32_t B, int32_t E, int32_t K,
+                                 int32_t ldx, int32_t ldw, int32_t nsplit, void* stream);
+
 /* ---- weight gradient of the dense voxel encoder at small batch:  dw[N][E] = x^T @ dpre --------------
  * x [Bk][ldx] (the betas, Bk <= 64 rows), dpre [Bk][E] (E % 32 == 0, E <= 512, 16-byte aligned), dw [N][E].
  * (NIC.py:64-69,248-249; ThinkAndTell model.py:22-33.)  Same result as tnt_gemm_f32(transA=1) up to f32
@@ -164,6 +171,13 @@ int32_t tnt_enc_tail_fwd_f32(const float* y, const float* gamma, const float* be
                              int32_t C, int32_t ldo, int32_t training, float eps, float momentum,
                              float r_feat, float r_lstm, uint64_t seed, uint32_t site_feat,
                              uint32_t site_lstm, const uint32_t* step_dev, void* stream);
+/* fwd from the K-split partials of tnt_dense_fwd_stream_f32: y = LeakyReLU(sum_s part[s] + bias, slope) in split
+ * order (the Dense layer's output, NIC.py:125; pre-activation stored to pre [rows][C] for the backward), then as above. */
+int32_t tnt_enc_tail_fwd_sk_f32(const float* part, int32_t nsplit, const float* bias, float* pre, float slope,
+                                const float* gamma, const float* beta, float* mov_mean, float* mov_var, float* out,
+                                float* xhat, float* inv_std, int32_t rows, int32_t C, int32_t ldo, int32_t training,
+                                float eps, float momentum, float r_feat, float r_lstm, uint64_t seed,
+                                uint32_t site_feat, uint32_t site_lstm, const uint32_t* step_dev, void* stream);
 int32_t tnt_enc_tail_bwd_f32(const float* dout, const float* xhat, const float* gamma, const float* inv_std,
                              const float* pre, float* dpre, float* dgamma, float* dbeta, float* dbias,
                              int32_t rows, int32_t C, int32_t ldo, float r_feat, float r_lstm, float slope,

@@ -403,6 +403,155 @@ __global__ __launch_bounds__(512) void dense_dw_skinny_kernel(DwArgs a) {
 }
 
 
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// Skinny-M forward of the dense voxel encoder:  part[s][B][E] = X[B][K-slice s] @ W[K-slice s][E]  with B <= 64 per
+// row block (NIC.dense_in / ThinkAndTell Encoder.fc, NIC.py:64-69,125; model.py:22-33).  The product streams the
+// 41 MB kernel once for 1.3 GFLOP: 6.5 us of HBM and 8.4 us of FP32 matrix work, where the generic tiled GEMM with
+// split-K spends 20 us (512 short-lived 64x64 tiles of ten LDS-staged chunks each) plus a 7 us reduce launch.
+// Here nothing goes through LDS on the way in.  A workgroup owns 32 output columns and one K split; its four waves
+// split the K range once more, tile by tile of 16 k, and every wave accumulates the full 64 x 32 block:
+//   A fragments  one dwordx4 per row tile: lane (kq, m) reads X[16 rt + m][k0 + 4 kq .. +3]  (k permuted inside the
+//                tile: MFMA step j multiplies k0 + 4 kq + j, the same on both operands),
+//   B fragments  one dwordx2 per k row:   lane (kq, n) reads W[k0 + 4 kq + j][c0 + 2 n, +1]  -- 16 lanes cover one
+//                128-byte line; column tile c of the MFMA is column 2 n + c (a permutation undone at the store),
+// i.e. 8 loads per 32 MFMAs, a ring of register stages per wave.  Tile i belongs to wave slot i % (4 nsplit), so at
+// any moment the chip reads one contiguous window of W.  The four wave partials meet in LDS; the <= 16 K-split
+// partials (2 MB) are summed by the encoder-tail kernel (tnt_enc_tail_fwd_sk_f32), which needs whole columns anyway.
+namespace {
+constexpr int DF_CW = 32;            // output columns per workgroup
+
+struct DfArgs { const float* x; const float* w; float* part; int B, E, K, ldx, ldw, nsplit; };
+
+template <int NW, int DEPTH>
+__global__ __launch_bounds__(64 * NW) void dense_fwd_stream_kernel(DfArgs a) {
+  __shared__ float red[NW][64][DF_CW + 4];
+  const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, ln = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Workgroup -> (column group, K split).  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2:
+  // when the splits divide by 8, an XCD gets ALL column groups of its nsplit / 8 splits, so its L2 sees whole rows of
+  // W and only its own eighth of X.
+  const int nct = a.E / DF_CW;
+  int ct, split;
+  if (a.nsplit % 8 == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    ct = slot % nct; split = xcd * (a.nsplit / 8) + slot / nct;
+  } else {
+    ct = blockIdx.x % nct; split = blockIdx.x / nct;
+  }
+  const int c0 = ct * DF_CW, rb = blockIdx.y * 64;
+  const int nslot = a.nsplit * NW, q = split * NW + w;
+  const int Tfull = a.K / 16;                       // full 16-k tiles; a K % 16 remainder is one masked tile at the end
+  const int nt = q < Tfull ? (Tfull - q + nslot - 1) / nslot : 0;
+  // Addresses = uniform tile base (scalar registers, scalar arithmetic) + a per-lane byte offset that never changes:
+  // the loop issues no vector address arithmetic at all.  Rows past B read row B-1 (their outputs are never stored:
+  // an output row of the MFMA depends on the same row of A only).
+  unsigned aoff[4], boff[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) aoff[rt] = ((unsigned)min(rb + rt * 16 + ln, a.B - 1) * a.ldx + kq * 4) * 4u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) boff[j] = ((unsigned)(kq * 4 + j) * a.ldw + c0 + 2 * ln) * 4u;
+  floatx4 acc[4][2];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[rt][c] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  float4 av[DEPTH][4];
+  float2 bv[DEPTH][4];
+  auto load = [&](int s, int tile) {                // tiles past the end re-read the last full tile (never multiplied)
+    const int tc = max(min(tile, Tfull - 1), 0);
+    const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)tc * 64;
+    const char* wb = reinterpret_cast<const char*>(a.w) + (size_t)tc * 64 * a.ldw;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) av[s][rt] = *reinterpret_cast<const float4*>(xb + aoff[rt]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[s][j] = *reinterpret_cast<const float2*>(wb + boff[j]);
+  };
+  auto mac = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const float4 v = av[s][rt];
+        const float x = j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
+        acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, bv[s][j].x, acc[rt][0], 0, 0, 0);
+        acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, bv[s][j].y, acc[rt][1], 0, 0, 0);
+      }
+    }
+  };
+  // Ring of DEPTH register stages.  Region i multiplies tile i (stage i % DEPTH) while the loads of tile i + DEPTH - 1
+  // are issued into the stage tile i - 1 just left, one load per four MFMAs: DEPTH - 2 whole regions (1024 MFMA cycles
+  // each) lie between a load and its use.
+#pragma unroll
+  for (int s = 0; s < DEPTH - 1; ++s) load(s, q + s * nslot);
+  int i = 0;
+  for (; i + DEPTH <= nt; i += DEPTH) {
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) {
+      load((s + DEPTH - 1) % DEPTH, q + (i + s + DEPTH - 1) * nslot);
+      mac(s);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // 4 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // 1 VMEM read
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < DEPTH - 1; ++s)
+    if (i + s < nt) mac(s);
+  if ((a.K & 15) && q == Tfull % nslot) {           // the partial tile: lanes with k >= K clamp their address, A := 0
+    const int k0 = Tfull * 16 + kq * 4, ka = min(k0, a.K - 4);
+    const float keep = k0 < a.K ? 1.f : 0.f;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const float4 v = *reinterpret_cast<const float4*>(a.x + (long)min(rb + rt * 16 + ln, a.B - 1) * a.ldx + ka);
+      av[0][rt] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[0][j] = *reinterpret_cast<const float2*>(a.w + (long)(ka + j) * a.ldw + c0 + 2 * ln);
+    mac(0);
+  }
+  // C/D map: col = lane & 15 -> output column 2 n + c, row = 4 kq + reg
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<float2*>(&red[w][rt * 16 + kq * 4 + r][2 * ln]) = make_float2(acc[rt][0][r], acc[rt][1][r]);
+  __syncthreads();
+  for (int e = tid; e < 64 * (DF_CW / 4); e += 64 * NW) {
+    const int row = e / (DF_CW / 4), c4 = (e % (DF_CW / 4)) * 4;
+    if (rb + row >= a.B) continue;
+    float4 t = *reinterpret_cast<const float4*>(&red[0][row][c4]);
+#pragma unroll
+    for (int k = 1; k < NW; ++k) {
+      const float4 u = *reinterpret_cast<const float4*>(&red[k][row][c4]);
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    *reinterpret_cast<float4*>(a.part + ((long)split * a.B + rb + row) * a.E + c0 + c4) = t;
+  }
+}
+}  // namespace
+
+extern "C" int32_t tnt_dense_fwd_stream_f32(const float* x, const float* w, float* part, int32_t B, int32_t E,
+                                            int32_t K, int32_t ldx, int32_t ldw, int32_t nsplit, void* stream) {
+  if (B <= 0 || K < 4 || K % 4 != 0 || ldx < K || ldx % 4 != 0) return TNT_BADARG(6);
+  if (E <= 0 || E % DF_CW != 0 || ldw < E || ldw % 2 != 0 || nsplit <= 0 || nsplit > 64) return TNT_BADARG(5);
+  if (!tnt_aligned16(x) || !tnt_aligned16(w) || !tnt_aligned16(part)) return TNT_BADARG(1);
+  if ((long)B * ldx * 4 >= (1L << 32) || 16L * ldw * 4 >= (1L << 32)) return TNT_BADARG(4);      // 32-bit lane offsets
+  DfArgs a{x, w, part, B, E, K, ldx, ldw, nsplit};
+  // Ring depth / waves measured on MI355X at 64 x 20000 x 512 (tools/enc_fwd_probe.py): 4 waves x depth 4: 17.3 us per
+  // back-to-back launch, depth 5 / 6: 18.0 / 18.5, 8 waves x depth 4 / 5: 18.3 / 19.6; loads served from L1 instead of
+  // HBM: 17.3 -- the loop is bound by the 20480 MFMA cycles per wave plus ramp-up, not by memory.
+  hipLaunchKernelGGL((dense_fwd_stream_kernel<4, 4>), dim3((E / DF_CW) * nsplit, (B + 63) / 64), dim3(256), 0,
+                     tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+namespace {
 // ---- input gradient of a stack of per-region Dense layers (the deeper stages of deep_layers.LocallyDense,
 // AttemptFour/Model/deep_layers.py:53-59: layer_r(x[:, r, :]) for every region r):
 //   dx[b][r][k] = sum_n dpre[b][r][n] * W_r[k][n],   W = [R][Din][Dout] (keras (in, out) kernels, concatenated)

@@ -435,6 +435,8 @@ struct EncTailArgs {
   int rows, C, ldo, training;
   float eps, momentum, r_feat, r_lstm, slope;
   uint64_t seed; uint32_t site_feat, site_lstm; const uint32_t* step_dev;
+  // forward from split-K partials (SK): y = leaky(sum_s part[s] + bias), pre-activation kept for the backward
+  const float* part; const float* bias; float* pre_out; int nsplit;
 };
 
 // column sums of a per-thread float4 over the 32 row groups, fixed order; result valid in every thread
@@ -459,6 +461,7 @@ __device__ __forceinline__ float4 et_drop4(float4 v, uint64_t e, float rate, flo
                      k[3] ? v.w * scale : 0.f);
 }
 
+template <bool SK>
 __global__ __launch_bounds__(256) void enc_tail_fwd_kernel(EncTailArgs a) {
   __shared__ float4 red[ET_RG][ET_CW / 4];
   const int c4 = threadIdx.x % (ET_CW / 4), rg = threadIdx.x / (ET_CW / 4);
@@ -473,7 +476,21 @@ __global__ __launch_bounds__(256) void enc_tail_fwd_kernel(EncTailArgs a) {
     const int r = rg + ET_RG * k;
     v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cok && r < a.rows) {
-      float4 x = *reinterpret_cast<const float4*>(a.y + (long)r * a.C + col);
+      float4 x;
+      if (SK) {       // the dense layer's K-split partials, summed in split order, + bias, LeakyReLU (NIC.py:125)
+        x = *reinterpret_cast<const float4*>(a.bias + col);
+        const float* pp = a.part + (long)r * a.C + col;
+#pragma unroll 8
+        for (int sp = 0; sp < a.nsplit; ++sp) {
+          const float4 u = *reinterpret_cast<const float4*>(pp + (long)sp * a.rows * a.C);
+          x.x += u.x; x.y += u.y; x.z += u.z; x.w += u.w;
+        }
+        *reinterpret_cast<float4*>(a.pre_out + (long)r * a.C + col) = x;
+        x.x = x.x > 0.f ? x.x : x.x * a.slope; x.y = x.y > 0.f ? x.y : x.y * a.slope;
+        x.z = x.z > 0.f ? x.z : x.z * a.slope; x.w = x.w > 0.f ? x.w : x.w * a.slope;
+      } else {
+        x = *reinterpret_cast<const float4*>(a.y + (long)r * a.C + col);
+      }
       if (a.training && a.r_feat > 0.f) x = et_drop4(x, (uint64_t)r * a.C + col, a.r_feat, sc_f, a.seed, a.site_feat, step);
       v[k] = x;
       s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
@@ -599,7 +616,29 @@ extern "C" int32_t tnt_enc_tail_fwd_f32(const float* y, const float* gamma, cons
   a.inv_std = inv_std; a.rows = rows; a.C = C; a.ldo = ldo; a.training = training; a.eps = eps; a.momentum = momentum;
   a.r_feat = r_feat; a.r_lstm = r_lstm; a.seed = seed; a.site_feat = site_feat; a.site_lstm = site_lstm;
   a.step_dev = step_dev;
-  hipLaunchKernelGGL(enc_tail_fwd_kernel, dim3((C + ET_CW - 1) / ET_CW), dim3(256), 0, tnt_stream(stream), a);
+  hipLaunchKernelGGL(enc_tail_fwd_kernel<false>, dim3((C + ET_CW - 1) / ET_CW), dim3(256), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_enc_tail_fwd_sk_f32(const float* part, int32_t nsplit, const float* bias, float* pre, float slope,
+                                           const float* gamma, const float* beta, float* mov_mean, float* mov_var,
+                                           float* out, float* xhat, float* inv_std, int32_t rows, int32_t C, int32_t ldo,
+                                           int32_t training, float eps, float momentum, float r_feat, float r_lstm,
+                                           uint64_t seed, uint32_t site_feat, uint32_t site_lstm,
+                                           const uint32_t* step_dev, void* stream) {
+  if (rows <= 0 || rows > ET_RG * ET_MAXR || nsplit <= 0) return TNT_BADARG(13);
+  if (C <= 0 || C % 4 != 0 || ldo < C || ldo % 4 != 0) return TNT_BADARG(14);
+  if (!tnt_aligned16(part) || !tnt_aligned16(bias) || !tnt_aligned16(pre) || !tnt_aligned16(out) || !tnt_aligned16(xhat) ||
+      !tnt_aligned16(gamma) || !tnt_aligned16(beta) || !tnt_aligned16(mov_mean) || !tnt_aligned16(mov_var) ||
+      !tnt_aligned16(inv_std)) return TNT_BADARG(1);
+  EncTailArgs a{};
+  a.part = part; a.nsplit = nsplit; a.bias = bias; a.pre_out = pre; a.slope = slope;
+  a.gamma = gamma; a.beta = beta; a.mov_mean = mov_mean; a.mov_var = mov_var; a.out = out; a.xhat = xhat;
+  a.inv_std = inv_std; a.rows = rows; a.C = C; a.ldo = ldo; a.training = training; a.eps = eps; a.momentum = momentum;
+  a.r_feat = r_feat; a.r_lstm = r_lstm; a.seed = seed; a.site_feat = site_feat; a.site_lstm = site_lstm;
+  a.step_dev = step_dev;
+  hipLaunchKernelGGL(enc_tail_fwd_kernel<true>, dim3((C + ET_CW - 1) / ET_CW), dim3(256), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
 }

@@ -22,6 +22,8 @@ from .model_base import (ModelBase, Metrics, interleave_gates, deinterleave_gate
                          BN_MOMENTUM)
 from .ops import ACT_LEAKY
 
+ENC_SPLITS = 16      # K splits of the streaming encoder forward: 16 column groups x 16 splits = one workgroup per CU
+
 
 def _r4(n):
     return (n + 3) // 4 * 4
@@ -149,6 +151,9 @@ class NIC(ModelBase):
         self.cap = torch.zeros(B, T, dtype=torch.int32, device=self.device)
         self.tgt = torch.zeros(T * B, dtype=torch.int32, device=self.device)
         self.enc_pre, self.enc_y = f(B, E), f(B, E)
+        # K-split partials of the streaming encoder forward (tnt_dense_fwd_stream_f32); None -> generic split-K GEMM
+        ok = self.norm == "batch" and B <= 256 and E % 32 == 0 and N % 4 == 0 and hasattr(self.be, "dense_fwd_stream")
+        self.enc_part = f(ENC_SPLITS * B * E) if ok and getattr(self, "stream_encoder", True) else None
         self.enc_yd = f(B, E) if self.r_feat > 0 else self.enc_y
         self.xhat = f(B, E)
         self.inv_std = f(max(B, E))
@@ -207,13 +212,25 @@ class NIC(ModelBase):
         if training and self.r_in > 0:                                              # NIC.py:122
             be.dropout(self.x, self.xd, B, N, self.ldx, 0, N, 0, self.r_in, sd, S_IN, 0, ds)
             x = self.xd
-        self.gemm_sk(x, a.p("dense_img/kernel"), self.enc_y, B, E, N, self.ldx, E, E, bias=a.p("dense_img/bias"),
-                     pre=self.enc_pre, act=ACT_LEAKY, slope=0.2)                          # :125
-        y = self.enc_y
         drop_l = training and self.r_lstm > 0
         xin = self.Xin_d if drop_l else self.Xin
         fused = self._fused_tail(B)
-        if fused:       # :126-128 + the feature step's LSTM input dropout in one launch
+        stream = fused and self.enc_part is not None
+        if stream:      # :125-128 + the feature step's LSTM input dropout: the streaming product's K-split partials are
+            #             summed (+ bias, LeakyReLU) by the tail kernel, which holds whole columns for the batch statistics
+            be.dense_fwd_stream(x, a.p("dense_img/kernel"), self.enc_part, B, E, N, self.ldx, E, ENC_SPLITS)
+            be.enc_tail_fwd_sk(self.enc_part, ENC_SPLITS, a.p("dense_img/bias"), self.enc_pre, 0.2,
+                               a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.mov_mean, self.mov_var, xin,
+                               self.xhat, self.inv_std, B, E, E, training, BN_EPS, BN_MOMENTUM,
+                               self.r_feat if training else 0.0, self.r_lstm if training else 0.0, sd, S_FEAT,
+                               S_LSTM_IN + 0, ds)
+        else:
+            self.gemm_sk(x, a.p("dense_img/kernel"), self.enc_y, B, E, N, self.ldx, E, E, bias=a.p("dense_img/bias"),
+                         pre=self.enc_pre, act=ACT_LEAKY, slope=0.2)                          # :125
+        y = self.enc_y
+        if stream:
+            pass
+        elif fused:     # :126-128 + the feature step's LSTM input dropout in one launch
             be.enc_tail_fwd(y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.mov_mean, self.mov_var, xin,
                             self.xhat, self.inv_std, B, E, E, training, BN_EPS, BN_MOMENTUM,
                             self.r_feat if training else 0.0, self.r_lstm if training else 0.0, sd, S_FEAT,

@@ -186,6 +186,17 @@ class HipBackend:
                                                  _p(dbeta), _p(dbias), rows, C, ldo, r_feat, r_lstm, slope, int(seed),
                                                  int(site_feat), int(site_lstm), _p(step_dev), self._s())
 
+    def dense_fwd_stream(self, x, w, part, B, E, K, ldx, ldw, nsplit):
+        self._call(self.lib.tnt_dense_fwd_stream_f32, "tnt_dense_fwd_stream_f32", _p(x), _p(w), _p(part), B, E, K, ldx, ldw,
+                   nsplit, self._s())
+
+    def enc_tail_fwd_sk(self, part, nsplit, bias, pre, slope, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C,
+                        ldo, training, eps, momentum, r_feat, r_lstm, seed, site_feat, site_lstm, step_dev=None):
+        self._call(self.lib.tnt_enc_tail_fwd_sk_f32, "tnt_enc_tail_fwd_sk_f32", _p(part), nsplit, _p(bias), _p(pre), slope,
+                   _p(gamma), _p(beta), _p(mov_mean), _p(mov_var), _p(out), _p(xhat), _p(inv_std), rows, C, ldo,
+                   int(training), eps, momentum, r_feat, r_lstm, int(seed), int(site_feat), int(site_lstm), _p(step_dev),
+                   self._s())
+
     def dense_dw_skinny(self, x, dpre, dw, N, E, Bk, ldx):
         self._call(self.lib.tnt_dense_dw_skinny_f32, "tnt_dense_dw_skinny_f32", _p(x), _p(dpre), _p(dw), N, E, Bk, ldx, self._s())
 

@@ -159,6 +159,24 @@ class MockBackend:
         if training and r_lstm > 0:
             self.dropout(out, out, rows, C, ldo, 0, C, 0, r_lstm, seed, site_lstm, 0, step_dev)
 
+    def dense_fwd_stream(self, x, w, part, B, E, K, ldx, ldw, nsplit):
+        """K-split partials in the kernel's tile order: 16-k tile i belongs to split (i % (4 nsplit)) // 4"""
+        X = mat(x, B, K, ldx).astype(np.float64)
+        W = mat(w, K, E, ldw).astype(np.float64)
+        out = flat(part)[:nsplit * B * E].reshape(nsplit, B, E)
+        out[...] = 0
+        for i in range((K + 15) // 16):
+            sp = (i % (4 * nsplit)) // 4
+            out[sp] += X[:, 16 * i:16 * i + 16] @ W[16 * i:16 * i + 16]
+
+    def enc_tail_fwd_sk(self, part, nsplit, bias, pre, slope, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C,
+                        ldo, training, eps, momentum, r_feat, r_lstm, seed, site_feat, site_lstm, step_dev=None):
+        z = flat(part)[:nsplit * rows * C].reshape(nsplit, rows, C).astype(np.float64).sum(0) + flat(bias)[:C]
+        mat(pre, rows, C, C)[...] = z
+        y = torch.from_numpy(np.where(z > 0, z, z * slope).astype(np.float32))
+        self.enc_tail_fwd(y, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C, ldo, training, eps, momentum,
+                          r_feat, r_lstm, seed, site_feat, site_lstm, step_dev)
+
     def enc_tail_bwd(self, dout, xhat, gamma, inv_std, pre, dpre, dgamma, dbeta, dbias, rows, C, ldo, r_feat, r_lstm,
                      slope, seed, site_feat, site_lstm, step_dev=None):
         dy = torch.zeros(rows, C, dtype=torch.float32)

@@ -1060,6 +1060,47 @@ def test_dense_dw_skinny(be, N, E, Bk, ldx):
     close(dw, ref.cpu().numpy(), rtol=2e-6)
 
 
+@pytest.mark.parametrize("B,K,E,ldx,ns", [(64, 20000, 512, 20000, 16), (5, 100, 32, 104, 3), (130, 1028, 64, 1028, 16),
+                                          (64, 36, 96, 36, 16), (33, 4, 32, 4, 1)])
+@pytest.mark.parametrize("training", [True, False])
+def test_dense_fwd_stream_and_tail(be, B, K, E, ldx, ns, training):
+    """Streaming skinny-M encoder forward (K-split partials) + the tail that sums them, against float64 / the oracle and
+    against the path they replace (generic GEMM with the bias + LeakyReLU epilogue -> tnt_enc_tail_fwd_f32)."""
+    rng = np.random.default_rng(98)
+    x = np.zeros((B, ldx)); x[:, :K] = rng.standard_normal((B, K))
+    w = rng.standard_normal((K, E)) / np.sqrt(K)
+    bias = 0.1 * rng.standard_normal(E)
+    part = torch.full((ns * B * E,), 7.0, device="cuda")
+    be.dense_fwd_stream(dev(x), dev(w), part, B, E, K, ldx, E, ns)
+    pre64 = x[:, :K] @ w + bias
+    close(part.view(ns, B, E).sum(0) + dev(bias), pre64, rtol=2e-5)       # f32 sums over K = 20000
+    gamma, beta = 1 + 0.1 * rng.standard_normal(E), 0.1 * rng.standard_normal(E)
+    mm0, mv0 = 0.1 * rng.standard_normal(E), 1 + 0.1 * rng.random(E)
+    step_dev = torch.tensor([4], dtype=torch.int32, device="cuda")
+    f = lambda *s: torch.zeros(*s, dtype=torch.float32, device="cuda")
+    rates = (0.1, 0.2) if training else (0.0, 0.0)
+    # --- the path it replaces
+    pre_a, y_a = f(B, E), f(B, E)
+    be.gemm(dev(x), dev(w), y_a, B, E, K, ldx, E, E, bias=dev(bias), pre=pre_a, act=1, slope=0.2)
+    mm_a, mv_a, out_a, xhat_a, inv_a = dev(mm0), dev(mv0), f(B, E), f(B, E), f(max(B, E))
+    be.enc_tail_fwd(y_a, dev(gamma), dev(beta), mm_a, mv_a, out_a, xhat_a, inv_a, B, E, E, training, 1e-3, 0.99, *rates,
+                    77, 2, 48, step_dev)
+    # --- partial-summing tail
+    pre_b = f(B, E)
+    mm_b, mv_b, out_b, xhat_b, inv_b = dev(mm0), dev(mv0), f(B, E), f(B, E), f(max(B, E))
+    be.enc_tail_fwd_sk(part, ns, dev(bias), pre_b, 0.2, dev(gamma), dev(beta), mm_b, mv_b, out_b, xhat_b, inv_b, B, E, E,
+                       training, 1e-3, 0.99, *rates, 77, 2, 48, step_dev)
+    close(pre_b, pre64, rtol=2e-5)
+    close(pre_b, pre_a.cpu().numpy(), rtol=2e-5)
+    # BatchNorm divides by the batch deviation, which amplifies the summation-order difference of the two products
+    for a_, b_ in ((out_a, out_b), (xhat_a, xhat_b), (inv_a[:E], inv_b[:E]), (mm_a, mm_b), (mv_a, mv_b)):
+        close(b_, a_.cpu().numpy(), rtol=2e-4, atol=2e-4)
+    assert torch.equal(out_a == 0, out_b == 0)                       # identical dropout pattern
+    y64 = np.where(pre64 > 0, pre64, 0.2 * pre64)
+    if not training:
+        close(out_b, (y64 - mm0) / np.sqrt(mv0 + 1e-3) * gamma + beta, rtol=2e-4, atol=2e-4)
+
+
 @pytest.mark.parametrize("B,N,R,D,piece", [(64, 2000, 36, 32, 64), (5, 300, 7, 16, 8), (150, 900, 9, 32, 50)])
 def test_locally_dense_split_equals_unsplit(be, B, N, R, D, piece):
     """Split mode (pieces of <= `piece` voxels per workgroup) of the region-wise encoder against the one-workgroup-
