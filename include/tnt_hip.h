@@ -151,12 +151,41 @@ int32_t tnt_locally_dense_bwd_split_f32(const float* x, int32_t ldx, const int32
 int32_t tnt_dense_fwd_stream_f32(const float* x, const float* w, float* part, int32_t B, int32_t E, int32_t K,
                                  int32_t ldx, int32_t ldw, int32_t nsplit, void* stream);
 
+/* Training variant with the two by-products the optimizer step needs to clip this kernel's gradient without forming
+ * it (one row block: B <= 64, K % 16 == 0, E >= 512): gx_part [nsplit][64][64] K-split partials of x x^T (rows/columns
+ * >= B undefined), w2_part [nsplit * E / 32] parts of sum w^2. */
+int32_t tnt_dense_fwd_stream_gram_f32(const float* x, const float* w, float* part, float* gx_part, float* w2_part,
+                                      int32_t B, int32_t E, int32_t K, int32_t ldx, int32_t ldw, int32_t nsplit,
+                                      void* stream);
+/* ... and the finish, after the backward pass produced dpre [Bk][E] (gradient w.r.t. the pre-activation pre [Bk][E]
+ * = x w + bias): for g = x^T dpre (NIC.py:248-249) the clipnorm input sum (g + 2 l2 w)^2 = ||g||^2 + 4 l2 <g, w> +
+ * 4 l2^2 ||w||^2 with ||g||^2 = sum (x x^T) o (dpre dpre^T) and <g, w> = sum dpre o (pre - bias), written as span
+ * partials (partial[2k] parts of the norm, partial[2k+1] parts of sum w^2, every k < nslot written; nslot >= 4 Bk + nw2)
+ * in the layout tnt_span_sqnorm_f32 / tnt_step_finalize_f32 use for this variable. */
+int32_t tnt_dense_gram_norm_f32(const float* dpre, const float* pre, const float* bias, const float* gx_part,
+                                int32_t nsplit, const float* w2_part, int32_t nw2, float l2, float* partial,
+                                int32_t nslot, int32_t Bk, int32_t E, void* stream);
+
 /* ---- weight gradient of the dense voxel encoder at small batch:  dw[N][E] = x^T @ dpre --------------
  * x [Bk][ldx] (the betas, Bk <= 64 rows), dpre [Bk][E] (E % 32 == 0, E <= 512, 16-byte aligned), dw [N][E].
  * (NIC.py:64-69,248-249; ThinkAndTell model.py:22-33.)  Same result as tnt_gemm_f32(transA=1) up to f32
  * summation order; a persistent, write-bound kernel instead of 2504 two-chunk tiles. */
 int32_t tnt_dense_dw_skinny_f32(const float* x, const float* dpre, float* dw, int32_t N, int32_t E,
                                 int32_t Bk, int32_t ldx, void* stream);
+
+/* ---- the same weight gradient, consumed in place by the single-process optimizer step (clipnorm + Adam of
+ * optimizer.apply_gradients, NIC.py:250-251, main.py:97) instead of being written out: E % 512 == 0, Bk <= 64.
+ * sqnorm: partial[2k] = part of sum (g + 2 l2 theta)^2, partial[2k+1] = part of sum theta^2, k < nslot -- the span-partial
+ *         layout of tnt_span_sqnorm_f32 for this variable's nslot >= 256 * E / 512 (or N/16 * E / 512) spans; every slot
+ *         is written.
+ * adam:   theta, m, v of the variable ([N][E]) updated exactly as tnt_adam_f32 does with grad = x^T dpre, clip factor
+ *         from sq[0] (sq_override[0] >= 0 wins), lr_t from *lr_t_dev; skipped when *guard != 0. */
+int32_t tnt_dense_dw_sqnorm_f32(const float* x, const float* dpre, const float* theta, float l2, float* partial,
+                                int32_t nslot, int32_t N, int32_t E, int32_t Bk, int32_t ldx, void* stream);
+int32_t tnt_dense_dw_adam_f32(const float* x, const float* dpre, float* theta, float* m, float* v, float l2,
+                              const float* sq, const float* sq_override, const float* lr_t_dev, float beta1,
+                              float beta2, float eps, float clipnorm, const uint32_t* guard, int32_t N, int32_t E,
+                              int32_t Bk, int32_t ldx, void* stream);
 
 /* ---- fused tail of the dense voxel encoder at small batch (rows <= 256, C % 4 == 0, 16-byte aligned
  * operands), NIC.py:126-128,138 ------------------------------------------------------------------

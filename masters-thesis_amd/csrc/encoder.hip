@@ -301,11 +301,29 @@ constexpr int DW_MS = 16;            // voxel rows per strip
 constexpr int DW_LDA = 48;           // As row stride: 48 % 32 == 16 -> the two k-rows of a half-wave hit disjoint banks
 constexpr int DW_KS = 16;            // k-steps of 4 (Bk <= 64)
 
-struct DwArgs { const float* x; const float* dpre; float* dw; int N, E, Bk, ldx; };
+struct DwArgs {
+  const float* x; const float* dpre; float* dw; int N, E, Bk, ldx;
+  // EPI 1 (squared norms) / EPI 2 (clip + Adam), see dense_dw_skinny_kernel
+  float* theta; float* m; float* v; float* partial; int nslot; float lam2;
+  const float* sq; const float* sq_override; const float* lr_t_dev; float b1, b2, eps, clipnorm; const uint32_t* guard;
+};
 
-template <int TPW>       // 16-column tiles per wave; a workgroup covers 8 * TPW * 16 columns (blockIdx.y picks the group)
+// PERM (every wave has all its TPW tiles, TPW = 2 or 4): MFMA column n of tile j is output column TPW n + j of the
+// wave's 16 TPW columns, so a lane's TPW results of one row are adjacent and leave as ONE dwordx2/x4 store covering
+// whole 128-byte lines per 16 lanes (4 stores per strip instead of 16 sixty-four-byte pieces).
+//
+// EPI (needs PERM, TPW = 4) -- the same product without ever writing dW, for the single-process optimizer step
+// (optimizer.apply_gradients with clipnorm + Adam, NIC.py:250-251 / main.py:97):
+//   1  per-workgroup partials of sum (g + 2 lambda theta)^2 and sum theta^2 over the workgroup's strips, written in the
+//      span-partial layout of tnt_span_sqnorm_f32 (slot = workgroup; the other slots of the variable get 0);
+//   2  clip + Adam on the strip as it leaves the MFMAs: theta, m, v stream through registers one strip ahead (their
+//      loads are issued before the previous strip's stores, so waiting for them never drains the stores), g is never
+//      stored -- 24 bytes per parameter instead of 4 (dW write) + 8 (norm pass) + 28 (Adam).
+template <int TPW, bool PERM, int EPI = 0>       // 16-column tiles per wave; a workgroup covers 8 * TPW * 16 columns (blockIdx.y picks the group)
 __global__ __launch_bounds__(512) void dense_dw_skinny_kernel(DwArgs a) {
+  static_assert(EPI == 0 || (PERM && TPW == 4), "fused epilogues use the vector row layout");
   constexpr int DW_MAXT = TPW;
+  if (EPI == 2 && a.guard && a.guard[0] != 0u) return;       // the step's forward pass was invalid: leave the model untouched
   __shared__ float As[2][DW_KS * 4 * DW_LDA];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lk = lane >> 4, lc = lane & 15;
@@ -313,14 +331,26 @@ __global__ __launch_bounds__(512) void dense_dw_skinny_kernel(DwArgs a) {
   // B fragments of this wave, resident for the whole kernel: bq[ks][j] = dpre[4 ks + lk][(t0 + j) * 16 + lc].
   // Branch-free: out-of-range rows / tiles read a clamped address and are multiplied by 0.
   float bq[DW_KS][DW_MAXT];
+  auto load_bq = [&]() {
 #pragma unroll
-  for (int ks = 0; ks < DW_KS; ++ks)
+    for (int ks = 0; ks < DW_KS; ++ks) {
+      const int k = 4 * ks + lk;
+      if (PERM && TPW == 4) {            // the lane's four adjacent columns: one 16-byte load per k-step
+        const float keep = k < a.Bk ? 1.f : 0.f;
+        const float4 b4 = *reinterpret_cast<const float4*>(a.dpre + (long)min(k, a.Bk - 1) * a.E + t0 * 16 + 4 * lc);
+        bq[ks][0] = keep * b4.x; bq[ks][DW_MAXT > 1 ? 1 : 0] = keep * b4.y;
+        bq[ks][DW_MAXT > 2 ? 2 : 0] = keep * b4.z; bq[ks][DW_MAXT > 3 ? 3 : 0] = keep * b4.w;
+        continue;
+      }
 #pragma unroll
-    for (int j = 0; j < DW_MAXT; ++j) {
-      const int k = 4 * ks + lk, t = t0 + j;
-      const float keep = (k < a.Bk && t < NT) ? 1.f : 0.f;
-      bq[ks][j] = keep * a.dpre[(long)min(k, a.Bk - 1) * a.E + min(t, NT - 1) * 16 + lc];
+      for (int j = 0; j < DW_MAXT; ++j) {
+        const int t = t0 + j;
+        const float keep = (k < a.Bk && t < NT) ? 1.f : 0.f;
+        bq[ks][j] = PERM ? keep * a.dpre[(long)min(k, a.Bk - 1) * a.E + t0 * 16 + TPW * lc + j]
+                         : keep * a.dpre[(long)min(k, a.Bk - 1) * a.E + min(t, NT - 1) * 16 + lc];
+      }
     }
+  };
   const int nstrip = (a.N + DW_MS - 1) / DW_MS;
   // A staging: 64 x 16 floats per strip = 2 per thread; thread -> (k = e / 16, m = e % 16).  Addresses are hoisted:
   // per thread a fixed row pointer, advanced by a strip; columns past N are clamped (their products are never stored).
@@ -348,10 +378,19 @@ __global__ __launch_bounds__(512) void dense_dw_skinny_kernel(DwArgs a) {
   };
   // C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.  Row pointers hoisted; full strips (all but
   // possibly the last) and full tile sets store without per-lane predicates.
-  float* wrow = a.dw + (long)(lk * 4) * a.E + t0 * 16 + lc;
+  float* wrow = a.dw + (long)(lk * 4) * a.E + t0 * 16 + (PERM ? TPW * lc : lc);
   const bool tiles_full = t0 + DW_MAXT <= NT;
   auto store_strip = [&](const floatx4* o, int st) {
     float* p0 = wrow + (long)st * DW_MS * a.E;
+    if (PERM) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (st * DW_MS + lk * 4 + r >= a.N) continue;
+        if (TPW == 4) *reinterpret_cast<float4*>(p0 + (long)r * a.E) = make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
+        else *reinterpret_cast<float2*>(p0 + (long)r * a.E) = make_float2(o[0][r], o[TPW > 1 ? 1 : 0][r]);
+      }
+      return;
+    }
     if (tiles_full && st * DW_MS + DW_MS <= a.N) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -370,9 +409,33 @@ __global__ __launch_bounds__(512) void dense_dw_skinny_kernel(DwArgs a) {
   };
   int s = blockIdx.x, cur = 0, sprev = -1;
   floatx4 outp[DW_MAXT];
-  gload(s);
+  // fused epilogues: this lane's 4 rows x 4 adjacent columns of theta / m / v for a strip
+  const long eoff = (long)(lk * 4) * a.E + t0 * 16 + TPW * lc;
+  float4 th[4], mm[4], vv[4], thn[4], mmn[4], vvn[4];
+  float q = 0.f, wq = 0.f, cs = 1.f, lr_t = 0.f;
+  auto tload = [&](int st, float4* t, float4* m_, float4* v_) {
+    const int sc = min(st, nstrip - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long o = ((long)min(sc * DW_MS + lk * 4 + r, a.N - 1) - lk * 4) * a.E + eoff;
+      t[r] = *reinterpret_cast<const float4*>(a.theta + o);
+      if (EPI == 2) { m_[r] = *reinterpret_cast<const float4*>(a.m + o); v_[r] = *reinterpret_cast<const float4*>(a.v + o); }
+    }
+  };
+  if (EPI == 2) {
+    cs = 1.f;
+    if (a.clipnorm > 0.f) {
+      float sqv = a.sq[0];
+      if (a.sq_override && a.sq_override[0] >= 0.f) sqv = a.sq_override[0];
+      cs = a.clipnorm / fmaxf(sqrtf(sqv), a.clipnorm);
+    }
+    lr_t = a.lr_t_dev[0];
+  }
+  gload(s);                                            // the first strip's X is in flight while the B fragments load
+  load_bq();
   sstore(0);
   gload(s + gridDim.x);
+  if (EPI >= 1) tload(s, thn, mmn, vvn);
   __syncthreads();
   for (; s < nstrip; s += gridDim.x, cur ^= 1) {
     float av[DW_KS];
@@ -384,8 +447,17 @@ __global__ __launch_bounds__(512) void dense_dw_skinny_kernel(DwArgs a) {
     // the next prefetch, THEN multiply -- the stores drain under the MFMAs instead of in front of a wait (PMC before
     // this reordering: waves 60 % in s_waitcnt, MFMA pipe 30 % busy).
     sstore(cur ^ 1);                                   // next strip (already in registers)
-    if (sprev >= 0) store_strip(outp, sprev);
+    if (EPI == 0 && sprev >= 0) store_strip(outp, sprev);
     gload(s + 2 * gridDim.x);                          // the one after, in flight during the MFMAs
+    if (EPI >= 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        th[r] = thn[r];
+        if (EPI == 2) { mm[r] = mmn[r]; vv[r] = vvn[r]; }
+      }
+      tload(s + gridDim.x, thn, mmn, vvn);             // next strip's state: a strip of MFMAs ahead of its use, and ahead of
+      //                                                  this strip's stores (waiting for it never drains them)
+    }
     floatx4 acc[DW_MAXT];
 #pragma unroll
     for (int j = 0; j < DW_MAXT; ++j) acc[j] = (floatx4){0.f, 0.f, 0.f, 0.f};
@@ -393,16 +465,58 @@ __global__ __launch_bounds__(512) void dense_dw_skinny_kernel(DwArgs a) {
     for (int ks = 0; ks < DW_KS; ++ks)
 #pragma unroll
       for (int j = 0; j < DW_MAXT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bq[ks][j], acc[j], 0, 0, 0);
+    if (EPI == 0) {
 #pragma unroll
-    for (int j = 0; j < DW_MAXT; ++j) outp[j] = acc[j];
+      for (int j = 0; j < DW_MAXT; ++j) outp[j] = acc[j];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (s * DW_MS + lk * 4 + r >= a.N) continue;
+        const float g4[4] = {acc[0][r], acc[TPW > 1 ? 1 : 0][r], acc[TPW > 2 ? 2 : 0][r], acc[TPW > 3 ? 3 : 0][r]};
+        float* wp = &th[r].x;
+        if (EPI == 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a0 = g4[j] + a.lam2 * wp[j];
+            q += a0 * a0; wq += wp[j] * wp[j];
+          }
+        } else {
+          float* mp = &mm[r].x; float* vp = &vv[r].x;
+          const float ob1 = 1.f - a.b1, ob2 = 1.f - a.b2;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {                 // exactly adam_kernel's arithmetic (optim.hip)
+            const float g = (g4[j] + a.lam2 * wp[j]) * cs;
+            mp[j] = mp[j] + (g - mp[j]) * ob1;
+            vp[j] = vp[j] + (g * g - vp[j]) * ob2;
+            wp[j] = wp[j] - lr_t * mp[j] / (sqrtf(vp[j]) + a.eps);
+          }
+          const long o = (long)s * DW_MS * a.E + (long)r * a.E + eoff;
+          *reinterpret_cast<float4*>(a.theta + o) = th[r];
+          *reinterpret_cast<float4*>(a.m + o) = mm[r];
+          *reinterpret_cast<float4*>(a.v + o) = vv[r];
+        }
+      }
+    }
     sprev = s;
     // As[cur^1] complete; everyone done reading As[cur].  Only LDS traffic has to be ordered (not vmcnt).
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
-  if (sprev >= 0) store_strip(outp, sprev);
+  if (EPI == 0 && sprev >= 0) store_strip(outp, sprev);
+  if (EPI == 1) {
+    __shared__ float rq[8], rw[8];
+    q = tnt_wave_sum(q); wq = tnt_wave_sum(wq);
+    if (lane == 0) { rq[w] = q; rw[w] = wq; }
+    __syncthreads();
+    if (tid == 0) {
+      float sq_ = 0.f, sw_ = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { sq_ += rq[k]; sw_ += rw[k]; }
+      const int slot = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+      a.partial[2 * slot] = sq_; a.partial[2 * slot + 1] = sw_;
+      for (int k = slot + nwg; k < a.nslot; k += nwg) { a.partial[2 * k] = 0.f; a.partial[2 * k + 1] = 0.f; }
+    }
+  }
 }
-
-
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
@@ -422,9 +536,16 @@ __global__ __launch_bounds__(512) void dense_dw_skinny_kernel(DwArgs a) {
 namespace {
 constexpr int DF_CW = 32;            // output columns per workgroup
 
-struct DfArgs { const float* x; const float* w; float* part; int B, E, K, ldx, ldw, nsplit; };
+struct DfArgs { const float* x; const float* w; float* part; int B, E, K, ldx, ldw, nsplit; float* gx_part; float* w2_part; };
 
-template <int NW, int DEPTH>
+// GRAM (training, when the optimizer step will consume the kernel's gradient X^T D without writing it): two by-products
+// that let its clip-by-norm factor be computed from 64 x 64 matrices instead of a pass over the 10 M-element gradient --
+//   gx_part[split][64][64]  K-split partials of the Gram matrix X X^T: the A fragments of row tile rt' in a lane are
+//                           exactly the B fragments of column tile rt' of X^T, so tile (rt, rt') costs 4 extra MFMAs per
+//                           k-tile from registers already loaded; the 16 column groups of a split take one tile each;
+//   w2_part[workgroup]      sum of squares of the W elements the workgroup streamed (each element exactly once).
+// ||X^T D||_F^2 = sum_{b,b'} (X X^T)[b,b'] (D D^T)[b,b'];  tnt_dense_gram_norm_f32 finishes the job.
+template <int NW, int DEPTH, bool GRAM>
 __global__ __launch_bounds__(64 * NW) void dense_fwd_stream_kernel(DfArgs a) {
   __shared__ float red[NW][64][DF_CW + 4];
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, ln = lane & 15;
@@ -459,6 +580,12 @@ __global__ __launch_bounds__(64 * NW) void dense_fwd_stream_kernel(DfArgs a) {
     for (int c = 0; c < 2; ++c) acc[rt][c] = (floatx4){0.f, 0.f, 0.f, 0.f};
   float4 av[DEPTH][4];
   float2 bv[DEPTH][4];
+  floatx4 accg = {0.f, 0.f, 0.f, 0.f};
+  float w2 = 0.f;
+  const int g_rt = (ct >> 2) & 3, g_rtp = ct & 3;   // this workgroup's Gram tile (column groups >= 16 repeat: not stored)
+  float ga[4], gb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { ga[t] = g_rt == t ? 1.f : 0.f; gb[t] = g_rtp == t ? 1.f : 0.f; }
   auto load = [&](int s, int tile) {                // tiles past the end re-read the last full tile (never multiplied)
     const int tc = max(min(tile, Tfull - 1), 0);
     const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)tc * 64;
@@ -480,6 +607,18 @@ __global__ __launch_bounds__(64 * NW) void dense_fwd_stream_kernel(DfArgs a) {
       }
     }
   };
+  auto gram = [&](int s) {        // its own scheduling region behind mac(s): 4 MFMAs + ~40 VALU on registers still live
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // row tiles g_rt / g_rtp of this stage, picked with 0/1 weights (exact; a ternary chain on the register array
+      // is turned into an indexed scratch access by the compiler)
+      auto el = [&](int t) { const float4 v = av[s][t]; return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; };
+      const float xa = el(0) * ga[0] + el(1) * ga[1] + el(2) * ga[2] + el(3) * ga[3];
+      const float xb = el(0) * gb[0] + el(1) * gb[1] + el(2) * gb[2] + el(3) * gb[3];
+      accg = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, xb, accg, 0, 0, 0);
+      w2 += bv[s][j].x * bv[s][j].x + bv[s][j].y * bv[s][j].y;
+    }
+  };
   // Ring of DEPTH register stages.  Region i multiplies tile i (stage i % DEPTH) while the loads of tile i + DEPTH - 1
   // are issued into the stage tile i - 1 just left, one load per four MFMAs: DEPTH - 2 whole regions (1024 MFMA cycles
   // each) lie between a load and its use.
@@ -489,6 +628,10 @@ __global__ __launch_bounds__(64 * NW) void dense_fwd_stream_kernel(DfArgs a) {
   for (; i + DEPTH <= nt; i += DEPTH) {
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) {
+      if (GRAM && i + s > 0) {       // the stage about to be refilled holds the tile of the previous region
+        gram((s + DEPTH - 1) % DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       load((s + DEPTH - 1) % DEPTH, q + (i + s + DEPTH - 1) * nslot);
       mac(s);
 #pragma unroll
@@ -499,9 +642,13 @@ __global__ __launch_bounds__(64 * NW) void dense_fwd_stream_kernel(DfArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if (GRAM && i > 0) gram(DEPTH - 1);               // the last region's tile
 #pragma unroll
   for (int s = 0; s < DEPTH - 1; ++s)
-    if (i + s < nt) mac(s);
+    if (i + s < nt) {
+      mac(s);
+      if (GRAM) gram(s);
+    }
   if ((a.K & 15) && q == Tfull % nslot) {           // the partial tile: lanes with k >= K clamp their address, A := 0
     const int k0 = Tfull * 16 + kq * 4, ka = min(k0, a.K - 4);
     const float keep = k0 < a.K ? 1.f : 0.f;
@@ -532,21 +679,130 @@ __global__ __launch_bounds__(64 * NW) void dense_fwd_stream_kernel(DfArgs a) {
     }
     *reinterpret_cast<float4*>(a.part + ((long)split * a.B + rb + row) * a.E + c0 + c4) = t;
   }
+  if (GRAM && blockIdx.y == 0) {
+    __syncthreads();
+    float* rg = &red[0][0][0];                      // [NW][16][17] Gram tile partials, then [NW] sums of squares
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rg[(w * 16 + kq * 4 + r) * 17 + ln] = accg[r];
+    w2 = tnt_wave_sum(w2);
+    if (lane == 0) rg[NW * 16 * 17 + w] = w2;
+    __syncthreads();
+    if (tid < 256 && ct < 16) {
+      const int row = tid >> 4, col = tid & 15;
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) t += rg[(k * 16 + row) * 17 + col];
+      a.gx_part[((long)split * 64 + g_rt * 16 + row) * 64 + g_rtp * 16 + col] = t;
+    }
+    if (tid == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) t += rg[NW * 16 * 17 + k];
+      a.w2_part[split * nct + ct] = t;
+    }
+  }
 }
 }  // namespace
 
-extern "C" int32_t tnt_dense_fwd_stream_f32(const float* x, const float* w, float* part, int32_t B, int32_t E,
-                                            int32_t K, int32_t ldx, int32_t ldw, int32_t nsplit, void* stream) {
+static int32_t dense_fwd_stream_launch(const float* x, const float* w, float* part, float* gx_part, float* w2_part,
+                                       int32_t B, int32_t E, int32_t K, int32_t ldx, int32_t ldw, int32_t nsplit,
+                                       void* stream) {
   if (B <= 0 || K < 4 || K % 4 != 0 || ldx < K || ldx % 4 != 0) return TNT_BADARG(6);
   if (E <= 0 || E % DF_CW != 0 || ldw < E || ldw % 2 != 0 || nsplit <= 0 || nsplit > 64) return TNT_BADARG(5);
   if (!tnt_aligned16(x) || !tnt_aligned16(w) || !tnt_aligned16(part)) return TNT_BADARG(1);
   if ((long)B * ldx * 4 >= (1L << 32) || 16L * ldw * 4 >= (1L << 32)) return TNT_BADARG(4);      // 32-bit lane offsets
-  DfArgs a{x, w, part, B, E, K, ldx, ldw, nsplit};
+  DfArgs a{x, w, part, B, E, K, ldx, ldw, nsplit, gx_part, w2_part};
   // Ring depth / waves measured on MI355X at 64 x 20000 x 512 (tools/enc_fwd_probe.py): 4 waves x depth 4: 17.3 us per
   // back-to-back launch, depth 5 / 6: 18.0 / 18.5, 8 waves x depth 4 / 5: 18.3 / 19.6; loads served from L1 instead of
   // HBM: 17.3 -- the loop is bound by the 20480 MFMA cycles per wave plus ramp-up, not by memory.
-  hipLaunchKernelGGL((dense_fwd_stream_kernel<4, 4>), dim3((E / DF_CW) * nsplit, (B + 63) / 64), dim3(256), 0,
-                     tnt_stream(stream), a);
+  const dim3 g((E / DF_CW) * nsplit, (B + 63) / 64);
+  if (gx_part) hipLaunchKernelGGL((dense_fwd_stream_kernel<4, 4, true>), g, dim3(256), 0, tnt_stream(stream), a);
+  else hipLaunchKernelGGL((dense_fwd_stream_kernel<4, 4, false>), g, dim3(256), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_dense_fwd_stream_f32(const float* x, const float* w, float* part, int32_t B, int32_t E,
+                                            int32_t K, int32_t ldx, int32_t ldw, int32_t nsplit, void* stream) {
+  return dense_fwd_stream_launch(x, w, part, nullptr, nullptr, B, E, K, ldx, ldw, nsplit, stream);
+}
+
+extern "C" int32_t tnt_dense_fwd_stream_gram_f32(const float* x, const float* w, float* part, float* gx_part,
+                                                 float* w2_part, int32_t B, int32_t E, int32_t K, int32_t ldx,
+                                                 int32_t ldw, int32_t nsplit, void* stream) {
+  // one Gram tile per column group (16 of them), whole 16-k tiles only, one row block
+  if (gx_part == nullptr || w2_part == nullptr || E / DF_CW < 16 || K % 16 != 0 || B > 64) return TNT_BADARG(4);
+  return dense_fwd_stream_launch(x, w, part, gx_part, w2_part, B, E, K, ldx, ldw, nsplit, stream);
+}
+
+// ---- clip-by-norm input of the dense encoder kernel without its gradient (see dense_fwd_stream_kernel<GRAM>):
+//   sum (g + 2 l2 W)^2 = ||X^T D||^2 + 4 l2 <X^T D, W> + 4 l2^2 ||W||^2,   g = X^T D,
+//   ||X^T D||^2 = sum_{b,b'} (X X^T)[b,b'] (D D^T)[b,b'],   <X^T D, W> = sum_{b,e} D[b,e] (X W)[b,e],  X W = pre - bias.
+// Four workgroups per row b < Bk: 16 entries of row b of D D^T each (E-long dots in double), contracted with row b of
+// X X^T (summed over the K splits), the first one adds the row's share of the middle term -> one span-partial slot per
+// workgroup (layout of tnt_span_sqnorm_f32).  The last workgroup spreads the ||W||^2 parts over the following slots
+// (q = 4 l2^2 w, wq = w) and zeroes the rest.
+namespace {
+constexpr int GN_Q = 4;        // workgroups per row b: 16 columns b' of the Gram contraction each
+__global__ __launch_bounds__(256) void dense_gram_norm_kernel(const float* dpre, const float* pre, const float* bias,
+                                                              const float* gx_part, int nsplit, const float* w2_part,
+                                                              int nw2, float l2, float* partial, int nslot, int Bk, int E) {
+  __shared__ double sd[256];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x == GN_Q * Bk) {
+    for (int k = tid; k < nslot - GN_Q * Bk; k += 256) {
+      const float w = k < nw2 ? w2_part[k] : 0.f;
+      partial[2 * (GN_Q * Bk + k)] = 4.f * l2 * l2 * w;
+      partial[2 * (GN_Q * Bk + k) + 1] = w;
+    }
+    return;
+  }
+  const int b = blockIdx.x / GN_Q, qd = blockIdx.x % GN_Q;
+  // (D D^T)[b][b'] for this workgroup's 16 b': 16 threads per b', each a contiguous 1/16 of the row in 16-byte loads
+  const int bp = qd * 16 + (tid >> 4), part = tid & 15;
+  double acc = 0.0;
+  if (bp < Bk) {
+    const int n4 = E / 64;                                  // float4 per thread (E % 64 == 0)
+    const float4* db = reinterpret_cast<const float4*>(dpre + (long)b * E) + part * n4;
+    const float4* dp = reinterpret_cast<const float4*>(dpre + (long)bp * E) + part * n4;
+#pragma unroll 8
+    for (int e = 0; e < n4; ++e) {
+      const float4 u = db[e], v = dp[e];
+      acc += (double)u.x * (double)v.x + (double)u.y * (double)v.y + (double)u.z * (double)v.z + (double)u.w * (double)v.w;
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 16);      // the 16 parts of one b'
+  double s = 0.0;
+  if (part == 0 && bp < Bk) {
+    double gx = 0.0;
+#pragma unroll 8
+    for (int sp = 0; sp < nsplit; ++sp) gx += (double)gx_part[((long)sp * 64 + b) * 64 + bp];
+    s = gx * acc;
+  }
+  if (qd == 0) {                                            // middle term: 4 l2 sum_e D[b,e] (X W)[b,e]
+    double s2 = 0.0;
+#pragma unroll 4
+    for (int e = tid; e < E; e += 256) s2 += (double)dpre[(long)b * E + e] * ((double)pre[(long)b * E + e] - (double)bias[e]);
+    s += 4.0 * (double)l2 * s2;
+  }
+  sd[tid] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (tid < k) sd[tid] += sd[tid + k];
+    __syncthreads();
+  }
+  if (tid == 0) { partial[2 * blockIdx.x] = (float)sd[0]; partial[2 * blockIdx.x + 1] = 0.f; }
+}
+}  // namespace
+
+extern "C" int32_t tnt_dense_gram_norm_f32(const float* dpre, const float* pre, const float* bias, const float* gx_part,
+                                           int32_t nsplit, const float* w2_part, int32_t nw2, float l2, float* partial,
+                                           int32_t nslot, int32_t Bk, int32_t E, void* stream) {
+  if (Bk <= 0 || Bk > 64 || E <= 0 || E % 64 != 0 || nsplit <= 0 || nw2 <= 0 || nslot < GN_Q * Bk + nw2) return TNT_BADARG(9);
+  if (!tnt_aligned16(dpre)) return TNT_BADARG(0);
+  hipLaunchKernelGGL(dense_gram_norm_kernel, dim3(GN_Q * Bk + 1), dim3(256), 0, tnt_stream(stream), dpre, pre, bias,
+                     gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E);
   TNT_LAUNCH_CHECK();
   return 0;
 }
@@ -589,9 +845,50 @@ extern "C" int32_t tnt_dense_dw_skinny_f32(const float* x, const float* dpre, fl
   const int tpw = E > 256 ? 4 : (E > 128 ? 2 : 1), grid = 256;
   const int NT = E / 16;
   dim3 g(nstrip < grid ? nstrip : grid, (NT + 8 * tpw - 1) / (8 * tpw));
-  if (tpw == 1) hipLaunchKernelGGL(dense_dw_skinny_kernel<1>, g, dim3(512), 0, tnt_stream(stream), a);
-  else if (tpw == 2) hipLaunchKernelGGL(dense_dw_skinny_kernel<2>, g, dim3(512), 0, tnt_stream(stream), a);
-  else hipLaunchKernelGGL(dense_dw_skinny_kernel<4>, g, dim3(512), 0, tnt_stream(stream), a);
+  const bool perm = tpw > 1 && E % (128 * tpw) == 0 && tnt_aligned16(dw);      // every wave full: vector row stores
+  if (tpw == 1) hipLaunchKernelGGL((dense_dw_skinny_kernel<1, false>), g, dim3(512), 0, tnt_stream(stream), a);
+  else if (tpw == 2 && perm) hipLaunchKernelGGL((dense_dw_skinny_kernel<2, true>), g, dim3(512), 0, tnt_stream(stream), a);
+  else if (tpw == 2) hipLaunchKernelGGL((dense_dw_skinny_kernel<2, false>), g, dim3(512), 0, tnt_stream(stream), a);
+  else if (perm) hipLaunchKernelGGL((dense_dw_skinny_kernel<4, true>), g, dim3(512), 0, tnt_stream(stream), a);
+  else hipLaunchKernelGGL((dense_dw_skinny_kernel<4, false>), g, dim3(512), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+static int32_t dw_fused_check(const float* x, const float* dpre, int32_t N, int32_t E, int32_t Bk, int32_t ldx) {
+  if (N <= 0 || Bk <= 0 || Bk > 4 * DW_KS || ldx < N) return TNT_BADARG(6);
+  if (E <= 0 || E % 512 != 0) return TNT_BADARG(5);       // whole waves of 4 tiles; a strip of 16 rows = E / 512 spans
+  if (!tnt_aligned16(x) || !tnt_aligned16(dpre)) return TNT_BADARG(1);
+  return 0;
+}
+
+extern "C" int32_t tnt_dense_dw_sqnorm_f32(const float* x, const float* dpre, const float* theta, float l2,
+                                           float* partial, int32_t nslot, int32_t N, int32_t E, int32_t Bk,
+                                           int32_t ldx, void* stream) {
+  if (int32_t rc = dw_fused_check(x, dpre, N, E, Bk, ldx)) return rc;
+  const int nstrip = (N + DW_MS - 1) / DW_MS, grid = nstrip < 256 ? nstrip : 256;
+  if (nslot < grid * (E / 512) || !tnt_aligned16(theta)) return TNT_BADARG(6);
+  DwArgs a{};
+  a.x = x; a.dpre = dpre; a.N = N; a.E = E; a.Bk = Bk; a.ldx = ldx;
+  a.theta = const_cast<float*>(theta); a.partial = partial; a.nslot = nslot; a.lam2 = 2.f * l2;
+  hipLaunchKernelGGL((dense_dw_skinny_kernel<4, true, 1>), dim3(grid, E / 512), dim3(512), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_dense_dw_adam_f32(const float* x, const float* dpre, float* theta, float* m, float* v, float l2,
+                                         const float* sq, const float* sq_override, const float* lr_t_dev, float beta1,
+                                         float beta2, float eps, float clipnorm, const uint32_t* guard, int32_t N,
+                                         int32_t E, int32_t Bk, int32_t ldx, void* stream) {
+  if (int32_t rc = dw_fused_check(x, dpre, N, E, Bk, ldx)) return rc;
+  if (!tnt_aligned16(theta) || !tnt_aligned16(m) || !tnt_aligned16(v) || lr_t_dev == nullptr || sq == nullptr)
+    return TNT_BADARG(3);
+  const int nstrip = (N + DW_MS - 1) / DW_MS, grid = nstrip < 256 ? nstrip : 256;
+  DwArgs a{};
+  a.x = x; a.dpre = dpre; a.N = N; a.E = E; a.Bk = Bk; a.ldx = ldx;
+  a.theta = theta; a.m = m; a.v = v; a.lam2 = 2.f * l2; a.sq = sq; a.sq_override = sq_override; a.lr_t_dev = lr_t_dev;
+  a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.clipnorm = clipnorm; a.guard = guard;
+  hipLaunchKernelGGL((dense_dw_skinny_kernel<4, true, 2>), dim3(grid, E / 512), dim3(512), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
 }

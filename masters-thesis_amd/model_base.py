@@ -153,7 +153,23 @@ class ModelBase:
         clip = opt.clipnorm if opt.clipnorm is not None else 0.0
         gd = self._guard_word()
         adam = opt.kind == "adam"
-        be.span_sqnorm(a.theta, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.partial, sp.nspan)
+        enc = self.__dict__.pop("_enc_fused", None)
+        s1 = 0
+        if enc is not None:
+            # The dense encoder kernel (segment 0, 59 % of config 2's parameters) never has its gradient written: one
+            # pass of the skinny product leaves its norm partials in the variable's span slots, a second one applies
+            # clip + Adam to the strips as they leave the MFMAs (24 bytes per parameter instead of 40).
+            name, x, dpre, rows, N, E, ldx, gram = enc
+            e = a.entries[name]
+            s1 = sp.first_host[e.seg + 1]
+            if gram is not None and 4 * rows + gram[5] <= s1:
+                # norm from the forward's by-products: ||X^T D||^2 = sum (X X^T) o (D D^T), no pass over the gradient
+                pre, bias, gx, nsplit, w2, nw2 = gram
+                be.dense_gram_norm(dpre, pre, bias, gx, nsplit, w2, nw2, e.l2, a.partial, s1, rows, E)
+            else:
+                be.dense_dw_sqnorm(x, dpre, a.p(name), e.l2, a.partial, s1, N, E, rows, ldx)
+        be.span_sqnorm(a.theta, a.grad, sp.span_seg[s1:], sp.span_off[s1:], sp.span_len[s1:], a.seg_l2, a.partial[2 * s1:],
+                       sp.nspan - s1)
         kw = dict(x0=d[0], out0=d[1], x1=d[2], out1=d[3], n=d[4], scale=d[5]) if d is not None else {}
         ef = self.__dict__.pop("_emb_finalize", None)
         if ef is not None:       # sparse embedding backward: sum its norm partials, hand this step's ids on as prev_ids
@@ -165,8 +181,14 @@ class ModelBase:
                          drop_step=self.drop_step, lr=self.lr_dev, lr_t=self.lr_t_dev if adam else None,
                          beta1=opt.beta_1 if adam else 0.0, beta2=opt.beta_2 if adam else 0.0, guard=gd, **kw)
         if adam:
-            be.adam(a.theta, self.opt_m, self.opt_v, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq,
-                    a.sq_override, sp.nspan, 0.0, self.lr_t_dev, opt.beta_1, opt.beta_2, opt.epsilon, clip, guard=gd)
+            be.adam(a.theta, self.opt_m, self.opt_v, a.grad, sp.span_seg[s1:], sp.span_off[s1:], sp.span_len[s1:], a.seg_l2,
+                    a.sq, a.sq_override, sp.nspan - s1, 0.0, self.lr_t_dev, opt.beta_1, opt.beta_2, opt.epsilon, clip,
+                    guard=gd)
+            if enc is not None:
+                sl = slice(e.off, e.off + e.size)
+                be.dense_dw_adam(x, dpre, a.theta[sl], self.opt_m[sl], self.opt_v[sl], e.l2, a.sq[e.seg:e.seg + 1],
+                                 a.sq_override[e.seg:e.seg + 1], self.lr_t_dev, opt.beta_1, opt.beta_2, opt.epsilon, clip,
+                                 N, E, rows, ldx, guard=gd)
         else:
             be.sgd(a.theta, self.opt_m, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq, a.sq_override,
                    sp.nspan, 0.0, self.lr_dev, opt.momentum, clip, guard=gd)

@@ -126,7 +126,25 @@ class NIC(ModelBase):
     def get_gradient(self, name):
         """Last computed gradient of a trainable (keras layout, *without* the L2 term, which the
         optimizer kernels add on the fly)."""
+        st = self.__dict__.get("_enc_grad_stale")
+        if name == "dense_img/kernel" and st is not None:
+            # the fused step consumed X^T dpre inside the optimizer launches without writing it: its operands are still
+            # in place, materialise it on request
+            x, dpre, rows = st
+            self.be.dense_dw_skinny(x, dpre, self.arena.g(name), self.N, self.E, rows, self.ldx)
+            self._enc_grad_stale = None
         return self._unpack(name, self.arena.g(name))
+
+    def _enc_update_fused(self, rows):
+        """True when the encoder kernel's gradient is consumed inside the optimizer launches instead of being written
+        out (tnt_dense_dw_sqnorm_f32 / tnt_dense_dw_adam_f32): the single-process fused step with Adam, no AGC."""
+        opt = self.optimizer
+        return bool(self.__dict__.get("_defer_sum2") and self.dp_world == 1 and getattr(self, "fuse_enc_update", True)
+                    and opt is not None and opt.kind == "adam" and not self.__dict__.get("agc") and rows <= 64
+                    and self.E % 512 == 0 and hasattr(self.be, "dense_dw_adam") and hasattr(self.be, "step_finalize")
+                    and self.arena.entries["dense_img/kernel"].seg == 0
+                    # one norm-partial slot per workgroup inside the variable's own span slots
+                    and min((self.N + 15) // 16, 256) * (self.E // 512) <= self.arena.spans.first_host[1])
 
     def state_tensors(self):
         """Non-trainable device state (BatchNorm moving statistics)."""
@@ -154,6 +172,7 @@ class NIC(ModelBase):
         # K-split partials of the streaming encoder forward (tnt_dense_fwd_stream_f32); None -> generic split-K GEMM
         ok = self.norm == "batch" and B <= 256 and E % 32 == 0 and N % 4 == 0 and hasattr(self.be, "dense_fwd_stream")
         self.enc_part = f(ENC_SPLITS * B * E) if ok and getattr(self, "stream_encoder", True) else None
+        self.enc_gx = self.enc_w2 = None        # Gram by-products of the forward (allocated on first use, outside captures)
         self.enc_yd = f(B, E) if self.r_feat > 0 else self.enc_y
         self.xhat = f(B, E)
         self.inv_std = f(max(B, E))
@@ -218,7 +237,19 @@ class NIC(ModelBase):
         stream = fused and self.enc_part is not None
         if stream:      # :125-128 + the feature step's LSTM input dropout: the streaming product's K-split partials are
             #             summed (+ bias, LeakyReLU) by the tail kernel, which holds whole columns for the batch statistics
-            be.dense_fwd_stream(x, a.p("dense_img/kernel"), self.enc_part, B, E, N, self.ldx, E, ENC_SPLITS)
+            self._enc_gram = None
+            if (training and self._enc_update_fused(B) and getattr(self, "gram_norm", True) and N % 16 == 0 and E >= 512
+                    and hasattr(be, "dense_gram_norm")):
+                # the optimizer step will take this kernel's gradient X^T dpre without writing it: leave X X^T and
+                # sum W^2 behind, from which (with dpre) its clip-by-norm factor follows (tnt_dense_gram_norm_f32)
+                if self.enc_gx is None:
+                    self.enc_gx, self.enc_w2 = self._f(ENC_SPLITS * 64 * 64), self._f(ENC_SPLITS * (E // 32))
+                be.dense_fwd_stream_gram(x, a.p("dense_img/kernel"), self.enc_part, self.enc_gx, self.enc_w2, B, E, N,
+                                         self.ldx, E, ENC_SPLITS)
+                self._enc_gram = (self.enc_pre, a.p("dense_img/bias"), self.enc_gx, ENC_SPLITS, self.enc_w2,
+                                  ENC_SPLITS * (E // 32))
+            else:
+                be.dense_fwd_stream(x, a.p("dense_img/kernel"), self.enc_part, B, E, N, self.ldx, E, ENC_SPLITS)
             be.enc_tail_fwd_sk(self.enc_part, ENC_SPLITS, a.p("dense_img/bias"), self.enc_pre, 0.2,
                                a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.mov_mean, self.mov_var, xin,
                                self.xhat, self.inv_std, B, E, E, training, BN_EPS, BN_MOMENTUM,
@@ -402,6 +433,12 @@ class NIC(ModelBase):
             x, dpre, rows = x_all, dpre_all, x_all.shape[0]
         else:
             dpre = self.dpre
+        self._enc_last_fused = None
+        if x_all is None and self._enc_update_fused(rows):
+            self._enc_fused = ("dense_img/kernel", x, dpre, rows, self.N, self.E, self.ldx,
+                               self.__dict__.get("_enc_gram"))                                    # -> _update_fused
+            self._enc_last_fused = (x, dpre, rows)       # train_step marks the gradient buffer stale after every (re)play
+            return
         if rows <= 64 and self.E % 16 == 0 and getattr(self, "skinny_dw", True):
             be.dense_dw_skinny(x, dpre, a.g("dense_img/kernel"), self.N, self.E, rows, self.ldx)
         else:
@@ -437,8 +474,10 @@ class NIC(ModelBase):
             raise RuntimeError("compile() the model before train_step")
         B, T = self._stage_batch(data[0], data[1], self.N)
         self._sync_lr()
+        self._enc_grad_stale = None
         if self.grad_sync is None:
             self._run_captured(("train", B, T), lambda: self._train_and_update_graph(B, T))
+            self._enc_grad_stale = self.__dict__.get("_enc_last_fused")
         elif getattr(self.grad_sync, "pipelined", False):
             self.grad_sync.step(self, B, T)
         else:       # data parallel: forward+backward | all-reduce of the flat gradient | update

@@ -190,12 +190,29 @@ class HipBackend:
         self._call(self.lib.tnt_dense_fwd_stream_f32, "tnt_dense_fwd_stream_f32", _p(x), _p(w), _p(part), B, E, K, ldx, ldw,
                    nsplit, self._s())
 
+    def dense_fwd_stream_gram(self, x, w, part, gx_part, w2_part, B, E, K, ldx, ldw, nsplit):
+        self._call(self.lib.tnt_dense_fwd_stream_gram_f32, "tnt_dense_fwd_stream_gram_f32", _p(x), _p(w), _p(part), _p(gx_part),
+                   _p(w2_part), B, E, K, ldx, ldw, nsplit, self._s())
+
+    def dense_gram_norm(self, dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E):
+        self._call(self.lib.tnt_dense_gram_norm_f32, "tnt_dense_gram_norm_f32", _p(dpre), _p(pre), _p(bias), _p(gx_part), nsplit,
+                   _p(w2_part), nw2, l2, _p(partial), nslot, Bk, E, self._s())
+
     def enc_tail_fwd_sk(self, part, nsplit, bias, pre, slope, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C,
                         ldo, training, eps, momentum, r_feat, r_lstm, seed, site_feat, site_lstm, step_dev=None):
         self._call(self.lib.tnt_enc_tail_fwd_sk_f32, "tnt_enc_tail_fwd_sk_f32", _p(part), nsplit, _p(bias), _p(pre), slope,
                    _p(gamma), _p(beta), _p(mov_mean), _p(mov_var), _p(out), _p(xhat), _p(inv_std), rows, C, ldo,
                    int(training), eps, momentum, r_feat, r_lstm, int(seed), int(site_feat), int(site_lstm), _p(step_dev),
                    self._s())
+
+    def dense_dw_sqnorm(self, x, dpre, theta, l2, partial, nslot, N, E, Bk, ldx):
+        self._call(self.lib.tnt_dense_dw_sqnorm_f32, "tnt_dense_dw_sqnorm_f32", _p(x), _p(dpre), _p(theta), l2, _p(partial),
+                   nslot, N, E, Bk, ldx, self._s())
+
+    def dense_dw_adam(self, x, dpre, theta, m, v, l2, sq, sq_override, lr_t_dev, beta1, beta2, eps, clipnorm, N, E, Bk, ldx,
+                      guard=None):
+        self._call(self.lib.tnt_dense_dw_adam_f32, "tnt_dense_dw_adam_f32", _p(x), _p(dpre), _p(theta), _p(m), _p(v), l2,
+                   _p(sq), _p(sq_override), _p(lr_t_dev), beta1, beta2, eps, clipnorm, _p(guard), N, E, Bk, ldx, self._s())
 
     def dense_dw_skinny(self, x, dpre, dw, N, E, Bk, ldx):
         self._call(self.lib.tnt_dense_dw_skinny_f32, "tnt_dense_dw_skinny_f32", _p(x), _p(dpre), _p(dw), N, E, Bk, ldx, self._s())

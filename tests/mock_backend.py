@@ -169,6 +169,27 @@ class MockBackend:
             sp = (i % (4 * nsplit)) // 4
             out[sp] += X[:, 16 * i:16 * i + 16] @ W[16 * i:16 * i + 16]
 
+    def dense_fwd_stream_gram(self, x, w, part, gx_part, w2_part, B, E, K, ldx, ldw, nsplit):
+        self.dense_fwd_stream(x, w, part, B, E, K, ldx, ldw, nsplit)
+        X = mat(x, B, K, ldx).astype(np.float64)
+        W = mat(w, K, E, ldw).astype(np.float64)
+        gx = flat(gx_part)[:nsplit * 64 * 64].reshape(nsplit, 64, 64)
+        gx[...] = 0
+        gx[0, :B, :B] = X @ X.T
+        w2 = flat(w2_part)
+        w2[:nsplit * (E // 32)] = 0
+        w2[0] = (W * W).sum()
+
+    def dense_gram_norm(self, dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E):
+        D = mat(dpre, Bk, E, E).astype(np.float64)
+        XW = mat(pre, Bk, E, E).astype(np.float64) - flat(bias)[:E].astype(np.float64)
+        gx = flat(gx_part)[:nsplit * 64 * 64].reshape(nsplit, 64, 64).astype(np.float64).sum(0)[:Bk, :Bk]
+        w2 = float(flat(w2_part)[:nw2].astype(np.float64).sum())
+        p = flat(partial)
+        p[:2 * nslot] = 0
+        p[0] = (gx * (D @ D.T)).sum() + 4 * l2 * (D * XW).sum() + 4 * l2 * l2 * w2
+        p[1] = w2
+
     def enc_tail_fwd_sk(self, part, nsplit, bias, pre, slope, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C,
                         ldo, training, eps, momentum, r_feat, r_lstm, seed, site_feat, site_lstm, step_dev=None):
         z = flat(part)[:nsplit * rows * C].reshape(nsplit, rows, C).astype(np.float64).sum(0) + flat(bias)[:C]
@@ -446,6 +467,29 @@ class MockBackend:
             th[o:o + n] = t - lr_t * m1 / (np.sqrt(v1) + eps)
             mm[o:o + n] = m1
             vv[o:o + n] = v1
+
+    def dense_dw_sqnorm(self, x, dpre, theta, l2, partial, nslot, N, E, Bk, ldx):
+        g = mat(x, Bk, N, ldx).astype(np.float64).T @ mat(dpre, Bk, E, E).astype(np.float64)
+        t = flat(theta)[:N * E].reshape(N, E).astype(np.float64)
+        p = flat(partial)
+        p[:2 * nslot] = 0
+        p[0], p[1] = ((g + 2 * l2 * t) ** 2).sum(), (t * t).sum()
+
+    def dense_dw_adam(self, x, dpre, theta, m, v, l2, sq, sq_override, lr_t_dev, beta1, beta2, eps, clipnorm, N, E, Bk, ldx,
+                      guard=None):
+        if guard is not None and int(guard[0]) != 0:
+            return
+        lr_t = float(flat(lr_t_dev)[0])
+        g = (mat(x, Bk, N, ldx).astype(np.float64).T @ mat(dpre, Bk, E, E).astype(np.float64)).reshape(-1)
+        th, mm, vv = flat(theta), flat(m), flat(v)
+        n = N * E
+        t = th[:n].astype(np.float64)
+        g = (g + 2 * l2 * t) * self._clip(sq, sq_override, 0, clipnorm)
+        m1 = mm[:n] + (g - mm[:n]) * (1 - beta1)
+        v1 = vv[:n] + (g * g - vv[:n]) * (1 - beta2)
+        th[:n] = t - lr_t * m1 / (np.sqrt(v1) + eps)
+        mm[:n] = m1
+        vv[:n] = v1
 
     def sgd(self, theta, mom, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr, lr_dev, momentum,
             clipnorm, guard=None):

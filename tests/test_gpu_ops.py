@@ -536,6 +536,90 @@ def test_optimizer(be):
         close(th2[o:o + n], tw, rtol=1e-6)
 
 
+@pytest.mark.parametrize("B,K,E,correlated", [(64, 20000, 512, False), (64, 20000, 512, True), (5, 64, 512, False),
+                                              (33, 1600, 1024, True)])
+def test_dense_gram_norm(be, B, K, E, correlated):
+    """Clip-by-norm input of the encoder kernel from the forward's Gram by-products (tnt_dense_fwd_stream_gram_f32 ->
+    tnt_dense_gram_norm_f32) against float64 sum (X^T D + 2 l2 W)^2, also for strongly correlated samples with
+    gradient rows that sum to zero (what BatchNorm's backward produces), where the Gram form cancels the most."""
+    rng = np.random.default_rng(B + K)
+    lam, ns = 0.01, 16
+    if correlated:
+        x = rng.standard_normal((1, K)) * 3 + 0.3 * rng.standard_normal((B, K))
+        dpre = rng.standard_normal((B, E)) * 0.01
+        dpre -= dpre.mean(0, keepdims=True)
+    else:
+        x, dpre = rng.standard_normal((B, K)), rng.standard_normal((B, E)) * 0.01
+    w = rng.standard_normal((K, E)) / np.sqrt(K)
+    bias = 0.1 * rng.standard_normal(E)
+    part = torch.zeros(ns * B * E, device="cuda")
+    gx, w2 = torch.full((ns * 64 * 64,), 7.0, device="cuda"), torch.full((ns * (E // 32),), 7.0, device="cuda")
+    be.dense_fwd_stream_gram(dev(x), dev(w), part, gx, w2, B, E, K, K, E, ns)
+    pre = (part.view(ns, B, E).sum(0) + dev(bias)).contiguous()
+    close(pre, x @ w + bias, rtol=2e-5)
+    close(gx.view(ns, 64, 64).sum(0)[:B, :B], x @ x.T, rtol=1e-5)
+    close(w2.sum().reshape(1), [(w * w).sum()], rtol=1e-5)
+    nslot = max(4 * B + ns * (E // 32) + 3, 900)
+    partial = torch.full((2 * nslot,), 7.0, device="cuda")
+    be.dense_gram_norm(dev(dpre), pre, dev(bias), gx, ns, w2, ns * (E // 32), lam, partial, nslot, B, E)
+    p = partial.cpu().double().numpy()
+    g = x.T @ dpre
+    want = ((g + 2 * lam * w) ** 2).sum()
+    # the three terms separately: the Gram contraction is the delicate one
+    print("norm^2", want, "||g||^2", (g * g).sum(), "gram sum", p[0::2].sum())
+    assert abs(p[0::2].sum() - want) <= 2e-5 * want, (p[0::2].sum(), want, (g * g).sum())
+    assert abs(p[1::2].sum() - (w * w).sum()) <= 1e-5 * (w * w).sum()
+
+
+@pytest.mark.parametrize("N,E,Bk,ldx,clip", [(20000, 512, 64, 20000, 0.1), (999, 512, 33, 1000, 0.1), (112, 1024, 7, 112, 0.0)])
+def test_dense_dw_fused_norm_and_adam(be, N, E, Bk, ldx, clip):
+    """tnt_dense_dw_sqnorm_f32 / tnt_dense_dw_adam_f32 (the encoder kernel's gradient consumed by the optimizer step
+    without being written) against the written-out path: dense_dw_skinny -> span norms -> tnt_adam_f32, and float64."""
+    from masters_thesis_amd.arena import build_spans
+    rng = np.random.default_rng(N + E)
+    lam = 0.01
+    x = np.zeros((Bk, ldx)); x[:, :N] = rng.standard_normal((Bk, N))
+    dpre = rng.standard_normal((Bk, E)) * 0.01
+    theta, m0, v0 = rng.standard_normal((N, E)) * 0.05, rng.standard_normal((N, E)) * 1e-3, rng.random((N, E)) * 1e-6
+    n = N * E
+    sp = build_spans([0], [n], device="cuda")
+    l2d = dev([lam])
+    # --- written-out path
+    g = torch.zeros(N, E, device="cuda")
+    be.dense_dw_skinny(dev(x), dev(dpre), g, N, E, Bk, ldx)
+    th_a, m_a, v_a = dev(theta), dev(m0), dev(v0)
+    sq_a, wsq_a, l2o = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    part = torch.zeros(2 * sp.nspan, device="cuda")
+    be.seg_sqnorm(th_a, g, sp.span_seg, sp.span_off, sp.span_len, sp.seg_first, l2d, part, sq_a, wsq_a, l2o, sp.nspan, 1)
+    lr_t = dev([3e-4])
+    be.adam(th_a, m_a, v_a, g, sp.span_seg, sp.span_off, sp.span_len, l2d, sq_a, None, sp.nspan, 0.0, lr_t, 0.9, 0.98, 1e-8,
+            clip)
+    # --- fused path
+    th_b, m_b, v_b = dev(theta), dev(m0), dev(v0)
+    part_b = torch.full((2 * sp.nspan,), 7.0, device="cuda")
+    be.dense_dw_sqnorm(dev(x), dev(dpre), th_b, lam, part_b, sp.nspan, N, E, Bk, ldx)
+    g64 = x[:, :N].T @ dpre
+    q64, w64 = ((g64 + 2 * lam * theta) ** 2).sum(), (theta ** 2).sum()
+    pb = part_b.cpu().double().numpy()
+    assert abs(pb[0::2].sum() - q64) <= 1e-5 * q64 and abs(pb[1::2].sum() - w64) <= 1e-5 * w64
+    close(sq_a, [q64], rtol=1e-5)
+    sq_b = dev([pb[0::2].sum()])
+    guard = torch.zeros(1, dtype=torch.int32, device="cuda")
+    guard[0] = 1                                                                  # tripped guard: nothing moves
+    be.dense_dw_adam(dev(x), dev(dpre), th_b, m_b, v_b, lam, sq_b, None, lr_t, 0.9, 0.98, 1e-8, clip, N, E, Bk, ldx, guard=guard)
+    assert torch.equal(th_b, dev(theta))
+    guard[0] = 0
+    be.dense_dw_adam(dev(x), dev(dpre), th_b, m_b, v_b, lam, sq_b, None, lr_t, 0.9, 0.98, 1e-8, clip, N, E, Bk, ldx, guard=guard)
+    for a_, b_ in ((th_a, th_b), (m_a, m_b), (v_a, v_b)):
+        close(b_, a_.cpu().numpy(), rtol=2e-6)
+    cs = clip / max(np.sqrt(q64), clip) if clip > 0 else 1.0
+    ge = (g64 + 2 * lam * theta) * cs
+    m1 = m0 + (ge - m0) * 0.1
+    v1 = v0 + (ge * ge - v0) * 0.02
+    close(m_b, m1, rtol=1e-5); close(v_b, v1, rtol=1e-5)
+    close(th_b, theta - 3e-4 * m1 / (np.sqrt(v1) + 1e-8), rtol=1e-6)
+
+
 # ------------------------------------------------------------------- locally dense
 @pytest.mark.parametrize("B,N,R,D", [(64, 2000, 36, 32), (3, 37, 4, 16), (64, 3000, 5, 32), (150, 500, 7, 32)])
 def test_locally_dense(be, B, N, R, D):
@@ -1046,7 +1130,8 @@ def test_embedding_fwd_drop_stage_sum2(be):
     close(out, [0.5 * v0.double().sum().item(), 0.5 * v1.double().sum().item()], rtol=1e-5)
 
 
-@pytest.mark.parametrize("N,E,Bk,ldx", [(20000, 512, 64, 20000), (37, 32, 3, 40), (1000, 96, 17, 1000), (2000, 64, 8, 2000)])
+@pytest.mark.parametrize("N,E,Bk,ldx", [(20000, 512, 64, 20000), (37, 32, 3, 40), (1000, 96, 17, 1000), (2000, 64, 8, 2000),
+                                         (1001, 256, 33, 1004), (999, 512, 64, 1000)])
 def test_dense_dw_skinny(be, N, E, Bk, ldx):
     """dW = X^T dpre of the dense encoder (persistent skinny-K kernel) against float64 and the generic GEMM."""
     rng = np.random.default_rng(97)
