@@ -57,6 +57,12 @@ int32_t tnt_gemm_blas_f32(const float* A, const float* B, float* C, int32_t M, i
                           int32_t lda, int32_t ldb, int32_t ldc, int32_t transA, int32_t transB,
                           int32_t accumulate, void* stream);
 
+/* The same product (no accumulate) through hipBLASLt in full FP32 (HIPBLAS_COMPUTE_32F), optional bias [N] added to every
+ * row of C (the Dense layers' bias, NIC.py:143).  The algorithm is the heuristic's first workspace-free candidate for the
+ * shape (reproducible); TNT_LT_TUNE=1 in the environment times the candidates at the first un-captured call instead. */
+int32_t tnt_gemm_lt_f32(const float* A, const float* B, float* C, const float* bias, int32_t M, int32_t N, int32_t K,
+                        int32_t lda, int32_t ldb, int32_t ldc, int32_t transA, int32_t transB, void* stream);
+
 /* One-round GEMM family for the products that carry no activation epilogue -- the weight / input gradients that
  * tape.gradient derives from the Dense / LSTM layers (lc_NIC.py:386-387, NIC.py:248-249) and the LSTM input projection
  * (NIC.py:138-140): C = op(A) op(B) (+ bias[N]), operand conventions of tnt_gemm_f32.  The workgroup tile is picked so

@@ -62,6 +62,7 @@ SIGNATURES = {
     "tnt_gru_step_fwd_f32": [P, P, P, P, P, P, I32, I32, P],
     "tnt_gru_step_bwd_f32": [P, P, P, P, P, P, P, P, P, I32, I32, P],
     "tnt_gemm_blas_f32": [P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
+    "tnt_gemm_lt_f32": [P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, P],
     "tnt_locally_dense_fwd_split_f32": [P, I32, P, P, P, P, I32, P, P, P, P, P, I32, I32, I32, F32, I32, P],
     "tnt_locally_dense_bwd_split_f32": [P, I32, P, P, P, P, I32, P, P, P, I32, I32, I32, I32, P],
     "tnt_sum2_f32": [P, P, P, P, I32, F32, P],

@@ -268,10 +268,28 @@ class ModelBase:
         need = max([self.pick_splitk(*s) * s[0] * s[1] for s in shapes] + [1])
         self.skwork = self._f(need)
 
+    def _route_lt(self, A, B, C, M, N, K, lda, ldb, ldc, ws, kw):
+        """hipBLASLt (tnt_gemm_lt_f32) for the vocabulary-sized GEMMs: one dimension of N / K at least 4096, i.e. the
+        head forward and its two gradients.  On MI355X it runs 960x5001x512 / 960x512x5001 / 512x5001x960 at 110-117 TF
+        (gemm.hip's one-round kernel: 92, rocBLAS: 79-92; tools/probe/hipblaslt_probe.cpp), while the LSTM-sized products
+        (every dimension <= 2048) are level or better on rocBLAS and stay there.  A fixed rule, not a timed choice: which
+        kernel multiplies decides the rounding, and results must not depend on a timing race.  True = call issued."""
+        be = self.be
+        if (not getattr(self, "use_lt", True) or not hasattr(be, "gemm_lt") or kw.get("pre") is not None or kw.get("act", 0)
+                or kw.get("accumulate") or max(N, K) < 4096 or 2.0 * M * N * K < getattr(self, "lt_min_flops", 1e9)):
+            return False
+        tA, tB = bool(kw.get("transA", False)), bool(kw.get("transB", False))
+        if tA and tB:
+            return False
+        be.gemm_lt(A, B, C, M, N, K, lda, ldb, ldc, transA=tA, transB=tB, bias=kw.get("bias"))
+        return True
+
     def gemm_sk(self, A, B, C, M, N, K, lda, ldb, ldc, ws=0, **kw):
         """GEMM with the calibrated split-K choice.  ``ws`` selects the split-K workspace (one per
         concurrent branch, see ``side``).  Workspaces grow on demand during eager (warm-up) passes;
         growing one invalidates captured graphs, which are then re-captured."""
+        if self._route_lt(A, B, C, M, N, K, lda, ldb, ldc, ws, kw):
+            return
         plain = kw.get("bias") is None and kw.get("pre") is None and kw.get("act", 0) == 0
         # One shape family where the vendor's pick is poor: NT with a narrow output and a very long K (config 3's
         # head dX = dlogits[960x5001] @ Wo^T[5001x256]: 59 us = 42 TF, against 38 us for the tiled kernel with

@@ -217,6 +217,10 @@ class HipBackend:
     def dense_dw_skinny(self, x, dpre, dw, N, E, Bk, ldx):
         self._call(self.lib.tnt_dense_dw_skinny_f32, "tnt_dense_dw_skinny_f32", _p(x), _p(dpre), _p(dw), N, E, Bk, ldx, self._s())
 
+    def gemm_lt(self, A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None):
+        self._call(self.lib.tnt_gemm_lt_f32, "tnt_gemm_lt_f32", _p(A), _p(B), _p(C), _p(bias), M, N, K, lda, ldb, ldc, int(transA),
+                   int(transB), self._s())
+
     def gemm_blas(self, A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, accumulate=False):
         self._call(self.lib.tnt_gemm_blas_f32, "tnt_gemm_blas_f32", _p(A), _p(B), _p(C), M, N, K, lda, ldb, ldc, int(transA), int(transB),
                                               int(accumulate), self._s())

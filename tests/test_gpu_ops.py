@@ -1286,3 +1286,33 @@ def test_gemm_blas(be, M, N, K, tA, tB, pad):
     ref = torch.zeros(M, ldc, device="cuda")
     be.gemm(Ad, Bd, ref, M, N, K, lda, ldb, ldc, bool(tA), bool(tB))
     close(Cd[:, :N], ref[:, :N].cpu().numpy(), rtol=2e-5)
+
+
+@pytest.mark.parametrize("M,N,K,tA,tB,pad,bias", [
+    (960, 5001, 512, 0, 0, 3, True), (960, 512, 5001, 0, 1, 3, False), (512, 5001, 960, 1, 0, 3, False),
+    (1024, 2048, 512, 0, 0, 0, True), (33, 17, 29, 0, 0, 0, True), (33, 17, 29, 0, 1, 2, False), (33, 17, 29, 1, 0, 1, False),
+])
+def test_gemm_lt(be, M, N, K, tA, tB, pad, bias):
+    """tnt_gemm_lt_f32 (hipBLASLt, full-FP32 compute, optional bias epilogue): operand conventions and results of
+    tnt_gemm_f32; float32-level accuracy against float64 (no reduced-precision passes); padding untouched; bitwise
+    reproducible over repeated calls with the algorithm the first call picked."""
+    rng = np.random.default_rng(M * 5 + N * 3 + K)
+    A = rng.standard_normal((M, K))
+    Bm = rng.standard_normal((K, N))
+    bv = rng.standard_normal(N) if bias else None
+    As = A.T if tA else A
+    Bs = Bm.T if tB else Bm
+    lda, ldb, ldc = As.shape[1] + pad, Bs.shape[1] + pad, N + pad
+    Ad = torch.zeros(As.shape[0], lda, device="cuda"); Ad[:, :As.shape[1]] = dev(As)
+    Bd = torch.zeros(Bs.shape[0], ldb, device="cuda"); Bd[:, :Bs.shape[1]] = dev(Bs)
+    bd = dev(bv) if bias else None
+    Cd = torch.full((M, ldc), 7.0, device="cuda")
+    be.gemm_lt(Ad, Bd, Cd, M, N, K, lda, ldb, ldc, bool(tA), bool(tB), bias=bd)
+    want = A @ Bm + (bv if bias else 0.0)
+    close(Cd[:, :N], want, rtol=1e-5)                            # f32 sums over K; TF32-style passes would miss it by 100x
+    if pad:
+        assert (Cd[:, N:] == 7.0).all()
+    for _ in range(5):
+        C2 = torch.full((M, ldc), 7.0, device="cuda")
+        be.gemm_lt(Ad, Bd, C2, M, N, K, lda, ldb, ldc, bool(tA), bool(tB), bias=bd)
+        assert torch.equal(Cd, C2)
