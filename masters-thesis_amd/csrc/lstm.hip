@@ -422,6 +422,20 @@ struct LstmSeqArgs {
   float* guard_out;      // nullable: set to the error code when the error word is seen set
 };
 
+// POLL: the hand-off of h between the steps needs no flag round at all.  hs[st+1] is written exactly once per launch, so
+// the DATA is its own flag: every element of hs[st+1] is reset to a sentinel bit pattern (a NaN no arithmetic produces)
+// before anyone can look for it, and a consuming wave simply re-issues its L1-bypassing loads of the 8 values it needs
+// until none of them is the sentinel.  Per step that removes: the drain of the h stores, two workgroup barriers, the flag
+// store, and the flag poll's L2 round trip -- and a wave waits only for the TWO workgroups that produce its 32 units
+// instead of for all 32.  Reset protocol (per element, by the thread that owns it): hs[1] at kernel start, made visible by
+// the launch's single flag barrier; hs[st+2] at the top of step st, completed (vmcnt(0)) before the same thread
+// publishes hs[st+1].  A wave that polls hs[st+2] has read every element of hs[st+1], so every owner's reset of hs[st+2]
+// is already in L2: stale values of the previous launch can never be taken for this launch's.  hs[st+2]'s old content has
+// no reader in this launch.  A poll that exceeds the spin limit sets the error word (the step is then rejected by the
+// guard, model_base.DeviceGuardError) and carries on with what it has, so no wave ever leaves the common control flow.
+constexpr unsigned TNT_SEQ_SENTINEL = 0x7FC5EED5u;
+
+template <bool POLL>
 __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   constexpr int NWF = 16, SS = 8, CK = 32;
   extern __shared__ __attribute__((aligned(16))) float seq_lds[];       // > 64 KB requested: one workgroup per CU
@@ -461,15 +475,34 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
     cp = a.cs[ee]; hp = a.hs[ee];
     x4 = *reinterpret_cast<const float4*>(a.xz + ee * 4);
   }
+  const float sentinel = __uint_as_float(TNT_SEQ_SENTINEL);
+  if (POLL) {
+    if (eok) a.hs[BU + ee] = sentinel;
+    tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
+  }
   for (int st = 0; st < a.S; ++st) {
-    // ---- A fragments: this row block's h of the previous step (own XCD's L2 after the barrier)
-    // (sc1 loads: the slab was stored by the other workgroups of this group one barrier ago)
+    if (POLL && eok && st + 2 <= a.S) a.hs[(long)(st + 2) * BU + ee] = sentinel;       // published by step st + 1
+    // ---- A fragments: this row block's h of the previous step (own XCD's L2)
+    // (sc1 loads: the slab was stored by the other workgroups of this group)
     float av[SS];
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
 #pragma unroll
-    for (int j = 0; j < SS / 4; ++j) {
-      const float4 t = arow < B ? tnt_ld4_l2(hs_rsrc, (unsigned)(((long)st * BU + (long)arow * U + w * CK + j * 16 + kq * 4) * 4))
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
-      av[4 * j + 0] = t.x; av[4 * j + 1] = t.y; av[4 * j + 2] = t.z; av[4 * j + 3] = t.w;
+      for (int j = 0; j < SS / 4; ++j) {
+        const float4 t = arow < B ? tnt_ld4_l2(hs_rsrc, (unsigned)(((long)st * BU + (long)arow * U + w * CK + j * 16 + kq * 4) * 4))
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        av[4 * j + 0] = t.x; av[4 * j + 1] = t.y; av[4 * j + 2] = t.z; av[4 * j + 3] = t.w;
+        if (POLL)
+          ok = ok && __float_as_uint(t.x) != TNT_SEQ_SENTINEL && __float_as_uint(t.y) != TNT_SEQ_SENTINEL &&
+               __float_as_uint(t.z) != TNT_SEQ_SENTINEL && __float_as_uint(t.w) != TNT_SEQ_SENTINEL;
+      }
+      if (!POLL || __all(ok)) break;
+      if (++spins > TNT_SEQ_SPIN_LIMIT) {        // never hang the grid: flag the error, go on with what there is
+        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     }
     int mid = 1;
     if (eok && a.mask_ids && st >= a.mask_s0) mid = a.mask_ids[eb * a.mask_T + (st - a.mask_s0)];
@@ -503,6 +536,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
       const bool m = mid != 0;
       const bool seq = st >= a.mask_s0;
       const float hn = m ? h2 : hp, cn = m ? c2 : cp;
+      if (POLL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's reset of hs[st+2] is in L2 first
       a.hs[(long)(st + 1) * BU + ee] = hn;
       a.cs[(long)(st + 1) * BU + ee] = cn;
       if (a.out && seq) { op = m ? h2 : op; a.out[(long)(st - a.mask_s0) * BU + ee] = op; }
@@ -511,8 +545,12 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
       if (st + 1 < a.S) x4 = *reinterpret_cast<const float4*>(a.xz + ((long)(st + 1) * BU + ee) * 4);
     }
     if (st + 1 == a.S) break;
-    // ---- XCD-local barrier (tnt_seq_sync.h): slices are in L2 once vmcnt drains, one flag word per workgroup
-    tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, st + 1), err);
+    if (POLL) {
+      __syncthreads();        // `red` is rewritten by the next step's MFMA phase
+    } else {
+      // ---- XCD-local barrier (tnt_seq_sync.h): slices are in L2 once vmcnt drains, one flag word per workgroup
+      tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, st + 1), err);
+    }
   }
   tnt_seq_leave(a.sync, xcc, a.guard_out);
 }
@@ -540,6 +578,14 @@ struct LstmSeqBwdArgs {
 constexpr int SB_DZLD = 68;                                   // row stride of the dz tile in LDS (16-byte rows, 68 % 64 == 4)
 constexpr int SB_LDS_BYTES = 82 * 1024;      // uses 16*68 + 16*256 + 4 floats; > half of the CU's 160 KB requested: one workgroup per CU
 
+// POLL: as in lstm_seq_fwd_kernel<POLL> the pushed tiles are their own flags.  The exchange area is a ring of THREE
+// buffers; exchange t (step s = S - 2 - t) uses buffer t % 3.  The thread that writes a 16-byte chunk (dest, src = its
+// workgroup, lane) owns that chunk in every buffer: it resets the chunk of buffer (t + 1) % 3 to the sentinel at the top
+// of exchange t, drains (vmcnt(0)), and only then publishes its chunk of buffer t % 3 -- so a workgroup that polls
+// buffer (t + 1) % 3 has already seen data that was stored after the reset of every chunk it will poll.  The old content
+// of buffer (t + 1) % 3 (exchange t - 2) was consumed before any workgroup could publish exchange t - 1, which the
+// resetting workgroup has fully gathered.  Buffer 0 is reset at kernel start behind the launch's only flag barrier.
+template <bool POLL>
 __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
   constexpr int NWB = 16, NTW = 2;                            // U = 512 = 16 waves x 2 column tiles x 16 units
   extern __shared__ __attribute__((aligned(16))) float sb_lds[];
@@ -560,7 +606,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
     return;
   }
   const int ub = slot.ub, rb = __builtin_amdgcn_readfirstlane((int)xcc);
-  const __amdgpu_buffer_rsrc_t x_rsrc = tnt_rsrc(a.xch, (unsigned)(2u * nrb * 32u * 32u * 1024u));
+  const __amdgpu_buffer_rsrc_t x_rsrc = tnt_rsrc(a.xch, (unsigned)(3u * nrb * 32u * 32u * 1024u));
   // ---- resident weights: B operand of the MFMAs, Ur^T[k][n] = Ur[n][ub*64 + k]; lane (kq, lr) of column tile j holds
   // n = w*32 + j*16 + lr and the 16 contraction indices k = kq*16 + ks (a permutation of the MFMA's natural k order,
   // applied to both operands: each lane's slice is 64 contiguous bytes in HBM and in LDS)
@@ -583,7 +629,16 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
   const long BU = (long)B * U;
   const int ridx = ((erow >> 2) * 16 + ecol) * 4 + (erow & 3);           // where the MFMA C layout keeps (erow, ecol)
   float da_c = 0.f, dc_c = 0.f, dout_c = 0.f;
+  const float sentinel = __uint_as_float(TNT_SEQ_SENTINEL);
+  const float4 sent4 = make_float4(sentinel, sentinel, sentinel, sentinel);
+  // this lane's chunk of the tile for workgroup `dest` in ring buffer `buf`: slot [dest][src = ub], lane-major 1 KB tiles
+  auto xslot = [&](int buf, int dest) { return a.xch + ((((long)(buf * nrb + rb) * 32 + dest) * 32 + ub) * 256) + lane * 4; };
   __syncthreads();
+  if (POLL) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) *reinterpret_cast<float4*>(xslot(0, w * NTW + j)) = sent4;
+    tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
+  }
   for (int s = S - 1; s >= 0; --s) {
     // epilogue operands of this step do not depend on the chain: fetch them first
     const bool seq = s >= a.mask_s0;
@@ -598,7 +653,11 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
     }
     float da = da_c;
     if (s < S - 1) {
-      const int par = s & 1;
+      const int xt = S - 2 - s, par = xt % 3;
+      if (POLL && s > 0) {         // the next exchange's buffer: reset this thread's chunks before publishing this one's
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) *reinterpret_cast<float4*>(xslot((xt + 1) % 3, w * NTW + j)) = sent4;
+      }
       // ---- partial da = dz_tile[16 x 64] @ Ur^T slice[64 x 512]: this wave's 2 column tiles
       float av[16];
 #pragma unroll
@@ -613,19 +672,33 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
       for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bw[j][ks], acc[j], 0, 0, 0);
-      // ---- push: tile j belongs to workgroup (w*2 + j) of this row block; slot [dest][src = ub], lane-major 1 KB tiles
+      // ---- push: tile j belongs to workgroup (w*2 + j) of this row block
+      if (POLL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's resets are in L2 first
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        float* X = a.xch + ((((long)(par * nrb + rb) * 32 + (w * NTW + j)) * 32 + ub) * 256) + lane * 4;
-        *reinterpret_cast<float4*>(X) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
-      }
-      tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, S - 1 - s), err);
+      for (int j = 0; j < NTW; ++j)
+        *reinterpret_cast<float4*>(xslot(par, w * NTW + j)) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+      if (!POLL) tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, S - 1 - s), err);
       // ---- gather the 32 partial tiles of this workgroup's block (sc1 loads: stored by other workgroups): wave w sums
       // sources w and w + 16, the 16 wave sums are combined through LDS in fixed order
       {
         const unsigned base = (unsigned)((((par * nrb + rb) * 32 + ub) * 32) * 1024) + (unsigned)lane * 16u;
-        const float4 p0 = tnt_ld4_l2(x_rsrc, base + (unsigned)w * 1024u);
-        const float4 p1 = tnt_ld4_l2(x_rsrc, base + (unsigned)(w + 16) * 1024u);
+        float4 p0, p1;
+        unsigned spins = 0;
+        for (;;) {
+          p0 = tnt_ld4_l2(x_rsrc, base + (unsigned)w * 1024u);
+          p1 = tnt_ld4_l2(x_rsrc, base + (unsigned)(w + 16) * 1024u);
+          if (!POLL) break;
+          const bool ok = __float_as_uint(p0.x) != TNT_SEQ_SENTINEL && __float_as_uint(p0.y) != TNT_SEQ_SENTINEL &&
+                          __float_as_uint(p0.z) != TNT_SEQ_SENTINEL && __float_as_uint(p0.w) != TNT_SEQ_SENTINEL &&
+                          __float_as_uint(p1.x) != TNT_SEQ_SENTINEL && __float_as_uint(p1.y) != TNT_SEQ_SENTINEL &&
+                          __float_as_uint(p1.z) != TNT_SEQ_SENTINEL && __float_as_uint(p1.w) != TNT_SEQ_SENTINEL;
+          if (__all(ok)) break;
+          if (++spins > TNT_SEQ_SPIN_LIMIT) {      // never hang the grid: flag the error, go on with what there is
+            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        }
         *reinterpret_cast<float4*>(red + w * 256 + lane * 4) = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
       }
       __syncthreads();
@@ -852,7 +925,8 @@ extern "C" int32_t tnt_lstm_seq_supported(int32_t B, int32_t U) {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     if (prop.multiProcessorCount != 256) return 0;
-    if (hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_LDS_BYTES) != hipSuccess) return 0;
+    if (hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_LDS_BYTES) != hipSuccess) return 0;
+    if (hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_LDS_BYTES) != hipSuccess) return 0;
     if (hipFuncSetAttribute((const void*)xcc_census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_LDS_BYTES) != hipSuccess) return 0;
     unsigned* hist = nullptr;
     if (hipMalloc(&hist, 64) != hipSuccess) return 0;
@@ -882,7 +956,9 @@ extern "C" int32_t tnt_lstm_seq_fwd_f32(const float* xz, float* hs, float* cs, c
   LstmSeqArgs a;
   a.xz = xz; a.hs = hs; a.cs = cs; a.Ur = Ur; a.zbias = xz_bias; a.mask_ids = mask_ids; a.out = out; a.gates = gates;
   a.S = S; a.B = B; a.U = U; a.mask_T = mask_T; a.mask_s0 = mask_s0; a.sync = sync; a.guard_out = guard_out;
-  hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(256), dim3(1024), SEQ_LDS_BYTES, s, a);
+  static const bool flags_only = getenv("TNT_SEQ_FLAGS") && atoi(getenv("TNT_SEQ_FLAGS")) != 0;       // A/B switch
+  if (flags_only) hipLaunchKernelGGL(lstm_seq_fwd_kernel<false>, dim3(256), dim3(1024), SEQ_LDS_BYTES, s, a);
+  else hipLaunchKernelGGL(lstm_seq_fwd_kernel<true>, dim3(256), dim3(1024), SEQ_LDS_BYTES, s, a);
   TNT_LAUNCH_CHECK();
   return 0;
 }
@@ -898,21 +974,24 @@ extern "C" int32_t tnt_lstm_seq_bwd_f32(const float* Ur, const float* dout_seq, 
   if (!tnt_aligned16(work) || !tnt_aligned16(Ur) || !tnt_aligned16(gates) || !tnt_aligned16(dz)) return TNT_BADARG(1);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS_BYTES) != hipSuccess)
       return TNT_BADARG(90);
     attr_set = true;
   }
   LstmSeqBwdArgs a;
   a.Ur = Ur; a.dout_seq = dout_seq; a.mask_ids = mask_ids; a.gates = gates; a.cs = cs; a.dz = dz; a.xch = work;
   a.sync = sync; a.guard_out = guard_out; a.S = S; a.B = B; a.U = U; a.mask_T = mask_T; a.mask_s0 = mask_s0;
-  hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(256), dim3(1024), SB_LDS_BYTES, tnt_stream(stream), a);
+  static const bool flags_only = getenv("TNT_SEQ_FLAGS") && atoi(getenv("TNT_SEQ_FLAGS")) != 0;       // A/B switch
+  if (flags_only) hipLaunchKernelGGL(lstm_seq_bwd_kernel<false>, dim3(256), dim3(1024), SB_LDS_BYTES, tnt_stream(stream), a);
+  else hipLaunchKernelGGL(lstm_seq_bwd_kernel<true>, dim3(256), dim3(1024), SB_LDS_BYTES, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int32_t tnt_lstm_seq_bwd_work_floats(int32_t B, int32_t U) {
   (void)U;
-  return 2 * ((B + 15) / 16) * 32 * 32 * 256;
+  return 3 * ((B + 15) / 16) * 32 * 32 * 256;       // ring of three exchange buffers
 }
 
 extern "C" int32_t tnt_ln_lstm_cell_fwd_f32(const float* zk, const float* zr, const float* bias, const float* c_prev,
