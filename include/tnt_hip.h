@@ -231,6 +231,9 @@ int32_t tnt_layernorm_bwd_f32(const float* dy, const float* xhat, const float* g
  * work: C*tnt_bn_nchunk(rows) floats. */
 int32_t tnt_colsum_f32(const float* x, float* out, int32_t rows, int32_t C, int32_t ld,
                        float* work, void* stream);
+/* two independent matrices of <= 2048 rows each in one launch (same results as two tnt_colsum_f32 calls) */
+int32_t tnt_colsum2_f32(const float* x0, float* out0, int32_t rows0, int32_t C0, int32_t ld0, const float* x1,
+                        float* out1, int32_t rows1, int32_t C1, int32_t ld1, void* stream);
 
 /* ---- Embedding (lc_NIC.py:105-112,233; NIC.py:75-79,131) ------------------------
  * fwd: out[(t*B+b)][:] = table[ids[b*T+t]][:]   (ids is the keras (B,T) int32 array)
@@ -254,11 +257,15 @@ int32_t tnt_embedding_fwd_drop_f32(const float* table, const int32_t* ids, float
  * squared norm in sq_part[k * ny + y] (ny = ceil(E / 256); tnt_embedding_bwd_parts(B, T, E) floats; their sum is the
  * norm of the un-deduplicated rows); rows that only the PREVIOUS step touched (prev_ids [B*T], -1 = none) are zeroed.
  * Contract: dtable starts zeroed and is written by nothing else between calls (no gradient all-reduce), prev_ids holds
- * the ids of the previous call (tnt_step_finalize_f32 copies them).  E % 4 == 0, 16-byte aligned rows. */
+ * the ids of the previous call (tnt_step_finalize_f32 copies them).  E % 4 == 0, 16-byte aligned rows.
+ * drop_rate > 0: drows is the gradient w.r.t. the dropped-out Embedding output (the LSTM layer's input dropout of the
+ * text call, NIC.py:131,140); the keep mask tnt_embedding_fwd_drop_f32 applied (element (b*T + t) * E + e of stream
+ * (drop_seed, drop_site, *drop_step_dev)) is applied to the rows as they are read. */
 int32_t tnt_embedding_bwd_parts(int32_t B, int32_t T, int32_t E);
 int32_t tnt_embedding_bwd_sparse_f32(const float* drows, const int32_t* ids, const int32_t* prev_ids, float* dtable,
                                      float* sq_part, int32_t B, int32_t T, int32_t E, int32_t ldd, int32_t V,
-                                     void* stream);
+                                     float drop_rate, uint64_t drop_seed, uint32_t drop_site,
+                                     const uint32_t* drop_step_dev, void* stream);
 int32_t tnt_embedding_bwd_f32(const float* drows, const int32_t* ids, float* dtable,
                               float* sq_norm, float* rowsq_work, int32_t B, int32_t T,
                               int32_t E, int32_t ldd, int32_t V, void* stream);

@@ -758,6 +758,43 @@ __global__ __launch_bounds__(1024) void col_sum_direct_kernel(const float* x, in
   }
 }
 
+// two independent short matrices in one launch (the head-bias and LSTM-bias gradients of a step): blocks [0, nb0) work
+// on the first, the rest on the second -- one dependent launch less in the captured step
+__global__ __launch_bounds__(1024) void col_sum_direct2_kernel(const float* x0, int ld0, int rows0, int C0, float* out0,
+                                                               int nb0, const float* x1, int ld1, int rows1, int C1,
+                                                               float* out1) {
+  __shared__ float sh[32][33];
+  const bool second = (int)blockIdx.x >= nb0;
+  const float* x = second ? x1 : x0;
+  float* out = second ? out1 : out0;
+  const int ld = second ? ld1 : ld0, rows = second ? rows1 : rows0, C = second ? C1 : C0;
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = (blockIdx.x - (second ? nb0 : 0)) * 32 + cl;
+  float v = 0.f;
+  if (c < C) {
+#pragma unroll 8
+    for (int r = rl; r < rows; r += 32) v += x[(long)r * ld + c];
+  }
+  sh[rl][cl] = v;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) t += sh[j][cl];
+    out[c] = t;
+  }
+}
+
+extern "C" int32_t tnt_colsum2_f32(const float* x0, float* out0, int32_t rows0, int32_t C0, int32_t ld0, const float* x1,
+                                   float* out1, int32_t rows1, int32_t C1, int32_t ld1, void* stream) {
+  if (rows0 <= 0 || C0 <= 0 || rows1 <= 0 || C1 <= 0 || rows0 > 2048 || rows1 > 2048) return TNT_BADARG(2);
+  const int nb0 = (C0 + 31) / 32, nb1 = (C1 + 31) / 32;
+  hipLaunchKernelGGL(col_sum_direct2_kernel, dim3(nb0 + nb1), dim3(1024), 0, tnt_stream(stream), x0, ld0, rows0, C0, out0, nb0,
+                     x1, ld1, rows1, C1, out1);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int32_t tnt_colsum_f32(const float* x, float* out, int32_t rows, int32_t C, int32_t ld, float* work,
                                   void* stream) {
   hipStream_t s = tnt_stream(stream);

@@ -178,9 +178,27 @@ __global__ __launch_bounds__(256) void emb_bwd4_kernel(const float* drows, const
 // Rows touched by neither step are zero already (the table gradient starts zeroed and nothing else writes it), rows of
 // this step are fully overwritten by their owner: no race between the two halves.  The caller copies ids -> prev_ids
 // after this launch (tnt_step_finalize_f32 does).
+// `rate` > 0: the rows are the gradient w.r.t. the DROPPED-OUT embedding output (the LSTM layer's input dropout of the
+// text call, NIC.py:131,140): the keep mask of element k * E + j in stream (seed, site, step) -- the one
+// tnt_embedding_fwd_drop_f32 applied -- is applied to every row chunk as it is read, instead of a dropout launch over
+// the row buffer in front of this one.
+struct EmbDrop { float rate, scale; uint64_t seed; uint32_t site; const uint32_t* step_dev; };
+
+__device__ __forceinline__ float4 emb_row4(const float* drows, int k, int B, int T, int E, int ldd, int j, const EmbDrop& d,
+                                           uint32_t step) {
+  float4 v = *reinterpret_cast<const float4*>(drows + (long)((k % T) * B + k / T) * ldd + j);
+  if (d.rate > 0.f) {
+    bool kp[4];
+    tnt_keep4((uint64_t)k * (uint64_t)E + (uint64_t)j, d.rate, d.seed, d.site, step, kp);
+    v.x = kp[0] ? v.x * d.scale : 0.f; v.y = kp[1] ? v.y * d.scale : 0.f;
+    v.z = kp[2] ? v.z * d.scale : 0.f; v.w = kp[3] ? v.w * d.scale : 0.f;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(256) void emb_bwd_sparse_kernel(const float* drows, const int* ids, const int* prev_ids,
                                                              float* dtable, float* sq_part, int B, int T, int E, int ldd,
-                                                             int V) {
+                                                             int V, EmbDrop drop) {
   __shared__ float4 part[4][64];
   __shared__ float sqw[4];
   __shared__ int s_flag;
@@ -221,8 +239,9 @@ __global__ __launch_bounds__(256) void emb_bwd_sparse_kernel(const float* drows,
   }
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float sq = 0.f;
+  const uint32_t dstep = drop.step_dev ? drop.step_dev[0] : 0u;
   if (w == 0 && jok) {
-    acc = *reinterpret_cast<const float4*>(drows + (long)((k % T) * B + k / T) * ldd + j);
+    acc = emb_row4(drows, k, B, T, E, ldd, j, drop, dstep);
     sq = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
   }
   constexpr int NF = 8;
@@ -241,8 +260,7 @@ __global__ __launch_bounds__(256) void emb_bwd_sparse_kernel(const float* drows,
       float4 v[NF];
 #pragma unroll
       for (int q = 0; q < NF; ++q)
-        v[q] = (kk[q] >= 0 && jok) ? *reinterpret_cast<const float4*>(drows + (long)((kk[q] % T) * B + kk[q] / T) * ldd + j)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[q] = (kk[q] >= 0 && jok) ? emb_row4(drows, kk[q], B, T, E, ldd, j, drop, dstep) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int q = 0; q < NF; ++q) {
         acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w;
@@ -696,12 +714,15 @@ extern "C" int32_t tnt_embedding_bwd_parts(int32_t B, int32_t T, int32_t E) { re
 
 extern "C" int32_t tnt_embedding_bwd_sparse_f32(const float* drows, const int32_t* ids, const int32_t* prev_ids,
                                                 float* dtable, float* sq_part, int32_t B, int32_t T, int32_t E,
-                                                int32_t ldd, int32_t V, void* stream) {
+                                                int32_t ldd, int32_t V, float drop_rate, uint64_t drop_seed,
+                                                uint32_t drop_site, const uint32_t* drop_step_dev, void* stream) {
   if (B <= 0 || T <= 0 || E <= 0 || V <= 0) return TNT_BADARG(6);
   if (E % 4 != 0 || ldd % 4 != 0 || !tnt_aligned16(drows) || !tnt_aligned16(dtable)) return TNT_BADARG(1);
   if (prev_ids == nullptr || sq_part == nullptr || prev_ids == ids) return TNT_BADARG(3);
+  if (drop_rate < 0.f || drop_rate >= 1.f) return TNT_BADARG(11);
+  const EmbDrop drop{drop_rate, 1.0f / (1.0f - drop_rate), drop_seed, drop_site, drop_step_dev};
   hipLaunchKernelGGL(emb_bwd_sparse_kernel, dim3(2 * B * T, (E + 255) / 256), dim3(256), 0, tnt_stream(stream), drows, ids,
-                     prev_ids, dtable, sq_part, B, T, E, ldd, V);
+                     prev_ids, dtable, sq_part, B, T, E, ldd, V, drop);
   TNT_LAUNCH_CHECK();
   return 0;
 }

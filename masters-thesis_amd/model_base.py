@@ -193,7 +193,12 @@ class ModelBase:
             be.sgd(a.theta, self.opt_m, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq, a.sq_override,
                    sp.nspan, 0.0, self.lr_dev, opt.momentum, clip, guard=gd)
 
-    def _embedding_bwd(self, drows, ids, name, B, T, E, ldd, V):
+    def _emb_sparse_ok(self, E, ldd):
+        """the sparse Embedding backward runs (single-process fused step)"""
+        return bool(self.__dict__.get("_defer_sum2") and self.dp_world == 1 and getattr(self, "sparse_emb_bwd", True)
+                    and hasattr(self.be, "embedding_bwd_sparse") and E % 4 == 0 and ldd % 4 == 0)
+
+    def _embedding_bwd(self, drows, ids, name, B, T, E, ldd, V, drop=None):
         """Embedding scatter + IndexedSlices norm.  Inside the fused single-process step (``_defer_sum2``) the sparse
         form runs: no table-wide zero fill (rows touched by the previous step only are cleaned through ``prev_ids``),
         the norm as per-block partials that the step-finalize launch sums.  Anywhere else (data parallel: the all-reduce
@@ -211,10 +216,11 @@ class ModelBase:
                                     self._f(nparts), nparts)
             a.g(name).zero_()
         _, prev, parts, nparts = st
-        sparse = (self.__dict__.get("_defer_sum2") and self.dp_world == 1 and getattr(self, "sparse_emb_bwd", True)
-                  and hasattr(be, "embedding_bwd_sparse") and E % 4 == 0 and ldd % 4 == 0)
+        sparse = self._emb_sparse_ok(E, ldd)
+        assert drop is None or sparse, "the input-dropout mask can only ride on the sparse form"
         if sparse:
-            be.embedding_bwd_sparse(drows, ids, prev, a.g(name), parts, B, T, E, ldd, V)
+            kw = dict(drop_rate=drop[0], drop_seed=drop[1], drop_site=drop[2], drop_step_dev=drop[3]) if drop else {}
+            be.embedding_bwd_sparse(drows, ids, prev, a.g(name), parts, B, T, E, ldd, V, **kw)
             self._emb_finalize = (parts, None if self.__dict__.get("agc") else sqo, nparts, ids, prev, B * T)
         else:
             be.embedding_bwd(drows, ids, a.g(name), sqo, self.rowsq, B, T, E, ldd, V)

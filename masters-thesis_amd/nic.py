@@ -343,7 +343,12 @@ class NIC(ModelBase):
             with self.side(0 if getattr(self, "side_head", True) else -1):
                 self.gemm_sk(self.Out, dlog, a.g("time_distributed_softmax/kernel"), U, V, T * B, U, ldV, ldV, transA=True,
                              ws=1)
-                be.colsum(dlog, a.g("time_distributed_softmax/bias"), T * B, V, ldV, self.work2)
+                if self.__dict__.get("_defer_sum2") and hasattr(be, "colsum2") and T * B <= 2048:
+                    # single-process step: the head-bias column sums share a launch with the LSTM-bias ones behind the
+                    # BPTT chain (dlogits stays in place until the next forward)
+                    self._colsum_deferred = (dlog, a.g("time_distributed_softmax/bias"), T * B, V, ldV)
+                else:
+                    be.colsum(dlog, a.g("time_distributed_softmax/bias"), T * B, V, ldV, self.work2)
         self.gemm_sk(dlog, Wo, self.dOut, T * B, U, V, ldV, ldV, U, transB=True)
         if join:
             self.join()
@@ -385,12 +390,21 @@ class NIC(ModelBase):
             # share dZ, the bias gradient (column sums of dZ) rides on the tiles the first row of workgroups loads anyway
             be.gemm_fused(xin, self.dZ, a.g("lstm/kernel"), E, 4 * U, R1, E, 4 * U, 4 * U, transA=True,
                           colsum=a.g("lstm/bias"), A2=self.Hs, C2=a.g("lstm/recurrent_kernel"))
+            d = self.__dict__.pop("_colsum_deferred", None)
+            if d is not None:
+                be.colsum(*d, self.work2)
             return
         with self.side(1):
             self.gemm_sk(self.Hs, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, R1, U, 4 * U, 4 * U, transA=True, ws=2)
         with self.side(0):
             self.gemm_sk(xin, self.dZ, a.g("lstm/kernel"), E, 4 * U, R1, E, 4 * U, 4 * U, transA=True, ws=1)
-            be.colsum(self.dZ, a.g("lstm/bias"), R1, 4 * U, 4 * U, self.work2)
+            d = self.__dict__.pop("_colsum_deferred", None)
+            if d is not None and R1 <= 2048:
+                be.colsum2(*d, self.dZ, a.g("lstm/bias"), R1, 4 * U, 4 * U)
+            else:
+                if d is not None:
+                    be.colsum(*d, self.work2)
+                be.colsum(self.dZ, a.g("lstm/bias"), R1, 4 * U, 4 * U, self.work2)
 
     def _bwd_seq_front(self, B, T):
         """LSTM input gradient -> embedding rows, BatchNorm, encoder activation, encoder bias."""
@@ -403,9 +417,16 @@ class NIC(ModelBase):
         if self.r_lstm > 0:
             if not fused:
                 be.dropout(self.dXin, self.dXin, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
+        # The text call's LSTM-input dropout' can ride on the sparse Embedding backward (mask applied to the rows as they are
+        # read; not when AGC needs the dropped-out rows themselves).  Off by default: measured 0.5761 -> 0.5845 ms/step --
+        # the Philox calls land on the few workgroups that own heavily duplicated ids, on the step's critical path, and cost
+        # more there than the 4 us launch they save.
+        fold = self.r_lstm > 0 and self._emb_sparse_ok(E, E) and not self.__dict__.get("agc") and getattr(self, "fold_emb_drop", False)
+        if self.r_lstm > 0 and not fold:
             be.dropout(self.dXin[B:], self.dXin[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
         self._emb_rows = (self.dXin[B:], T * B, E, E, "emb_text/embeddings")
-        self._embedding_bwd(self.dXin[B:], self.cap, "emb_text/embeddings", B, T, E, E, V)
+        self._embedding_bwd(self.dXin[B:], self.cap, "emb_text/embeddings", B, T, E, E, V,
+                            drop=(self.r_lstm, sd, S_LSTM_IN + 1, ds) if fold else None)
         if fused:       # dropout' -> BatchNorm' -> dropout' -> LeakyReLU' -> dpre, encoder bias gradient: one launch
             be.enc_tail_bwd(self.dXin, self.xhat, a.p("batch_norm/gamma"), self.inv_std, self.enc_pre, self.dpre,
                             a.g("batch_norm/gamma"), a.g("batch_norm/beta"), a.g("dense_img/bias"), B, E, E,
@@ -476,7 +497,8 @@ class NIC(ModelBase):
         self._sync_lr()
         self._enc_grad_stale = None
         if self.grad_sync is None:
-            self._run_captured(("train", B, T), lambda: self._train_and_update_graph(B, T))
+            run = self._run_planned if getattr(self, "plan_step", False) else self._run_captured
+            run(("train", B, T), lambda: self._train_and_update_graph(B, T))
             self._enc_grad_stale = self.__dict__.get("_enc_last_fused")
         elif getattr(self.grad_sync, "pipelined", False):
             self.grad_sync.step(self, B, T)

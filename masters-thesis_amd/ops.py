@@ -104,6 +104,10 @@ class HipBackend:
         self._call(self.lib.tnt_layernorm_bwd_f32, "tnt_layernorm_bwd_f32", _p(dy), _p(xhat), _p(gamma), _p(inv_std), _p(dx), _p(dgamma),
                                                   _p(dbeta), rows, C, lddy, _p(work), self._s())
 
+    def colsum2(self, x0, out0, rows0, C0, ld0, x1, out1, rows1, C1, ld1):
+        self._call(self.lib.tnt_colsum2_f32, "tnt_colsum2_f32", _p(x0), _p(out0), rows0, C0, ld0, _p(x1), _p(out1), rows1, C1, ld1,
+                   self._s())
+
     def colsum(self, x, out, rows, C, ld, work):
         self._call(self.lib.tnt_colsum_f32, "tnt_colsum_f32", _p(x), _p(out), rows, C, ld, _p(work), self._s())
 
@@ -296,9 +300,10 @@ class HipBackend:
     def embedding_bwd_parts(self, B, T, E):
         return int(self.lib.tnt_embedding_bwd_parts(B, T, E))
 
-    def embedding_bwd_sparse(self, drows, ids, prev_ids, dtable, sq_part, B, T, E, ldd, V):
+    def embedding_bwd_sparse(self, drows, ids, prev_ids, dtable, sq_part, B, T, E, ldd, V, drop_rate=0.0, drop_seed=0,
+                             drop_site=0, drop_step_dev=None):
         self._call(self.lib.tnt_embedding_bwd_sparse_f32, "tnt_embedding_bwd_sparse_f32", _p(drows), _p(ids), _p(prev_ids), _p(dtable),
-                   _p(sq_part), B, T, E, ldd, V, self._s())
+                   _p(sq_part), B, T, E, ldd, V, drop_rate, int(drop_seed), int(drop_site), _p(drop_step_dev), self._s())
 
     def agc(self, theta, grad, tab, gsq_cols=None, sq_out=None, clip_factor=0.01, eps=1e-3):
         """unit-wise adaptive gradient clipping over the arena; ``tab`` = arena.AgcTable"""

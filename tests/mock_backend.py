@@ -251,6 +251,10 @@ class MockBackend:
         flat(dz)[:B * U * 4] = out.reshape(-1)
         flat(dc_prev)[:B * U] = (dcr * gf).reshape(-1)
 
+    def colsum2(self, x0, out0, rows0, C0, ld0, x1, out1, rows1, C1, ld1):
+        self.colsum(x0, out0, rows0, C0, ld0, None)
+        self.colsum(x1, out1, rows1, C1, ld1, None)
+
     def colsum(self, x, out, rows, C, ld, work):
         flat(out)[:C] = mat(x, rows, C, ld).astype(np.float64).sum(0)
 
@@ -550,9 +554,15 @@ class MockBackend:
     def embedding_bwd_parts(self, B, T, E):
         return B * T * ((E + 255) // 256)
 
-    def embedding_bwd_sparse(self, drows, ids, prev_ids, dtable, sq_part, B, T, E, ldd, V):
+    def embedding_bwd_sparse(self, drows, ids, prev_ids, dtable, sq_part, B, T, E, ldd, V, drop_rate=0.0, drop_seed=0,
+                             drop_site=0, drop_step_dev=None):
         """include/tnt_hip.h: tnt_embedding_bwd_sparse_f32 from its contract: only rows of ids and prev_ids are touched"""
         idv = np.clip(flat(ids)[:B * T].reshape(B, T), 0, V - 1)
+        if drop_rate > 0:         # the mask the forward applied, on a copy (the row buffer itself stays undropped)
+            tmp = torch.zeros(T * B, E, dtype=torch.float32)
+            tmp.copy_(torch.as_strided(drows, (T * B, E), (ldd, 1)))
+            self.dropout(tmp, tmp, T * B, E, E, B, E, 0, drop_rate, drop_seed, drop_site, 0, drop_step_dev)
+            drows, ldd = tmp, E
         rows = mat(drows, T * B, E, ldd).reshape(T, B, E).astype(np.float64)
         tab = flat(dtable)[:V * E].reshape(V, E)
         for p in set(int(x) for x in flat(prev_ids)[:B * T] if 0 <= x < V):

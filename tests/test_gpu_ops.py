@@ -320,9 +320,19 @@ def test_embedding_bwd_sparse_over_consecutive_steps(be, B, T, E, V):
         if step == 2:
             ids[:] = 1                                          # one id owns every row
         drows = rng.standard_normal((T, B, E))
-        want = O.embedding_bwd_dense(np.transpose(drows, (1, 0, 2)), ids, V)
         idd = dev(ids, torch.int32)
-        be.embedding_bwd_sparse(dev(drows.reshape(T * B, E)), idd, prev, table, parts, B, T, E, E, V)
+        if step % 2 == 1 and E % 4 == 0:
+            # with the forward's input-dropout mask folded in: same result as a dropout launch over the rows in front
+            step_dev = torch.tensor([3 + step], dtype=torch.int32, device="cuda")
+            dd = dev(drows.reshape(T * B, E)).clone()
+            be.dropout(dd, dd, T * B, E, E, B, E, 0, 0.3, 91, 49, 0, step_dev)
+            want_rows = dd.cpu().double().numpy().reshape(T, B, E)
+            be.embedding_bwd_sparse(dev(drows.reshape(T * B, E)), idd, prev, table, parts, B, T, E, E, V, drop_rate=0.3,
+                                    drop_seed=91, drop_site=49, drop_step_dev=step_dev)
+            drows = want_rows
+        else:
+            be.embedding_bwd_sparse(dev(drows.reshape(T * B, E)), idd, prev, table, parts, B, T, E, E, V)
+        want = O.embedding_bwd_dense(np.transpose(drows, (1, 0, 2)), ids, V)
         be.step_finalize(none, None, None, None, None, None, 0, extra_part=parts, extra=sq, n_extra=nparts, ids_src=idd,
                          ids_dst=prev, n_ids=n)
         torch.cuda.synchronize()
