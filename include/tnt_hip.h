@@ -552,6 +552,17 @@ int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* F, const fl
                                    const float* dctx_part, int32_t nparts, const uint8_t* keep4,
                                    float alpha_mse_coef, void* stream);
 
+/* ---- the attention layer's hoisted first Dense (P = LeakyReLU(F W1 + b1), attention.py:32) backward, behind the chain:
+ * with dP [rows][A] the score gradient accumulated over the T steps and Ppre its pre-activation:
+ *   g = dP * LeakyReLU'(Ppre, slope);  db1 = column sums of g;  dW1 [D][A] = F^T g;  dF [rows][D] += g W1^T
+ * (lc_NIC.py:386-387) in two launches; g is not stored.  part: tnt_attention_front_bwd_parts(rows, D, A) floats of
+ * scratch.  D = A = 32 (the reference's attention width; other sizes: TNT_BADARG, use the generic entry points).
+ * Deterministic (partials summed in row-chunk order). */
+int32_t tnt_attention_front_bwd_parts(int32_t rows, int32_t D, int32_t A);
+int32_t tnt_attention_front_bwd_f32(const float* Ppre, const float* dP, const float* F, const float* W1, float* dF,
+                                    float* dW1, float* db1, float* part, int32_t rows, int32_t D, int32_t A,
+                                    float slope, void* stream);
+
 /* attention "coverage" metric (lc_NIC.py:365-367): mean over (T,R) of
  * (1 - sum_b alpha[t][b][r])^2.  alpha is [T][B][R]. */
 int32_t tnt_attention_metric_f32(const float* alpha, float* out, float* work /* T floats */,

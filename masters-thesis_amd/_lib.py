@@ -35,6 +35,7 @@ SIGNATURES = {
     "tnt_colsum2_f32": [P, P, I32, I32, I32, P, P, I32, I32, I32, P],
     "tnt_embedding_fwd_f32": [P, P, P, I32, I32, I32, I32, I32, P],
     "tnt_embedding_bwd_parts": [I32, I32, I32],
+    "tnt_attention_front_bwd_parts": [I32, I32, I32],
     "tnt_embedding_bwd_sparse_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, F32, U64, U32, P, P],
     "tnt_embedding_bwd_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, P],
     "tnt_lstm_seq_supported": [I32, I32],
@@ -62,6 +63,7 @@ SIGNATURES = {
                                 U32, P, P],
     "tnt_gru_step_fwd_f32": [P, P, P, P, P, P, I32, I32, P],
     "tnt_gru_step_bwd_f32": [P, P, P, P, P, P, P, P, P, I32, I32, P],
+    "tnt_attention_front_bwd_f32": [P, P, P, P, P, P, P, P, I32, I32, I32, F32, P],
     "tnt_gemm_blas_f32": [P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
     "tnt_gemm_lt_f32": [P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, P],
     "tnt_locally_dense_fwd_split_f32": [P, I32, P, P, P, P, I32, P, P, P, P, P, I32, I32, I32, F32, I32, P],

@@ -740,3 +740,127 @@ extern "C" int32_t tnt_attention_metric_f32(const float* alpha, float* out, floa
   TNT_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Everything behind the T-step chain that consumes the accumulated score gradient dP [B*R][A] (the hoisted
+// P = LeakyReLU(F W1 + b1) of attention.py:32; lc_NIC.py:386-387 for its gradients):
+//   g = dP * LeakyReLU'(Ppre)   (never stored: nothing downstream reads it)
+//   db1 = column sums of g,  dW1 = F^T g,  dF += g W1^T
+// in TWO launches instead of act_bwd + a 32 x 32 x 23040 GEMM (21 us on the vendor library for 47 MFLOP) + a two-launch
+// column sum + a 23040 x 32 x 32 GEMM (12 us).  Launch 1 has two kinds of workgroups: [0, nA) each reduce a chunk of
+// AF_CHUNK rows to a partial of dW1 / db1 (tiles of g / F in LDS, outputs strided over the threads); [nA, nA + nB) update
+// one row of dF per thread (g in registers, W1 broadcast from LDS).  Launch 2 sums the nA partials in chunk order
+// (deterministic).
+namespace {
+constexpr int AF_TILE = 120, AF_CHUNK = 120, AF_BROWS = 64, AF_W = 32;      // D = A = AF_W (the reference's sizes)
+
+__global__ __launch_bounds__(256) void attention_front_bwd_kernel(const float* Ppre, const float* dP, const float* F,
+                                                                  const float* W1, float* dF, float* part, int rows,
+                                                                  float slope, int nA) {
+  constexpr int W = AF_W, LD = AF_W + 4;                 // LDS rows of 36 floats: 16-byte aligned float4 reads
+  __shared__ __attribute__((aligned(16))) float gs[AF_TILE * LD];
+  __shared__ __attribute__((aligned(16))) float Fs[AF_TILE * LD];
+  const int tid = threadIdx.x;
+  // coalesced tile loader: float4 per thread, 8 float4 per row; g = dP * LeakyReLU'(Ppre) on the fly
+  auto load_g = [&](int row0, int nr, int tile_rows) {
+    for (int e = tid; e < tile_rows * (W / 4); e += 256) {
+      const int r = e >> 3, c = (e & 7) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < nr) {
+        const long o = (long)(row0 + r) * W + c;
+        const float4 p = *reinterpret_cast<const float4*>(Ppre + o), d = *reinterpret_cast<const float4*>(dP + o);
+        v = make_float4(tnt_act_grad(p.x, d.x, 1, slope), tnt_act_grad(p.y, d.y, 1, slope), tnt_act_grad(p.z, d.z, 1, slope),
+                        tnt_act_grad(p.w, d.w, 1, slope));
+      }
+      *reinterpret_cast<float4*>(gs + r * LD + c) = v;
+    }
+  };
+  if ((int)blockIdx.x >= nA) {
+    // ---- dF[rows of this workgroup] += g W1^T: thread = (row, 8 consecutive d)
+    float* Ws = Fs;                                        // [W][LD]: W1[d][a]
+    const int row0 = (blockIdx.x - nA) * AF_BROWS, nr = min(AF_BROWS, rows - row0);
+    load_g(row0, nr, AF_BROWS);
+    for (int e = tid; e < W * (W / 4); e += 256) {
+      const int d = e >> 3, c = (e & 7) * 4;
+      *reinterpret_cast<float4*>(Ws + d * LD + c) = *reinterpret_cast<const float4*>(W1 + d * W + c);
+    }
+    __syncthreads();
+    const int r = tid >> 2, d0 = (tid & 3) * 8;
+    if (r >= nr) return;
+    float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a4 = 0; a4 < W; a4 += 4) {
+      const float4 g = *reinterpret_cast<const float4*>(gs + r * LD + a4);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float4 w = *reinterpret_cast<const float4*>(Ws + (d0 + k) * LD + a4);
+        t[k] += g.x * w.x + g.y * w.y + g.z * w.z + g.w * w.w;
+      }
+    }
+    float4* o = reinterpret_cast<float4*>(dF + (long)(row0 + r) * W + d0);
+    float4 u0 = o[0], u1 = o[1];
+    u0.x += t[0]; u0.y += t[1]; u0.z += t[2]; u0.w += t[3]; u1.x += t[4]; u1.y += t[5]; u1.z += t[6]; u1.w += t[7];
+    o[0] = u0; o[1] = u1;
+    return;
+  }
+  // ---- partial of dW1 (thread = (d, 4 consecutive a)) and db1 (threads 0..31) over this chunk's rows
+  const int c0 = blockIdx.x * AF_CHUNK, c1 = min(rows, c0 + AF_CHUNK);
+  const int d = tid >> 3, a0 = (tid & 7) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float bsum = 0.f;
+  for (int t0 = c0; t0 < c1; t0 += AF_TILE) {
+    const int nr = min(AF_TILE, c1 - t0);
+    __syncthreads();
+    load_g(t0, nr, AF_TILE);
+    for (int e = tid; e < AF_TILE * (W / 4); e += 256) {
+      const int r = e >> 3, c = (e & 7) * 4;
+      *reinterpret_cast<float4*>(Fs + r * LD + c) =
+          r < nr ? *reinterpret_cast<const float4*>(F + (long)(t0 + r) * W + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < AF_TILE; ++r) {
+      const float f = Fs[r * LD + d];
+      const float4 g = *reinterpret_cast<const float4*>(gs + r * LD + a0);
+      acc.x += f * g.x; acc.y += f * g.y; acc.z += f * g.z; acc.w += f * g.w;
+    }
+    if (tid < W) {
+#pragma unroll 8
+      for (int r = 0; r < AF_TILE; ++r) bsum += gs[r * LD + tid];
+    }
+  }
+  float* mine = part + (long)blockIdx.x * (W * W + W);
+  *reinterpret_cast<float4*>(mine + d * W + a0) = acc;
+  if (tid < W) mine[W * W + tid] = bsum;
+}
+
+__global__ __launch_bounds__(64) void attention_front_finalize_kernel(const float* part, int nA, int nout, int nw, float* dW1,
+                                                                      float* db1) {
+  const int o = blockIdx.x * 64 + threadIdx.x;
+  if (o >= nout) return;
+  float t = 0.f;
+#pragma unroll 8
+  for (int g = 0; g < nA; ++g) t += part[(long)g * nout + o];
+  if (o < nw) dW1[o] = t; else db1[o - nw] = t;
+}
+}  // namespace
+
+extern "C" int32_t tnt_attention_front_bwd_parts(int32_t rows, int32_t D, int32_t A) {
+  return ((rows + AF_CHUNK - 1) / AF_CHUNK) * (D * A + A);
+}
+
+extern "C" int32_t tnt_attention_front_bwd_f32(const float* Ppre, const float* dP, const float* F, const float* W1,
+                                               float* dF, float* dW1, float* db1, float* part, int32_t rows, int32_t D,
+                                               int32_t A, float slope, void* stream) {
+  if (rows <= 0 || D != AF_W || A != AF_W) return TNT_BADARG(9);          // callers keep the unfused sequence otherwise
+  if (!tnt_aligned16(Ppre) || !tnt_aligned16(dP) || !tnt_aligned16(F) || !tnt_aligned16(W1) || !tnt_aligned16(dF) ||
+      !tnt_aligned16(part)) return TNT_BADARG(1);
+  const int nA = (rows + AF_CHUNK - 1) / AF_CHUNK, nB = (rows + AF_BROWS - 1) / AF_BROWS;
+  hipStream_t s = tnt_stream(stream);
+  hipLaunchKernelGGL(attention_front_bwd_kernel, dim3(nA + nB), dim3(256), 0, s, Ppre, dP, F, W1, dF, part, rows, slope, nA);
+  TNT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attention_front_finalize_kernel, dim3((D * A + A + 63) / 64), dim3(64), 0, s, part, nA, D * A + A, D * A,
+                     dW1, db1);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}

@@ -674,10 +674,20 @@ class NIC(ModelBase):
         be.colsum(self.dqpre, a.g("attention/W2/bias"), n, A, A, self.work)
         be.colsum(self.dvb, a.g("attention/V/kernel"), B, A, A + 1, self.work)
         be.colsum(self.dvb.view(-1)[A:], a.g("attention/V/bias"), B, 1, A + 1, self.work)
-        be.act_bwd(self.Ppre, self.dP, self.dP, B * R * A, ACT_LEAKY, 0.2)
-        self.gemm_sk(self.F, self.dP, a.g("attention/W1/kernel"), D, A, B * R, D, A, A, transA=True)
-        be.colsum(self.dP, a.g("attention/W1/bias"), B * R, A, A, self.work)
-        self.gemm_sk(self.dP, a.p("attention/W1/kernel"), self.dF, B * R, D, A, A, A, D, transB=True, accumulate=True)
+        if getattr(self, "fused_att_front", True) and hasattr(be, "attention_front_bwd") and D == 32 and A == 32:
+            # LeakyReLU' + bias gradient + W1 gradient + the dF contribution of the hoisted Dense in two launches instead of five
+            fb = self.__dict__.get("_att_fb")
+            if fb is None or fb[1] != (B * R, D, A):
+                if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("attention front-backward scratch must be built outside a graph capture")
+                fb = self._att_fb = (self._f(be.attention_front_bwd_parts(B * R, D, A)), (B * R, D, A))
+            be.attention_front_bwd(self.Ppre, self.dP, self.F, a.p("attention/W1/kernel"), self.dF,
+                                   a.g("attention/W1/kernel"), a.g("attention/W1/bias"), fb[0], B * R, D, A, 0.2)
+        else:
+            be.act_bwd(self.Ppre, self.dP, self.dP, B * R * A, ACT_LEAKY, 0.2)
+            self.gemm_sk(self.F, self.dP, a.g("attention/W1/kernel"), D, A, B * R, D, A, A, transA=True)
+            be.colsum(self.dP, a.g("attention/W1/bias"), B * R, A, A, self.work)
+            self.gemm_sk(self.dP, a.p("attention/W1/kernel"), self.dF, B * R, D, A, A, A, D, transB=True, accumulate=True)
         # encoder
         S = self.S
         Bs = B // S

@@ -221,6 +221,13 @@ class HipBackend:
     def dense_dw_skinny(self, x, dpre, dw, N, E, Bk, ldx):
         self._call(self.lib.tnt_dense_dw_skinny_f32, "tnt_dense_dw_skinny_f32", _p(x), _p(dpre), _p(dw), N, E, Bk, ldx, self._s())
 
+    def attention_front_bwd_parts(self, rows, D, A):
+        return int(self.lib.tnt_attention_front_bwd_parts(rows, D, A))
+
+    def attention_front_bwd(self, Ppre, dP, F, W1, dF, dW1, db1, part, rows, D, A, slope=0.2):
+        self._call(self.lib.tnt_attention_front_bwd_f32, "tnt_attention_front_bwd_f32", _p(Ppre), _p(dP), _p(F), _p(W1), _p(dF),
+                   _p(dW1), _p(db1), _p(part), rows, D, A, slope, self._s())
+
     def gemm_lt(self, A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None):
         self._call(self.lib.tnt_gemm_lt_f32, "tnt_gemm_lt_f32", _p(A), _p(B), _p(C), _p(bias), M, N, K, lda, ldb, ldc, int(transA),
                    int(transB), self._s())

@@ -251,6 +251,18 @@ class MockBackend:
         flat(dz)[:B * U * 4] = out.reshape(-1)
         flat(dc_prev)[:B * U] = (dcr * gf).reshape(-1)
 
+    def attention_front_bwd_parts(self, rows, D, A):
+        return 1
+
+    def attention_front_bwd(self, Ppre, dP, F, W1, dF, dW1, db1, part, rows, D, A, slope=0.2):
+        pre = mat(Ppre, rows, A, A).astype(np.float64)
+        g = mat(dP, rows, A, A).astype(np.float64) * np.where(pre > 0, 1.0, slope)
+        Fm = mat(F, rows, D, D).astype(np.float64)
+        W = flat(W1)[:D * A].reshape(D, A).astype(np.float64)
+        flat(db1)[:A] = g.sum(0)
+        flat(dW1)[:D * A] = (Fm.T @ g).reshape(-1)
+        mat(dF, rows, D, D)[...] += g @ W.T
+
     def colsum2(self, x0, out0, rows0, C0, ld0, x1, out1, rows1, C1, ld1):
         self.colsum(x0, out0, rows0, C0, ld0, None)
         self.colsum(x1, out1, rows1, C1, ld1, None)

@@ -1375,3 +1375,25 @@ def test_gemm_lt(be, M, N, K, tA, tB, pad, bias):
         C2 = torch.full((M, ldc), 7.0, device="cuda")
         be.gemm_lt(Ad, Bd, C2, M, N, K, lda, ldb, ldc, bool(tA), bool(tB), bias=bd)
         assert torch.equal(Cd, C2)
+
+
+@pytest.mark.parametrize("rows,D,A", [(23040, 32, 32), (300, 32, 32), (129, 32, 32), (5, 32, 32)])
+def test_attention_front_bwd(be, rows, D, A):
+    """tnt_attention_front_bwd_f32 (LeakyReLU' + bias gradient + W1 gradient + dF contribution of the attention layer's
+    hoisted Dense: one launch of row-chunk reducers + row updaters, one finalize) against float64; repeated launches
+    bit-identical (fixed summation order)."""
+    rng = np.random.default_rng(rows + D)
+    pre, dP, F = rng.standard_normal((rows, A)), rng.standard_normal((rows, A)) * 0.1, rng.standard_normal((rows, D))
+    W1, dF0 = rng.standard_normal((D, A)) * 0.3, rng.standard_normal((rows, D)) * 0.1
+    g = dP * np.where(pre > 0, 1.0, 0.2)
+    part = torch.zeros(be.attention_front_bwd_parts(rows, D, A), device="cuda")
+    outs = []
+    for rep in range(3):
+        dF, dW1, db1 = dev(dF0), torch.full((D, A), 7.0, device="cuda"), torch.full((A,), 7.0, device="cuda")
+        be.attention_front_bwd(dev(pre), dev(dP), dev(F), dev(W1), dF, dW1, db1, part, rows, D, A, 0.2)
+        torch.cuda.synchronize()
+        outs.append((dF, dW1, db1))
+    dF, dW1, db1 = outs[0]
+    close(dW1, F.T @ g, rtol=2e-5); close(db1, g.sum(0), rtol=2e-5); close(dF, dF0 + g @ W1.T, rtol=1e-5)
+    for o in outs[1:]:
+        assert all(torch.equal(x, y) for x, y in zip(outs[0], o))
