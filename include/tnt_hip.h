@@ -113,6 +113,15 @@ int32_t tnt_dropout_f32(const float* x, float* y, int32_t rows, int32_t cols, in
 /* ---- activation backward: dx = dy * act'(pre)  ---------------------------------- */
 int32_t tnt_act_bwd_f32(const float* pre, const float* dy, float* dx, int64_t n, int32_t act,
                         float slope, void* stream);
+/* Backward of y = Dropout(act(pre)) of a layer applied to rows <= 2048 rows, up to its bias gradient, in one launch:
+ * dx = dropout'(dy) * act'(pre) (dx may alias dy), dbias[c] = sum_r dx[r][c].  The dropout stream / logical layout
+ * arguments are those of tnt_dropout_f32 for the forward's mask (rate 0: no dropout).  cols, ld, lwidth, lcol0 % 4 == 0,
+ * 16-byte aligned.  Optional second job in the same launch: out1 = column sums of x1 [rows1 <= 2048][C1] (x1 NULL: none).
+ * (TimeDistributed(Dense) + Dropout of the caption head, lc_NIC.py:271-275, and its bias gradients.) */
+int32_t tnt_bias_act_drop_bwd_f32(const float* dy, const float* pre, float* dx, float* dbias, int32_t rows, int32_t cols,
+                                  int32_t ld, int32_t act, float slope, int32_t tmajor_B, int32_t lwidth, int32_t lcol0,
+                                  float rate, uint64_t seed, uint32_t site, const uint32_t* step_dev, const float* x1,
+                                  float* out1, int32_t rows1, int32_t C1, int32_t ld1, void* stream);
 
 /* ---- BatchNormalization, axis=-1, non-fused keras semantics ---------------------
  * (layers.py:40,50; NIC.py:62,128; fullyConnected.py:18,24)
@@ -231,7 +240,11 @@ int32_t tnt_layernorm_bwd_f32(const float* dy, const float* xhat, const float* g
  * work: C*tnt_bn_nchunk(rows) floats. */
 int32_t tnt_colsum_f32(const float* x, float* out, int32_t rows, int32_t C, int32_t ld,
                        float* work, void* stream);
-/* two independent matrices of <= 2048 rows each in one launch (same results as two tnt_colsum_f32 calls) */
+/* two / up to four independent matrices of <= 2048 rows each in one launch (same results as separate tnt_colsum_f32
+ * calls; in tnt_colsum4_f32 a job with x == NULL is skipped) */
+int32_t tnt_colsum4_f32(const float* x0, float* out0, int32_t rows0, int32_t C0, int32_t ld0, const float* x1, float* out1,
+                        int32_t rows1, int32_t C1, int32_t ld1, const float* x2, float* out2, int32_t rows2, int32_t C2,
+                        int32_t ld2, const float* x3, float* out3, int32_t rows3, int32_t C3, int32_t ld3, void* stream);
 int32_t tnt_colsum2_f32(const float* x0, float* out0, int32_t rows0, int32_t C0, int32_t ld0, const float* x1,
                         float* out1, int32_t rows1, int32_t C1, int32_t ld1, void* stream);
 

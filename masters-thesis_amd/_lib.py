@@ -32,7 +32,9 @@ SIGNATURES = {
     "tnt_layernorm_fwd_f32": [P, P, P, P, P, P, I32, I32, I32, F32, P],
     "tnt_layernorm_bwd_f32": [P, P, P, P, P, P, P, I32, I32, I32, P, P],
     "tnt_colsum_f32": [P, P, I32, I32, I32, P, P],
+    "tnt_bias_act_drop_bwd_f32": [P, P, P, P, I32, I32, I32, I32, F32, I32, I32, I32, F32, U64, U32, P, P, P, I32, I32, I32, P],
     "tnt_colsum2_f32": [P, P, I32, I32, I32, P, P, I32, I32, I32, P],
+    "tnt_colsum4_f32": [P, P, I32, I32, I32, P, P, I32, I32, I32, P, P, I32, I32, I32, P, P, I32, I32, I32, P],
     "tnt_embedding_fwd_f32": [P, P, P, I32, I32, I32, I32, I32, P],
     "tnt_embedding_bwd_parts": [I32, I32, I32],
     "tnt_attention_front_bwd_parts": [I32, I32, I32],

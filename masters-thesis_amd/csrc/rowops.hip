@@ -758,18 +758,21 @@ __global__ __launch_bounds__(1024) void col_sum_direct_kernel(const float* x, in
   }
 }
 
-// two independent short matrices in one launch (the head-bias and LSTM-bias gradients of a step): blocks [0, nb0) work
-// on the first, the rest on the second -- one dependent launch less in the captured step
-__global__ __launch_bounds__(1024) void col_sum_direct2_kernel(const float* x0, int ld0, int rows0, int C0, float* out0,
-                                                               int nb0, const float* x1, int ld1, int rows1, int C1,
-                                                               float* out1) {
+// up to four independent short matrices in one launch (bias gradients that become final at the same point of a step):
+// job j owns the blocks [first[j], first[j+1]) -- one dependent launch instead of up to four in the captured step
+struct ColJobs { const float* x[4]; float* out[4]; int ld[4], rows[4], C[4], first[5]; };
+
+__global__ __launch_bounds__(1024) void col_sum_multi_kernel(ColJobs j) {
   __shared__ float sh[32][33];
-  const bool second = (int)blockIdx.x >= nb0;
-  const float* x = second ? x1 : x0;
-  float* out = second ? out1 : out0;
-  const int ld = second ? ld1 : ld0, rows = second ? rows1 : rows0, C = second ? C1 : C0;
+  int q = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) q += (int)blockIdx.x >= j.first[k] ? 1 : 0;
+  const float* x = j.x[0]; float* out = j.out[0]; int ld = j.ld[0], rows = j.rows[0], C = j.C[0], b0 = j.first[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (q == k) { x = j.x[k]; out = j.out[k]; ld = j.ld[k]; rows = j.rows[k]; C = j.C[k]; b0 = j.first[k]; }
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = (blockIdx.x - (second ? nb0 : 0)) * 32 + cl;
+  const int c = (blockIdx.x - b0) * 32 + cl;
   float v = 0.f;
   if (c < C) {
 #pragma unroll 8
@@ -780,17 +783,126 @@ __global__ __launch_bounds__(1024) void col_sum_direct2_kernel(const float* x0, 
   if (rl == 0 && c < C) {
     float t = 0.f;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) t += sh[j][cl];
+    for (int k = 0; k < 32; ++k) t += sh[k][cl];
     out[c] = t;
   }
 }
 
+extern "C" int32_t tnt_colsum4_f32(const float* x0, float* out0, int32_t rows0, int32_t C0, int32_t ld0, const float* x1,
+                                   float* out1, int32_t rows1, int32_t C1, int32_t ld1, const float* x2, float* out2,
+                                   int32_t rows2, int32_t C2, int32_t ld2, const float* x3, float* out3, int32_t rows3,
+                                   int32_t C3, int32_t ld3, void* stream) {
+  ColJobs j{};
+  const float* xs[4] = {x0, x1, x2, x3}; float* outs[4] = {out0, out1, out2, out3};
+  const int rs[4] = {rows0, rows1, rows2, rows3}, cs[4] = {C0, C1, C2, C3}, lds[4] = {ld0, ld1, ld2, ld3};
+  int nb = 0;
+  for (int k = 0; k < 4; ++k) {          // unused jobs (x == NULL) get an empty block range
+    j.first[k] = nb;
+    j.x[k] = xs[k]; j.out[k] = outs[k]; j.ld[k] = lds[k]; j.rows[k] = rs[k]; j.C[k] = cs[k];
+    if (xs[k] == nullptr) continue;
+    if (rs[k] <= 0 || cs[k] <= 0 || rs[k] > 2048 || outs[k] == nullptr) return TNT_BADARG(2 + 5 * k);
+    nb += (cs[k] + 31) / 32;
+  }
+  j.first[4] = nb;
+  if (nb == 0) return 0;
+  // an empty job must not capture blocks: give it the start of the next job (q counts first[k] <= block)
+  for (int k = 3; k >= 0; --k) if (xs[k] == nullptr) j.first[k] = j.first[k + 1];
+  hipLaunchKernelGGL(col_sum_multi_kernel, dim3(nb), dim3(1024), 0, tnt_stream(stream), j);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int32_t tnt_colsum2_f32(const float* x0, float* out0, int32_t rows0, int32_t C0, int32_t ld0, const float* x1,
                                    float* out1, int32_t rows1, int32_t C1, int32_t ld1, void* stream) {
-  if (rows0 <= 0 || C0 <= 0 || rows1 <= 0 || C1 <= 0 || rows0 > 2048 || rows1 > 2048) return TNT_BADARG(2);
-  const int nb0 = (C0 + 31) / 32, nb1 = (C1 + 31) / 32;
-  hipLaunchKernelGGL(col_sum_direct2_kernel, dim3(nb0 + nb1), dim3(1024), 0, tnt_stream(stream), x0, ld0, rows0, C0, out0, nb0,
-                     x1, ld1, rows1, C1, out1);
+  if (x0 == nullptr || x1 == nullptr) return TNT_BADARG(0);
+  return tnt_colsum4_f32(x0, out0, rows0, C0, ld0, x1, out1, rows1, C1, ld1, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0,
+                         0, stream);
+}
+
+// ---- backward of  y = Dropout(act(pre)),  pre = x W + b  up to the bias gradient, for a layer applied to T*B <= 2048 rows
+// (TimeDistributed(Dense) + Dropout of the caption head, lc_NIC.py:271-275): dx = dropout'(dy) * act'(pre) in place of a
+// dropout launch + an act_bwd launch, and db = column sums of dx in the same pass instead of a third launch.  A workgroup
+// owns 32 columns (8 column quads x 128 row lanes: float4 loads, one Philox call per 4 elements).  A second, independent
+// column-sum job (x1 -> out1: another layer's bias gradient that is final at the same point) rides in the same launch.
+struct BadArgs {
+  DropArgs d;              // x = dy, y = dx, rows, cols, ld, logical layout + stream of the forward's dropout (rate 0: none)
+  const float* pre; float* dbias; int act; float slope; int nb0;
+  const float* x1; float* out1; int rows1, C1, ld1;
+};
+
+__global__ __launch_bounds__(1024) void bias_act_drop_bwd_kernel(BadArgs a) {
+  __shared__ float4 red[128][9];
+  __shared__ float sh[32][33];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= a.nb0) {          // plain column sums of the second job: 32 columns x 32 row lanes
+    const int cl = tid & 31, rl = tid >> 5, c = (blockIdx.x - a.nb0) * 32 + cl;
+    float v = 0.f;
+    if (c < a.C1) {
+#pragma unroll 8
+      for (int r = rl; r < a.rows1; r += 32) v += a.x1[(long)r * a.ld1 + c];
+    }
+    sh[rl][cl] = v;
+    __syncthreads();
+    if (rl == 0 && c < a.C1) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) t += sh[k][cl];
+      a.out1[c] = t;
+    }
+    return;
+  }
+  const DropArgs& d = a.d;
+  const uint32_t step = d.step + (d.step_dev ? d.step_dev[0] : 0u);
+  const int cq = tid & 7, rl = tid >> 3, c = blockIdx.x * 32 + cq * 4;       // 8 column quads x 128 row lanes
+  const int T = d.tB > 0 ? d.rows / d.tB : 0;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < d.cols) {
+    for (int r = rl; r < d.rows; r += 128) {
+      const long o = (long)r * d.ld + c;
+      float4 v = *reinterpret_cast<const float4*>(d.x + o);
+      if (d.rate > 0.f) {
+        long lrow; uint32_t site;
+        drop_row(d, r, T, lrow, site);
+        bool k[4];
+        tnt_keep4((uint64_t)lrow * (uint64_t)d.lwidth + (uint64_t)(d.lcol0 + c), d.rate, d.seed, site, step, k);
+        v.x = k[0] ? v.x * d.scale : 0.f; v.y = k[1] ? v.y * d.scale : 0.f;
+        v.z = k[2] ? v.z * d.scale : 0.f; v.w = k[3] ? v.w * d.scale : 0.f;
+      }
+      const float4 p = *reinterpret_cast<const float4*>(a.pre + o);
+      v = make_float4(tnt_act_grad(p.x, v.x, a.act, a.slope), tnt_act_grad(p.y, v.y, a.act, a.slope),
+                      tnt_act_grad(p.z, v.z, a.act, a.slope), tnt_act_grad(p.w, v.w, a.act, a.slope));
+      *reinterpret_cast<float4*>(d.y + o) = v;
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  red[rl][cq] = acc;
+  __syncthreads();
+  if (rl == 0 && c < d.cols) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int k = 0; k < 128; ++k) { const float4 u = red[k][cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    *reinterpret_cast<float4*>(a.dbias + c) = t;
+  }
+}
+
+extern "C" int32_t tnt_bias_act_drop_bwd_f32(const float* dy, const float* pre, float* dx, float* dbias, int32_t rows,
+                                             int32_t cols, int32_t ld, int32_t act, float slope, int32_t tmajor_B,
+                                             int32_t lwidth, int32_t lcol0, float rate, uint64_t seed, uint32_t site,
+                                             const uint32_t* step_dev, const float* x1, float* out1, int32_t rows1,
+                                             int32_t C1, int32_t ld1, void* stream) {
+  if (rows <= 0 || cols <= 0 || rows > 2048 || ((cols | ld | lwidth | lcol0) & 3) != 0) return TNT_BADARG(4);
+  if (!tnt_aligned16(dy) || !tnt_aligned16(pre) || !tnt_aligned16(dx) || !tnt_aligned16(dbias)) return TNT_BADARG(1);
+  if (tmajor_B > 0 && rows % tmajor_B != 0) return TNT_BADARG(9);
+  if (rate < 0.f || rate >= 1.f) return TNT_BADARG(12);
+  if (x1 != nullptr && (rows1 <= 0 || C1 <= 0 || rows1 > 2048 || out1 == nullptr)) return TNT_BADARG(18);
+  BadArgs a{};
+  a.d.x = dy; a.d.y = dx; a.d.rows = rows; a.d.cols = cols; a.d.ld = ld; a.d.tB = tmajor_B; a.d.lwidth = lwidth;
+  a.d.lcol0 = lcol0; a.d.rows_per_site = 0; a.d.rate = rate; a.d.scale = 1.0f / (1.0f - rate); a.d.seed = seed;
+  a.d.site = site; a.d.step = 0; a.d.step_dev = step_dev;
+  a.pre = pre; a.dbias = dbias; a.act = act; a.slope = slope; a.nb0 = (cols + 31) / 32;
+  a.x1 = x1; a.out1 = out1; a.rows1 = rows1; a.C1 = C1; a.ld1 = ld1;
+  const int nb1 = x1 ? (C1 + 31) / 32 : 0;
+  hipLaunchKernelGGL(bias_act_drop_bwd_kernel, dim3(a.nb0 + nb1), dim3(1024), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
 }

@@ -555,13 +555,21 @@ class NIC(ModelBase):
         sd, ds = self.seed, self.drop_step
         dlog, inter, hs = self.logits, self._inter_used, self._hs_used
         self.gemm_sk(inter, dlog, a.g("time_distributed_softmax/kernel"), H, V, n, H, ldV, ldV, transA=True)
-        be.colsum(dlog, a.g("time_distributed_softmax/bias"), n, V, ldV, self.work)
         self.gemm_sk(dlog, a.p("time_distributed_softmax/kernel"), self.dinter, n, H, V, ldV, ldV, H, transB=True)
-        if self.r_out > 0:
-            be.dropout(self.dinter, self.dinter, n, H, H, B, H, 0, self.r_out, sd, S_OUT, 0, ds)
-        be.act_bwd(self.ipre, self.dinter, self.dinter, n * H, ACT_LEAKY, 0.2)
-        self.gemm_sk(hs, self.dinter, a.g("time_distributed_nonlinear/kernel"), U, H, n, U, H, H, transA=True)
-        be.colsum(self.dinter, a.g("time_distributed_nonlinear/bias"), n, H, H, self.work)
+        if getattr(self, "fused_head_tail", True) and hasattr(be, "bias_act_drop_bwd") and n <= 2048 and H % 4 == 0:
+            # dropout' + LeakyReLU' + the nonlinear layer's bias gradient in one pass over dinter, with the softmax layer's
+            # bias gradient (column sums of dlogits) riding in the same launch: 1 launch instead of 4
+            be.bias_act_drop_bwd(self.dinter, self.ipre, self.dinter, a.g("time_distributed_nonlinear/bias"), n, H, H,
+                                 ACT_LEAKY, 0.2, B, H, 0, self.r_out, sd, S_OUT, ds,
+                                 extra=(dlog, a.g("time_distributed_softmax/bias"), n, V, ldV))
+            self.gemm_sk(hs, self.dinter, a.g("time_distributed_nonlinear/kernel"), U, H, n, U, H, H, transA=True)
+        else:
+            be.colsum(dlog, a.g("time_distributed_softmax/bias"), n, V, ldV, self.work)
+            if self.r_out > 0:
+                be.dropout(self.dinter, self.dinter, n, H, H, B, H, 0, self.r_out, sd, S_OUT, 0, ds)
+            be.act_bwd(self.ipre, self.dinter, self.dinter, n * H, ACT_LEAKY, 0.2)
+            self.gemm_sk(hs, self.dinter, a.g("time_distributed_nonlinear/kernel"), U, H, n, U, H, H, transA=True)
+            be.colsum(self.dinter, a.g("time_distributed_nonlinear/bias"), n, H, H, self.work)
         self.gemm_sk(self.dinter, a.p("time_distributed_nonlinear/kernel"), self.dHs, n, U, H, H, H, U, transB=True)
         if self.r_lstm > 0:
             be.dropout(self.dHs, self.dHs, n, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds, rows_per_site=B)
@@ -671,9 +679,13 @@ class NIC(ModelBase):
         hprev = self.Hs[:T].view(n, U)
         # attention parameters
         self.gemm_sk(hprev, self.dqpre, a.g("attention/W2/kernel"), U, A, n, U, A, A, transA=True)
-        be.colsum(self.dqpre, a.g("attention/W2/bias"), n, A, A, self.work)
-        be.colsum(self.dvb, a.g("attention/V/kernel"), B, A, A + 1, self.work)
-        be.colsum(self.dvb.view(-1)[A:], a.g("attention/V/bias"), B, 1, A + 1, self.work)
+        jobs = [(self.dqpre, a.g("attention/W2/bias"), n, A, A), (self.dvb, a.g("attention/V/kernel"), B, A, A + 1),
+                (self.dvb.view(-1)[A:], a.g("attention/V/bias"), B, 1, A + 1)]
+        if hasattr(be, "colsum_multi") and n <= 2048 and B <= 2048:
+            be.colsum_multi(jobs)                     # the three small bias-type gradients of the attention layer: one launch
+        else:
+            for x, out, rows, C, ld in jobs:
+                be.colsum(x, out, rows, C, ld, self.work)
         if getattr(self, "fused_att_front", True) and hasattr(be, "attention_front_bwd") and D == 32 and A == 32:
             # LeakyReLU' + bias gradient + W1 gradient + the dF contribution of the hoisted Dense in two launches instead of five
             fb = self.__dict__.get("_att_fb")

@@ -83,6 +83,14 @@ class HipBackend:
         self._call(self.lib.tnt_dropout_mask4_u8, "tnt_dropout_mask4_u8", _p(out), n, nsites, rate, int(seed), int(site0), int(step), _p(step_dev),
                    self._s())
 
+    def bias_act_drop_bwd(self, dy, pre, dx, dbias, rows, cols, ld, act, slope, tmajor_B, lwidth, lcol0, rate, seed, site,
+                          step_dev=None, extra=None):
+        """dx = dropout'(dy) * act'(pre), dbias = column sums of dx; ``extra`` = (x1, out1, rows1, C1, ld1) second colsum job"""
+        x1, out1, rows1, C1, ld1 = extra if extra is not None else (None, None, 0, 0, 0)
+        self._call(self.lib.tnt_bias_act_drop_bwd_f32, "tnt_bias_act_drop_bwd_f32", _p(dy), _p(pre), _p(dx), _p(dbias), rows, cols,
+                   ld, act, slope, tmajor_B, lwidth, lcol0, rate, int(seed), int(site), _p(step_dev), _p(x1), _p(out1), rows1,
+                   C1, ld1, self._s())
+
     def act_bwd(self, pre, dy, dx, n, act, slope=0.2):
         self._call(self.lib.tnt_act_bwd_f32, "tnt_act_bwd_f32", _p(pre), _p(dy), _p(dx), n, act, slope, self._s())
 
@@ -103,6 +111,14 @@ class HipBackend:
     def layernorm_bwd(self, dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, work):
         self._call(self.lib.tnt_layernorm_bwd_f32, "tnt_layernorm_bwd_f32", _p(dy), _p(xhat), _p(gamma), _p(inv_std), _p(dx), _p(dgamma),
                                                   _p(dbeta), rows, C, lddy, _p(work), self._s())
+
+    def colsum_multi(self, jobs):
+        """jobs: up to four (x, out, rows, C, ld) column-sum jobs of <= 2048 rows each, one launch"""
+        args = []
+        for k in range(4):
+            x, out, rows, C, ld = jobs[k] if k < len(jobs) else (None, None, 0, 0, 0)
+            args += [_p(x), _p(out), rows, C, ld]
+        self._call(self.lib.tnt_colsum4_f32, "tnt_colsum4_f32", *args, self._s())
 
     def colsum2(self, x0, out0, rows0, C0, ld0, x1, out1, rows1, C1, ld1):
         self._call(self.lib.tnt_colsum2_f32, "tnt_colsum2_f32", _p(x0), _p(out0), rows0, C0, ld0, _p(x1), _p(out1), rows1, C1, ld1,

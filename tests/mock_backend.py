@@ -263,6 +263,24 @@ class MockBackend:
         flat(dW1)[:D * A] = (Fm.T @ g).reshape(-1)
         mat(dF, rows, D, D)[...] += g @ W.T
 
+    def bias_act_drop_bwd(self, dy, pre, dx, dbias, rows, cols, ld, act, slope, tmajor_B, lwidth, lcol0, rate, seed, site,
+                          step_dev=None, extra=None):
+        tmp = torch.zeros(rows, cols, dtype=torch.float32)
+        tmp.copy_(torch.as_strided(dy, (rows, cols), (ld, 1)))
+        if rate > 0:
+            self.dropout(tmp, tmp, rows, cols, cols, tmajor_B, lwidth, lcol0, rate, seed, site, 0, step_dev)
+        p = torch.zeros(rows, cols, dtype=torch.float32)
+        p.copy_(torch.as_strided(pre, (rows, cols), (ld, 1)))
+        self.act_bwd(p, tmp, tmp, rows * cols, act, slope)
+        torch.as_strided(dx, (rows, cols), (ld, 1)).copy_(tmp)
+        self.colsum(tmp, dbias, rows, cols, cols, None)
+        if extra is not None:
+            self.colsum(*extra, None)
+
+    def colsum_multi(self, jobs):
+        for x, out, rows, C, ld in jobs:
+            self.colsum(x, out, rows, C, ld, None)
+
     def colsum2(self, x0, out0, rows0, C0, ld0, x1, out1, rows1, C1, ld1):
         self.colsum(x0, out0, rows0, C0, ld0, None)
         self.colsum(x1, out1, rows1, C1, ld1, None)

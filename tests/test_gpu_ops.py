@@ -1397,3 +1397,39 @@ def test_attention_front_bwd(be, rows, D, A):
     close(dW1, F.T @ g, rtol=2e-5); close(db1, g.sum(0), rtol=2e-5); close(dF, dF0 + g @ W1.T, rtol=1e-5)
     for o in outs[1:]:
         assert all(torch.equal(x, y) for x, y in zip(outs[0], o))
+
+
+@pytest.mark.parametrize("T,B,C,rate,V", [(15, 64, 256, 0.2, 5001), (3, 5, 8, 0.0, 0), (7, 9, 36, 0.5, 33)])
+def test_bias_act_drop_bwd_and_colsum_multi(be, T, B, C, rate, V):
+    """tnt_bias_act_drop_bwd_f32 against the launches it replaces (dropout -> act_bwd -> colsum, + the riding colsum job),
+    identical dropout pattern; tnt_colsum4_f32 against separate column sums, skipped jobs included."""
+    rng = np.random.default_rng(T * B + C)
+    rows = T * B
+    dy, pre = rng.standard_normal((rows, C)), rng.standard_normal((rows, C))
+    step_dev = torch.tensor([5], dtype=torch.int32, device="cuda")
+    ref = dev(dy).clone()
+    if rate > 0:
+        be.dropout(ref, ref, rows, C, C, B, C, 0, rate, 77, 13, 0, step_dev)
+    be.act_bwd(dev(pre), ref, ref, rows * C, 1, 0.2)
+    db_ref = torch.zeros(C, device="cuda")
+    be.colsum(ref, db_ref, rows, C, C, torch.zeros(4 * C + 64, device="cuda"))
+    x1 = rng.standard_normal((rows, V + 3)) if V else None
+    dx, db = dev(dy).clone(), torch.full((C,), 7.0, device="cuda")
+    out1 = torch.full((max(V, 1),), 7.0, device="cuda")
+    be.bias_act_drop_bwd(dx, dev(pre), dx, db, rows, C, C, 1, 0.2, B, C, 0, rate, 77, 13, step_dev,
+                         extra=(dev(x1), out1, rows, V, V + 3) if V else None)
+    assert torch.equal(dx, ref)
+    close(db, db_ref.cpu().numpy(), rtol=1e-5)
+    close(db, ref.cpu().double().numpy().sum(0), rtol=1e-5)
+    if V:
+        close(out1, x1[:, :V].sum(0), rtol=1e-5)
+    # colsum_multi: jobs 0 and 2 used through the 4-slot entry, with a hole
+    a_, b_ = rng.standard_normal((rows, C)), rng.standard_normal((B, 5))
+    oa, ob = torch.full((C,), 7.0, device="cuda"), torch.full((5,), 7.0, device="cuda")
+    ad, bd = dev(a_), dev(b_)
+    be._call(be.lib.tnt_colsum4_f32, "tnt_colsum4_f32", ad.data_ptr(), oa.data_ptr(), rows, C, C, None, None, 0, 0, 0,
+             bd.data_ptr(), ob.data_ptr(), B, 5, 5, None, None, 0, 0, 0, be._s())
+    close(oa, a_.sum(0), rtol=1e-5); close(ob, b_.sum(0), rtol=1e-5)
+    o1, o2, o3 = (torch.full((k,), 7.0, device="cuda") for k in (C, 5, 1))
+    be.colsum_multi([(ad, o1, rows, C, C), (bd, o2, B, 5, 5), (bd.view(-1)[4:], o3, B, 1, 5)])
+    close(o1, a_.sum(0), rtol=1e-5); close(o2, b_.sum(0), rtol=1e-5); close(o3, b_[:, 4:5].sum(0), rtol=1e-5)
