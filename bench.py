@@ -34,10 +34,14 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak
 # HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes), by call
 # group; filled from the summaries committed under profiles/ (None = not collected for that kernel)
+_PMC2 = "profiles/r02_pmc_seq_poll_and_encoder.txt"
 PMC_TRAFFIC = {
     "dense": {"tnt_gemm_f32 NN 960x5001x512": (int((2 * 13029.1 + 18885.8) * 1024), "profiles/r01_gemm_head_pmc_v3.txt"),
-              "tnt_lstm_seq_fwd_f32 S=16 B=64 U=512": (int((2 * 13424.4 + 14276.4) * 1024), "profiles/r02_lstm_seq_pmc.txt"),
-              "tnt_lstm_seq_bwd_f32 S=16 B=64 U=512": (int((2 * 18487.1 + 56852.5) * 1024), "profiles/r02_lstm_seq_pmc.txt")},
+              "tnt_lstm_seq_fwd_f32 S=16 B=64 U=512": (int((2 * 13420.2 + 14220.4) * 1024), _PMC2),
+              "tnt_lstm_seq_bwd_f32 S=16 B=64 U=512": (int((2 * 22179.7 + 127485.1) * 1024), _PMC2),
+              "tnt_dense_fwd_stream_gram_f32 64x512x20000": (int((2 * 22663.2 + 2305.0) * 1024), _PMC2),
+              "tnt_dense_dw_adam_f32 20000x512x64": (int((2 * 65998.5 + 120000.0) * 1024), _PMC2),
+              "tnt_dense_dw_skinny_f32 20000x512x64": (int((2 * 5568.5 + 40000.0) * 1024), _PMC2)},
     "attention": {"tnt_gemm_f32 NN 960x5001x256": (int((2 * 6575.1 + 18885.0) * 1024), "profiles/r01_gemm_head_c3_pmc.txt")},
 }
 STEP_GFLOP = {"dense": 30.3, "attention": 22.0}          # SURVEY 8d, whole training step
@@ -159,8 +163,9 @@ def _work_model(name, a):
     if name == "tnt_dense_dw_skinny_f32":
         Nq, Eq, Bk = a[3], a[4], a[5]
         return f"{name} {Nq}x{Eq}x{Bk}", 2.0 * Nq * Eq * Bk, 4.0 * (Nq * Eq + Bk * Nq + Bk * Eq)
-    if name == "tnt_dense_fwd_stream_f32":       # x, w, part, B, E, K, ...: streams the kernel once, writes nsplit partials
-        Bq, Eq, K, ns = a[3], a[4], a[5], a[8]
+    if name in ("tnt_dense_fwd_stream_f32", "tnt_dense_fwd_stream_gram_f32"):       # streams the kernel once, writes nsplit partials
+        o = 2 if name.endswith("gram_f32") else 0                                       # (+ gx_part, w2_part pointers)
+        Bq, Eq, K, ns = a[3 + o], a[4 + o], a[5 + o], a[8 + o]
         return f"{name} {Bq}x{Eq}x{K}", 2.0 * Bq * Eq * K, 4.0 * (K * Eq + Bq * K + ns * Bq * Eq)
     if name == "tnt_dense_dw_sqnorm_f32":        # the skinny product again, reading theta (norm of g + 2 l2 theta)
         Nq, Eq, Bk = a[6], a[7], a[8]
