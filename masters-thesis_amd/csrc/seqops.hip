@@ -196,11 +196,16 @@ __device__ __forceinline__ float4 emb_row4(const float* drows, int k, int B, int
   return v;
 }
 
-__global__ __launch_bounds__(256) void emb_bwd_sparse_kernel(const float* drows, const int* ids, const int* prev_ids,
-                                                             float* dtable, float* sq_part, int B, int T, int E, int ldd,
-                                                             int V, EmbDrop drop) {
-  __shared__ float4 part[4][64];
-  __shared__ float sqw[4];
+constexpr int EBS_W = 16;            // waves per workgroup = ways the duplicate list of an id is split
+
+__global__ __launch_bounds__(64 * EBS_W) void emb_bwd_sparse_kernel(const float* drows, const int* ids, const int* prev_ids,
+                                                                    float* dtable, float* sq_part, int B, int T, int E,
+                                                                    int ldd, int V, EmbDrop drop) {
+  // The critical path of this launch is the owner of the most frequent id (the padding id: ~400 of 960 rows in a caption
+  // batch): its row sum is split 16 ways (4 ways cost 9 us for that one workgroup, 2 ways 17).
+  constexpr int NT = 64 * EBS_W;
+  __shared__ float4 part[EBS_W][64];
+  __shared__ float sqw[EBS_W];
   __shared__ int s_flag;
   const int n = B * T, ny = gridDim.y;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -213,8 +218,8 @@ __global__ __launch_bounds__(256) void emb_bwd_sparse_kernel(const float* drows,
     const int k = blockIdx.x - n;
     const int id = prev_ids[k];
     if (id < 0 || id >= V) return;
-    for (int i = threadIdx.x; i < k; i += 256) if (prev_ids[i] == id) s_flag = 1;          // an earlier entry handles it
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = threadIdx.x; i < k; i += NT) if (prev_ids[i] == id) s_flag = 1;           // an earlier entry handles it
+    for (int i = threadIdx.x; i < n; i += NT) {
       int cur = ids[i];
       cur = cur < 0 ? 0 : (cur >= V ? V - 1 : cur);
       if (cur == id) s_flag = 1;                                                            // rewritten by its owner
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(256) void emb_bwd_sparse_kernel(const float* drows,
   const int k = blockIdx.x;
   int id = ids[k];
   id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-  for (int i = threadIdx.x; i < k; i += 256) {           // an earlier occurrence owns the row
+  for (int i = threadIdx.x; i < k; i += NT) {            // an earlier occurrence owns the row
     int other = ids[i];
     other = other < 0 ? 0 : (other >= V ? V - 1 : other);
     if (other == id) s_flag = 1;
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256) void emb_bwd_sparse_kernel(const float* drows,
     sq = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
   }
   constexpr int NF = 8;
-  for (int base = k + 1 + 64 * w; base < n; base += 256) {
+  for (int base = k + 1 + 64 * w; base < n; base += NT) {
     const int i = base + lane;
     int other = i < n ? ids[i] : -1;
     other = other >= V ? V - 1 : other;
@@ -273,11 +278,17 @@ __global__ __launch_bounds__(256) void emb_bwd_sparse_kernel(const float* drows,
   if (lane == 0) sqw[w] = sq;
   __syncthreads();
   if (w == 0 && jok) {
-    const float4 a = part[0][lane], b = part[1][lane], c = part[2][lane], d = part[3][lane];
-    *reinterpret_cast<float4*>(dtable + (long)id * E + j) =
-        make_float4(((a.x + b.x) + c.x) + d.x, ((a.y + b.y) + c.y) + d.y, ((a.z + b.z) + c.z) + d.z, ((a.w + b.w) + c.w) + d.w);
+    float4 t = part[0][lane];
+#pragma unroll
+    for (int q = 1; q < EBS_W; ++q) { const float4 u = part[q][lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    *reinterpret_cast<float4*>(dtable + (long)id * E + j) = t;
   }
-  if (threadIdx.x == 0) sq_part[(long)k * ny + blockIdx.y] = ((sqw[0] + sqw[1]) + sqw[2]) + sqw[3];
+  if (threadIdx.x == 0) {
+    float t = sqw[0];
+#pragma unroll
+    for (int q = 1; q < EBS_W; ++q) t += sqw[q];
+    sq_part[(long)k * ny + blockIdx.y] = t;
+  }
 }
 
 __global__ __launch_bounds__(1024) void sum_accum_kernel(const float* x, float* out, int n) {
@@ -721,8 +732,8 @@ extern "C" int32_t tnt_embedding_bwd_sparse_f32(const float* drows, const int32_
   if (prev_ids == nullptr || sq_part == nullptr || prev_ids == ids) return TNT_BADARG(3);
   if (drop_rate < 0.f || drop_rate >= 1.f) return TNT_BADARG(11);
   const EmbDrop drop{drop_rate, 1.0f / (1.0f - drop_rate), drop_seed, drop_site, drop_step_dev};
-  hipLaunchKernelGGL(emb_bwd_sparse_kernel, dim3(2 * B * T, (E + 255) / 256), dim3(256), 0, tnt_stream(stream), drows, ids,
-                     prev_ids, dtable, sq_part, B, T, E, ldd, V, drop);
+  hipLaunchKernelGGL(emb_bwd_sparse_kernel, dim3(2 * B * T, (E + 255) / 256), dim3(64 * EBS_W), 0, tnt_stream(stream), drows,
+                     ids, prev_ids, dtable, sq_part, B, T, E, ldd, V, drop);
   TNT_LAUNCH_CHECK();
   return 0;
 }
