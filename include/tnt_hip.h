@@ -565,6 +565,20 @@ int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* F, const fl
                                    const float* dctx_part, int32_t nparts, const uint8_t* keep4,
                                    float alpha_mse_coef, void* stream);
 
+/* ---- the forward chain of the attention captioner as ONE persistent launch (lc_NIC.py:244-256): for i < T:
+ * tnt_attention_step_fwd_f32(h = hs[i], ..., qpre[i], alpha[i], ctx[i], ctx_d[i], keep4 + i * keep_stride, sites + i) then
+ * tnt_lstm_step_fwd_f32(xz[i], hs[i], cs[i], Ur, ctx_d[i], Wc, ... -> hs[i+1], cs[i+1], gates[i]) with xz_bias.
+ * hs / cs [T+1][B][U] (slab 0 = initial state), xz [T][B][U][4], qpre [T][B][A], alpha [T][B][R], ctx / ctx_d [T][B][D],
+ * gates [T][B][U][4].  U == 512, B <= 128, R <= 512, A % 4 == D % 4 == 0, A, D <= 64, the device census of
+ * tnt_lstm_seq_supported.  sync / guard_out: as tnt_lstm_seq_fwd_f32 (same state words). */
+int32_t tnt_lc_seq_fwd_f32(const float* F, const float* P, const float* W2, const float* b2, const float* v,
+                           const float* bv, float* qpre, float* alpha, float* ctx, float* ctx_d, const uint8_t* keep4,
+                           int64_t keep_stride, const float* xz, const float* Wc, const float* Ur, const float* xz_bias,
+                           float* hs, float* cs, float* gates, int32_t T, int32_t B, int32_t R, int32_t D, int32_t A,
+                           int32_t U, float slope, float rate_attn, float rate_in, int32_t in_lwidth, uint64_t seed,
+                           uint32_t site_attn0, uint32_t site_in0, const uint32_t* step_dev, uint32_t* sync,
+                           float* guard_out, void* stream);
+
 /* ---- the attention layer's hoisted first Dense (P = LeakyReLU(F W1 + b1), attention.py:32) backward, behind the chain:
  * with dP [rows][A] the score gradient accumulated over the T steps and Ppre its pre-activation:
  *   g = dP * LeakyReLU'(Ppre, slope);  db1 = column sums of g;  dW1 [D][A] = F^T g;  dF [rows][D] += g W1^T

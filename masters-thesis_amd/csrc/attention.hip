@@ -354,20 +354,33 @@ __device__ __forceinline__ float adj_sum(float v) {
 }
 
 // G4 = A/4 (= D/4 after padding to the larger of the two): lanes per row
-template <int G4>
-__global__ __launch_bounds__(WT) void attention_fwd_wide_kernel(AttArgs g) {
+// LDS of one attention forward step (shared by the per-step kernel and the persistent chain kernel)
+struct AttFwdLds {
+  float* hs;                 // [MAXU] the sample's h, 16-byte aligned
+  float* es;                 // [MAXR]
+  float (*wred)[64];         // [WW][64], 16-byte aligned
+  float* qs;                 // [64], 16-byte aligned
+  float* red;                // [WW]
+};
+
+// One attention forward step of sample b, h already in l.hs (and a workgroup barrier behind it).  PERSIST: the caller is the
+// persistent chain kernel, whose consumers poll ctx_d for a sentinel -- the thread that publishes ctx_d[b][tid] drains its
+// earlier stores (its reset of the NEXT step's element) first.
+template <int G4, bool PERSIST, int NP = MAXP>        // NP: row passes held in registers (R <= NP * WT / G4)
+__device__ __forceinline__ void att_fwd_body(const AttArgs& g, int b, const AttFwdLds& l, int si = 0, long keep_stride = 0) {
   constexpr int RPP = WT / G4;               // rows per pass
-  __shared__ __attribute__((aligned(16))) float hs[MAXU];
-  __shared__ float es[MAXR];
-  __shared__ __attribute__((aligned(16))) float wred[WW][64];
-  __shared__ __attribute__((aligned(16))) float qs[64];
-  __shared__ float red[WW];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // step si of a chain (PERSIST): the per-step outputs / masks / dropout sites are those of step 0 advanced by si
+  float* const o_qpre = g.qpre + (long)si * g.B * g.A;
+  float* const o_alpha = g.alpha + (long)si * g.B * g.R;
+  float* const o_ctx = g.ctx + (long)si * g.B * g.D;
+  float* const o_ctxd = g.ctx_d ? g.ctx_d + (long)si * g.B * g.D : nullptr;
+  const uint8_t* const keep4 = g.keep4 ? g.keep4 + (long)si * keep_stride : nullptr;
+  const uint32_t site_attn = g.site_attn + (uint32_t)si, site_in = g.site_in + (uint32_t)si;
+  float* hs = l.hs; float* es = l.es; float (*wred)[64] = l.wred; float* qs = l.qs; float* red = l.red;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c4 = tid % G4, rl = tid / G4;    // 4-column group, row lane
   const int A = g.A, D = g.D, R = g.R, U = g.U;
   const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
-  for (int k = tid; k < U; k += WT) hs[k] = g.h[(long)b * U + k];
-  __syncthreads();
   // ---- q = LeakyReLU(h W2 + b2): thread (c4, rl) sums rows k = rl, rl+RPP, ...
   {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -387,29 +400,29 @@ __global__ __launch_bounds__(WT) void attention_fwd_wide_kernel(AttArgs g) {
       float t = g.b2[tid];
 #pragma unroll
       for (int k = 0; k < WW; ++k) t += wred[k][tid];
-      g.qpre[(long)b * A + tid] = t;
+      o_qpre[(long)b * A + tid] = t;
       qs[tid] = t > 0.f ? t : t * g.slope;
     }
     __syncthreads();
   }
   // ---- scores e[r] = sum_a dropout(tanh(P + q)) v + bv
   {
-    float4 pv[MAXP];
-    uint32_t mk[MAXP];
+    float4 pv[NP];
+    uint32_t mk[NP];
     const bool cok = c4 * 4 < A;
-    const bool stored = g.keep4 != nullptr && g.rate_attn > 0.f;
+    const bool stored = keep4 != nullptr && g.rate_attn > 0.f;
 #pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int r = p * RPP + rl;
       pv[p] = (cok && r < R) ? *reinterpret_cast<const float4*>(g.P + ((long)b * R + r) * A + c4 * 4)
                              : make_float4(0.f, 0.f, 0.f, 0.f);
-      mk[p] = (stored && cok && r < R) ? g.keep4[(((long)b * R + r) * A + c4 * 4) >> 2] : 0u;
+      mk[p] = (stored && cok && r < R) ? keep4[(((long)b * R + r) * A + c4 * 4) >> 2] : 0u;
     }
     const float4 q4 = cok ? *reinterpret_cast<const float4*>(&qs[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 v4 = cok ? *reinterpret_cast<const float4*>(g.v + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float scale_a = 1.f / (1.f - g.rate_attn), bv = g.bv[0];
 #pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int r = p * RPP + rl;
       float t = 0.f;
       if (cok && r < R) {
@@ -418,7 +431,7 @@ __global__ __launch_bounds__(WT) void attention_fwd_wide_kernel(AttArgs g) {
         if (g.rate_attn > 0.f) {
           bool k[4];
           if (stored) { k[0] = mk[p] & 1u; k[1] = mk[p] & 2u; k[2] = mk[p] & 4u; k[3] = mk[p] & 8u; }
-          else tnt_keep4((uint64_t)e, g.rate_attn, g.seed, g.site_attn, step, k);
+          else tnt_keep4((uint64_t)e, g.rate_attn, g.seed, site_attn, step, k);
           s0 = k[0] ? s0 * scale_a : 0.f; s1 = k[1] ? s1 * scale_a : 0.f;
           s2 = k[2] ? s2 * scale_a : 0.f; s3 = k[3] ? s3 * scale_a : 0.f;
         }
@@ -438,21 +451,21 @@ __global__ __launch_bounds__(WT) void attention_fwd_wide_kernel(AttArgs g) {
   for (int r = tid; r < R; r += WT) { const float ex = expf(es[r] - m); es[r] = ex; z += ex; }
   z = block_sum_w(z, red);
   const float invz = 1.f / z;
-  for (int r = tid; r < R; r += WT) { const float al = es[r] * invz; es[r] = al; g.alpha[(long)b * R + r] = al; }
+  for (int r = tid; r < R; r += WT) { const float al = es[r] * invz; es[r] = al; o_alpha[(long)b * R + r] = al; }
   __syncthreads();
   // ---- context = sum_r alpha[r] F[r][:]
   {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool cok = c4 * 4 < D;
-    float4 fv[MAXP];
+    float4 fv[NP];
 #pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int r = p * RPP + rl;
       fv[p] = (cok && r < R) ? *reinterpret_cast<const float4*>(g.F + ((long)b * R + r) * D + c4 * 4)
                              : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int r = p * RPP + rl;
       const float al = r < R ? es[r] : 0.f;
       acc.x += al * fv[p].x; acc.y += al * fv[p].y; acc.z += al * fv[p].z; acc.w += al * fv[p].w;
@@ -465,16 +478,30 @@ __global__ __launch_bounds__(WT) void attention_fwd_wide_kernel(AttArgs g) {
       float t = 0.f;
 #pragma unroll
       for (int k = 0; k < WW; ++k) t += wred[k][tid];
-      g.ctx[(long)b * D + tid] = t;
-      if (g.ctx_d) {
+      o_ctx[(long)b * D + tid] = t;
+      if (o_ctxd) {
         float td = t;
         if (g.rate_in > 0.f)
-          td = tnt_keep((uint64_t)b * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, g.site_in, step)
+          td = tnt_keep((uint64_t)b * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, site_in, step)
                    ? t * (1.f / (1.f - g.rate_in)) : 0.f;
-        g.ctx_d[(long)b * D + tid] = td;
+        if (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        o_ctxd[(long)b * D + tid] = td;
       }
     }
   }
+}
+
+template <int G4>
+__global__ __launch_bounds__(WT) void attention_fwd_wide_kernel(AttArgs g) {
+  __shared__ __attribute__((aligned(16))) float hs[MAXU];
+  __shared__ float es[MAXR];
+  __shared__ __attribute__((aligned(16))) float wred[WW][64];
+  __shared__ __attribute__((aligned(16))) float qs[64];
+  __shared__ float red[WW];
+  const int b = blockIdx.x;
+  for (int k = threadIdx.x; k < g.U; k += WT) hs[k] = g.h[(long)b * g.U + k];
+  __syncthreads();
+  att_fwd_body<G4, false>(g, b, AttFwdLds{hs, es, wred, qs, red});
 }
 
 template <int G4>
@@ -861,6 +888,231 @@ extern "C" int32_t tnt_attention_front_bwd_f32(const float* Ppre, const float* d
   TNT_LAUNCH_CHECK();
   hipLaunchKernelGGL(attention_front_finalize_kernel, dim3((D * A + A + 63) / 64), dim3(64), 0, s, part, nA, D * A + A, D * A,
                      dW1, db1);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The forward chain of the attention captioner (lc_NIC.py:244-256: for every step, attention over the regions with the
+// previous h as the query, then ONE LSTM step on [context, word]) as ONE persistent launch instead of 2 T dependent
+// launches.  Placement, tickets, epochs and the data-polling hand-off are those of lstm_seq_fwd_kernel<POLL> (lstm.hip,
+// tnt_seq_sync.h): a 16-row block of the batch lives on one XCD, its 32 workgroups each own 16 LSTM units (recurrent
+// weights resident in VGPRs), and the first 16 of them also own one SAMPLE each for the attention phase.  Per step:
+//   attention (16 workgroups): poll h[i][b] (sentinel), att_fwd_body, publish ctx_d[i][b];
+//   LSTM (32 workgroups):      poll h[i] (this wave's K chunk) and ctx_d[i] (waves < D/4: one k-step of the context part
+//                              each), MFMAs, combine, gates, publish h[i+1].
+// Sentinel resets, by the owning thread: h[i+2] and ctx_d[i+1] at the top of step i (drained before the same thread
+// publishes h[i+1] / ctx_d[i]); h[1] and ctx_d[0] at kernel start behind the launch's only flag barrier.
+#include "tnt_seq_sync.h"
+
+namespace {
+struct LcSeqArgs {
+  AttArgs att;             // per-step pointers (qpre, alpha, ctx, ctx_d, keep4) point at step 0; sites at step 0
+  long keep_stride;        // bytes between the stored keep masks of consecutive steps
+  const float* xz;         // [T][B][U][4] text half of x W (no bias)
+  const float* Wc;         // [D][U][4] context rows of lstm/kernel
+  const float* Ur;         // [U][U][4]
+  const float* zbias;      // [U][4]
+  float* hs; float* cs;    // [T+1][B][U]
+  float* gates;            // [T][B][U][4]
+  int T;
+  unsigned* sync; float* guard_out;
+};
+
+constexpr unsigned LC_SENTINEL = 0x7FC5EED5u;          // = TNT_SEQ_SENTINEL of lstm.hip
+constexpr int LC_SEQ_LDS_BYTES = 16 * 4 * 16 * 17 * 4 + 16;
+
+__device__ __forceinline__ float lc_ld1_l2(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)byte_off, 0, /*sc1*/ 16));
+}
+
+template <int G4, int NP>
+__global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
+  constexpr int NWF = 16, SS = 8, CK = 32;
+  extern __shared__ __attribute__((aligned(16))) float lc_lds[];
+  float (*red)[4][16][17] = reinterpret_cast<float (*)[4][16][17]>(lc_lds);          // [NWF][4][16][17]
+  unsigned* s_slot = reinterpret_cast<unsigned*>(lc_lds + NWF * 4 * 16 * 17);
+  __shared__ __attribute__((aligned(16))) float hs_l[512];
+  __shared__ float es_l[512];
+  __shared__ __attribute__((aligned(16))) float wred_l[WW][64];
+  __shared__ __attribute__((aligned(16))) float qs_l[64];
+  __shared__ float red_l[WW];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kq = lane >> 4, lr = lane & 15;
+  const int U = a.att.U, B = a.att.B, D = a.att.D, R = a.att.R, A = a.att.A, T = a.T;
+  const unsigned xcc = tnt_xcc_id();
+  const int nrb = (B + 15) / 16;
+  if ((int)xcc >= nrb) return;
+  unsigned* bar = a.sync + xcc * 64;
+  unsigned* err = a.sync + TNT_SEQ_ERR;
+  const TntSeqSlot slot = tnt_seq_enter(a.sync, xcc, s_slot);
+  if (slot.ub < 0) {
+    if (tid == 0 && a.guard_out) a.guard_out[0] = 2.f;
+    return;
+  }
+  const int ub = slot.ub, rb = __builtin_amdgcn_readfirstlane((int)xcc);
+  const long BU = (long)B * U;
+  const __amdgpu_buffer_rsrc_t hs_rsrc = tnt_rsrc(a.hs, (unsigned)((long)(T + 1) * BU * 4));
+  const __amdgpu_buffer_rsrc_t cx_rsrc = tnt_rsrc(a.att.ctx_d, (unsigned)((long)T * B * D * 4));
+  const int arow = rb * 16 + lr, ucol = ub * 16 + lr;
+  // The weight fragments (recurrent: every wave; context rows: waves < D / 4 take k-step w of the context part) are NOT kept
+  // in registers across the steps here, unlike lstm_seq_fwd_kernel: the attention phase needs ~90 VGPRs of its own and the
+  // two sets together spill (128 VGPRs per lane at 1024 threads).  They are re-read from L2 (128 KB per workgroup, as the
+  // per-step kernel does) right behind the attention phase, in flight while the hand-off polls run.
+  const bool cwave = w * 4 < D;
+  // ---- LSTM epilogue thread state
+  const int erow = tid >> 4, ecol = tid & 15;
+  const int eb = rb * 16 + erow, eu = ub * 16 + ecol;
+  const bool eok = tid < 256 && eb < B;
+  const long ee = (long)eb * U + eu;
+  float4 zb = make_float4(0.f, 0.f, 0.f, 0.f), x4 = zb;
+  float cp = 0.f;
+  if (eok) {
+    if (a.zbias) zb = *reinterpret_cast<const float4*>(a.zbias + (long)eu * 4);
+    cp = a.cs[ee];
+    x4 = *reinterpret_cast<const float4*>(a.xz + ee * 4);
+  }
+  // ---- attention role
+  const int ab = rb * 16 + ub;                         // this workgroup's sample
+  const bool arole = ub < 16 && ab < B;
+  const float sentinel = __uint_as_float(LC_SENTINEL);
+  if (eok) a.hs[BU + ee] = sentinel;
+  if (arole && tid < D) a.att.ctx_d[(long)ab * D + tid] = sentinel;
+  tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
+  for (int i = 0; i < T; ++i) {
+    if (eok && i + 2 <= T) a.hs[(long)(i + 2) * BU + ee] = sentinel;
+    if (arole && tid < D && i + 1 < T) a.att.ctx_d[((long)(i + 1) * B + ab) * D + tid] = sentinel;
+    if (arole) {
+      // ---- this sample's h of step i
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+        for (int k = tid; k < U; k += WT) {
+          const float v = lc_ld1_l2(hs_rsrc, (unsigned)(((long)i * BU + (long)ab * U + k) * 4));
+          hs_l[k] = v;
+          ok = ok && __float_as_uint(v) != LC_SENTINEL;
+        }
+        if (__all(ok)) break;
+        if (++spins > TNT_SEQ_SPIN_LIMIT) {
+          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      }
+      __syncthreads();
+      att_fwd_body<G4, true, NP>(a.att, ab, AttFwdLds{hs_l, es_l, wred_l, qs_l, red_l}, i, a.keep_stride);
+    }
+    // ---- LSTM step: A fragments = h[i] (this wave's K chunk), context fragment for the waves that own a context k-step
+    int opaque = 0;
+    asm volatile("" : "+s"(opaque));       // the loads below are loop-invariant: keep the compiler from hoisting them back
+    const float* Urp = a.Ur + opaque;
+    const float* Wcp = a.Wc + opaque;
+    float4 bv[SS];
+#pragma unroll
+    for (int s = 0; s < SS; ++s) bv[s] = *reinterpret_cast<const float4*>(Urp + ((long)(w * CK + (s >> 2) * 16 + kq * 4 + (s & 3)) * U + ucol) * 4);
+    float4 cbv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cwave && w * 4 + kq < D) cbv = *reinterpret_cast<const float4*>(Wcp + ((long)(w * 4 + kq) * U + ucol) * 4);
+    float av[SS];
+    float cxv = 0.f;
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < SS / 4; ++j) {
+        const float4 t = arow < B ? tnt_ld4_l2(hs_rsrc, (unsigned)(((long)i * BU + (long)arow * U + w * CK + j * 16 + kq * 4) * 4))
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        av[4 * j + 0] = t.x; av[4 * j + 1] = t.y; av[4 * j + 2] = t.z; av[4 * j + 3] = t.w;
+        ok = ok && __float_as_uint(t.x) != LC_SENTINEL && __float_as_uint(t.y) != LC_SENTINEL &&
+             __float_as_uint(t.z) != LC_SENTINEL && __float_as_uint(t.w) != LC_SENTINEL;
+      }
+      if (cwave) {
+        cxv = (arow < B && w * 4 + kq < D) ? lc_ld1_l2(cx_rsrc, (unsigned)((((long)i * B + arow) * D + w * 4 + kq) * 4)) : 0.f;
+        ok = ok && __float_as_uint(cxv) != LC_SENTINEL;
+      }
+      if (__all(ok)) break;
+      if (++spins > TNT_SEQ_SPIN_LIMIT) {
+        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
+    floatx4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < SS; ++s) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].w, acc[3], 0, 0, 0);
+    }
+    if (cwave) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cxv, cbv.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cxv, cbv.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(cxv, cbv.z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(cxv, cbv.w, acc[3], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][g][kq * 4 + r][lr] = acc[g][r];
+    __syncthreads();
+    if (eok) {
+      float z[4] = {x4.x + zb.x, x4.y + zb.y, x4.z + zb.z, x4.w + zb.w};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < NWF; ++k) sacc += red[k][g][erow][ecol];
+        z[g] += sacc;
+      }
+      const float gi = tnt_sigmoid_fast(z[0]), gf = tnt_sigmoid_fast(z[1]), gg = tnt_tanh(z[2]), go = tnt_sigmoid_fast(z[3]);
+      const float c2 = gf * cp + gi * gg;
+      const float h2 = go * tnt_tanh(c2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's reset of hs[i+2] is in L2 first
+      a.hs[(long)(i + 1) * BU + ee] = h2;
+      a.cs[(long)(i + 1) * BU + ee] = c2;
+      *reinterpret_cast<float4*>(a.gates + ((long)i * BU + ee) * 4) = make_float4(gi, gf, gg, go);
+      cp = c2;
+      if (i + 1 < T) x4 = *reinterpret_cast<const float4*>(a.xz + ((long)(i + 1) * BU + ee) * 4);
+    }
+    if (i + 1 == T) break;
+    __syncthreads();        // `red` is rewritten by the next step's MFMA phase
+  }
+  tnt_seq_leave(a.sync, xcc, a.guard_out);
+}
+}  // namespace
+
+extern "C" int32_t tnt_lc_seq_fwd_f32(const float* F, const float* P, const float* W2, const float* b2, const float* v,
+                                      const float* bv, float* qpre, float* alpha, float* ctx, float* ctx_d,
+                                      const uint8_t* keep4, int64_t keep_stride, const float* xz, const float* Wc,
+                                      const float* Ur, const float* xz_bias, float* hs, float* cs, float* gates, int32_t T,
+                                      int32_t B, int32_t R, int32_t D, int32_t A, int32_t U, float slope, float rate_attn,
+                                      float rate_in, int32_t in_lwidth, uint64_t seed, uint32_t site_attn0,
+                                      uint32_t site_in0, const uint32_t* step_dev, uint32_t* sync, float* guard_out,
+                                      void* stream) {
+  if (T <= 0 || sync == nullptr || U != 512 || B <= 0 || B > 128) return TNT_BADARG(24);
+  if (!wide_ok(R, D, A) || R > 512 || D > 64 || A > 64) return TNT_BADARG(21);
+  if ((long)(T + 1) * B * U * 4 >= (1L << 32)) return TNT_BADARG(19);
+  if (!tnt_aligned16(P) || !tnt_aligned16(F) || !tnt_aligned16(W2) || !tnt_aligned16(v) || !tnt_aligned16(xz) ||
+      !tnt_aligned16(Wc) || !tnt_aligned16(Ur) || !tnt_aligned16(gates)) return TNT_BADARG(1);
+  LcSeqArgs a{};
+  AttArgs& g = a.att;
+  g.F = F; g.P = P; g.W2 = W2; g.b2 = b2; g.v = v; g.bv = bv; g.qpre = qpre; g.alpha = alpha; g.ctx = ctx; g.ctx_d = ctx_d;
+  g.s_out = nullptr; g.B = B; g.R = R; g.D = D; g.A = A; g.U = U; g.in_lwidth = in_lwidth; g.slope = slope;
+  g.rate_attn = rate_attn; g.rate_in = rate_in; g.seed = seed; g.site_attn = site_attn0; g.site_in = site_in0; g.step = 0;
+  g.step_dev = step_dev; g.keep4 = keep4;
+  a.keep_stride = keep_stride; a.xz = xz; a.Wc = Wc; a.Ur = Ur; a.zbias = xz_bias; a.hs = hs; a.cs = cs; a.gates = gates;
+  a.T = T; a.sync = sync; a.guard_out = guard_out;
+  // row passes of the attention phase held in registers: as few as R needs (the LSTM weights are resident next to them)
+  const int g4 = (A <= 32 && D <= 32) ? 8 : 16, np = (R + WT / g4 - 1) / (WT / g4);
+  void (*kern)(LcSeqArgs) = nullptr;
+  if (g4 == 8) kern = np <= 3 ? lc_seq_fwd_kernel<8, 3> : lc_seq_fwd_kernel<8, 6>;
+  else kern = np <= 3 ? lc_seq_fwd_kernel<16, 3> : lc_seq_fwd_kernel<16, 6>;
+  if (np > 6) return TNT_BADARG(21);
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LC_SEQ_LDS_BYTES) != hipSuccess)
+    return TNT_BADARG(90);
+  hipLaunchKernelGGL(kern, dim3(256), dim3(1024), LC_SEQ_LDS_BYTES, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
 }

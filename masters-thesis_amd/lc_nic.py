@@ -348,6 +348,7 @@ class NIC(ModelBase):
         self.logits = f(n, ldV)
         self.loss_row, self.corr_row = f(n), f(n)
         self.met = f(8 + 4 * self.S)
+        self._init_seq_lstm(B, U)        # device census + sync state of the persistent forward chain (tnt_lc_seq_fwd_f32)
         self.colB = f(2 * B)
         # backward
         self.dinter, self.dHs = f(n, H), f(n, U)
@@ -447,6 +448,18 @@ class NIC(ModelBase):
         self.gemm_sk(self.F, a.p("attention/W1/kernel"), self.P, B * R, self.A, D, D, self.A, self.A,
                 bias=a.p("attention/W1/bias"), pre=self.Ppre, act=ACT_LEAKY, slope=0.2)      # attention.py:32 (hoisted)
 
+    def _lc_seq_ok(self):
+        """the persistent forward-chain kernel applies (tnt_lc_seq_fwd_f32's shape limits; the device census was taken by
+        _init_seq_lstm in _build)"""
+        # Opt-in (use_lc_seq = True): measured on MI355X at B = 64, R = 360, U = 512 the one-launch chain runs 16.3 us per
+        # step against 15.6 us for the two per-step launches (config 3: 1.078 vs 1.062 ms/step) -- the attention phase
+        # occupies only the 16 workgroups of an XCD that own a sample while the other 16 wait, and at 1024 threads the
+        # attention and LSTM register sets do not fit side by side (58 VGPRs spill).  Kept for the shapes / devices where
+        # the launch gap weighs more, and parity-tested (test_lc_seq_fwd_chain_equals_step_kernels).
+        return bool(self.__dict__.get("_seq_lstm") and getattr(self, "use_lc_seq", False) and not self.use_layer_norm
+                    and hasattr(self.be, "lc_seq_fwd") and self.R <= 512 and self.A % 4 == 0 and self.D % 4 == 0
+                    and self.A <= 64 and self.D <= 64)
+
     def _decode_step(self, i, B, training, s_out=None, xz_bias=None):
         """attention -> concat -> one LSTM step (lc_NIC.py:246-255)."""
         be, a = self.be, self.arena
@@ -498,8 +511,19 @@ class NIC(ModelBase):
         self.gemm_sk(self.text, Wl[D:], self.XZ, n, 4 * U, Et, Et, 4 * U, 4 * U)
         if training and self._keep_stored:
             be.dropout_mask4(self.att_keep, B * R * A, T, self.r_attn, sd, S_ATTN, 0, ds)
-        for i in range(T):                                                                      # :244-256
-            self._decode_step(i, B, training, xz_bias=a.p("lstm/bias"))
+        if self._lc_seq_ok():
+            # the T attention -> LSTM steps as ONE persistent launch (tnt_lc_seq_fwd_f32), XCD-local data-polling hand-offs
+            r_in = self.r_lstm if training else 0.0
+            keep = self.att_keep if (training and self._keep_stored) else None
+            be.lc_seq_fwd(self.F, self.P, a.p("attention/W2/kernel"), a.p("attention/W2/bias"), a.p("attention/V/kernel"),
+                          a.p("attention/V/bias"), self.qpre, self.alpha, self.ctx, self.ctx_d, keep,
+                          B * R * A // 4 if keep is not None else 0, self.XZ, Wl[:D], a.p("lstm/recurrent_kernel"),
+                          a.p("lstm/bias"), self.Hs, self.Cs, self.gates, T, B, R, D, A, U, 0.2,
+                          self.r_attn if training else 0.0, r_in, D + Et, self.seed, S_ATTN, S_LSTM_IN, self.drop_step,
+                          self.seq_sync, self._guard_out())
+        else:
+            for i in range(T):                                                                  # :244-256
+                self._decode_step(i, B, training, xz_bias=a.p("lstm/bias"))
         hs = self.Hs[1:].view(n, U)
         if training and self.r_lstm > 0:                                                        # :256
             be.dropout(hs, self.Hd, n, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds, rows_per_site=B)
@@ -779,7 +803,7 @@ class NIC(ModelBase):
                 out[f"loss{tag}"], out[f"accuracy{tag}"], out[f"attention{tag}"] = m[k], m[k + 1], m[k + 2]
         if with_lr:
             out["lr"] = self.lr_dev.clone()[0]
-        return out
+        return out.guarded(self, m[self.GUARD]) if self.__dict__.get("_seq_lstm") else out
 
     def train_step(self, data):
         """lc_NIC.train_step (lc_NIC.py:328-408): returns {loss, L2, accuracy, attention, lr}."""
@@ -862,10 +886,13 @@ class NIC(ModelBase):
         """lc_NIC.call -> call_attention (lc_NIC.py:163-164,223-263):
         returns (probabilities (B,T,V), attention scores (T,B,R,1))."""
         B, T = self._stage_inputs(data)
-        self._forward(B, T, training)
-        self.be.softmax_cce(self.logits, None, self.logits, None, None, None, T * B, self.V, self.ldV, 0.0)
-        probs = self.logits.view(T, B, self.ldV)[:, :, :self.V].permute(1, 0, 2).contiguous()
-        return probs, self.alpha.clone().unsqueeze(-1)
+
+        def run():
+            self._forward(B, T, training)
+            self.be.softmax_cce(self.logits, None, self.logits, None, None, None, T * B, self.V, self.ldV, 0.0)
+            probs = self.logits.view(T, B, self.ldV)[:, :, :self.V].permute(1, 0, 2).contiguous()
+            return probs, self.alpha.clone().unsqueeze(-1)
+        return self._guarded(run)
 
     call = call_attention = __call__
 

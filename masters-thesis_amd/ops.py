@@ -237,6 +237,14 @@ class HipBackend:
     def dense_dw_skinny(self, x, dpre, dw, N, E, Bk, ldx):
         self._call(self.lib.tnt_dense_dw_skinny_f32, "tnt_dense_dw_skinny_f32", _p(x), _p(dpre), _p(dw), N, E, Bk, ldx, self._s())
 
+    def lc_seq_fwd(self, F, P, W2, b2, v, bv, qpre, alpha, ctx, ctx_d, keep4, keep_stride, xz, Wc, Ur, xz_bias, hs, cs, gates, T,
+                   B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, seed, site_attn0, site_in0, step_dev, sync,
+                   guard_out=None):
+        self._call(self.lib.tnt_lc_seq_fwd_f32, "tnt_lc_seq_fwd_f32", _p(F), _p(P), _p(W2), _p(b2), _p(v), _p(bv), _p(qpre), _p(alpha),
+                   _p(ctx), _p(ctx_d), _p(keep4), int(keep_stride), _p(xz), _p(Wc), _p(Ur), _p(xz_bias), _p(hs), _p(cs), _p(gates),
+                   T, B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, int(seed), int(site_attn0), int(site_in0),
+                   _p(step_dev), _p(sync), _p(guard_out), self._s())
+
     def attention_front_bwd_parts(self, rows, D, A):
         return int(self.lib.tnt_attention_front_bwd_parts(rows, D, A))
 

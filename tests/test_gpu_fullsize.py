@@ -120,6 +120,32 @@ def test_edge_shapes(kind, b, t):
     assert np.asarray(words).size == b * 4
 
 
+def test_lc_seq_fwd_chain_equals_step_kernels():
+    """tnt_lc_seq_fwd_f32 (the T attention -> LSTM steps of config 3 as one persistent launch, opt-in) against the per-step
+    kernels on the same model: dropout on (stored keep masks, context input dropout), captured training steps -- same
+    losses, attention metric and weights up to float32 rounding of the gate math, error word 0; and inference outputs."""
+    rng = np.random.default_rng(11)
+    data, tgt = synth(rng)
+    a, b = make("attention"), make("attention")
+    a.use_lc_seq = True
+    ha = [a.train_step((data, tgt)).as_floats() for _ in range(4)]
+    hb = [b.train_step((data, tgt)).as_floats() for _ in range(4)]
+    if not a._lc_seq_ok():
+        pytest.skip("persistent chain kernel not supported on this device")
+    assert not b._lc_seq_ok()
+    a.check_device_errors()
+    for x, y in zip(ha, hb):
+        for k in x:
+            assert abs(x[k] - y[k]) <= 2e-5 * max(1.0, abs(y[k])), (k, x, y)
+    wa, wb = a.get_weights_dict(), b.get_weights_dict()
+    for k in wa:
+        d = np.abs(wa[k] - wb[k])
+        assert (d > 3e-5).mean() <= 5e-3, (k, d.max())          # see the LeakyReLU-kink note in the test below
+    pa, aa = a(data, training=False)
+    pb, ab = b(data, training=False)
+    assert (pa - pb).abs().max().item() <= 2e-4 and (aa - ab).abs().max().item() <= 2e-5
+
+
 def test_persistent_lstm_forward_trains_like_the_step_kernels():
     """Config 2 with the persistent sequence kernel (tnt_lstm_seq_fwd_f32: one launch for the T+1 dependent LSTM steps)
     against the same model on the per-step kernels: same losses and weights over captured training steps (the two
