@@ -10,7 +10,7 @@
 namespace {
 
 // column reductions run in two levels: <= MAX_CHUNKS row chunks -> per-column finalize
-constexpr int MAX_CHUNKS = 32;
+constexpr int MAX_CHUNKS = 128;
 inline int chunk_count(int rows) { int n = (rows + 63) / 64; return n > MAX_CHUNKS ? MAX_CHUNKS : (n < 1 ? 1 : n); }
 inline int chunk_rows(int rows) { const int n = chunk_count(rows); return (rows + n - 1) / n; }
 
@@ -101,14 +101,15 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* a, int ld
   const int r0 = chunk * crows, r1 = min(rows, r0 + crows);
   float v0 = 0.f, v1 = 0.f, n = 0.f;
   if (c < C) {
+    // MODE 0: sums of (x - K) and (x - K)^2 with K = the thread's first row (shifted sums: no catastrophic cancellation
+    // in S2 - S1^2 / n, and no per-element division on a serial chain as in the textbook Welford update)
+    const float K = (MODE == 0 && r0 + rl < r1) ? a[(long)(r0 + rl) * lda + c] : 0.f;
 #pragma unroll 4
     for (int r = r0 + rl; r < r1; r += RL) {
       const float x = a[(long)r * lda + c];
       if (MODE == 0) {
-        n += 1.f;
-        const float d = x - v0;
-        v0 += d / n;
-        v1 += d * (x - v0);
+        const float d = x - K;
+        n += 1.f; v0 += d; v1 += d * d;
       } else if (MODE == 1) {
         v0 += x;
         v1 += x * b[(long)r * ldb + c];
@@ -116,6 +117,11 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* a, int ld
         v0 += x;
       }
     }
+  }
+  if (MODE == 0 && n > 0.f) {          // (count, mean, M2) of this thread's rows from the shifted sums
+    const float K = a[(long)(r0 + rl) * lda + c], m = v0 / n;
+    v1 = v1 - v0 * m;                  // sum (x - mean)^2 = S2 - S1^2 / n
+    v0 = K + m;
   }
   s0[rl][cl] = v0; s1[rl][cl] = v1; sn[rl][cl] = n;
   __syncthreads();
@@ -157,21 +163,31 @@ void launch_col_partial(const float* a, int lda, const float* b, int ldb, int ro
                        C, crows, work);
 }
 
-// BN statistics finalize (training): Chan merge over chunks in fixed order.
-__global__ void bn_finalize_kernel(const float* work, int rows, int C, int nchunk, int crows, float eps, float momentum,
-                                   float* mov_mean, float* mov_var, float* mean_out, float* inv_std) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
+// BN statistics finalize (training), one wave per column, lanes over the chunks: mean = sum n_j m_j / N, then
+// M2 = sum (M2_j + n_j (m_j - mean)^2); fixed order (lane-strided partial sums + the shuffle tree of tnt_wave_sum).
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* work, int rows, int C, int nchunk, int crows,
+                                                         float eps, float momentum, float* mov_mean, float* mov_var,
+                                                         float* mean_out, float* inv_std) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   if (c >= C) return;
-  float nn = 0.f, mean = 0.f, m2 = 0.f;
-  for (int k = 0; k < nchunk; ++k) {
+  float nn = 0.f, ms = 0.f;
+  for (int k = lane; k < nchunk; k += 64) {
     const float nj = (float)(min(rows, (k + 1) * crows) - k * crows);
     if (nj <= 0.f) continue;
-    const float mj = work[((long)k * 2 + 0) * C + c], m2j = work[((long)k * 2 + 1) * C + c];
-    const float d = mj - mean, nt = nn + nj;
-    mean += d * nj / nt;
-    m2 += m2j + d * d * nn * nj / nt;
-    nn = nt;
+    nn += nj;
+    ms += nj * work[((long)k * 2 + 0) * C + c];
   }
+  nn = tnt_wave_sum(nn); ms = tnt_wave_sum(ms);
+  const float mean = ms / nn;
+  float m2 = 0.f;
+  for (int k = lane; k < nchunk; k += 64) {
+    const float nj = (float)(min(rows, (k + 1) * crows) - k * crows);
+    if (nj <= 0.f) continue;
+    const float d = work[((long)k * 2 + 0) * C + c] - mean;
+    m2 += work[((long)k * 2 + 1) * C + c] + nj * d * d;
+  }
+  m2 = tnt_wave_sum(m2);
+  if (lane != 0) return;
   const float var = m2 / nn;
   mean_out[c] = mean;
   inv_std[c] = 1.f / sqrtf(var + eps);
@@ -199,14 +215,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
   }
 }
 
-// sums over chunks: out0[c] = sum_k work[k][0][c] (and out1 from slot 1 if TWO)
+// sums over chunks: out0[c] = sum_k work[k][0][c] (and out1 from slot 1 if TWO); one wave per column, lanes over chunks
 template <bool TWO>
-__global__ void col_finalize_kernel(const float* work, int C, int nchunk, float* out0, float* out1) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(64) void col_finalize_kernel(const float* work, int C, int nchunk, float* out0, float* out1) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   if (c >= C) return;
   float t0 = 0.f, t1 = 0.f;
-#pragma unroll 8
-  for (int k = 0; k < nchunk; ++k) {
+  for (int k = lane; k < nchunk; k += 64) {
     if (TWO) {
       t0 += work[((long)k * 2 + 0) * C + c];
       t1 += work[((long)k * 2 + 1) * C + c];
@@ -214,8 +229,12 @@ __global__ void col_finalize_kernel(const float* work, int C, int nchunk, float*
       t0 += work[(long)k * C + c];
     }
   }
-  out0[c] = t0;
-  if (TWO) out1[c] = t1;
+  t0 = tnt_wave_sum(t0);
+  if (TWO) t1 = tnt_wave_sum(t1);
+  if (lane == 0) {
+    out0[c] = t0;
+    if (TWO) out1[c] = t1;
+  }
 }
 
 // dx = gamma*inv/n * (n*dy - dbeta - xhat*dgamma)   (training)  |  gamma*inv*dy (inference)
@@ -673,7 +692,7 @@ extern "C" int32_t tnt_batchnorm_fwd_f32(const float* x, const float* gamma, con
   if (training) {
     launch_col_partial<0>(x, C, nullptr, 0, rows, C, part, s);
     TNT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, part, rows, C, nchunk, chunk_rows(rows),
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, rows, C, nchunk, chunk_rows(rows),
                        eps, momentum, mov_mean, mov_var, mean, inv_std);
     TNT_LAUNCH_CHECK();
   } else {
@@ -697,7 +716,7 @@ extern "C" int32_t tnt_batchnorm_bwd_f32(const float* dy, const float* xhat, con
     float* part = work + C;
     launch_col_partial<1>(dy, lddy, xhat, C, rows, C, part, s);
     TNT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_finalize_kernel<true>, dim3((C + 63) / 64), dim3(64), 0, s, part, C, nchunk, dbeta, dgamma);
+    hipLaunchKernelGGL(col_finalize_kernel<true>, dim3(C), dim3(64), 0, s, part, C, nchunk, dbeta, dgamma);
     TNT_LAUNCH_CHECK();
   }
   if (dx) {
@@ -726,7 +745,7 @@ extern "C" int32_t tnt_layernorm_bwd_f32(const float* dy, const float* xhat, con
     float* part = work + C;
     launch_col_partial<1>(dy, lddy, xhat, C, rows, C, part, s);
     TNT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_finalize_kernel<true>, dim3((C + 63) / 64), dim3(64), 0, s, part, C, nchunk, dbeta, dgamma);
+    hipLaunchKernelGGL(col_finalize_kernel<true>, dim3(C), dim3(64), 0, s, part, C, nchunk, dbeta, dgamma);
     TNT_LAUNCH_CHECK();
   }
   if (dx) {
@@ -919,7 +938,7 @@ extern "C" int32_t tnt_colsum_f32(const float* x, float* out, int32_t rows, int3
   const int nchunk = chunk_count(rows);
   launch_col_partial<2>(x, ld, nullptr, 0, rows, C, work, s);
   TNT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_finalize_kernel<false>, dim3((C + 63) / 64), dim3(64), 0, s, work, C, nchunk, out,
+  hipLaunchKernelGGL(col_finalize_kernel<false>, dim3(C), dim3(64), 0, s, work, C, nchunk, out,
                      (float*)nullptr);
   TNT_LAUNCH_CHECK();
   return 0;
