@@ -805,7 +805,7 @@ class NIC(ModelBase):
                 tag, k = chr(ord("A") + q), 8 + 4 * q
                 out[f"loss{tag}"], out[f"accuracy{tag}"], out[f"attention{tag}"] = m[k], m[k + 1], m[k + 2]
         if with_lr:
-            out["lr"] = self.lr_dev.clone()[0]
+            out["lr"] = torch.tensor(self._lr_host, dtype=torch.float32)      # host-set (ModelBase._sync_lr): no device copy
         return out.guarded(self, m[self.GUARD]) if self.__dict__.get("_seq_lstm") else out
 
     def train_step(self, data):
