@@ -141,6 +141,23 @@ int32_t tnt_batchnorm_bwd_f32(const float* dy, const float* xhat, const float* g
                               int32_t rows, int32_t C, int32_t lddy, int32_t training,
                               float* work, void* stream);
 
+/* Synchronised BatchNorm (data parallel, opt-in; the reference trains on one device, so this is what makes G replicas x
+ * local batch equal ONE process on the concatenated batch when the encoder uses BatchNorm): the pieces of the two
+ * functions above around the caller's collectives.
+ *   stats        part = this replica's row-chunk partials, tnt_bn_nchunk(rows) * 2 * C floats;
+ *   apply_stats  part_all = nrep replicas' partials back to back (all-gathered, every replica `rows` rows): statistics over
+ *                nrep * rows rows, moving statistics updated, y / xhat / inv_std written; mean_work: C floats of scratch;
+ *   dx           input gradient from dgamma_sum / dbeta_sum taken over all n_total rows (all-reduced local sums of
+ *                tnt_batchnorm_bwd_f32 called with dx = NULL). */
+int32_t tnt_batchnorm_stats_f32(const float* x, int32_t rows, int32_t C, float* part, void* stream);
+int32_t tnt_batchnorm_apply_stats_f32(const float* part_all, int32_t nrep, const float* x, const float* gamma,
+                                      const float* beta, float* mov_mean, float* mov_var, float* y, float* xhat,
+                                      float* inv_std, int32_t rows, int32_t C, int32_t ldy, float eps, float momentum,
+                                      float* mean_work, void* stream);
+int32_t tnt_batchnorm_dx_f32(const float* dy, int32_t lddy, const float* xhat, const float* gamma, const float* inv_std,
+                             const float* dgamma_sum, const float* dbeta_sum, float* dx, int32_t rows, int32_t C,
+                             int32_t n_total, void* stream);
+
 /* Split mode of the two entry points above: the launch runs over PIECES of at most `piece` voxels of a region's index
  * list, so that one large region does not set the kernel time (regions span 8..400+ voxels; measured 39 -> ~12 us
  * at 360 regions of 18..240 voxels).  Tables (host-built from goff): vgoff[NV+1] CSR range of each piece, vreg[NV] its

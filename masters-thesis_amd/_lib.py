@@ -29,6 +29,9 @@ SIGNATURES = {
     "tnt_bn_nchunk": [I32],
     "tnt_batchnorm_fwd_f32": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, F32, F32, P, P],
     "tnt_batchnorm_bwd_f32": [P, P, P, P, P, P, P, I32, I32, I32, I32, P, P],
+    "tnt_batchnorm_stats_f32": [P, I32, I32, P, P],
+    "tnt_batchnorm_apply_stats_f32": [P, I32, P, P, P, P, P, P, P, P, I32, I32, I32, F32, F32, P, P],
+    "tnt_batchnorm_dx_f32": [P, I32, P, P, P, P, P, P, I32, I32, I32, P],
     "tnt_layernorm_fwd_f32": [P, P, P, P, P, P, I32, I32, I32, F32, P],
     "tnt_layernorm_bwd_f32": [P, P, P, P, P, P, P, I32, I32, I32, P, P],
     "tnt_colsum_f32": [P, P, I32, I32, I32, P, P],

@@ -165,14 +165,18 @@ void launch_col_partial(const float* a, int lda, const float* b, int ldb, int ro
 
 // BN statistics finalize (training), one wave per column, lanes over the chunks: mean = sum n_j m_j / N, then
 // M2 = sum (M2_j + n_j (m_j - mean)^2); fixed order (lane-strided partial sums + the shuffle tree of tnt_wave_sum).
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* work, int rows, int C, int nchunk, int crows,
+// nrep > 1 (synchronised BatchNorm): `work` holds nrep replicas' chunk partials back to back (all-gathered), each of `rows`
+// rows: the statistics are those of the nrep * rows rows.
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* work, int rows, int C, int nchunk1, int crows,
                                                          float eps, float momentum, float* mov_mean, float* mov_var,
-                                                         float* mean_out, float* inv_std) {
+                                                         float* mean_out, float* inv_std, int nrep) {
   const int c = blockIdx.x, lane = threadIdx.x;
   if (c >= C) return;
+  const int nchunk = nchunk1 * nrep;
   float nn = 0.f, ms = 0.f;
   for (int k = lane; k < nchunk; k += 64) {
-    const float nj = (float)(min(rows, (k + 1) * crows) - k * crows);
+    const int k1 = k % nchunk1;
+    const float nj = (float)(min(rows, (k1 + 1) * crows) - k1 * crows);
     if (nj <= 0.f) continue;
     nn += nj;
     ms += nj * work[((long)k * 2 + 0) * C + c];
@@ -181,7 +185,8 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* work, int 
   const float mean = ms / nn;
   float m2 = 0.f;
   for (int k = lane; k < nchunk; k += 64) {
-    const float nj = (float)(min(rows, (k + 1) * crows) - k * crows);
+    const int k1 = k % nchunk1;
+    const float nj = (float)(min(rows, (k1 + 1) * crows) - k1 * crows);
     if (nj <= 0.f) continue;
     const float d = work[((long)k * 2 + 0) * C + c] - mean;
     m2 += work[((long)k * 2 + 1) * C + c] + nj * d * d;
@@ -240,9 +245,9 @@ __global__ __launch_bounds__(64) void col_finalize_kernel(const float* work, int
 // dx = gamma*inv/n * (n*dy - dbeta - xhat*dgamma)   (training)  |  gamma*inv*dy (inference)
 __global__ __launch_bounds__(256) void bn_dx_kernel(const float* dy, int lddy, const float* xhat, const float* gamma,
                                                     const float* inv_std, const float* dgamma, const float* dbeta,
-                                                    float* dx, int rows, int C, int training) {
+                                                    float* dx, int rows, int C, int training, int n_total) {
   const long total = (long)rows * C;
-  const float n = (float)rows;
+  const float n = (float)n_total;       // rows of the whole (possibly cross-replica) batch the sums were taken over
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int r = (int)(e / C), c = (int)(e % C);
     const float g = dy[(long)r * lddy + c];
@@ -693,7 +698,7 @@ extern "C" int32_t tnt_batchnorm_fwd_f32(const float* x, const float* gamma, con
     launch_col_partial<0>(x, C, nullptr, 0, rows, C, part, s);
     TNT_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, rows, C, nchunk, chunk_rows(rows),
-                       eps, momentum, mov_mean, mov_var, mean, inv_std);
+                       eps, momentum, mov_mean, mov_var, mean, inv_std, 1);
     TNT_LAUNCH_CHECK();
   } else {
     hipLaunchKernelGGL(bn_infer_prep_kernel, dim3((C + 63) / 64), dim3(64), 0, s, mov_mean, mov_var, C, eps, mean,
@@ -721,9 +726,45 @@ extern "C" int32_t tnt_batchnorm_bwd_f32(const float* dy, const float* xhat, con
   }
   if (dx) {
     hipLaunchKernelGGL(bn_dx_kernel, dim3(ew_blocks((long)rows * C)), dim3(256), 0, s, dy, lddy, xhat, gamma, inv_std,
-                       dgamma, dbeta, dx, rows, C, training);
+                       dgamma, dbeta, dx, rows, C, training, rows);
     TNT_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+// ---- synchronised BatchNorm (data parallel, opt-in): the three pieces of tnt_batchnorm_{fwd,bwd}_f32 around the caller's
+// collectives.  stats: this replica's chunk partials (tnt_bn_nchunk(rows) * 2 * C floats); apply_stats: statistics of the
+// nrep replicas' all-gathered partials, moving statistics, then y / xhat; dx: the input gradient from sums taken over all
+// n_total rows (the caller all-reduces the local dgamma / dbeta sums of tnt_batchnorm_bwd_f32(dx = NULL)).
+extern "C" int32_t tnt_batchnorm_stats_f32(const float* x, int32_t rows, int32_t C, float* part, void* stream) {
+  if (rows <= 0 || C <= 0) return TNT_BADARG(1);
+  launch_col_partial<0>(x, C, nullptr, 0, rows, C, part, tnt_stream(stream));
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_batchnorm_apply_stats_f32(const float* part_all, int32_t nrep, const float* x, const float* gamma,
+                                                 const float* beta, float* mov_mean, float* mov_var, float* y, float* xhat,
+                                                 float* inv_std, int32_t rows, int32_t C, int32_t ldy, float eps,
+                                                 float momentum, float* mean_work, void* stream) {
+  if (rows <= 0 || C <= 0 || nrep <= 0) return TNT_BADARG(10);
+  hipStream_t s = tnt_stream(stream);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part_all, rows, C, chunk_count(rows), chunk_rows(rows), eps,
+                     momentum, mov_mean, mov_var, mean_work, inv_std, nrep);
+  TNT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks((long)rows * C)), dim3(256), 0, s, x, mean_work, inv_std, gamma, beta, y,
+                     xhat, rows, C, ldy);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_batchnorm_dx_f32(const float* dy, int32_t lddy, const float* xhat, const float* gamma,
+                                        const float* inv_std, const float* dgamma_sum, const float* dbeta_sum, float* dx,
+                                        int32_t rows, int32_t C, int32_t n_total, void* stream) {
+  if (rows <= 0 || C <= 0 || n_total < rows) return TNT_BADARG(8);
+  hipLaunchKernelGGL(bn_dx_kernel, dim3(ew_blocks((long)rows * C)), dim3(256), 0, tnt_stream(stream), dy, lddy, xhat, gamma,
+                     inv_std, dgamma_sum, dbeta_sum, dx, rows, C, 1, n_total);
+  TNT_LAUNCH_CHECK();
   return 0;
 }
 

@@ -276,14 +276,18 @@ def _sparse_norm_slot(model):
     return model.arena.sq_override[seg:seg + 1]
 
 
-def attach(model, world=None, bucket_elems=None, pipelined=None, rank=None):
+def attach(model, world=None, bucket_elems=None, pipelined=None, rank=None, sync_bn=False):
     """Make ``model`` data-parallel over the default process group.  The dense-encoder NIC and the attention NIC
     (incl. its multi-subject form) get their pipelined schedules unless pipelined=False; every other model the
     generic one (all-reduce of the whole arena between backward and update).
     Each replica draws its own dropout masks: the Philox key is derived from (seed, rank), so G replicas see G
     independent mask sets like G disjoint slices of one large batch would (rank 0 keeps the model's seed).  The
     "G ranks x local batch == one rank on the concatenated batch" contract is exact for the deterministic part of
-    the step (tests/test_dp_gloo.py, dropout-free) and statistical for the masks."""
+    the step (tests/test_dp_gloo.py, dropout-free) and statistical for the masks.
+    sync_bn=True: BatchNorm statistics over the GLOBAL batch (ModelBase._bn_fwd / _bn_bwd: an all-gather of the chunk
+    partials in the forward, an all-reduce of two sums per channel in the backward), which extends that contract to
+    BatchNorm encoders.  The collectives sit inside the forward / backward pass, so such a model runs the generic schedule
+    eagerly (no captured segments); per-replica statistics with the pipelined schedules remain the default."""
     world = dist.get_world_size() if world is None else world
     rank = dist.get_rank() if rank is None else rank
     model.dp_world = world
@@ -292,6 +296,10 @@ def attach(model, world=None, bucket_elems=None, pipelined=None, rank=None):
     from .lc_nic import NIC as AttentionNIC
     dense = type(model) is DenseNIC          # subclasses (fc mode) have other variables -> generic schedule
     att = isinstance(model, AttentionNIC) and hasattr(model, "_bwd_chain")
+    model.sync_bn = bool(sync_bn)
+    if sync_bn:
+        pipelined = False
+        model.use_graph = False
     if pipelined is None:
         pipelined = dense or att
     if pipelined and dense:

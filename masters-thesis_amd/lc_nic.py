@@ -422,9 +422,8 @@ class NIC(ModelBase):
             bn = self.bn_name(q)
             Fq, xh = self.Fs[0][r0:r1], self.xhat[r0 * R:r1 * R]
             if self.norm == "batch":
-                be.batchnorm_fwd(self.enc_y[r0:r1], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), self.mov_mean[q],
-                                 self.mov_var[q], Fq, xh, self.inv_std[q], Bs * R, D, D, training, BN_EPS, BN_MOMENTUM,
-                                 self.work)
+                self._bn_fwd(self.enc_y[r0:r1], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), self.mov_mean[q],
+                             self.mov_var[q], Fq, xh, self.inv_std[q], Bs * R, D, D, training, self.work)
             else:
                 be.layernorm_fwd(self.enc_y[r0:r1], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), Fq, xh, self.inv_std[q],
                                  Bs * R, D, D, BN_EPS)
@@ -438,8 +437,8 @@ class NIC(ModelBase):
                                  self.deep_y[i], B, R, D, 0.2)
             bn, q = f"input_bn/deep{i}", self.S + i
             if self.norm == "batch":
-                be.batchnorm_fwd(self.deep_y[i], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), self.mov_mean[q], self.mov_var[q], out,
-                                 self.deep_xhat[i], self.deep_istd[i], B * R, D, D, training, BN_EPS, BN_MOMENTUM, self.work)
+                self._bn_fwd(self.deep_y[i], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), self.mov_mean[q], self.mov_var[q], out,
+                             self.deep_xhat[i], self.deep_istd[i], B * R, D, D, training, self.work)
             else:
                 be.layernorm_fwd(self.deep_y[i], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), out, self.deep_xhat[i],
                                  self.deep_istd[i], B * R, D, D, BN_EPS)
@@ -736,8 +735,8 @@ class NIC(ModelBase):
             if self.r_feat > 0:
                 be.dropout(dF_enc, dF_enc, B * R, D, D, 0, D, 0, self.r_feat, sd, S_DEEP + i, 0, ds)
             if self.norm == "batch":
-                be.batchnorm_bwd(dF_enc, self.deep_xhat[i], a.p(f"{bn}/gamma"), self.deep_istd[i], self.dbn,
-                                 a.g(f"{bn}/gamma"), a.g(f"{bn}/beta"), B * R, D, D, True, self.work)
+                self._bn_bwd(dF_enc, self.deep_xhat[i], a.p(f"{bn}/gamma"), self.deep_istd[i], self.dbn,
+                             a.g(f"{bn}/gamma"), a.g(f"{bn}/beta"), B * R, D, D, self.work)
             else:
                 be.layernorm_bwd(dF_enc, self.deep_xhat[i], a.p(f"{bn}/gamma"), self.deep_istd[i], self.dbn,
                                  a.g(f"{bn}/gamma"), a.g(f"{bn}/beta"), B * R, D, D, self.work)
@@ -756,8 +755,8 @@ class NIC(ModelBase):
                 be.dropout(dFq, dFq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT + off, 0, ds)
             bn = self.bn_name(q)
             if self.norm == "batch":
-                be.batchnorm_bwd(dFq, xh, a.p(f"{bn}/gamma"), self.inv_std[q], dbn, a.g(f"{bn}/gamma"),
-                                 a.g(f"{bn}/beta"), Bs * R, D, D, True, self.work)
+                self._bn_bwd(dFq, xh, a.p(f"{bn}/gamma"), self.inv_std[q], dbn, a.g(f"{bn}/gamma"),
+                             a.g(f"{bn}/beta"), Bs * R, D, D, self.work)
             else:
                 be.layernorm_bwd(dFq, xh, a.p(f"{bn}/gamma"), self.inv_std[q], dbn, a.g(f"{bn}/gamma"),
                                  a.g(f"{bn}/beta"), Bs * R, D, D, self.work)

@@ -193,6 +193,47 @@ class ModelBase:
             be.sgd(a.theta, self.opt_m, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq, a.sq_override,
                    sp.nspan, 0.0, self.lr_dev, opt.momentum, clip, guard=gd)
 
+    # ------------------------------------------------------------------ BatchNorm, optionally synchronised across replicas
+    def _sync_bn_on(self):
+        """Synchronised BatchNorm (``sync_bn = True`` on a data-parallel model): batch statistics over the GLOBAL batch, so
+        G replicas x local batch train exactly like one process on the concatenated batch.  The reference has no
+        counterpart (it trains on one device); per-replica statistics remain the default.  The collectives sit inside
+        the forward / backward pass, so dp.attach puts such a model on the generic (non-pipelined, eager) schedule."""
+        return bool(getattr(self, "sync_bn", False) and self.dp_world > 1)
+
+    def _bn_fwd(self, x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, training, work):
+        be = self.be
+        if not (training and self._sync_bn_on()):
+            be.batchnorm_fwd(x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, training, BN_EPS, BN_MOMENTUM,
+                             work)
+            return
+        import torch.distributed as dist
+        n = be.bn_nchunk(rows) * 2 * C
+        part, allp = work[C:C + n], self._bn_scratch(self.dp_world * n)
+        be.batchnorm_stats(x, rows, C, part)
+        dist.all_gather(list(allp.view(self.dp_world, n).unbind(0)), part.contiguous())
+        be.batchnorm_apply_stats(allp, self.dp_world, x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, BN_EPS,
+                                 BN_MOMENTUM, work)
+
+    def _bn_bwd(self, dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, work):
+        be = self.be
+        if not self._sync_bn_on():
+            be.batchnorm_bwd(dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, True, work)
+            return
+        import torch.distributed as dist
+        # local sums stay in the gradient buffers (the replicas' gradients are averaged as usual); dx needs the global sums
+        be.batchnorm_bwd(dy, xhat, gamma, inv_std, None, dgamma, dbeta, rows, C, lddy, True, work)
+        sums = self._bn_scratch(2 * C)
+        sums[:C].copy_(dgamma.reshape(-1)[:C]); sums[C:2 * C].copy_(dbeta.reshape(-1)[:C])
+        dist.all_reduce(sums[:2 * C], op=dist.ReduceOp.SUM)
+        be.batchnorm_dx(dy, lddy, xhat, gamma, inv_std, sums[:C], sums[C:2 * C], dx, rows, C, rows * self.dp_world)
+
+    def _bn_scratch(self, n):
+        buf = self.__dict__.get("_bn_buf")
+        if buf is None or buf.numel() < n:
+            buf = self._bn_buf = self._f(n)
+        return buf[:n]
+
     def _emb_sparse_ok(self, E, ldd):
         """the sparse Embedding backward runs (single-process fused step)"""
         return bool(self.__dict__.get("_defer_sum2") and self.dp_world == 1 and getattr(self, "sparse_emb_bwd", True)

@@ -219,7 +219,8 @@ class NIC(ModelBase):
 
     def _fused_tail(self, B):
         """one-launch encoder tail (tnt_enc_tail_*): BatchNorm encoder, batch <= 256 rows, E % 4 == 0"""
-        return self.norm == "batch" and B <= 256 and self.E % 4 == 0 and getattr(self, "fuse_tail", True)
+        return (self.norm == "batch" and B <= 256 and self.E % 4 == 0 and getattr(self, "fuse_tail", True)
+                and not self._sync_bn_on())        # synchronised BatchNorm: the statistics leave the kernel for a collective
 
     # ------------------------------------------------------------------ forward
     def _forward(self, B, T, training):
@@ -271,8 +272,8 @@ class NIC(ModelBase):
                 be.dropout(self.enc_y, self.enc_yd, B, E, E, 0, E, 0, self.r_feat, sd, S_FEAT, 0, ds)
                 y = self.enc_yd
             if self.norm == "batch":                                                    # :127-128
-                be.batchnorm_fwd(y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.mov_mean, self.mov_var,
-                                 self.Xin, self.xhat, self.inv_std, B, E, E, training, BN_EPS, BN_MOMENTUM, self.work)
+                self._bn_fwd(y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.mov_mean, self.mov_var,
+                             self.Xin, self.xhat, self.inv_std, B, E, E, training, self.work)
             else:
                 be.layernorm_fwd(y, a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.Xin, self.xhat,
                                  self.inv_std, B, E, E, BN_EPS)
@@ -433,8 +434,8 @@ class NIC(ModelBase):
                             self.r_feat, self.r_lstm, 0.2, sd, S_FEAT, S_LSTM_IN + 0, ds)
             return
         if self.norm == "batch":
-            be.batchnorm_bwd(self.dXin, self.xhat, a.p("batch_norm/gamma"), self.inv_std, self.dyd,
-                             a.g("batch_norm/gamma"), a.g("batch_norm/beta"), B, E, E, True, self.work)
+            self._bn_bwd(self.dXin, self.xhat, a.p("batch_norm/gamma"), self.inv_std, self.dyd,
+                         a.g("batch_norm/gamma"), a.g("batch_norm/beta"), B, E, E, self.work)
         else:
             be.layernorm_bwd(self.dXin, self.xhat, a.p("batch_norm/gamma"), self.inv_std, self.dyd,
                              a.g("batch_norm/gamma"), a.g("batch_norm/beta"), B, E, E, self.work)

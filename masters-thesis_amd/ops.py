@@ -104,6 +104,19 @@ class HipBackend:
         self._call(self.lib.tnt_batchnorm_bwd_f32, "tnt_batchnorm_bwd_f32", _p(dy), _p(xhat), _p(gamma), _p(inv_std), _p(dx), _p(dgamma),
                                                   _p(dbeta), rows, C, lddy, int(training), _p(work), self._s())
 
+    def batchnorm_stats(self, x, rows, C, part):
+        self._call(self.lib.tnt_batchnorm_stats_f32, "tnt_batchnorm_stats_f32", _p(x), rows, C, _p(part), self._s())
+
+    def batchnorm_apply_stats(self, part_all, nrep, x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, eps,
+                              momentum, mean_work):
+        self._call(self.lib.tnt_batchnorm_apply_stats_f32, "tnt_batchnorm_apply_stats_f32", _p(part_all), nrep, _p(x), _p(gamma),
+                   _p(beta), _p(mov_mean), _p(mov_var), _p(y), _p(xhat), _p(inv_std), rows, C, ldy, eps, momentum, _p(mean_work),
+                   self._s())
+
+    def batchnorm_dx(self, dy, lddy, xhat, gamma, inv_std, dgamma_sum, dbeta_sum, dx, rows, C, n_total):
+        self._call(self.lib.tnt_batchnorm_dx_f32, "tnt_batchnorm_dx_f32", _p(dy), lddy, _p(xhat), _p(gamma), _p(inv_std),
+                   _p(dgamma_sum), _p(dbeta_sum), _p(dx), rows, C, n_total, self._s())
+
     def layernorm_fwd(self, x, gamma, beta, y, xhat, inv_std, rows, C, ldy, eps):
         self._call(self.lib.tnt_layernorm_fwd_f32, "tnt_layernorm_fwd_f32", _p(x), _p(gamma), _p(beta), _p(y), _p(xhat), _p(inv_std), rows, C,
                                                   ldy, eps, self._s())

@@ -44,7 +44,7 @@ class MockBackend:
     name = "mock-cpu"
 
     def bn_nchunk(self, rows):
-        return (rows + 63) // 64
+        return max(2, (rows + 63) // 64)        # >= 2: the mock's synchronised-BatchNorm partials need 3 * C floats
 
     # ---------------------------------------------------------------- gemm
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, pre=None, act=0,
@@ -122,6 +122,36 @@ class MockBackend:
         if dgamma is not None:
             flat(dgamma)[:C] = dg
             flat(dbeta)[:C] = db
+
+    # synchronised BatchNorm pieces: the mock's "partials" are per-column (n, sum, sum of squares) in float64-exact float32s
+    def batchnorm_stats(self, x, rows, C, part):
+        xs = mat(x, rows, C, C).astype(np.float64)
+        p = flat(part)
+        p[:self.bn_nchunk(rows) * 2 * C] = 0
+        p[0:C] = rows; p[C:2 * C] = xs.sum(0); p[2 * C:3 * C] = (xs * xs).sum(0)
+
+    def batchnorm_apply_stats(self, part_all, nrep, x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, eps,
+                              momentum, mean_work):
+        stride = self.bn_nchunk(rows) * 2 * C
+        p = flat(part_all)[:nrep * stride].reshape(nrep, stride)[:, :3 * C].reshape(nrep, 3, C).astype(np.float64)
+        n, s1, s2 = p[:, 0].sum(0), p[:, 1].sum(0), p[:, 2].sum(0)
+        mean = s1 / n
+        var = s2 / n - mean * mean
+        inv = 1.0 / np.sqrt(var + eps)
+        xs = mat(x, rows, C, C).astype(np.float64)
+        xh = (xs - mean) * inv
+        mat(xhat, rows, C, C)[...] = xh
+        mat(y, rows, C, ldy)[...] = xh * flat(gamma)[:C] + flat(beta)[:C]
+        flat(inv_std)[:C] = inv
+        mm, mv = flat(mov_mean)[:C], flat(mov_var)[:C]
+        mm[...] = mm * momentum + mean * (1 - momentum)
+        mv[...] = mv * momentum + var * (1 - momentum)
+
+    def batchnorm_dx(self, dy, lddy, xhat, gamma, inv_std, dgamma_sum, dbeta_sum, dx, rows, C, n_total):
+        g = mat(dy, rows, C, lddy).astype(np.float64)
+        xh = mat(xhat, rows, C, C).astype(np.float64)
+        k = flat(gamma)[:C].astype(np.float64) * flat(inv_std)[:C]
+        mat(dx, rows, C, C)[...] = k / n_total * (n_total * g - flat(dbeta_sum)[:C] - xh * flat(dgamma_sum)[:C])
 
     def ln_lstm_cell_fwd(self, zk, zr, bias, c_prev, gamma_s, beta_s, gates, chat, istd, c, h, B, U, eps):
         """include/tnt_hip.h: tnt_ln_lstm_cell_fwd_f32 (gate-interleaved [B][U][4] tensors)"""

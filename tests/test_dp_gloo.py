@@ -104,6 +104,86 @@ def test_dp2_equals_single_process(kind):
         ops.set_backend(old)
 
 
+def _worker_syncbn(rank, world, port, kind, q):
+    sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import masters_thesis_amd.ops as ops
+    from masters_thesis_amd import dp
+    from masters_thesis_amd.optimizers import Adam
+    from mock_backend import MockBackend
+    ops.set_backend(MockBackend())
+    model = _make_bn(kind, seed=100 + rank)
+    model.compile(Adam(1e-3, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    dp.attach(model, sync_bn=True)
+    rng = np.random.default_rng(7)
+    losses = []
+    for step in range(2):
+        data, tgt = _global_batch(rng, world)
+        sl = slice(rank * DIMS["B"], (rank + 1) * DIMS["B"])
+        m = model.train_step((tuple(a[sl] for a in data), tgt[sl]))
+        losses.append(float(dp.allreduce_metrics(m)["loss"]))
+    q.put((rank, model.get_weights_dict(), losses, type(model.grad_sync).__name__))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _make_bn(kind, seed):
+    d = DIMS
+    if kind == "nic":
+        from masters_thesis_amd.nic import NIC
+        return NIC(d["N"], d["U"], d["E"], d["V"], d["T"], 0.0, 0.0, 0.0, 0.01, 3e-5, 1e-5, norm="batch", device="cpu",
+                   seed=seed)
+    from masters_thesis_amd.lc_nic import NIC
+    from helpers import tiny_groups
+    g = (tiny_groups(d["N"], 4, np.random.default_rng(3)), [16] * 4)
+    return NIC(g, d["U"], 512, d["E"], 6, d["V"], d["T"], 0, 0, 0, 0, 0, 0, 0.01, 0.001, 3e-5, 1e-5, norm="batch",
+               device="cpu", seed=seed)
+
+
+@pytest.mark.parametrize("kind", ["nic", "lcnic"])
+def test_dp2_sync_batchnorm_equals_single_process_on_the_global_batch(kind):
+    """dp.attach(sync_bn=True): BatchNorm statistics over the global batch (all-gathered chunk partials in the forward,
+    all-reduced sums in the backward) -- two replicas on half batches train like ONE process on the whole batch, moving
+    statistics included, with the BatchNorm encoders of both model families."""
+    world, port = 2, 33500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_syncbn, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, w, losses, sched = q.get(timeout=120)
+        res[r] = (w, losses, sched)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][2] == "function" or "Pipelined" not in res[0][2]           # generic schedule
+    for k in res[0][0]:
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k                    # replicas identical, moving statistics too
+    sys.path.insert(0, HERE)
+    import masters_thesis_amd.ops as ops
+    from masters_thesis_amd.optimizers import Adam
+    from mock_backend import MockBackend
+    old = ops._backend
+    ops.set_backend(MockBackend())
+    try:
+        ref = _make_bn(kind, seed=100)
+        ref.compile(Adam(1e-3, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+        rng = np.random.default_rng(7)
+        for step in range(2):
+            data, tgt = _global_batch(rng, world)
+            m = ref.train_step((data, tgt)).as_floats()
+            assert abs(m["loss"] - res[0][1][step]) < 1e-5, (step, m["loss"], res[0][1][step])
+        for k, v in ref.get_weights_dict().items():
+            if k == "attention/V/bias":
+                continue
+            assert np.allclose(res[0][0][k], v, rtol=1e-4, atol=5e-6), (k, np.abs(res[0][0][k] - v).max())
+    finally:
+        ops.set_backend(old)
+
+
 def _worker_bn(rank, world, port, tmp, q):
     sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)

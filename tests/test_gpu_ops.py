@@ -1433,3 +1433,47 @@ def test_bias_act_drop_bwd_and_colsum_multi(be, T, B, C, rate, V):
     o1, o2, o3 = (torch.full((k,), 7.0, device="cuda") for k in (C, 5, 1))
     be.colsum_multi([(ad, o1, rows, C, C), (bd, o2, B, 5, 5), (bd.view(-1)[4:], o3, B, 1, 5)])
     close(o1, a_.sum(0), rtol=1e-5); close(o2, b_.sum(0), rtol=1e-5); close(o3, b_[:, 4:5].sum(0), rtol=1e-5)
+
+
+@pytest.mark.parametrize("rows,C", [(23040, 32), (64, 512), (130, 12)])
+def test_sync_batchnorm_pieces(be, rows, C):
+    """tnt_batchnorm_stats / apply_stats / dx (the pieces of BatchNorm around the data-parallel collectives): two "replicas"
+    holding the halves of one batch, their partials concatenated as an all-gather would, reproduce tnt_batchnorm_fwd/bwd of
+    the whole batch (statistics, moving statistics, outputs, input gradient); one replica reproduces it trivially."""
+    rng = np.random.default_rng(rows + C)
+    x, dy = rng.standard_normal((2 * rows, C)) * 2 + 0.5, rng.standard_normal((2 * rows, C))
+    gamma, beta = 1 + 0.1 * rng.standard_normal(C), 0.1 * rng.standard_normal(C)
+    mm0, mv0 = 0.1 * rng.standard_normal(C), 1 + 0.1 * rng.random(C)
+    f = lambda *sh: torch.zeros(*sh, device="cuda")
+    nch = be.bn_nchunk(2 * rows)
+    work = f(C * (2 * nch + 1))
+    # whole batch, existing entry points
+    mm_w, mv_w, y_w, xh_w, inv_w = dev(mm0), dev(mv0), f(2 * rows, C), f(2 * rows, C), f(max(2 * rows, C))
+    be.batchnorm_fwd(dev(x), dev(gamma), dev(beta), mm_w, mv_w, y_w, xh_w, inv_w, 2 * rows, C, C, True, 1e-3, 0.99, work)
+    dx_w, dg_w, db_w = f(2 * rows, C), f(C), f(C)
+    be.batchnorm_bwd(dev(dy), xh_w, dev(gamma), inv_w, dx_w, dg_w, db_w, 2 * rows, C, C, True, work)
+    # two replicas
+    n1 = be.bn_nchunk(rows) * 2 * C
+    allp = f(2 * n1)
+    xs = [dev(x[:rows]), dev(x[rows:])]
+    for r in range(2):
+        be.batchnorm_stats(xs[r], rows, C, allp[r * n1:(r + 1) * n1])
+    sums = f(2 * C)
+    outs = []
+    for r in range(2):
+        mm, mv, y, xh, inv, mw = dev(mm0), dev(mv0), f(rows, C), f(rows, C), f(max(rows, C)), f(C)
+        be.batchnorm_apply_stats(allp, 2, xs[r], dev(gamma), dev(beta), mm, mv, y, xh, inv, rows, C, C, 1e-3, 0.99, mw)
+        dg, db = f(C), f(C)
+        be.batchnorm_bwd(dev(dy[r * rows:(r + 1) * rows]), xh, dev(gamma), inv, None, dg, db, rows, C, C, True, work)
+        sums[:C] += dg; sums[C:] += db
+        outs.append((mm, mv, y, xh, inv))
+    for r in range(2):
+        mm, mv, y, xh, inv = outs[r]
+        sl = slice(r * rows, (r + 1) * rows)
+        close(mm, mm_w.cpu().numpy(), rtol=2e-6); close(mv, mv_w.cpu().numpy(), rtol=2e-5)
+        close(y, y_w[sl].cpu().numpy(), rtol=2e-5); close(xh, xh_w[sl].cpu().numpy(), rtol=2e-5)
+        close(inv[:C], inv_w[:C].cpu().numpy(), rtol=2e-5)
+        dx = f(rows, C)
+        be.batchnorm_dx(dev(dy[sl]), C, xh, dev(gamma), inv, sums[:C], sums[C:], dx, rows, C, 2 * rows)
+        close(dx, dx_w[sl].cpu().numpy(), rtol=5e-5)
+    close(sums[:C], dg_w.cpu().numpy(), rtol=2e-5); close(sums[C:], db_w.cpu().numpy(), rtol=2e-5)
