@@ -315,64 +315,51 @@ struct FinalizeArgs {
 };
 
 __global__ __launch_bounds__(1024) void step_finalize_kernel(FinalizeArgs a) {
-  __shared__ float sw[16], sw2[16];
+  // One workgroup, ONE barrier: every job's global loads are issued up front and its per-thread partial kept in a register
+  // (the jobs used to run one after the other, each a cold load round trip + a barrier pair: 8 us back to back, 13 us inside
+  // the captured step, where every input was just written by other CUs), then all wave partials meet in LDS once and four
+  // different threads finish the four scalars while a fifth ticks the step counters.
+  __shared__ float sw[4][16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  // (1) small variables (<= 8 spans: every variable of the region-wise model, hundreds of them) one per THREAD, serially
-  // over their spans; large ones one per wave, lanes striding over the spans + a fixed shuffle tree.  (A wave per small
-  // variable would walk 700+ variables 16 at a time, each step a dependent load pair: ~30 us on the attention model.)
+  float l = 0.f, s0 = 0.f, s1 = 0.f, e = 0.f;
+  // (1) per-variable norms.  Small variables (<= 8 spans: every variable of the region-wise model, hundreds of them) one per
+  // THREAD, serially over their spans; large ones one per wave, lanes striding over the spans + a fixed shuffle tree.  (A wave
+  // per small variable would walk 700+ variables 16 at a time, each step a dependent load pair: ~30 us on the attention
+  // model.)  (2) The L2 metric sum_s lambda_s ||theta_s||^2 is accumulated from the same sums.
   for (int s = tid; s < a.nseg; s += 1024) {
     const int k0 = a.t.seg_first[s], k1 = a.t.seg_first[s + 1];
     if (k1 - k0 > 8) continue;
     float q = 0.f, ws = 0.f;
     for (int k = k0; k < k1; ++k) { q += a.partial[2 * k]; ws += a.partial[2 * k + 1]; }
     a.sq[s] = q; a.wsq[s] = ws;
+    l += a.t.seg_l2[s] * ws;
   }
+  // (3) loss / accuracy totals, (4) extra partials (the Embedding's sparse norm), ids hand-over: loads in flight together
+  for (int i = tid; i < a.n; i += 1024) { s0 += a.x0[i]; if (a.x1) s1 += a.x1[i]; }
+  for (int i = tid; i < a.n_extra; i += 1024) e += a.extra_part[i];
+  for (int i = tid; i < a.n_ids; i += 1024) a.ids_dst[i] = a.ids_src[i];
   for (int s = w; s < a.nseg; s += 16) {
     const int k0 = a.t.seg_first[s], k1 = a.t.seg_first[s + 1];
     if (k1 - k0 <= 8) continue;                 // wave-uniform
     float q = 0.f, ws = 0.f;
     for (int k = k0 + lane; k < k1; k += 64) { q += a.partial[2 * k]; ws += a.partial[2 * k + 1]; }
     q = tnt_wave_sum(q); ws = tnt_wave_sum(ws);
-    if (lane == 0) { a.sq[s] = q; a.wsq[s] = ws; }
+    if (lane == 0) { a.sq[s] = q; a.wsq[s] = ws; l += a.t.seg_l2[s] * ws; }
   }
+  l = tnt_wave_sum(l); s0 = tnt_wave_sum(s0); s1 = tnt_wave_sum(s1); e = tnt_wave_sum(e);
+  if (lane == 0) { sw[0][w] = l; sw[1][w] = s0; sw[2][w] = s1; sw[3][w] = e; }
   __syncthreads();
-  // (2)
-  if (a.l2_out != nullptr) {
-    float l = 0.f;
-    for (int s = tid; s < a.nseg; s += 1024) l += a.t.seg_l2[s] * a.wsq[s];
-    l = tnt_wave_sum(l);
-    if (lane == 0) sw[w] = l;
-    __syncthreads();
-    if (tid == 0) { float t = 0.f; for (int k = 0; k < 16; ++k) t += sw[k]; a.l2_out[0] = t; }
-    __syncthreads();
+  if (lane == 0 && w < 4) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sw[w][k];
+    if (w == 0 && a.l2_out != nullptr) a.l2_out[0] = t;
+    if (w == 1 && a.n > 0) a.out0[0] = t * a.scale;
+    if (w == 2 && a.n > 0 && a.x1) a.out1[0] = t * a.scale;
+    if (w == 3 && a.n_extra > 0) a.extra[0] = t;
   }
-  // (3)
-  if (a.n > 0) {
-    float s0 = 0.f, s1 = 0.f;
-    for (int i = tid; i < a.n; i += 1024) { s0 += a.x0[i]; if (a.x1) s1 += a.x1[i]; }
-    s0 = tnt_wave_sum(s0); s1 = tnt_wave_sum(s1);
-    if (lane == 0) { sw[w] = s0; sw2[w] = s1; }
-    __syncthreads();
-    if (tid == 0) {
-      float t0 = 0.f, t1 = 0.f;
-      for (int k = 0; k < 16; ++k) { t0 += sw[k]; t1 += sw2[k]; }
-      a.out0[0] = t0 * a.scale;
-      if (a.x1) a.out1[0] = t1 * a.scale;
-    }
-    __syncthreads();
-  }
-  // (4)
-  if (a.n_extra > 0) {
-    float e = 0.f;
-    for (int i = tid; i < a.n_extra; i += 1024) e += a.extra_part[i];
-    e = tnt_wave_sum(e);
-    if (lane == 0) sw[w] = e;
-    __syncthreads();
-    if (tid == 0) { float t = 0.f; for (int k = 0; k < 16; ++k) t += sw[k]; a.extra[0] = t; }
-  }
-  for (int i = tid; i < a.n_ids; i += 1024) a.ids_dst[i] = a.ids_src[i];
   // (5)
-  if (tid == 0 && !(a.guard && a.guard[0] != 0u)) {
+  if (tid == 256 && !(a.guard && a.guard[0] != 0u)) {
     if (a.drop_step) a.drop_step[0] += 1u;
     if (a.adam_t) {
       const int64_t t = a.adam_t[0] + 1;
