@@ -197,6 +197,13 @@ int32_t tnt_dense_fwd_stream_gram_f32(const float* x, const float* w, float* par
 int32_t tnt_dense_gram_norm_f32(const float* dpre, const float* pre, const float* bias, const float* gx_part,
                                 int32_t nsplit, const float* w2_part, int32_t nw2, float l2, float* partial,
                                 int32_t nslot, int32_t Bk, int32_t E, void* stream);
+/* ... with tnt_span_sqnorm_f32's job for the other variables (same arguments: the span tables and partial buffer of the
+ * nspan spans that are NOT this variable's) riding in the same launch */
+int32_t tnt_dense_gram_norm_spans_f32(const float* dpre, const float* pre, const float* bias, const float* gx_part,
+                                      int32_t nsplit, const float* w2_part, int32_t nw2, float l2, float* partial,
+                                      int32_t nslot, int32_t Bk, int32_t E, const float* theta, const float* grad,
+                                      const int32_t* span_seg, const int64_t* span_off, const int32_t* span_len,
+                                      const float* seg_l2, float* span_partial, int32_t nspan, void* stream);
 
 /* ---- weight gradient of the dense voxel encoder at small batch:  dw[N][E] = x^T @ dpre --------------
  * x [Bk][ldx] (the betas, Bk <= 64 rows), dpre [Bk][E] (E % 32 == 0, E <= 512, 16-byte aligned), dw [N][E].
@@ -244,6 +251,16 @@ int32_t tnt_enc_tail_bwd_f32(const float* dout, const float* xhat, const float* 
                              int32_t rows, int32_t C, int32_t ldo, float r_feat, float r_lstm, float slope,
                              uint64_t seed, uint32_t site_feat, uint32_t site_lstm,
                              const uint32_t* step_dev, void* stream);
+/* bwd with an independent in-place dropout' job in the same launch: drop_x [drop_rows][drop_cols] (row stride drop_ld) gets
+ * the keep mask of stream (seed, drop_site, *step_dev) in the logical layout arguments of tnt_dropout_f32 -- the text
+ * call's LSTM-input dropout over the other rows of the same gradient buffer (NIC.py:131,140).  All % 4 == 0. */
+int32_t tnt_enc_tail_bwd_drop_f32(const float* dout, const float* xhat, const float* gamma, const float* inv_std,
+                                  const float* pre, float* dpre, float* dgamma, float* dbeta, float* dbias, int32_t rows,
+                                  int32_t C, int32_t ldo, float r_feat, float r_lstm, float slope, uint64_t seed,
+                                  uint32_t site_feat, uint32_t site_lstm, const uint32_t* step_dev, float* drop_x,
+                                  int32_t drop_rows, int32_t drop_cols, int32_t drop_ld, int32_t drop_tmajor_B,
+                                  int32_t drop_lwidth, int32_t drop_lcol0, float drop_rate, uint32_t drop_site,
+                                  void* stream);
 
 /* ---- LayerNormalization(axis=-1) (layers.py:41 alternative; BASELINE north_star) - */
 int32_t tnt_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,

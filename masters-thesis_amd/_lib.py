@@ -57,12 +57,15 @@ SIGNATURES = {
     "tnt_argmax_rows_f32": [P, P, I32, I32, I32, P],
     "tnt_enc_tail_fwd_f32": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, F32, F32, F32, F32, U64, U32, U32, P, P],
     "tnt_enc_tail_bwd_f32": [P, P, P, P, P, P, P, P, P, I32, I32, I32, F32, F32, F32, U64, U32, U32, P, P],
+    "tnt_enc_tail_bwd_drop_f32": [P, P, P, P, P, P, P, P, P, I32, I32, I32, F32, F32, F32, U64, U32, U32, P, P, I32, I32, I32, I32,
+                                  I32, I32, F32, U32, P],
     "tnt_embedding_fwd_drop_f32": [P, P, P, P, I32, I32, I32, I32, I32, F32, U64, U32, U32, P, P],
     "tnt_dense_dw_skinny_f32": [P, P, P, I32, I32, I32, I32, P],
     "tnt_dense_dw_sqnorm_f32": [P, P, P, F32, P, I32, I32, I32, I32, I32, P],
     "tnt_dense_dw_adam_f32": [P, P, P, P, P, F32, P, P, P, F32, F32, F32, F32, P, I32, I32, I32, I32, P],
     "tnt_dense_fwd_stream_gram_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, P],
     "tnt_dense_gram_norm_f32": [P, P, P, P, I32, P, I32, F32, P, I32, I32, I32, P],
+    "tnt_dense_gram_norm_spans_f32": [P, P, P, P, I32, P, I32, F32, P, I32, I32, I32, P, P, P, P, P, P, P, I32, P],
     "tnt_dense_fwd_stream_f32": [P, P, P, I32, I32, I32, I32, I32, I32, P],
     "tnt_enc_tail_fwd_sk_f32": [P, I32, P, P, F32, P, P, P, P, P, P, P, I32, I32, I32, I32, F32, F32, F32, F32, U64, U32,
                                 U32, P, P],

@@ -744,11 +744,49 @@ extern "C" int32_t tnt_dense_fwd_stream_gram_f32(const float* x, const float* w,
 // (q = 4 l2^2 w, wq = w) and zeroes the rest.
 namespace {
 constexpr int GN_Q = 4;        // workgroups per row b: 16 columns b' of the Gram contraction each
+// The span norms of every OTHER variable of the step (tnt_span_sqnorm_f32's job) ride in the same launch as extra
+// workgroups: both are inputs of the same finalize launch, and a launch less is ~4 us of the captured step.
+struct GnSpans {
+  const float* theta; const float* grad; const int32_t* span_seg; const int64_t* span_off; const int32_t* span_len;
+  const float* seg_l2; float* partial; int nspan;
+};
+
 __global__ __launch_bounds__(256) void dense_gram_norm_kernel(const float* dpre, const float* pre, const float* bias,
                                                               const float* gx_part, int nsplit, const float* w2_part,
-                                                              int nw2, float l2, float* partial, int nslot, int Bk, int E) {
+                                                              int nw2, float l2, float* partial, int nslot, int Bk, int E,
+                                                              GnSpans sp) {
   __shared__ double sd[256];
   const int tid = threadIdx.x;
+  if ((int)blockIdx.x > GN_Q * Bk) {
+    // ---- span role: partial[2 s] = sum (g + 2 lambda theta)^2, partial[2 s + 1] = sum theta^2 over span s (optim.hip)
+    __shared__ float s0[4], s1[4];
+    const int s = blockIdx.x - (GN_Q * Bk + 1);
+    if (s >= sp.nspan) return;
+    const long off = sp.span_off[s];
+    const int len = sp.span_len[s];
+    const float lam2 = 2.f * sp.seg_l2[sp.span_seg[s]];
+    float q = 0.f, wq = 0.f;
+    const int len4 = len & ~3;
+    for (int i = tid * 4; i < len4; i += 1024) {
+      const float4 g = *reinterpret_cast<const float4*>(sp.grad + off + i);
+      const float4 w = *reinterpret_cast<const float4*>(sp.theta + off + i);
+      const float a0 = g.x + lam2 * w.x, a1 = g.y + lam2 * w.y, a2 = g.z + lam2 * w.z, a3 = g.w + lam2 * w.w;
+      q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+      wq += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+    }
+    for (int i = len4 + tid; i < len; i += 256) {
+      const float w = sp.theta[off + i], a0 = sp.grad[off + i] + lam2 * w;
+      q += a0 * a0; wq += w * w;
+    }
+    q = tnt_wave_sum(q); wq = tnt_wave_sum(wq);
+    if ((tid & 63) == 0) { s0[tid >> 6] = q; s1[tid >> 6] = wq; }
+    __syncthreads();
+    if (tid == 0) {
+      sp.partial[2 * s + 0] = s0[0] + s0[1] + s0[2] + s0[3];
+      sp.partial[2 * s + 1] = s1[0] + s1[1] + s1[2] + s1[3];
+    }
+    return;
+  }
   if ((int)blockIdx.x == GN_Q * Bk) {
     for (int k = tid; k < nslot - GN_Q * Bk; k += 256) {
       const float w = k < nw2 ? w2_part[k] : 0.f;
@@ -796,15 +834,32 @@ __global__ __launch_bounds__(256) void dense_gram_norm_kernel(const float* dpre,
 }
 }  // namespace
 
+static int32_t gram_norm_launch(const float* dpre, const float* pre, const float* bias, const float* gx_part, int32_t nsplit,
+                                const float* w2_part, int32_t nw2, float l2, float* partial, int32_t nslot, int32_t Bk,
+                                int32_t E, const GnSpans& sp, void* stream) {
+  if (Bk <= 0 || Bk > 64 || E <= 0 || E % 64 != 0 || nsplit <= 0 || nw2 <= 0 || nslot < GN_Q * Bk + nw2) return TNT_BADARG(9);
+  if (!tnt_aligned16(dpre)) return TNT_BADARG(0);
+  hipLaunchKernelGGL(dense_gram_norm_kernel, dim3(GN_Q * Bk + 1 + sp.nspan), dim3(256), 0, tnt_stream(stream), dpre, pre, bias,
+                     gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E, sp);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int32_t tnt_dense_gram_norm_f32(const float* dpre, const float* pre, const float* bias, const float* gx_part,
                                            int32_t nsplit, const float* w2_part, int32_t nw2, float l2, float* partial,
                                            int32_t nslot, int32_t Bk, int32_t E, void* stream) {
-  if (Bk <= 0 || Bk > 64 || E <= 0 || E % 64 != 0 || nsplit <= 0 || nw2 <= 0 || nslot < GN_Q * Bk + nw2) return TNT_BADARG(9);
-  if (!tnt_aligned16(dpre)) return TNT_BADARG(0);
-  hipLaunchKernelGGL(dense_gram_norm_kernel, dim3(GN_Q * Bk + 1), dim3(256), 0, tnt_stream(stream), dpre, pre, bias,
-                     gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E);
-  TNT_LAUNCH_CHECK();
-  return 0;
+  return gram_norm_launch(dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E, GnSpans{}, stream);
+}
+
+extern "C" int32_t tnt_dense_gram_norm_spans_f32(const float* dpre, const float* pre, const float* bias,
+                                                 const float* gx_part, int32_t nsplit, const float* w2_part, int32_t nw2,
+                                                 float l2, float* partial, int32_t nslot, int32_t Bk, int32_t E,
+                                                 const float* theta, const float* grad, const int32_t* span_seg,
+                                                 const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
+                                                 float* span_partial, int32_t nspan, void* stream) {
+  if (nspan < 0 || (nspan > 0 && (theta == nullptr || grad == nullptr || span_partial == nullptr))) return TNT_BADARG(19);
+  return gram_norm_launch(dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E,
+                          GnSpans{theta, grad, span_seg, span_off, span_len, seg_l2, span_partial, nspan}, stream);
 }
 
 namespace {

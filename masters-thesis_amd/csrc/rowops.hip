@@ -461,6 +461,9 @@ struct EncTailArgs {
   uint64_t seed; uint32_t site_feat, site_lstm; const uint32_t* step_dev;
   // forward from split-K partials (SK): y = leaky(sum_s part[s] + bias), pre-activation kept for the backward
   const float* part; const float* bias; float* pre_out; int nsplit;
+  // backward: an independent in-place dropout' job riding in the same launch (blocks >= nb_tail; rate 0: none) -- the text
+  // call's LSTM-input dropout over the other rows of the same gradient buffer (NIC.py:131,140)
+  DropArgs drop; int nb_tail;
 };
 
 // column sums of a per-thread float4 over the 32 row groups, fixed order; result valid in every thread
@@ -572,6 +575,25 @@ __global__ __launch_bounds__(256) void enc_tail_fwd_kernel(EncTailArgs a) {
 }
 
 __global__ __launch_bounds__(256) void enc_tail_bwd_kernel(EncTailArgs a) {
+  if (a.drop.rate > 0.f && (int)blockIdx.x >= a.nb_tail) {          // the riding dropout' job (as dropout4_kernel)
+    const DropArgs& d = a.drop;
+    const uint32_t dstep = d.step + (d.step_dev ? d.step_dev[0] : 0u);
+    const int c4n = d.cols >> 2, nbk = gridDim.x - a.nb_tail;
+    const long total = (long)d.rows * c4n;
+    const int T = d.tB > 0 ? d.rows / d.tB : 0;
+    for (long e = (long)(blockIdx.x - a.nb_tail) * 256 + threadIdx.x; e < total; e += (long)nbk * 256) {
+      const int r = (int)(e / c4n), c = (int)(e % c4n) * 4;
+      long lrow; uint32_t site;
+      drop_row(d, r, T, lrow, site);
+      bool k[4];
+      tnt_keep4((uint64_t)lrow * (uint64_t)d.lwidth + (uint64_t)(d.lcol0 + c), d.rate, d.seed, site, dstep, k);
+      const long o = (long)r * d.ld + c;
+      const float4 v = *reinterpret_cast<const float4*>(d.x + o);
+      *reinterpret_cast<float4*>(d.y + o) = make_float4(k[0] ? v.x * d.scale : 0.f, k[1] ? v.y * d.scale : 0.f,
+                                                        k[2] ? v.z * d.scale : 0.f, k[3] ? v.w * d.scale : 0.f);
+    }
+    return;
+  }
   __shared__ float4 red[ET_RG][ET_CW / 4];
   const int c4 = threadIdx.x % (ET_CW / 4), rg = threadIdx.x / (ET_CW / 4);
   const int col = blockIdx.x * ET_CW + 4 * c4;
@@ -680,7 +702,36 @@ extern "C" int32_t tnt_enc_tail_bwd_f32(const float* dout, const float* xhat, co
   a.dout = dout; a.xhat = const_cast<float*>(xhat); a.gamma = gamma; a.inv_std = const_cast<float*>(inv_std); a.pre = pre; a.dpre = dpre; a.dgamma = dgamma;
   a.dbeta = dbeta; a.dbias = dbias; a.rows = rows; a.C = C; a.ldo = ldo; a.r_feat = r_feat; a.r_lstm = r_lstm;
   a.slope = slope; a.seed = seed; a.site_feat = site_feat; a.site_lstm = site_lstm; a.step_dev = step_dev;
-  hipLaunchKernelGGL(enc_tail_bwd_kernel, dim3((C + ET_CW - 1) / ET_CW), dim3(256), 0, tnt_stream(stream), a);
+  a.nb_tail = (C + ET_CW - 1) / ET_CW;
+  hipLaunchKernelGGL(enc_tail_bwd_kernel, dim3(a.nb_tail), dim3(256), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_enc_tail_bwd_drop_f32(const float* dout, const float* xhat, const float* gamma, const float* inv_std,
+                                             const float* pre, float* dpre, float* dgamma, float* dbeta, float* dbias,
+                                             int32_t rows, int32_t C, int32_t ldo, float r_feat, float r_lstm, float slope,
+                                             uint64_t seed, uint32_t site_feat, uint32_t site_lstm, const uint32_t* step_dev,
+                                             float* drop_x, int32_t drop_rows, int32_t drop_cols, int32_t drop_ld,
+                                             int32_t drop_tmajor_B, int32_t drop_lwidth, int32_t drop_lcol0, float drop_rate,
+                                             uint32_t drop_site, void* stream) {
+  if (rows <= 0 || rows > ET_RG * ET_MAXR) return TNT_BADARG(10);
+  if (C <= 0 || C % 4 != 0 || ldo < C || ldo % 4 != 0) return TNT_BADARG(11);
+  if (!tnt_aligned16(dout) || !tnt_aligned16(xhat) || !tnt_aligned16(gamma) || !tnt_aligned16(inv_std) || !tnt_aligned16(pre) ||
+      !tnt_aligned16(dpre) || !tnt_aligned16(dgamma) || !tnt_aligned16(dbeta) || !tnt_aligned16(dbias)) return TNT_BADARG(1);
+  if (drop_rate < 0.f || drop_rate >= 1.f || drop_rows <= 0 || ((drop_cols | drop_ld | drop_lwidth | drop_lcol0) & 3) != 0 ||
+      !tnt_aligned16(drop_x) || (drop_tmajor_B > 0 && drop_rows % drop_tmajor_B != 0)) return TNT_BADARG(20);
+  EncTailArgs a{};
+  a.dout = dout; a.xhat = const_cast<float*>(xhat); a.gamma = gamma; a.inv_std = const_cast<float*>(inv_std); a.pre = pre; a.dpre = dpre; a.dgamma = dgamma;
+  a.dbeta = dbeta; a.dbias = dbias; a.rows = rows; a.C = C; a.ldo = ldo; a.r_feat = r_feat; a.r_lstm = r_lstm;
+  a.slope = slope; a.seed = seed; a.site_feat = site_feat; a.site_lstm = site_lstm; a.step_dev = step_dev;
+  a.nb_tail = (C + ET_CW - 1) / ET_CW;
+  DropArgs& d = a.drop;
+  d.x = drop_x; d.y = drop_x; d.rows = drop_rows; d.cols = drop_cols; d.ld = drop_ld; d.tB = drop_tmajor_B; d.lwidth = drop_lwidth;
+  d.lcol0 = drop_lcol0; d.rows_per_site = 0; d.rate = drop_rate; d.scale = 1.0f / (1.0f - drop_rate); d.seed = seed;
+  d.site = drop_site; d.step = 0; d.step_dev = step_dev;
+  const int nbd = drop_rate > 0.f ? ew_blocks((long)drop_rows * (drop_cols / 4)) : 0;
+  hipLaunchKernelGGL(enc_tail_bwd_kernel, dim3(a.nb_tail + nbd), dim3(256), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
 }

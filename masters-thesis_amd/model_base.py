@@ -154,7 +154,7 @@ class ModelBase:
         gd = self._guard_word()
         adam = opt.kind == "adam"
         enc = self.__dict__.pop("_enc_fused", None)
-        s1 = 0
+        s1, rest_done = 0, False
         if enc is not None:
             # The dense encoder kernel (segment 0, 59 % of config 2's parameters) never has its gradient written: one
             # pass of the skinny product leaves its norm partials in the variable's span slots, a second one applies
@@ -165,11 +165,16 @@ class ModelBase:
             if gram is not None and 4 * rows + gram[5] <= s1:
                 # norm from the forward's by-products: ||X^T D||^2 = sum (X X^T) o (D D^T), no pass over the gradient
                 pre, bias, gx, nsplit, w2, nw2 = gram
-                be.dense_gram_norm(dpre, pre, bias, gx, nsplit, w2, nw2, e.l2, a.partial, s1, rows, E)
+                # ... with the span norms of every other variable riding in the same launch
+                be.dense_gram_norm(dpre, pre, bias, gx, nsplit, w2, nw2, e.l2, a.partial, s1, rows, E,
+                                   spans=(a.theta, a.grad, sp.span_seg[s1:], sp.span_off[s1:], sp.span_len[s1:], a.seg_l2,
+                                          a.partial[2 * s1:], sp.nspan - s1))
+                rest_done = True
             else:
                 be.dense_dw_sqnorm(x, dpre, a.p(name), e.l2, a.partial, s1, N, E, rows, ldx)
-        be.span_sqnorm(a.theta, a.grad, sp.span_seg[s1:], sp.span_off[s1:], sp.span_len[s1:], a.seg_l2, a.partial[2 * s1:],
-                       sp.nspan - s1)
+        if not rest_done:
+            be.span_sqnorm(a.theta, a.grad, sp.span_seg[s1:], sp.span_off[s1:], sp.span_len[s1:], a.seg_l2, a.partial[2 * s1:],
+                           sp.nspan - s1)
         kw = dict(x0=d[0], out0=d[1], x1=d[2], out1=d[3], n=d[4], scale=d[5]) if d is not None else {}
         ef = self.__dict__.pop("_emb_finalize", None)
         if ef is not None:       # sparse embedding backward: sum its norm partials, hand this step's ids on as prev_ids

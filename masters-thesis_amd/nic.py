@@ -423,11 +423,22 @@ class NIC(ModelBase):
         # the Philox calls land on the few workgroups that own heavily duplicated ids, on the step's critical path, and cost
         # more there than the 4 us launch they save.
         fold = self.r_lstm > 0 and self._emb_sparse_ok(E, E) and not self.__dict__.get("agc") and getattr(self, "fold_emb_drop", False)
-        if self.r_lstm > 0 and not fold:
+        # ... else it shares a launch with the encoder tail backward (both read the dXin the GEMM above just wrote, different
+        # rows), which then runs in front of the Embedding backward
+        ride = (self.r_lstm > 0 and not fold and fused and E % 4 == 0 and hasattr(be, "enc_tail_bwd_drop")
+                and getattr(self, "tail_drop_ride", True))
+        if ride:
+            be.enc_tail_bwd_drop(self.dXin, self.xhat, a.p("batch_norm/gamma"), self.inv_std, self.enc_pre, self.dpre,
+                                 a.g("batch_norm/gamma"), a.g("batch_norm/beta"), a.g("dense_img/bias"), B, E, E,
+                                 self.r_feat, self.r_lstm, 0.2, sd, S_FEAT, S_LSTM_IN + 0, ds,
+                                 self.dXin[B:], T * B, E, E, B, E, 0, self.r_lstm, S_LSTM_IN + 1)
+        elif self.r_lstm > 0 and not fold:
             be.dropout(self.dXin[B:], self.dXin[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
         self._emb_rows = (self.dXin[B:], T * B, E, E, "emb_text/embeddings")
         self._embedding_bwd(self.dXin[B:], self.cap, "emb_text/embeddings", B, T, E, E, V,
                             drop=(self.r_lstm, sd, S_LSTM_IN + 1, ds) if fold else None)
+        if ride:
+            return
         if fused:       # dropout' -> BatchNorm' -> dropout' -> LeakyReLU' -> dpre, encoder bias gradient: one launch
             be.enc_tail_bwd(self.dXin, self.xhat, a.p("batch_norm/gamma"), self.inv_std, self.enc_pre, self.dpre,
                             a.g("batch_norm/gamma"), a.g("batch_norm/beta"), a.g("dense_img/bias"), B, E, E,

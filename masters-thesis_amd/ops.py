@@ -213,6 +213,14 @@ class HipBackend:
                                                  _p(inv_std), rows, C, ldo, int(training), eps, momentum, r_feat, r_lstm,
                                                  int(seed), int(site_feat), int(site_lstm), _p(step_dev), self._s())
 
+    def enc_tail_bwd_drop(self, dout, xhat, gamma, inv_std, pre, dpre, dgamma, dbeta, dbias, rows, C, ldo, r_feat, r_lstm,
+                          slope, seed, site_feat, site_lstm, step_dev, drop_x, drop_rows, drop_cols, drop_ld, drop_tmajor_B,
+                          drop_lwidth, drop_lcol0, drop_rate, drop_site):
+        self._call(self.lib.tnt_enc_tail_bwd_drop_f32, "tnt_enc_tail_bwd_drop_f32", _p(dout), _p(xhat), _p(gamma), _p(inv_std),
+                   _p(pre), _p(dpre), _p(dgamma), _p(dbeta), _p(dbias), rows, C, ldo, r_feat, r_lstm, slope, int(seed),
+                   int(site_feat), int(site_lstm), _p(step_dev), _p(drop_x), drop_rows, drop_cols, drop_ld, drop_tmajor_B,
+                   drop_lwidth, drop_lcol0, drop_rate, int(drop_site), self._s())
+
     def enc_tail_bwd(self, dout, xhat, gamma, inv_std, pre, dpre, dgamma, dbeta, dbias, rows, C, ldo, r_feat, r_lstm,
                      slope, seed, site_feat, site_lstm, step_dev=None):
         self._call(self.lib.tnt_enc_tail_bwd_f32, "tnt_enc_tail_bwd_f32", _p(dout), _p(xhat), _p(gamma), _p(inv_std), _p(pre), _p(dpre), _p(dgamma),
@@ -227,9 +235,17 @@ class HipBackend:
         self._call(self.lib.tnt_dense_fwd_stream_gram_f32, "tnt_dense_fwd_stream_gram_f32", _p(x), _p(w), _p(part), _p(gx_part),
                    _p(w2_part), B, E, K, ldx, ldw, nsplit, self._s())
 
-    def dense_gram_norm(self, dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E):
-        self._call(self.lib.tnt_dense_gram_norm_f32, "tnt_dense_gram_norm_f32", _p(dpre), _p(pre), _p(bias), _p(gx_part), nsplit,
-                   _p(w2_part), nw2, l2, _p(partial), nslot, Bk, E, self._s())
+    def dense_gram_norm(self, dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E, spans=None):
+        """``spans`` = (theta, grad, span_seg, span_off, span_len, seg_l2, span_partial, nspan): the span norms of the other
+        variables in the same launch (tnt_dense_gram_norm_spans_f32)"""
+        if spans is None:
+            self._call(self.lib.tnt_dense_gram_norm_f32, "tnt_dense_gram_norm_f32", _p(dpre), _p(pre), _p(bias), _p(gx_part), nsplit,
+                       _p(w2_part), nw2, l2, _p(partial), nslot, Bk, E, self._s())
+            return
+        th, gr, sseg, soff, slen, sl2, spart, nspan = spans
+        self._call(self.lib.tnt_dense_gram_norm_spans_f32, "tnt_dense_gram_norm_spans_f32", _p(dpre), _p(pre), _p(bias), _p(gx_part),
+                   nsplit, _p(w2_part), nw2, l2, _p(partial), nslot, Bk, E, _p(th), _p(gr), _p(sseg), _p(soff), _p(slen), _p(sl2),
+                   _p(spart), nspan, self._s())
 
     def enc_tail_fwd_sk(self, part, nsplit, bias, pre, slope, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C,
                         ldo, training, eps, momentum, r_feat, r_lstm, seed, site_feat, site_lstm, step_dev=None):

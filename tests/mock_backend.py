@@ -210,7 +210,10 @@ class MockBackend:
         w2[:nsplit * (E // 32)] = 0
         w2[0] = (W * W).sum()
 
-    def dense_gram_norm(self, dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E):
+    def dense_gram_norm(self, dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E, spans=None):
+        if spans is not None:
+            th, gr, sseg, soff, slen, sl2, spart, nspan = spans
+            self.span_sqnorm(th, gr, sseg, soff, slen, sl2, spart, nspan)
         D = mat(dpre, Bk, E, E).astype(np.float64)
         XW = mat(pre, Bk, E, E).astype(np.float64) - flat(bias)[:E].astype(np.float64)
         gx = flat(gx_part)[:nsplit * 64 * 64].reshape(nsplit, 64, 64).astype(np.float64).sum(0)[:Bk, :Bk]
@@ -227,6 +230,15 @@ class MockBackend:
         y = torch.from_numpy(np.where(z > 0, z, z * slope).astype(np.float32))
         self.enc_tail_fwd(y, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C, ldo, training, eps, momentum,
                           r_feat, r_lstm, seed, site_feat, site_lstm, step_dev)
+
+    def enc_tail_bwd_drop(self, dout, xhat, gamma, inv_std, pre, dpre, dgamma, dbeta, dbias, rows, C, ldo, r_feat, r_lstm,
+                          slope, seed, site_feat, site_lstm, step_dev, drop_x, drop_rows, drop_cols, drop_ld, drop_tmajor_B,
+                          drop_lwidth, drop_lcol0, drop_rate, drop_site):
+        self.enc_tail_bwd(dout, xhat, gamma, inv_std, pre, dpre, dgamma, dbeta, dbias, rows, C, ldo, r_feat, r_lstm, slope,
+                          seed, site_feat, site_lstm, step_dev)
+        if drop_rate > 0:
+            self.dropout(drop_x, drop_x, drop_rows, drop_cols, drop_ld, drop_tmajor_B, drop_lwidth, drop_lcol0, drop_rate, seed,
+                         drop_site, 0, step_dev)
 
     def enc_tail_bwd(self, dout, xhat, gamma, inv_std, pre, dpre, dgamma, dbeta, dbias, rows, C, ldo, r_feat, r_lstm,
                      slope, seed, site_feat, site_lstm, step_dev=None):
