@@ -246,6 +246,16 @@ int32_t tnt_enc_tail_fwd_sk_f32(const float* part, int32_t nsplit, const float* 
                                 float* xhat, float* inv_std, int32_t rows, int32_t C, int32_t ldo, int32_t training,
                                 float eps, float momentum, float r_feat, float r_lstm, uint64_t seed,
                                 uint32_t site_feat, uint32_t site_lstm, const uint32_t* step_dev, void* stream);
+/* ... with the Embedding gather + input dropout of the text rows (tnt_embedding_fwd_drop_f32 with out = NULL: table
+ * [emb_V][C], ids [emb_B][emb_T], emb_out rows t*B + b with row stride ldo, stream (seed, emb_site, *step_dev), rate 0 =
+ * plain gather) riding in the same launch: both feed the same LSTM input buffer (NIC.py:131,138-140) */
+int32_t tnt_enc_tail_fwd_sk_emb_f32(const float* part, int32_t nsplit, const float* bias, float* pre, float slope,
+                                    const float* gamma, const float* beta, float* mov_mean, float* mov_var, float* out,
+                                    float* xhat, float* inv_std, int32_t rows, int32_t C, int32_t ldo, int32_t training,
+                                    float eps, float momentum, float r_feat, float r_lstm, uint64_t seed,
+                                    uint32_t site_feat, uint32_t site_lstm, const uint32_t* step_dev,
+                                    const float* emb_table, const int32_t* emb_ids, float* emb_out, int32_t emb_B,
+                                    int32_t emb_T, int32_t emb_V, float emb_rate, uint32_t emb_site, void* stream);
 int32_t tnt_enc_tail_bwd_f32(const float* dout, const float* xhat, const float* gamma, const float* inv_std,
                              const float* pre, float* dpre, float* dgamma, float* dbeta, float* dbias,
                              int32_t rows, int32_t C, int32_t ldo, float r_feat, float r_lstm, float slope,

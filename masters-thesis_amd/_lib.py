@@ -69,6 +69,8 @@ SIGNATURES = {
     "tnt_dense_fwd_stream_f32": [P, P, P, I32, I32, I32, I32, I32, I32, P],
     "tnt_enc_tail_fwd_sk_f32": [P, I32, P, P, F32, P, P, P, P, P, P, P, I32, I32, I32, I32, F32, F32, F32, F32, U64, U32,
                                 U32, P, P],
+    "tnt_enc_tail_fwd_sk_emb_f32": [P, I32, P, P, F32, P, P, P, P, P, P, P, I32, I32, I32, I32, F32, F32, F32, F32, U64, U32,
+                                    U32, P, P, P, P, I32, I32, I32, F32, U32, P],
     "tnt_gru_step_fwd_f32": [P, P, P, P, P, P, I32, I32, P],
     "tnt_gru_step_bwd_f32": [P, P, P, P, P, P, P, P, P, I32, I32, P],
     "tnt_lc_seq_fwd_f32": [P, P, P, P, P, P, P, P, P, P, P, I64, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, F32, F32, F32,

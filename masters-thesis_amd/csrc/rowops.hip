@@ -464,6 +464,9 @@ struct EncTailArgs {
   // backward: an independent in-place dropout' job riding in the same launch (blocks >= nb_tail; rate 0: none) -- the text
   // call's LSTM-input dropout over the other rows of the same gradient buffer (NIC.py:131,140)
   DropArgs drop; int nb_tail;
+  // forward (SK): the Embedding gather + the text call's LSTM-input dropout riding in the same launch (blocks >= nb_tail;
+  // emb_table NULL: none): out rows t*B + b of emb_out (row stride ldo), mask element (b*T + t)*E + j of stream emb_site
+  const float* emb_table; const int* emb_ids; float* emb_out; int emb_B, emb_T, emb_V; float emb_rate; uint32_t emb_site;
 };
 
 // column sums of a per-thread float4 over the 32 row groups, fixed order; result valid in every thread
@@ -490,6 +493,26 @@ __device__ __forceinline__ float4 et_drop4(float4 v, uint64_t e, float rate, flo
 
 template <bool SK>
 __global__ __launch_bounds__(256) void enc_tail_fwd_kernel(EncTailArgs a) {
+  if (SK && a.emb_table != nullptr && (int)blockIdx.x >= a.nb_tail) {      // the riding Embedding job (as emb_fwd_drop_kernel)
+    const int row = (blockIdx.x - a.nb_tail) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // row = t*B + b
+    if (row >= a.emb_B * a.emb_T) return;
+    const uint32_t estep = a.step_dev ? a.step_dev[0] : 0u;
+    const int t = row / a.emb_B, b = row % a.emb_B, E = a.C;
+    int id = a.emb_ids[b * a.emb_T + t];
+    id = id < 0 ? 0 : (id >= a.emb_V ? a.emb_V - 1 : id);
+    const float* src = a.emb_table + (long)id * E;
+    const float scale = 1.0f / (1.0f - a.emb_rate);
+    for (int j = lane * 4; j < E; j += 256) {
+      float4 v = *reinterpret_cast<const float4*>(src + j);
+      if (a.emb_rate > 0.f) {
+        bool k[4];
+        tnt_keep4((uint64_t)(b * a.emb_T + t) * E + j, a.emb_rate, a.seed, a.emb_site, estep, k);
+        v = make_float4(k[0] ? v.x * scale : 0.f, k[1] ? v.y * scale : 0.f, k[2] ? v.z * scale : 0.f, k[3] ? v.w * scale : 0.f);
+      }
+      *reinterpret_cast<float4*>(a.emb_out + (long)row * a.ldo + j) = v;
+    }
+    return;
+  }
   __shared__ float4 red[ET_RG][ET_CW / 4];
   const int c4 = threadIdx.x % (ET_CW / 4), rg = threadIdx.x / (ET_CW / 4);
   const int col = blockIdx.x * ET_CW + 4 * c4;
@@ -667,12 +690,14 @@ extern "C" int32_t tnt_enc_tail_fwd_f32(const float* y, const float* gamma, cons
   return 0;
 }
 
-extern "C" int32_t tnt_enc_tail_fwd_sk_f32(const float* part, int32_t nsplit, const float* bias, float* pre, float slope,
-                                           const float* gamma, const float* beta, float* mov_mean, float* mov_var,
-                                           float* out, float* xhat, float* inv_std, int32_t rows, int32_t C, int32_t ldo,
-                                           int32_t training, float eps, float momentum, float r_feat, float r_lstm,
-                                           uint64_t seed, uint32_t site_feat, uint32_t site_lstm,
-                                           const uint32_t* step_dev, void* stream) {
+extern "C" int32_t tnt_enc_tail_fwd_sk_emb_f32(const float* part, int32_t nsplit, const float* bias, float* pre, float slope,
+                                               const float* gamma, const float* beta, float* mov_mean, float* mov_var,
+                                               float* out, float* xhat, float* inv_std, int32_t rows, int32_t C, int32_t ldo,
+                                               int32_t training, float eps, float momentum, float r_feat, float r_lstm,
+                                               uint64_t seed, uint32_t site_feat, uint32_t site_lstm,
+                                               const uint32_t* step_dev, const float* emb_table, const int32_t* emb_ids,
+                                               float* emb_out, int32_t emb_B, int32_t emb_T, int32_t emb_V, float emb_rate,
+                                               uint32_t emb_site, void* stream) {
   if (rows <= 0 || rows > ET_RG * ET_MAXR || nsplit <= 0) return TNT_BADARG(13);
   if (C <= 0 || C % 4 != 0 || ldo < C || ldo % 4 != 0) return TNT_BADARG(14);
   if (!tnt_aligned16(part) || !tnt_aligned16(bias) || !tnt_aligned16(pre) || !tnt_aligned16(out) || !tnt_aligned16(xhat) ||
@@ -684,9 +709,29 @@ extern "C" int32_t tnt_enc_tail_fwd_sk_f32(const float* part, int32_t nsplit, co
   a.inv_std = inv_std; a.rows = rows; a.C = C; a.ldo = ldo; a.training = training; a.eps = eps; a.momentum = momentum;
   a.r_feat = r_feat; a.r_lstm = r_lstm; a.seed = seed; a.site_feat = site_feat; a.site_lstm = site_lstm;
   a.step_dev = step_dev;
-  hipLaunchKernelGGL(enc_tail_fwd_kernel<true>, dim3((C + ET_CW - 1) / ET_CW), dim3(256), 0, tnt_stream(stream), a);
+  a.nb_tail = (C + ET_CW - 1) / ET_CW;
+  int nbe = 0;
+  if (emb_table != nullptr) {       // Embedding width = C (both feed the same LSTM input), rows behind the feature rows
+    if (emb_ids == nullptr || emb_out == nullptr || emb_B <= 0 || emb_T <= 0 || emb_V <= 0 || emb_rate < 0.f || emb_rate >= 1.f ||
+        !tnt_aligned16(emb_table) || !tnt_aligned16(emb_out)) return TNT_BADARG(25);
+    a.emb_table = emb_table; a.emb_ids = emb_ids; a.emb_out = emb_out; a.emb_B = emb_B; a.emb_T = emb_T; a.emb_V = emb_V;
+    a.emb_rate = emb_rate; a.emb_site = emb_site;
+    nbe = (emb_B * emb_T + 3) / 4;
+  }
+  hipLaunchKernelGGL(enc_tail_fwd_kernel<true>, dim3(a.nb_tail + nbe), dim3(256), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int32_t tnt_enc_tail_fwd_sk_f32(const float* part, int32_t nsplit, const float* bias, float* pre, float slope,
+                                           const float* gamma, const float* beta, float* mov_mean, float* mov_var,
+                                           float* out, float* xhat, float* inv_std, int32_t rows, int32_t C, int32_t ldo,
+                                           int32_t training, float eps, float momentum, float r_feat, float r_lstm,
+                                           uint64_t seed, uint32_t site_feat, uint32_t site_lstm,
+                                           const uint32_t* step_dev, void* stream) {
+  return tnt_enc_tail_fwd_sk_emb_f32(part, nsplit, bias, pre, slope, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C,
+                                     ldo, training, eps, momentum, r_feat, r_lstm, seed, site_feat, site_lstm, step_dev,
+                                     nullptr, nullptr, nullptr, 0, 0, 0, 0.f, 0u, stream);
 }
 
 extern "C" int32_t tnt_enc_tail_bwd_f32(const float* dout, const float* xhat, const float* gamma, const float* inv_std,

@@ -236,6 +236,7 @@ class NIC(ModelBase):
         xin = self.Xin_d if drop_l else self.Xin
         fused = self._fused_tail(B)
         stream = fused and self.enc_part is not None
+        emb_ride = False
         if stream:      # :125-128 + the feature step's LSTM input dropout: the streaming product's K-split partials are
             #             summed (+ bias, LeakyReLU) by the tail kernel, which holds whole columns for the batch statistics
             self._enc_gram = None
@@ -251,11 +252,16 @@ class NIC(ModelBase):
                                   ENC_SPLITS * (E // 32))
             else:
                 be.dense_fwd_stream(x, a.p("dense_img/kernel"), self.enc_part, B, E, N, self.ldx, E, ENC_SPLITS)
-            be.enc_tail_fwd_sk(self.enc_part, ENC_SPLITS, a.p("dense_img/bias"), self.enc_pre, 0.2,
-                               a.p("batch_norm/gamma"), a.p("batch_norm/beta"), self.mov_mean, self.mov_var, xin,
-                               self.xhat, self.inv_std, B, E, E, training, BN_EPS, BN_MOMENTUM,
-                               self.r_feat if training else 0.0, self.r_lstm if training else 0.0, sd, S_FEAT,
-                               S_LSTM_IN + 0, ds)
+            emb_ride = E % 4 == 0 and hasattr(be, "enc_tail_fwd_sk_emb") and getattr(self, "emb_ride", True)
+            targs = (self.enc_part, ENC_SPLITS, a.p("dense_img/bias"), self.enc_pre, 0.2, a.p("batch_norm/gamma"),
+                     a.p("batch_norm/beta"), self.mov_mean, self.mov_var, xin, self.xhat, self.inv_std, B, E, E, training,
+                     BN_EPS, BN_MOMENTUM, self.r_feat if training else 0.0, self.r_lstm if training else 0.0, sd, S_FEAT,
+                     S_LSTM_IN + 0, ds)
+            if emb_ride:    # ... with the Embedding gather (+ the text call's input dropout) of the rows behind the features
+                be.enc_tail_fwd_sk_emb(*targs, a.p("emb_text/embeddings"), self.cap, xin[B:], B, T, V,
+                                       self.r_lstm if drop_l else 0.0, S_LSTM_IN + 1)
+            else:
+                be.enc_tail_fwd_sk(*targs)
         else:
             self.gemm_sk(x, a.p("dense_img/kernel"), self.enc_y, B, E, N, self.ldx, E, E, bias=a.p("dense_img/bias"),
                          pre=self.enc_pre, act=ACT_LEAKY, slope=0.2)                          # :125
@@ -279,7 +285,9 @@ class NIC(ModelBase):
                                  self.inv_std, B, E, E, BN_EPS)
         if drop_l and not fused:
             be.dropout(self.Xin, self.Xin_d, B, E, E, 0, E, 0, self.r_lstm, sd, S_LSTM_IN + 0, 0, ds)
-        if drop_l and E % 4 == 0:       # :131 + the text call's LSTM(dropout=...) input mask in one launch
+        if stream and emb_ride:
+            pass                        # gathered by the tail launch above
+        elif drop_l and E % 4 == 0:     # :131 + the text call's LSTM(dropout=...) input mask in one launch
             be.embedding_fwd_drop(a.p("emb_text/embeddings"), self.cap, None, self.Xin_d[B:], B, T, E, E, V, self.r_lstm,
                                   sd, S_LSTM_IN + 1, 0, ds)
         else:

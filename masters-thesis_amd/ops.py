@@ -247,6 +247,14 @@ class HipBackend:
                    nsplit, _p(w2_part), nw2, l2, _p(partial), nslot, Bk, E, _p(th), _p(gr), _p(sseg), _p(soff), _p(slen), _p(sl2),
                    _p(spart), nspan, self._s())
 
+    def enc_tail_fwd_sk_emb(self, part, nsplit, bias, pre, slope, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C,
+                            ldo, training, eps, momentum, r_feat, r_lstm, seed, site_feat, site_lstm, step_dev, emb_table,
+                            emb_ids, emb_out, emb_B, emb_T, emb_V, emb_rate, emb_site):
+        self._call(self.lib.tnt_enc_tail_fwd_sk_emb_f32, "tnt_enc_tail_fwd_sk_emb_f32", _p(part), nsplit, _p(bias), _p(pre), slope,
+                   _p(gamma), _p(beta), _p(mov_mean), _p(mov_var), _p(out), _p(xhat), _p(inv_std), rows, C, ldo,
+                   int(training), eps, momentum, r_feat, r_lstm, int(seed), int(site_feat), int(site_lstm), _p(step_dev),
+                   _p(emb_table), _p(emb_ids), _p(emb_out), emb_B, emb_T, emb_V, emb_rate, int(emb_site), self._s())
+
     def enc_tail_fwd_sk(self, part, nsplit, bias, pre, slope, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C,
                         ldo, training, eps, momentum, r_feat, r_lstm, seed, site_feat, site_lstm, step_dev=None):
         self._call(self.lib.tnt_enc_tail_fwd_sk_f32, "tnt_enc_tail_fwd_sk_f32", _p(part), nsplit, _p(bias), _p(pre), slope,

@@ -223,6 +223,17 @@ class MockBackend:
         p[0] = (gx * (D @ D.T)).sum() + 4 * l2 * (D * XW).sum() + 4 * l2 * l2 * w2
         p[1] = w2
 
+    def enc_tail_fwd_sk_emb(self, part, nsplit, bias, pre, slope, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C,
+                            ldo, training, eps, momentum, r_feat, r_lstm, seed, site_feat, site_lstm, step_dev, emb_table,
+                            emb_ids, emb_out, emb_B, emb_T, emb_V, emb_rate, emb_site):
+        self.enc_tail_fwd_sk(part, nsplit, bias, pre, slope, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C, ldo,
+                             training, eps, momentum, r_feat, r_lstm, seed, site_feat, site_lstm, step_dev)
+        if emb_rate > 0:
+            self.embedding_fwd_drop(emb_table, emb_ids, None, emb_out, emb_B, emb_T, C, ldo, emb_V, emb_rate, seed, emb_site, 0,
+                                    step_dev)
+        else:
+            self.embedding_fwd(emb_table, emb_ids, emb_out, emb_B, emb_T, C, ldo, emb_V)
+
     def enc_tail_fwd_sk(self, part, nsplit, bias, pre, slope, gamma, beta, mov_mean, mov_var, out, xhat, inv_std, rows, C,
                         ldo, training, eps, momentum, r_feat, r_lstm, seed, site_feat, site_lstm, step_dev=None):
         z = flat(part)[:nsplit * rows * C].reshape(nsplit, rows, C).astype(np.float64).sum(0) + flat(bias)[:C]
