@@ -597,7 +597,9 @@ int32_t tnt_attention_step_fwd_f32(const float* h, const float* F, const float* 
  * rows of the LSTM kernel [D][4U]) and the dctx_d argument is ignored.  If dctx_part is non-null ([nparts][B][D], written
  * by tnt_lstm_step_bwd_f32; nparts*D <= 1024) the context gradient is the sum of the parts and dctx_d / dz are ignored. */
 /* alpha_mse_coef: dalpha[b][r] += alpha_mse_coef * (alpha[b][r] - 1) before the softmax backward -- the gradient of
- * c * sum (1 - alpha)^2 with alpha_mse_coef = 2c (lc_NIC.train_step_sam's attention term, lc_NIC.py:751-752); 0 = none. */
+ * c * sum (1 - alpha)^2 with alpha_mse_coef = 2c (lc_NIC.train_step_sam's attention term, lc_NIC.py:751-752); 0 = none.
+ * fresh != 0: dP / dF / dvb are overwritten with this step's terms instead of added to (the first executed step of a
+ * chain, so the caller needs no zero fill of the three accumulators). */
 int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* F, const float* P,
                                    const float* W2, const float* v, const float* qpre,
                                    const float* alpha, float* dP, float* dF, float* dvb,
@@ -607,7 +609,7 @@ int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* F, const fl
                                    uint32_t site_attn, uint32_t site_in, uint32_t step,
                                    const uint32_t* step_dev, const float* dz, const float* Wc,
                                    const float* dctx_part, int32_t nparts, const uint8_t* keep4,
-                                   float alpha_mse_coef, void* stream);
+                                   float alpha_mse_coef, int32_t fresh, void* stream);
 
 /* ---- the forward chain of the attention captioner as ONE persistent launch (lc_NIC.py:244-256): for i < T:
  * tnt_attention_step_fwd_f32(h = hs[i], ..., qpre[i], alpha[i], ctx[i], ctx_d[i], keep4 + i * keep_stride, sites + i) then

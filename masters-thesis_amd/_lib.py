@@ -103,7 +103,7 @@ SIGNATURES = {
     "tnt_attention_step_fwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, F32,
                                    I32, U64, U32, U32, U32, P, P, P],
     "tnt_attention_step_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, F32,
-                                   I32, U64, U32, U32, U32, P, P, P, P, I32, P, F32, P],
+                                   I32, U64, U32, U32, U32, P, P, P, P, I32, P, F32, I32, P],
     "tnt_attention_metric_f32": [P, P, P, I32, I32, I32, I64, P],
 }
 

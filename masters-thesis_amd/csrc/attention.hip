@@ -55,6 +55,9 @@ struct AttArgs {
   // backward only: dalpha[r] += alpha_mse * (alpha[r] - 1) -- the gradient of c * sum (1 - alpha)^2 with alpha_mse = 2c
   // (lc_NIC.train_step_sam adds MSE(ones, attention_scores) to the loss of its first pass, lc_NIC.py:751-752,766)
   float alpha_mse;
+  // backward only: 1 = the accumulators dP / dF / dvb are written, not added to (the first executed step of a chain: saves
+  // the caller a zero fill of the three buffers)
+  int fresh;
 };
 
 // q[a] = LeakyReLU(sum_k h[k] W2[k][a] + b2[a]); threads = (a = tid % AP, part = tid / AP)
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttArgs g) {
       const bool ok = r < g.R && d < g.D;
       const long e = ((long)b * g.R + r) * g.D + d;
       fv[u] = ok ? g.F[e] : 0.f;
-      dfv[u] = ok ? g.dF[e] : 0.f;
+      dfv[u] = (ok && !g.fresh) ? g.dF[e] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttArgs g) {
         const int r = r0 + u * RP;
         const long e = ((long)b * g.R + r) * g.A + a;
         pv[u] = r < g.R ? g.P[e] : 0.f;
-        dpv[u] = r < g.R ? g.dP[e] : 0.f;
+        dpv[u] = (r < g.R && !g.fresh) ? g.dP[e] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -269,13 +272,13 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttArgs g) {
   if (tid < AP && tid < g.A) {
     float tv = 0.f, tq = 0.f;
     for (int j = 0; j < RP; ++j) { tv += part[j * AP + tid]; tq += part2[j * AP + tid]; }
-    g.dvb[(long)b * (g.A + 1) + tid] += tv;
+    g.dvb[(long)b * (g.A + 1) + tid] = (g.fresh ? 0.f : g.dvb[(long)b * (g.A + 1) + tid]) + tv;
     const float qp = g.qpre_in[(long)b * g.A + tid];
     const float dqp = qp > 0.f ? tq : tq * g.slope;
     dq_s[tid] = dqp;
     g.dqpre[(long)b * g.A + tid] = dqp;
   }
-  if (tid == 0) g.dvb[(long)b * (g.A + 1) + g.A] += dbv;
+  if (tid == 0) g.dvb[(long)b * (g.A + 1) + g.A] = (g.fresh ? 0.f : g.dvb[(long)b * (g.A + 1) + g.A]) + dbv;
   __syncthreads();
   // dh[k] = sum_a dqpre[a] W2[k][a]
   for (int k = tid; k < g.U; k += 256) {
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(WT) void attention_bwd_wide_kernel(AttArgs g) {
       const bool ok = cok && r < R;
       const long e = ((long)b * R + r) * D + c4 * 4;
       fv[p] = ok ? *reinterpret_cast<const float4*>(g.F + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-      dfv[p] = ok ? *reinterpret_cast<const float4*>(g.dF + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dfv[p] = (ok && !g.fresh) ? *reinterpret_cast<const float4*>(g.dF + e) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(WT) void attention_bwd_wide_kernel(AttArgs g) {
       const bool ok = cok && r < R;
       const long e = ((long)b * R + r) * A + c4 * 4;
       pv[p] = ok ? *reinterpret_cast<const float4*>(g.P + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-      dpv[p] = ok ? *reinterpret_cast<const float4*>(g.dP + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dpv[p] = (ok && !g.fresh) ? *reinterpret_cast<const float4*>(g.dP + e) : make_float4(0.f, 0.f, 0.f, 0.f);
       mk[p] = (stored && ok) ? g.keep4[e >> 2] : 0u;
     }
     float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), dq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -657,13 +660,13 @@ __global__ __launch_bounds__(WT) void attention_bwd_wide_kernel(AttArgs g) {
       float tv = 0.f, tq = 0.f;
 #pragma unroll
       for (int k = 0; k < WW; ++k) { tv += wred[k][tid]; tq += wred2[k][tid]; }
-      g.dvb[(long)b * (A + 1) + tid] += tv;
+      g.dvb[(long)b * (A + 1) + tid] = (g.fresh ? 0.f : g.dvb[(long)b * (A + 1) + tid]) + tv;
       const float qp = g.qpre_in[(long)b * A + tid];
       const float dqp = qp > 0.f ? tq : tq * g.slope;
       dq_s[tid] = dqp;
       g.dqpre[(long)b * A + tid] = dqp;
     }
-    if (tid == 0) g.dvb[(long)b * (A + 1) + A] += dbv;
+    if (tid == 0) g.dvb[(long)b * (A + 1) + A] = (g.fresh ? 0.f : g.dvb[(long)b * (A + 1) + A]) + dbv;
     __syncthreads();
   }
   // ---- dh[k] = sum_a dqpre[a] W2[k][a]
@@ -731,13 +734,13 @@ extern "C" int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* 
                                               int32_t in_lwidth, uint64_t seed, uint32_t site_attn, uint32_t site_in,
                                               uint32_t step, const uint32_t* step_dev, const float* dz, const float* Wc,
                                               const float* dctx_part, int32_t nparts, const uint8_t* keep4,
-                                              float alpha_mse_coef, void* stream) {
+                                              float alpha_mse_coef, int32_t fresh, void* stream) {
   if (int32_t rc = check_dims(B, R, D, A, U)) return rc;
   if (dz != nullptr && (U % 16 != 0 || Wc == nullptr)) return TNT_BADARG(27);
   if (dz == nullptr && dctx_d == nullptr && dctx_part == nullptr) return TNT_BADARG(1);
   if (dctx_part != nullptr && (nparts <= 0 || nparts * D > 1024)) return TNT_BADARG(30);
   AttArgs g{};
-  g.dz = dz; g.Wc = Wc; g.dctx_part = dctx_part; g.nparts = nparts; g.keep4 = keep4; g.alpha_mse = alpha_mse_coef;
+  g.dz = dz; g.Wc = Wc; g.dctx_part = dctx_part; g.nparts = nparts; g.keep4 = keep4; g.alpha_mse = alpha_mse_coef; g.fresh = fresh != 0;
   g.dctx_d = dctx_d; g.F = F; g.P = P; g.W2 = W2; g.v = v; g.qpre_in = qpre; g.alpha_in = alpha; g.dP = dP; g.dF = dF;
   g.dvb = dvb; g.dqpre = dqpre; g.dh = dh; g.B = B; g.R = R; g.D = D; g.A = A; g.U = U; g.in_lwidth = in_lwidth;
   g.slope = slope; g.rate_attn = rate_attn; g.rate_in = rate_in; g.seed = seed; g.site_attn = site_attn;
@@ -861,13 +864,25 @@ __global__ __launch_bounds__(256) void attention_front_bwd_kernel(const float* P
   if (tid < W) mine[W * W + tid] = bsum;
 }
 
-__global__ __launch_bounds__(64) void attention_front_finalize_kernel(const float* part, int nA, int nout, int nw, float* dW1,
-                                                                      float* db1) {
-  const int o = blockIdx.x * 64 + threadIdx.x;
-  if (o >= nout) return;
+// 64 outputs per workgroup x AFF_S slices of the chunk list: every thread sums its slice's partials (independent loads, all in
+// flight), the slices are combined through LDS in slice order -- the same summation tree on every run.
+constexpr int AFF_S = 16;
+__global__ __launch_bounds__(64 * AFF_S) void attention_front_finalize_kernel(const float* part, int nA, int nout, int nw,
+                                                                              float* dW1, float* db1) {
+  __shared__ float red[AFF_S][64];
+  const int ol = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + ol;
+  const int per = (nA + AFF_S - 1) / AFF_S, g0 = sl * per, g1 = min(nA, g0 + per);
   float t = 0.f;
-#pragma unroll 8
-  for (int g = 0; g < nA; ++g) t += part[(long)g * nout + o];
+  if (o < nout) {
+#pragma unroll 4
+    for (int g = g0; g < g1; ++g) t += part[(long)g * nout + o];
+  }
+  red[sl][ol] = t;
+  __syncthreads();
+  if (sl != 0 || o >= nout) return;
+#pragma unroll
+  for (int k = 1; k < AFF_S; ++k) t += red[k][ol];
   if (o < nw) dW1[o] = t; else db1[o - nw] = t;
 }
 }  // namespace
@@ -886,7 +901,7 @@ extern "C" int32_t tnt_attention_front_bwd_f32(const float* Ppre, const float* d
   hipStream_t s = tnt_stream(stream);
   hipLaunchKernelGGL(attention_front_bwd_kernel, dim3(nA + nB), dim3(256), 0, s, Ppre, dP, F, W1, dF, part, rows, slope, nA);
   TNT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attention_front_finalize_kernel, dim3((D * A + A + 63) / 64), dim3(64), 0, s, part, nA, D * A + A, D * A,
+  hipLaunchKernelGGL(attention_front_finalize_kernel, dim3((D * A + A + 63) / 64), dim3(64 * AFF_S), 0, s, part, nA, D * A + A, D * A,
                      dW1, db1);
   TNT_LAUNCH_CHECK();
   return 0;

@@ -606,7 +606,7 @@ class NIC(ModelBase):
         R, D, A, U, Et = self.R, self.D, self.A, self.U, self.Et
         n = T * B
         sd, ds = self.seed, self.drop_step
-        self.datt.zero_()
+        # no zero fill of dP / dF / dvb: the first executed step (i = T-1) overwrites them (fresh)
         Wl, Ur = a.p("lstm/kernel"), a.p("lstm/recurrent_kernel")
         W2, v = a.p("attention/W2/kernel"), a.p("attention/V/kernel")
         if self.use_layer_norm:
@@ -626,13 +626,13 @@ class NIC(ModelBase):
                                       self.dvb, self.dqpre[i], self.dh_att, B, R, D, A, U, 0.2, self.r_attn, self.r_lstm,
                                       D + Et, sd, S_ATTN + i, S_LSTM_IN + i, 0, ds, dctx_part=self.dctx_part,
                                       nparts=U // 16, keep4=self.att_keep[i] if self._keep_stored else None,
-                                      alpha_mse=self._alpha_mse)
+                                      alpha_mse=self._alpha_mse, fresh=last)
             else:
                 be.attention_step_bwd(None, self.F, self.P, W2, v, self.qpre[i], self.alpha[i], self.dP, self.dF,
                                       self.dvb, self.dqpre[i], self.dh_att, B, R, D, A, U, 0.2, self.r_attn, self.r_lstm,
                                       D + Et, sd, S_ATTN + i, S_LSTM_IN + i, 0, ds, dz=self.dZ[i * B:(i + 1) * B],
                                       Wc=Wl[:D], keep4=self.att_keep[i] if self._keep_stored else None,
-                                      alpha_mse=self._alpha_mse)
+                                      alpha_mse=self._alpha_mse, fresh=last)
         hprev = self.Hs[:T].view(n, U)
         gWl = a.g("lstm/kernel")
         self.gemm_sk(hprev, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True)
@@ -665,7 +665,7 @@ class NIC(ModelBase):
                                   self.dvb, self.dqpre[i], self.dh_att, B, R, D, A, U, 0.2, self.r_attn, 0.0,
                                   D + Et, sd, S_ATTN + i, S_LSTM_IN + i, 0, ds, dz=self.dZK[rows],
                                   Wc=Wl[:D], keep4=self.att_keep[i] if self._keep_stored else None,
-                                  alpha_mse=self._alpha_mse)
+                                  alpha_mse=self._alpha_mse, fresh=last)
         hprev = self.Hs[:T].view(n, U)
         gWl = a.g("lstm/kernel")
         self.gemm_sk(hprev, self.dZR, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True)

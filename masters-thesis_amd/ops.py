@@ -411,12 +411,12 @@ class HipBackend:
 
     def attention_step_bwd(self, dctx_d, F, P, W2, v, qpre, alpha, dP, dF, dvb, dqpre, dh, B, R, D, A, U, slope,
                            rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None, dz=None,
-                           Wc=None, dctx_part=None, nparts=0, keep4=None, alpha_mse=0.0):
+                           Wc=None, dctx_part=None, nparts=0, keep4=None, alpha_mse=0.0, fresh=False):
         self._call(self.lib.tnt_attention_step_bwd_f32, "tnt_attention_step_bwd_f32", _p(dctx_d), _p(F), _p(P), _p(W2), _p(v), _p(qpre), _p(alpha),
                                                        _p(dP), _p(dF), _p(dvb), _p(dqpre), _p(dh), B, R, D, A, U,
                                                        slope, rate_attn, rate_in, in_lwidth, seed, site_attn, site_in,
                                                        step, _p(step_dev), _p(dz), _p(Wc), _p(dctx_part), nparts,
-                                                       _p(keep4), float(alpha_mse), self._s())
+                                                       _p(keep4), float(alpha_mse), int(bool(fresh)), self._s())
 
     def attention_metric(self, alpha, out, work, T, B, R, tstride=0):
         self._call(self.lib.tnt_attention_metric_f32, "tnt_attention_metric_f32", _p(alpha), _p(out), _p(work), T, B, R, tstride, self._s())

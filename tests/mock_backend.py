@@ -774,7 +774,7 @@ class MockBackend:
 
     def attention_step_bwd(self, dctx_d, F, P, W2, v, qpre, alpha, dP, dF, dvb, dqpre, dh, B, R, D, A, U, slope,
                            rate_attn, rate_in, in_lwidth, seed, site_attn, site_in, step, step_dev=None, dz=None,
-                           Wc=None, dctx_part=None, nparts=0, keep4=None, alpha_mse=0.0):
+                           Wc=None, dctx_part=None, nparts=0, keep4=None, alpha_mse=0.0, fresh=False):
         if step_dev is not None:
             step = (step + int(step_dev[0])) & 0xFFFFFFFF
         f64 = lambda t, *s: flat(t)[:int(np.prod(s))].reshape(*s).astype(np.float64)
@@ -797,6 +797,10 @@ class MockBackend:
         dv = (sd * de[:, :, None]).sum(1)                     # per-sample (B,A)
         dsum = O.dropout_bwd(de[:, :, None] * vm[:, 0], keep, rate_attn) * (1 - s * s)
         dq = O.act_bwd(qp, dsum.sum(1), O.ACT_LEAKY, slope)
+        if fresh:
+            flat(dP)[:B * R * A] = 0
+            flat(dF)[:B * R * D] = 0
+            flat(dvb)[:B * (A + 1)] = 0
         flat(dP)[:B * R * A] += dsum.reshape(-1).astype(np.float32)
         flat(dF)[:B * R * D] += dFv.reshape(-1).astype(np.float32)
         dvbm = flat(dvb)[:B * (A + 1)].reshape(B, A + 1)

@@ -690,6 +690,13 @@ def test_attention_step(be, B, R, D, A, U, rate):
     close(dvb[:, :A].sum(0), dv[:, 0], atol=1e-4 * (np.abs(dv).max() + 1))
     close(h.T @ dq.cpu().double().numpy(), dW2, atol=1e-4 * (np.abs(dW2).max() + 1))
     assert abs(dvb[:, A].sum().item()) < 1e-4
+    # fresh: the three accumulators are overwritten, whatever they held (the chain's first step replaces a zero fill)
+    nan = float("nan")
+    dPf, dFf, dvbf = (torch.full((B, R, A), nan, device="cuda"), torch.full((B, R, D), nan, device="cuda"),
+                      torch.full((B, A + 1), nan, device="cuda"))
+    be.attention_step_bwd(dev(dctx_d), Fd, Pd, W2d, vd, qpre, al, dPf, dFf, dvbf, dq, dhd, B, R, D, A, U, 0.2, rate,
+                          rate_in, lw, seed, site_a, site_i, step, fresh=True)
+    close(dPf, dsum); close(dFf, dF); assert torch.equal(dvbf, dvb)
     if U % 16 == 0:
         # fused form: dctx_d = dz @ Wc^T computed inside the kernel
         dz = rng.standard_normal((B, 4 * U)) * 0.3
