@@ -109,6 +109,14 @@ int32_t tnt_dropout_f32(const float* x, float* y, int32_t rows, int32_t cols, in
                         int32_t tmajor_B, int32_t lwidth, int32_t lcol0, int32_t rows_per_site,
                         float rate, uint64_t seed, uint32_t site, uint32_t step,
                         const uint32_t* step_dev, void* stream);
+/* y = mask_b(mask_a(x)): two Dropout masks over the same matrix in one launch, each with its own logical layout, rate and
+ * site (arguments as in tnt_dropout_f32, suffix _a / _b), same seed and step -- bit-identical to the two tnt_dropout_f32
+ * calls it replaces (the LSTM input mask and the Embedding Dropout of the text rows in the backward pass,
+ * lc_NIC.py:233-234,255).  Both rates in (0, 1); cols, ld, lwidth_*, lcol0_* % 4 == 0, x / y 16-byte aligned. */
+int32_t tnt_dropout2_f32(const float* x, float* y, int32_t rows, int32_t cols, int32_t ld, int32_t tmajor_B_a,
+                         int32_t lwidth_a, int32_t lcol0_a, int32_t rows_per_site_a, float rate_a, uint32_t site_a,
+                         int32_t tmajor_B_b, int32_t lwidth_b, int32_t lcol0_b, int32_t rows_per_site_b, float rate_b,
+                         uint32_t site_b, uint64_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
 
 /* ---- activation backward: dx = dy * act'(pre)  ---------------------------------- */
 int32_t tnt_act_bwd_f32(const float* pre, const float* dy, float* dx, int64_t n, int32_t act,
@@ -135,11 +143,25 @@ int32_t tnt_batchnorm_fwd_f32(const float* x, const float* gamma, const float* b
                               float* inv_std, int32_t rows, int32_t C, int32_t ldy,
                               int32_t training, float eps, float momentum, float* work,
                               void* stream);
+/* ... with the keras Dropout that follows the normalisation (layers.py:50-51) applied to y in the same pass: element
+ * r*C + c of stream (seed, site, *step_dev); xhat stays the un-dropped normalised value.  rate 0 = tnt_batchnorm_fwd_f32. */
+int32_t tnt_batchnorm_fwd_drop_f32(const float* x, const float* gamma, const float* beta,
+                                   float* mov_mean, float* mov_var, float* y, float* xhat,
+                                   float* inv_std, int32_t rows, int32_t C, int32_t ldy,
+                                   int32_t training, float eps, float momentum, float* work,
+                                   float rate, uint64_t seed, uint32_t site, const uint32_t* step_dev,
+                                   void* stream);
 /* dx (nullable), dgamma[C], dbeta[C] from dy (row stride lddy), xhat, inv_std. */
 int32_t tnt_batchnorm_bwd_f32(const float* dy, const float* xhat, const float* gamma,
                               const float* inv_std, float* dx, float* dgamma, float* dbeta,
                               int32_t rows, int32_t C, int32_t lddy, int32_t training,
                               float* work, void* stream);
+/* ... with dx further multiplied by LeakyReLU'(act_pre [rows][C], slope): the backward of the activation in front of the
+ * normalisation (layers.py:48-50) in the same pass.  act_pre NULL = tnt_batchnorm_bwd_f32. */
+int32_t tnt_batchnorm_bwd_act_f32(const float* dy, const float* xhat, const float* gamma,
+                              const float* inv_std, float* dx, float* dgamma, float* dbeta,
+                              int32_t rows, int32_t C, int32_t lddy, int32_t training,
+                              float* work, const float* act_pre, float slope, void* stream);
 
 /* Synchronised BatchNorm (data parallel, opt-in; the reference trains on one device, so this is what makes G replicas x
  * local batch equal ONE process on the concatenated batch when the encoder uses BatchNorm): the pieces of the two
@@ -309,6 +331,14 @@ int32_t tnt_embedding_fwd_drop_f32(const float* table, const int32_t* ids, float
                                    int32_t B, int32_t T, int32_t E, int32_t ldo, int32_t V, float rate,
                                    uint64_t seed, uint32_t site, uint32_t step, const uint32_t* step_dev,
                                    void* stream);
+/* ... followed, when rate2 > 0, by a second mask in the same pass: the LSTM layer's per-call input dropout, whose call of
+ * timestep t draws one mask over its (B, lwidth2) input from site2 + t; the text rows are its columns lcol0_2 .. lcol0_2 + E
+ * (lc_NIC.py:255).  Bit-identical to tnt_embedding_fwd_drop_f32 + tnt_dropout_f32(rows_per_site = B).
+ * lwidth2, lcol0_2 % 4 == 0. */
+int32_t tnt_embedding_fwd_drop2_f32(const float* table, const int32_t* ids, float* out, float* out_drop,
+                                    int32_t B, int32_t T, int32_t E, int32_t ldo, int32_t V, float rate,
+                                    uint64_t seed, uint32_t site, uint32_t step, const uint32_t* step_dev,
+                                    float rate2, uint32_t site2, int32_t lwidth2, int32_t lcol0_2, void* stream);
 /* Single-process form of tnt_embedding_bwd_f32 without the table-wide zero fill and the row-norm launches: the first
  * occurrence of an id sums its rows into dtable[id] (deterministic, as above) and leaves its share of the IndexedSlices
  * squared norm in sq_part[k * ny + y] (ny = ceil(E / 256); tnt_embedding_bwd_parts(B, T, E) floats; their sum is the
@@ -498,8 +528,10 @@ int32_t tnt_seg_sqnorm_f32(const float* theta, const float* grad, const int32_t*
  * l2_out = sum_s seg_l2[s]*wsq[s]; out0 = scale*sum x0[0..n), out1 = scale*sum x1[0..n) (loss / accuracy totals,
  * lc_NIC.py:370-376; x1 nullable); extra[0] = sum extra_part[0..n_extra) (the Embedding's IndexedSlices squared norm
  * from the per-block partials of the scatter); ids_dst[0..n_ids) = ids_src (this step's token ids become the
- * prev_ids of tnt_embedding_bwd_sparse_f32); then the step state of tnt_step_tick advances (same arguments, same
- * guard rule).  Every piece is optional: nseg = 0, n = 0, n_extra = 0, null state pointers.  Fixed summation order. */
+ * prev_ids of tnt_embedding_bwd_sparse_f32); out2 = scale2*sum x2[0..n2) (one more scaled total: the per-timestep partials
+ * of tnt_attention_metric_f32 called with out = NULL); then the step state of tnt_step_tick advances (same arguments,
+ * same guard rule).  Every piece is optional: nseg = 0, n = 0, n_extra = 0, n2 = 0, null state pointers.  Fixed summation
+ * order. */
 int32_t tnt_span_sqnorm_f32(const float* theta, const float* grad, const int32_t* span_seg,
                             const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
                             float* partial, int32_t nspan, void* stream);
@@ -507,7 +539,8 @@ int32_t tnt_step_finalize_f32(const float* partial, const int32_t* seg_first, co
                               float* wsq, float* l2_out, int32_t nseg, const float* x0, float* out0,
                               const float* x1, float* out1, int32_t n, float scale, const float* extra_part,
                               float* extra, int32_t n_extra, const int32_t* ids_src, int32_t* ids_dst,
-                              int32_t n_ids, int64_t* adam_t, uint32_t* drop_step, const float* lr,
+                              int32_t n_ids, const float* x2, float* out2, int32_t n2, float scale2,
+                              int64_t* adam_t, uint32_t* drop_step, const float* lr,
                               float* lr_t, float beta1, float beta2, const uint32_t* guard, void* stream);
 /* out[0] = sum_s seg_l2[s]*wsq[s]; for callers that run tnt_seg_sqnorm_f32 on slices of the span
  * table (offset pointers, slice-local seg_first; the pipelined data-parallel update) and need the
@@ -635,10 +668,20 @@ int32_t tnt_attention_front_bwd_parts(int32_t rows, int32_t D, int32_t A);
 int32_t tnt_attention_front_bwd_f32(const float* Ppre, const float* dP, const float* F, const float* W1, float* dF,
                                     float* dW1, float* db1, float* part, int32_t rows, int32_t D, int32_t A,
                                     float slope, void* stream);
+/* ... and, with drop_rate > 0, the backward of the feature Dropout that produced F (layers.py:51) applied to the finished
+ * dF in the same pass: dF = keep ? (dF + g W1^T) / (1 - rate) : 0, element row*D + d of stream (drop_seed, drop_site,
+ * *drop_step_dev). */
+int32_t tnt_attention_front_bwd_drop_f32(const float* Ppre, const float* dP, const float* F, const float* W1, float* dF,
+                                         float* dW1, float* db1, float* part, int32_t rows, int32_t D, int32_t A,
+                                         float slope, float drop_rate, uint64_t drop_seed, uint32_t drop_site,
+                                         const uint32_t* drop_step_dev, void* stream);
 
 /* attention "coverage" metric (lc_NIC.py:365-367): mean over (T,R) of
- * (1 - sum_b alpha[t][b][r])^2.  alpha is [T][B][R]. */
-int32_t tnt_attention_metric_f32(const float* alpha, float* out, float* work /* T floats */,
+ * (1 - sum_b alpha[t][b][r])^2.  alpha is [T][B][R].  work: tnt_attention_metric_parts(T, R) floats of partial sums;
+ * out == NULL: only the partials are written, and the metric is their sum times 1 / (T R) (taken by
+ * tnt_step_finalize_f32's x2 job inside the fused training step). */
+int32_t tnt_attention_metric_parts(int32_t T, int32_t R);
+int32_t tnt_attention_metric_f32(const float* alpha, float* out, float* work,
                                  int32_t T, int32_t B, int32_t R,
                                  int64_t tstride /* floats between timesteps; 0 = B*R */, void* stream);
 

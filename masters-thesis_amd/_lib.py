@@ -25,10 +25,13 @@ SIGNATURES = {
     "tnt_gemm_fused_cfg": [I32, I32, I32, I32, I32, I32],
     "tnt_dropout_mask4_u8": [P, I64, I32, F32, U64, U32, U32, P, P],
     "tnt_dropout_f32": [P, P, I32, I32, I32, I32, I32, I32, I32, F32, U64, U32, U32, P, P],
+    "tnt_dropout2_f32": [P, P, I32, I32, I32, I32, I32, I32, I32, F32, U32, I32, I32, I32, I32, F32, U32, U64, U32, P, P],
     "tnt_act_bwd_f32": [P, P, P, I64, I32, F32, P],
     "tnt_bn_nchunk": [I32],
     "tnt_batchnorm_fwd_f32": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, F32, F32, P, P],
     "tnt_batchnorm_bwd_f32": [P, P, P, P, P, P, P, I32, I32, I32, I32, P, P],
+    "tnt_batchnorm_fwd_drop_f32": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, F32, F32, P, F32, U64, U32, P, P],
+    "tnt_batchnorm_bwd_act_f32": [P, P, P, P, P, P, P, I32, I32, I32, I32, P, P, F32, P],
     "tnt_batchnorm_stats_f32": [P, I32, I32, P, P],
     "tnt_batchnorm_apply_stats_f32": [P, I32, P, P, P, P, P, P, P, P, I32, I32, I32, F32, F32, P, P],
     "tnt_batchnorm_dx_f32": [P, I32, P, P, P, P, P, P, I32, I32, I32, P],
@@ -41,6 +44,7 @@ SIGNATURES = {
     "tnt_embedding_fwd_f32": [P, P, P, I32, I32, I32, I32, I32, P],
     "tnt_embedding_bwd_parts": [I32, I32, I32],
     "tnt_attention_front_bwd_parts": [I32, I32, I32],
+    "tnt_attention_metric_parts": [I32, I32],
     "tnt_embedding_bwd_sparse_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, F32, U64, U32, P, P],
     "tnt_embedding_bwd_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, P],
     "tnt_lstm_seq_supported": [I32, I32],
@@ -60,6 +64,7 @@ SIGNATURES = {
     "tnt_enc_tail_bwd_drop_f32": [P, P, P, P, P, P, P, P, P, I32, I32, I32, F32, F32, F32, U64, U32, U32, P, P, I32, I32, I32, I32,
                                   I32, I32, F32, U32, P],
     "tnt_embedding_fwd_drop_f32": [P, P, P, P, I32, I32, I32, I32, I32, F32, U64, U32, U32, P, P],
+    "tnt_embedding_fwd_drop2_f32": [P, P, P, P, I32, I32, I32, I32, I32, F32, U64, U32, U32, P, F32, U32, I32, I32, P],
     "tnt_dense_dw_skinny_f32": [P, P, P, I32, I32, I32, I32, P],
     "tnt_dense_dw_sqnorm_f32": [P, P, P, F32, P, I32, I32, I32, I32, I32, P],
     "tnt_dense_dw_adam_f32": [P, P, P, P, P, F32, P, P, P, F32, F32, F32, F32, P, I32, I32, I32, I32, P],
@@ -76,6 +81,7 @@ SIGNATURES = {
     "tnt_lc_seq_fwd_f32": [P, P, P, P, P, P, P, P, P, P, P, I64, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, F32, F32, F32,
                            I32, U64, U32, U32, P, P, P, P],
     "tnt_attention_front_bwd_f32": [P, P, P, P, P, P, P, P, I32, I32, I32, F32, P],
+    "tnt_attention_front_bwd_drop_f32": [P, P, P, P, P, P, P, P, I32, I32, I32, F32, F32, U64, U32, P, P],
     "tnt_gemm_blas_f32": [P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
     "tnt_gemm_lt_f32": [P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, P],
     "tnt_locally_dense_fwd_split_f32": [P, I32, P, P, P, P, I32, P, P, P, P, P, I32, I32, I32, F32, I32, P],
@@ -89,7 +95,8 @@ SIGNATURES = {
     "tnt_l2_total_f32": [P, P, I32, P, P],
     "tnt_seg_sqnorm_f32": [P, P, P, P, P, P, P, P, P, P, P, I32, I32, P],
     "tnt_span_sqnorm_f32": [P, P, P, P, P, P, P, I32, P],
-    "tnt_step_finalize_f32": [P, P, P, P, P, P, I32, P, P, P, P, I32, F32, P, P, I32, P, P, I32, P, P, P, P, F32, F32, P, P],
+    "tnt_step_finalize_f32": [P, P, P, P, P, P, I32, P, P, P, P, I32, F32, P, P, I32, P, P, I32, P, P, I32, F32, P, P, P, P,
+                              F32, F32, P, P],
     "tnt_adam_f32": [P, P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, F32, F32, P, P],
     "tnt_sgd_f32": [P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, P, P],
     "tnt_agc_f32": [P, P, P, P, P, P, P, I32, P, P, I32, I32, I32, P, P, F32, F32, P],

@@ -289,27 +289,34 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttArgs g) {
   }
 }
 
-// one workgroup per timestep: partial[t] = sum_r (1 - sum_b alpha[t][b][r])^2
+// workgroup (t, c): partial[t * nc + c] = sum over its 64 regions r of (1 - sum_b alpha[t][b][r])^2; the 4 waves split the
+// batch (independent loads), their partial sums meet in LDS in wave order
 __global__ __launch_bounds__(256) void attention_metric_kernel(const float* alpha, float* partial, int T, int B, int R,
                                                                long tstride) {
-  __shared__ float sw[4];
-  const int t = blockIdx.x;
-  float acc = 0.f;
-  for (int r = threadIdx.x; r < R; r += 256) {
-    float s = 0.f;
+  __shared__ float sb[4][64];
+  const int t = blockIdx.x, c = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = c * 64 + lane;
+  float s = 0.f;
+  if (r < R) {
 #pragma unroll 8
-    for (int b = 0; b < B; ++b) s += alpha[(long)t * tstride + (long)b * R + r];
-    acc += (1.f - s) * (1.f - s);
+    for (int b = w; b < B; b += 4) s += alpha[(long)t * tstride + (long)b * R + r];
   }
-  acc = block_sum256(acc, sw);
-  if (threadIdx.x == 0) partial[t] = acc;
+  sb[w][lane] = s;
+  __syncthreads();
+  if (w != 0) return;
+  float acc = 0.f;
+  if (r < R) {
+    const float tot = ((sb[0][lane] + sb[1][lane]) + sb[2][lane]) + sb[3][lane];
+    acc = (1.f - tot) * (1.f - tot);
+  }
+  acc = tnt_wave_sum(acc);
+  if (lane == 0) partial[t * gridDim.y + c] = acc;
 }
-__global__ void attention_metric_final_kernel(const float* partial, float* out, int T, float scale) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float s = 0.f;
-    for (int t = 0; t < T; ++t) s += partial[t];
-    out[0] = s * scale;
-  }
+__global__ void attention_metric_final_kernel(const float* partial, float* out, int n, float scale) {
+  float s = 0.f;
+  for (int t = threadIdx.x; t < n; t += 64) s += partial[t];
+  s = tnt_wave_sum(s);
+  if (threadIdx.x == 0) out[0] = s * scale;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -759,13 +766,18 @@ extern "C" int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* 
   return 0;
 }
 
+extern "C" int32_t tnt_attention_metric_parts(int32_t T, int32_t R) { return T * ((R + 63) / 64); }
+
 extern "C" int32_t tnt_attention_metric_f32(const float* alpha, float* out, float* work, int32_t T, int32_t B,
                                             int32_t R, int64_t tstride, void* stream) {
+  if (T <= 0 || B <= 0 || R <= 0) return TNT_BADARG(4);
   if (tstride <= 0) tstride = (int64_t)B * R;
-  hipLaunchKernelGGL(attention_metric_kernel, dim3(T), dim3(256), 0, tnt_stream(stream), alpha, work, T, B, R,
+  const int nc = (R + 63) / 64;
+  hipLaunchKernelGGL(attention_metric_kernel, dim3(T, nc), dim3(256), 0, tnt_stream(stream), alpha, work, T, B, R,
                      (long)tstride);
   TNT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attention_metric_final_kernel, dim3(1), dim3(64), 0, tnt_stream(stream), work, out, T,
+  if (out == nullptr) return 0;           // the caller totals work[0 .. T * nc) * 1 / (T R) (tnt_step_finalize_f32's x2 job)
+  hipLaunchKernelGGL(attention_metric_final_kernel, dim3(1), dim3(64), 0, tnt_stream(stream), work, out, T * nc,
                      1.f / ((float)T * (float)R));
   TNT_LAUNCH_CHECK();
   return 0;
@@ -786,7 +798,8 @@ constexpr int AF_TILE = 120, AF_CHUNK = 120, AF_BROWS = 64, AF_W = 32;      // D
 
 __global__ __launch_bounds__(256) void attention_front_bwd_kernel(const float* Ppre, const float* dP, const float* F,
                                                                   const float* W1, float* dF, float* part, int rows,
-                                                                  float slope, int nA) {
+                                                                  float slope, int nA, float drop_rate, uint64_t drop_seed,
+                                                                  uint32_t drop_site, const uint32_t* drop_step_dev) {
   constexpr int W = AF_W, LD = AF_W + 4;                 // LDS rows of 36 floats: 16-byte aligned float4 reads
   __shared__ __attribute__((aligned(16))) float gs[AF_TILE * LD];
   __shared__ __attribute__((aligned(16))) float Fs[AF_TILE * LD];
@@ -830,6 +843,17 @@ __global__ __launch_bounds__(256) void attention_front_bwd_kernel(const float* P
     float4* o = reinterpret_cast<float4*>(dF + (long)(row0 + r) * W + d0);
     float4 u0 = o[0], u1 = o[1];
     u0.x += t[0]; u0.y += t[1]; u0.z += t[2]; u0.w += t[3]; u1.x += t[4]; u1.y += t[5]; u1.z += t[6]; u1.w += t[7];
+    if (drop_rate > 0.f) {
+      // dF is complete here: the backward of the feature Dropout in front of the attention (layers.py:51) in the same pass
+      const uint32_t step = drop_step_dev ? drop_step_dev[0] : 0u;
+      const float sc = 1.f / (1.f - drop_rate);
+      const uint64_t le = (uint64_t)(row0 + r) * W + d0;
+      bool k0[4], k1[4];
+      tnt_keep4(le, drop_rate, drop_seed, drop_site, step, k0);
+      tnt_keep4(le + 4, drop_rate, drop_seed, drop_site, step, k1);
+      u0.x = k0[0] ? u0.x * sc : 0.f; u0.y = k0[1] ? u0.y * sc : 0.f; u0.z = k0[2] ? u0.z * sc : 0.f; u0.w = k0[3] ? u0.w * sc : 0.f;
+      u1.x = k1[0] ? u1.x * sc : 0.f; u1.y = k1[1] ? u1.y * sc : 0.f; u1.z = k1[2] ? u1.z * sc : 0.f; u1.w = k1[3] ? u1.w * sc : 0.f;
+    }
     o[0] = u0; o[1] = u1;
     return;
   }
@@ -891,20 +915,29 @@ extern "C" int32_t tnt_attention_front_bwd_parts(int32_t rows, int32_t D, int32_
   return ((rows + AF_CHUNK - 1) / AF_CHUNK) * (D * A + A);
 }
 
-extern "C" int32_t tnt_attention_front_bwd_f32(const float* Ppre, const float* dP, const float* F, const float* W1,
-                                               float* dF, float* dW1, float* db1, float* part, int32_t rows, int32_t D,
-                                               int32_t A, float slope, void* stream) {
+extern "C" int32_t tnt_attention_front_bwd_drop_f32(const float* Ppre, const float* dP, const float* F, const float* W1,
+                                                    float* dF, float* dW1, float* db1, float* part, int32_t rows, int32_t D,
+                                                    int32_t A, float slope, float drop_rate, uint64_t drop_seed,
+                                                    uint32_t drop_site, const uint32_t* drop_step_dev, void* stream) {
+  if (drop_rate < 0.f || drop_rate >= 1.f) return TNT_BADARG(13);
   if (rows <= 0 || D != AF_W || A != AF_W) return TNT_BADARG(9);          // callers keep the unfused sequence otherwise
   if (!tnt_aligned16(Ppre) || !tnt_aligned16(dP) || !tnt_aligned16(F) || !tnt_aligned16(W1) || !tnt_aligned16(dF) ||
       !tnt_aligned16(part)) return TNT_BADARG(1);
   const int nA = (rows + AF_CHUNK - 1) / AF_CHUNK, nB = (rows + AF_BROWS - 1) / AF_BROWS;
   hipStream_t s = tnt_stream(stream);
-  hipLaunchKernelGGL(attention_front_bwd_kernel, dim3(nA + nB), dim3(256), 0, s, Ppre, dP, F, W1, dF, part, rows, slope, nA);
+  hipLaunchKernelGGL(attention_front_bwd_kernel, dim3(nA + nB), dim3(256), 0, s, Ppre, dP, F, W1, dF, part, rows, slope, nA,
+                     drop_rate, drop_seed, drop_site, drop_step_dev);
   TNT_LAUNCH_CHECK();
   hipLaunchKernelGGL(attention_front_finalize_kernel, dim3((D * A + A + 63) / 64), dim3(64 * AFF_S), 0, s, part, nA, D * A + A, D * A,
                      dW1, db1);
   TNT_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int32_t tnt_attention_front_bwd_f32(const float* Ppre, const float* dP, const float* F, const float* W1,
+                                               float* dF, float* dW1, float* db1, float* part, int32_t rows, int32_t D,
+                                               int32_t A, float slope, void* stream) {
+  return tnt_attention_front_bwd_drop_f32(Ppre, dP, F, W1, dF, dW1, db1, part, rows, D, A, slope, 0.f, 0, 0, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -311,6 +311,7 @@ struct FinalizeArgs {
   const float* x0; float* out0; const float* x1; float* out1; int n; float scale;
   const float* extra_part; float* extra; int n_extra;
   const int32_t* ids_src; int32_t* ids_dst; int n_ids;       // (4b) ids of this step -> prev_ids (tnt_embedding_bwd_sparse_f32)
+  const float* x2; float* out2; int n2; float scale2;        // (4c) one more scaled total (the attention metric's T partials)
   int64_t* adam_t; uint32_t* drop_step; const float* lr; float* lr_t; float b1, b2; const uint32_t* guard;
 };
 
@@ -319,9 +320,9 @@ __global__ __launch_bounds__(1024) void step_finalize_kernel(FinalizeArgs a) {
   // (the jobs used to run one after the other, each a cold load round trip + a barrier pair: 8 us back to back, 13 us inside
   // the captured step, where every input was just written by other CUs), then all wave partials meet in LDS once and four
   // different threads finish the four scalars while a fifth ticks the step counters.
-  __shared__ float sw[4][16];
+  __shared__ float sw[5][16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  float l = 0.f, s0 = 0.f, s1 = 0.f, e = 0.f;
+  float l = 0.f, s0 = 0.f, s1 = 0.f, e = 0.f, s2 = 0.f;
   // (1) per-variable norms.  Small variables (<= 8 spans: every variable of the region-wise model, hundreds of them) one per
   // THREAD, serially over their spans; large ones one per wave, lanes striding over the spans + a fixed shuffle tree.  (A wave
   // per small variable would walk 700+ variables 16 at a time, each step a dependent load pair: ~30 us on the attention
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(1024) void step_finalize_kernel(FinalizeArgs a) {
   // (3) loss / accuracy totals, (4) extra partials (the Embedding's sparse norm), ids hand-over: loads in flight together
   for (int i = tid; i < a.n; i += 1024) { s0 += a.x0[i]; if (a.x1) s1 += a.x1[i]; }
   for (int i = tid; i < a.n_extra; i += 1024) e += a.extra_part[i];
+  for (int i = tid; i < a.n2; i += 1024) s2 += a.x2[i];
   for (int i = tid; i < a.n_ids; i += 1024) a.ids_dst[i] = a.ids_src[i];
   for (int s = w; s < a.nseg; s += 16) {
     const int k0 = a.t.seg_first[s], k1 = a.t.seg_first[s + 1];
@@ -346,10 +348,10 @@ __global__ __launch_bounds__(1024) void step_finalize_kernel(FinalizeArgs a) {
     q = tnt_wave_sum(q); ws = tnt_wave_sum(ws);
     if (lane == 0) { a.sq[s] = q; a.wsq[s] = ws; l += a.t.seg_l2[s] * ws; }
   }
-  l = tnt_wave_sum(l); s0 = tnt_wave_sum(s0); s1 = tnt_wave_sum(s1); e = tnt_wave_sum(e);
-  if (lane == 0) { sw[0][w] = l; sw[1][w] = s0; sw[2][w] = s1; sw[3][w] = e; }
+  l = tnt_wave_sum(l); s0 = tnt_wave_sum(s0); s1 = tnt_wave_sum(s1); e = tnt_wave_sum(e); s2 = tnt_wave_sum(s2);
+  if (lane == 0) { sw[0][w] = l; sw[1][w] = s0; sw[2][w] = s1; sw[3][w] = e; sw[4][w] = s2; }
   __syncthreads();
-  if (lane == 0 && w < 4) {
+  if (lane == 0 && w < 5) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += sw[w][k];
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(1024) void step_finalize_kernel(FinalizeArgs a) {
     if (w == 1 && a.n > 0) a.out0[0] = t * a.scale;
     if (w == 2 && a.n > 0 && a.x1) a.out1[0] = t * a.scale;
     if (w == 3 && a.n_extra > 0) a.extra[0] = t;
+    if (w == 4 && a.n2 > 0) a.out2[0] = t * a.scale2;
   }
   // (5)
   if (tid == 256 && !(a.guard && a.guard[0] != 0u)) {
@@ -483,15 +486,18 @@ extern "C" int32_t tnt_step_finalize_f32(const float* partial, const int32_t* se
                                          float* wsq, float* l2_out, int32_t nseg, const float* x0, float* out0,
                                          const float* x1, float* out1, int32_t n, float scale, const float* extra_part,
                                          float* extra, int32_t n_extra, const int32_t* ids_src, int32_t* ids_dst,
-                                         int32_t n_ids, int64_t* adam_t, uint32_t* drop_step, const float* lr,
+                                         int32_t n_ids, const float* x2, float* out2, int32_t n2, float scale2,
+                                         int64_t* adam_t, uint32_t* drop_step, const float* lr,
                                          float* lr_t, float beta1, float beta2, const uint32_t* guard, void* stream) {
-  if (nseg < 0 || n < 0 || n_extra < 0) return TNT_BADARG(7);
+  if (nseg < 0 || n < 0 || n_extra < 0 || n2 < 0) return TNT_BADARG(7);
+  if (n2 > 0 && (x2 == nullptr || out2 == nullptr)) return TNT_BADARG(20);
   if (n > 0 && (x0 == nullptr || out0 == nullptr)) return TNT_BADARG(8);
   FinalizeArgs a;
   a.partial = partial; a.t = SpanTab{nullptr, nullptr, nullptr, seg_first, seg_l2}; a.sq = sq; a.wsq = wsq; a.l2_out = l2_out;
   a.nseg = nseg; a.x0 = x0; a.out0 = out0; a.x1 = x1; a.out1 = out1; a.n = n; a.scale = scale;
   a.extra_part = extra_part; a.extra = extra; a.n_extra = n_extra;
   a.ids_src = ids_src; a.ids_dst = ids_dst; a.n_ids = (ids_src && ids_dst) ? n_ids : 0;
+  a.x2 = x2; a.out2 = out2; a.n2 = n2; a.scale2 = scale2;
   a.adam_t = adam_t; a.drop_step = drop_step; a.lr = lr; a.lr_t = lr_t; a.b1 = beta1; a.b2 = beta2; a.guard = guard;
   hipLaunchKernelGGL(step_finalize_kernel, dim3(1), dim3(1024), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();

@@ -64,6 +64,31 @@ __global__ __launch_bounds__(256) void dropout4_kernel(DropArgs a) {
   }
 }
 
+// two masks in one pass (y = mask_b(mask_a(x)), the bits of two tnt_dropout_f32 launches): same matrix, two logical layouts
+__global__ __launch_bounds__(256) void dropout4x2_kernel(DropArgs a, DropArgs b) {
+  const uint32_t step = a.step + (a.step_dev ? a.step_dev[0] : 0u);
+  const int c4n = a.cols >> 2;
+  const long total = (long)a.rows * c4n;
+  const int Ta = a.tB > 0 ? a.rows / a.tB : 0, Tb = b.tB > 0 ? b.rows / b.tB : 0;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int r = (int)(e / c4n), c = (int)(e % c4n) * 4;
+    long lrow; uint32_t site;
+    bool ka[4], kb[4];
+    drop_row(a, r, Ta, lrow, site);
+    tnt_keep4((uint64_t)lrow * (uint64_t)a.lwidth + (uint64_t)(a.lcol0 + c), a.rate, a.seed, site, step, ka);
+    drop_row(b, r, Tb, lrow, site);
+    tnt_keep4((uint64_t)lrow * (uint64_t)b.lwidth + (uint64_t)(b.lcol0 + c), b.rate, b.seed, site, step, kb);
+    const long o = (long)r * a.ld + c;
+    const float4 v = *reinterpret_cast<const float4*>(a.x + o);
+    float4 w;
+    w.x = ka[0] ? v.x * a.scale : 0.f; w.y = ka[1] ? v.y * a.scale : 0.f;
+    w.z = ka[2] ? v.z * a.scale : 0.f; w.w = ka[3] ? v.w * a.scale : 0.f;
+    w.x = kb[0] ? w.x * b.scale : 0.f; w.y = kb[1] ? w.y * b.scale : 0.f;
+    w.z = kb[2] ? w.z * b.scale : 0.f; w.w = kb[3] ? w.w * b.scale : 0.f;
+    *reinterpret_cast<float4*>(a.y + o) = w;
+  }
+}
+
 // Keep-masks only, one byte per 4 consecutive logical elements (bit j = element 4g + j kept), for `nsites`
 // consecutive sites of n4 groups each.  Philox4x32-10 is 40 quarter-rate integer multiplies per call: ~2 us inside each
 // of the per-timestep attention kernels, which run on B of the 256 CUs on the serial chain, but ~10 us for all T
@@ -208,15 +233,49 @@ __global__ void bn_infer_prep_kernel(const float* mov_mean, const float* mov_var
   inv_std[c] = 1.f / sqrtf(mov_var[c] + eps);
 }
 
+// y = BN(x) (and xhat for the backward); rate > 0: the keras Dropout behind the normalisation (layers.py:50-51) in the same
+// pass -- y = keep ? BN(x) / (1 - rate) : 0, element r * C + c of stream (seed, site, step)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const float* mean, const float* inv_std,
                                                        const float* gamma, const float* beta, float* y, float* xhat,
-                                                       int rows, int C, int ldy) {
+                                                       int rows, int C, int ldy, float rate, uint64_t seed, uint32_t site,
+                                                       const uint32_t* step_dev) {
   const long total = (long)rows * C;
+  const uint32_t step = step_dev ? step_dev[0] : 0u;
+  const float scale = 1.f / (1.f - rate);
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int r = (int)(e / C), c = (int)(e % C);
     const float xh = (x[e] - mean[c]) * inv_std[c];
     xhat[e] = xh;
-    y[(long)r * ldy + c] = xh * gamma[c] + beta[c];
+    float v = xh * gamma[c] + beta[c];
+    if (rate > 0.f) v = tnt_keep((uint64_t)e, rate, seed, site, step) ? v * scale : 0.f;
+    y[(long)r * ldy + c] = v;
+  }
+}
+
+// 4 consecutive columns per thread (C, ldy % 4 == 0, 16-byte aligned): one Philox call per float4
+__global__ __launch_bounds__(256) void bn_apply4_kernel(const float* x, const float* mean, const float* inv_std,
+                                                        const float* gamma, const float* beta, float* y, float* xhat,
+                                                        int rows, int C, int ldy, float rate, uint64_t seed, uint32_t site,
+                                                        const uint32_t* step_dev) {
+  const int c4n = C >> 2;
+  const long total = (long)rows * c4n;
+  const uint32_t step = step_dev ? step_dev[0] : 0u;
+  const float scale = 1.f / (1.f - rate);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int r = (int)(e / c4n), c = (int)(e % c4n) * 4;
+    const float4 xv = *reinterpret_cast<const float4*>(x + e * 4);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(inv_std + c);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+    const float4 xh = make_float4((xv.x - mu.x) * is.x, (xv.y - mu.y) * is.y, (xv.z - mu.z) * is.z, (xv.w - mu.w) * is.w);
+    *reinterpret_cast<float4*>(xhat + e * 4) = xh;
+    float4 v = make_float4(xh.x * ga.x + be.x, xh.y * ga.y + be.y, xh.z * ga.z + be.z, xh.w * ga.w + be.w);
+    if (rate > 0.f) {
+      bool k[4];
+      tnt_keep4((uint64_t)e * 4, rate, seed, site, step, k);
+      v.x = k[0] ? v.x * scale : 0.f; v.y = k[1] ? v.y * scale : 0.f;
+      v.z = k[2] ? v.z * scale : 0.f; v.w = k[3] ? v.w * scale : 0.f;
+    }
+    *reinterpret_cast<float4*>(y + (long)r * ldy + c) = v;
   }
 }
 
@@ -243,16 +302,21 @@ __global__ __launch_bounds__(64) void col_finalize_kernel(const float* work, int
 }
 
 // dx = gamma*inv/n * (n*dy - dbeta - xhat*dgamma)   (training)  |  gamma*inv*dy (inference)
+// act_pre != NULL: dx is further multiplied by LeakyReLU'(act_pre) -- the activation in front of the normalisation
+// (layers.py:48-50), whose backward would otherwise be one more elementwise launch over the same matrix
 __global__ __launch_bounds__(256) void bn_dx_kernel(const float* dy, int lddy, const float* xhat, const float* gamma,
                                                     const float* inv_std, const float* dgamma, const float* dbeta,
-                                                    float* dx, int rows, int C, int training, int n_total) {
+                                                    float* dx, int rows, int C, int training, int n_total,
+                                                    const float* act_pre, float slope) {
   const long total = (long)rows * C;
   const float n = (float)n_total;       // rows of the whole (possibly cross-replica) batch the sums were taken over
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int r = (int)(e / C), c = (int)(e % C);
     const float g = dy[(long)r * lddy + c];
     const float k = gamma[c] * inv_std[c];
-    dx[e] = training ? k / n * (n * g - dbeta[c] - xhat[e] * dgamma[c]) : k * g;
+    float d = training ? k / n * (n * g - dbeta[c] - xhat[e] * dgamma[c]) : k * g;
+    if (act_pre) d = tnt_act_grad(act_pre[e], d, 1, slope);
+    dx[e] = d;
   }
 }
 
@@ -414,6 +478,36 @@ extern "C" int32_t tnt_dropout_f32(const float* x, float* y, int32_t rows, int32
     hipLaunchKernelGGL(dropout4_kernel, dim3(ew_blocks((long)rows * (cols / 4))), dim3(256), 0, tnt_stream(stream), a);
   else
     hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks((long)rows * cols)), dim3(256), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+// y = mask_b(mask_a(x)) in one launch: two Dropout masks over the same [rows][cols] matrix, each with its own logical layout
+// (tmajor_B / lwidth / lcol0 / rows_per_site as in tnt_dropout_f32), rate and site; same seed and step.  Vectorised only:
+// cols, ld, lwidth*, lcol0* % 4 == 0 and 16-byte aligned x / y (else TNT_BADARG: issue two tnt_dropout_f32 calls).
+extern "C" int32_t tnt_dropout2_f32(const float* x, float* y, int32_t rows, int32_t cols, int32_t ld, int32_t tmajor_B_a,
+                                    int32_t lwidth_a, int32_t lcol0_a, int32_t rows_per_site_a, float rate_a, uint32_t site_a,
+                                    int32_t tmajor_B_b, int32_t lwidth_b, int32_t lcol0_b, int32_t rows_per_site_b,
+                                    float rate_b, uint32_t site_b, uint64_t seed, uint32_t step, const uint32_t* step_dev,
+                                    void* stream) {
+  if (rows <= 0 || cols <= 0) return 0;
+  if (!(rate_a > 0.f && rate_a < 1.f && rate_b > 0.f && rate_b < 1.f)) return TNT_BADARG(10);
+  const int tb[2] = {tmajor_B_a, tmajor_B_b}, rps[2] = {rows_per_site_a, rows_per_site_b};
+  for (int k = 0; k < 2; ++k) {
+    const int rsite = rps[k] > 0 ? rps[k] : rows;
+    if (tb[k] > 0 && rsite % tb[k] != 0) return TNT_BADARG(6);
+    if (rps[k] > 0 && tb[k] > 0) return TNT_BADARG(9);
+  }
+  if (((cols | ld | lwidth_a | lcol0_a | lwidth_b | lcol0_b) & 3) != 0 || !tnt_aligned16(x) || !tnt_aligned16(y))
+    return TNT_BADARG(3);
+  DropArgs a, b;
+  a.x = x; a.y = y; a.rows = rows; a.cols = cols; a.ld = ld; a.tB = tmajor_B_a; a.lwidth = lwidth_a; a.lcol0 = lcol0_a;
+  a.rows_per_site = rows_per_site_a; a.rate = rate_a; a.scale = 1.0f / (1.0f - rate_a); a.seed = seed; a.site = site_a;
+  a.step = step; a.step_dev = step_dev;
+  b = a;
+  b.tB = tmajor_B_b; b.lwidth = lwidth_b; b.lcol0 = lcol0_b; b.rows_per_site = rows_per_site_b; b.rate = rate_b;
+  b.scale = 1.0f / (1.0f - rate_b); b.site = site_b;
+  hipLaunchKernelGGL(dropout4x2_kernel, dim3(ew_blocks((long)rows * (cols / 4))), dim3(256), 0, tnt_stream(stream), a, b);
   TNT_LAUNCH_CHECK();
   return 0;
 }
@@ -782,10 +876,27 @@ extern "C" int32_t tnt_enc_tail_bwd_drop_f32(const float* dout, const float* xha
 }
 
 // work layout for BN: [mean C][partials 2*C*nchunk]
-extern "C" int32_t tnt_batchnorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* mov_mean,
-                                         float* mov_var, float* y, float* xhat, float* inv_std, int32_t rows, int32_t C,
-                                         int32_t ldy, int32_t training, float eps, float momentum, float* work,
-                                         void* stream) {
+namespace {
+void launch_bn_apply(const float* x, const float* mean, const float* inv_std, const float* gamma, const float* beta, float* y,
+                     float* xhat, int rows, int C, int ldy, float rate, uint64_t seed, uint32_t site,
+                     const uint32_t* step_dev, hipStream_t s) {
+  const bool vec = ((C | ldy) & 3) == 0 && tnt_aligned16(x) && tnt_aligned16(y) && tnt_aligned16(xhat) && tnt_aligned16(mean) &&
+                   tnt_aligned16(inv_std) && tnt_aligned16(gamma) && tnt_aligned16(beta);
+  if (vec)
+    hipLaunchKernelGGL(bn_apply4_kernel, dim3(ew_blocks((long)rows * (C / 4))), dim3(256), 0, s, x, mean, inv_std, gamma, beta,
+                       y, xhat, rows, C, ldy, rate, seed, site, step_dev);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks((long)rows * C)), dim3(256), 0, s, x, mean, inv_std, gamma, beta, y,
+                       xhat, rows, C, ldy, rate, seed, site, step_dev);
+}
+}  // namespace
+
+extern "C" int32_t tnt_batchnorm_fwd_drop_f32(const float* x, const float* gamma, const float* beta, float* mov_mean,
+                                              float* mov_var, float* y, float* xhat, float* inv_std, int32_t rows,
+                                              int32_t C, int32_t ldy, int32_t training, float eps, float momentum,
+                                              float* work, float rate, uint64_t seed, uint32_t site,
+                                              const uint32_t* step_dev, void* stream) {
+  if (rate < 0.f || rate >= 1.f) return TNT_BADARG(16);
   hipStream_t s = tnt_stream(stream);
   const int nchunk = chunk_count(rows);
   float* mean = work;
@@ -801,15 +912,23 @@ extern "C" int32_t tnt_batchnorm_fwd_f32(const float* x, const float* gamma, con
                        inv_std);
     TNT_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks((long)rows * C)), dim3(256), 0, s, x, mean, inv_std, gamma, beta, y,
-                     xhat, rows, C, ldy);
+  launch_bn_apply(x, mean, inv_std, gamma, beta, y, xhat, rows, C, ldy, rate, seed, site, step_dev, s);
   TNT_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int32_t tnt_batchnorm_bwd_f32(const float* dy, const float* xhat, const float* gamma, const float* inv_std,
-                                         float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, int32_t lddy,
-                                         int32_t training, float* work, void* stream) {
+extern "C" int32_t tnt_batchnorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* mov_mean,
+                                         float* mov_var, float* y, float* xhat, float* inv_std, int32_t rows, int32_t C,
+                                         int32_t ldy, int32_t training, float eps, float momentum, float* work,
+                                         void* stream) {
+  return tnt_batchnorm_fwd_drop_f32(x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, training, eps, momentum,
+                                    work, 0.f, 0, 0, nullptr, stream);
+}
+
+extern "C" int32_t tnt_batchnorm_bwd_act_f32(const float* dy, const float* xhat, const float* gamma, const float* inv_std,
+                                             float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, int32_t lddy,
+                                             int32_t training, float* work, const float* act_pre, float slope,
+                                             void* stream) {
   hipStream_t s = tnt_stream(stream);
   if (dgamma != nullptr || dbeta != nullptr) {        // both null: input gradient only (per-step use inside a T-step chain)
     if (dgamma == nullptr || dbeta == nullptr || work == nullptr) return TNT_BADARG(6);
@@ -822,10 +941,17 @@ extern "C" int32_t tnt_batchnorm_bwd_f32(const float* dy, const float* xhat, con
   }
   if (dx) {
     hipLaunchKernelGGL(bn_dx_kernel, dim3(ew_blocks((long)rows * C)), dim3(256), 0, s, dy, lddy, xhat, gamma, inv_std,
-                       dgamma, dbeta, dx, rows, C, training, rows);
+                       dgamma, dbeta, dx, rows, C, training, rows, act_pre, slope);
     TNT_LAUNCH_CHECK();
   }
   return 0;
+}
+
+extern "C" int32_t tnt_batchnorm_bwd_f32(const float* dy, const float* xhat, const float* gamma, const float* inv_std,
+                                         float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, int32_t lddy,
+                                         int32_t training, float* work, void* stream) {
+  return tnt_batchnorm_bwd_act_f32(dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, training, work, nullptr, 0.f,
+                                   stream);
 }
 
 // ---- synchronised BatchNorm (data parallel, opt-in): the three pieces of tnt_batchnorm_{fwd,bwd}_f32 around the caller's
@@ -848,8 +974,7 @@ extern "C" int32_t tnt_batchnorm_apply_stats_f32(const float* part_all, int32_t 
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part_all, rows, C, chunk_count(rows), chunk_rows(rows), eps,
                      momentum, mov_mean, mov_var, mean_work, inv_std, nrep);
   TNT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks((long)rows * C)), dim3(256), 0, s, x, mean_work, inv_std, gamma, beta, y,
-                     xhat, rows, C, ldy);
+  launch_bn_apply(x, mean_work, inv_std, gamma, beta, y, xhat, rows, C, ldy, 0.f, 0, 0, nullptr, s);
   TNT_LAUNCH_CHECK();
   return 0;
 }
@@ -859,7 +984,7 @@ extern "C" int32_t tnt_batchnorm_dx_f32(const float* dy, int32_t lddy, const flo
                                         int32_t rows, int32_t C, int32_t n_total, void* stream) {
   if (rows <= 0 || C <= 0 || n_total < rows) return TNT_BADARG(8);
   hipLaunchKernelGGL(bn_dx_kernel, dim3(ew_blocks((long)rows * C)), dim3(256), 0, tnt_stream(stream), dy, lddy, xhat, gamma,
-                     inv_std, dgamma_sum, dbeta_sum, dx, rows, C, 1, n_total);
+                     inv_std, dgamma_sum, dbeta_sum, dx, rows, C, 1, n_total, nullptr, 0.f);
   TNT_LAUNCH_CHECK();
   return 0;
 }

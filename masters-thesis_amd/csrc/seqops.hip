@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(const float* table, const 
 // layer's input dropout): element index (b*T + t)*E + j, 4 columns per Philox call (E % 4 == 0).
 __global__ __launch_bounds__(256) void emb_fwd_drop_kernel(const float* table, const int* ids, float* out, float* out_drop,
                                                            int B, int T, int E, int ldo, int V, float rate, uint64_t seed,
-                                                           uint32_t site, uint32_t step, const uint32_t* step_dev) {
+                                                           uint32_t site, uint32_t step, const uint32_t* step_dev,
+                                                           float rate2, uint32_t site2, int lwidth2, int lcol0_2) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // row = t*B + b
   if (row >= B * T) return;
   if (step_dev) step += step_dev[0];
@@ -39,8 +40,15 @@ __global__ __launch_bounds__(256) void emb_fwd_drop_kernel(const float* table, c
     if (out) *reinterpret_cast<float4*>(out + (long)row * ldo + j) = v;
     bool k[4];
     tnt_keep4((uint64_t)(b * T + t) * E + j, rate, seed, site, step, k);
-    *reinterpret_cast<float4*>(out_drop + (long)row * ldo + j) =
-        make_float4(k[0] ? v.x * scale : 0.f, k[1] ? v.y * scale : 0.f, k[2] ? v.z * scale : 0.f, k[3] ? v.w * scale : 0.f);
+    float4 w = make_float4(k[0] ? v.x * scale : 0.f, k[1] ? v.y * scale : 0.f, k[2] ? v.z * scale : 0.f, k[3] ? v.w * scale : 0.f);
+    if (rate2 > 0.f) {
+      // second mask: the LSTM layer's per-call input dropout over its (B, lwidth2) input, of which these are columns
+      // lcol0_2.. of the call of timestep t (site2 + t) -- lc_NIC.py:255 with dropout on the cell input
+      const float sc2 = 1.0f / (1.0f - rate2);
+      tnt_keep4((uint64_t)b * lwidth2 + lcol0_2 + j, rate2, seed, site2 + (uint32_t)t, step, k);
+      w = make_float4(k[0] ? w.x * sc2 : 0.f, k[1] ? w.y * sc2 : 0.f, k[2] ? w.z * sc2 : 0.f, k[3] ? w.w * sc2 : 0.f);
+    }
+    *reinterpret_cast<float4*>(out_drop + (long)row * ldo + j) = w;
   }
 }
 
@@ -629,16 +637,26 @@ extern "C" int32_t tnt_embedding_fwd_f32(const float* table, const int32_t* ids,
   return 0;
 }
 
+extern "C" int32_t tnt_embedding_fwd_drop2_f32(const float* table, const int32_t* ids, float* out, float* out_drop,
+                                               int32_t B, int32_t T, int32_t E, int32_t ldo, int32_t V, float rate,
+                                               uint64_t seed, uint32_t site, uint32_t step, const uint32_t* step_dev,
+                                               float rate2, uint32_t site2, int32_t lwidth2, int32_t lcol0_2, void* stream) {
+  if (E % 4 != 0 || ldo % 4 != 0 || !tnt_aligned16(table) || !tnt_aligned16(out_drop) || (out && !tnt_aligned16(out)))
+    return TNT_BADARG(7);
+  if (rate < 0.f || rate >= 1.f || rate2 < 0.f || rate2 >= 1.f) return TNT_BADARG(10);
+  if (rate2 > 0.f && ((lwidth2 | lcol0_2) % 4 != 0 || lcol0_2 < 0 || lcol0_2 + E > lwidth2)) return TNT_BADARG(17);
+  hipLaunchKernelGGL(emb_fwd_drop_kernel, dim3((B * T + 3) / 4), dim3(256), 0, tnt_stream(stream), table, ids, out,
+                     out_drop, B, T, E, ldo, V, rate, seed, site, step, step_dev, rate2, site2, lwidth2, lcol0_2);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int32_t tnt_embedding_fwd_drop_f32(const float* table, const int32_t* ids, float* out, float* out_drop,
                                               int32_t B, int32_t T, int32_t E, int32_t ldo, int32_t V, float rate,
                                               uint64_t seed, uint32_t site, uint32_t step, const uint32_t* step_dev,
                                               void* stream) {
-  if (E % 4 != 0 || ldo % 4 != 0 || !tnt_aligned16(table) || !tnt_aligned16(out_drop) || (out && !tnt_aligned16(out)))
-    return TNT_BADARG(7);
-  hipLaunchKernelGGL(emb_fwd_drop_kernel, dim3((B * T + 3) / 4), dim3(256), 0, tnt_stream(stream), table, ids, out,
-                     out_drop, B, T, E, ldo, V, rate, seed, site, step, step_dev);
-  TNT_LAUNCH_CHECK();
-  return 0;
+  return tnt_embedding_fwd_drop2_f32(table, ids, out, out_drop, B, T, E, ldo, V, rate, seed, site, step, step_dev, 0.f, 0, 0, 0,
+                                     stream);
 }
 
 extern "C" int32_t tnt_embedding_bwd_f32(const float* drows, const int32_t* ids, float* dtable, float* sq_norm,

@@ -371,6 +371,7 @@ class NIC(ModelBase):
         nch = max(self.be.bn_nchunk(B * R), self.be.bn_nchunk(n))
         self.work = f(max(D, A, 4 * U, ldV, H) * (2 * nch + 1))
         self.rowsq = f(n)
+        self.metric_part = f(T * ((self.R + 63) // 64))      # partial sums of the attention metric (tnt_attention_metric_parts)
         self._alloc_splitk([(n, H, V), (n, Et, 4 * U), (n, U, H), (D, 4 * U, n), (U, A, n), (D, A, B * R)])
         self.emb_seg = self.arena.entries["emb_text/embeddings"].seg
         self._shape = (B, T)
@@ -421,14 +422,17 @@ class NIC(ModelBase):
                                      self.enc_pre[r0:r1], self.enc_y[r0:r1], Bs, R, D, 0.2)
             bn = self.bn_name(q)
             Fq, xh = self.Fs[0][r0:r1], self.xhat[r0 * R:r1 * R]
-            if self.norm == "batch":
-                self._bn_fwd(self.enc_y[r0:r1], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), self.mov_mean[q],
-                             self.mov_var[q], Fq, xh, self.inv_std[q], Bs * R, D, D, training, self.work)
+            dropped = False
+            if self.norm == "batch":                 # the feature Dropout (layers.py:51) rides in the BN apply pass
+                drop = (self.r_feat, sd, S_FEAT + off, ds) if training and self.r_feat > 0 else None
+                dropped = self._bn_fwd(self.enc_y[r0:r1], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), self.mov_mean[q],
+                                       self.mov_var[q], Fq, xh, self.inv_std[q], Bs * R, D, D, training, self.work, drop=drop)
             else:
                 be.layernorm_fwd(self.enc_y[r0:r1], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), Fq, xh, self.inv_std[q],
                                  Bs * R, D, D, BN_EPS)
             if training and self.r_feat > 0:
-                be.dropout(Fq, Fq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT + off, 0, ds)        # layers.py:51
+                if not dropped:
+                    be.dropout(Fq, Fq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT + off, 0, ds)        # layers.py:51
                 if S > 1:                        # ms2_NIC.py:214,257: the feature Dropout is applied a second time
                     be.dropout(Fq, Fq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT2 + off, 0, ds)
         for i in range(self.depth):              # deep_layers.one_layer (deep_layers.py:53-59): Dense_r(x[:, r, :]), BN, Dropout
@@ -436,13 +440,15 @@ class NIC(ModelBase):
             be.locally_dense_fwd(xin, R * D, self.deep_idx, self.deep_goff, self.deepW[i], self.deepB[i], self.deep_pre[i],
                                  self.deep_y[i], B, R, D, 0.2)
             bn, q = f"input_bn/deep{i}", self.S + i
+            dropped = False
             if self.norm == "batch":
-                self._bn_fwd(self.deep_y[i], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), self.mov_mean[q], self.mov_var[q], out,
-                             self.deep_xhat[i], self.deep_istd[i], B * R, D, D, training, self.work)
+                drop = (self.r_feat, sd, S_DEEP + i, ds) if training and self.r_feat > 0 else None
+                dropped = self._bn_fwd(self.deep_y[i], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), self.mov_mean[q], self.mov_var[q],
+                                       out, self.deep_xhat[i], self.deep_istd[i], B * R, D, D, training, self.work, drop=drop)
             else:
                 be.layernorm_fwd(self.deep_y[i], a.p(f"{bn}/gamma"), a.p(f"{bn}/beta"), out, self.deep_xhat[i],
                                  self.deep_istd[i], B * R, D, D, BN_EPS)
-            if training and self.r_feat > 0:
+            if training and self.r_feat > 0 and not dropped:
                 be.dropout(out, out, B * R, D, D, 0, D, 0, self.r_feat, sd, S_DEEP + i, 0, ds)
         self.gemm_sk(self.F, a.p("attention/W1/kernel"), self.P, B * R, self.A, D, D, self.A, self.A,
                 bias=a.p("attention/W1/bias"), pre=self.Ppre, act=ACT_LEAKY, slope=0.2)      # attention.py:32 (hoisted)
@@ -498,14 +504,18 @@ class NIC(ModelBase):
         n = T * B
         sd, ds = self.seed, self.drop_step
         self._encode(B, training)
+        lstm_in_mask = training and self.r_lstm > 0 and not self.use_layer_norm
         if training and self.r_text > 0 and Et % 4 == 0:     # lc_NIC.py:233 + its Dropout in one launch
+            # ... and the text half of the per-call LSTM input mask over (B, 1, D + Et) behind it, when the layout allows
+            ride = lstm_in_mask and D % 4 == 0 and getattr(self, "fused_text_masks", True)
             be.embedding_fwd_drop(a.p("emb_text/embeddings"), self.cap, None, self.text, B, T, Et, Et, V, self.r_text,
-                                  sd, S_TEXT, 0, ds)
+                                  sd, S_TEXT, 0, ds, mask2=(self.r_lstm, S_LSTM_IN, D + Et, D) if ride else None)
+            lstm_in_mask = lstm_in_mask and not ride
         else:
             be.embedding_fwd(a.p("emb_text/embeddings"), self.cap, self.text, B, T, Et, Et, V)       # lc_NIC.py:233
             if training and self.r_text > 0:
                 be.dropout(self.text, self.text, n, Et, Et, B, Et, 0, self.r_text, sd, S_TEXT, 0, ds)
-        if training and self.r_lstm > 0 and not self.use_layer_norm:       # text half of the per-call LSTM input mask over (B,1,D+Et)
+        if lstm_in_mask:                                                   # text half of the per-call LSTM input mask over (B,1,D+Et)
             be.dropout(self.text, self.text, n, Et, Et, 0, D + Et, D, self.r_lstm, sd, S_LSTM_IN, 0, ds,
                        rows_per_site=B)
         Wl = a.p("lstm/kernel")
@@ -552,7 +562,13 @@ class NIC(ModelBase):
                            0.0)
         self._sum2(self.loss_row, self.met[0:1], self.corr_row, self.met[1:2], n, 1.0 / n)
         if self.S == 1:
-            be.attention_metric(self.alpha, self.met[3:4], self.rowsq, T, B, self.R)                        # :365-367
+            npart = be.attention_metric_parts(T, self.R) if hasattr(be, "attention_metric_parts") else 0
+            if self.__dict__.get("_defer_sum2") and want_grad and 0 < npart <= self.metric_part.numel():
+                # fused single-process step: partials only, their total rides in the step-finalize launch
+                be.attention_metric(self.alpha, None, self.metric_part, T, B, self.R)
+                self._metric_deferred = (self.metric_part, self.met[3:4], npart, 1.0 / (T * self.R))
+            else:
+                be.attention_metric(self.alpha, self.met[3:4], self.metric_part, T, B, self.R)              # :365-367
         else:       # per-subject loss / accuracy / attention metric (ms2_NIC.py:324-372)
             S, Bs = self.S, B // self.S
             be.colsum(self.loss_row, self.colB[:B], T, B, B, self.work)
@@ -561,7 +577,7 @@ class NIC(ModelBase):
                 k = 8 + 4 * q
                 be.sum(self.colB[q * Bs:], self.met[k:k + 1], Bs, 1.0 / (Bs * T))
                 be.sum(self.colB[B + q * Bs:], self.met[k + 1:k + 2], Bs, 1.0 / (Bs * T))
-                be.attention_metric(self.alpha.view(-1)[q * Bs * self.R:], self.met[k + 2:k + 3], self.rowsq, T, Bs,
+                be.attention_metric(self.alpha.view(-1)[q * Bs * self.R:], self.met[k + 2:k + 3], self.metric_part, T, Bs,
                                     self.R, B * self.R)
 
     # ------------------------------------------------------------------ backward
@@ -688,11 +704,18 @@ class NIC(ModelBase):
         sd, ds = self.seed, self.drop_step
         Wl = a.p("lstm/kernel")
         self.gemm_sk(self.dZK if self.use_layer_norm else self.dZ, Wl[D:], self.dtext, n, Et, 4 * U, 4 * U, 4 * U, Et, transB=True)
-        if self.r_lstm > 0 and not self.use_layer_norm:
-            be.dropout(self.dtext, self.dtext, n, Et, Et, 0, D + Et, D, self.r_lstm, sd, S_LSTM_IN, 0, ds,
-                       rows_per_site=B)
-        if self.r_text > 0:
-            be.dropout(self.dtext, self.dtext, n, Et, Et, B, Et, 0, self.r_text, sd, S_TEXT, 0, ds)
+        lstm_in = self.r_lstm > 0 and not self.use_layer_norm
+        if (lstm_in and self.r_text > 0 and Et % 4 == 0 and D % 4 == 0 and hasattr(be, "dropout2")
+                and getattr(self, "fused_text_masks", True)):
+            # the LSTM input mask and the Embedding Dropout of the text rows in one pass
+            be.dropout2(self.dtext, self.dtext, n, Et, Et, (0, D + Et, D, B, self.r_lstm, S_LSTM_IN),
+                        (B, Et, 0, 0, self.r_text, S_TEXT), sd, 0, ds)
+        else:
+            if lstm_in:
+                be.dropout(self.dtext, self.dtext, n, Et, Et, 0, D + Et, D, self.r_lstm, sd, S_LSTM_IN, 0, ds,
+                           rows_per_site=B)
+            if self.r_text > 0:
+                be.dropout(self.dtext, self.dtext, n, Et, Et, B, Et, 0, self.r_text, sd, S_TEXT, 0, ds)
         self._emb_rows = (self.dtext, n, Et, Et, "emb_text/embeddings")
         self._embedding_bwd(self.dtext, self.cap, "emb_text/embeddings", B, T, Et, Et, V)
 
@@ -712,6 +735,7 @@ class NIC(ModelBase):
         else:
             for x, out, rows, C, ld in jobs:
                 be.colsum(x, out, rows, C, ld, self.work)
+        fdrop = None                                   # (rate, seed, site, step_dev) of the Dropout' folded into the dF pass
         if getattr(self, "fused_att_front", True) and hasattr(be, "attention_front_bwd") and D == 32 and A == 32:
             # LeakyReLU' + bias gradient + W1 gradient + the dF contribution of the hoisted Dense in two launches instead of five
             fb = self.__dict__.get("_att_fb")
@@ -719,8 +743,12 @@ class NIC(ModelBase):
                 if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
                     raise RuntimeError("attention front-backward scratch must be built outside a graph capture")
                 fb = self._att_fb = (self._f(be.attention_front_bwd_parts(B * R, D, A)), (B * R, D, A))
+            # dF is finished by this launch: the backward of the LAST feature Dropout (one site over all B*R rows: the
+            # deepest stage's, or the single-subject encoder's) rides in its dF pass
+            if self.r_feat > 0 and getattr(self, "fused_bn_drop", True) and (self.depth > 0 or self.S == 1):
+                fdrop = (self.r_feat, sd, S_DEEP + self.depth - 1 if self.depth > 0 else S_FEAT, ds)
             be.attention_front_bwd(self.Ppre, self.dP, self.F, a.p("attention/W1/kernel"), self.dF,
-                                   a.g("attention/W1/kernel"), a.g("attention/W1/bias"), fb[0], B * R, D, A, 0.2)
+                                   a.g("attention/W1/kernel"), a.g("attention/W1/bias"), fb[0], B * R, D, A, 0.2, drop=fdrop)
         else:
             be.act_bwd(self.Ppre, self.dP, self.dP, B * R * A, ACT_LEAKY, 0.2)
             self.gemm_sk(self.F, self.dP, a.g("attention/W1/kernel"), D, A, B * R, D, A, A, transA=True)
@@ -732,15 +760,17 @@ class NIC(ModelBase):
         dF_enc = self.dF
         for i in range(self.depth - 1, -1, -1):          # the deep stages, last first; dF_enc: gradient wrt Fs[i + 1]
             bn = f"input_bn/deep{i}"
-            if self.r_feat > 0:
+            if self.r_feat > 0 and not (fdrop is not None and i == self.depth - 1):
                 be.dropout(dF_enc, dF_enc, B * R, D, D, 0, D, 0, self.r_feat, sd, S_DEEP + i, 0, ds)
+            acted = False
             if self.norm == "batch":
-                self._bn_bwd(dF_enc, self.deep_xhat[i], a.p(f"{bn}/gamma"), self.deep_istd[i], self.dbn,
-                             a.g(f"{bn}/gamma"), a.g(f"{bn}/beta"), B * R, D, D, self.work)
+                acted = self._bn_bwd(dF_enc, self.deep_xhat[i], a.p(f"{bn}/gamma"), self.deep_istd[i], self.dbn,
+                                     a.g(f"{bn}/gamma"), a.g(f"{bn}/beta"), B * R, D, D, self.work, act_pre=self.deep_pre[i])
             else:
                 be.layernorm_bwd(dF_enc, self.deep_xhat[i], a.p(f"{bn}/gamma"), self.deep_istd[i], self.dbn,
                                  a.g(f"{bn}/gamma"), a.g(f"{bn}/beta"), B * R, D, D, self.work)
-            be.act_bwd(self.deep_pre[i], self.dbn, self.dbn, B * R * D, ACT_LEAKY, 0.2)
+            if not acted:
+                be.act_bwd(self.deep_pre[i], self.dbn, self.dbn, B * R * D, ACT_LEAKY, 0.2)
             be.locally_dense_bwd(self.Fs[i], R * D, self.deep_idx, self.deep_goff, self.dbn, self.deepWg[i], self.deepBg[i],
                                  B, R, D)
             be.block_dense_dx(self.dbn, self.deepW[i], self.dFd, B, R, D, D)
@@ -752,15 +782,18 @@ class NIC(ModelBase):
             if self.r_feat > 0:
                 if S > 1:
                     be.dropout(dFq, dFq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT2 + off, 0, ds)
-                be.dropout(dFq, dFq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT + off, 0, ds)
+                if not (fdrop is not None and self.depth == 0):
+                    be.dropout(dFq, dFq, Bs * R, D, D, 0, D, 0, self.r_feat, sd, S_FEAT + off, 0, ds)
             bn = self.bn_name(q)
+            acted = False
             if self.norm == "batch":
-                self._bn_bwd(dFq, xh, a.p(f"{bn}/gamma"), self.inv_std[q], dbn, a.g(f"{bn}/gamma"),
-                             a.g(f"{bn}/beta"), Bs * R, D, D, self.work)
+                acted = self._bn_bwd(dFq, xh, a.p(f"{bn}/gamma"), self.inv_std[q], dbn, a.g(f"{bn}/gamma"),
+                                     a.g(f"{bn}/beta"), Bs * R, D, D, self.work, act_pre=self.enc_pre[r0:r1])
             else:
                 be.layernorm_bwd(dFq, xh, a.p(f"{bn}/gamma"), self.inv_std[q], dbn, a.g(f"{bn}/gamma"),
                                  a.g(f"{bn}/beta"), Bs * R, D, D, self.work)
-            be.act_bwd(self.enc_pre[r0:r1], dbn, dbn, Bs * R * D, ACT_LEAKY, 0.2)
+            if not acted:
+                be.act_bwd(self.enc_pre[r0:r1], dbn, dbn, Bs * R * D, ACT_LEAKY, 0.2)
             x = (self.xd if self.r_in > 0 else self.x)[r0:r1]
             if self.NV > R and hasattr(be, "locally_dense_bwd_split") and getattr(self, "split_encoder", True):
                 vm = self.xT is not None and getattr(self, "voxel_major", True)

@@ -147,6 +147,9 @@ class ModelBase:
         if not hasattr(be, "step_finalize"):
             if d is not None:
                 be.sum2(*d)
+            md = self.__dict__.pop("_metric_deferred", None)
+            if md is not None:
+                be.sum(md[0], md[1], md[2], md[3])
             self._norms_and_l2(l2_out)
             self._apply_optimizer()
             return
@@ -176,6 +179,9 @@ class ModelBase:
             be.span_sqnorm(a.theta, a.grad, sp.span_seg[s1:], sp.span_off[s1:], sp.span_len[s1:], a.seg_l2, a.partial[2 * s1:],
                            sp.nspan - s1)
         kw = dict(x0=d[0], out0=d[1], x1=d[2], out1=d[3], n=d[4], scale=d[5]) if d is not None else {}
+        md = self.__dict__.pop("_metric_deferred", None)
+        if md is not None:
+            kw.update(x2=md[0], out2=md[1], n2=md[2], scale2=md[3])
         ef = self.__dict__.pop("_emb_finalize", None)
         if ef is not None:       # sparse embedding backward: sum its norm partials, hand this step's ids on as prev_ids
             parts, sqo, nparts, ids, prev, nids = ef
@@ -206,12 +212,18 @@ class ModelBase:
         the forward / backward pass, so dp.attach puts such a model on the generic (non-pipelined, eager) schedule."""
         return bool(getattr(self, "sync_bn", False) and self.dp_world > 1)
 
-    def _bn_fwd(self, x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, training, work):
+    def _bn_fwd(self, x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, training, work, drop=None):
+        """drop = (rate, seed, site, step_dev), training only: the Dropout over y that follows the normalisation, fused into
+        the apply pass where the backend offers it (returns True when it was applied)"""
         be = self.be
         if not (training and self._sync_bn_on()):
+            if drop is not None and drop[0] > 0 and getattr(self, "fused_bn_drop", True):
+                be.batchnorm_fwd(x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, training, BN_EPS,
+                                 BN_MOMENTUM, work, drop=drop)
+                return True
             be.batchnorm_fwd(x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, training, BN_EPS, BN_MOMENTUM,
                              work)
-            return
+            return False
         import torch.distributed as dist
         n = be.bn_nchunk(rows) * 2 * C
         part, allp = work[C:C + n], self._bn_scratch(self.dp_world * n)
@@ -220,11 +232,17 @@ class ModelBase:
         be.batchnorm_apply_stats(allp, self.dp_world, x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, BN_EPS,
                                  BN_MOMENTUM, work)
 
-    def _bn_bwd(self, dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, work):
+    def _bn_bwd(self, dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, work, act_pre=None, slope=0.2):
+        """act_pre: LeakyReLU' of the activation in front of the normalisation folded into the dx pass (returns True when
+        it was applied)"""
         be = self.be
         if not self._sync_bn_on():
+            if act_pre is not None and getattr(self, "fused_bn_drop", True):
+                be.batchnorm_bwd(dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, True, work, act_pre=act_pre,
+                                 slope=slope)
+                return True
             be.batchnorm_bwd(dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, True, work)
-            return
+            return False
         import torch.distributed as dist
         # local sums stay in the gradient buffers (the replicas' gradients are averaged as usual); dx needs the global sums
         be.batchnorm_bwd(dy, xhat, gamma, inv_std, None, dgamma, dbeta, rows, C, lddy, True, work)

@@ -78,6 +78,12 @@ class HipBackend:
         self._call(self.lib.tnt_dropout_f32, "tnt_dropout_f32", _p(x), _p(y), rows, cols, ld, tmajor_B, lwidth, lcol0, rows_per_site,
                                             rate, seed, site, step, _p(step_dev), self._s())
 
+    def dropout2(self, x, y, rows, cols, ld, mask_a, mask_b, seed, step, step_dev=None):
+        """two masks in one pass; mask_* = (tmajor_B, lwidth, lcol0, rows_per_site, rate, site)"""
+        self._call(self.lib.tnt_dropout2_f32, "tnt_dropout2_f32", _p(x), _p(y), rows, cols, ld, *[v for m in (mask_a, mask_b)
+                   for v in (int(m[0]), int(m[1]), int(m[2]), int(m[3]), float(m[4]), int(m[5]))], int(seed), int(step),
+                   _p(step_dev), self._s())
+
     def dropout_mask4(self, out, n, nsites, rate, seed, site0, step, step_dev=None):
         """uint8 keep-masks (4 elements per byte) of ``nsites`` consecutive dropout sites, no data pass."""
         self._call(self.lib.tnt_dropout_mask4_u8, "tnt_dropout_mask4_u8", _p(out), n, nsites, rate, int(seed), int(site0), int(step), _p(step_dev),
@@ -95,12 +101,25 @@ class HipBackend:
         self._call(self.lib.tnt_act_bwd_f32, "tnt_act_bwd_f32", _p(pre), _p(dy), _p(dx), n, act, slope, self._s())
 
     def batchnorm_fwd(self, x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, training, eps,
-                      momentum, work):
+                      momentum, work, drop=None):
+        """drop = (rate, seed, site, step_dev): the Dropout behind the normalisation applied to y in the same pass"""
+        if drop is not None and drop[0] > 0:
+            rate, seed, site, step_dev = drop
+            self._call(self.lib.tnt_batchnorm_fwd_drop_f32, "tnt_batchnorm_fwd_drop_f32", _p(x), _p(gamma), _p(beta), _p(mov_mean),
+                       _p(mov_var), _p(y), _p(xhat), _p(inv_std), rows, C, ldy, int(training), eps, momentum, _p(work),
+                       float(rate), int(seed), int(site), _p(step_dev), self._s())
+            return
         self._call(self.lib.tnt_batchnorm_fwd_f32, "tnt_batchnorm_fwd_f32", _p(x), _p(gamma), _p(beta), _p(mov_mean), _p(mov_var), _p(y),
                                                   _p(xhat), _p(inv_std), rows, C, ldy, int(training), eps, momentum,
                                                   _p(work), self._s())
 
-    def batchnorm_bwd(self, dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, training, work):
+    def batchnorm_bwd(self, dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, training, work, act_pre=None,
+                      slope=0.0):
+        """act_pre: dx is further multiplied by LeakyReLU'(act_pre, slope) (the activation in front of the normalisation)"""
+        if act_pre is not None:
+            self._call(self.lib.tnt_batchnorm_bwd_act_f32, "tnt_batchnorm_bwd_act_f32", _p(dy), _p(xhat), _p(gamma), _p(inv_std),
+                       _p(dx), _p(dgamma), _p(dbeta), rows, C, lddy, int(training), _p(work), _p(act_pre), float(slope), self._s())
+            return
         self._call(self.lib.tnt_batchnorm_bwd_f32, "tnt_batchnorm_bwd_f32", _p(dy), _p(xhat), _p(gamma), _p(inv_std), _p(dx), _p(dgamma),
                                                   _p(dbeta), rows, C, lddy, int(training), _p(work), self._s())
 
@@ -143,7 +162,14 @@ class HipBackend:
     def embedding_fwd(self, table, ids, out, B, T, E, ldo, V):
         self._call(self.lib.tnt_embedding_fwd_f32, "tnt_embedding_fwd_f32", _p(table), _p(ids), _p(out), B, T, E, ldo, V, self._s())
 
-    def embedding_fwd_drop(self, table, ids, out, out_drop, B, T, E, ldo, V, rate, seed, site, step, step_dev=None):
+    def embedding_fwd_drop(self, table, ids, out, out_drop, B, T, E, ldo, V, rate, seed, site, step, step_dev=None,
+                           mask2=None):
+        """mask2 = (rate2, site2, lwidth2, lcol0_2): the per-timestep LSTM input mask applied behind the Embedding Dropout"""
+        if mask2 is not None and mask2[0] > 0:
+            self._call(self.lib.tnt_embedding_fwd_drop2_f32, "tnt_embedding_fwd_drop2_f32", _p(table), _p(ids), _p(out), _p(out_drop),
+                       B, T, E, ldo, V, rate, int(seed), int(site), int(step), _p(step_dev), float(mask2[0]), int(mask2[1]),
+                       int(mask2[2]), int(mask2[3]), self._s())
+            return
         self._call(self.lib.tnt_embedding_fwd_drop_f32, "tnt_embedding_fwd_drop_f32", _p(table), _p(ids), _p(out), _p(out_drop), B, T, E, ldo, V, rate,
                                                        int(seed), int(site), int(step), _p(step_dev), self._s())
 
@@ -285,7 +311,14 @@ class HipBackend:
     def attention_front_bwd_parts(self, rows, D, A):
         return int(self.lib.tnt_attention_front_bwd_parts(rows, D, A))
 
-    def attention_front_bwd(self, Ppre, dP, F, W1, dF, dW1, db1, part, rows, D, A, slope=0.2):
+    def attention_front_bwd(self, Ppre, dP, F, W1, dF, dW1, db1, part, rows, D, A, slope=0.2, drop=None):
+        """drop = (rate, seed, site, step_dev): Dropout' of the feature Dropout applied to the finished dF in the same pass"""
+        if drop is not None and drop[0] > 0:
+            rate, seed, site, step_dev = drop
+            self._call(self.lib.tnt_attention_front_bwd_drop_f32, "tnt_attention_front_bwd_drop_f32", _p(Ppre), _p(dP), _p(F),
+                       _p(W1), _p(dF), _p(dW1), _p(db1), _p(part), rows, D, A, slope, float(rate), int(seed), int(site),
+                       _p(step_dev), self._s())
+            return
         self._call(self.lib.tnt_attention_front_bwd_f32, "tnt_attention_front_bwd_f32", _p(Ppre), _p(dP), _p(F), _p(W1), _p(dF),
                    _p(dW1), _p(db1), _p(part), rows, D, A, slope, self._s())
 
@@ -359,10 +392,11 @@ class HipBackend:
 
     def step_finalize(self, partial, seg_first, seg_l2, sq, wsq, l2_out, nseg, x0=None, out0=None, x1=None, out1=None, n=0,
                       scale=1.0, extra_part=None, extra=None, n_extra=0, ids_src=None, ids_dst=None, n_ids=0, adam_t=None,
-                      drop_step=None, lr=None, lr_t=None, beta1=0.0, beta2=0.0, guard=None):
+                      drop_step=None, lr=None, lr_t=None, beta1=0.0, beta2=0.0, guard=None, x2=None, out2=None, n2=0,
+                      scale2=1.0):
         self._call(self.lib.tnt_step_finalize_f32, "tnt_step_finalize_f32", _p(partial), _p(seg_first), _p(seg_l2), _p(sq), _p(wsq),
                    _p(l2_out), nseg, _p(x0), _p(out0), _p(x1), _p(out1), n, scale, _p(extra_part), _p(extra), n_extra,
-                   _p(ids_src), _p(ids_dst), n_ids, _p(adam_t), _p(drop_step), _p(lr), _p(lr_t), beta1, beta2, _p(guard),
+                   _p(ids_src), _p(ids_dst), n_ids, _p(x2), _p(out2), n2, scale2, _p(adam_t), _p(drop_step), _p(lr), _p(lr_t), beta1, beta2, _p(guard),
                    self._s())
 
     def embedding_bwd_parts(self, B, T, E):
@@ -417,6 +451,9 @@ class HipBackend:
                                                        slope, rate_attn, rate_in, in_lwidth, seed, site_attn, site_in,
                                                        step, _p(step_dev), _p(dz), _p(Wc), _p(dctx_part), nparts,
                                                        _p(keep4), float(alpha_mse), int(bool(fresh)), self._s())
+
+    def attention_metric_parts(self, T, R):
+        return int(self.lib.tnt_attention_metric_parts(T, R))
 
     def attention_metric(self, alpha, out, work, T, B, R, tstride=0):
         self._call(self.lib.tnt_attention_metric_f32, "tnt_attention_metric_f32", _p(alpha), _p(out), _p(work), T, B, R, tstride, self._s())

@@ -80,6 +80,10 @@ class MockBackend:
         scale = np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
         ys[...] = np.where(k, xs * scale, np.float32(0))
 
+    def dropout2(self, x, y, rows, cols, ld, mask_a, mask_b, seed, step, step_dev=None):
+        for k, (tB, lw, lc0, rps, rate, site) in enumerate((mask_a, mask_b)):
+            self.dropout(x if k == 0 else y, y, rows, cols, ld, tB, lw, lc0, rate, seed, site, step, step_dev, rows_per_site=rps)
+
     def dropout_mask4(self, out, n, nsites, rate, seed, site0, step, step_dev=None):
         if step_dev is not None:
             step = (step + int(step_dev[0])) & 0xFFFFFFFF
@@ -102,7 +106,7 @@ class MockBackend:
 
     # ---------------------------------------------------------------- norms
     def batchnorm_fwd(self, x, gamma, beta, mov_mean, mov_var, y, xhat, inv_std, rows, C, ldy, training, eps,
-                      momentum, work):
+                      momentum, work, drop=None):
         xs = mat(x, rows, C, C).astype(np.float64)
         mm, mv = flat(mov_mean)[:C], flat(mov_var)[:C]
         yo, (xh, inv, _), nmm, nmv = O.batchnorm_fwd(xs, flat(gamma)[:C].astype(np.float64),
@@ -113,11 +117,17 @@ class MockBackend:
         flat(inv_std)[:C] = inv
         mm[...] = nmm
         mv[...] = nmv
+        if drop is not None and drop[0] > 0:
+            rate, seed, site, step_dev = drop
+            self.dropout(y, y, rows, C, ldy, 0, C, 0, rate, seed, site, 0, step_dev)
 
-    def batchnorm_bwd(self, dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, training, work):
+    def batchnorm_bwd(self, dy, xhat, gamma, inv_std, dx, dgamma, dbeta, rows, C, lddy, training, work, act_pre=None,
+                      slope=0.0):
         cache = (mat(xhat, rows, C, C).astype(np.float64), flat(inv_std)[:C].astype(np.float64), bool(training))
         dxo, dg, db = O.batchnorm_bwd(mat(dy, rows, C, lddy).astype(np.float64), flat(gamma)[:C].astype(np.float64), cache)
         if dx is not None:
+            if act_pre is not None:
+                dxo = dxo * np.where(mat(act_pre, rows, C, C) > 0, 1.0, slope)
             mat(dx, rows, C, C)[...] = dxo
         if dgamma is not None:
             flat(dgamma)[:C] = dg
@@ -307,7 +317,7 @@ class MockBackend:
     def attention_front_bwd_parts(self, rows, D, A):
         return 1
 
-    def attention_front_bwd(self, Ppre, dP, F, W1, dF, dW1, db1, part, rows, D, A, slope=0.2):
+    def attention_front_bwd(self, Ppre, dP, F, W1, dF, dW1, db1, part, rows, D, A, slope=0.2, drop=None):
         pre = mat(Ppre, rows, A, A).astype(np.float64)
         g = mat(dP, rows, A, A).astype(np.float64) * np.where(pre > 0, 1.0, slope)
         Fm = mat(F, rows, D, D).astype(np.float64)
@@ -315,6 +325,9 @@ class MockBackend:
         flat(db1)[:A] = g.sum(0)
         flat(dW1)[:D * A] = (Fm.T @ g).reshape(-1)
         mat(dF, rows, D, D)[...] += g @ W.T
+        if drop is not None and drop[0] > 0:
+            rate, seed, site, step_dev = drop
+            self.dropout(dF, dF, rows, D, D, 0, D, 0, rate, seed, site, 0, step_dev)
 
     def bias_act_drop_bwd(self, dy, pre, dx, dbias, rows, cols, ld, act, slope, tmajor_B, lwidth, lcol0, rate, seed, site,
                           step_dev=None, extra=None):
@@ -369,10 +382,14 @@ class MockBackend:
         tab = mat(table, V, E, E)
         mat(out, T * B, E, ldo)[...] = tab[idv.T.reshape(-1)]
 
-    def embedding_fwd_drop(self, table, ids, out, out_drop, B, T, E, ldo, V, rate, seed, site, step, step_dev=None):
+    def embedding_fwd_drop(self, table, ids, out, out_drop, B, T, E, ldo, V, rate, seed, site, step, step_dev=None,
+                           mask2=None):
         tmp = out if out is not None else torch.zeros(B * T, ldo, dtype=torch.float32)
         self.embedding_fwd(table, ids, tmp, B, T, E, ldo, V)
         self.dropout(tmp, out_drop, T * B, E, ldo, B, E, 0, rate, seed, site, step, step_dev)
+        if mask2 is not None and mask2[0] > 0:
+            rate2, site2, lw2, lc2 = mask2
+            self.dropout(out_drop, out_drop, T * B, E, ldo, 0, lw2, lc2, rate2, seed, site2, step, step_dev, rows_per_site=B)
 
     def embedding_bwd(self, drows, ids, dtable, sq_norm, rowsq_work, B, T, E, ldd, V):
         idv = flat(ids)[:B * T].reshape(B, T)
@@ -670,7 +687,10 @@ class MockBackend:
 
     def step_finalize(self, partial, seg_first, seg_l2, sq, wsq, l2_out, nseg, x0=None, out0=None, x1=None, out1=None, n=0,
                       scale=1.0, extra_part=None, extra=None, n_extra=0, ids_src=None, ids_dst=None, n_ids=0, adam_t=None,
-                      drop_step=None, lr=None, lr_t=None, beta1=0.0, beta2=0.0, guard=None):
+                      drop_step=None, lr=None, lr_t=None, beta1=0.0, beta2=0.0, guard=None, x2=None, out2=None, n2=0,
+                      scale2=1.0):
+        if n2 > 0:
+            flat(out2)[0] = flat(x2)[:n2].astype(np.float64).sum() * scale2
         if nseg > 0:
             pa, first = flat(partial).astype(np.float64), flat(seg_first)
             for s in range(nseg):
@@ -812,4 +832,13 @@ class MockBackend:
     def attention_metric(self, alpha, out, work, T, B, R, tstride=0):
         ts = tstride if tstride > 0 else B * R
         al = np.lib.stride_tricks.as_strided(flat(alpha), (T, B, R), (ts * 4, R * 4, 4)).astype(np.float64)
-        flat(out)[0] = ((1 - al.sum(1)) ** 2).mean()
+        v = ((1 - al.sum(1)) ** 2)
+        if out is None:                       # partials only: one per timestep, the rest of the slots zero
+            n = self.attention_metric_parts(T, R)
+            flat(work)[:n] = 0
+            flat(work)[:T] = v.sum(1)
+            return
+        flat(out)[0] = v.mean()
+
+    def attention_metric_parts(self, T, R):
+        return T * ((R + 63) // 64)

@@ -191,6 +191,27 @@ def _sync_oracle(model, orc, opt, step):
     opt.t = step
 
 
+def _kink_flips(kind, model, w0, data, step, rates):
+    """LeakyReLU elements whose float32 pre-activation has the other sign than the float64 oracle's (|pre| ~ 1e-8: a handful
+    of the 1.7 M pre-activations of a step land that close to zero every few steps).  The derivative jumps from 1 to 0.2
+    there, so the two sides legitimately back-propagate different values through that one element."""
+    orc2 = make_oracle(kind, rates)
+    orc2.p = w0
+    _, cache = orc2.forward(data, training=True, drop=M.DropCtx(seed=model.seed, step=step, training=True))
+    if kind == "dense":
+        pairs = [(model.enc_pre, cache["pre"])]
+    else:
+        pairs = [(model.Ppre, cache["Ppre"]), (model.ipre, np.swapaxes(cache["ipre"], 0, 1)), (model.enc_pre, cache["enc"]["pre"])]
+    flips = 0
+    for mine, ref in pairs:
+        a, b = mine.detach().cpu().numpy().reshape(-1), np.asarray(ref).reshape(-1)
+        assert a.size == b.size
+        bad = (a > 0) != (b > 0)
+        assert np.abs(b[bad]).max(initial=0.0) < 1e-6, "pre-activation sign differs away from zero"
+        flips += int(bad.sum())
+    return flips
+
+
 @pytest.mark.parametrize("kind", ["dense", "attention"])
 @pytest.mark.parametrize("dropout", [True, False])
 def test_train_step_matches_oracle_at_full_size(kind, dropout):
@@ -200,6 +221,7 @@ def test_train_step_matches_oracle_at_full_size(kind, dropout):
     post-Adam weights (main.py:97, lc_NIC.py:389).  This is the only place where the kernels that exist only at full
     size -- the persistent LSTM forward (U == 512), lstm_bwd_lds (4U % 1024 == 0), the one-round head GEMM, the skinny
     encoder dW, the in-kernel-reduced gradient GEMMs -- run inside one oracle-checked step.
+    A gradient outside the 1e-4 bound is accepted only if the step is shown to contain a LeakyReLU kink flip (_kink_flips).
     The weights are checked twice: loosely against the oracle's own update (Adam turns a 1e-4 gradient error on a
     near-zero element into a fraction of lr), and tightly (1e-3 of one update) against the float64 Adam formulas
     applied to the gradients the model itself produced, which pins clip-by-norm + Adam + the IndexedSlices norm."""
@@ -226,7 +248,7 @@ def test_train_step_matches_oracle_at_full_size(kind, dropout):
                 continue
             tol = 1e-6 if k == "accuracy" else 1e-4 * abs(res[k]) + 1e-7
             assert abs(got[k] - res[k]) <= tol, (step, k, got[k], res[k])
-        gm = {}
+        gm, kinks = {}, None
         for k in names:
             gm[k] = model.get_gradient(k).astype(np.float64) + 2 * lam[k] * w0[k]
             if grads.get(k) is None:
@@ -236,7 +258,12 @@ def test_train_step_matches_oracle_at_full_size(kind, dropout):
                 assert np.abs(gm[k]).max() < 1e-5
                 continue
             err = np.abs(gm[k] - grads[k]).max()
-            assert err <= 1e-4 * scale + 1e-10, (step, k, err, scale)
+            if err > 1e-4 * scale + 1e-10:
+                # only acceptable with a LeakyReLU element on the other side of its kink in this step (see _kink_flips): its
+                # rank-one effect on the gradients is bounded instead (measured: 1.4e-3 of the smallest-scale tensor)
+                if kinks is None:
+                    kinks = _kink_flips(kind, model, w0, data, step, rates)
+                assert 0 < kinks <= 3 and err <= 5e-3 * scale + 1e-10, (step, k, err, scale, kinks)
         # BatchNorm moving statistics
         for k in orc.p:
             if "moving_" in k:

@@ -208,6 +208,32 @@ def test_dropout_rows_per_site(be):
         assert np.array_equal(yd[i * B:(i + 1) * B].cpu().numpy(), want)
 
 
+def test_two_masks_in_one_pass(be):
+    """tnt_dropout2_f32 and tnt_embedding_fwd_drop2_f32 (the Embedding Dropout and the per-timestep LSTM input mask of the
+    text rows, lc_NIC.py:233-234,255) give the bits of the two launches they replace, and the oracle's Philox pattern."""
+    rng = np.random.default_rng(5)
+    T, B, E, D, V, r_text, r_lstm, seed, s_text, s_in, step = 7, 6, 16, 8, 50, 0.25, 0.4, 31337, 7, 48, 3
+    step_dev = torch.tensor([step], dtype=torch.int32, device="cuda")
+    x = dev(rng.standard_normal((T * B, E)))
+    want = x.clone()
+    be.dropout(want, want, T * B, E, E, 0, D + E, D, r_lstm, seed, s_in, 0, step_dev, rows_per_site=B)
+    be.dropout(want, want, T * B, E, E, B, E, 0, r_text, seed, s_text, 0, step_dev)
+    got = torch.zeros_like(x)
+    be.dropout2(x, got, T * B, E, E, (0, D + E, D, B, r_lstm, s_in), (B, E, 0, 0, r_text, s_text), seed, 0, step_dev)
+    assert torch.equal(got, want)
+    k_text = keep_mask((B, T, E), r_text, seed, s_text, step).transpose(1, 0, 2)                    # (T, B, E)
+    k_in = np.stack([keep_mask((B, D + E), r_lstm, seed, s_in + t, step)[:, D:] for t in range(T)])
+    assert np.array_equal(got.cpu().numpy().reshape(T, B, E) != 0, k_text & k_in & (x.cpu().numpy().reshape(T, B, E) != 0))
+    table, ids = dev(rng.standard_normal((V, E))), torch.tensor(rng.integers(0, V, (B, T)), dtype=torch.int32, device="cuda")
+    w2 = torch.zeros(T * B, E, device="cuda")
+    be.embedding_fwd_drop(table, ids, None, w2, B, T, E, E, V, r_text, seed, s_text, 0, step_dev)
+    be.dropout(w2, w2, T * B, E, E, 0, D + E, D, r_lstm, seed, s_in, 0, step_dev, rows_per_site=B)
+    g2 = torch.zeros(T * B, E, device="cuda")
+    be.embedding_fwd_drop(table, ids, None, g2, B, T, E, E, V, r_text, seed, s_text, 0, step_dev, mask2=(r_lstm, s_in, D + E, D))
+    assert torch.equal(g2, w2)
+    assert np.array_equal(g2.cpu().numpy().reshape(T, B, E) != 0, k_text & k_in)
+
+
 # ------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("rows,C", [(64, 512), (1440, 32), (7, 5)])
 def test_batchnorm(be, rows, C):
@@ -228,6 +254,35 @@ def test_batchnorm(be, rows, C):
         be.batchnorm_bwd(dev(dy), xhat, dev(gam), inv, dx, dg, db, rows, C, C, training, work)
         dxo, dgo, dbo = O.batchnorm_bwd(dy, gam, cache)
         close(dx, dxo); close(dg, dgo); close(db, dbo)
+
+
+@pytest.mark.parametrize("rows,C", [(23040, 32), (130, 36), (7, 5)])
+def test_batchnorm_with_dropout_and_activation_gradient(be, rows, C):
+    """tnt_batchnorm_fwd_drop_f32: y = Dropout(BN(x)) with the Philox pattern of tnt_dropout_f32 (bit pattern from the
+    oracle's stream), xhat un-dropped; tnt_batchnorm_bwd_act_f32: dx = BN'(dy) * LeakyReLU'(pre)."""
+    rng = np.random.default_rng(rows)
+    x, dy, pre = rng.standard_normal((rows, C)) * 2 + 0.5, rng.standard_normal((rows, C)), rng.standard_normal((rows, C))
+    gam, bet, mm0, mv0 = rng.standard_normal(C), rng.standard_normal(C), rng.standard_normal(C), rng.random(C) + 0.5
+    rate, seed, site, step = 0.3, 987654321, 21, 6
+    step_dev = torch.tensor([step], dtype=torch.int32, device="cuda")
+    work = torch.zeros(C * (2 * be.bn_nchunk(rows) + 1), device="cuda")
+    mm, mv = dev(mm0), dev(mv0)
+    y, xhat, inv = torch.zeros(rows, C, device="cuda"), torch.zeros(rows, C, device="cuda"), torch.zeros(C, device="cuda")
+    be.batchnorm_fwd(dev(x), dev(gam), dev(bet), mm, mv, y, xhat, inv, rows, C, C, True, 1e-3, 0.99, work,
+                     drop=(rate, seed, site, step_dev))
+    yo, cache, mmo, mvo = O.batchnorm_fwd(x, gam, bet, mm0, mv0, True)
+    keep = keep_mask((rows, C), rate, seed, site, step)
+    close(y, O.dropout_fwd(yo, keep, rate)); close(xhat, cache[0]); close(mm, mmo); close(mv, mvo)
+    assert np.array_equal(y.cpu().numpy() == 0, ~keep | (yo.astype(np.float32) == 0))
+    # the two-launch form gives the same bits
+    y2, xh2, inv2 = torch.zeros_like(y), torch.zeros_like(xhat), torch.zeros_like(inv)
+    be.batchnorm_fwd(dev(x), dev(gam), dev(bet), dev(mm0), dev(mv0), y2, xh2, inv2, rows, C, C, True, 1e-3, 0.99, work)
+    be.dropout(y2, y2, rows, C, C, 0, C, 0, rate, seed, site, 0, step_dev)
+    assert torch.equal(y, y2) and torch.equal(xhat, xh2)
+    dx, dg, db = torch.zeros(rows, C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    be.batchnorm_bwd(dev(dy), xhat, dev(gam), inv, dx, dg, db, rows, C, C, True, work, act_pre=dev(pre), slope=0.2)
+    dxo, dgo, dbo = O.batchnorm_bwd(dy, gam, cache)
+    close(dx, dxo * np.where(pre > 0, 1.0, 0.2)); close(dg, dgo); close(db, dbo)
 
 
 @pytest.mark.parametrize("rows,C", [(64, 512), (9, 33)])
@@ -1042,13 +1097,23 @@ def test_lstm_seq_guard_codes(be):
     assert int(sync[1024]) == 0 and float(guard) == 0.0 and torch.equal(Hs, good)
 
 
-def test_attention_metric(be):
+@pytest.mark.parametrize("T,B,R", [(5, 8, 30), (15, 64, 360), (3, 5, 129)])
+def test_attention_metric(be, T, B, R):
     rng = np.random.default_rng(13)
-    T, B, R = 5, 8, 30
     alpha = O.softmax(rng.standard_normal((T, B, R)), axis=-1)
+    want = ((1 - alpha.sum(1)) ** 2).mean()
     out = torch.zeros(1, device="cuda")
-    be.attention_metric(dev(alpha), out, torch.zeros(T, device="cuda"), T, B, R)
-    close(out, [((1 - alpha.sum(1)) ** 2).mean()])
+    npart = be.attention_metric_parts(T, R)
+    be.attention_metric(dev(alpha), out, torch.zeros(npart, device="cuda"), T, B, R)
+    close(out, [want])
+    # partials only (out = None), totalled by the step-finalize launch's third job
+    work, out2 = torch.full((npart + 3,), 7.0, device="cuda"), torch.zeros(1, device="cuda")
+    be.attention_metric(dev(alpha), None, work, T, B, R)
+    assert (work[npart:] == 7.0).all()
+    z = torch.zeros(1, device="cuda")
+    be.step_finalize(z, torch.zeros(1, dtype=torch.int32, device="cuda"), z, z, z, None, 0, x2=work, out2=out2, n2=npart,
+                     scale2=1.0 / (T * R))
+    close(out2, [want])
 
 
 @pytest.mark.parametrize("V,ld,from_logits,temp", [(11, 12, True, 1.0), (5001, 5004, False, 1.0), (5001, 5004, True, 0.7),
@@ -1404,6 +1469,16 @@ def test_attention_front_bwd(be, rows, D, A):
     close(dW1, F.T @ g, rtol=2e-5); close(db1, g.sum(0), rtol=2e-5); close(dF, dF0 + g @ W1.T, rtol=1e-5)
     for o in outs[1:]:
         assert all(torch.equal(x, y) for x, y in zip(outs[0], o))
+    # with the feature Dropout' folded into the dF pass: same bits as the launch plus tnt_dropout_f32 on its result
+    step_dev = torch.tensor([4], dtype=torch.int32, device="cuda")
+    dFd, dW1d, db1d = dev(dF0), torch.zeros(D, A, device="cuda"), torch.zeros(A, device="cuda")
+    be.attention_front_bwd(dev(pre), dev(dP), dev(F), dev(W1), dFd, dW1d, db1d, part, rows, D, A, 0.2,
+                           drop=(0.25, 4242, 17, step_dev))
+    ref = outs[0][0].clone()
+    be.dropout(ref, ref, rows, D, D, 0, D, 0, 0.25, 4242, 17, 0, step_dev)
+    assert torch.equal(dFd, ref) and torch.equal(dW1d, dW1) and torch.equal(db1d, db1)
+    keep = keep_mask((rows, D), 0.25, 4242, 17, 4)
+    assert np.array_equal(dFd.cpu().numpy() != 0, keep & (outs[0][0].cpu().numpy() != 0))
 
 
 @pytest.mark.parametrize("T,B,C,rate,V", [(15, 64, 256, 0.2, 5001), (3, 5, 8, 0.0, 0), (7, 9, 36, 0.5, 33)])
