@@ -974,17 +974,29 @@ __device__ __forceinline__ float lc_ld1_l2(__amdgpu_buffer_rsrc_t rsrc, unsigned
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)byte_off, 0, /*sc1*/ 16));
 }
 
+// Role-specialised workgroups.  A group is the 32 workgroups of one XCD and owns one block of 16 samples: slots 0..15 run
+// the ATTENTION of one sample each, slots 16..31 the LSTM step of 32 units each (two 16-unit blocks) for the 16 samples.
+// Everything step-invariant stays on chip for all T steps: an attention workgroup keeps its sample's P and F rows in
+// registers and W2 in LDS (A <= 32); an LSTM workgroup keeps its recurrent-kernel fragments in registers and its context
+// rows of the LSTM kernel in LDS.  Per step the two roles overlap: while the attention workgroups work on step i, the LSTM
+// workgroups already multiply h[i] with the recurrent kernel (the bulk of their step, 512 of the 544 input columns); only
+// the 32-column context term and the gate math wait for the attention's ctx_d[i].  Hand-offs are data-polling on the
+// sentinel (h and ctx_d are their own flags, reset-before-publish by the owning thread, as in lstm_seq_fwd_kernel).
 template <int G4, int NP>
 __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
-  constexpr int NWF = 16, SS = 8, CK = 32;
+  constexpr int NWF = 16, SS = 8, CK = 32, RPP = WT / G4;
+  constexpr bool W2L = G4 == 8;                         // W2 [U][A <= 32] fits the dynamic LDS block
   extern __shared__ __attribute__((aligned(16))) float lc_lds[];
-  float (*red)[4][16][17] = reinterpret_cast<float (*)[4][16][17]>(lc_lds);          // [NWF][4][16][17]
+  float (*red)[4][16][17] = reinterpret_cast<float (*)[4][16][17]>(lc_lds);          // LSTM role: [NWF][4][16][17]
+  float* w2_l = lc_lds;                                                               // attention role: [U][A]
   unsigned* s_slot = reinterpret_cast<unsigned*>(lc_lds + NWF * 4 * 16 * 17);
   __shared__ __attribute__((aligned(16))) float hs_l[512];
   __shared__ float es_l[512];
   __shared__ __attribute__((aligned(16))) float wred_l[WW][64];
   __shared__ __attribute__((aligned(16))) float qs_l[64];
   __shared__ float red_l[WW];
+  __shared__ __attribute__((aligned(16))) float wc_l[64 * 32 * 4];                    // [D][32 units][4 gates]
+  __shared__ float ctx_l[16 * 64];                                                    // [16 rows][D]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
   const int U = a.att.U, B = a.att.B, D = a.att.D, R = a.att.R, A = a.att.A, T = a.T;
@@ -1002,35 +1014,53 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   const long BU = (long)B * U;
   const __amdgpu_buffer_rsrc_t hs_rsrc = tnt_rsrc(a.hs, (unsigned)((long)(T + 1) * BU * 4));
   const __amdgpu_buffer_rsrc_t cx_rsrc = tnt_rsrc(a.att.ctx_d, (unsigned)((long)T * B * D * 4));
-  const int arow = rb * 16 + lr, ucol = ub * 16 + lr;
-  // The weight fragments (recurrent: every wave; context rows: waves < D / 4 take k-step w of the context part) are NOT kept
-  // in registers across the steps here, unlike lstm_seq_fwd_kernel: the attention phase needs ~90 VGPRs of its own and the
-  // two sets together spill (128 VGPRs per lane at 1024 threads).  They are re-read from L2 (128 KB per workgroup, as the
-  // per-step kernel does) right behind the attention phase, in flight while the hand-off polls run.
-  const bool cwave = w * 4 < D;
-  // ---- LSTM epilogue thread state
-  const int erow = tid >> 4, ecol = tid & 15;
-  const int eb = rb * 16 + erow, eu = ub * 16 + ecol;
-  const bool eok = tid < 256 && eb < B;
-  const long ee = (long)eb * U + eu;
-  float4 zb = make_float4(0.f, 0.f, 0.f, 0.f), x4 = zb;
-  float cp = 0.f;
-  if (eok) {
-    if (a.zbias) zb = *reinterpret_cast<const float4*>(a.zbias + (long)eu * 4);
-    cp = a.cs[ee];
-    x4 = *reinterpret_cast<const float4*>(a.xz + ee * 4);
-  }
-  // ---- attention role
-  const int ab = rb * 16 + ub;                         // this workgroup's sample
-  const bool arole = ub < 16 && ab < B;
   const float sentinel = __uint_as_float(LC_SENTINEL);
-  if (eok) a.hs[BU + ee] = sentinel;
-  if (arole && tid < D) a.att.ctx_d[(long)ab * D + tid] = sentinel;
-  tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
-  for (int i = 0; i < T; ++i) {
-    if (eok && i + 2 <= T) a.hs[(long)(i + 2) * BU + ee] = sentinel;
-    if (arole && tid < D && i + 1 < T) a.att.ctx_d[((long)(i + 1) * B + ab) * D + tid] = sentinel;
-    if (arole) {
+  const AttArgs& g = a.att;
+
+  if (ub < 16) {
+    // =========================================================== attention role: sample ab
+    const int ab = rb * 16 + ub;
+    const bool live = ab < B;
+    const int c4 = tid % G4, rl = tid / G4;
+    const bool cokA = c4 * 4 < A, cokD = c4 * 4 < D;
+    float4 pv[NP], fv[NP];
+    float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float b2v = 0.f, bvv = 0.f;
+    if (live) {
+      if (W2L) {
+        for (int e = tid; e < U * A / 4; e += WT) reinterpret_cast<float4*>(w2_l)[e] = reinterpret_cast<const float4*>(g.W2)[e];
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int r = p * RPP + rl;
+        pv[p] = (cokA && r < R) ? *reinterpret_cast<const float4*>(g.P + ((long)ab * R + r) * A + c4 * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        fv[p] = (cokD && r < R) ? *reinterpret_cast<const float4*>(g.F + ((long)ab * R + r) * D + c4 * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (cokA) v4 = *reinterpret_cast<const float4*>(g.v + c4 * 4);
+      if (tid < A) b2v = g.b2[tid];
+      bvv = g.bv[0];
+      if (tid < D) g.ctx_d[(long)ab * D + tid] = sentinel;
+    }
+    tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
+    const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
+    const bool stored = g.keep4 != nullptr && g.rate_attn > 0.f;
+    const float scale_a = 1.f / (1.f - g.rate_attn);
+    if (live) for (int i = 0; i < T; ++i) {
+      float* const o_qpre = g.qpre + (long)i * B * A;
+      float* const o_alpha = g.alpha + (long)i * B * R;
+      float* const o_ctx = g.ctx + (long)i * B * D;
+      float* const o_ctxd = g.ctx_d + (long)i * B * D;
+      const uint32_t site_attn = g.site_attn + (uint32_t)i, site_in = g.site_in + (uint32_t)i;
+      if (tid < D && i + 1 < T) g.ctx_d[((long)(i + 1) * B + ab) * D + tid] = sentinel;
+      // this step's keep bits: in flight while h[i] is polled
+      uint32_t mk[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int r = p * RPP + rl;
+        mk[p] = (stored && cokA && r < R) ? g.keep4[(long)i * a.keep_stride + ((((long)ab * R + r) * A + c4 * 4) >> 2)] : 0u;
+      }
       // ---- this sample's h of step i
       unsigned spins = 0;
       for (;;) {
@@ -1048,34 +1078,141 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
         if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       }
       __syncthreads();
-      att_fwd_body<G4, true, NP>(a.att, ab, AttFwdLds{hs_l, es_l, wred_l, qs_l, red_l}, i, a.keep_stride);
-    }
-    // ---- LSTM step: A fragments = h[i] (this wave's K chunk), context fragment for the waves that own a context k-step
-    int opaque = 0;
-    asm volatile("" : "+s"(opaque));       // the loads below are loop-invariant: keep the compiler from hoisting them back
-    const float* Urp = a.Ur + opaque;
-    const float* Wcp = a.Wc + opaque;
-    float4 bv[SS];
+      // ---- q = LeakyReLU(h W2 + b2)   (the arithmetic of att_fwd_body, operand for operand)
+      {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cokA) {
+#pragma unroll 4
+          for (int k = rl; k < U; k += RPP) {
+            const float4 wv = W2L ? *reinterpret_cast<const float4*>(w2_l + k * A + c4 * 4)
+                                  : *reinterpret_cast<const float4*>(g.W2 + (long)k * A + c4 * 4);
+            const float hk = hs_l[k];
+            acc.x += hk * wv.x; acc.y += hk * wv.y; acc.z += hk * wv.z; acc.w += hk * wv.w;
+          }
+        }
+        acc.x = stride_sum<G4>(acc.x); acc.y = stride_sum<G4>(acc.y);
+        acc.z = stride_sum<G4>(acc.z); acc.w = stride_sum<G4>(acc.w);
+        if (lane < G4) *reinterpret_cast<float4*>(&wred_l[w][lane * 4]) = acc;
+        __syncthreads();
+        if (tid < A) {
+          float t = b2v;
 #pragma unroll
-    for (int s = 0; s < SS; ++s) bv[s] = *reinterpret_cast<const float4*>(Urp + ((long)(w * CK + (s >> 2) * 16 + kq * 4 + (s & 3)) * U + ucol) * 4);
-    float4 cbv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cwave && w * 4 + kq < D) cbv = *reinterpret_cast<const float4*>(Wcp + ((long)(w * 4 + kq) * U + ucol) * 4);
+          for (int k = 0; k < WW; ++k) t += wred_l[k][tid];
+          o_qpre[(long)ab * A + tid] = t;
+          qs_l[tid] = t > 0.f ? t : t * g.slope;
+        }
+        __syncthreads();
+      }
+      // ---- scores
+      {
+        const float4 q4 = cokA ? *reinterpret_cast<const float4*>(&qs_l[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int r = p * RPP + rl;
+          float t = 0.f;
+          if (cokA && r < R) {
+            const long e = ((long)ab * R + r) * A + c4 * 4;
+            float s0 = tnt_tanh(pv[p].x + q4.x), s1 = tnt_tanh(pv[p].y + q4.y), s2 = tnt_tanh(pv[p].z + q4.z), s3 = tnt_tanh(pv[p].w + q4.w);
+            if (g.rate_attn > 0.f) {
+              bool k[4];
+              if (stored) { k[0] = mk[p] & 1u; k[1] = mk[p] & 2u; k[2] = mk[p] & 4u; k[3] = mk[p] & 8u; }
+              else tnt_keep4((uint64_t)e, g.rate_attn, g.seed, site_attn, step, k);
+              s0 = k[0] ? s0 * scale_a : 0.f; s1 = k[1] ? s1 * scale_a : 0.f;
+              s2 = k[2] ? s2 * scale_a : 0.f; s3 = k[3] ? s3 * scale_a : 0.f;
+            }
+            t = s0 * v4.x + s1 * v4.y + s2 * v4.z + s3 * v4.w;
+          }
+          t = adj_sum<G4>(t);
+          if (c4 == 0 && r < R) es_l[r] = t + bvv;
+        }
+        __syncthreads();
+      }
+      // ---- softmax over regions
+      float m = -INFINITY;
+      for (int r = tid; r < R; r += WT) m = fmaxf(m, es_l[r]);
+      m = block_max_w(m, red_l);
+      float z = 0.f;
+      for (int r = tid; r < R; r += WT) { const float ex = expf(es_l[r] - m); es_l[r] = ex; z += ex; }
+      z = block_sum_w(z, red_l);
+      const float invz = 1.f / z;
+      for (int r = tid; r < R; r += WT) { const float al = es_l[r] * invz; es_l[r] = al; o_alpha[(long)ab * R + r] = al; }
+      __syncthreads();
+      // ---- context
+      {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int r = p * RPP + rl;
+          const float al = r < R ? es_l[r] : 0.f;
+          acc.x += al * fv[p].x; acc.y += al * fv[p].y; acc.z += al * fv[p].z; acc.w += al * fv[p].w;
+        }
+        acc.x = stride_sum<G4>(acc.x); acc.y = stride_sum<G4>(acc.y);
+        acc.z = stride_sum<G4>(acc.z); acc.w = stride_sum<G4>(acc.w);
+        if (lane < G4) *reinterpret_cast<float4*>(&wred_l[w][lane * 4]) = acc;
+        __syncthreads();
+        if (tid < D) {
+          float t = 0.f;
+#pragma unroll
+          for (int k = 0; k < WW; ++k) t += wred_l[k][tid];
+          o_ctx[(long)ab * D + tid] = t;
+          float td = t;
+          if (g.rate_in > 0.f)
+            td = tnt_keep((uint64_t)ab * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, site_in, step)
+                     ? t * (1.f / (1.f - g.rate_in)) : 0.f;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the reset of ctx_d[i+1] is in L2 before ctx_d[i] is published
+          o_ctxd[(long)ab * D + tid] = td;
+        }
+      }
+      // hs_l / es_l / wred_l are rewritten next step only behind the barrier that follows the h poll
+    }
+    tnt_seq_leave(a.sync, xcc, a.guard_out);
+    return;
+  }
+
+  // ============================================================= LSTM role: units [32 j, 32 j + 32) of the 16 samples
+  const int j = ub - 16;
+  const int arow = rb * 16 + lr;
+  // recurrent-kernel fragments of both 16-unit blocks: resident for all T steps
+  float4 bv[2][SS];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int ucol = (2 * j + q) * 16 + lr;
+#pragma unroll
+    for (int s = 0; s < SS; ++s)
+      bv[q][s] = *reinterpret_cast<const float4*>(a.Ur + ((long)(w * CK + (s >> 2) * 16 + kq * 4 + (s & 3)) * U + ucol) * 4);
+  }
+  for (int e = tid; e < D * 32; e += WT) {
+    const int d = e >> 5, ul = e & 31;
+    reinterpret_cast<float4*>(wc_l)[e] = *reinterpret_cast<const float4*>(a.Wc + ((long)d * U + j * 32 + ul) * 4);
+  }
+  // epilogue threads: (unit block q, row, unit)
+  const int eq = tid >> 8, erow = (tid & 255) >> 4, ecol = tid & 15;
+  const int eb = rb * 16 + erow, eu = (2 * j + eq) * 16 + ecol;
+  const bool eok = tid < 512 && eb < B;
+  const long ee = (long)eb * U + eu;
+  float4 zb = make_float4(0.f, 0.f, 0.f, 0.f), x4 = zb;
+  float cp = 0.f;
+  if (eok) {
+    if (a.zbias) zb = *reinterpret_cast<const float4*>(a.zbias + (long)eu * 4);
+    cp = a.cs[ee];
+    x4 = *reinterpret_cast<const float4*>(a.xz + ee * 4);
+    a.hs[BU + ee] = sentinel;
+  }
+  tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
+  for (int i = 0; i < T; ++i) {
+    if (eok && i + 2 <= T) a.hs[(long)(i + 2) * BU + ee] = sentinel;
+    // ---- A fragments = h[i] (this wave's K chunk)
     float av[SS];
-    float cxv = 0.f;
     unsigned spins = 0;
     for (;;) {
       bool ok = true;
 #pragma unroll
-      for (int j = 0; j < SS / 4; ++j) {
-        const float4 t = arow < B ? tnt_ld4_l2(hs_rsrc, (unsigned)(((long)i * BU + (long)arow * U + w * CK + j * 16 + kq * 4) * 4))
+      for (int q = 0; q < SS / 4; ++q) {
+        const float4 t = arow < B ? tnt_ld4_l2(hs_rsrc, (unsigned)(((long)i * BU + (long)arow * U + w * CK + q * 16 + kq * 4) * 4))
                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-        av[4 * j + 0] = t.x; av[4 * j + 1] = t.y; av[4 * j + 2] = t.z; av[4 * j + 3] = t.w;
+        av[4 * q + 0] = t.x; av[4 * q + 1] = t.y; av[4 * q + 2] = t.z; av[4 * q + 3] = t.w;
         ok = ok && __float_as_uint(t.x) != LC_SENTINEL && __float_as_uint(t.y) != LC_SENTINEL &&
              __float_as_uint(t.z) != LC_SENTINEL && __float_as_uint(t.w) != LC_SENTINEL;
-      }
-      if (cwave) {
-        cxv = (arow < B && w * 4 + kq < D) ? lc_ld1_l2(cx_rsrc, (unsigned)((((long)i * B + arow) * D + w * 4 + kq) * 4)) : 0.f;
-        ok = ok && __float_as_uint(cxv) != LC_SENTINEL;
       }
       if (__all(ok)) break;
       if (++spins > TNT_SEQ_SPIN_LIMIT) {
@@ -1084,35 +1221,63 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       }
       if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     }
-    floatx4 acc[4];
+    // ---- h[i] U for both unit blocks (off the critical path: the attention of step i runs meanwhile)
+    float zs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 2; ++q) {
+      floatx4 acc[4];
 #pragma unroll
-    for (int s = 0; s < SS; ++s) {
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].y, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].z, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].w, acc[3], 0, 0, 0);
+      for (int gg = 0; gg < 4; ++gg) acc[gg] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < SS; ++s) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[q][s].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[q][s].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[q][s].z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[q][s].w, acc[3], 0, 0, 0);
+      }
+      if (q == 1) __syncthreads();           // block 0's sums have been read
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w][gg][kq * 4 + r][lr] = acc[gg][r];
+      __syncthreads();
+      if (tid < 512 && eq == q) {
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int k = 0; k < NWF; ++k) sacc += red[k][gg][erow][ecol];
+          zs[gg] = sacc;
+        }
+      }
     }
-    if (cwave) {
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cxv, cbv.x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cxv, cbv.y, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(cxv, cbv.z, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(cxv, cbv.w, acc[3], 0, 0, 0);
+    // ---- the attention's context of step i for the 16 samples
+    spins = 0;
+    for (;;) {
+      bool ok = true;
+      for (int e = tid; e < 16 * D; e += WT) {
+        const int r = e / D, d = e - r * D;
+        const float v = rb * 16 + r < B ? lc_ld1_l2(cx_rsrc, (unsigned)((((long)i * B + rb * 16 + r) * D + d) * 4)) : 0.f;
+        ctx_l[r * 64 + d] = v;
+        ok = ok && __float_as_uint(v) != LC_SENTINEL;
+      }
+      if (__all(ok)) break;
+      if (++spins > TNT_SEQ_SPIN_LIMIT) {
+        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     }
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[w][g][kq * 4 + r][lr] = acc[g][r];
     __syncthreads();
     if (eok) {
-      float z[4] = {x4.x + zb.x, x4.y + zb.y, x4.z + zb.z, x4.w + zb.w};
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int k = 0; k < NWF; ++k) sacc += red[k][g][erow][ecol];
-        z[g] += sacc;
+      float z[4] = {x4.x + zb.x + zs[0], x4.y + zb.y + zs[1], x4.z + zb.z + zs[2], x4.w + zb.w + zs[3]};
+      const float* cr = ctx_l + erow * 64;
+      const float4* wq = reinterpret_cast<const float4*>(wc_l) + eq * 16 + ecol;
+#pragma unroll 8
+      for (int d = 0; d < D; ++d) {
+        const float c = cr[d];
+        const float4 wv = wq[d * 32];
+        z[0] += c * wv.x; z[1] += c * wv.y; z[2] += c * wv.z; z[3] += c * wv.w;
       }
       const float gi = tnt_sigmoid_fast(z[0]), gf = tnt_sigmoid_fast(z[1]), gg = tnt_tanh(z[2]), go = tnt_sigmoid_fast(z[3]);
       const float c2 = gf * cp + gi * gg;
@@ -1124,8 +1289,8 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       cp = c2;
       if (i + 1 < T) x4 = *reinterpret_cast<const float4*>(a.xz + ((long)(i + 1) * BU + ee) * 4);
     }
-    if (i + 1 == T) break;
-    __syncthreads();        // `red` is rewritten by the next step's MFMA phase
+    // `red` and ctx_l are rewritten next step only behind barriers that every thread passes after this point
+    __syncthreads();
   }
   tnt_seq_leave(a.sync, xcc, a.guard_out);
 }

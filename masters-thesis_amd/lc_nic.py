@@ -456,15 +456,13 @@ class NIC(ModelBase):
     def _lc_seq_ok(self):
         """the persistent forward-chain kernel applies (tnt_lc_seq_fwd_f32's shape limits; the device census was taken by
         _init_seq_lstm in _build)"""
-        # Opt-in (use_lc_seq = True): measured on MI355X at B = 64, R = 360, U = 512 the one-launch chain runs 16.3 us per
-        # step against 15.6 us for the two per-step launches (config 3: 1.078 vs 1.062 ms/step).  In-kernel timestamps
-        # (wall_clock64 around the phases of one workgroup): attention phase 13.6 us (its stand-alone kernel: 9.0), LSTM
-        # phase 3.5, hand-offs 1.6 -- the attention phase runs on only the 16 workgroups of an XCD that own a sample (all 4
-        # row blocks' samples share 4 L2s instead of 8) while the other 16 wait, and at 1024 threads the attention and
-        # LSTM register sets do not fit side by side (58 VGPRs spill); a back-off in the waiting workgroups' polls changes
-        # nothing.  What would make it win: two workgroups per sample (region halves + a softmax combine).  Kept
-        # parity-tested (test_lc_seq_fwd_chain_equals_step_kernels) as the base for that.
-        return bool(self.__dict__.get("_seq_lstm") and getattr(self, "use_lc_seq", False) and not self.use_layer_norm
+        # Default on (use_lc_seq = False selects the two per-step launches).  MI355X, B = 64, R = 360, U = 512: the chain as one
+        # launch of role-specialised workgroups (16 attention + 16 LSTM workgroups per XCD, step-invariant operands resident,
+        # the recurrent product overlapped with the attention) takes config 3 from 1.010 to 0.920 ms/step
+        # (tools/ab_attr.py attention use_lc_seq=False).  An earlier form that ran both phases on the same workgroups one
+        # after the other was slower than the per-step launches (16.3 vs 15.6 us per step): attention and LSTM register sets
+        # together spilled 58 VGPRs and half of each group idled through the attention phase.
+        return bool(self.__dict__.get("_seq_lstm") and getattr(self, "use_lc_seq", True) and not self.use_layer_norm
                     and hasattr(self.be, "lc_seq_fwd") and self.R <= 512 and self.A % 4 == 0 and self.D % 4 == 0
                     and self.A <= 64 and self.D <= 64)
 

@@ -121,13 +121,13 @@ def test_edge_shapes(kind, b, t):
 
 
 def test_lc_seq_fwd_chain_equals_step_kernels():
-    """tnt_lc_seq_fwd_f32 (the T attention -> LSTM steps of config 3 as one persistent launch, opt-in) against the per-step
+    """tnt_lc_seq_fwd_f32 (the T attention -> LSTM steps of config 3 as one persistent launch, the default) against the per-step
     kernels on the same model: dropout on (stored keep masks, context input dropout), captured training steps -- same
     losses, attention metric and weights up to float32 rounding of the gate math, error word 0; and inference outputs."""
     rng = np.random.default_rng(11)
     data, tgt = synth(rng)
     a, b = make("attention"), make("attention")
-    a.use_lc_seq = True
+    b.use_lc_seq = False
     ha = [a.train_step((data, tgt)).as_floats() for _ in range(4)]
     hb = [b.train_step((data, tgt)).as_floats() for _ in range(4)]
     if not a._lc_seq_ok():

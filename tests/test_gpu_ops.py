@@ -1097,6 +1097,52 @@ def test_lstm_seq_guard_codes(be):
     assert int(sync[1024]) == 0 and float(guard) == 0.0 and torch.equal(Hs, good)
 
 
+@pytest.mark.parametrize("T,B,R,D,A,r_attn,r_in", [(4, 20, 100, 32, 32, 0.2, 0.3), (3, 64, 200, 48, 40, 0.0, 0.0),
+                                                   (2, 5, 7, 4, 8, 0.25, 0.0), (1, 128, 360, 32, 32, 0.2, 0.2)])
+def test_lc_seq_fwd_equals_step_kernels(be, T, B, R, D, A, r_attn, r_in):
+    """tnt_lc_seq_fwd_f32 (role-specialised persistent chain: attention workgroups + LSTM workgroups per XCD) against the
+    per-step launches it replaces (tnt_attention_step_fwd_f32 + tnt_lstm_step_fwd_f32, themselves oracle-checked above):
+    ragged batches (B not a multiple of 16), both attention widths (G4 = 8 / 16), stored keep masks and in-kernel Philox,
+    context input dropout.  Same arithmetic up to float32 summation order (gate pre-activations, softmax normalisation)."""
+    U = 512
+    if not be.lstm_seq_supported(B, U):
+        pytest.skip("persistent chain kernels not supported on this device")
+    rng = np.random.default_rng(T * 1000 + B)
+    f = lambda *sh, sc=1.0: dev(rng.standard_normal(sh) * sc)
+    F, P, W2, b2, v, bv = f(B, R, D), f(B, R, A), f(U, A, sc=U ** -0.5), f(A, sc=0.1), f(A), f(1)
+    xz, Wc, Ur, zb = f(T, B, U, 4, sc=0.5), f(D, U, 4, sc=D ** -0.5), f(U, U, 4, sc=U ** -0.5), f(U, 4, sc=0.1)
+    h0, c0 = f(B, U, sc=0.5), f(B, U, sc=0.5)
+    seed, s_att, s_in, lw = 4711, 16, 48, D + 20
+    step_dev = torch.tensor([3], dtype=torch.int32, device="cuda")
+    keep = None
+    if r_attn > 0 and T != 2:                        # T == 2 case: masks drawn inside the kernels
+        keep = torch.zeros(T, B * R * A // 4, dtype=torch.uint8, device="cuda")
+        be.dropout_mask4(keep, B * R * A, T, r_attn, seed, s_att, 0, step_dev)
+
+    def buffers():
+        z = lambda *sh: torch.zeros(*sh, device="cuda")
+        hs, cs = z(T + 1, B, U), z(T + 1, B, U)
+        hs[0], cs[0] = h0, c0
+        return dict(hs=hs, cs=cs, gates=z(T, B, U, 4), qpre=z(T, B, A), alpha=z(T, B, R), ctx=z(T, B, D), ctx_d=z(T, B, D))
+    ref, got = buffers(), buffers()
+    for i in range(T):
+        be.attention_step_fwd(ref["hs"][i], F, P, W2, b2, v, bv, ref["qpre"][i], ref["alpha"][i], ref["ctx"][i], ref["ctx_d"][i],
+                              None, B, R, D, A, U, 0.2, r_attn, r_in, lw, seed, s_att + i, s_in + i, 0, step_dev,
+                              keep4=keep[i] if keep is not None else None)
+        be.lstm_step_fwd(xz[i], ref["hs"][i], ref["cs"][i], Ur, ref["ctx_d"][i], Wc, D, None, 0, 0, None, ref["hs"][i + 1],
+                         ref["cs"][i + 1], None, ref["gates"][i], B, U, xz_bias=zb)
+    sync, guard = torch.zeros(1025, dtype=torch.int32, device="cuda"), torch.zeros(1, device="cuda")
+    for rep in range(2):                             # the second launch starts from the state the first one left
+        be.lc_seq_fwd(F, P, W2, b2, v, bv, got["qpre"], got["alpha"], got["ctx"], got["ctx_d"], keep,
+                      B * R * A // 4 if keep is not None else 0, xz, Wc, Ur, zb, got["hs"], got["cs"], got["gates"], T, B, R, D,
+                      A, U, 0.2, r_attn, r_in, lw, seed, s_att, s_in, step_dev, sync, guard)
+        torch.cuda.synchronize()
+        assert int(sync[1024]) == 0 and float(guard) == 0.0
+        for k in ref:
+            d = (got[k] - ref[k]).abs().max().item()
+            assert d <= 2e-5 * max(1.0, ref[k].abs().max().item()), (k, d)
+
+
 @pytest.mark.parametrize("T,B,R", [(5, 8, 30), (15, 64, 360), (3, 5, 129)])
 def test_attention_metric(be, T, B, R):
     rng = np.random.default_rng(13)
