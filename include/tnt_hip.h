@@ -658,6 +658,24 @@ int32_t tnt_lc_seq_fwd_f32(const float* F, const float* P, const float* W2, cons
                            uint32_t site_attn0, uint32_t site_in0, const uint32_t* step_dev, uint32_t* sync,
                            float* guard_out, void* stream);
 
+/* ---- the backward chain of the attention captioner as ONE persistent launch (tape.gradient through lc_NIC.py:244-256):
+ * for i = T-1 .. 0: tnt_lstm_step_bwd_f32(dz_next = dz[i+1], dh_ext = the attention's query gradient of step i+1,
+ * dout_t = dout[i], gates[i], cs[i+1], cs[i] -> dz[i], context-gradient parts) then tnt_attention_step_bwd_f32(parts,
+ * qpre[i], alpha[i], keep4 + i * keep_stride, sites + i -> dqpre[i], query gradient), with dP [B][R][A], dF [B][R][D] and
+ * dvb [B][A+1] accumulated on chip over the T steps and WRITTEN once (no zero fill by the caller).
+ * dout [T][B][U], gates / dz [T][B][U][4], cs [T+1][B][U], qpre / dqpre [T][B][A], alpha [T][B][R]; work:
+ * tnt_lc_seq_bwd_work_floats(B, U) floats of exchange space (contents irrelevant).  Shape limits, sync and guard_out as
+ * tnt_lc_seq_fwd_f32. */
+int32_t tnt_lc_seq_bwd_work_floats(int32_t B, int32_t U);
+int32_t tnt_lc_seq_bwd_f32(const float* F, const float* P, const float* W2, const float* v, const float* qpre,
+                           const float* alpha, const uint8_t* keep4, int64_t keep_stride, float* dP, float* dF,
+                           float* dvb, float* dqpre, const float* Ur, const float* Wc, const float* dout,
+                           const float* gates, const float* cs, float* dz, float* work, int32_t T, int32_t B,
+                           int32_t R, int32_t D, int32_t A, int32_t U, float slope, float rate_attn, float rate_in,
+                           int32_t in_lwidth, uint64_t seed, uint32_t site_attn0, uint32_t site_in0,
+                           const uint32_t* step_dev, float alpha_mse_coef, uint32_t* sync, float* guard_out,
+                           void* stream);
+
 /* ---- the attention layer's hoisted first Dense (P = LeakyReLU(F W1 + b1), attention.py:32) backward, behind the chain:
  * with dP [rows][A] the score gradient accumulated over the T steps and Ppre its pre-activation:
  *   g = dP * LeakyReLU'(Ppre, slope);  db1 = column sums of g;  dW1 [D][A] = F^T g;  dF [rows][D] += g W1^T

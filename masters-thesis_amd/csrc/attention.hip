@@ -1329,3 +1329,455 @@ extern "C" int32_t tnt_lc_seq_fwd_f32(const float* F, const float* P, const floa
   TNT_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// The backward chain of the attention captioner (tape.gradient through lc_NIC.py:244-256: for i = T-1 .. 0 the LSTM step
+// backward, then the attention backward of the same step, whose query gradient feeds the LSTM step before) as ONE
+// persistent launch, with the forward chain's placement: per XCD / block of 16 samples, slots 0..15 run the ATTENTION
+// backward of one sample each, slots 16..31 the LSTM backward of 32 units each.
+//   LSTM workgroup: the "push" BPTT of lstm_seq_bwd_kernel (lstm.hip), two 16-unit blocks per workgroup: its Ur^T slices
+//     stay in registers, its dz tiles in LDS; per step it multiplies the tiles into partial da tiles for all 32 unit blocks
+//     (ring of three exchange buffers, the tiles are their own flags), gathers the 32 partials of its own blocks, adds the
+//     attention's query gradient dh_att of the step behind, runs the cell backward, and leaves the partial context
+//     gradient of its 32 units (dz . Wc^T, Wc slice in LDS) for the attention workgroups.
+//   attention workgroup: its sample's F and P rows AND the dF / dP accumulators stay in registers for all T steps (the
+//     per-step kernel reads and rewrites both accumulators every step: 11.8 of its 17.7 MB of traffic), W2 in LDS
+//     (A <= 32), dv / dbv accumulators in LDS; it waits for the 16 context-gradient parts of its sample, runs the
+//     attention backward, and publishes dh_att = dq W2^T for the LSTM workgroups.  dP, dF and dvb are WRITTEN once at the
+//     end (no zero fill, no accumulation by the caller).
+//   Overlap: while the attention backward of step i runs, the LSTM workgroups already push / gather dz_i Ur^T for step
+//   i - 1; only the cell backward waits for dh_att.
+// Hand-offs are data-polling on the sentinel with the reset-before-publish rule of lstm_seq_bwd_kernel<POLL>: every
+// hand-off buffer is a ring of three indexed by the exchange number, the thread that publishes a chunk resets the same
+// chunk of the next buffer first (and drains), a consumer reads every chunk of a producer each step.
+namespace {
+struct LcSeqBwdArgs {
+  AttArgs att;             // F, P, W2, v; qpre_in / alpha_in / dqpre / keep4 point at step 0; dP, dF, dvb: outputs
+  long keep_stride;
+  const float* Ur;         // [U][U][4]
+  const float* Wc;         // [D][U][4]
+  const float* dout;       // [T][B][U]   gradient w.r.t. the LSTM outputs
+  const float* gates;      // [T][B][U][4]
+  const float* cs;         // [T+1][B][U]
+  float* dz;               // [T][B][U][4]
+  float* xch;              // 3 * nrb * 32 * 32 * 256   partial da tiles
+  float* dhx;              // 3 * B * U                 dh_att
+  float* parts;            // 3 * nrb * 16 * 16 * 64    context-gradient parts
+  int T;
+  unsigned* sync; float* guard_out;
+};
+constexpr int LB_DZLD = 68, LB_WCLD = 132;
+constexpr int LB_LDS_FLOATS = 2 * 16 * LB_DZLD + 16 * 256 + 64 * LB_WCLD;            // LSTM role: dz tiles, gather buffer, Wc slice
+constexpr int LB_LDS_BYTES = (LB_LDS_FLOATS > 512 * 32 ? LB_LDS_FLOATS : 512 * 32) * 4 + 16;
+
+template <int G4, int NP>
+__global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
+  constexpr int RPP = WT / G4, NTW = 2, NWB = 16;
+  constexpr bool W2L = G4 == 8;
+  extern __shared__ __attribute__((aligned(16))) float lb_lds[];
+  unsigned* s_slot = reinterpret_cast<unsigned*>(lb_lds + (LB_LDS_BYTES - 16) / 4);
+  __shared__ float als[512], das[512];
+  __shared__ __attribute__((aligned(16))) float wred[WW][64], wred2[WW][64];
+  __shared__ __attribute__((aligned(16))) float qs[64], dcs[64], dq_s[64];
+  __shared__ float red_l[WW], dv_acc[64], scr[16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kq = lane >> 4, lr = lane & 15;
+  const AttArgs& g = a.att;
+  const int U = g.U, B = g.B, D = g.D, R = g.R, A = g.A, T = a.T;
+  const unsigned xcc = tnt_xcc_id();
+  const int nrb = (B + 15) / 16;
+  if ((int)xcc >= nrb) return;
+  unsigned* bar = a.sync + xcc * 64;
+  unsigned* err = a.sync + TNT_SEQ_ERR;
+  const TntSeqSlot slot = tnt_seq_enter(a.sync, xcc, s_slot);
+  if (slot.ub < 0) {
+    if (tid == 0 && a.guard_out) a.guard_out[0] = 2.f;
+    return;
+  }
+  const int ub = slot.ub, rb = __builtin_amdgcn_readfirstlane((int)xcc);
+  const long BU = (long)B * U;
+  const float sentinel = __uint_as_float(LC_SENTINEL);
+  const float4 sent4 = make_float4(sentinel, sentinel, sentinel, sentinel);
+  const __amdgpu_buffer_rsrc_t x_rsrc = tnt_rsrc(a.xch, (unsigned)(3u * nrb * 32u * 32u * 1024u));
+  const __amdgpu_buffer_rsrc_t dh_rsrc = tnt_rsrc(a.dhx, (unsigned)(3 * BU * 4));
+  const __amdgpu_buffer_rsrc_t pt_rsrc = tnt_rsrc(a.parts, (unsigned)(3u * nrb * 16u * 1024u * 4u));
+  auto poll_fail = [&](unsigned& spins) {          // true: give up (error word set here or elsewhere)
+    if (++spins > TNT_SEQ_SPIN_LIMIT) {
+      if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return true;
+    }
+    return (spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  };
+
+  if (ub < 16) {
+    // =========================================================== attention role: sample ab
+    float* w2_l = lb_lds;
+    const int ab = rb * 16 + ub;
+    const bool live = ab < B;
+    const int c4 = tid % G4, rl = tid / G4;
+    const bool cokA = c4 * 4 < A, cokD = c4 * 4 < D;
+    float4 pv[NP], fv[NP], dpa[NP], dfa[NP];
+    float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dbv_acc = 0.f;
+    if (live) {
+      if (W2L) {
+        for (int e = tid; e < U * A / 4; e += WT) reinterpret_cast<float4*>(w2_l)[e] = reinterpret_cast<const float4*>(g.W2)[e];
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int r = p * RPP + rl;
+        pv[p] = (cokA && r < R) ? *reinterpret_cast<const float4*>(g.P + ((long)ab * R + r) * A + c4 * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        fv[p] = (cokD && r < R) ? *reinterpret_cast<const float4*>(g.F + ((long)ab * R + r) * D + c4 * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        dpa[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dfa[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (cokA) v4 = *reinterpret_cast<const float4*>(g.v + c4 * 4);
+      if (tid < 64) dv_acc[tid] = 0.f;
+      // dh_att chunks of this thread (rows k = rl + m RPP, owned by the lane with c4 == 0): buffer 0 armed
+      if (c4 == 0)
+        for (int k = rl; k < U; k += RPP) a.dhx[(long)ab * U + k] = sentinel;
+    }
+    tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
+    const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
+    const bool stored = g.keep4 != nullptr && g.rate_attn > 0.f;
+    const float scale_a = g.rate_attn > 0.f ? 1.f / (1.f - g.rate_attn) : 1.f;
+    if (live) for (int i = T - 1; i >= 0; --i) {
+      const int pi = (T - 1 - i) % 3, pn = (pi + 1) % 3;
+      const uint32_t site_attn = g.site_attn + (uint32_t)i, site_in = g.site_in + (uint32_t)i;
+      if (c4 == 0 && i > 0)
+        for (int k = rl; k < U; k += RPP) a.dhx[((long)pn * B + ab) * U + k] = sentinel;
+      // ---- operands of this step that do not depend on the chain
+      for (int r = tid; r < R; r += WT) als[r] = g.alpha_in[((long)i * B + ab) * R + r];
+      float qp = 0.f;
+      if (tid < A) qp = g.qpre_in[((long)i * B + ab) * A + tid];
+      if (tid < 64) qs[tid] = tid < A ? (qp > 0.f ? qp : qp * g.slope) : 0.f;
+      uint32_t mk[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int r = p * RPP + rl;
+        mk[p] = (stored && cokA && r < R) ? g.keep4[(long)i * a.keep_stride + ((((long)ab * R + r) * A + c4 * 4) >> 2)] : 0u;
+      }
+      // ---- the 16 context-gradient parts of this sample (thread = (part, d))
+      {
+        float v = 0.f;
+        unsigned spins = 0;
+        const bool mine = tid < 16 * D;
+        const unsigned off = (unsigned)(((((pi * nrb + rb) * 16 + tid / D) * 16 + ub) * 64 + tid % D) * 4);
+        for (;;) {
+          if (mine) v = lc_ld1_l2(pt_rsrc, off);
+          if (__all(!mine || __float_as_uint(v) != LC_SENTINEL)) break;
+          if (poll_fail(spins)) break;
+        }
+        if (mine) scr[tid] = v;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float dc = 0.f;
+        if (tid < D) {
+#pragma unroll
+          for (int p = 0; p < 16; ++p) dc += scr[p * D + tid];
+          if (g.rate_in > 0.f)
+            dc = tnt_keep((uint64_t)ab * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, site_in, step)
+                     ? dc * (1.f / (1.f - g.rate_in)) : 0.f;
+        }
+        dcs[tid] = dc;
+      }
+      __syncthreads();
+      // ---- dalpha[r] = dctx . F[r];  dF[r] += alpha[r] dctx   (accumulator in registers)
+      {
+        const float4 dc4 = cokD ? *reinterpret_cast<const float4*>(&dcs[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int r = p * RPP + rl;
+          float t = 0.f;
+          if (cokD && r < R) {
+            t = dc4.x * fv[p].x + dc4.y * fv[p].y + dc4.z * fv[p].z + dc4.w * fv[p].w;
+            const float al = als[r];
+            dfa[p].x += al * dc4.x; dfa[p].y += al * dc4.y; dfa[p].z += al * dc4.z; dfa[p].w += al * dc4.w;
+          }
+          t = adj_sum<G4>(t);
+          if (c4 == 0 && r < R) das[r] = t + g.alpha_mse * (als[r] - 1.f);
+        }
+        __syncthreads();
+      }
+      float dot = 0.f;
+      for (int r = tid; r < R; r += WT) dot += als[r] * das[r];
+      dot = block_sum_w(dot, red_l);
+      float dbv = 0.f;
+      for (int r = tid; r < R; r += WT) { const float de = als[r] * (das[r] - dot); als[r] = de; dbv += de; }
+      dbv = block_sum_w(dbv, red_l);
+      // ---- through e = s_d . v, dropout, tanh
+      {
+        const float4 q4 = cokA ? *reinterpret_cast<const float4*>(&qs[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), dq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int r = p * RPP + rl;
+          if (!(cokA && r < R)) continue;
+          const long e = ((long)ab * R + r) * A + c4 * 4;
+          const float s0 = tnt_tanh(pv[p].x + q4.x), s1 = tnt_tanh(pv[p].y + q4.y), s2 = tnt_tanh(pv[p].z + q4.z), s3 = tnt_tanh(pv[p].w + q4.w);
+          bool k[4] = {true, true, true, true};
+          if (stored) { k[0] = mk[p] & 1u; k[1] = mk[p] & 2u; k[2] = mk[p] & 4u; k[3] = mk[p] & 8u; }
+          else if (g.rate_attn > 0.f) tnt_keep4((uint64_t)e, g.rate_attn, g.seed, site_attn, step, k);
+          const float k0 = k[0] ? scale_a : 0.f, k1 = k[1] ? scale_a : 0.f, k2 = k[2] ? scale_a : 0.f, k3 = k[3] ? scale_a : 0.f;
+          const float de = als[r];
+          dv.x += s0 * k0 * de; dv.y += s1 * k1 * de; dv.z += s2 * k2 * de; dv.w += s3 * k3 * de;
+          const float d0 = de * v4.x * k0 * (1.f - s0 * s0), d1 = de * v4.y * k1 * (1.f - s1 * s1);
+          const float d2 = de * v4.z * k2 * (1.f - s2 * s2), d3 = de * v4.w * k3 * (1.f - s3 * s3);
+          dpa[p].x += d0; dpa[p].y += d1; dpa[p].z += d2; dpa[p].w += d3;
+          dq.x += d0; dq.y += d1; dq.z += d2; dq.w += d3;
+        }
+        dv.x = stride_sum<G4>(dv.x); dv.y = stride_sum<G4>(dv.y); dv.z = stride_sum<G4>(dv.z); dv.w = stride_sum<G4>(dv.w);
+        dq.x = stride_sum<G4>(dq.x); dq.y = stride_sum<G4>(dq.y); dq.z = stride_sum<G4>(dq.z); dq.w = stride_sum<G4>(dq.w);
+        if (lane < G4) {
+          *reinterpret_cast<float4*>(&wred[w][lane * 4]) = dv;
+          *reinterpret_cast<float4*>(&wred2[w][lane * 4]) = dq;
+        }
+        __syncthreads();
+        if (tid < 64) {
+          float dqp = 0.f;
+          if (tid < A) {
+            float tv = 0.f, tq = 0.f;
+#pragma unroll
+            for (int k = 0; k < WW; ++k) { tv += wred[k][tid]; tq += wred2[k][tid]; }
+            dv_acc[tid] += tv;
+            dqp = qp > 0.f ? tq : tq * g.slope;
+            g.dqpre[((long)i * B + ab) * A + tid] = dqp;
+          }
+          dq_s[tid] = dqp;
+        }
+        if (tid == 0) dbv_acc += dbv;
+        __syncthreads();
+      }
+      // ---- dh_att[k] = sum_a dqpre[a] W2[k][a]: thread (c4, rl) takes its 4 columns of rows k = rl + m RPP
+      if (i > 0) {
+        const float4 dq4 = cokA ? *reinterpret_cast<const float4*>(&dq_s[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this thread's resets of the next buffer are in L2 first
+        for (int k = rl; k < U; k += RPP) {
+          float t = 0.f;
+          if (cokA) {
+            const float4 wv = W2L ? *reinterpret_cast<const float4*>(w2_l + k * A + c4 * 4)
+                                  : *reinterpret_cast<const float4*>(g.W2 + (long)k * A + c4 * 4);
+            t = dq4.x * wv.x + dq4.y * wv.y + dq4.z * wv.z + dq4.w * wv.w;
+          }
+          t = adj_sum<G4>(t);
+          if (c4 == 0) a.dhx[((long)pi * B + ab) * U + k] = t;
+        }
+      }
+      // als / das / qs / scr are rewritten next step; every reader of this step is behind the barriers above
+      __syncthreads();
+    }
+    if (live) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int r = p * RPP + rl;
+        if (r < R && cokA) *reinterpret_cast<float4*>(g.dP + ((long)ab * R + r) * A + c4 * 4) = dpa[p];
+        if (r < R && cokD) *reinterpret_cast<float4*>(g.dF + ((long)ab * R + r) * D + c4 * 4) = dfa[p];
+      }
+      if (tid < A) g.dvb[(long)ab * (A + 1) + tid] = dv_acc[tid];
+      if (tid == 0) g.dvb[(long)ab * (A + 1) + A] = dbv_acc;
+    }
+    tnt_seq_leave(a.sync, xcc, a.guard_out);
+    return;
+  }
+
+  // ============================================================= LSTM role: unit blocks 2 j and 2 j + 1 of the 16 samples
+  const int j = ub - 16;
+  float* dzs = lb_lds;                                         // [2][16][LB_DZLD]
+  float* red = lb_lds + 2 * 16 * LB_DZLD;                      // [NWB][256]
+  float* wc_l = red + NWB * 256;                               // [D][LB_WCLD]: Wc[d][32 j .. 32 j + 32][4]
+  // resident B operands: Ur^T[k][n] = Ur[n][vub * 64 + k], lane (kq, lr) of column tile t holds n = w*32 + t*16 + lr and the
+  // contraction indices k = kq*16 + ks (lstm_seq_bwd_kernel's layout)
+  float bw[2][NTW][16];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const float* src = a.Ur + ((long)(w * 32 + t * 16 + lr) * U + (2 * j + q) * 16) * 4 + kq * 16;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 x = *reinterpret_cast<const float4*>(src + 4 * c);
+        bw[q][t][4 * c + 0] = x.x; bw[q][t][4 * c + 1] = x.y; bw[q][t][4 * c + 2] = x.z; bw[q][t][4 * c + 3] = x.w;
+      }
+    }
+  for (int e = tid; e < D * 32; e += WT) {
+    const int d = e >> 5, c = (e & 31) * 4;
+    *reinterpret_cast<float4*>(wc_l + d * LB_WCLD + c) = *reinterpret_cast<const float4*>(a.Wc + ((long)d * U + j * 32) * 4 + c);
+  }
+  for (int e = tid; e < 2 * 16 * LB_DZLD; e += WT) dzs[e] = 0.f;             // rows past B stay zero
+  const int eq = tid >> 8, erow = (tid & 255) >> 4, ecol = tid & 15;
+  const int eb = rb * 16 + erow, eu = (2 * j + eq) * 16 + ecol;
+  const bool eok = tid < 512 && eb < B;
+  const long ee = (long)eb * U + eu;
+  const int ridx = ((erow >> 2) * 16 + ecol) * 4 + (erow & 3);
+  float dc_c = 0.f;
+  // this lane's chunk of the tile (dest, src) in ring buffer buf
+  auto xslot = [&](int buf, int dest, int src) { return a.xch + ((((long)(buf * nrb + rb) * 32 + dest) * 32 + src) * 256) + lane * 4; };
+  // this thread's element (row, d) of this workgroup's context-gradient part in ring buffer buf
+  const int prow = tid / D, pd = tid - prow * D;
+  const bool pmine = tid < 16 * D;
+  auto pslot = [&](int buf) { return a.parts + ((((long)(buf * nrb + rb) * 16 + j) * 16 + prow) * 64 + pd); };
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) *reinterpret_cast<float4*>(xslot(0, w * NTW + t, 2 * j + q)) = sent4;
+  if (pmine) *pslot(0) = sentinel;
+  tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
+  for (int i = T - 1; i >= 0; --i) {
+    const int pi = (T - 1 - i) % 3, pn = (pi + 1) % 3;
+    // epilogue operands of this step do not depend on the chain: fetch them first
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cval = 0.f, cprev = 0.f, dout_t = 0.f;
+    if (eok) {
+      g4 = *reinterpret_cast<const float4*>(a.gates + ((long)i * BU + ee) * 4);
+      cval = a.cs[(long)(i + 1) * BU + ee]; cprev = a.cs[(long)i * BU + ee];
+      dout_t = a.dout[(long)i * BU + ee];
+    }
+    if (pmine && i > 0) *pslot(pn) = sentinel;
+    float da = 0.f;
+    if (i < T - 1) {
+      const int par = (T - 2 - i) % 3;                       // exchange of dz_{i+1} Ur^T; also the buffer of dh_att_{i+1}
+      if (i > 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) *reinterpret_cast<float4*>(xslot((par + 1) % 3, w * NTW + t, 2 * j + q)) = sent4;
+      }
+      floatx4 acc[2][NTW];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float av[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 x = *reinterpret_cast<const float4*>(dzs + (q * 16 + lr) * LB_DZLD + kq * 16 + 4 * c);
+          av[4 * c + 0] = x.x; av[4 * c + 1] = x.y; av[4 * c + 2] = x.z; av[4 * c + 3] = x.w;
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[q][t] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bw[q][t][ks], acc[q][t], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's resets are in L2 first
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+          *reinterpret_cast<float4*>(xslot(par, w * NTW + t, 2 * j + q)) = make_float4(acc[q][t][0], acc[q][t][1], acc[q][t][2], acc[q][t][3]);
+      // ---- gather the 32 partial tiles of each of this workgroup's two blocks: wave w sums sources w and w + 16
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const unsigned base = (unsigned)((((par * nrb + rb) * 32 + (2 * j + q)) * 32) * 1024) + (unsigned)lane * 16u;
+        float4 p0, p1;
+        unsigned spins = 0;
+        for (;;) {
+          p0 = tnt_ld4_l2(x_rsrc, base + (unsigned)w * 1024u);
+          p1 = tnt_ld4_l2(x_rsrc, base + (unsigned)(w + 16) * 1024u);
+          const bool ok = __float_as_uint(p0.x) != LC_SENTINEL && __float_as_uint(p0.y) != LC_SENTINEL &&
+                          __float_as_uint(p0.z) != LC_SENTINEL && __float_as_uint(p0.w) != LC_SENTINEL &&
+                          __float_as_uint(p1.x) != LC_SENTINEL && __float_as_uint(p1.y) != LC_SENTINEL &&
+                          __float_as_uint(p1.z) != LC_SENTINEL && __float_as_uint(p1.w) != LC_SENTINEL;
+          if (__all(ok)) break;
+          if (poll_fail(spins)) break;
+        }
+        if (q == 1) __syncthreads();                         // block 0's sums have been read
+        *reinterpret_cast<float4*>(red + w * 256 + lane * 4) = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
+        __syncthreads();
+        if (eok && eq == q) {
+#pragma unroll
+          for (int k = 0; k < NWB; ++k) da += red[k * 256 + ridx];
+        }
+      }
+      // ---- the attention's query gradient of the step behind (dh_att_{i+1}, buffer par)
+      {
+        float v = 0.f;
+        unsigned spins = 0;
+        for (;;) {
+          if (eok) v = lc_ld1_l2(dh_rsrc, (unsigned)((((long)par * B + eb) * U + eu) * 4));
+          if (__all(!eok || __float_as_uint(v) != LC_SENTINEL)) break;
+          if (poll_fail(spins)) break;
+        }
+        da += v;
+      }
+    }
+    // ---- cell backward (the arithmetic of bwd_epilogue, lstm.hip)
+    __syncthreads();          // every wave has read the dz tiles of the step behind (MFMA operands) before they are rewritten
+    if (eok) {
+      const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
+      const float tc = tnt_tanh(cval);
+      const float dh = da + dout_t;
+      const float dgo = dh * tc;
+      const float dc = dc_c + dh * go * (1.f - tc * tc);
+      const float4 dz4 = make_float4(dc * gg * gi * (1.f - gi), dc * cprev * gf * (1.f - gf), dc * gi * (1.f - gg * gg),
+                                     dgo * go * (1.f - go));
+      dc_c = dc * gf;
+      *reinterpret_cast<float4*>(a.dz + ((long)i * BU + ee) * 4) = dz4;
+      *reinterpret_cast<float4*>(dzs + (eq * 16 + erow) * LB_DZLD + ecol * 4) = dz4;
+    }
+    __syncthreads();
+    // ---- partial context gradient of this workgroup's 32 units: part[row][d] = sum_c dz[row][c] Wc[d][c]
+    if (pmine) {
+      float t = 0.f;
+      const float* wr = wc_l + pd * LB_WCLD;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float* zr = dzs + (q * 16 + prow) * LB_DZLD;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const float4 x = *reinterpret_cast<const float4*>(zr + 4 * c), y = *reinterpret_cast<const float4*>(wr + q * 64 + 4 * c);
+          t += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's reset of the next buffer's element is in L2 first
+      *pslot(pi) = t;
+    }
+  }
+  tnt_seq_leave(a.sync, xcc, a.guard_out);
+}
+}  // namespace
+
+extern "C" int32_t tnt_lc_seq_bwd_work_floats(int32_t B, int32_t U) {
+  if (B <= 0 || B > 128 || U != 512) return 0;
+  const int nrb = (B + 15) / 16;
+  return 3 * nrb * 32 * 32 * 256 + 3 * B * U + 3 * nrb * 16 * 16 * 64;
+}
+
+extern "C" int32_t tnt_lc_seq_bwd_f32(const float* F, const float* P, const float* W2, const float* v, const float* qpre,
+                                      const float* alpha, const uint8_t* keep4, int64_t keep_stride, float* dP, float* dF,
+                                      float* dvb, float* dqpre, const float* Ur, const float* Wc, const float* dout,
+                                      const float* gates, const float* cs, float* dz, float* work, int32_t T, int32_t B,
+                                      int32_t R, int32_t D, int32_t A, int32_t U, float slope, float rate_attn,
+                                      float rate_in, int32_t in_lwidth, uint64_t seed, uint32_t site_attn0,
+                                      uint32_t site_in0, const uint32_t* step_dev, float alpha_mse_coef, uint32_t* sync,
+                                      float* guard_out, void* stream) {
+  if (T <= 0 || sync == nullptr || work == nullptr || U != 512 || B <= 0 || B > 128) return TNT_BADARG(24);
+  if (!wide_ok(R, D, A) || R > 512 || D > 64 || A > 64) return TNT_BADARG(21);
+  if ((long)(T + 1) * B * U * 4 >= (1L << 32)) return TNT_BADARG(19);
+  if (!tnt_aligned16(P) || !tnt_aligned16(F) || !tnt_aligned16(W2) || !tnt_aligned16(v) || !tnt_aligned16(dP) ||
+      !tnt_aligned16(dF) || !tnt_aligned16(Wc) || !tnt_aligned16(Ur) || !tnt_aligned16(gates) || !tnt_aligned16(dz) ||
+      !tnt_aligned16(work)) return TNT_BADARG(1);
+  LcSeqBwdArgs a{};
+  AttArgs& g = a.att;
+  g.F = F; g.P = P; g.W2 = W2; g.v = v; g.qpre_in = qpre; g.alpha_in = alpha; g.keep4 = keep4; g.dP = dP; g.dF = dF; g.dvb = dvb;
+  g.dqpre = dqpre; g.B = B; g.R = R; g.D = D; g.A = A; g.U = U; g.in_lwidth = in_lwidth; g.slope = slope;
+  g.rate_attn = rate_attn; g.rate_in = rate_in; g.seed = seed; g.site_attn = site_attn0; g.site_in = site_in0; g.step = 0;
+  g.step_dev = step_dev; g.alpha_mse = alpha_mse_coef;
+  const int64_t nrb = (B + 15) / 16;
+  a.keep_stride = keep_stride; a.Ur = Ur; a.Wc = Wc; a.dout = dout; a.gates = gates; a.cs = cs; a.dz = dz;
+  a.xch = work; a.dhx = work + 3 * nrb * 32 * 32 * 256; a.parts = a.dhx + 3 * (int64_t)B * U;
+  a.T = T; a.sync = sync; a.guard_out = guard_out;
+  const int g4 = (A <= 32 && D <= 32) ? 8 : 16, np = (R + WT / g4 - 1) / (WT / g4);
+  if (np > 6) return TNT_BADARG(21);
+  void (*kern)(LcSeqBwdArgs) = nullptr;
+  if (g4 == 8) kern = np <= 3 ? lc_seq_bwd_kernel<8, 3> : lc_seq_bwd_kernel<8, 6>;
+  else kern = np <= 3 ? lc_seq_bwd_kernel<16, 3> : lc_seq_bwd_kernel<16, 6>;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_BYTES) != hipSuccess)
+    return TNT_BADARG(90);
+  hipLaunchKernelGGL(kern, dim3(256), dim3(1024), LB_LDS_BYTES, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}

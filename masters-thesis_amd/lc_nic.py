@@ -348,7 +348,10 @@ class NIC(ModelBase):
         self.logits = f(n, ldV)
         self.loss_row, self.corr_row = f(n), f(n)
         self.met = f(8 + 4 * self.S)
-        self._init_seq_lstm(B, U)        # device census + sync state of the persistent forward chain (tnt_lc_seq_fwd_f32)
+        self._init_seq_lstm(B, U)        # device census + sync state of the persistent chain kernels (tnt_lc_seq_{fwd,bwd}_f32)
+        self.lc_xch = None                # exchange space of the persistent backward chain
+        if self.__dict__.get("_seq_lstm") and hasattr(self.be, "lc_seq_bwd") and B <= 128:
+            self.lc_xch = f(self.be.lc_seq_bwd_work_floats(B, U))
         self.colB = f(2 * B)
         # backward
         self.dinter, self.dHs = f(n, H), f(n, U)
@@ -625,6 +628,28 @@ class NIC(ModelBase):
         W2, v = a.p("attention/W2/kernel"), a.p("attention/V/kernel")
         if self.use_layer_norm:
             return self._bwd_chain_ln(B, T)
+        if self._lc_seq_ok() and self.__dict__.get("lc_xch") is not None and getattr(self, "use_lc_seq_bwd", True):
+            # the T LSTM-backward -> attention-backward steps as ONE persistent launch (tnt_lc_seq_bwd_f32): role-specialised
+            # workgroups per XCD, dP / dF / dvb accumulated on chip and written once
+            keep = self.att_keep if self._keep_stored else None
+            be.lc_seq_bwd(self.F, self.P, W2, v, self.qpre, self.alpha, keep, B * R * A // 4 if keep is not None else 0,
+                          self.dP, self.dF, self.dvb, self.dqpre, Ur, Wl[:D], self.dHs, self.gates, self.Cs, self.dZ,
+                          self.lc_xch, T, B, R, D, A, U, 0.2, self.r_attn, self.r_lstm, D + Et, sd, S_ATTN, S_LSTM_IN, ds,
+                          self._alpha_mse, self.seq_sync, self._guard_out())
+        else:
+            self._bwd_chain_steps(B, T, Wl, Ur, W2, v)
+        hprev = self.Hs[:T].view(n, U)
+        gWl = a.g("lstm/kernel")
+        self.gemm_sk(hprev, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True)
+        self.gemm_sk(self.text, self.dZ, gWl[D:], Et, 4 * U, n, Et, 4 * U, 4 * U, transA=True)
+        self.gemm_sk(self.ctx_d, self.dZ, gWl[:D], D, 4 * U, n, D, 4 * U, 4 * U, transA=True)
+        be.colsum(self.dZ, a.g("lstm/bias"), n, 4 * U, 4 * U, self.work)
+
+    def _bwd_chain_steps(self, B, T, Wl, Ur, W2, v):
+        """the chain as 2 T per-step launches"""
+        be = self.be
+        R, D, A, U, Et = self.R, self.D, self.A, self.U, self.Et
+        sd, ds = self.seed, self.drop_step
         for i in range(T - 1, -1, -1):
             last = i == T - 1
             # dctx_i = dZ_i @ Wc^T: every LSTM-backward workgroup leaves the partial of its 16 units, the attention
@@ -647,12 +672,6 @@ class NIC(ModelBase):
                                       D + Et, sd, S_ATTN + i, S_LSTM_IN + i, 0, ds, dz=self.dZ[i * B:(i + 1) * B],
                                       Wc=Wl[:D], keep4=self.att_keep[i] if self._keep_stored else None,
                                       alpha_mse=self._alpha_mse, fresh=last)
-        hprev = self.Hs[:T].view(n, U)
-        gWl = a.g("lstm/kernel")
-        self.gemm_sk(hprev, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True)
-        self.gemm_sk(self.text, self.dZ, gWl[D:], Et, 4 * U, n, Et, 4 * U, 4 * U, transA=True)
-        self.gemm_sk(self.ctx_d, self.dZ, gWl[:D], D, 4 * U, n, D, 4 * U, 4 * U, transA=True)
-        be.colsum(self.dZ, a.g("lstm/bias"), n, 4 * U, 4 * U, self.work)
 
     def _bwd_chain_ln(self, B, T):
         """The T-step chain with the LayerNormLSTMCell (reverse of _decode_step's LayerNorm branch).  Per step: cell

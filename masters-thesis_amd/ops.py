@@ -308,6 +308,17 @@ class HipBackend:
                    T, B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, int(seed), int(site_attn0), int(site_in0),
                    _p(step_dev), _p(sync), _p(guard_out), self._s())
 
+    def lc_seq_bwd_work_floats(self, B, U):
+        return int(self.lib.tnt_lc_seq_bwd_work_floats(int(B), int(U)))
+
+    def lc_seq_bwd(self, F, P, W2, v, qpre, alpha, keep4, keep_stride, dP, dF, dvb, dqpre, Ur, Wc, dout, gates, cs, dz, work, T,
+                   B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, seed, site_attn0, site_in0, step_dev, alpha_mse, sync,
+                   guard_out=None):
+        self._call(self.lib.tnt_lc_seq_bwd_f32, "tnt_lc_seq_bwd_f32", _p(F), _p(P), _p(W2), _p(v), _p(qpre), _p(alpha), _p(keep4),
+                   int(keep_stride), _p(dP), _p(dF), _p(dvb), _p(dqpre), _p(Ur), _p(Wc), _p(dout), _p(gates), _p(cs), _p(dz),
+                   _p(work), T, B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, int(seed), int(site_attn0), int(site_in0),
+                   _p(step_dev), float(alpha_mse), _p(sync), _p(guard_out), self._s())
+
     def attention_front_bwd_parts(self, rows, D, A):
         return int(self.lib.tnt_attention_front_bwd_parts(rows, D, A))
 

@@ -1143,6 +1143,67 @@ def test_lc_seq_fwd_equals_step_kernels(be, T, B, R, D, A, r_attn, r_in):
             assert d <= 2e-5 * max(1.0, ref[k].abs().max().item()), (k, d)
 
 
+@pytest.mark.parametrize("T,B,R,D,A,r_attn,r_in,mse", [(4, 20, 100, 32, 32, 0.2, 0.3, 0.0), (3, 64, 200, 48, 40, 0.0, 0.0, 0.01),
+                                                       (2, 5, 7, 4, 8, 0.25, 0.0, 0.0), (1, 128, 360, 32, 32, 0.2, 0.2, 0.0),
+                                                       (15, 64, 360, 32, 32, 0.2, 0.2, 0.0)])
+def test_lc_seq_bwd_equals_step_kernels(be, T, B, R, D, A, r_attn, r_in, mse):
+    """tnt_lc_seq_bwd_f32 (the backward chain as one persistent launch: LSTM-backward workgroups pushing partial da tiles,
+    attention-backward workgroups with dP / dF accumulated in registers) against the per-step launches it replaces
+    (tnt_lstm_step_bwd_f32 with context-gradient parts + tnt_attention_step_bwd_f32, themselves oracle-checked above):
+    dz of every step, dqpre, and the accumulated dP / dF / dvb.  Ragged batches, both attention widths, stored and in-kernel
+    masks, context input dropout, the attention-MSE term.  Two launches: the second starts from the ring state of the first."""
+    U = 512
+    if not be.lstm_seq_supported(B, U):
+        pytest.skip("persistent chain kernels not supported on this device")
+    rng = np.random.default_rng(T * 1000 + B + 1)
+    f = lambda *sh, sc=1.0: dev(rng.standard_normal(sh) * sc)
+    F, P, W2, v = f(B, R, D), f(B, R, A), f(U, A, sc=U ** -0.5), f(A)
+    Wc, Ur = f(D, U, 4, sc=D ** -0.5), f(U, U, 4, sc=U ** -0.5)
+    alpha = dev(O.softmax(rng.standard_normal((T, B, R)), axis=-1))
+    qpre, dout = f(T, B, A), f(T, B, U, sc=0.1)
+    gates = torch.sigmoid(f(T, B, U, 4))
+    gates[..., 2] = gates[..., 2] * 2 - 1                    # the candidate gate is a tanh
+    cs = f(T + 1, B, U, sc=0.5)
+    seed, s_att, s_in, lw = 4711, 16, 48, D + 20
+    step_dev = torch.tensor([3], dtype=torch.int32, device="cuda")
+    keep = None
+    if r_attn > 0 and T != 2:
+        keep = torch.zeros(T, B * R * A // 4, dtype=torch.uint8, device="cuda")
+        be.dropout_mask4(keep, B * R * A, T, r_attn, seed, s_att, 0, step_dev)
+    z = lambda *sh: torch.zeros(*sh, device="cuda")
+    # ---- per-step reference
+    r_dz, r_dq, r_dP, r_dF, r_dvb = z(T, B, U, 4), z(T, B, A), z(B, R, A), z(B, R, D), z(B, A + 1)
+    dh_att, dc, parts = z(B, U), z(B, U), z(U // 16, B, D)
+    for i in range(T - 1, -1, -1):
+        last = i == T - 1
+        use_parts = (U // 16) * D <= 1024                  # the per-step kernels' limit; else dctx = dz Wc^T inside the attention step
+        be.lstm_step_bwd(None if last else r_dz[i + 1], Ur, None, None if last else dh_att, None if last else dc, None,
+                         dout[i], None, 0, 0, gates[i], cs[i + 1], cs[i], r_dz[i], None, dc, None, B, U,
+                         Wc=Wc if use_parts else None, D=D, dctx_part=parts if use_parts else None)
+        kw = dict(dctx_part=parts, nparts=U // 16) if use_parts else dict(dz=r_dz[i], Wc=Wc)
+        be.attention_step_bwd(None, F, P, W2, v, qpre[i], alpha[i], r_dP, r_dF, r_dvb, r_dq[i], dh_att, B, R, D, A, U, 0.2,
+                              r_attn, r_in, lw, seed, s_att + i, s_in + i, 0, step_dev,
+                              keep4=keep[i] if keep is not None else None, alpha_mse=mse, fresh=last, **kw)
+    # ---- one launch
+    work = torch.full((be.lc_seq_bwd_work_floats(B, U),), 7.0, device="cuda")
+    sync, guard = torch.zeros(1025, dtype=torch.int32, device="cuda"), torch.zeros(1, device="cuda")
+    nan = float("nan")
+    for rep in range(2):
+        g_dz, g_dq = torch.full((T, B, U, 4), nan, device="cuda"), torch.full((T, B, A), nan, device="cuda")
+        g_dP, g_dF, g_dvb = (torch.full((B, R, A), nan, device="cuda"), torch.full((B, R, D), nan, device="cuda"),
+                             torch.full((B, A + 1), nan, device="cuda"))
+        be.lc_seq_bwd(F, P, W2, v, qpre, alpha, keep, B * R * A // 4 if keep is not None else 0, g_dP, g_dF, g_dvb, g_dq, Ur, Wc,
+                      dout, gates, cs, g_dz, work, T, B, R, D, A, U, 0.2, r_attn, r_in, lw, seed, s_att, s_in, step_dev, mse,
+                      sync, guard)
+        torch.cuda.synchronize()
+        assert int(sync[1024]) == 0 and float(guard) == 0.0
+        for name, got, ref in (("dz", g_dz, r_dz), ("dqpre", g_dq, r_dq), ("dP", g_dP, r_dP), ("dF", g_dF, r_dF),
+                               ("dvb", g_dvb[:, :A], r_dvb[:, :A])):
+            d = (got - ref).abs().max().item()
+            assert d <= 3e-5 * max(1e-3, ref.abs().max().item()), (rep, name, d, ref.abs().max().item())
+        assert g_dvb[:, A].abs().max().item() < 1e-4
+
+
 @pytest.mark.parametrize("T,B,R", [(5, 8, 30), (15, 64, 360), (3, 5, 129)])
 def test_attention_metric(be, T, B, R):
     rng = np.random.default_rng(13)
