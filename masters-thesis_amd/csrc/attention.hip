@@ -1054,6 +1054,9 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       float* const o_ctxd = g.ctx_d + (long)i * B * D;
       const uint32_t site_attn = g.site_attn + (uint32_t)i, site_in = g.site_in + (uint32_t)i;
       if (tid < D && i + 1 < T) g.ctx_d[((long)(i + 1) * B + ab) * D + tid] = sentinel;
+      // the context's input-dropout decision of this step (a Philox call) does not depend on the chain: taken here
+      bool kin = true;
+      if (tid < D && g.rate_in > 0.f) kin = tnt_keep((uint64_t)ab * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, site_in, step);
       // this step's keep bits: in flight while h[i] is polled
       uint32_t mk[NP];
 #pragma unroll
@@ -1135,7 +1138,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       for (int r = tid; r < R; r += WT) { const float ex = expf(es_l[r] - m); es_l[r] = ex; z += ex; }
       z = block_sum_w(z, red_l);
       const float invz = 1.f / z;
-      for (int r = tid; r < R; r += WT) { const float al = es_l[r] * invz; es_l[r] = al; o_alpha[(long)ab * R + r] = al; }
+      for (int r = tid; r < R; r += WT) es_l[r] *= invz;
       __syncthreads();
       // ---- context
       {
@@ -1154,16 +1157,16 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
           float t = 0.f;
 #pragma unroll
           for (int k = 0; k < WW; ++k) t += wred_l[k][tid];
-          o_ctx[(long)ab * D + tid] = t;
-          float td = t;
-          if (g.rate_in > 0.f)
-            td = tnt_keep((uint64_t)ab * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, site_in, step)
-                     ? t * (1.f / (1.f - g.rate_in)) : 0.f;
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the reset of ctx_d[i+1] is in L2 before ctx_d[i] is published
+          const float td = g.rate_in > 0.f ? (kin ? t * (1.f / (1.f - g.rate_in)) : 0.f) : t;
+          // the reset of ctx_d[i+1] (issued at the top of the step, long drained) is in L2 before ctx_d[i] is published;
+          // nothing else of this thread is in flight: the step's other outputs are stored BEHIND the publish
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           o_ctxd[(long)ab * D + tid] = td;
+          o_ctx[(long)ab * D + tid] = t;
         }
       }
-      // hs_l / es_l / wred_l are rewritten next step only behind the barrier that follows the h poll
+      // off the critical path: alpha of this step (es_l is rewritten next step only behind the barrier that follows the h poll)
+      for (int r = tid; r < R; r += WT) o_alpha[(long)ab * R + r] = es_l[r];
     }
     tnt_seq_leave(a.sync, xcc, a.guard_out);
     return;
@@ -1350,6 +1353,21 @@ extern "C" int32_t tnt_lc_seq_fwd_f32(const float* F, const float* P, const floa
 // Hand-offs are data-polling on the sentinel with the reset-before-publish rule of lstm_seq_bwd_kernel<POLL>: every
 // hand-off buffer is a ring of three indexed by the exchange number, the thread that publishes a chunk resets the same
 // chunk of the next buffer first (and drains), a consumer reads every chunk of a producer each step.
+#ifdef TNT_LC_TRACE
+__device__ unsigned long long lc_trace[64];
+extern "C" int32_t tnt_debug_lc_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc_trace), sizeof(lc_trace)) == hipSuccess ? 0 : -1;
+}
+// timestamps are parked in LDS and written out when the workgroup leaves: a global store at a trace point would sit in
+// front of the very s_waitcnt vmcnt(0) it is meant to time
+#define LCT(k) do { if (tid == 0 && rb == 0 && i == T - 3) lct_l[(k)] = wall_clock64(); } while (0)
+#define LCT_DECL __shared__ unsigned long long lct_l[64];
+#define LCT_DUMP(lo, hi) do { if (tid == 0 && rb == 0) for (int q_ = (lo); q_ < (hi); ++q_) lc_trace[q_] = lct_l[q_]; } while (0)
+#else
+#define LCT(k) do {} while (0)
+#define LCT_DECL
+#define LCT_DUMP(lo, hi) do {} while (0)
+#endif
 namespace {
 struct LcSeqBwdArgs {
   AttArgs att;             // F, P, W2, v; qpre_in / alpha_in / dqpre / keep4 point at step 0; dP, dF, dvb: outputs
@@ -1366,20 +1384,24 @@ struct LcSeqBwdArgs {
   int T;
   unsigned* sync; float* guard_out;
 };
-constexpr int LB_DZLD = 68, LB_WCLD = 132;
-constexpr int LB_LDS_FLOATS = 2 * 16 * LB_DZLD + 16 * 256 + 64 * LB_WCLD;            // LSTM role: dz tiles, gather buffer, Wc slice
-constexpr int LB_LDS_BYTES = (LB_LDS_FLOATS > 512 * 32 ? LB_LDS_FLOATS : 512 * 32) * 4 + 16;
+constexpr int LB_DZLD = 68;
+constexpr int LB_RED_FLOATS = 16 * 4 * 16 * 17;                  // gather sums [2][16][256] / context-part tiles [16 waves][4][16][17]
+constexpr int LB_LDS_FLOATS = 2 * 16 * LB_DZLD + LB_RED_FLOATS;  // LSTM role: dz tiles, reduction buffer
+constexpr int LB_W2LD = 65;                                      // row stride of the LSTM role's W2 slice [32][A <= 64]
+constexpr int LB_LSTM_FLOATS = LB_LDS_FLOATS + 32 * LB_W2LD + 16 * 64;             // + W2 slice + the 16 samples' dq
+constexpr int LB_PF_FLOATS = 512 * 64;                           // attention role: P and F rows of the sample, R (A + D) <= this
+constexpr int LB_LDS_BYTES = (LB_LSTM_FLOATS > LB_PF_FLOATS ? LB_LSTM_FLOATS : LB_PF_FLOATS) * 4 + 16;
 
 template <int G4, int NP>
 __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   constexpr int RPP = WT / G4, NTW = 2, NWB = 16;
-  constexpr bool W2L = G4 == 8;
   extern __shared__ __attribute__((aligned(16))) float lb_lds[];
   unsigned* s_slot = reinterpret_cast<unsigned*>(lb_lds + (LB_LDS_BYTES - 16) / 4);
   __shared__ float als[512], das[512];
   __shared__ __attribute__((aligned(16))) float wred[WW][64], wred2[WW][64];
   __shared__ __attribute__((aligned(16))) float qs[64], dcs[64], dq_s[64];
   __shared__ float red_l[WW], dv_acc[64], scr[16 * 64];
+  LCT_DECL
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
   const AttArgs& g = a.att;
@@ -1399,7 +1421,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   const float sentinel = __uint_as_float(LC_SENTINEL);
   const float4 sent4 = make_float4(sentinel, sentinel, sentinel, sentinel);
   const __amdgpu_buffer_rsrc_t x_rsrc = tnt_rsrc(a.xch, (unsigned)(3u * nrb * 32u * 32u * 1024u));
-  const __amdgpu_buffer_rsrc_t dh_rsrc = tnt_rsrc(a.dhx, (unsigned)(3 * BU * 4));
+  const __amdgpu_buffer_rsrc_t dq_rsrc = tnt_rsrc(a.dhx, (unsigned)(3 * B * 64 * 4));          // [3][B][64]: dq of the attention
   const __amdgpu_buffer_rsrc_t pt_rsrc = tnt_rsrc(a.parts, (unsigned)(3u * nrb * 16u * 1024u * 4u));
   auto poll_fail = [&](unsigned& spins) {          // true: give up (error word set here or elsewhere)
     if (++spins > TNT_SEQ_SPIN_LIMIT) {
@@ -1411,33 +1433,29 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
 
   if (ub < 16) {
     // =========================================================== attention role: sample ab
-    float* w2_l = lb_lds;
+    // the sample's P [R][A] and F [R][D] rows: in LDS for all T steps (the accumulators dP / dF take the registers)
+    float* p_l = lb_lds;
+    float* f_l = lb_lds + R * A;
     const int ab = rb * 16 + ub;
     const bool live = ab < B;
     const int c4 = tid % G4, rl = tid / G4;
     const bool cokA = c4 * 4 < A, cokD = c4 * 4 < D;
-    float4 pv[NP], fv[NP], dpa[NP], dfa[NP];
+    float4 dpa[NP], dfa[NP];
     float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float dbv_acc = 0.f;
     if (live) {
-      if (W2L) {
-        for (int e = tid; e < U * A / 4; e += WT) reinterpret_cast<float4*>(w2_l)[e] = reinterpret_cast<const float4*>(g.W2)[e];
-      }
+      for (int e = tid; e < R * A / 4; e += WT)
+        reinterpret_cast<float4*>(p_l)[e] = reinterpret_cast<const float4*>(g.P + (long)ab * R * A)[e];
+      for (int e = tid; e < R * D / 4; e += WT)
+        reinterpret_cast<float4*>(f_l)[e] = reinterpret_cast<const float4*>(g.F + (long)ab * R * D)[e];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        const int r = p * RPP + rl;
-        pv[p] = (cokA && r < R) ? *reinterpret_cast<const float4*>(g.P + ((long)ab * R + r) * A + c4 * 4)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
-        fv[p] = (cokD && r < R) ? *reinterpret_cast<const float4*>(g.F + ((long)ab * R + r) * D + c4 * 4)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
         dpa[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         dfa[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       if (cokA) v4 = *reinterpret_cast<const float4*>(g.v + c4 * 4);
       if (tid < 64) dv_acc[tid] = 0.f;
-      // dh_att chunks of this thread (rows k = rl + m RPP, owned by the lane with c4 == 0): buffer 0 armed
-      if (c4 == 0)
-        for (int k = rl; k < U; k += RPP) a.dhx[(long)ab * U + k] = sentinel;
+      if (tid < A) a.dhx[(long)ab * 64 + tid] = sentinel;         // this thread's element of the dq hand-off: buffer 0 armed
     }
     tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
     const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
@@ -1446,8 +1464,10 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
     if (live) for (int i = T - 1; i >= 0; --i) {
       const int pi = (T - 1 - i) % 3, pn = (pi + 1) % 3;
       const uint32_t site_attn = g.site_attn + (uint32_t)i, site_in = g.site_in + (uint32_t)i;
-      if (c4 == 0 && i > 0)
-        for (int k = rl; k < U; k += RPP) a.dhx[((long)pn * B + ab) * U + k] = sentinel;
+      if (tid < A && i > 0) a.dhx[((long)pn * B + ab) * 64 + tid] = sentinel;
+      LCT(0);
+      bool kin = true;          // input-dropout decision of the context gradient (a Philox call): off the critical path
+      if (tid < D && g.rate_in > 0.f) kin = tnt_keep((uint64_t)ab * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, site_in, step);
       // ---- operands of this step that do not depend on the chain
       for (int r = tid; r < R; r += WT) als[r] = g.alpha_in[((long)i * B + ab) * R + r];
       float qp = 0.f;
@@ -1472,19 +1492,19 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
         }
         if (mine) scr[tid] = v;
       }
+      LCT(1);
       __syncthreads();
       if (tid < 64) {
         float dc = 0.f;
         if (tid < D) {
 #pragma unroll
           for (int p = 0; p < 16; ++p) dc += scr[p * D + tid];
-          if (g.rate_in > 0.f)
-            dc = tnt_keep((uint64_t)ab * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, site_in, step)
-                     ? dc * (1.f / (1.f - g.rate_in)) : 0.f;
+          if (g.rate_in > 0.f) dc = kin ? dc * (1.f / (1.f - g.rate_in)) : 0.f;
         }
         dcs[tid] = dc;
       }
       __syncthreads();
+      LCT(2);
       // ---- dalpha[r] = dctx . F[r];  dF[r] += alpha[r] dctx   (accumulator in registers)
       {
         const float4 dc4 = cokD ? *reinterpret_cast<const float4*>(&dcs[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1493,7 +1513,8 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
           const int r = p * RPP + rl;
           float t = 0.f;
           if (cokD && r < R) {
-            t = dc4.x * fv[p].x + dc4.y * fv[p].y + dc4.z * fv[p].z + dc4.w * fv[p].w;
+            const float4 fv = *reinterpret_cast<const float4*>(f_l + r * D + c4 * 4);
+            t = dc4.x * fv.x + dc4.y * fv.y + dc4.z * fv.z + dc4.w * fv.w;
             const float al = als[r];
             dfa[p].x += al * dc4.x; dfa[p].y += al * dc4.y; dfa[p].z += al * dc4.z; dfa[p].w += al * dc4.w;
           }
@@ -1502,13 +1523,16 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
         }
         __syncthreads();
       }
+      LCT(3);
       float dot = 0.f;
       for (int r = tid; r < R; r += WT) dot += als[r] * das[r];
       dot = block_sum_w(dot, red_l);
       float dbv = 0.f;
       for (int r = tid; r < R; r += WT) { const float de = als[r] * (das[r] - dot); als[r] = de; dbv += de; }
       dbv = block_sum_w(dbv, red_l);
+      LCT(4);
       // ---- through e = s_d . v, dropout, tanh
+      float dqp = 0.f;
       {
         const float4 q4 = cokA ? *reinterpret_cast<const float4*>(&qs[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), dq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1517,7 +1541,8 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
           const int r = p * RPP + rl;
           if (!(cokA && r < R)) continue;
           const long e = ((long)ab * R + r) * A + c4 * 4;
-          const float s0 = tnt_tanh(pv[p].x + q4.x), s1 = tnt_tanh(pv[p].y + q4.y), s2 = tnt_tanh(pv[p].z + q4.z), s3 = tnt_tanh(pv[p].w + q4.w);
+          const float4 pv = *reinterpret_cast<const float4*>(p_l + r * A + c4 * 4);
+          const float s0 = tnt_tanh(pv.x + q4.x), s1 = tnt_tanh(pv.y + q4.y), s2 = tnt_tanh(pv.z + q4.z), s3 = tnt_tanh(pv.w + q4.w);
           bool k[4] = {true, true, true, true};
           if (stored) { k[0] = mk[p] & 1u; k[1] = mk[p] & 2u; k[2] = mk[p] & 4u; k[3] = mk[p] & 8u; }
           else if (g.rate_attn > 0.f) tnt_keep4((uint64_t)e, g.rate_attn, g.seed, site_attn, step, k);
@@ -1537,35 +1562,26 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
         }
         __syncthreads();
         if (tid < 64) {
-          float dqp = 0.f;
           if (tid < A) {
             float tv = 0.f, tq = 0.f;
 #pragma unroll
             for (int k = 0; k < WW; ++k) { tv += wred[k][tid]; tq += wred2[k][tid]; }
             dv_acc[tid] += tv;
             dqp = qp > 0.f ? tq : tq * g.slope;
-            g.dqpre[((long)i * B + ab) * A + tid] = dqp;
           }
           dq_s[tid] = dqp;
         }
         if (tid == 0) dbv_acc += dbv;
         __syncthreads();
       }
-      // ---- dh_att[k] = sum_a dqpre[a] W2[k][a]: thread (c4, rl) takes its 4 columns of rows k = rl + m RPP
-      if (i > 0) {
-        const float4 dq4 = cokA ? *reinterpret_cast<const float4*>(&dq_s[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this thread's resets of the next buffer are in L2 first
-        for (int k = rl; k < U; k += RPP) {
-          float t = 0.f;
-          if (cokA) {
-            const float4 wv = W2L ? *reinterpret_cast<const float4*>(w2_l + k * A + c4 * 4)
-                                  : *reinterpret_cast<const float4*>(g.W2 + (long)k * A + c4 * 4);
-            t = dq4.x * wv.x + dq4.y * wv.y + dq4.z * wv.z + dq4.w * wv.w;
-          }
-          t = adj_sum<G4>(t);
-          if (c4 == 0) a.dhx[((long)pi * B + ab) * U + k] = t;
-        }
+      LCT(5);
+      // ---- hand dq = d(query pre-activation) to the LSTM workgroups: each takes dh_att = dq W2^T for its own 32 units
+      if (i > 0 && tid < A) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this thread's reset of the next buffer's element is in L2 first
+        a.dhx[((long)pi * B + ab) * 64 + tid] = dqp;
       }
+      LCT(6);
+      if (tid < A) g.dqpre[((long)i * B + ab) * A + tid] = dqp;        // behind the publish: its drain is off the critical path
       // als / das / qs / scr are rewritten next step; every reader of this step is behind the barriers above
       __syncthreads();
     }
@@ -1579,6 +1595,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       if (tid < A) g.dvb[(long)ab * (A + 1) + tid] = dv_acc[tid];
       if (tid == 0) g.dvb[(long)ab * (A + 1) + A] = dbv_acc;
     }
+    if (ub == 0) LCT_DUMP(0, 16);
     tnt_seq_leave(a.sync, xcc, a.guard_out);
     return;
   }
@@ -1586,26 +1603,35 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   // ============================================================= LSTM role: unit blocks 2 j and 2 j + 1 of the 16 samples
   const int j = ub - 16;
   float* dzs = lb_lds;                                         // [2][16][LB_DZLD]
-  float* red = lb_lds + 2 * 16 * LB_DZLD;                      // [NWB][256]
-  float* wc_l = red + NWB * 256;                               // [D][LB_WCLD]: Wc[d][32 j .. 32 j + 32][4]
+  float* red = lb_lds + 2 * 16 * LB_DZLD;                      // [2][NWB][256], later [NWB][4][16][17]
+  float* w2s = lb_lds + LB_LDS_FLOATS;                         // [32][LB_W2LD]: W2[32 j .. 32 j + 32][A]
+  float* dq_l = w2s + 32 * LB_W2LD;                            // [16][64]: dq of the 16 samples, this step
   // resident B operands: Ur^T[k][n] = Ur[n][vub * 64 + k], lane (kq, lr) of column tile t holds n = w*32 + t*16 + lr and the
   // contraction indices k = kq*16 + ks (lstm_seq_bwd_kernel's layout)
   float bw[2][NTW][16];
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
+  auto load_bw = [&](int q, const float* Ur) {
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-      const float* src = a.Ur + ((long)(w * 32 + t * 16 + lr) * U + (2 * j + q) * 16) * 4 + kq * 16;
+      const float* src = Ur + ((long)(w * 32 + t * 16 + lr) * U + (2 * j + q) * 16) * 4 + kq * 16;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float4 x = *reinterpret_cast<const float4*>(src + 4 * c);
         bw[q][t][4 * c + 0] = x.x; bw[q][t][4 * c + 1] = x.y; bw[q][t][4 * c + 2] = x.z; bw[q][t][4 * c + 3] = x.w;
       }
     }
-  for (int e = tid; e < D * 32; e += WT) {
-    const int d = e >> 5, c = (e & 31) * 4;
-    *reinterpret_cast<float4*>(wc_l + d * LB_WCLD + c) = *reinterpret_cast<const float4*>(a.Wc + ((long)d * U + j * 32) * 4 + c);
-  }
+  };
+  load_bw(0, a.Ur);
+  load_bw(1, a.Ur);
+  // context-gradient part of this workgroup: part[16 rows][D] = dz[16][128 k] Wc^T[128 k][D] on the MFMAs; wave w owns the
+  // contraction quads 2 w and 2 w + 1 (k = 4 quad + kq), its B operands (Wc[d = 16 t + lr][32 j units][k]) stay in registers
+  const int ntile = (D + 15) / 16;
+  float wcb[2][4];
+#pragma unroll
+  for (int sq = 0; sq < 2; ++sq)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      wcb[sq][t] = (t * 16 + lr < D) ? a.Wc[((long)(t * 16 + lr) * U + j * 32) * 4 + (2 * w + sq) * 4 + kq] : 0.f;
+  for (int e = tid; e < 32 * A; e += WT) w2s[(e / A) * LB_W2LD + e % A] = g.W2[(long)(j * 32 + e / A) * A + e % A];
   for (int e = tid; e < 2 * 16 * LB_DZLD; e += WT) dzs[e] = 0.f;             // rows past B stay zero
   const int eq = tid >> 8, erow = (tid & 255) >> 4, ecol = tid & 15;
   const int eb = rb * 16 + erow, eu = (2 * j + eq) * 16 + ecol;
@@ -1636,6 +1662,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       cval = a.cs[(long)(i + 1) * BU + ee]; cprev = a.cs[(long)i * BU + ee];
       dout_t = a.dout[(long)i * BU + ee];
     }
+    LCT(16);
     if (pmine && i > 0) *pslot(pn) = sentinel;
     float da = 0.f;
     if (i < T - 1) {
@@ -1668,44 +1695,65 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
           *reinterpret_cast<float4*>(xslot(par, w * NTW + t, 2 * j + q)) = make_float4(acc[q][t][0], acc[q][t][1], acc[q][t][2], acc[q][t][3]);
+      LCT(17);
       // ---- gather the 32 partial tiles of each of this workgroup's two blocks: wave w sums sources w and w + 16
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const unsigned base = (unsigned)((((par * nrb + rb) * 32 + (2 * j + q)) * 32) * 1024) + (unsigned)lane * 16u;
-        float4 p0, p1;
+      // (both blocks' loads in flight together; `red` holds [2][NWB][256])
+      {
+        const unsigned base = (unsigned)((((par * nrb + rb) * 32 + 2 * j) * 32) * 1024) + (unsigned)lane * 16u;
+        float4 p[2][2];
         unsigned spins = 0;
         for (;;) {
-          p0 = tnt_ld4_l2(x_rsrc, base + (unsigned)w * 1024u);
-          p1 = tnt_ld4_l2(x_rsrc, base + (unsigned)(w + 16) * 1024u);
-          const bool ok = __float_as_uint(p0.x) != LC_SENTINEL && __float_as_uint(p0.y) != LC_SENTINEL &&
-                          __float_as_uint(p0.z) != LC_SENTINEL && __float_as_uint(p0.w) != LC_SENTINEL &&
-                          __float_as_uint(p1.x) != LC_SENTINEL && __float_as_uint(p1.y) != LC_SENTINEL &&
-                          __float_as_uint(p1.z) != LC_SENTINEL && __float_as_uint(p1.w) != LC_SENTINEL;
+          bool ok = true;
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              p[q][h] = tnt_ld4_l2(x_rsrc, base + (unsigned)q * 32u * 1024u + (unsigned)(w + 16 * h) * 1024u);
+              ok = ok && __float_as_uint(p[q][h].x) != LC_SENTINEL && __float_as_uint(p[q][h].y) != LC_SENTINEL &&
+                   __float_as_uint(p[q][h].z) != LC_SENTINEL && __float_as_uint(p[q][h].w) != LC_SENTINEL;
+            }
           if (__all(ok)) break;
           if (poll_fail(spins)) break;
         }
-        if (q == 1) __syncthreads();                         // block 0's sums have been read
-        *reinterpret_cast<float4*>(red + w * 256 + lane * 4) = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
-        __syncthreads();
-        if (eok && eq == q) {
 #pragma unroll
-          for (int k = 0; k < NWB; ++k) da += red[k * 256 + ridx];
+        for (int q = 0; q < 2; ++q)
+          *reinterpret_cast<float4*>(red + (q * NWB + w) * 256 + lane * 4) =
+              make_float4(p[q][0].x + p[q][1].x, p[q][0].y + p[q][1].y, p[q][0].z + p[q][1].z, p[q][0].w + p[q][1].w);
+        __syncthreads();
+        if (eok) {
+#pragma unroll
+          for (int k = 0; k < NWB; ++k) da += red[(eq * NWB + k) * 256 + ridx];
         }
       }
-      // ---- the attention's query gradient of the step behind (dh_att_{i+1}, buffer par)
+      LCT(18);
+      // ---- the attention's query gradient of the step behind: dh_att_{i+1} = dq_{i+1} W2^T for this workgroup's units
+      // (dq of the 16 samples from buffer par, thread = (row, a))
       {
         float v = 0.f;
         unsigned spins = 0;
+        const int qr = tid / A, qa = tid - qr * A;
+        const bool mine = tid < 16 * A && rb * 16 + qr < B;
         for (;;) {
-          if (eok) v = lc_ld1_l2(dh_rsrc, (unsigned)((((long)par * B + eb) * U + eu) * 4));
-          if (__all(!eok || __float_as_uint(v) != LC_SENTINEL)) break;
+          if (mine) v = lc_ld1_l2(dq_rsrc, (unsigned)((((long)par * B + rb * 16 + qr) * 64 + qa) * 4));
+          if (__all(!mine || __float_as_uint(v) != LC_SENTINEL)) break;
           if (poll_fail(spins)) break;
         }
-        da += v;
+        if (tid < 16 * A) dq_l[qr * 64 + qa] = v;
+        __syncthreads();
+        if (eok) {
+          const float* qrow = dq_l + erow * 64;
+          const float* wrow = w2s + (eq * 16 + ecol) * LB_W2LD;
+          float t = 0.f;
+#pragma unroll 8
+          for (int c = 0; c < A; ++c) t += qrow[c] * wrow[c];
+          da += t;
+        }
       }
+      LCT(19);
     }
     // ---- cell backward (the arithmetic of bwd_epilogue, lstm.hip)
     __syncthreads();          // every wave has read the dz tiles of the step behind (MFMA operands) before they are rewritten
+    float4 dz_keep = make_float4(0.f, 0.f, 0.f, 0.f);
     if (eok) {
       const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
       const float tc = tnt_tanh(cval);
@@ -1715,27 +1763,44 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       const float4 dz4 = make_float4(dc * gg * gi * (1.f - gi), dc * cprev * gf * (1.f - gf), dc * gi * (1.f - gg * gg),
                                      dgo * go * (1.f - go));
       dc_c = dc * gf;
-      *reinterpret_cast<float4*>(a.dz + ((long)i * BU + ee) * 4) = dz4;
+      dz_keep = dz4;
       *reinterpret_cast<float4*>(dzs + (eq * 16 + erow) * LB_DZLD + ecol * 4) = dz4;
     }
     __syncthreads();
+    LCT(20);
     // ---- partial context gradient of this workgroup's 32 units: part[row][d] = sum_c dz[row][c] Wc[d][c]
-    if (pmine) {
-      float t = 0.f;
-      const float* wr = wc_l + pd * LB_WCLD;
+    {
+      float pa[2];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float* zr = dzs + (q * 16 + prow) * LB_DZLD;
+      for (int sq = 0; sq < 2; ++sq) {
+        const int kk = (2 * w + sq) * 4 + kq;                  // 0..127: block kk / 64, column kk % 64 of its dz tile
+        pa[sq] = dzs[((kk >> 6) * 16 + lr) * LB_DZLD + (kk & 63)];
+      }
+      float (*pr)[4][16][17] = reinterpret_cast<float (*)[4][16][17]>(red);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const float4 x = *reinterpret_cast<const float4*>(zr + 4 * c), y = *reinterpret_cast<const float4*>(wr + q * 64 + 4 * c);
-          t += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      for (int t = 0; t < 4; ++t) {
+        if (t < ntile) {
+          floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[0], wcb[0][t], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[1], wcb[1][t], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pr[w][t][kq * 4 + r][lr] = acc[r];
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's reset of the next buffer's element is in L2 first
-      *pslot(pi) = t;
+      __syncthreads();
+      if (pmine) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < NWB; ++k) t += pr[k][pd >> 4][prow][pd & 15];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's reset of the next buffer's element is in L2 first
+        *pslot(pi) = t;
+      }
     }
+    LCT(21);
+    // behind the publish (its drain is off the critical path): this step's dz for the weight-gradient GEMMs after the chain
+    if (eok) *reinterpret_cast<float4*>(a.dz + ((long)i * BU + ee) * 4) = dz_keep;
   }
+  if (ub == 16) LCT_DUMP(16, 32);
   tnt_seq_leave(a.sync, xcc, a.guard_out);
 }
 }  // namespace
@@ -1771,7 +1836,7 @@ extern "C" int32_t tnt_lc_seq_bwd_f32(const float* F, const float* P, const floa
   a.xch = work; a.dhx = work + 3 * nrb * 32 * 32 * 256; a.parts = a.dhx + 3 * (int64_t)B * U;
   a.T = T; a.sync = sync; a.guard_out = guard_out;
   const int g4 = (A <= 32 && D <= 32) ? 8 : 16, np = (R + WT / g4 - 1) / (WT / g4);
-  if (np > 6) return TNT_BADARG(21);
+  if (np > 6 || R * (A + D) > LB_PF_FLOATS) return TNT_BADARG(21);
   void (*kern)(LcSeqBwdArgs) = nullptr;
   if (g4 == 8) kern = np <= 3 ? lc_seq_bwd_kernel<8, 3> : lc_seq_bwd_kernel<8, 6>;
   else kern = np <= 3 ? lc_seq_bwd_kernel<16, 3> : lc_seq_bwd_kernel<16, 6>;

@@ -1,0 +1,22 @@
+"""In-kernel phase timestamps of the persistent backward chain (build csrc with -DTNT_LC_TRACE: make CXXFLAGS+=... ;
+wall_clock64 ticks of 10 ns).  One attention workgroup and one LSTM workgroup of row block 0, step T-3."""
+import ctypes, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import bench
+from masters_thesis_amd import _lib
+dev = torch.device("cuda", 0)
+batch, _ = bench.synth(0, dev)
+m = bench.make_model("attention", dev)
+for _ in range(30): m.train_step(batch)
+torch.cuda.synchronize()
+lib = _lib.load() if hasattr(_lib, "load") else m.be.lib
+buf = (ctypes.c_ulonglong * 64)()
+lib.tnt_debug_lc_trace.argtypes = [ctypes.c_void_p]
+assert lib.tnt_debug_lc_trace(buf) == 0
+t = list(buf)
+base = min(x for x in t if x)
+names = {0: "A top", 1: "A parts in", 2: "A dctx", 3: "A dalpha", 4: "A softmax'", 5: "A scores'", 6: "A dh out",
+         16: "L top", 17: "L pushed", 18: "L gathered", 19: "L dh in", 20: "L cell", 21: "L parts out"}
+for k in sorted(names, key=lambda k: t[k]):
+    print(f"{names[k]:14s} {(t[k] - base) * 10:8d} ns")
