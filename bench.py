@@ -160,6 +160,11 @@ def _work_model(name, a):
     if name in ("tnt_lstm_seq_fwd_f32", "tnt_lstm_seq_bwd_f32"):
         S, Bq, Uq = a[10], a[11], a[12]
         return f"{name} S={S} B={Bq} U={Uq}", 2.0 * S * Bq * 4 * Uq * Uq, 0.0
+    if name in ("tnt_lc_seq_fwd_f32", "tnt_lc_seq_bwd_f32"):       # config 3's chains: LSTM step + attention step, T times
+        Tq, Bq, R, D, A, Uq = a[19:25]
+        lstm = 2.0 * Bq * 4 * Uq * (Uq + D)
+        att = (2.0 * Bq * Uq * A + 2.0 * Bq * R * (A + D)) * (1 if name.endswith("fwd_f32") else 2)
+        return f"{name} T={Tq} B={Bq} R={R} U={Uq}", Tq * (lstm + att), 0.0
     if name == "tnt_dense_dw_skinny_f32":
         Nq, Eq, Bk = a[3], a[4], a[5]
         return f"{name} {Nq}x{Eq}x{Bk}", 2.0 * Nq * Eq * Bk, 4.0 * (Nq * Eq + Bk * Nq + Bk * Eq)
