@@ -974,6 +974,22 @@ __device__ __forceinline__ float lc_ld1_l2(__amdgpu_buffer_rsrc_t rsrc, unsigned
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)byte_off, 0, /*sc1*/ 16));
 }
 
+#ifdef TNT_LC_TRACE
+__device__ unsigned long long lc_trace[64];
+extern "C" int32_t tnt_debug_lc_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc_trace), sizeof(lc_trace)) == hipSuccess ? 0 : -1;
+}
+// timestamps are parked in LDS and written out when the workgroup leaves: a global store at a trace point would sit in
+// front of the very s_waitcnt vmcnt(0) it is meant to time
+#define LCT(k) do { if (tid == 0 && rb == 0 && i == LCT_STEP) lct_l[(k)] = wall_clock64(); } while (0)
+#define LCT_DECL __shared__ unsigned long long lct_l[64];
+#define LCT_STEP 5
+#define LCT_DUMP(lo, hi) do { if (tid == 0 && rb == 0) for (int q_ = (lo); q_ < (hi); ++q_) lc_trace[q_] = lct_l[q_]; } while (0)
+#else
+#define LCT(k) do {} while (0)
+#define LCT_DECL
+#define LCT_DUMP(lo, hi) do {} while (0)
+#endif
 // Role-specialised workgroups.  A group is the 32 workgroups of one XCD and owns one block of 16 samples: slots 0..15 run
 // the ATTENTION of one sample each, slots 16..31 the LSTM step of 32 units each (two 16-unit blocks) for the 16 samples.
 // Everything step-invariant stays on chip for all T steps: an attention workgroup keeps its sample's P and F rows in
@@ -997,6 +1013,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   __shared__ float red_l[WW];
   __shared__ __attribute__((aligned(16))) float wc_l[64 * 32 * 4];                    // [D][32 units][4 gates]
   __shared__ float ctx_l[16 * 64];                                                    // [16 rows][D]
+  LCT_DECL
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
   const int U = a.att.U, B = a.att.B, D = a.att.D, R = a.att.R, A = a.att.A, T = a.T;
@@ -1054,6 +1071,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       float* const o_ctxd = g.ctx_d + (long)i * B * D;
       const uint32_t site_attn = g.site_attn + (uint32_t)i, site_in = g.site_in + (uint32_t)i;
       if (tid < D && i + 1 < T) g.ctx_d[((long)(i + 1) * B + ab) * D + tid] = sentinel;
+      LCT(32);
       // the context's input-dropout decision of this step (a Philox call) does not depend on the chain: taken here
       bool kin = true;
       if (tid < D && g.rate_in > 0.f) kin = tnt_keep((uint64_t)ab * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, site_in, step);
@@ -1081,6 +1099,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
         if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       }
       __syncthreads();
+      LCT(33);
       // ---- q = LeakyReLU(h W2 + b2)   (the arithmetic of att_fwd_body, operand for operand)
       {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1106,6 +1125,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
         }
         __syncthreads();
       }
+      LCT(34);
       // ---- scores
       {
         const float4 q4 = cokA ? *reinterpret_cast<const float4*>(&qs_l[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1130,6 +1150,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
         }
         __syncthreads();
       }
+      LCT(35);
       // ---- softmax over regions
       float m = -INFINITY;
       for (int r = tid; r < R; r += WT) m = fmaxf(m, es_l[r]);
@@ -1140,6 +1161,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       const float invz = 1.f / z;
       for (int r = tid; r < R; r += WT) es_l[r] *= invz;
       __syncthreads();
+      LCT(36);
       // ---- context
       {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1165,9 +1187,11 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
           o_ctx[(long)ab * D + tid] = t;
         }
       }
+      LCT(37);
       // off the critical path: alpha of this step (es_l is rewritten next step only behind the barrier that follows the h poll)
       for (int r = tid; r < R; r += WT) o_alpha[(long)ab * R + r] = es_l[r];
     }
+    if (ub == 0) LCT_DUMP(32, 40);
     tnt_seq_leave(a.sync, xcc, a.guard_out);
     return;
   }
@@ -1203,6 +1227,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   }
   tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
   for (int i = 0; i < T; ++i) {
+    LCT(48);
     if (eok && i + 2 <= T) a.hs[(long)(i + 2) * BU + ee] = sentinel;
     // ---- A fragments = h[i] (this wave's K chunk)
     float av[SS];
@@ -1224,6 +1249,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       }
       if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     }
+    LCT(49);
     // ---- h[i] U for both unit blocks (off the critical path: the attention of step i runs meanwhile)
     float zs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1254,6 +1280,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
         }
       }
     }
+    LCT(50);
     // ---- the attention's context of step i for the 16 samples
     spins = 0;
     for (;;) {
@@ -1272,6 +1299,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     }
     __syncthreads();
+    LCT(51);
     if (eok) {
       float z[4] = {x4.x + zb.x + zs[0], x4.y + zb.y + zs[1], x4.z + zb.z + zs[2], x4.w + zb.w + zs[3]};
       const float* cr = ctx_l + erow * 64;
@@ -1292,9 +1320,11 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       cp = c2;
       if (i + 1 < T) x4 = *reinterpret_cast<const float4*>(a.xz + ((long)(i + 1) * BU + ee) * 4);
     }
+    LCT(52);
     // `red` and ctx_l are rewritten next step only behind barriers that every thread passes after this point
     __syncthreads();
   }
+  if (ub == 16) LCT_DUMP(48, 56);
   tnt_seq_leave(a.sync, xcc, a.guard_out);
 }
 }  // namespace
@@ -1353,21 +1383,6 @@ extern "C" int32_t tnt_lc_seq_fwd_f32(const float* F, const float* P, const floa
 // Hand-offs are data-polling on the sentinel with the reset-before-publish rule of lstm_seq_bwd_kernel<POLL>: every
 // hand-off buffer is a ring of three indexed by the exchange number, the thread that publishes a chunk resets the same
 // chunk of the next buffer first (and drains), a consumer reads every chunk of a producer each step.
-#ifdef TNT_LC_TRACE
-__device__ unsigned long long lc_trace[64];
-extern "C" int32_t tnt_debug_lc_trace(unsigned long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc_trace), sizeof(lc_trace)) == hipSuccess ? 0 : -1;
-}
-// timestamps are parked in LDS and written out when the workgroup leaves: a global store at a trace point would sit in
-// front of the very s_waitcnt vmcnt(0) it is meant to time
-#define LCT(k) do { if (tid == 0 && rb == 0 && i == T - 3) lct_l[(k)] = wall_clock64(); } while (0)
-#define LCT_DECL __shared__ unsigned long long lct_l[64];
-#define LCT_DUMP(lo, hi) do { if (tid == 0 && rb == 0) for (int q_ = (lo); q_ < (hi); ++q_) lc_trace[q_] = lct_l[q_]; } while (0)
-#else
-#define LCT(k) do {} while (0)
-#define LCT_DECL
-#define LCT_DUMP(lo, hi) do {} while (0)
-#endif
 namespace {
 struct LcSeqBwdArgs {
   AttArgs att;             // F, P, W2, v; qpre_in / alpha_in / dqpre / keep4 point at step 0; dP, dF, dvb: outputs

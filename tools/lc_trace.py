@@ -15,8 +15,12 @@ buf = (ctypes.c_ulonglong * 64)()
 lib.tnt_debug_lc_trace.argtypes = [ctypes.c_void_p]
 assert lib.tnt_debug_lc_trace(buf) == 0
 t = list(buf)
-base = min(x for x in t if x)
-names = {0: "A top", 1: "A parts in", 2: "A dctx", 3: "A dalpha", 4: "A softmax'", 5: "A scores'", 6: "A dh out",
-         16: "L top", 17: "L pushed", 18: "L gathered", 19: "L dh in", 20: "L cell", 21: "L parts out"}
-for k in sorted(names, key=lambda k: t[k]):
-    print(f"{names[k]:14s} {(t[k] - base) * 10:8d} ns")
+bwd = {0: "A top", 1: "A parts in", 2: "A dctx", 3: "A dalpha", 4: "A softmax'", 5: "A scores'", 6: "A dq out",
+       16: "L top", 17: "L pushed", 18: "L gathered", 19: "L dh in", 20: "L cell", 21: "L parts out"}
+fwd = {32: "A top", 33: "A h in", 34: "A q", 35: "A scores", 36: "A softmax", 37: "A ctx out",
+       48: "L top", 49: "L h in", 50: "L h U done", 51: "L ctx in", 52: "L h out"}
+for title, names in (("forward chain, step 5", fwd), ("backward chain, step 5", bwd)):
+    base = min(t[k] for k in names if t[k])
+    print(title)
+    for k in sorted(names, key=lambda k: t[k]):
+        print(f"  {names[k]:14s} {(t[k] - base) * 10:8d} ns")
