@@ -435,7 +435,9 @@ struct LstmSeqArgs {
 // guard, model_base.DeviceGuardError) and carries on with what it has, so no wave ever leaves the common control flow.
 constexpr unsigned TNT_SEQ_SENTINEL = 0x7FC5EED5u;
 
-template <bool POLL>
+// RB: batch rows per row block (= per XCD).  16 fills the MFMA's M dimension; 8 spreads B <= 64 over all 8 XCDs (half of every
+// A fragment is zero -- the MFMA count per wave is the same -- but a group exchanges, polls and reduces half as many rows).
+template <bool POLL, int RB>
 __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   constexpr int NWF = 16, SS = 8, CK = 32;
   extern __shared__ __attribute__((aligned(16))) float seq_lds[];       // > 64 KB requested: one workgroup per CU
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   const int kq = lane >> 4, lr = lane & 15;
   const int U = a.U, B = a.B;
   const unsigned xcc = tnt_xcc_id();
-  const int nrb = (B + 15) / 16;
+  const int nrb = (B + RB - 1) / RB;
   if ((int)xcc >= nrb) return;                             // this XCD has no row block
   unsigned* bar = a.sync + xcc * 64;
   unsigned* err = a.sync + TNT_SEQ_ERR;
@@ -456,15 +458,15 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   }
   const int ub = slot.ub, rb = __builtin_amdgcn_readfirstlane((int)xcc);
   const __amdgpu_buffer_rsrc_t hs_rsrc = tnt_rsrc(a.hs, (unsigned)((long)(a.S + 1) * B * U * 4));
-  const int arow = rb * 16 + lr, ucol = ub * 16 + lr;
+  const int arow = (lr < RB) ? rb * RB + lr : B, ucol = ub * 16 + lr;      // rows past RB: zero fragments
   // ---- this wave's weight fragments, resident for the whole sequence
   float4 bv[SS];
 #pragma unroll
   for (int s = 0; s < SS; ++s) bv[s] = ld4g(a.Ur + ((long)(w * CK + (s >> 2) * 16 + kq * 4 + (s & 3)) * U + ucol) * 4, true);
   // ---- epilogue thread state
   const int erow = tid >> 4, ecol = tid & 15;
-  const int eb = rb * 16 + erow, eu = ub * 16 + ecol;
-  const bool eok = tid < 256 && eb < B;
+  const int eb = rb * RB + erow, eu = ub * 16 + ecol;
+  const bool eok = tid < 16 * RB && eb < B;
   const long ee = (long)eb * U + eu;
   const long BU = (long)B * U;
   float4 zb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -585,7 +587,9 @@ constexpr int SB_LDS_BYTES = 82 * 1024;      // uses 16*68 + 16*256 + 4 floats; 
 // buffer (t + 1) % 3 has already seen data that was stored after the reset of every chunk it will poll.  The old content
 // of buffer (t + 1) % 3 (exchange t - 2) was consumed before any workgroup could publish exchange t - 1, which the
 // resetting workgroup has fully gathered.  Buffer 0 is reset at kernel start behind the launch's only flag barrier.
-template <bool POLL>
+// RB: batch rows per row block, as in lstm_seq_fwd_kernel.  With RB = 8 only the half of every partial tile that holds rows < 8
+// (lanes 0..31 in the MFMA's C layout) is pushed and gathered.
+template <bool POLL, int RB>
 __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
   constexpr int NWB = 16, NTW = 2;                            // U = 512 = 16 waves x 2 column tiles x 16 units
   extern __shared__ __attribute__((aligned(16))) float sb_lds[];
@@ -596,7 +600,8 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
   const int kq = lane >> 4, lr = lane & 15;
   const int U = a.U, B = a.B, S = a.S;
   const unsigned xcc = tnt_xcc_id();
-  const int nrb = (B + 15) / 16;
+  const int nrb = (B + RB - 1) / RB;
+  const bool xl = kq * 4 < RB;                               // this lane's rows of a partial tile exist
   if ((int)xcc >= nrb) return;
   unsigned* bar = a.sync + xcc * 64;
   unsigned* err = a.sync + TNT_SEQ_ERR;
@@ -623,8 +628,8 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
   for (int e = tid; e < 16 * SB_DZLD; e += 1024) dzs[e] = 0.f;           // rows past B stay zero
   // ---- epilogue thread state (element (erow, ecol) of the 16 x 16 block), carried across the steps in registers
   const int erow = tid >> 4, ecol = tid & 15;
-  const int eb = rb * 16 + erow, eu = ub * 16 + ecol;
-  const bool eok = tid < 256 && eb < B;
+  const int eb = rb * RB + erow, eu = ub * 16 + ecol;
+  const bool eok = tid < 16 * RB && eb < B;
   const long ee = (long)eb * U + eu;
   const long BU = (long)B * U;
   const int ridx = ((erow >> 2) * 16 + ecol) * 4 + (erow & 3);           // where the MFMA C layout keeps (erow, ecol)
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
   __syncthreads();
   if (POLL) {
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) *reinterpret_cast<float4*>(xslot(0, w * NTW + j)) = sent4;
+    for (int j = 0; j < NTW; ++j) if (xl) *reinterpret_cast<float4*>(xslot(0, w * NTW + j)) = sent4;
     tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
   }
   for (int s = S - 1; s >= 0; --s) {
@@ -656,7 +661,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
       const int xt = S - 2 - s, par = xt % 3;
       if (POLL && s > 0) {         // the next exchange's buffer: reset this thread's chunks before publishing this one's
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) *reinterpret_cast<float4*>(xslot((xt + 1) % 3, w * NTW + j)) = sent4;
+        for (int j = 0; j < NTW; ++j) if (xl) *reinterpret_cast<float4*>(xslot((xt + 1) % 3, w * NTW + j)) = sent4;
       }
       // ---- partial da = dz_tile[16 x 64] @ Ur^T slice[64 x 512]: this wave's 2 column tiles
       float av[16];
@@ -676,17 +681,19 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
       if (POLL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's resets are in L2 first
 #pragma unroll
       for (int j = 0; j < NTW; ++j)
-        *reinterpret_cast<float4*>(xslot(par, w * NTW + j)) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+        if (xl) *reinterpret_cast<float4*>(xslot(par, w * NTW + j)) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
       if (!POLL) tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, S - 1 - s), err);
       // ---- gather the 32 partial tiles of this workgroup's block (sc1 loads: stored by other workgroups): wave w sums
       // sources w and w + 16, the 16 wave sums are combined through LDS in fixed order
       {
         const unsigned base = (unsigned)((((par * nrb + rb) * 32 + ub) * 32) * 1024) + (unsigned)lane * 16u;
-        float4 p0, p1;
+        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
         unsigned spins = 0;
         for (;;) {
-          p0 = tnt_ld4_l2(x_rsrc, base + (unsigned)w * 1024u);
-          p1 = tnt_ld4_l2(x_rsrc, base + (unsigned)(w + 16) * 1024u);
+          if (xl) {
+            p0 = tnt_ld4_l2(x_rsrc, base + (unsigned)w * 1024u);
+            p1 = tnt_ld4_l2(x_rsrc, base + (unsigned)(w + 16) * 1024u);
+          }
           if (!POLL) break;
           const bool ok = __float_as_uint(p0.x) != TNT_SEQ_SENTINEL && __float_as_uint(p0.y) != TNT_SEQ_SENTINEL &&
                           __float_as_uint(p0.z) != TNT_SEQ_SENTINEL && __float_as_uint(p0.w) != TNT_SEQ_SENTINEL &&
@@ -925,8 +932,9 @@ extern "C" int32_t tnt_lstm_seq_supported(int32_t B, int32_t U) {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     if (prop.multiProcessorCount != 256) return 0;
-    if (hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_LDS_BYTES) != hipSuccess) return 0;
-    if (hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_LDS_BYTES) != hipSuccess) return 0;
+    if (hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_LDS_BYTES) != hipSuccess) return 0;
+    if (hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_LDS_BYTES) != hipSuccess) return 0;
+    if (hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_LDS_BYTES) != hipSuccess) return 0;
     if (hipFuncSetAttribute((const void*)xcc_census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_LDS_BYTES) != hipSuccess) return 0;
     unsigned* hist = nullptr;
     if (hipMalloc(&hist, 64) != hipSuccess) return 0;
@@ -957,8 +965,10 @@ extern "C" int32_t tnt_lstm_seq_fwd_f32(const float* xz, float* hs, float* cs, c
   a.xz = xz; a.hs = hs; a.cs = cs; a.Ur = Ur; a.zbias = xz_bias; a.mask_ids = mask_ids; a.out = out; a.gates = gates;
   a.S = S; a.B = B; a.U = U; a.mask_T = mask_T; a.mask_s0 = mask_s0; a.sync = sync; a.guard_out = guard_out;
   static const bool flags_only = getenv("TNT_SEQ_FLAGS") && atoi(getenv("TNT_SEQ_FLAGS")) != 0;       // A/B switch
-  if (flags_only) hipLaunchKernelGGL(lstm_seq_fwd_kernel<false>, dim3(256), dim3(1024), SEQ_LDS_BYTES, s, a);
-  else hipLaunchKernelGGL(lstm_seq_fwd_kernel<true>, dim3(256), dim3(1024), SEQ_LDS_BYTES, s, a);
+  static const bool rb8 = !(getenv("TNT_SEQ_RB16") && atoi(getenv("TNT_SEQ_RB16")) != 0);             // A/B switch: 16-row blocks
+  if (flags_only) hipLaunchKernelGGL((lstm_seq_fwd_kernel<false, 16>), dim3(256), dim3(1024), SEQ_LDS_BYTES, s, a);
+  else if (rb8 && B <= 64) hipLaunchKernelGGL((lstm_seq_fwd_kernel<true, 8>), dim3(256), dim3(1024), SEQ_LDS_BYTES, s, a);
+  else hipLaunchKernelGGL((lstm_seq_fwd_kernel<true, 16>), dim3(256), dim3(1024), SEQ_LDS_BYTES, s, a);
   TNT_LAUNCH_CHECK();
   return 0;
 }
@@ -974,8 +984,9 @@ extern "C" int32_t tnt_lstm_seq_bwd_f32(const float* Ur, const float* dout_seq, 
   if (!tnt_aligned16(work) || !tnt_aligned16(Ur) || !tnt_aligned16(gates) || !tnt_aligned16(dz)) return TNT_BADARG(1);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS_BYTES) != hipSuccess)
       return TNT_BADARG(90);
     attr_set = true;
   }
@@ -983,15 +994,20 @@ extern "C" int32_t tnt_lstm_seq_bwd_f32(const float* Ur, const float* dout_seq, 
   a.Ur = Ur; a.dout_seq = dout_seq; a.mask_ids = mask_ids; a.gates = gates; a.cs = cs; a.dz = dz; a.xch = work;
   a.sync = sync; a.guard_out = guard_out; a.S = S; a.B = B; a.U = U; a.mask_T = mask_T; a.mask_s0 = mask_s0;
   static const bool flags_only = getenv("TNT_SEQ_FLAGS") && atoi(getenv("TNT_SEQ_FLAGS")) != 0;       // A/B switch
-  if (flags_only) hipLaunchKernelGGL(lstm_seq_bwd_kernel<false>, dim3(256), dim3(1024), SB_LDS_BYTES, tnt_stream(stream), a);
-  else hipLaunchKernelGGL(lstm_seq_bwd_kernel<true>, dim3(256), dim3(1024), SB_LDS_BYTES, tnt_stream(stream), a);
+  static const bool rb8 = !(getenv("TNT_SEQ_RB16") && atoi(getenv("TNT_SEQ_RB16")) != 0);             // A/B switch: 16-row blocks
+  if (flags_only) hipLaunchKernelGGL((lstm_seq_bwd_kernel<false, 16>), dim3(256), dim3(1024), SB_LDS_BYTES, tnt_stream(stream), a);
+  else if (rb8 && B <= 64) hipLaunchKernelGGL((lstm_seq_bwd_kernel<true, 8>), dim3(256), dim3(1024), SB_LDS_BYTES, tnt_stream(stream), a);
+  else hipLaunchKernelGGL((lstm_seq_bwd_kernel<true, 16>), dim3(256), dim3(1024), SB_LDS_BYTES, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int32_t tnt_lstm_seq_bwd_work_floats(int32_t B, int32_t U) {
   (void)U;
-  return 3 * ((B + 15) / 16) * 32 * 32 * 256;       // ring of three exchange buffers
+  // ring of three exchange buffers, one [32 dest][32 src] set of 1 KB tiles per row block; row blocks of 8 rows when the
+  // batch fits the 8 XCDs that way
+  const int nrb = B <= 64 ? (B + 7) / 8 : (B + 15) / 16;
+  return 3 * nrb * 32 * 32 * 256;
 }
 
 extern "C" int32_t tnt_ln_lstm_cell_fwd_f32(const float* zk, const float* zr, const float* bias, const float* c_prev,

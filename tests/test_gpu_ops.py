@@ -1008,10 +1008,10 @@ def test_lstm_seq_sync_state_after_graph_replays(be):
     torch.cuda.synchronize()
     st = sync.cpu().numpy().astype(np.int64)
     assert st[1024] == 0 and float(guard) == 0.0
-    nrb = (B + 15) // 16
     epochs = st[512 + 2:1024:64]
     active = np.nonzero(epochs)[0]
-    assert len(active) == nrb and (epochs[active] == 1 + reps).all(), epochs
+    # row blocks of 8 rows on all 8 XCDs when the batch fits that way (B <= 64), else of 16 rows
+    assert len(active) in ((B + 15) // 16, (B + 7) // 8) and (epochs[active] == 1 + reps).all(), epochs
     assert (st[512:1024:64] == 0).all() and (st[513:1024:64] == 0).all(), "ticket / exit counters not re-armed"
     for x in active:
         flags = st[x * 64:x * 64 + 32]
