@@ -998,7 +998,9 @@ extern "C" int32_t tnt_debug_lc_trace(unsigned long long* out) {
 // workgroups already multiply h[i] with the recurrent kernel (the bulk of their step, 512 of the 544 input columns); only
 // the 32-column context term and the gate math wait for the attention's ctx_d[i].  Hand-offs are data-polling on the
 // sentinel (h and ctx_d are their own flags, reset-before-publish by the owning thread, as in lstm_seq_fwd_kernel).
-template <int G4, int NP>
+// RB: samples per row block (= per XCD): 16, or 8 to spread B <= 64 over all 8 XCDs (then 8 attention workgroups per XCD;
+// the LSTM workgroups' A fragments are half empty, but a group hands over, polls and reduces half as many rows).
+template <int G4, int NP, int RB>
 __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   constexpr int NWF = 16, SS = 8, CK = 32, RPP = WT / G4;
   constexpr bool W2L = G4 == 8;                         // W2 [U][A <= 32] fits the dynamic LDS block
@@ -1018,7 +1020,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   const int kq = lane >> 4, lr = lane & 15;
   const int U = a.att.U, B = a.att.B, D = a.att.D, R = a.att.R, A = a.att.A, T = a.T;
   const unsigned xcc = tnt_xcc_id();
-  const int nrb = (B + 15) / 16;
+  const int nrb = (B + RB - 1) / RB;
   if ((int)xcc >= nrb) return;
   unsigned* bar = a.sync + xcc * 64;
   unsigned* err = a.sync + TNT_SEQ_ERR;
@@ -1036,8 +1038,8 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
 
   if (ub < 16) {
     // =========================================================== attention role: sample ab
-    const int ab = rb * 16 + ub;
-    const bool live = ab < B;
+    const int ab = rb * RB + ub;
+    const bool live = ub < RB && ab < B;
     const int c4 = tid % G4, rl = tid / G4;
     const bool cokA = c4 * 4 < A, cokD = c4 * 4 < D;
     float4 pv[NP], fv[NP];
@@ -1198,7 +1200,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
 
   // ============================================================= LSTM role: units [32 j, 32 j + 32) of the 16 samples
   const int j = ub - 16;
-  const int arow = rb * 16 + lr;
+  const int arow = lr < RB ? rb * RB + lr : B;               // rows past RB: zero fragments
   // recurrent-kernel fragments of both 16-unit blocks: resident for all T steps
   float4 bv[2][SS];
 #pragma unroll
@@ -1214,8 +1216,8 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   }
   // epilogue threads: (unit block q, row, unit)
   const int eq = tid >> 8, erow = (tid & 255) >> 4, ecol = tid & 15;
-  const int eb = rb * 16 + erow, eu = (2 * j + eq) * 16 + ecol;
-  const bool eok = tid < 512 && eb < B;
+  const int eb = rb * RB + erow, eu = (2 * j + eq) * 16 + ecol;
+  const bool eok = tid < 512 && erow < RB && eb < B;
   const long ee = (long)eb * U + eu;
   float4 zb = make_float4(0.f, 0.f, 0.f, 0.f), x4 = zb;
   float cp = 0.f;
@@ -1287,7 +1289,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       bool ok = true;
       for (int e = tid; e < 16 * D; e += WT) {
         const int r = e / D, d = e - r * D;
-        const float v = rb * 16 + r < B ? lc_ld1_l2(cx_rsrc, (unsigned)((((long)i * B + rb * 16 + r) * D + d) * 4)) : 0.f;
+        const float v = (r < RB && rb * RB + r < B) ? lc_ld1_l2(cx_rsrc, (unsigned)((((long)i * B + rb * RB + r) * D + d) * 4)) : 0.f;
         ctx_l[r * 64 + d] = v;
         ok = ok && __float_as_uint(v) != LC_SENTINEL;
       }
@@ -1353,8 +1355,14 @@ extern "C" int32_t tnt_lc_seq_fwd_f32(const float* F, const float* P, const floa
   // row passes of the attention phase held in registers: as few as R needs (the LSTM weights are resident next to them)
   const int g4 = (A <= 32 && D <= 32) ? 8 : 16, np = (R + WT / g4 - 1) / (WT / g4);
   void (*kern)(LcSeqArgs) = nullptr;
-  if (g4 == 8) kern = np <= 3 ? lc_seq_fwd_kernel<8, 3> : lc_seq_fwd_kernel<8, 6>;
-  else kern = np <= 3 ? lc_seq_fwd_kernel<16, 3> : lc_seq_fwd_kernel<16, 6>;
+  static const bool rb16 = getenv("TNT_SEQ_RB16") && atoi(getenv("TNT_SEQ_RB16")) != 0;               // A/B switch
+  if (B <= 64 && !rb16) {
+    if (g4 == 8) kern = np <= 3 ? lc_seq_fwd_kernel<8, 3, 8> : lc_seq_fwd_kernel<8, 6, 8>;
+    else kern = np <= 3 ? lc_seq_fwd_kernel<16, 3, 8> : lc_seq_fwd_kernel<16, 6, 8>;
+  } else {
+    if (g4 == 8) kern = np <= 3 ? lc_seq_fwd_kernel<8, 3, 16> : lc_seq_fwd_kernel<8, 6, 16>;
+    else kern = np <= 3 ? lc_seq_fwd_kernel<16, 3, 16> : lc_seq_fwd_kernel<16, 6, 16>;
+  }
   if (np > 6) return TNT_BADARG(21);
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LC_SEQ_LDS_BYTES) != hipSuccess)
     return TNT_BADARG(90);
@@ -1407,7 +1415,7 @@ constexpr int LB_LSTM_FLOATS = LB_LDS_FLOATS + 32 * LB_W2LD + 16 * 64;          
 constexpr int LB_PF_FLOATS = 512 * 64;                           // attention role: P and F rows of the sample, R (A + D) <= this
 constexpr int LB_LDS_BYTES = (LB_LSTM_FLOATS > LB_PF_FLOATS ? LB_LSTM_FLOATS : LB_PF_FLOATS) * 4 + 16;
 
-template <int G4, int NP>
+template <int G4, int NP, int RB>
 __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   constexpr int RPP = WT / G4, NTW = 2, NWB = 16;
   extern __shared__ __attribute__((aligned(16))) float lb_lds[];
@@ -1422,7 +1430,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   const AttArgs& g = a.att;
   const int U = g.U, B = g.B, D = g.D, R = g.R, A = g.A, T = a.T;
   const unsigned xcc = tnt_xcc_id();
-  const int nrb = (B + 15) / 16;
+  const int nrb = (B + RB - 1) / RB;
   if ((int)xcc >= nrb) return;
   unsigned* bar = a.sync + xcc * 64;
   unsigned* err = a.sync + TNT_SEQ_ERR;
@@ -1451,8 +1459,8 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
     // the sample's P [R][A] and F [R][D] rows: in LDS for all T steps (the accumulators dP / dF take the registers)
     float* p_l = lb_lds;
     float* f_l = lb_lds + R * A;
-    const int ab = rb * 16 + ub;
-    const bool live = ab < B;
+    const int ab = rb * RB + ub;
+    const bool live = ub < RB && ab < B;
     const int c4 = tid % G4, rl = tid / G4;
     const bool cokA = c4 * 4 < A, cokD = c4 * 4 < D;
     float4 dpa[NP], dfa[NP];
@@ -1649,8 +1657,8 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   for (int e = tid; e < 32 * A; e += WT) w2s[(e / A) * LB_W2LD + e % A] = g.W2[(long)(j * 32 + e / A) * A + e % A];
   for (int e = tid; e < 2 * 16 * LB_DZLD; e += WT) dzs[e] = 0.f;             // rows past B stay zero
   const int eq = tid >> 8, erow = (tid & 255) >> 4, ecol = tid & 15;
-  const int eb = rb * 16 + erow, eu = (2 * j + eq) * 16 + ecol;
-  const bool eok = tid < 512 && eb < B;
+  const int eb = rb * RB + erow, eu = (2 * j + eq) * 16 + ecol;
+  const bool eok = tid < 512 && erow < RB && eb < B;
   const long ee = (long)eb * U + eu;
   const int ridx = ((erow >> 2) * 16 + ecol) * 4 + (erow & 3);
   float dc_c = 0.f;
@@ -1747,9 +1755,9 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
         float v = 0.f;
         unsigned spins = 0;
         const int qr = tid / A, qa = tid - qr * A;
-        const bool mine = tid < 16 * A && rb * 16 + qr < B;
+        const bool mine = tid < 16 * A && qr < RB && rb * RB + qr < B;
         for (;;) {
-          if (mine) v = lc_ld1_l2(dq_rsrc, (unsigned)((((long)par * B + rb * 16 + qr) * 64 + qa) * 4));
+          if (mine) v = lc_ld1_l2(dq_rsrc, (unsigned)((((long)par * B + rb * RB + qr) * 64 + qa) * 4));
           if (__all(!mine || __float_as_uint(v) != LC_SENTINEL)) break;
           if (poll_fail(spins)) break;
         }
@@ -1822,7 +1830,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
 
 extern "C" int32_t tnt_lc_seq_bwd_work_floats(int32_t B, int32_t U) {
   if (B <= 0 || B > 128 || U != 512) return 0;
-  const int nrb = (B + 15) / 16;
+  const int nrb = B <= 64 ? (B + 7) / 8 : (B + 15) / 16;     // row blocks of 8 samples when the batch fits the 8 XCDs that way
   return 3 * nrb * 32 * 32 * 256 + 3 * B * U + 3 * nrb * 16 * 16 * 64;
 }
 
@@ -1846,15 +1854,22 @@ extern "C" int32_t tnt_lc_seq_bwd_f32(const float* F, const float* P, const floa
   g.dqpre = dqpre; g.B = B; g.R = R; g.D = D; g.A = A; g.U = U; g.in_lwidth = in_lwidth; g.slope = slope;
   g.rate_attn = rate_attn; g.rate_in = rate_in; g.seed = seed; g.site_attn = site_attn0; g.site_in = site_in0; g.step = 0;
   g.step_dev = step_dev; g.alpha_mse = alpha_mse_coef;
-  const int64_t nrb = (B + 15) / 16;
+  static const bool rb16 = getenv("TNT_SEQ_RB16") && atoi(getenv("TNT_SEQ_RB16")) != 0;               // A/B switch
+  const bool rb8 = B <= 64 && !rb16;
+  const int64_t nrb = rb8 ? (B + 7) / 8 : (B + 15) / 16;
   a.keep_stride = keep_stride; a.Ur = Ur; a.Wc = Wc; a.dout = dout; a.gates = gates; a.cs = cs; a.dz = dz;
   a.xch = work; a.dhx = work + 3 * nrb * 32 * 32 * 256; a.parts = a.dhx + 3 * (int64_t)B * U;
   a.T = T; a.sync = sync; a.guard_out = guard_out;
   const int g4 = (A <= 32 && D <= 32) ? 8 : 16, np = (R + WT / g4 - 1) / (WT / g4);
   if (np > 6 || R * (A + D) > LB_PF_FLOATS) return TNT_BADARG(21);
   void (*kern)(LcSeqBwdArgs) = nullptr;
-  if (g4 == 8) kern = np <= 3 ? lc_seq_bwd_kernel<8, 3> : lc_seq_bwd_kernel<8, 6>;
-  else kern = np <= 3 ? lc_seq_bwd_kernel<16, 3> : lc_seq_bwd_kernel<16, 6>;
+  if (rb8) {
+    if (g4 == 8) kern = np <= 3 ? lc_seq_bwd_kernel<8, 3, 8> : lc_seq_bwd_kernel<8, 6, 8>;
+    else kern = np <= 3 ? lc_seq_bwd_kernel<16, 3, 8> : lc_seq_bwd_kernel<16, 6, 8>;
+  } else {
+    if (g4 == 8) kern = np <= 3 ? lc_seq_bwd_kernel<8, 3, 16> : lc_seq_bwd_kernel<8, 6, 16>;
+    else kern = np <= 3 ? lc_seq_bwd_kernel<16, 3, 16> : lc_seq_bwd_kernel<16, 6, 16>;
+  }
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_BYTES) != hipSuccess)
     return TNT_BADARG(90);
   hipLaunchKernelGGL(kern, dim3(256), dim3(1024), LB_LDS_BYTES, tnt_stream(stream), a);
