@@ -551,6 +551,16 @@ int32_t tnt_adam_f32(float* theta, float* m, float* v, const float* grad,
                      const float* seg_l2, const float* sq, const float* sq_override,
                      int32_t nspan, float lr_t, const float* lr_t_dev, float beta1, float beta2,
                      float eps, float clipnorm, const uint32_t* guard, void* stream);
+/* tnt_adam_f32 that also files the step's metrics vector in a ring (one wave of the launch, before the guard check): met
+ * [nmet <= 62] is copied to row (*ring_t % ring_rows) of ring [ring_rows][nmet + 1], column nmet = the launch number *ring_t
+ * (low 24 bits, as a float), and *ring_t advances -- the host reads that row when it wants the step's metrics instead of
+ * copying `met` behind every step (a 5 us launch on a 0.55 ms step).  ring NULL = tnt_adam_f32. */
+int32_t tnt_adam_ring_f32(float* theta, float* m, float* v, const float* grad,
+                     const int32_t* span_seg, const int64_t* span_off, const int32_t* span_len,
+                     const float* seg_l2, const float* sq, const float* sq_override,
+                     int32_t nspan, float lr_t, const float* lr_t_dev, float beta1, float beta2,
+                     float eps, float clipnorm, const uint32_t* guard, const float* met, int32_t nmet, float* ring,
+                          int32_t ring_rows, uint32_t* ring_t, void* stream);
 int32_t tnt_sgd_f32(float* theta, float* mom, const float* grad, const int32_t* span_seg,
                     const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
                     const float* sq, const float* sq_override, int32_t nspan, float lr,

@@ -101,6 +101,7 @@ SIGNATURES = {
     "tnt_step_finalize_f32": [P, P, P, P, P, P, I32, P, P, P, P, I32, F32, P, P, I32, P, P, I32, P, P, I32, F32, P, P, P, P,
                               F32, F32, P, P],
     "tnt_adam_f32": [P, P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, F32, F32, P, P],
+    "tnt_adam_ring_f32": [P, P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, F32, F32, P, P, I32, P, I32, P, P],
     "tnt_sgd_f32": [P, P, P, P, P, P, P, P, P, I32, F32, P, F32, F32, P, P],
     "tnt_agc_f32": [P, P, P, P, P, P, P, I32, P, P, I32, I32, I32, P, P, F32, F32, P],
     "tnt_colsq_f32": [P, P, I32, I32, I32, P],

@@ -79,12 +79,23 @@ __device__ __forceinline__ float clip_scale(const float* sq, const float* sq_ove
   return clipnorm / fmaxf(sqrtf(q), clipnorm);
 }
 
+struct MetRing { const float* met; float* ring; uint32_t* ring_t; int nmet, rows; };
+
 __global__ __launch_bounds__(256) void adam_kernel(float* theta, float* m, float* v, const float* grad, SpanTab t,
                                                    const float* sq, const float* sq_override, int nspan, float lr_t,
                                                    const float* lr_t_dev, float b1, float b2, float eps,
-                                                   float clipnorm, const uint32_t* guard) {
+                                                   float clipnorm, const uint32_t* guard, MetRing r) {
   const int sp = blockIdx.x;
   if (sp >= nspan) return;
+  // Metrics ring (one wave of workgroup 0, off every critical path: the metrics are final before this launch starts): the
+  // step's metrics vector met[0..nmet) goes to row (*ring_t % rows) of `ring` with the launch number in column nmet, and
+  // *ring_t advances -- the host reads the row when it wants the numbers instead of cloning `met` behind every step.
+  if (r.ring && sp == 0 && (int)threadIdx.x <= r.nmet) {
+    const uint32_t rt = r.ring_t[0];                       // nmet + 1 <= 64 lanes: one wave, the load precedes the store
+    float* row = r.ring + (long)(rt % (uint32_t)r.rows) * (r.nmet + 1);
+    if ((int)threadIdx.x < r.nmet) row[threadIdx.x] = r.met[threadIdx.x];
+    else { row[r.nmet] = (float)(rt & 0xFFFFFFu); r.ring_t[0] = rt + 1u; }
+  }
   if (guard && guard[0] != 0u) return;       // the step's forward pass was invalid: leave the model untouched
   if (lr_t_dev) lr_t = lr_t_dev[0];
   const long off = t.span_off[sp];
@@ -409,16 +420,26 @@ extern "C" int32_t tnt_l2_total_f32(const float* wsq, const float* seg_l2, int32
   return 0;
 }
 
+extern "C" int32_t tnt_adam_ring_f32(float* theta, float* m, float* v, const float* grad, const int32_t* span_seg,
+                                     const int64_t* span_off, const int32_t* span_len, const float* seg_l2, const float* sq,
+                                     const float* sq_override, int32_t nspan, float lr_t, const float* lr_t_dev, float beta1,
+                                     float beta2, float eps, float clipnorm, const uint32_t* guard, const float* met,
+                                     int32_t nmet, float* ring, int32_t ring_rows, uint32_t* ring_t, void* stream) {
+  if (nspan <= 0) return ring ? TNT_BADARG(11) : 0;
+  if (ring != nullptr && (met == nullptr || ring_t == nullptr || nmet <= 0 || nmet > 62 || ring_rows <= 0)) return TNT_BADARG(20);
+  SpanTab t{span_seg, span_off, span_len, nullptr, seg_l2};
+  hipLaunchKernelGGL(adam_kernel, dim3(nspan), dim3(256), 0, tnt_stream(stream), theta, m, v, grad, t, sq, sq_override,
+                     nspan, lr_t, lr_t_dev, beta1, beta2, eps, clipnorm, guard, MetRing{met, ring, ring_t, nmet, ring_rows});
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int32_t tnt_adam_f32(float* theta, float* m, float* v, const float* grad, const int32_t* span_seg,
                                 const int64_t* span_off, const int32_t* span_len, const float* seg_l2, const float* sq,
                                 const float* sq_override, int32_t nspan, float lr_t, const float* lr_t_dev, float beta1,
                                 float beta2, float eps, float clipnorm, const uint32_t* guard, void* stream) {
-  if (nspan <= 0) return 0;
-  SpanTab t{span_seg, span_off, span_len, nullptr, seg_l2};
-  hipLaunchKernelGGL(adam_kernel, dim3(nspan), dim3(256), 0, tnt_stream(stream), theta, m, v, grad, t, sq, sq_override,
-                     nspan, lr_t, lr_t_dev, beta1, beta2, eps, clipnorm, guard);
-  TNT_LAUNCH_CHECK();
-  return 0;
+  return tnt_adam_ring_f32(theta, m, v, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr_t, lr_t_dev, beta1,
+                           beta2, eps, clipnorm, guard, nullptr, 0, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int32_t tnt_sgd_f32(float* theta, float* mom, const float* grad, const int32_t* span_seg,

@@ -260,14 +260,15 @@ class NICfc(_DenseNIC):
             raise RuntimeError("compile() the model before train_step")
         B, T = self._stage_batch(data[0], data[1], self.N)
         self._sync_lr()
+        ring = False
         if self.grad_sync is None:
-            self._run_captured(("train", B, T), lambda: self._train_and_update_graph(B, T))
+            ring = self._run_step(self._run_captured, ("train", B, T), lambda: self._train_and_update_graph(B, T))
         else:
             self._run_captured(("train_fb", B, T), lambda: self._train_graph(B, T))
             self.grad_sync(self)
             self._run_captured(("train_up", B, T), self._update_graph)
         self.optimizer.iterations += 1
-        m = self.met.clone()
+        m = self._met_snapshot(ring)
         return self._metrics_from(m, loss=0, L2=2, accuracy=1, lr=self.lr_dev.clone()[0])
 
     def __call__(self, data, training=False):

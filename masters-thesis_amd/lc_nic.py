@@ -844,8 +844,8 @@ class NIC(ModelBase):
             self._defer_sum2 = False
         self._update_fused(self.met[2:3])
 
-    def _metrics(self, with_lr):
-        m = self.met.clone()
+    def _metrics(self, with_lr, ring=False):
+        m = self._met_snapshot(ring)
         if self.S == 1:
             out = Metrics(loss=m[0], L2=m[2], accuracy=m[1], attention=m[3])
         else:       # keys of ms2_NIC.train_step's return dict (ms2_NIC.py:366-374), A, B, C ... per subject
@@ -855,6 +855,7 @@ class NIC(ModelBase):
                 out[f"loss{tag}"], out[f"accuracy{tag}"], out[f"attention{tag}"] = m[k], m[k + 1], m[k + 2]
         if with_lr:
             out["lr"] = torch.tensor(self._lr_host, dtype=torch.float32)      # host-set (ModelBase._sync_lr): no device copy
+        out._ring = self.__dict__.get("_last_ring")
         return out.guarded(self, m[self.GUARD]) if self.__dict__.get("_seq_lstm") else out
 
     def train_step(self, data):
@@ -863,8 +864,9 @@ class NIC(ModelBase):
             raise RuntimeError("compile() the model before train_step")
         B, T = self._stage_batch(data[0], data[1], self.n_in)
         self._sync_lr()
+        ring = False
         if self.grad_sync is None:
-            self._run_captured(("train", B, T), lambda: self._train_and_update_graph(B, T))
+            ring = self._run_step(self._run_captured, ("train", B, T), lambda: self._train_and_update_graph(B, T))
         elif getattr(self.grad_sync, "pipelined", False):
             self.grad_sync.step(self, B, T)
         else:
@@ -872,7 +874,7 @@ class NIC(ModelBase):
             self.grad_sync(self)
             self._run_captured(("train_up", B, T), self._update_graph)
         self.optimizer.iterations += 1
-        return self._metrics(True)
+        return self._metrics(True, ring)
 
     _alpha_mse = 0.0        # coefficient of the attention-MSE gradient in the backward chain (train_step_sam's first pass)
 

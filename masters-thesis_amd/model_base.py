@@ -62,7 +62,7 @@ class Metrics(dict):
     """train_step/test_step result: values are 0-d device tensors (no host sync until read).  The step's device guard
     word (ModelBase.GUARD slot of ``met``, copied in the same clone as the metrics) rides along: reading the metrics
     raises DeviceGuardError when it is set, so an invalid step cannot go unnoticed -- and costs no extra sync."""
-    _guard = _model = None
+    _guard = _model = _ring = None
 
     def guarded(self, model, word):
         self._model, self._guard = model, word
@@ -70,6 +70,11 @@ class Metrics(dict):
 
     def as_floats(self):
         out = {k: float(v) for k, v in self.items()}
+        if self._ring is not None:        # values are views of a metrics-ring row (ModelBase._met_snapshot): still this step's?
+            row, tag = self._ring
+            if int(float(row[-1])) != tag:
+                raise RuntimeError(f"these metrics were read more than {ModelBase.METRIC_RING} training steps after their step: "
+                                   "the ring row has been reused (read metrics earlier, or set model.metric_ring = False)")
         if self._guard is not None and float(self._guard) != 0.0:
             self._model._on_guard_trip(int(float(self._guard)))
         return out
@@ -77,6 +82,7 @@ class Metrics(dict):
 
 class ModelBase:
     GUARD = 7       # slot of ``met`` that carries the device guard word of the step (see Metrics)
+    METRIC_RING = 1024      # rows of the metrics ring: a step's Metrics stay readable for this many further training steps
     # subclasses fill: self.layers_spec = OrderedDict(layer -> [weight names]),
     # self.keras_shapes = {full name: keras shape}
     def __init__(self, device=None, seed=42, use_graph=True, grad_sync=None):
@@ -194,7 +200,7 @@ class ModelBase:
         if adam:
             be.adam(a.theta, self.opt_m, self.opt_v, a.grad, sp.span_seg[s1:], sp.span_off[s1:], sp.span_len[s1:], a.seg_l2,
                     a.sq, a.sq_override, sp.nspan - s1, 0.0, self.lr_t_dev, opt.beta_1, opt.beta_2, opt.epsilon, clip,
-                    guard=gd)
+                    guard=gd, **(self._ring_args() if sp.nspan - s1 > 0 else {}))
             if enc is not None:
                 sl = slice(e.off, e.off + e.size)
                 be.dense_dw_adam(x, dpre, a.theta[sl], self.opt_m[sl], self.opt_v[sl], e.l2, a.sq[e.seg:e.seg + 1],
@@ -593,9 +599,50 @@ class ModelBase:
         """Where the persistent kernel reports its error code for the host: slot GUARD of the metrics buffer."""
         return self.met[self.GUARD:self.GUARD + 1]
 
+    def _run_step(self, run, key, fn):
+        """``run(key, fn)`` (_run_captured / _run_planned) for a training step; returns whether that step's finalize launch
+        filed the metrics vector in the ring (known when ``fn`` actually runs -- eager or under capture --, remembered per
+        key for the replays)."""
+        graphs = self.use_graph and self.device.type == "cuda"
+        st = self._graphs.get(key) if graphs else None
+        executed = (not graphs) or st is None or (isinstance(st, str) and st == "warm")
+        self._ring_hit = False
+        run(key, fn)
+        keys = self.__dict__.setdefault("_ring_keys", set())
+        if executed or self._ring_hit:
+            (keys.add if self._ring_hit else keys.discard)(key)
+        return key in keys
+
+    def _met_snapshot(self, ring=False):
+        """This step's metrics vector: the row the step's Adam launch copied it to (``ring``: fused single-process step, no
+        device copy behind the step -- a 5 us launch on a 0.55 ms step), else a clone of ``met``."""
+        if ring:
+            t = self._ring_host
+            self._ring_host = t + 1
+            row = self.met_ring[t % self.METRIC_RING]
+            self._last_ring = (row, t & 0xFFFFFF)
+            return row
+        self._last_ring = None
+        return self.met.clone()
+
+    def _ring_args(self):
+        """keyword arguments that make the Adam launch of the fused step file the metrics vector in the ring"""
+        if not getattr(self, "metric_ring", True) or self.__dict__.get("met") is None or self.met.numel() > 62:
+            return {}
+        if self.__dict__.get("met_ring") is None or self.met_ring.shape[1] != self.met.numel() + 1:
+            if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                return {}
+            self.met_ring = self._f(self.METRIC_RING, self.met.numel() + 1)
+            self.ring_t = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._ring_host = 0
+            self._graphs = {}
+        self._ring_hit = True
+        return dict(met=self.met, ring=self.met_ring, ring_t=self.ring_t)
+
     def _metrics_from(self, m, **slots):
-        """Metrics from a clone ``m`` of the metrics buffer; the guard word of the same clone rides along."""
+        """Metrics from a snapshot ``m`` of the metrics buffer (_met_snapshot); the guard word of the same snapshot rides along."""
         out = Metrics((k, m[i] if isinstance(i, int) else i) for k, i in slots.items())
+        out._ring = self.__dict__.get("_last_ring")
         return out.guarded(self, m[self.GUARD]) if self.__dict__.get("_seq_lstm") else out
 
     def _on_guard_trip(self, code):

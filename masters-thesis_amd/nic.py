@@ -516,9 +516,10 @@ class NIC(ModelBase):
         B, T = self._stage_batch(data[0], data[1], self.N)
         self._sync_lr()
         self._enc_grad_stale = None
+        ring = False
         if self.grad_sync is None:
             run = self._run_planned if getattr(self, "plan_step", False) else self._run_captured
-            run(("train", B, T), lambda: self._train_and_update_graph(B, T))
+            ring = self._run_step(run, ("train", B, T), lambda: self._train_and_update_graph(B, T))
             self._enc_grad_stale = self.__dict__.get("_enc_last_fused")
         elif getattr(self.grad_sync, "pipelined", False):
             self.grad_sync.step(self, B, T)
@@ -527,7 +528,7 @@ class NIC(ModelBase):
             self.grad_sync(self)
             self._run_captured(("train_up", B, T), self._update_graph)
         self.optimizer.iterations += 1
-        m = self.met.clone()
+        m = self._met_snapshot(ring)
         return self._metrics_from(m, loss=0, L2=2, accuracy=1)
 
     def test_step(self, data):
@@ -539,7 +540,7 @@ class NIC(ModelBase):
             self._loss_metrics(B, T, False)
             self._norms_and_l2(self.met[2:3])
         self._run_captured(("test", B, T), run)
-        m = self.met.clone()
+        m = self._met_snapshot()
         return self._metrics_from(m, loss=0, L2=2, accuracy=1)
 
     def __call__(self, data, training=False):

@@ -379,7 +379,12 @@ class HipBackend:
         self._call(self.lib.tnt_l2_total_f32, "tnt_l2_total_f32", _p(wsq), _p(seg_l2), nseg, _p(out), self._s())
 
     def adam(self, theta, m, v, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr_t, lr_t_dev,
-             beta1, beta2, eps, clipnorm, guard=None):
+             beta1, beta2, eps, clipnorm, guard=None, met=None, ring=None, ring_t=None):
+        if ring is not None:       # ... and the step's metrics vector filed in the metrics ring by the same launch
+            self._call(self.lib.tnt_adam_ring_f32, "tnt_adam_ring_f32", _p(theta), _p(m), _p(v), _p(grad), _p(span_seg), _p(span_off),
+                       _p(span_len), _p(seg_l2), _p(sq), _p(sq_override), nspan, lr_t, _p(lr_t_dev), beta1, beta2, eps, clipnorm,
+                       _p(guard), _p(met), met.numel(), _p(ring), ring.shape[0], _p(ring_t), self._s())
+            return
         self._call(self.lib.tnt_adam_f32, "tnt_adam_f32", _p(theta), _p(m), _p(v), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
                                          _p(seg_l2), _p(sq), _p(sq_override), nspan, lr_t, _p(lr_t_dev), beta1,
                                          beta2, eps, clipnorm, _p(guard), self._s())

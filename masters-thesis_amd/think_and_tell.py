@@ -294,7 +294,7 @@ class CaptionGenerator(ModelBase):
         return (1.0 if self.sat else 1.0 / T) / (B * self.dp_world)
 
     def _result(self):
-        m = self.met.clone()
+        m = self._met_snapshot()
         if self.sat:
             return Metrics({"loss": m[0], "norm loss": m[1]})
         out = Metrics(scce=m[1], L2=m[2], loss=m[1] + m[2])

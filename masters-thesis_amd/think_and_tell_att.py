@@ -236,7 +236,7 @@ class CaptionGenerator(_CaptionGeneratorLSTM):
         return 1.0 / (T * B * self.dp_world)
 
     def _result(self):
-        m = self.met.clone()
+        m = self._met_snapshot()
         return Metrics(scce=m[1], L2=m[2], loss=m[1] + m[2])
 
     def train_step_SAM(self, data, rho=0.05):

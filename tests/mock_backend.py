@@ -557,7 +557,14 @@ class MockBackend:
         return clipnorm / max(np.sqrt(q), clipnorm)
 
     def adam(self, theta, m, v, grad, span_seg, span_off, span_len, seg_l2, sq, sq_override, nspan, lr_t, lr_t_dev,
-             beta1, beta2, eps, clipnorm, guard=None):
+             beta1, beta2, eps, clipnorm, guard=None, met=None, ring=None, ring_t=None):
+        if ring is not None:              # the metrics ring job (before the guard check, like the kernel)
+            rt = int(flat(ring_t)[0])
+            nmet = met.numel()
+            row = flat(ring)[(rt % ring.shape[0]) * (nmet + 1):][:nmet + 1]
+            row[:nmet] = flat(met)[:nmet]
+            row[nmet] = float(rt & 0xFFFFFF)
+            flat(ring_t)[0] = rt + 1
         if guard is not None and int(guard[0]) != 0:
             return
         if lr_t_dev is not None:

@@ -231,3 +231,33 @@ def test_adaptive_gradient_clipping_matches_oracle():
         assert 0 < changed, "the clip never triggered: the test exercises nothing"
         for k, v in orc.p.items():
             assert np.allclose(model.get_weight(k), v, rtol=2e-4, atol=2e-6), (step, k)
+
+
+def test_metrics_ring_keeps_each_steps_values_until_its_row_is_reused():
+    """The fused step files its metrics vector in a ring (tnt_adam_ring_f32) instead of cloning it behind
+    every step: Metrics objects of earlier steps keep THEIR values while later steps run, test_step still clones, and a
+    Metrics object read after its row was reused says so instead of returning another step's numbers."""
+    rng = np.random.default_rng(3)
+    B, N, T, V, U = 5, 23, 6, 13, 16
+    model, orc = make_pair(rng, (0, 0, 0))
+    model.METRIC_RING = 4
+    model.compile(Adam(learning_rate=1e-2, clipnorm=0.1), CategoricalCrossentropy(from_logits=False, reduction="none"))
+    ref, _ = make_pair(np.random.default_rng(3), (0, 0, 0))
+    ref.metric_ring = False
+    ref.compile(Adam(learning_rate=1e-2, clipnorm=0.1), CategoricalCrossentropy(from_logits=False, reduction="none"))
+    for k, v in model.get_weights_dict().items():
+        ref.set_weight(k, v)
+    held, want = [], []
+    for step in range(6):
+        data, tgt = synth_batch(B, N, T, V, U, rng)
+        held.append(model.train_step((data, tgt)))
+        want.append(ref.train_step((data, tgt)).as_floats())
+        if step == 2:
+            t1, t2 = model.test_step((data, tgt)).as_floats(), ref.test_step((data, tgt)).as_floats()
+            assert t1 == t2
+    assert model.met_ring.shape == (4, model.met.numel() + 1) and ref.__dict__.get("met_ring") is None
+    for step in (2, 3, 4, 5):                # the four newest rows are intact, whatever ran since
+        assert held[step].as_floats() == want[step]
+    for step in (0, 1):                      # rows reused by steps 4 and 5
+        with pytest.raises(RuntimeError, match="ring row has been reused"):
+            held[step].as_floats()
