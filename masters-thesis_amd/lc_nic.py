@@ -866,7 +866,8 @@ class NIC(ModelBase):
         self._sync_lr()
         ring = False
         if self.grad_sync is None:
-            ring = self._run_step(self._run_captured, ("train", B, T), lambda: self._train_and_update_graph(B, T))
+            run = self._run_planned if getattr(self, "plan_step", False) else self._run_captured
+            ring = self._run_step(run, ("train", B, T), lambda: self._train_and_update_graph(B, T))
         elif getattr(self.grad_sync, "pipelined", False):
             self.grad_sync.step(self, B, T)
         else:
