@@ -350,3 +350,31 @@ def test_guard_trip_skips_the_update_and_falls_back():
     d.seq_sync[1024] = 1
     p1 = d(data, training=False)
     assert not d._seq_lstm and (p0 - p1).abs().max().item() <= 1e-5
+
+
+def test_guard_trip_of_the_attention_chains_skips_the_update_and_falls_back():
+    """The same fault injection for the attention model, whose forward AND backward T-step chains are persistent launches
+    (tnt_lc_seq_fwd_f32 / tnt_lc_seq_bwd_f32) sharing the dense model's sync state and guard: the step's metrics raise, the
+    update was skipped, the model continues on the per-step attention / LSTM launches and matches a model that never
+    used the chain kernels."""
+    from masters_thesis_amd.model_base import DeviceGuardError
+    rng = np.random.default_rng(29)
+    data, tgt = synth(rng)
+    a, b = make("attention"), make("attention")
+    b.use_lc_seq = False
+    for _ in range(3):
+        a.train_step((data, tgt)).as_floats(); b.train_step((data, tgt)).as_floats()
+    if not a._lc_seq_ok():
+        pytest.skip("persistent chain kernels not supported on this device")
+    torch.cuda.synchronize()
+    before = (a.arena.theta.clone(), a.opt_m.clone(), a.opt_v.clone(), a.adam_t.clone(), a.drop_step.clone())
+    a.seq_sync[1024] = 1
+    res = a.train_step((data, tgt))
+    with pytest.raises(DeviceGuardError):
+        res.as_floats()
+    after = (a.arena.theta, a.opt_m, a.opt_v, a.adam_t, a.drop_step)
+    assert all(torch.equal(x, y) for x, y in zip(before, after)), "a guarded step must leave the model untouched"
+    assert not a._lc_seq_ok() and int(a.seq_sync[1024]) == 0
+    ra, rb = a.train_step((data, tgt)).as_floats(), b.train_step((data, tgt)).as_floats()
+    for k in ("loss", "attention"):
+        assert abs(ra[k] - rb[k]) <= 5e-5 * max(1.0, abs(rb[k])), (k, ra, rb)
