@@ -37,8 +37,8 @@ MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak
 _PMC2 = "profiles/r02_pmc_seq_poll_and_encoder.txt"
 PMC_TRAFFIC = {
     "dense": {"tnt_gemm_f32 NN 960x5001x512": (int((2 * 13029.1 + 18885.8) * 1024), "profiles/r01_gemm_head_pmc_v3.txt"),
-              "tnt_lstm_seq_fwd_f32 S=16 B=64 U=512": (int((2 * 13420.2 + 14220.4) * 1024), _PMC2),
-              "tnt_lstm_seq_bwd_f32 S=16 B=64 U=512": (int((2 * 22179.7 + 127485.1) * 1024), _PMC2),
+              "tnt_lstm_seq_fwd_f32 S=16 B=64 U=512": (int((2 * 21651.0 + 14232.8) * 1024), _PMC2),
+              "tnt_lstm_seq_bwd_f32 S=16 B=64 U=512": (int((2 * 28713.9 + 25008.8) * 1024), _PMC2),
               "tnt_dense_fwd_stream_gram_f32 64x512x20000": (int((2 * 22663.2 + 2305.0) * 1024), _PMC2),
               "tnt_dense_dw_adam_f32 20000x512x64": (int((2 * 65998.5 + 120000.0) * 1024), _PMC2),
               "tnt_dense_dw_skinny_f32 20000x512x64": (int((2 * 5568.5 + 40000.0) * 1024), _PMC2)},
