@@ -191,11 +191,20 @@ def kernel_breakdown(model, batch, workload, reps=20, limit=12):
     be = model.be
     saved_graphs = model._graphs
     model._graphs = {}                          # next train_step runs its launch sequence eagerly
+    # the recorded calls are re-issued many times below: keep the metrics-ring job (which advances a device counter the host
+    # mirrors) out of the recording, and leave the model's notion of which captured steps file their metrics there untouched
+    saved_ring = (model.__dict__.get("metric_ring", None), set(model.__dict__.get("_ring_keys", ())))
+    model.metric_ring = False
     be._rec = rec = []
     try:
         model.train_step(batch)
     finally:
         be._rec = None
+        if saved_ring[0] is None:
+            del model.metric_ring
+        else:
+            model.metric_ring = saved_ring[0]
+        model._ring_keys = saved_ring[1]
     torch.cuda.synchronize()
     model._graphs = saved_graphs
     n_param = int(model.arena.total)
