@@ -500,6 +500,16 @@ int32_t tnt_stage_batch_f32(const float* x, float* x_dst, const int32_t* cap, in
                             const int32_t* tgt, int32_t* tgt_tmajor, const float* a0, float* h0,
                             const float* c0, float* c0_dst, int32_t B, int32_t T, int32_t N, int32_t ldx,
                             int32_t U, float* xT_dst, int32_t ldt, void* stream);
+/* tnt_stage_batch_f32 with tnt_dropout_mask4_u8's job riding in the same launch: keep_out [keep_sites][keep_n / 4] bytes, the
+ * keep masks of sites keep_site0 .. of stream (keep_seed, *keep_step_dev) -- the attention-dropout masks of the training
+ * step this batch feeds (attention.py:36).  The Philox-bound mask blocks and the memory-bound copies share the chip; the
+ * captured step then starts without its own mask launch. */
+int32_t tnt_stage_batch_masks_f32(const float* x, float* x_dst, const int32_t* cap, int32_t* cap_dst,
+                            const int32_t* tgt, int32_t* tgt_tmajor, const float* a0, float* h0,
+                            const float* c0, float* c0_dst, int32_t B, int32_t T, int32_t N, int32_t ldx,
+                            int32_t U, float* xT_dst, int32_t ldt, uint8_t* keep_out, int64_t keep_n,
+                                  int32_t keep_sites, float keep_rate, uint64_t keep_seed, uint32_t keep_site0,
+                                  const uint32_t* keep_step_dev, void* stream);
 /* Same staging for betas that crossed PCIe as IEEE half (x_half: (B,N) uint16 bit patterns, 8-byte aligned when
  * N % 4 == 0): widened to float in the same pass.  Opt-in "fp16 on-wire" input of data.PinnedPrefetcher
  * (at full-cortex width, N = 327 684, the 84 MB float batch is what bounds the step). */

@@ -92,6 +92,7 @@ SIGNATURES = {
     "tnt_sum2_f32": [P, P, P, P, I32, F32, P],
     "tnt_stage_batch_f32": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, I32, P],
     "tnt_stage_batch_h16": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, I32, P],
+    "tnt_stage_batch_masks_f32": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, I32, P, I64, I32, F32, U64, U32, P, P],
     "tnt_sample_rows_f32": [P, P, I32, I32, I32, F32, I32, U64, U32, U32, P, P],
     "tnt_sqdiff_mean_f32": [P, P, I64, F32, P],
     "tnt_sum_f32": [P, P, I32, F32, P],

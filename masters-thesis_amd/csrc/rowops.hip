@@ -401,6 +401,9 @@ struct StageArgs {
   const float* a0; float* h0; const float* c0; float* c0d;
   int B, T, N, ldx, U;
   float* xT; int ldt; int ncopy;      // optional voxel-major copy xT[N][ldt] (blocks >= ncopy transpose 64x64 tiles)
+  // optional riding job (blocks >= nstage): the keep masks of tnt_dropout_mask4_u8 for the step that this batch feeds
+  uint8_t* mk_out; long mk_n4, mk_total; float mk_rate; uint64_t mk_seed; uint32_t mk_site0; const uint32_t* mk_step_dev;
+  int nstage;
 };
 __device__ __forceinline__ float stage_ld(const float* p) { return *p; }
 __device__ __forceinline__ float stage_ld(const __half* p) { return __half2float(*p); }
@@ -413,11 +416,22 @@ __device__ __forceinline__ float4 stage_ld4(const __half* p) {          // 8-byt
 }
 template <typename XT>
 __global__ __launch_bounds__(256) void stage_batch_kernel(StageArgs<XT> a) {
+  if ((int)blockIdx.x >= a.nstage) {          // Philox-bound, the copies around it memory-bound: they share the chip
+    const uint32_t st = a.mk_step_dev ? a.mk_step_dev[0] : 0u;
+    const long nb = gridDim.x - a.nstage;
+    for (long g = (long)(blockIdx.x - a.nstage) * 256 + threadIdx.x; g < a.mk_total; g += nb * 256) {
+      const long k = g / a.mk_n4, gi = g - k * a.mk_n4;
+      bool kp[4];
+      tnt_keep4((uint64_t)gi * 4u, a.mk_rate, a.mk_seed, a.mk_site0 + (uint32_t)k, st, kp);
+      a.mk_out[g] = (uint8_t)((kp[0] ? 1 : 0) | (kp[1] ? 2 : 0) | (kp[2] ? 4 : 0) | (kp[3] ? 8 : 0));
+    }
+    return;
+  }
   if ((int)blockIdx.x >= a.ncopy) {
     // voxel-major copy for the region-wise encoder's gather: tile = 64 voxels x 64 batch rows through LDS
     __shared__ float tile[64][65];
     const int ntc = (a.N + 63) / 64, ntr = (a.B + 63) / 64;
-    for (int t = blockIdx.x - a.ncopy; t < ntc * ntr; t += gridDim.x - a.ncopy) {
+    for (int t = blockIdx.x - a.ncopy; t < ntc * ntr; t += a.nstage - a.ncopy) {
       const int c0 = (t % ntc) * 64, r0 = (t / ntc) * 64;
       __syncthreads();
       for (int e = threadIdx.x; e < 64 * 64; e += 256) {
@@ -1223,17 +1237,30 @@ namespace {
 template <typename XT>
 int32_t stage_batch_launch(const XT* x, float* x_dst, const int32_t* cap, int32_t* cap_dst, const int32_t* tgt,
                            int32_t* tgt_tmajor, const float* a0, float* h0, const float* c0, float* c0_dst, int32_t B,
-                           int32_t T, int32_t N, int32_t ldx, int32_t U, float* xT_dst, int32_t ldt, void* stream) {
+                           int32_t T, int32_t N, int32_t ldx, int32_t U, float* xT_dst, int32_t ldt, void* stream,
+                           uint8_t* keep_out = nullptr, int64_t keep_n = 0, int32_t keep_sites = 0, float keep_rate = 0.f,
+                           uint64_t keep_seed = 0, uint32_t keep_site0 = 0, const uint32_t* keep_step_dev = nullptr) {
   if (B <= 0 || T <= 0 || N <= 0 || ldx < N || U <= 0) return TNT_BADARG(11);
+  if (keep_out != nullptr && (keep_n <= 0 || keep_n % 4 != 0 || keep_sites <= 0)) return TNT_BADARG(19);
   if (xT_dst && ldt < B) return TNT_BADARG(16);
   const bool vec = (N % 4 == 0) && (ldx % 4 == 0);
   const bool src_ok = sizeof(XT) == 4 ? tnt_aligned16(x) : ((reinterpret_cast<uintptr_t>(x) & 7u) == 0);
   if (vec && (!src_ok || !tnt_aligned16(x_dst))) return TNT_BADARG(1);
-  StageArgs<XT> a{x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U, xT_dst, ldt, 0};
+  StageArgs<XT> a{};
+  a.x = x; a.xd = x_dst; a.cap = cap; a.capd = cap_dst; a.tgt = tgt; a.tgtd = tgt_tmajor; a.a0 = a0; a.h0 = h0; a.c0 = c0;
+  a.c0d = c0_dst; a.B = B; a.T = T; a.N = N; a.ldx = ldx; a.U = U; a.xT = xT_dst; a.ldt = ldt;
   a.ncopy = ew_blocks((long)B * N / (vec ? 4 : 1));
   int nt = 0;
   if (xT_dst) { nt = ((N + 63) / 64) * ((B + 63) / 64); if (nt > 1024) nt = 1024; }
-  hipLaunchKernelGGL(stage_batch_kernel<XT>, dim3(a.ncopy + nt), dim3(256), 0, tnt_stream(stream), a);
+  a.nstage = a.ncopy + nt;
+  long nmask = 0;
+  if (keep_out) {
+    a.mk_out = keep_out; a.mk_n4 = keep_n / 4; a.mk_total = a.mk_n4 * keep_sites; a.mk_rate = keep_rate; a.mk_seed = keep_seed;
+    a.mk_site0 = keep_site0; a.mk_step_dev = keep_step_dev;
+    nmask = (a.mk_total + 255) / 256;
+    if (nmask > 8192) nmask = 8192;
+  }
+  hipLaunchKernelGGL(stage_batch_kernel<XT>, dim3(a.nstage + (int)nmask), dim3(256), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
 }
@@ -1245,6 +1272,16 @@ extern "C" int32_t tnt_stage_batch_f32(const float* x, float* x_dst, const int32
                                        int32_t U, float* xT_dst, int32_t ldt, void* stream) {
   return stage_batch_launch<float>(x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U, xT_dst,
                                    ldt, stream);
+}
+
+extern "C" int32_t tnt_stage_batch_masks_f32(const float* x, float* x_dst, const int32_t* cap, int32_t* cap_dst,
+                                             const int32_t* tgt, int32_t* tgt_tmajor, const float* a0, float* h0,
+                                             const float* c0, float* c0_dst, int32_t B, int32_t T, int32_t N, int32_t ldx,
+                                             int32_t U, float* xT_dst, int32_t ldt, uint8_t* keep_out, int64_t keep_n,
+                                             int32_t keep_sites, float keep_rate, uint64_t keep_seed, uint32_t keep_site0,
+                                             const uint32_t* keep_step_dev, void* stream) {
+  return stage_batch_launch<float>(x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U, xT_dst,
+                                   ldt, stream, keep_out, keep_n, keep_sites, keep_rate, keep_seed, keep_site0, keep_step_dev);
 }
 
 extern "C" int32_t tnt_stage_batch_h16(const uint16_t* x_half, float* x_dst, const int32_t* cap, int32_t* cap_dst,

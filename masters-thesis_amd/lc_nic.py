@@ -522,7 +522,8 @@ class NIC(ModelBase):
         Wl = a.p("lstm/kernel")
         # text half of the input projection for all T steps: one epilogue-free GEMM; bias added in the step kernel
         self.gemm_sk(self.text, Wl[D:], self.XZ, n, 4 * U, Et, Et, 4 * U, 4 * U)
-        if training and self._keep_stored:
+        if training and self._keep_stored and not self.__dict__.get("_masks_staged"):
+            # (a training step has them generated with its batch staging, outside the captured sequence: _stage_mask_job)
             be.dropout_mask4(self.att_keep, B * R * A, T, self.r_attn, sd, S_ATTN, 0, ds)
         if self._lc_seq_ok():
             # the T attention -> LSTM steps as ONE persistent launch (tnt_lc_seq_fwd_f32), XCD-local data-polling hand-offs
@@ -844,6 +845,12 @@ class NIC(ModelBase):
             self._defer_sum2 = False
         self._update_fused(self.met[2:3])
 
+    def _stage_mask_job(self):
+        if not (self._keep_stored and getattr(self, "stage_masks", True)):
+            return None
+        B, T = self._shape
+        return (self.att_keep, B * self.R * self.A, T, self.r_attn, self.seed, S_ATTN, self.drop_step)
+
     def _metrics(self, with_lr, ring=False):
         m = self._met_snapshot(ring)
         if self.S == 1:
@@ -862,7 +869,8 @@ class NIC(ModelBase):
         """lc_NIC.train_step (lc_NIC.py:328-408): returns {loss, L2, accuracy, attention, lr}."""
         if self.optimizer is None:
             raise RuntimeError("compile() the model before train_step")
-        B, T = self._stage_batch(data[0], data[1], self.n_in)
+        B, T = self._stage_batch(data[0], data[1], self.n_in, masks=True)
+        self._masks_staged = self._stage_mask_job() is not None
         self._sync_lr()
         ring = False
         if self.grad_sync is None:
@@ -890,7 +898,8 @@ class NIC(ModelBase):
             raise RuntimeError("compile() the model before train_step_sam")
         if self.S != 1:
             raise NotImplementedError("train_step_sam is a single-subject step (lc_NIC.py)")
-        B, T = self._stage_batch(data[0], data[1], self.n_in)
+        B, T = self._stage_batch(data[0], data[1], self.n_in, masks=True)
+        self._masks_staged = self._stage_mask_job() is not None
         self._sync_lr()
         be, a, sp = self.be, self.arena, self.arena.spans
         if self.__dict__.get("ew") is None:
@@ -924,6 +933,7 @@ class NIC(ModelBase):
     def test_step(self, data):
         """lc_NIC.test_step (lc_NIC.py:410-459)."""
         B, T = self._stage_batch(data[0], data[1], self.n_in)
+        self._masks_staged = False
 
         # ms2_NIC.test_step calls its sub-models with training=True (ms2_NIC.py:419,426) -- quirk kept
         train_flag = self.S > 1
@@ -941,6 +951,7 @@ class NIC(ModelBase):
         """lc_NIC.call -> call_attention (lc_NIC.py:163-164,223-263):
         returns (probabilities (B,T,V), attention scores (T,B,R,1))."""
         B, T = self._stage_inputs(data)
+        self._masks_staged = False
 
         def run():
             self._forward(B, T, training)

@@ -546,7 +546,12 @@ class ModelBase:
             return a.to(device=self.device, dtype=dtype, non_blocking=True)
         return torch.as_tensor(np.asarray(a), dtype=dtype).to(self.device, non_blocking=True)
 
-    def _stage_batch(self, inputs, target, n_cols):
+    def _stage_mask_job(self):
+        """(out, n, nsites, rate, seed, site0, step_dev) of the dropout masks a training step wants generated with its
+        batch staging (attention model: the stored attention-dropout masks of all T steps), or None"""
+        return None
+
+    def _stage_batch(self, inputs, target, n_cols, masks=False):
         """(inputs, target) -> static buffers.  A batch that already sits on the model's device in the staged
         dtypes (float32 -- or float16 "on-wire" -- betas, float32 states, int32 ids, contiguous) goes through ONE launch
         (tnt_stage_batch_f32 / _h16);
@@ -564,17 +569,24 @@ class ModelBase:
             B, T = self._stage_inputs(inputs)
             if target is not None:
                 self._stage_target(target, B, T)
+            mk = self._stage_mask_job() if masks else None
+            if mk is not None:
+                self.be.dropout_mask4(mk[0], mk[1], mk[2], mk[3], mk[4], mk[5], 0, mk[6])
             return B, T
         B, T = cap.shape
         self._build(B, T)
         assert a0.shape == c0.shape == (B, self.U), f"state shape {tuple(a0.shape)} != {(B, self.U)}"
         xT = getattr(self, "xT", None)       # voxel-major copy for the region-wise encoder, written in the same launch
+        kw = {}
+        mk = self._stage_mask_job() if masks else None
+        if mk is not None:                   # the step's dropout masks ride in the staging launch
+            kw["masks"] = mk
         if xT is not None:
             self.be.stage_batch(x, self.x, cap, self.cap, target, self.tgt, a0, self.Hs[0], c0, self.Cs[0], B, T, n_cols,
-                                self.ldx, self.U, xT, xT.shape[1])
+                                self.ldx, self.U, xT, xT.shape[1], **kw)
         else:
             self.be.stage_batch(x, self.x, cap, self.cap, target, self.tgt, a0, self.Hs[0], c0, self.Cs[0], B, T, n_cols,
-                                self.ldx, self.U)
+                                self.ldx, self.U, **kw)
         return B, T
 
     def _stage_target(self, target, B, T):

@@ -354,9 +354,19 @@ class HipBackend:
     def sum2(self, x0, out0, x1, out1, n, scale):
         self._call(self.lib.tnt_sum2_f32, "tnt_sum2_f32", _p(x0), _p(out0), _p(x1), _p(out1), n, scale, self._s())
 
-    def stage_batch(self, x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U, xT_dst=None, ldt=0):
-        """x: float32 betas, or float16 ("fp16 on-wire": widened to float by the staging kernel)."""
+    def stage_batch(self, x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U, xT_dst=None, ldt=0,
+                    masks=None):
+        """x: float32 betas, or float16 ("fp16 on-wire": widened to float by the staging kernel).
+        masks = (out, n, nsites, rate, seed, site0, step_dev): dropout_mask4's job in the same launch (float32 betas)."""
         half = x.dtype == torch.float16
+        if masks is not None and not half:
+            out, n, nsites, rate, seed, site0, step_dev = masks
+            self._call(self.lib.tnt_stage_batch_masks_f32, "tnt_stage_batch_masks_f32", _p(x), _p(x_dst), _p(cap), _p(cap_dst),
+                       _p(tgt), _p(tgt_tmajor), _p(a0), _p(h0), _p(c0), _p(c0_dst), B, T, N, ldx, U, _p(xT_dst), ldt, _p(out),
+                       int(n), int(nsites), float(rate), int(seed), int(site0), _p(step_dev), self._s())
+            return
+        if masks is not None:
+            self.dropout_mask4(masks[0], masks[1], masks[2], masks[3], masks[4], masks[5], 0, masks[6])
         fn, name = (self.lib.tnt_stage_batch_h16, "tnt_stage_batch_h16") if half else \
                    (self.lib.tnt_stage_batch_f32, "tnt_stage_batch_f32")
         self._call(fn, name, _p(x), _p(x_dst), _p(cap), _p(cap_dst), _p(tgt), _p(tgt_tmajor), _p(a0),

@@ -362,7 +362,10 @@ class MockBackend:
         self.sum(x0, out0, n, scale)
         self.sum(x1, out1, n, scale)
 
-    def stage_batch(self, x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U, xT_dst=None, ldt=0):
+    def stage_batch(self, x, x_dst, cap, cap_dst, tgt, tgt_tmajor, a0, h0, c0, c0_dst, B, T, N, ldx, U, xT_dst=None, ldt=0,
+                    masks=None):
+        if masks is not None:
+            self.dropout_mask4(masks[0], masks[1], masks[2], masks[3], masks[4], masks[5], 0, masks[6])
         xs = x.reshape(-1)[:B * N].float().numpy().reshape(B, N)          # float32 or float16 ("on-wire") betas
         mat(x_dst, B, N, ldx)[...] = xs
         if xT_dst is not None:

@@ -1348,6 +1348,14 @@ def test_embedding_fwd_drop_stage_sum2(be):
     assert torch.equal(xd, x) and torch.equal(capd, cap) and torch.equal(h0, a0) and torch.equal(c0d, c0)
     assert torch.equal(xT[:, :B], x.t()) and float(xT[:, B:].abs().sum()) == 0.0
     assert torch.equal(tgtd.view(T, B), tgt.t())
+    # ... with tnt_dropout_mask4_u8's job riding in the same launch (tnt_stage_batch_masks_f32): same copies, same mask bytes
+    nm, ns = 4 * 1000, 3
+    mk_ref, mk = torch.zeros(ns, nm // 4, dtype=torch.uint8, device="cuda"), torch.full((ns, nm // 4), 255, dtype=torch.uint8, device="cuda")
+    be.dropout_mask4(mk_ref, nm, ns, 0.2, 99, 16, 0, step_dev)
+    xd.zero_(); xT.fill_(7.0); capd.zero_(); h0.zero_()
+    be.stage_batch(x, xd, cap, capd, tgt, tgtd, a0, h0, c0, c0d, B, T, N, N, U, xT, 8, masks=(mk, nm, ns, 0.2, 99, 16, step_dev))
+    assert torch.equal(mk, mk_ref)
+    assert torch.equal(xd, x) and torch.equal(capd, cap) and torch.equal(h0, a0) and torch.equal(xT[:, :B], x.t())
     x2 = dev(rng.standard_normal((B, 37))); xd2 = torch.zeros(B, 40, device="cuda")      # ragged width, padded rows
     be.stage_batch(x2, xd2, cap, capd, None, tgtd, a0, h0, c0, c0d, B, T, 37, 40, U)
     assert torch.equal(xd2[:, :37], x2) and float(xd2[:, 37:].abs().sum()) == 0.0
