@@ -1411,7 +1411,7 @@ constexpr int LB_DZLD = 68;
 constexpr int LB_RED_FLOATS = 16 * 4 * 16 * 17;                  // gather sums [2][16][256] / context-part tiles [16 waves][4][16][17]
 constexpr int LB_LDS_FLOATS = 2 * 16 * LB_DZLD + LB_RED_FLOATS;  // LSTM role: dz tiles, reduction buffer
 constexpr int LB_W2LD = 65;                                      // row stride of the LSTM role's W2 slice [32][A <= 64]
-constexpr int LB_LSTM_FLOATS = LB_LDS_FLOATS + 32 * LB_W2LD + 16 * 64;             // + W2 slice + the 16 samples' dq
+constexpr int LB_LSTM_FLOATS = LB_LDS_FLOATS + 32 * LB_W2LD + 16 * 64 + 16 * 2 * 4 * 64;   // + W2 slice + the 16 samples' dq + Wc operands
 constexpr int LB_PF_FLOATS = 512 * 64;                           // attention role: P and F rows of the sample, R (A + D) <= this
 constexpr int LB_LDS_BYTES = (LB_LSTM_FLOATS > LB_PF_FLOATS ? LB_LSTM_FLOATS : LB_PF_FLOATS) * 4 + 16;
 
@@ -1648,12 +1648,14 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   // context-gradient part of this workgroup: part[16 rows][D] = dz[16][128 k] Wc^T[128 k][D] on the MFMAs; wave w owns the
   // contraction quads 2 w and 2 w + 1 (k = 4 quad + kq), its B operands (Wc[d = 16 t + lr][32 j units][k]) stay in registers
   const int ntile = (D + 15) / 16;
-  float wcb[2][4];
+  // (parked in LDS, [wave][quad][tile][lane]: 8 resident VGPRs per lane are 8 more spilled ones in this role)
+  float* wcb_l = dq_l + 16 * 64;                               // [16][2][4][64]
 #pragma unroll
   for (int sq = 0; sq < 2; ++sq)
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      wcb[sq][t] = (t * 16 + lr < D) ? a.Wc[((long)(t * 16 + lr) * U + j * 32) * 4 + (2 * w + sq) * 4 + kq] : 0.f;
+      wcb_l[((w * 2 + sq) * 4 + t) * 64 + lane] =
+          (t * 16 + lr < D) ? a.Wc[((long)(t * 16 + lr) * U + j * 32) * 4 + (2 * w + sq) * 4 + kq] : 0.f;
   for (int e = tid; e < 32 * A; e += WT) w2s[(e / A) * LB_W2LD + e % A] = g.W2[(long)(j * 32 + e / A) * A + e % A];
   for (int e = tid; e < 2 * 16 * LB_DZLD; e += WT) dzs[e] = 0.f;             // rows past B stay zero
   const int eq = tid >> 8, erow = (tid & 255) >> 4, ecol = tid & 15;
@@ -1804,8 +1806,8 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       for (int t = 0; t < 4; ++t) {
         if (t < ntile) {
           floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[0], wcb[0][t], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[1], wcb[1][t], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[0], wcb_l[((w * 2 + 0) * 4 + t) * 64 + lane], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[1], wcb_l[((w * 2 + 1) * 4 + t) * 64 + lane], acc, 0, 0, 0);
 #pragma unroll
           for (int r = 0; r < 4; ++r) pr[w][t][kq * 4 + r][lr] = acc[r];
         }
