@@ -1015,6 +1015,9 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   __shared__ float red_l[WW];
   __shared__ __attribute__((aligned(16))) float wc_l[64 * 32 * 4];                    // [D][32 units][4 gates]
   __shared__ float ctx_l[16 * 64];                                                    // [16 rows][D]
+  // LSTM role, per epilogue thread: the gate bias, and (text projection + bias) of the current step -- parked in LDS: resident
+  // in registers they are 8 of the VGPRs this role spills
+  __shared__ __attribute__((aligned(16))) float4 zb_l[512], zx_l[512];
   LCT_DECL
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
@@ -1219,10 +1222,10 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   const int eb = rb * RB + erow, eu = (2 * j + eq) * 16 + ecol;
   const bool eok = tid < 512 && erow < RB && eb < B;
   const long ee = (long)eb * U + eu;
-  float4 zb = make_float4(0.f, 0.f, 0.f, 0.f), x4 = zb;
+  float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float cp = 0.f;
   if (eok) {
-    if (a.zbias) zb = *reinterpret_cast<const float4*>(a.zbias + (long)eu * 4);
+    zb_l[tid] = a.zbias ? *reinterpret_cast<const float4*>(a.zbias + (long)eu * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     cp = a.cs[ee];
     x4 = *reinterpret_cast<const float4*>(a.xz + ee * 4);
     a.hs[BU + ee] = sentinel;
@@ -1230,6 +1233,10 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
   for (int i = 0; i < T; ++i) {
     LCT(48);
+    if (eok) {          // x4 = xz[i] (loaded behind the previous step's publish) meets the bias here and leaves the registers
+      const float4 b4 = zb_l[tid];
+      zx_l[tid] = make_float4(x4.x + b4.x, x4.y + b4.y, x4.z + b4.z, x4.w + b4.w);
+    }
     if (eok && i + 2 <= T) a.hs[(long)(i + 2) * BU + ee] = sentinel;
     // ---- A fragments = h[i] (this wave's K chunk)
     float av[SS];
@@ -1303,7 +1310,8 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
     __syncthreads();
     LCT(51);
     if (eok) {
-      float z[4] = {x4.x + zb.x + zs[0], x4.y + zb.y + zs[1], x4.z + zb.z + zs[2], x4.w + zb.w + zs[3]};
+      const float4 zx = zx_l[tid];
+      float z[4] = {zx.x + zs[0], zx.y + zs[1], zx.z + zs[2], zx.w + zs[3]};
       const float* cr = ctx_l + erow * 64;
       const float4* wq = reinterpret_cast<const float4*>(wc_l) + eq * 16 + ecol;
 #pragma unroll 8

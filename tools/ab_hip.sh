@@ -1,4 +1,7 @@
-# A/B of two versions of csrc/attention.hip on ONE box: the tree's build, then tools/probe/att_prev.hip.txt built in its place
+# A/B/A of two versions of csrc/attention.hip on ONE box: the tree's build, then tools/probe/att_prev.hip.txt (a copy of the other
+# version, e.g. `git show HEAD~1:masters-thesis_amd/csrc/attention.hip`) built in its place, then the tree's again.  Separate
+# processes drift by ~1 % even on one box (the two tree runs bracket that): differences below it need an in-process switch
+# (tools/ab_attr.py).
 set -e
 R=$GRAFT_REPO_ROOT
 cd $R
