@@ -1,10 +1,13 @@
 """Margins of the full-size gradient check (tests/test_gpu_fullsize.py::test_train_step_matches_oracle_at_full_size): per
 variable, the worst err / (1e-4 * max|grad| + 1e-10) over three steps, with model attributes set from the command line
-(python tools/grad_margin.py attention fused_bn_drop=0)."""
+(python tests/dev_grad_margin.py attention fused_bn_drop=0; a development aid, not collected by pytest: it lives under tests/
+because it calls the oracle)."""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
-from tests import test_gpu_fullsize as F
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import test_gpu_fullsize as F
 from oracle import models as M
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "attention"
