@@ -42,7 +42,9 @@ PMC_TRAFFIC = {
               "tnt_dense_fwd_stream_gram_f32 64x512x20000": (int((2 * 22663.2 + 2305.0) * 1024), _PMC2),
               "tnt_dense_dw_adam_f32 20000x512x64": (int((2 * 65998.5 + 120000.0) * 1024), _PMC2),
               "tnt_dense_dw_skinny_f32 20000x512x64": (int((2 * 5568.5 + 40000.0) * 1024), _PMC2)},
-    "attention": {"tnt_gemm_f32 NN 960x5001x256": (int((2 * 6575.1 + 18885.0) * 1024), "profiles/r01_gemm_head_c3_pmc.txt")},
+    "attention": {"tnt_gemm_f32 NN 960x5001x256": (int((2 * 6575.1 + 18885.0) * 1024), "profiles/r01_gemm_head_c3_pmc.txt"),
+                  "tnt_lc_seq_fwd_f32 T=15 B=64 R=360 U=512": (int((2 * 27934.6 + 19743.6) * 1024), "profiles/r02_pmc_attention_chains.txt"),
+                  "tnt_lc_seq_bwd_f32 T=15 B=64 R=360 U=512": (int((2 * 35027.5 + 45564.7) * 1024), "profiles/r02_pmc_attention_chains.txt")},
 }
 STEP_GFLOP = {"dense": 30.3, "attention": 22.0}          # SURVEY 8d, whole training step
 WORKLOAD_NAME = {

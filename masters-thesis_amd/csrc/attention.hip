@@ -1677,6 +1677,9 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   const long ee = (long)eb * U + eu;
   const int ridx = ((erow >> 2) * 16 + ecol) * 4 + (erow & 3);
   float dc_c = 0.f;
+  // with row blocks of 8 samples only the half of a partial tile that holds rows < 8 (lanes 0..31 of the MFMA's C layout) is
+  // pushed, reset and gathered
+  const bool xl = kq * 4 < RB;
   // this lane's chunk of the tile (dest, src) in ring buffer buf
   auto xslot = [&](int buf, int dest, int src) { return a.xch + ((((long)(buf * nrb + rb) * 32 + dest) * 32 + src) * 256) + lane * 4; };
   // this thread's element (row, d) of this workgroup's context-gradient part in ring buffer buf
@@ -1687,7 +1690,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) *reinterpret_cast<float4*>(xslot(0, w * NTW + t, 2 * j + q)) = sent4;
+    for (int t = 0; t < NTW; ++t) if (xl) *reinterpret_cast<float4*>(xslot(0, w * NTW + t, 2 * j + q)) = sent4;
   if (pmine) *pslot(0) = sentinel;
   tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
   for (int i = T - 1; i >= 0; --i) {
@@ -1709,7 +1712,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) *reinterpret_cast<float4*>(xslot((par + 1) % 3, w * NTW + t, 2 * j + q)) = sent4;
+          for (int t = 0; t < NTW; ++t) if (xl) *reinterpret_cast<float4*>(xslot((par + 1) % 3, w * NTW + t, 2 * j + q)) = sent4;
       }
       floatx4 acc[2][NTW];
 #pragma unroll
@@ -1732,7 +1735,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
-          *reinterpret_cast<float4*>(xslot(par, w * NTW + t, 2 * j + q)) = make_float4(acc[q][t][0], acc[q][t][1], acc[q][t][2], acc[q][t][3]);
+          if (xl) *reinterpret_cast<float4*>(xslot(par, w * NTW + t, 2 * j + q)) = make_float4(acc[q][t][0], acc[q][t][1], acc[q][t][2], acc[q][t][3]);
       LCT(17);
       // ---- gather the 32 partial tiles of each of this workgroup's two blocks: wave w sums sources w and w + 16
       // (both blocks' loads in flight together; `red` holds [2][NWB][256])
@@ -1746,7 +1749,8 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
           for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              p[q][h] = tnt_ld4_l2(x_rsrc, base + (unsigned)q * 32u * 1024u + (unsigned)(w + 16 * h) * 1024u);
+              p[q][h] = xl ? tnt_ld4_l2(x_rsrc, base + (unsigned)q * 32u * 1024u + (unsigned)(w + 16 * h) * 1024u)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
               ok = ok && __float_as_uint(p[q][h].x) != LC_SENTINEL && __float_as_uint(p[q][h].y) != LC_SENTINEL &&
                    __float_as_uint(p[q][h].z) != LC_SENTINEL && __float_as_uint(p[q][h].w) != LC_SENTINEL;
             }
