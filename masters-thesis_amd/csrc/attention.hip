@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   __shared__ __attribute__((aligned(16))) float wred_l[WW][64];
   __shared__ __attribute__((aligned(16))) float qs_l[64];
   __shared__ float red_l[WW];
-  __shared__ __attribute__((aligned(16))) float wc_l[64 * 32 * 4];                    // [D][32 units][4 gates]
+  __shared__ float wcb_l[16 * 8 * 64];          // LSTM role: B operands of the context-term MFMAs, [wave][quad slot][lane]
   __shared__ float ctx_l[16 * 64];                                                    // [16 rows][D]
   // LSTM role, per epilogue thread: the gate bias, and (text projection + bias) of the current step -- parked in LDS: resident
   // in registers they are 8 of the VGPRs this role spills
@@ -1213,10 +1213,19 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
     for (int s = 0; s < SS; ++s)
       bv[q][s] = *reinterpret_cast<const float4*>(a.Ur + ((long)(w * CK + (s >> 2) * 16 + kq * 4 + (s & 3)) * U + ucol) * 4);
   }
-  for (int e = tid; e < D * 32; e += WT) {
-    const int d = e >> 5, ul = e & 31;
-    reinterpret_cast<float4*>(wc_l)[e] = *reinterpret_cast<const float4*>(a.Wc + ((long)d * U + j * 32 + ul) * 4);
+  // the context term ctx[16][D] Wc[D][128 gate columns of this workgroup] runs on the MFMAs (a scalar loop over D is a chain of
+  // 2 D dependent LDS round trips: 1.3 us on the critical path at D = 32): wave w owns column tile w & 7 (4 units x 4 gates)
+  // and the contraction quads 2 s + (w >> 3); its B operands are parked in LDS, not in registers (this role spills)
+  const int t8 = w & 7, kh = w >> 3;
+  constexpr int NQ = G4 == 8 ? 4 : 8;          // quads per wave: D <= 32 -> 4, D <= 64 -> 8 (operands past D are zero)
+#pragma unroll
+  for (int sq = 0; sq < NQ; ++sq) {
+    const int d = (2 * sq + kh) * 4 + kq;
+    wcb_l[(w * 8 + sq) * 64 + lane] = d < D ? a.Wc[((long)d * U + j * 32) * 4 + t8 * 16 + lr] : 0.f;
   }
+  ctx_l[tid] = 0.f;                            // columns past D are never written again: 0 * 0 in the padded MFMA quads
+  constexpr int ZCLD = 132;
+  float* zc = lc_lds;                      // [2 k-halves][16 rows][ZCLD]: aliases `red`, free between the bulk phase and the next one
   // epilogue threads: (unit block q, row, unit)
   const int eq = tid >> 8, erow = (tid & 255) >> 4, ecol = tid & 15;
   const int eb = rb * RB + erow, eu = (2 * j + eq) * 16 + ecol;
@@ -1309,20 +1318,32 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
     }
     __syncthreads();
     LCT(51);
+    {
+      floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+      float ca[NQ], cb[NQ];
+#pragma unroll
+      for (int sq = 0; sq < NQ; ++sq) {         // all operand reads in flight together, then the MFMAs back to back
+        ca[sq] = ctx_l[lr * 64 + (2 * sq + kh) * 4 + kq];
+        cb[sq] = wcb_l[(w * 8 + sq) * 64 + lane];
+      }
+#pragma unroll
+      for (int sq = 0; sq < NQ; ++sq) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[sq], cb[sq], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zc[(kh * 16 + kq * 4 + r) * ZCLD + t8 * 16 + lr] = acc[r];
+    }
+    LCT(53);
+    __syncthreads();
+    LCT(54);
     if (eok) {
       const float4 zx = zx_l[tid];
       float z[4] = {zx.x + zs[0], zx.y + zs[1], zx.z + zs[2], zx.w + zs[3]};
-      const float* cr = ctx_l + erow * 64;
-      const float4* wq = reinterpret_cast<const float4*>(wc_l) + eq * 16 + ecol;
-#pragma unroll 8
-      for (int d = 0; d < D; ++d) {
-        const float c = cr[d];
-        const float4 wv = wq[d * 32];
-        z[0] += c * wv.x; z[1] += c * wv.y; z[2] += c * wv.z; z[3] += c * wv.w;
-      }
+      const float4 c0 = *reinterpret_cast<const float4*>(zc + erow * ZCLD + (eq * 16 + ecol) * 4);
+      const float4 c1 = *reinterpret_cast<const float4*>(zc + (16 + erow) * ZCLD + (eq * 16 + ecol) * 4);
+      z[0] += c0.x + c1.x; z[1] += c0.y + c1.y; z[2] += c0.z + c1.z; z[3] += c0.w + c1.w;
       const float gi = tnt_sigmoid_fast(z[0]), gf = tnt_sigmoid_fast(z[1]), gg = tnt_tanh(z[2]), go = tnt_sigmoid_fast(z[3]);
       const float c2 = gf * cp + gi * gg;
       const float h2 = go * tnt_tanh(c2);
+      LCT(55);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's reset of hs[i+2] is in L2 first
       a.hs[(long)(i + 1) * BU + ee] = h2;
       a.cs[(long)(i + 1) * BU + ee] = c2;
