@@ -629,7 +629,9 @@ class NIC(ModelBase):
         W2, v = a.p("attention/W2/kernel"), a.p("attention/V/kernel")
         if self.use_layer_norm:
             return self._bwd_chain_ln(B, T)
-        if self._lc_seq_ok() and self.__dict__.get("lc_xch") is not None and getattr(self, "use_lc_seq_bwd", True):
+        # (the backward kernel keeps the sample's P, F and dF rows in LDS: R (A + 2 D) <= 35 K floats, tnt_lc_seq_bwd_f32)
+        if (self._lc_seq_ok() and self.__dict__.get("lc_xch") is not None and getattr(self, "use_lc_seq_bwd", True)
+                and R * (A + 2 * D) <= 35 * 1024):
             # the T LSTM-backward -> attention-backward steps as ONE persistent launch (tnt_lc_seq_bwd_f32): role-specialised
             # workgroups per XCD, dP / dF / dvb accumulated on chip and written once
             keep = self.att_keep if self._keep_stored else None
