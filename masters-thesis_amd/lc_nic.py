@@ -466,8 +466,8 @@ class NIC(ModelBase):
         # after the other was slower than the per-step launches (16.3 vs 15.6 us per step): attention and LSTM register sets
         # together spilled 58 VGPRs and half of each group idled through the attention phase.
         return bool(self.__dict__.get("_seq_lstm") and getattr(self, "use_lc_seq", True) and not self.use_layer_norm
-                    and hasattr(self.be, "lc_seq_fwd") and self.R <= 512 and self.A % 4 == 0 and self.D % 4 == 0
-                    and self.A <= 64 and self.D <= 64)
+                    and hasattr(self.be, "lc_seq_fwd") and self.R <= (512 if max(self.A, self.D) <= 32 else 384)
+                    and self.A % 4 == 0 and self.D % 4 == 0 and self.A <= 64 and self.D <= 64)
 
     def _decode_step(self, i, B, training, s_out=None, xz_bias=None):
         """attention -> concat -> one LSTM step (lc_NIC.py:246-255)."""
