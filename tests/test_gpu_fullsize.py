@@ -378,3 +378,35 @@ def test_guard_trip_of_the_attention_chains_skips_the_update_and_falls_back():
     ra, rb = a.train_step((data, tgt)).as_floats(), b.train_step((data, tgt)).as_floats()
     for k in ("loss", "attention"):
         assert abs(ra[k] - rb[k]) <= 5e-5 * max(1.0, abs(rb[k])), (k, ra, rb)
+
+
+@pytest.mark.parametrize("R,D,A,Bq", [(400, 32, 32, 20), (100, 32, 48, 64), (360, 32, 32, 70)])
+def test_attention_chain_kernels_off_the_benchmark_shape(R, D, A, Bq):
+    """The one-launch chains away from config 3's shape: R = 400 (the backward chain's LDS limit sends it to the per-step
+    launches while the forward chain runs), attention width 48 (the 16-lanes-per-row variants), a ragged batch of 70
+    (16-row blocks, the last one partly empty) -- each against the same model on the per-step launches, dropout on."""
+    from masters_thesis_amd.lc_nic import NIC, synthetic_groups
+    from masters_thesis_amd.optimizers import Adam
+
+    def build():
+        m = NIC(synthetic_groups(6000, R, D, seed=1), U, 512, E, A, V, T, 0.0, 0.2, 0.2, 0.2, 0.2, 0.2, 0.01, 0.001, 0.00003,
+                0.00001, seed=42)
+        m.compile(Adam(learning_rate=1e-4, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+        return m
+    rng = np.random.default_rng(R + A)
+    (x, cap, z, c), tgt = synth(rng, b=Bq)
+    data = (x[:, :6000].copy(), cap, z, c)
+    a, b = build(), build()
+    b.use_lc_seq = False
+    ha = [a.train_step((data, tgt)).as_floats() for _ in range(3)]
+    hb = [b.train_step((data, tgt)).as_floats() for _ in range(3)]
+    if not a._lc_seq_ok():
+        pytest.skip("persistent chain kernels not supported on this device")
+    a.check_device_errors()
+    for s_, (p, q) in enumerate(zip(ha, hb)):
+        for k in ("loss", "accuracy", "attention"):
+            assert abs(p[k] - q[k]) <= 3e-5 * max(1.0, abs(q[k])), (s_, k, p, q)
+    wa, wb = a.get_weights_dict(), b.get_weights_dict()
+    for k in wa:
+        d = np.abs(wa[k] - wb[k])
+        assert (d > 3e-5).mean() <= 5e-3, (k, d.max())
