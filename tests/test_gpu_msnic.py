@@ -52,3 +52,11 @@ def test_ms_config5_shape():
     ls = [model.train_step((data, tgt)).as_floats() for _ in range(5)]
     assert abs(ls[0]["loss"] - np.log(V)) < 0.5 and ls[-1]["loss"] < ls[0]["loss"]
     assert abs(ls[0]["loss"] - np.mean([ls[0][f"loss{t}"] for t in "ABCD"])) < 1e-5
+    # the same steps on the per-step attention / LSTM launches (the model above runs the one-launch chains where supported)
+    ref = NIC(groups, U, 512, 512, 32, V, T, 0, 0.2, 0.2, 0.2, 0.2, 0.2, 0.01, 0.001, 3e-5, 1e-5, n_subjects=S, seed=5)
+    ref.use_lc_seq = False
+    ref.compile(Adam(1e-3, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    lr_ = [ref.train_step((data, tgt)).as_floats() for _ in range(5)]
+    for p, q in zip(ls, lr_):
+        for k in q:
+            assert abs(p[k] - q[k]) <= 1e-3 * max(1.0, abs(q[k])), (k, p[k], q[k])
