@@ -435,6 +435,19 @@ struct LstmSeqArgs {
 // guard, model_base.DeviceGuardError) and carries on with what it has, so no wave ever leaves the common control flow.
 constexpr unsigned TNT_SEQ_SENTINEL = 0x7FC5EED5u;
 
+#ifdef TNT_LC_TRACE
+__device__ unsigned long long ls_trace[64];
+extern "C" int32_t tnt_debug_ls_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ls_trace), sizeof(ls_trace)) == hipSuccess ? 0 : -1;
+}
+#define LST(k) do { if (tid == 0 && rb == 0 && ub == 0 && st == 5) lst_l[(k)] = wall_clock64(); } while (0)
+#define LST_DECL __shared__ unsigned long long lst_l[16];
+#define LST_DUMP do { if (tid == 0 && rb == 0 && ub == 0) for (int q_ = 0; q_ < 16; ++q_) ls_trace[q_] = lst_l[q_]; } while (0)
+#else
+#define LST(k) do {} while (0)
+#define LST_DECL
+#define LST_DUMP do {} while (0)
+#endif
 // RB: batch rows per row block (= per XCD).  16 fills the MFMA's M dimension; 8 spreads B <= 64 over all 8 XCDs (half of every
 // A fragment is zero -- the MFMA count per wave is the same -- but a group exchanges, polls and reduces half as many rows).
 template <bool POLL, int RB>
@@ -443,6 +456,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   extern __shared__ __attribute__((aligned(16))) float seq_lds[];       // > 64 KB requested: one workgroup per CU
   float (*red)[4][16][17] = reinterpret_cast<float (*)[4][16][17]>(seq_lds);       // [NWF][4][16][17] = 69.6 KB
   unsigned* s_slot = reinterpret_cast<unsigned*>(seq_lds + NWF * 4 * 16 * 17);      // 2 words behind the reduction buffer
+  LST_DECL
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
   const int U = a.U, B = a.B;
@@ -484,6 +498,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   }
   for (int st = 0; st < a.S; ++st) {
     if (POLL && eok && st + 2 <= a.S) a.hs[(long)(st + 2) * BU + ee] = sentinel;       // published by step st + 1
+    LST(0);
     // ---- A fragments: this row block's h of the previous step (own XCD's L2)
     // (sc1 loads: the slab was stored by the other workgroups of this group)
     float av[SS];
@@ -506,6 +521,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
       }
       if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     }
+    LST(1);
     int mid = 1;
     if (eok && a.mask_ids && st >= a.mask_s0) mid = a.mask_ids[eb * a.mask_T + (st - a.mask_s0)];
     floatx4 acc[4];
@@ -518,11 +534,13 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
       acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].z, acc[2], 0, 0, 0);
       acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].w, acc[3], 0, 0, 0);
     }
+    LST(2);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[w][g][kq * 4 + r][lr] = acc[g][r];
     __syncthreads();
+    LST(3);
     if (eok) {
       float z[4] = {x4.x + zb.x, x4.y + zb.y, x4.z + zb.z, x4.w + zb.w};
 #pragma unroll
@@ -538,6 +556,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
       const bool m = mid != 0;
       const bool seq = st >= a.mask_s0;
       const float hn = m ? h2 : hp, cn = m ? c2 : cp;
+      LST(4);
       if (POLL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's reset of hs[st+2] is in L2 first
       a.hs[(long)(st + 1) * BU + ee] = hn;
       a.cs[(long)(st + 1) * BU + ee] = cn;
@@ -546,6 +565,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
       hp = hn; cp = cn;
       if (st + 1 < a.S) x4 = *reinterpret_cast<const float4*>(a.xz + ((long)(st + 1) * BU + ee) * 4);
     }
+    LST(5);
     if (st + 1 == a.S) break;
     if (POLL) {
       __syncthreads();        // `red` is rewritten by the next step's MFMA phase
@@ -554,6 +574,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
       tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, st + 1), err);
     }
   }
+  LST_DUMP;
   tnt_seq_leave(a.sync, xcc, a.guard_out);
 }
 
