@@ -475,8 +475,27 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   const int arow = (lr < RB) ? rb * RB + lr : B, ucol = ub * 16 + lr;      // rows past RB: zero fragments
   // ---- this wave's weight fragments, resident for the whole sequence
   float4 bv[SS];
+  // RB == 8: the batched 4x4x1 MFMA (16 independent 4 x 4 blocks = 8 rows x 32 gate columns per instruction: no padded rows).
+  // Lane l = 32 rg + 4 cg + j: row group rg, column group cg, column j.  One instruction handles ONE k: its A column (the 8
+  // rows' h[k]) is taken from block `abid` of each half and broadcast to the half's 8 blocks (cbsz = 3), so a lane's float4 of
+  // h -- rows rg*4 + j, k = 32 w + 4 cg + m -- serves the instructions (m, abid = cg); its B row comes from one half of the
+  // wave (blgp 1 / 2), so every B register holds U[k][col] for an even k in lanes 0..31 and for the next k in lanes 32..63.
+  const int x_rg = lane >> 5, x_cg = (lane >> 2) & 7, x_j = lane & 3;
+  float bx[2][8][2];                       // [column half][abid = k quad][m pair]
+  if (RB == 8) {
 #pragma unroll
-  for (int s = 0; s < SS; ++s) bv[s] = ld4g(a.Ur + ((long)(w * CK + (s >> 2) * 16 + kq * 4 + (s & 3)) * U + ucol) * 4, true);
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const int k = w * CK + 4 * q + 2 * pr + x_rg;
+          bx[ch][q][pr] = a.Ur[((long)k * U + ub * 16) * 4 + ch * 32 + x_cg * 4 + x_j];
+        }
+  } else {
+#pragma unroll
+    for (int s = 0; s < SS; ++s) bv[s] = ld4g(a.Ur + ((long)(w * CK + (s >> 2) * 16 + kq * 4 + (s & 3)) * U + ucol) * 4, true);
+  }
   // ---- epilogue thread state
   const int erow = tid >> 4, ecol = tid & 15;
   const int eb = rb * RB + erow, eu = ub * 16 + ecol;
@@ -499,56 +518,110 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   for (int st = 0; st < a.S; ++st) {
     if (POLL && eok && st + 2 <= a.S) a.hs[(long)(st + 2) * BU + ee] = sentinel;       // published by step st + 1
     LST(0);
-    // ---- A fragments: this row block's h of the previous step (own XCD's L2)
-    // (sc1 loads: the slab was stored by the other workgroups of this group)
-    float av[SS];
-    unsigned spins = 0;
-    for (;;) {
-      bool ok = true;
-#pragma unroll
-      for (int j = 0; j < SS / 4; ++j) {
-        const float4 t = arow < B ? tnt_ld4_l2(hs_rsrc, (unsigned)(((long)st * BU + (long)arow * U + w * CK + j * 16 + kq * 4) * 4))
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-        av[4 * j + 0] = t.x; av[4 * j + 1] = t.y; av[4 * j + 2] = t.z; av[4 * j + 3] = t.w;
-        if (POLL)
-          ok = ok && __float_as_uint(t.x) != TNT_SEQ_SENTINEL && __float_as_uint(t.y) != TNT_SEQ_SENTINEL &&
-               __float_as_uint(t.z) != TNT_SEQ_SENTINEL && __float_as_uint(t.w) != TNT_SEQ_SENTINEL;
-      }
-      if (!POLL || __all(ok)) break;
-      if (++spins > TNT_SEQ_SPIN_LIMIT) {        // never hang the grid: flag the error, go on with what there is
-        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-    }
-    LST(1);
     int mid = 1;
     if (eok && a.mask_ids && st >= a.mask_s0) mid = a.mask_ids[eb * a.mask_T + (st - a.mask_s0)];
-    floatx4 acc[4];
+    if (RB == 8) {
+      // ---- this lane's float4 of h[st]: row rg*4 + j of the block, k = 32 w + 4 cg .. + 3 (sc1 loads, polled)
+      const int xrow = rb * RB + x_rg * 4 + x_j;
+      float4 am = make_float4(0.f, 0.f, 0.f, 0.f);
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+        if (xrow < B) {
+          am = tnt_ld4_l2(hs_rsrc, (unsigned)(((long)st * BU + (long)xrow * U + w * CK + x_cg * 4) * 4));
+          if (POLL)
+            ok = __float_as_uint(am.x) != TNT_SEQ_SENTINEL && __float_as_uint(am.y) != TNT_SEQ_SENTINEL &&
+                 __float_as_uint(am.z) != TNT_SEQ_SENTINEL && __float_as_uint(am.w) != TNT_SEQ_SENTINEL;
+        }
+        if (!POLL || __all(ok)) break;
+        if (++spins > TNT_SEQ_SPIN_LIMIT) {
+          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      }
+      LST(1);
+      floatx4 xa[2];
+      xa[0] = (floatx4){0.f, 0.f, 0.f, 0.f}; xa[1] = xa[0];
+#define TNT_X4(q)                                                                                              \
+      xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.x, bx[0][q][0], xa[0], 3, q, 1);                             \
+      xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.x, bx[1][q][0], xa[1], 3, q, 1);                             \
+      xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.y, bx[0][q][0], xa[0], 3, q, 2);                             \
+      xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.y, bx[1][q][0], xa[1], 3, q, 2);                             \
+      xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.z, bx[0][q][1], xa[0], 3, q, 1);                             \
+      xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.z, bx[1][q][1], xa[1], 3, q, 1);                             \
+      xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.w, bx[0][q][1], xa[0], 3, q, 2);                             \
+      xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.w, bx[1][q][1], xa[1], 3, q, 2);
+      TNT_X4(0) TNT_X4(1) TNT_X4(2) TNT_X4(3) TNT_X4(4) TNT_X4(5) TNT_X4(6) TNT_X4(7)
+#undef TNT_X4
+      LST(2);
+      // partial z[row rg*4 + r][col ch*32 + cg*4 + j] of this wave's k chunk: red viewed as [NWF][8 rows][64 + 4]
+      float* rx = &red[0][0][0][0] + w * (8 * 68);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = (floatx4){0.f, 0.f, 0.f, 0.f};
+      for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-    for (int s = 0; s < SS; ++s) {
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].y, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].z, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].w, acc[3], 0, 0, 0);
+        for (int r = 0; r < 4; ++r) rx[(x_rg * 4 + r) * 68 + ch * 32 + x_cg * 4 + x_j] = xa[ch][r];
+      __syncthreads();
+    } else {
+    // ---- A fragments: this row block's h of the previous step (own XCD's L2)
+      // (sc1 loads: the slab was stored by the other workgroups of this group)
+      float av[SS];
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < SS / 4; ++j) {
+          const float4 t = arow < B ? tnt_ld4_l2(hs_rsrc, (unsigned)(((long)st * BU + (long)arow * U + w * CK + j * 16 + kq * 4) * 4))
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+          av[4 * j + 0] = t.x; av[4 * j + 1] = t.y; av[4 * j + 2] = t.z; av[4 * j + 3] = t.w;
+          if (POLL)
+            ok = ok && __float_as_uint(t.x) != TNT_SEQ_SENTINEL && __float_as_uint(t.y) != TNT_SEQ_SENTINEL &&
+                 __float_as_uint(t.z) != TNT_SEQ_SENTINEL && __float_as_uint(t.w) != TNT_SEQ_SENTINEL;
+        }
+        if (!POLL || __all(ok)) break;
+        if (++spins > TNT_SEQ_SPIN_LIMIT) {        // never hang the grid: flag the error, go on with what there is
+          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      }
+      floatx4 acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < SS; ++s) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s].w, acc[3], 0, 0, 0);
+      }
+      LST(2);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w][g][kq * 4 + r][lr] = acc[g][r];
+      __syncthreads();
     }
-    LST(2);
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[w][g][kq * 4 + r][lr] = acc[g][r];
-    __syncthreads();
     LST(3);
     if (eok) {
       float z[4] = {x4.x + zb.x, x4.y + zb.y, x4.z + zb.z, x4.w + zb.w};
+      if (RB == 8) {
+        const float* rx = &red[0][0][0][0] + erow * 68 + ecol * 4;
+        float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float sacc = 0.f;
+        for (int k = 0; k < NWF; ++k) {
+          const float4 t = *reinterpret_cast<const float4*>(rx + k * (8 * 68));
+          sacc.x += t.x; sacc.y += t.y; sacc.z += t.z; sacc.w += t.w;
+        }
+        z[0] += sacc.x; z[1] += sacc.y; z[2] += sacc.z; z[3] += sacc.w;
+      } else {
 #pragma unroll
-        for (int k = 0; k < NWF; ++k) sacc += red[k][g][erow][ecol];
-        z[g] += sacc;
+        for (int g = 0; g < 4; ++g) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int k = 0; k < NWF; ++k) sacc += red[k][g][erow][ecol];
+          z[g] += sacc;
+        }
       }
       const float gi = tnt_sigmoid_fast(z[0]), gf = tnt_sigmoid_fast(z[1]), gg = tnt_tanh(z[2]), go = tnt_sigmoid_fast(z[3]);
       const float c2 = gf * cp + gi * gg;
