@@ -710,13 +710,29 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
   // n = w*32 + j*16 + lr and the 16 contraction indices k = kq*16 + ks (a permutation of the MFMA's natural k order,
   // applied to both operands: each lane's slice is 64 contiguous bytes in HBM and in LDS)
   float bw[NTW][16];
+  // RB == 8: the batched 4x4x1 MFMA as in lstm_seq_fwd_kernel (8 rows x 32 columns x ONE k per instruction, no padded rows).
+  // Lane l = 32 rg + 4 cg + j owns column n = 32 w + 4 cg + j of the partial da and rows rg*4 .. +3; B registers hold
+  // Ur^T[k][n] = Ur[n][64 ub + k] for an even k in lanes 0..31 and the next k in lanes 32..63 (blgp 1 / 2), A comes from
+  // the block `abid` of each half (cbsz 3): a lane's two float4 of the dz tile -- row rg*4 + j, k = 32 kh + 4 cg + m.
+  const int x_rg = lane >> 5, x_cg = (lane >> 2) & 7, x_j = lane & 3;
+  float bx[2][8][2];                       // [k half][abid = k quad][m pair]
+  if (RB == 8) {
+    const float* src = a.Ur + ((long)(w * 32 + x_cg * 4 + x_j) * U + ub * 16) * 4;
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) {
-    const float* src = a.Ur + ((long)(w * 32 + j * 16 + lr) * U + ub * 16) * 4 + kq * 16;
+    for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 t = *reinterpret_cast<const float4*>(src + 4 * q);
-      bw[j][4 * q + 0] = t.x; bw[j][4 * q + 1] = t.y; bw[j][4 * q + 2] = t.z; bw[j][4 * q + 3] = t.w;
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) bx[kh][q][pr] = src[kh * 32 + 4 * q + 2 * pr + x_rg];
+  } else {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const float* src = a.Ur + ((long)(w * 32 + j * 16 + lr) * U + ub * 16) * 4 + kq * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(src + 4 * q);
+        bw[j][4 * q + 0] = t.x; bw[j][4 * q + 1] = t.y; bw[j][4 * q + 2] = t.z; bw[j][4 * q + 3] = t.w;
+      }
     }
   }
   for (int e = tid; e < 16 * SB_DZLD; e += 1024) dzs[e] = 0.f;           // rows past B stay zero
@@ -732,10 +748,17 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
   const float4 sent4 = make_float4(sentinel, sentinel, sentinel, sentinel);
   // this lane's chunk of the tile for workgroup `dest` in ring buffer `buf`: slot [dest][src = ub], lane-major 1 KB tiles
   auto xslot = [&](int buf, int dest) { return a.xch + ((((long)(buf * nrb + rb) * 32 + dest) * 32 + ub) * 256) + lane * 4; };
+  // RB == 8: this lane's float4 (rows rg*4 .. +3 of column 4 (cg & 3) + j) sits where the 16x16 C layout keeps those rows:
+  // chunk rg*16 + 4 (cg & 3) + j of the tile for workgroup 2 w + (cg >> 2); one chunk per lane, owned in every ring buffer
+  auto xslot8 = [&](int buf) {
+    return a.xch + ((((long)(buf * nrb + rb) * 32 + (w * 2 + (x_cg >> 2))) * 32 + ub) * 256) + (x_rg * 16 + (x_cg & 3) * 4 + x_j) * 4;
+  };
   __syncthreads();
   if (POLL) {
+    if (RB == 8) *reinterpret_cast<float4*>(xslot8(0)) = sent4;
+    else
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) if (xl) *reinterpret_cast<float4*>(xslot(0, w * NTW + j)) = sent4;
+      for (int j = 0; j < NTW; ++j) if (xl) *reinterpret_cast<float4*>(xslot(0, w * NTW + j)) = sent4;
     tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
   }
   for (int s = S - 1; s >= 0; --s) {
@@ -754,28 +777,48 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
     if (s < S - 1) {
       const int xt = S - 2 - s, par = xt % 3;
       if (POLL && s > 0) {         // the next exchange's buffer: reset this thread's chunks before publishing this one's
+        if (RB == 8) *reinterpret_cast<float4*>(xslot8((xt + 1) % 3)) = sent4;
+        else
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) if (xl) *reinterpret_cast<float4*>(xslot((xt + 1) % 3, w * NTW + j)) = sent4;
+          for (int j = 0; j < NTW; ++j) if (xl) *reinterpret_cast<float4*>(xslot((xt + 1) % 3, w * NTW + j)) = sent4;
       }
       // ---- partial da = dz_tile[16 x 64] @ Ur^T slice[64 x 512]: this wave's 2 column tiles
-      float av[16];
+      if (RB == 8) {
+        float4 am[2];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 t = *reinterpret_cast<const float4*>(dzs + lr * SB_DZLD + kq * 16 + 4 * q);
-        av[4 * q + 0] = t.x; av[4 * q + 1] = t.y; av[4 * q + 2] = t.z; av[4 * q + 3] = t.w;
+        for (int kh = 0; kh < 2; ++kh)
+          am[kh] = *reinterpret_cast<const float4*>(dzs + (x_rg * 4 + x_j) * SB_DZLD + kh * 32 + x_cg * 4);
+        floatx4 xa = (floatx4){0.f, 0.f, 0.f, 0.f};
+#define TNT_X4(kh, q)                                                                         \
+        xa = __builtin_amdgcn_mfma_f32_4x4x1f32(am[kh].x, bx[kh][q][0], xa, 3, q, 1);          \
+        xa = __builtin_amdgcn_mfma_f32_4x4x1f32(am[kh].y, bx[kh][q][0], xa, 3, q, 2);          \
+        xa = __builtin_amdgcn_mfma_f32_4x4x1f32(am[kh].z, bx[kh][q][1], xa, 3, q, 1);          \
+        xa = __builtin_amdgcn_mfma_f32_4x4x1f32(am[kh].w, bx[kh][q][1], xa, 3, q, 2);
+        TNT_X4(0, 0) TNT_X4(0, 1) TNT_X4(0, 2) TNT_X4(0, 3) TNT_X4(0, 4) TNT_X4(0, 5) TNT_X4(0, 6) TNT_X4(0, 7)
+        TNT_X4(1, 0) TNT_X4(1, 1) TNT_X4(1, 2) TNT_X4(1, 3) TNT_X4(1, 4) TNT_X4(1, 5) TNT_X4(1, 6) TNT_X4(1, 7)
+#undef TNT_X4
+        if (POLL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's reset is in L2 first
+        *reinterpret_cast<float4*>(xslot8(par)) = make_float4(xa[0], xa[1], xa[2], xa[3]);
+      } else {
+        float av[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(dzs + lr * SB_DZLD + kq * 16 + 4 * q);
+          av[4 * q + 0] = t.x; av[4 * q + 1] = t.y; av[4 * q + 2] = t.z; av[4 * q + 3] = t.w;
+        }
+        floatx4 acc[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bw[j][ks], acc[j], 0, 0, 0);
+        // ---- push: tile j belongs to workgroup (w*2 + j) of this row block
+        if (POLL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's resets are in L2 first
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+          if (xl) *reinterpret_cast<float4*>(xslot(par, w * NTW + j)) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
       }
-      floatx4 acc[NTW];
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) acc[j] = (floatx4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bw[j][ks], acc[j], 0, 0, 0);
-      // ---- push: tile j belongs to workgroup (w*2 + j) of this row block
-      if (POLL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's resets are in L2 first
-#pragma unroll
-      for (int j = 0; j < NTW; ++j)
-        if (xl) *reinterpret_cast<float4*>(xslot(par, w * NTW + j)) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
       if (!POLL) tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, S - 1 - s), err);
       // ---- gather the 32 partial tiles of this workgroup's block (sc1 loads: stored by other workgroups): wave w sums
       // sources w and w + 16, the 16 wave sums are combined through LDS in fixed order
