@@ -98,6 +98,7 @@ def test_full_width_forward_and_persistent_lstm():
         assert abs(ra["loss"] - rb["loss"]) <= 2e-5 * abs(rb["loss"]), (step, ra, rb)
     a.check_device_errors()
     assert not b._seq_lstm
-    if a._seq_lstm:                       # rounding-level differences only
-        for k in orc.p:
-            assert np.abs(a.get_weight(k) - b.get_weight(k)).max() <= 3e-5, k
+    if a._seq_lstm:                       # rounding-level differences only: Adam moves a weight by ~lr per step whatever the
+        for k in orc.p:                   # gradient's size, so a near-zero gradient element whose rounding differs shows up as
+            d = np.abs(a.get_weight(k) - b.get_weight(k))      # a fraction of 4 lr on that element (same rule as the other
+            assert (d > 3e-5).mean() <= 5e-3 and d.max() <= 5e-4, (k, d.max())      # chain-vs-step tests)
