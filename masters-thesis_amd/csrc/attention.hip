@@ -1206,12 +1206,28 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   const int arow = lr < RB ? rb * RB + lr : B;               // rows past RB: zero fragments
   // recurrent-kernel fragments of both 16-unit blocks: resident for all T steps
   float4 bv[2][SS];
+  // RB == 8: the batched 4x4x1 MFMA of lstm_seq_fwd_kernel (lstm.hip: 8 rows x 32 gate columns x one k per instruction, lane
+  // l = 32 rg + 4 cg + j, A broadcast from block `abid` of each half, B from one half of the wave) -- no padded rows
+  const int x_rg = lane >> 5, x_cg = (lane >> 2) & 7, x_j = lane & 3;
+  float bx[2][2][8][2];                    // [unit block][column half][abid = k quad][m pair]
+  if (RB == 8) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int ucol = (2 * j + q) * 16 + lr;
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int s = 0; s < SS; ++s)
-      bv[q][s] = *reinterpret_cast<const float4*>(a.Ur + ((long)(w * CK + (s >> 2) * 16 + kq * 4 + (s & 3)) * U + ucol) * 4);
+      for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int qd = 0; qd < 8; ++qd)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr)
+            bx[q][ch][qd][pr] = a.Ur[((long)(w * CK + 4 * qd + 2 * pr + x_rg) * U + (2 * j + q) * 16) * 4 + ch * 32 + x_cg * 4 + x_j];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int ucol = (2 * j + q) * 16 + lr;
+#pragma unroll
+      for (int s = 0; s < SS; ++s)
+        bv[q][s] = *reinterpret_cast<const float4*>(a.Ur + ((long)(w * CK + (s >> 2) * 16 + kq * 4 + (s & 3)) * U + ucol) * 4);
+    }
   }
   // the context term ctx[16][D] Wc[D][128 gate columns of this workgroup] runs on the MFMAs (a scalar loop over D is a chain of
   // 2 D dependent LDS round trips: 1.3 us on the critical path at D = 32): wave w owns column tile w & 7 (4 units x 4 gates)
@@ -1247,54 +1263,110 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       zx_l[tid] = make_float4(x4.x + b4.x, x4.y + b4.y, x4.z + b4.z, x4.w + b4.w);
     }
     if (eok && i + 2 <= T) a.hs[(long)(i + 2) * BU + ee] = sentinel;
-    // ---- A fragments = h[i] (this wave's K chunk)
-    float av[SS];
     unsigned spins = 0;
-    for (;;) {
-      bool ok = true;
-#pragma unroll
-      for (int q = 0; q < SS / 4; ++q) {
-        const float4 t = arow < B ? tnt_ld4_l2(hs_rsrc, (unsigned)(((long)i * BU + (long)arow * U + w * CK + q * 16 + kq * 4) * 4))
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-        av[4 * q + 0] = t.x; av[4 * q + 1] = t.y; av[4 * q + 2] = t.z; av[4 * q + 3] = t.w;
-        ok = ok && __float_as_uint(t.x) != LC_SENTINEL && __float_as_uint(t.y) != LC_SENTINEL &&
-             __float_as_uint(t.z) != LC_SENTINEL && __float_as_uint(t.w) != LC_SENTINEL;
-      }
-      if (__all(ok)) break;
-      if (++spins > TNT_SEQ_SPIN_LIMIT) {
-        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-    }
-    LCT(49);
-    // ---- h[i] U for both unit blocks (off the critical path: the attention of step i runs meanwhile)
     float zs[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      floatx4 acc[4];
-#pragma unroll
-      for (int gg = 0; gg < 4; ++gg) acc[gg] = (floatx4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < SS; ++s) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[q][s].x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[q][s].y, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[q][s].z, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[q][s].w, acc[3], 0, 0, 0);
+    if (RB == 8) {
+      // ---- this lane's float4 of h[i]: row rg*4 + j of the block, k = 32 w + 4 cg .. + 3
+      const int xrow = rb * RB + x_rg * 4 + x_j;
+      float4 am = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (;;) {
+        bool ok = true;
+        if (xrow < B) {
+          am = tnt_ld4_l2(hs_rsrc, (unsigned)(((long)i * BU + (long)xrow * U + w * CK + x_cg * 4) * 4));
+          ok = __float_as_uint(am.x) != LC_SENTINEL && __float_as_uint(am.y) != LC_SENTINEL &&
+               __float_as_uint(am.z) != LC_SENTINEL && __float_as_uint(am.w) != LC_SENTINEL;
+        }
+        if (__all(ok)) break;
+        if (++spins > TNT_SEQ_SPIN_LIMIT) {
+          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       }
-      if (q == 1) __syncthreads();           // block 0's sums have been read
+      LCT(49);
+      // ---- h[i] U for both unit blocks (off the critical path: the attention of step i runs meanwhile); the partials of both
+      // blocks go to LDS together -- [block][wave][8 rows][64 + 4 columns] fills `red` exactly -- and meet ONE barrier
+      float* rx = &red[0][0][0][0];
 #pragma unroll
-      for (int gg = 0; gg < 4; ++gg)
+      for (int q = 0; q < 2; ++q) {
+        floatx4 xa[2];
+        xa[0] = (floatx4){0.f, 0.f, 0.f, 0.f}; xa[1] = xa[0];
+#define TNT_X4(qd)                                                                                               \
+        xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.x, bx[q][0][qd][0], xa[0], 3, qd, 1);                         \
+        xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.x, bx[q][1][qd][0], xa[1], 3, qd, 1);                         \
+        xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.y, bx[q][0][qd][0], xa[0], 3, qd, 2);                         \
+        xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.y, bx[q][1][qd][0], xa[1], 3, qd, 2);                         \
+        xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.z, bx[q][0][qd][1], xa[0], 3, qd, 1);                         \
+        xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.z, bx[q][1][qd][1], xa[1], 3, qd, 1);                         \
+        xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.w, bx[q][0][qd][1], xa[0], 3, qd, 2);                         \
+        xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.w, bx[q][1][qd][1], xa[1], 3, qd, 2);
+        TNT_X4(0) TNT_X4(1) TNT_X4(2) TNT_X4(3) TNT_X4(4) TNT_X4(5) TNT_X4(6) TNT_X4(7)
+#undef TNT_X4
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[w][gg][kq * 4 + r][lr] = acc[gg][r];
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            rx[((q * NWF + w) * 8 + x_rg * 4 + r) * 68 + ch * 32 + x_cg * 4 + x_j] = xa[ch][r];
+      }
       __syncthreads();
-      if (tid < 512 && eq == q) {
+      if (tid < 512 && erow < 8) {
+        const float* rr = rx + (eq * NWF * 8 + erow) * 68 + ecol * 4;
+        float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-          float sacc = 0.f;
+        for (int k = 0; k < NWF; ++k) {
+          const float4 t = *reinterpret_cast<const float4*>(rr + k * (8 * 68));
+          sacc.x += t.x; sacc.y += t.y; sacc.z += t.z; sacc.w += t.w;
+        }
+        zs[0] = sacc.x; zs[1] = sacc.y; zs[2] = sacc.z; zs[3] = sacc.w;
+      }
+    } else {
+    // ---- A fragments = h[i] (this wave's K chunk)
+      float av[SS];
+      for (;;) {
+        bool ok = true;
 #pragma unroll
-          for (int k = 0; k < NWF; ++k) sacc += red[k][gg][erow][ecol];
-          zs[gg] = sacc;
+        for (int q = 0; q < SS / 4; ++q) {
+          const float4 t = arow < B ? tnt_ld4_l2(hs_rsrc, (unsigned)(((long)i * BU + (long)arow * U + w * CK + q * 16 + kq * 4) * 4))
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+          av[4 * q + 0] = t.x; av[4 * q + 1] = t.y; av[4 * q + 2] = t.z; av[4 * q + 3] = t.w;
+          ok = ok && __float_as_uint(t.x) != LC_SENTINEL && __float_as_uint(t.y) != LC_SENTINEL &&
+               __float_as_uint(t.z) != LC_SENTINEL && __float_as_uint(t.w) != LC_SENTINEL;
+        }
+        if (__all(ok)) break;
+        if (++spins > TNT_SEQ_SPIN_LIMIT) {
+          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      }
+      LCT(49);
+      // ---- h[i] U for both unit blocks (off the critical path: the attention of step i runs meanwhile)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        floatx4 acc[4];
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) acc[gg] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < SS; ++s) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[q][s].x, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[q][s].y, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[q][s].z, acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[q][s].w, acc[3], 0, 0, 0);
+        }
+        if (q == 1) __syncthreads();           // block 0's sums have been read
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[w][gg][kq * 4 + r][lr] = acc[gg][r];
+        __syncthreads();
+        if (tid < 512 && eq == q) {
+#pragma unroll
+          for (int gg = 0; gg < 4; ++gg) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int k = 0; k < NWF; ++k) sacc += red[k][gg][erow][ecol];
+            zs[gg] = sacc;
+          }
         }
       }
     }
