@@ -1749,8 +1749,25 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       }
     }
   };
-  load_bw(0, a.Ur);
-  load_bw(1, a.Ur);
+  // RB == 8: the batched 4x4x1 MFMA of lstm_seq_bwd_kernel (lstm.hip): lane l = 32 rg + 4 cg + j owns column n = 32 w + 4 cg + j
+  // of the partial da and rows rg*4 .. +3; per unit block 64 instructions of 8 cycles instead of 32 of 32
+  const int x_rg = lane >> 5, x_cg = (lane >> 2) & 7, x_j = lane & 3;
+  float bx[2][2][8][2];                    // [unit block][k half][abid = k quad][m pair]
+  if (RB == 8) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float* src = a.Ur + ((long)(w * 32 + x_cg * 4 + x_j) * U + (2 * j + q) * 16) * 4;
+#pragma unroll
+      for (int kh2 = 0; kh2 < 2; ++kh2)
+#pragma unroll
+        for (int qd = 0; qd < 8; ++qd)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) bx[q][kh2][qd][pr] = src[kh2 * 32 + 4 * qd + 2 * pr + x_rg];
+    }
+  } else {
+    load_bw(0, a.Ur);
+    load_bw(1, a.Ur);
+  }
   // context-gradient part of this workgroup: part[16 rows][D] = dz[16][128 k] Wc^T[128 k][D] on the MFMAs; wave w owns the
   // contraction quads 2 w and 2 w + 1 (k = 4 quad + kq), its B operands (Wc[d = 16 t + lr][32 j units][k]) stay in registers
   const int ntile = (D + 15) / 16;
@@ -1775,15 +1792,23 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   const bool xl = kq * 4 < RB;
   // this lane's chunk of the tile (dest, src) in ring buffer buf
   auto xslot = [&](int buf, int dest, int src) { return a.xch + ((((long)(buf * nrb + rb) * 32 + dest) * 32 + src) * 256) + lane * 4; };
+  // RB == 8 (4x4x1 form): this lane's float4 -- rows rg*4 .. +3 of column 4 (cg & 3) + j -- sits where the 16x16 C layout keeps
+  // those rows: chunk rg*16 + 4 (cg & 3) + j of the tile for workgroup 2 w + (cg >> 2); one chunk per lane and source block
+  auto xslot8 = [&](int buf, int src) {
+    return a.xch + ((((long)(buf * nrb + rb) * 32 + (w * 2 + (x_cg >> 2))) * 32 + src) * 256) + (x_rg * 16 + (x_cg & 3) * 4 + x_j) * 4;
+  };
   // this thread's element (row, d) of this workgroup's context-gradient part in ring buffer buf
   const int prow = tid / D, pd = tid - prow * D;
   const bool pmine = tid < 16 * D;
   auto pslot = [&](int buf) { return a.parts + ((((long)(buf * nrb + rb) * 16 + j) * 16 + prow) * 64 + pd); };
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
+  for (int q = 0; q < 2; ++q) {
+    if (RB == 8) *reinterpret_cast<float4*>(xslot8(0, 2 * j + q)) = sent4;
+    else
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) if (xl) *reinterpret_cast<float4*>(xslot(0, w * NTW + t, 2 * j + q)) = sent4;
+      for (int t = 0; t < NTW; ++t) if (xl) *reinterpret_cast<float4*>(xslot(0, w * NTW + t, 2 * j + q)) = sent4;
+  }
   if (pmine) *pslot(0) = sentinel;
   tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
   for (int i = T - 1; i >= 0; --i) {
@@ -1803,32 +1828,59 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       const int par = (T - 2 - i) % 3;                       // exchange of dz_{i+1} Ur^T; also the buffer of dh_att_{i+1}
       if (i > 0) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < 2; ++q) {
+          if (RB == 8) *reinterpret_cast<float4*>(xslot8((par + 1) % 3, 2 * j + q)) = sent4;
+          else
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) if (xl) *reinterpret_cast<float4*>(xslot((par + 1) % 3, w * NTW + t, 2 * j + q)) = sent4;
+            for (int t = 0; t < NTW; ++t) if (xl) *reinterpret_cast<float4*>(xslot((par + 1) % 3, w * NTW + t, 2 * j + q)) = sent4;
+        }
       }
+      if (RB == 8) {
+        floatx4 xa[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float4 am[2];
+#pragma unroll
+          for (int kh2 = 0; kh2 < 2; ++kh2)
+            am[kh2] = *reinterpret_cast<const float4*>(dzs + (q * 16 + x_rg * 4 + x_j) * LB_DZLD + kh2 * 32 + x_cg * 4);
+          xa[q] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#define TNT_X4(k2, qd)                                                                                   \
+          xa[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(am[k2].x, bx[q][k2][qd][0], xa[q], 3, qd, 1);          \
+          xa[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(am[k2].y, bx[q][k2][qd][0], xa[q], 3, qd, 2);          \
+          xa[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(am[k2].z, bx[q][k2][qd][1], xa[q], 3, qd, 1);          \
+          xa[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(am[k2].w, bx[q][k2][qd][1], xa[q], 3, qd, 2);
+          TNT_X4(0, 0) TNT_X4(0, 1) TNT_X4(0, 2) TNT_X4(0, 3) TNT_X4(0, 4) TNT_X4(0, 5) TNT_X4(0, 6) TNT_X4(0, 7)
+          TNT_X4(1, 0) TNT_X4(1, 1) TNT_X4(1, 2) TNT_X4(1, 3) TNT_X4(1, 4) TNT_X4(1, 5) TNT_X4(1, 6) TNT_X4(1, 7)
+#undef TNT_X4
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's resets are in L2 first
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          *reinterpret_cast<float4*>(xslot8(par, 2 * j + q)) = make_float4(xa[q][0], xa[q][1], xa[q][2], xa[q][3]);
+      } else {
       floatx4 acc[2][NTW];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        float av[16];
+        for (int q = 0; q < 2; ++q) {
+          float av[16];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float4 x = *reinterpret_cast<const float4*>(dzs + (q * 16 + lr) * LB_DZLD + kq * 16 + 4 * c);
-          av[4 * c + 0] = x.x; av[4 * c + 1] = x.y; av[4 * c + 2] = x.z; av[4 * c + 3] = x.w;
+          for (int c = 0; c < 4; ++c) {
+            const float4 x = *reinterpret_cast<const float4*>(dzs + (q * 16 + lr) * LB_DZLD + kq * 16 + 4 * c);
+            av[4 * c + 0] = x.x; av[4 * c + 1] = x.y; av[4 * c + 2] = x.z; av[4 * c + 3] = x.w;
+          }
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[q][t] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bw[q][t][ks], acc[q][t], 0, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's resets are in L2 first
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[q][t] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks)
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bw[q][t][ks], acc[q][t], 0, 0, 0);
+          for (int t = 0; t < NTW; ++t)
+            if (xl) *reinterpret_cast<float4*>(xslot(par, w * NTW + t, 2 * j + q)) = make_float4(acc[q][t][0], acc[q][t][1], acc[q][t][2], acc[q][t][3]);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's resets are in L2 first
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-          if (xl) *reinterpret_cast<float4*>(xslot(par, w * NTW + t, 2 * j + q)) = make_float4(acc[q][t][0], acc[q][t][1], acc[q][t][2], acc[q][t][3]);
       LCT(17);
       // ---- gather the 32 partial tiles of each of this workgroup's two blocks: wave w sums sources w and w + 16
       // (both blocks' loads in flight together; `red` holds [2][NWB][256])
