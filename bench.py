@@ -38,13 +38,13 @@ _PMC2 = "profiles/r02_pmc_seq_poll_and_encoder.txt"
 PMC_TRAFFIC = {
     "dense": {"tnt_gemm_f32 NN 960x5001x512": (int((2 * 13029.1 + 18885.8) * 1024), "profiles/r01_gemm_head_pmc_v3.txt"),
               "tnt_lstm_seq_fwd_f32 S=16 B=64 U=512": (int((2 * 21651.0 + 14232.8) * 1024), _PMC2),
-              "tnt_lstm_seq_bwd_f32 S=16 B=64 U=512": (int((2 * 28713.9 + 25008.8) * 1024), _PMC2),
+              "tnt_lstm_seq_bwd_f32 S=16 B=64 U=512": (int((2 * 28719.7 + 23831.9) * 1024), _PMC2),
               "tnt_dense_fwd_stream_gram_f32 64x512x20000": (int((2 * 22663.2 + 2305.0) * 1024), _PMC2),
               "tnt_dense_dw_adam_f32 20000x512x64": (int((2 * 65998.5 + 120000.0) * 1024), _PMC2),
               "tnt_dense_dw_skinny_f32 20000x512x64": (int((2 * 5568.5 + 40000.0) * 1024), _PMC2)},
     "attention": {"tnt_gemm_f32 NN 960x5001x256": (int((2 * 6575.1 + 18885.0) * 1024), "profiles/r01_gemm_head_c3_pmc.txt"),
-                  "tnt_lc_seq_fwd_f32 T=15 B=64 R=360 U=512": (int((2 * 27934.6 + 19743.6) * 1024), "profiles/r02_pmc_attention_chains.txt"),
-                  "tnt_lc_seq_bwd_f32 T=15 B=64 R=360 U=512": (int((2 * 35027.5 + 45564.7) * 1024), "profiles/r02_pmc_attention_chains.txt")},
+                  "tnt_lc_seq_fwd_f32 T=15 B=64 R=360 U=512": (int((2 * 27789.2 + 18382.3) * 1024), "profiles/r02_pmc_attention_chains.txt"),
+                  "tnt_lc_seq_bwd_f32 T=15 B=64 R=360 U=512": (int((2 * 35036.1 + 48647.1) * 1024), "profiles/r02_pmc_attention_chains.txt")},
 }
 STEP_GFLOP = {"dense": 30.3, "attention": 22.0}          # SURVEY 8d, whole training step
 WORKLOAD_NAME = {
