@@ -690,6 +690,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
   float* dzs = sb_lds;                                        // [16][SB_DZLD]: this workgroup's dz tile of the previous step
   float* red = sb_lds + 16 * SB_DZLD;                         // [NWB][64][4]
   unsigned* s_slot = reinterpret_cast<unsigned*>(red + NWB * 256);
+  LST_DECL
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
   const int U = a.U, B = a.B, S = a.S;
@@ -762,6 +763,8 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
     tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
   }
   for (int s = S - 1; s >= 0; --s) {
+    const int st = S - 1 - s;          // trace step index (LST)
+    LST(8);
     // epilogue operands of this step do not depend on the chain: fetch them first
     const bool seq = s >= a.mask_s0;
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -819,6 +822,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
         for (int j = 0; j < NTW; ++j)
           if (xl) *reinterpret_cast<float4*>(xslot(par, w * NTW + j)) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
       }
+      LST(9);
       if (!POLL) tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, S - 1 - s), err);
       // ---- gather the 32 partial tiles of this workgroup's block (sc1 loads: stored by other workgroups): wave w sums
       // sources w and w + 16, the 16 wave sums are combined through LDS in fixed order
@@ -843,9 +847,11 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
           }
           if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         }
+        LST(10);
         *reinterpret_cast<float4*>(red + w * 256 + lane * 4) = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
       }
       __syncthreads();
+      LST(11);
       if (eok) {
 #pragma unroll
         for (int k = 0; k < NWB; ++k) da += red[k * 256 + ridx];
@@ -873,8 +879,10 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
       *reinterpret_cast<float4*>(a.dz + ((long)s * BU + ee) * 4) = dz4;
       *reinterpret_cast<float4*>(dzs + erow * SB_DZLD + ecol * 4) = dz4;
     }
+    LST(12);
     __syncthreads();          // the dz tile is complete before the next step's A fragments are read; `red` is free again
   }
+  LST_DUMP;
   tnt_seq_leave(a.sync, xcc, a.guard_out);
 }
 

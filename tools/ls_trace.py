@@ -1,4 +1,4 @@
-"""In-kernel phase timestamps of one step of the dense model's persistent LSTM forward (library built with -DTNT_LC_TRACE)."""
+"""In-kernel phase timestamps of one step of the dense model's persistent LSTM chains (library built with -DTNT_LC_TRACE)."""
 import ctypes, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -12,7 +12,10 @@ buf = (ctypes.c_ulonglong * 64)()
 m.be.lib.tnt_debug_ls_trace.argtypes = [ctypes.c_void_p]
 assert m.be.lib.tnt_debug_ls_trace(buf) == 0
 t = list(buf)
-names = {0: "top", 1: "h fragments in", 2: "MFMA done", 3: "partials in LDS, synced", 4: "reduced, gates", 5: "h out"}
-base = t[0]
-for k in names:
-    print(f"{names[k]:26s} {(t[k] - base) * 10:7d} ns")
+fwd = {0: "top", 1: "h fragments in", 2: "MFMA done", 3: "partials in LDS, synced", 4: "reduced, gates", 5: "h out"}
+bwd = {8: "top", 9: "MFMA done, tiles pushed", 10: "32 partial tiles in", 11: "wave sums in LDS, synced", 12: "reduced, cell backward"}
+for title, names in (("forward chain, step 5", fwd), ("BPTT chain, step 5", bwd)):
+    print(title)
+    base = t[min(names)]
+    for k in names:
+        print(f"  {names[k]:28s} {(t[k] - base) * 10:7d} ns")
