@@ -677,6 +677,16 @@ int32_t tnt_lc_seq_fwd_f32(const float* F, const float* P, const float* W2, cons
                            int32_t U, float slope, float rate_attn, float rate_in, int32_t in_lwidth, uint64_t seed,
                            uint32_t site_attn0, uint32_t site_in0, const uint32_t* step_dev, uint32_t* sync,
                            float* guard_out, void* stream);
+/* the same launch with the Dropout behind the LSTM (lc_NIC.py:256) as a rider: hd [T][B][U] (nullable) receives
+ * tnt_dropout_f32(hs[1:], rows_per_site = B, site = site_out0 + i for step i) as the states leave the chain. */
+int32_t tnt_lc_seq_fwd_drop_f32(const float* F, const float* P, const float* W2, const float* b2, const float* v,
+                                const float* bv, float* qpre, float* alpha, float* ctx, float* ctx_d,
+                                const uint8_t* keep4, int64_t keep_stride, const float* xz, const float* Wc,
+                                const float* Ur, const float* xz_bias, float* hs, float* cs, float* gates, int32_t T,
+                                int32_t B, int32_t R, int32_t D, int32_t A, int32_t U, float slope, float rate_attn,
+                                float rate_in, int32_t in_lwidth, uint64_t seed, uint32_t site_attn0,
+                                uint32_t site_in0, const uint32_t* step_dev, float* hd, float rate_out,
+                                uint32_t site_out0, uint32_t* sync, float* guard_out, void* stream);
 
 /* ---- the backward chain of the attention captioner as ONE persistent launch (tape.gradient through lc_NIC.py:244-256):
  * for i = T-1 .. 0: tnt_lstm_step_bwd_f32(dz_next = dz[i+1], dh_ext = the attention's query gradient of step i+1,
@@ -695,6 +705,16 @@ int32_t tnt_lc_seq_bwd_f32(const float* F, const float* P, const float* W2, cons
                            int32_t in_lwidth, uint64_t seed, uint32_t site_attn0, uint32_t site_in0,
                            const uint32_t* step_dev, float alpha_mse_coef, uint32_t* sync, float* guard_out,
                            void* stream);
+/* the same launch with that Dropout's backward as a rider: dout is the gradient w.r.t. the DROPPED outputs and meets the
+ * keep mask (rate_out, site_out0 + i for step i; the bits of tnt_lc_seq_fwd_drop_f32) as the chain reads it. */
+int32_t tnt_lc_seq_bwd_drop_f32(const float* F, const float* P, const float* W2, const float* v, const float* qpre,
+                                const float* alpha, const uint8_t* keep4, int64_t keep_stride, float* dP, float* dF,
+                                float* dvb, float* dqpre, const float* Ur, const float* Wc, const float* dout,
+                                const float* gates, const float* cs, float* dz, float* work, int32_t T, int32_t B,
+                                int32_t R, int32_t D, int32_t A, int32_t U, float slope, float rate_attn,
+                                float rate_in, int32_t in_lwidth, uint64_t seed, uint32_t site_attn0,
+                                uint32_t site_in0, const uint32_t* step_dev, float alpha_mse_coef, float rate_out,
+                                uint32_t site_out0, uint32_t* sync, float* guard_out, void* stream);
 
 /* ---- the attention layer's hoisted first Dense (P = LeakyReLU(F W1 + b1), attention.py:32) backward, behind the chain:
  * with dP [rows][A] the score gradient accumulated over the T steps and Ppre its pre-activation:

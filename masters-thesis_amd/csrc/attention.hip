@@ -963,6 +963,8 @@ struct LcSeqArgs {
   const float* zbias;      // [U][4]
   float* hs; float* cs;    // [T+1][B][U]
   float* gates;            // [T][B][U][4]
+  float* hd;               // nullable [T][B][U]: Dropout(hs[1:]) with one site per step (tnt_dropout_f32, rows_per_site = B)
+  float rate_out; uint32_t site_out0;
   int T;
   unsigned* sync; float* guard_out;
 };
@@ -1249,6 +1251,8 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   const long ee = (long)eb * U + eu;
   float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float cp = 0.f;
+  const uint32_t step_l = a.att.step + (a.att.step_dev ? a.att.step_dev[0] : 0u);
+  const float oscale = a.rate_out > 0.f ? 1.f / (1.f - a.rate_out) : 1.f;
   if (eok) {
     zb_l[tid] = a.zbias ? *reinterpret_cast<const float4*>(a.zbias + (long)eu * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     cp = a.cs[ee];
@@ -1263,6 +1267,9 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       zx_l[tid] = make_float4(x4.x + b4.x, x4.y + b4.y, x4.z + b4.z, x4.w + b4.w);
     }
     if (eok && i + 2 <= T) a.hs[(long)(i + 2) * BU + ee] = sentinel;
+    bool kout = true;
+    if (eok && a.hd && a.rate_out > 0.f)
+      kout = tnt_keep((uint64_t)ee, a.rate_out, a.att.seed, a.site_out0 + (uint32_t)i, step_l);
     unsigned spins = 0;
     float zs[4] = {0.f, 0.f, 0.f, 0.f};
     if (RB == 8) {
@@ -1420,6 +1427,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       a.hs[(long)(i + 1) * BU + ee] = h2;
       a.cs[(long)(i + 1) * BU + ee] = c2;
       *reinterpret_cast<float4*>(a.gates + ((long)i * BU + ee) * 4) = make_float4(gi, gf, gg, go);
+      if (a.hd) a.hd[(long)i * BU + ee] = kout ? h2 * oscale : 0.f;
       cp = c2;
       if (i + 1 < T) x4 = *reinterpret_cast<const float4*>(a.xz + ((long)(i + 1) * BU + ee) * 4);
     }
@@ -1432,15 +1440,16 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
 }
 }  // namespace
 
-extern "C" int32_t tnt_lc_seq_fwd_f32(const float* F, const float* P, const float* W2, const float* b2, const float* v,
+extern "C" int32_t tnt_lc_seq_fwd_drop_f32(const float* F, const float* P, const float* W2, const float* b2, const float* v,
                                       const float* bv, float* qpre, float* alpha, float* ctx, float* ctx_d,
                                       const uint8_t* keep4, int64_t keep_stride, const float* xz, const float* Wc,
                                       const float* Ur, const float* xz_bias, float* hs, float* cs, float* gates, int32_t T,
                                       int32_t B, int32_t R, int32_t D, int32_t A, int32_t U, float slope, float rate_attn,
                                       float rate_in, int32_t in_lwidth, uint64_t seed, uint32_t site_attn0,
-                                      uint32_t site_in0, const uint32_t* step_dev, uint32_t* sync, float* guard_out,
-                                      void* stream) {
+                                      uint32_t site_in0, const uint32_t* step_dev, float* hd, float rate_out,
+                                      uint32_t site_out0, uint32_t* sync, float* guard_out, void* stream) {
   if (T <= 0 || sync == nullptr || U != 512 || B <= 0 || B > 128) return TNT_BADARG(24);
+  if (hd && !(rate_out >= 0.f && rate_out < 1.f)) return TNT_BADARG(36);
   if (!wide_ok(R, D, A) || R > 512 || D > 64 || A > 64) return TNT_BADARG(21);
   if ((long)(T + 1) * B * U * 4 >= (1L << 32)) return TNT_BADARG(19);
   if (!tnt_aligned16(P) || !tnt_aligned16(F) || !tnt_aligned16(W2) || !tnt_aligned16(v) || !tnt_aligned16(xz) ||
@@ -1452,7 +1461,7 @@ extern "C" int32_t tnt_lc_seq_fwd_f32(const float* F, const float* P, const floa
   g.rate_attn = rate_attn; g.rate_in = rate_in; g.seed = seed; g.site_attn = site_attn0; g.site_in = site_in0; g.step = 0;
   g.step_dev = step_dev; g.keep4 = keep4;
   a.keep_stride = keep_stride; a.xz = xz; a.Wc = Wc; a.Ur = Ur; a.zbias = xz_bias; a.hs = hs; a.cs = cs; a.gates = gates;
-  a.T = T; a.sync = sync; a.guard_out = guard_out;
+  a.T = T; a.sync = sync; a.guard_out = guard_out; a.hd = hd; a.rate_out = hd ? rate_out : 0.f; a.site_out0 = site_out0;
   // row passes of the attention phase held in registers: as few as R needs (the LSTM weights are resident next to them)
   const int g4 = (A <= 32 && D <= 32) ? 8 : 16, np = (R + WT / g4 - 1) / (WT / g4);
   void (*kern)(LcSeqArgs) = nullptr;
@@ -1470,6 +1479,19 @@ extern "C" int32_t tnt_lc_seq_fwd_f32(const float* F, const float* P, const floa
   hipLaunchKernelGGL(kern, dim3(256), dim3(1024), LC_SEQ_LDS_BYTES, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int32_t tnt_lc_seq_fwd_f32(const float* F, const float* P, const float* W2, const float* b2, const float* v,
+                                      const float* bv, float* qpre, float* alpha, float* ctx, float* ctx_d,
+                                      const uint8_t* keep4, int64_t keep_stride, const float* xz, const float* Wc,
+                                      const float* Ur, const float* xz_bias, float* hs, float* cs, float* gates, int32_t T,
+                                      int32_t B, int32_t R, int32_t D, int32_t A, int32_t U, float slope, float rate_attn,
+                                      float rate_in, int32_t in_lwidth, uint64_t seed, uint32_t site_attn0,
+                                      uint32_t site_in0, const uint32_t* step_dev, uint32_t* sync, float* guard_out,
+                                      void* stream) {
+  return tnt_lc_seq_fwd_drop_f32(F, P, W2, b2, v, bv, qpre, alpha, ctx, ctx_d, keep4, keep_stride, xz, Wc, Ur, xz_bias, hs, cs,
+                                 gates, T, B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, seed, site_attn0, site_in0,
+                                 step_dev, nullptr, 0.f, 0, sync, guard_out, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1505,6 +1527,7 @@ struct LcSeqBwdArgs {
   float* xch;              // 3 * nrb * 32 * 32 * 256   partial da tiles
   float* dhx;              // 3 * B * U                 dh_att
   float* parts;            // 3 * nrb * 16 * 16 * 64    context-gradient parts
+  float rate_out; uint32_t site_out0;   // Dropout' of the LSTM outputs applied to dout as it is read (one site per step)
   int T;
   unsigned* sync; float* guard_out;
 };
@@ -1785,6 +1808,8 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   const int eb = rb * RB + erow, eu = (2 * j + eq) * 16 + ecol;
   const bool eok = tid < 512 && erow < RB && eb < B;
   const long ee = (long)eb * U + eu;
+  const uint32_t step_l = a.att.step + (a.att.step_dev ? a.att.step_dev[0] : 0u);
+  const float oscale = a.rate_out > 0.f ? 1.f / (1.f - a.rate_out) : 1.f;
   const int ridx = ((erow >> 2) * 16 + ecol) * 4 + (erow & 3);
   float dc_c = 0.f;
   // with row blocks of 8 samples only the half of a partial tile that holds rows < 8 (lanes 0..31 of the MFMA's C layout) is
@@ -1820,6 +1845,8 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       g4 = *reinterpret_cast<const float4*>(a.gates + ((long)i * BU + ee) * 4);
       cval = a.cs[(long)(i + 1) * BU + ee]; cprev = a.cs[(long)i * BU + ee];
       dout_t = a.dout[(long)i * BU + ee];
+      if (a.rate_out > 0.f)
+        dout_t = tnt_keep((uint64_t)ee, a.rate_out, a.att.seed, a.site_out0 + (uint32_t)i, step_l) ? dout_t * oscale : 0.f;
     }
     LCT(16);
     if (pmine && i > 0) *pslot(pn) = sentinel;
@@ -1998,15 +2025,16 @@ extern "C" int32_t tnt_lc_seq_bwd_work_floats(int32_t B, int32_t U) {
   return 3 * nrb * 32 * 32 * 256 + 3 * B * U + 3 * nrb * 16 * 16 * 64;
 }
 
-extern "C" int32_t tnt_lc_seq_bwd_f32(const float* F, const float* P, const float* W2, const float* v, const float* qpre,
+extern "C" int32_t tnt_lc_seq_bwd_drop_f32(const float* F, const float* P, const float* W2, const float* v, const float* qpre,
                                       const float* alpha, const uint8_t* keep4, int64_t keep_stride, float* dP, float* dF,
                                       float* dvb, float* dqpre, const float* Ur, const float* Wc, const float* dout,
                                       const float* gates, const float* cs, float* dz, float* work, int32_t T, int32_t B,
                                       int32_t R, int32_t D, int32_t A, int32_t U, float slope, float rate_attn,
                                       float rate_in, int32_t in_lwidth, uint64_t seed, uint32_t site_attn0,
-                                      uint32_t site_in0, const uint32_t* step_dev, float alpha_mse_coef, uint32_t* sync,
-                                      float* guard_out, void* stream) {
+                                      uint32_t site_in0, const uint32_t* step_dev, float alpha_mse_coef, float rate_out,
+                                      uint32_t site_out0, uint32_t* sync, float* guard_out, void* stream) {
   if (T <= 0 || sync == nullptr || work == nullptr || U != 512 || B <= 0 || B > 128) return TNT_BADARG(24);
+  if (!(rate_out >= 0.f && rate_out < 1.f)) return TNT_BADARG(36);
   if (!wide_ok(R, D, A) || R > 512 || D > 64 || A > 64) return TNT_BADARG(21);
   if ((long)(T + 1) * B * U * 4 >= (1L << 32)) return TNT_BADARG(19);
   if (!tnt_aligned16(P) || !tnt_aligned16(F) || !tnt_aligned16(W2) || !tnt_aligned16(v) || !tnt_aligned16(dP) ||
@@ -2022,6 +2050,7 @@ extern "C" int32_t tnt_lc_seq_bwd_f32(const float* F, const float* P, const floa
   const bool rb8 = B <= 64 && !rb16;
   const int64_t nrb = rb8 ? (B + 7) / 8 : (B + 15) / 16;
   a.keep_stride = keep_stride; a.Ur = Ur; a.Wc = Wc; a.dout = dout; a.gates = gates; a.cs = cs; a.dz = dz;
+  a.rate_out = rate_out; a.site_out0 = site_out0;
   a.xch = work; a.dhx = work + 3 * nrb * 32 * 32 * 256; a.parts = a.dhx + 3 * (int64_t)B * U;
   a.T = T; a.sync = sync; a.guard_out = guard_out;
   const int g4 = (A <= 32 && D <= 32) ? 8 : 16, np = (R + WT / g4 - 1) / (WT / g4);
@@ -2039,4 +2068,17 @@ extern "C" int32_t tnt_lc_seq_bwd_f32(const float* F, const float* P, const floa
   hipLaunchKernelGGL(kern, dim3(256), dim3(1024), LB_LDS_BYTES, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int32_t tnt_lc_seq_bwd_f32(const float* F, const float* P, const float* W2, const float* v, const float* qpre,
+                                      const float* alpha, const uint8_t* keep4, int64_t keep_stride, float* dP, float* dF,
+                                      float* dvb, float* dqpre, const float* Ur, const float* Wc, const float* dout,
+                                      const float* gates, const float* cs, float* dz, float* work, int32_t T, int32_t B,
+                                      int32_t R, int32_t D, int32_t A, int32_t U, float slope, float rate_attn,
+                                      float rate_in, int32_t in_lwidth, uint64_t seed, uint32_t site_attn0,
+                                      uint32_t site_in0, const uint32_t* step_dev, float alpha_mse_coef, uint32_t* sync,
+                                      float* guard_out, void* stream) {
+  return tnt_lc_seq_bwd_drop_f32(F, P, W2, v, qpre, alpha, keep4, keep_stride, dP, dF, dvb, dqpre, Ur, Wc, dout, gates, cs, dz,
+                                 work, T, B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, seed, site_attn0, site_in0,
+                                 step_dev, alpha_mse_coef, 0.f, 0, sync, guard_out, stream);
 }

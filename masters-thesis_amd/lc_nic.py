@@ -529,17 +529,23 @@ class NIC(ModelBase):
             # the T attention -> LSTM steps as ONE persistent launch (tnt_lc_seq_fwd_f32), XCD-local data-polling hand-offs
             r_in = self.r_lstm if training else 0.0
             keep = self.att_keep if (training and self._keep_stored) else None
+            # (with the Dropout behind the LSTM, :256, as a rider of the same launch: Hd leaves the chain with hs)
+            self._out_dropped = bool(training and self.r_lstm > 0 and (int(getattr(self, "fuse_out_drop", 3)) & 1))
             be.lc_seq_fwd(self.F, self.P, a.p("attention/W2/kernel"), a.p("attention/W2/bias"), a.p("attention/V/kernel"),
                           a.p("attention/V/bias"), self.qpre, self.alpha, self.ctx, self.ctx_d, keep,
                           B * R * A // 4 if keep is not None else 0, self.XZ, Wl[:D], a.p("lstm/recurrent_kernel"),
                           a.p("lstm/bias"), self.Hs, self.Cs, self.gates, T, B, R, D, A, U, 0.2,
                           self.r_attn if training else 0.0, r_in, D + Et, self.seed, S_ATTN, S_LSTM_IN, self.drop_step,
-                          self.seq_sync, self._guard_out())
+                          self.seq_sync, self._guard_out(),
+                          out_drop=(self.Hd, self.r_lstm, S_LSTM_OUT) if self._out_dropped else None)
         else:
+            self._out_dropped = False
             for i in range(T):                                                                  # :244-256
                 self._decode_step(i, B, training, xz_bias=a.p("lstm/bias"))
         hs = self.Hs[1:].view(n, U)
-        if training and self.r_lstm > 0:                                                        # :256
+        if self._out_dropped:
+            hs = self.Hd
+        elif training and self.r_lstm > 0:                                                      # :256
             be.dropout(hs, self.Hd, n, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds, rows_per_site=B)
             hs = self.Hd
         self._hs_used = hs
@@ -615,8 +621,15 @@ class NIC(ModelBase):
             self.gemm_sk(hs, self.dinter, a.g("time_distributed_nonlinear/kernel"), U, H, n, U, H, H, transA=True)
             be.colsum(self.dinter, a.g("time_distributed_nonlinear/bias"), n, H, H, self.work)
         self.gemm_sk(self.dinter, a.p("time_distributed_nonlinear/kernel"), self.dHs, n, U, H, H, H, U, transB=True)
-        if self.r_lstm > 0:
+        self._dout_masked = not (self.r_lstm > 0 and self._lc_seq_bwd_ok() and (int(getattr(self, "fuse_out_drop", 3)) & 2))
+        if self.r_lstm > 0 and self._dout_masked:           # (else Dropout' rides in the backward chain: tnt_lc_seq_bwd_drop_f32)
             be.dropout(self.dHs, self.dHs, n, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds, rows_per_site=B)
+
+    def _lc_seq_bwd_ok(self):
+        """the persistent backward-chain kernel applies (it keeps a sample's P, F and dF rows in LDS:
+        R (A + 2 D) <= 35 K floats, tnt_lc_seq_bwd_f32)."""
+        return bool(not self.use_layer_norm and self._lc_seq_ok() and self.__dict__.get("lc_xch") is not None
+                    and getattr(self, "use_lc_seq_bwd", True) and self.R * (self.A + 2 * self.D) <= 35 * 1024)
 
     def _bwd_chain(self, B, T):
         """the T-step chain (LSTM step backward -> attention step backward) and the LSTM parameter gradients."""
@@ -629,16 +642,15 @@ class NIC(ModelBase):
         W2, v = a.p("attention/W2/kernel"), a.p("attention/V/kernel")
         if self.use_layer_norm:
             return self._bwd_chain_ln(B, T)
-        # (the backward kernel keeps the sample's P, F and dF rows in LDS: R (A + 2 D) <= 35 K floats, tnt_lc_seq_bwd_f32)
-        if (self._lc_seq_ok() and self.__dict__.get("lc_xch") is not None and getattr(self, "use_lc_seq_bwd", True)
-                and R * (A + 2 * D) <= 35 * 1024):
+        if self._lc_seq_bwd_ok():
             # the T LSTM-backward -> attention-backward steps as ONE persistent launch (tnt_lc_seq_bwd_f32): role-specialised
             # workgroups per XCD, dP / dF / dvb accumulated on chip and written once
             keep = self.att_keep if self._keep_stored else None
             be.lc_seq_bwd(self.F, self.P, W2, v, self.qpre, self.alpha, keep, B * R * A // 4 if keep is not None else 0,
                           self.dP, self.dF, self.dvb, self.dqpre, Ur, Wl[:D], self.dHs, self.gates, self.Cs, self.dZ,
                           self.lc_xch, T, B, R, D, A, U, 0.2, self.r_attn, self.r_lstm, D + Et, sd, S_ATTN, S_LSTM_IN, ds,
-                          self._alpha_mse, self.seq_sync, self._guard_out())
+                          self._alpha_mse, self.seq_sync, self._guard_out(),
+                          out_drop=None if self.__dict__.get("_dout_masked", True) else (self.r_lstm, S_LSTM_OUT))
         else:
             self._bwd_chain_steps(B, T, Wl, Ur, W2, v)
         hprev = self.Hs[:T].view(n, U)

@@ -302,7 +302,16 @@ class HipBackend:
 
     def lc_seq_fwd(self, F, P, W2, b2, v, bv, qpre, alpha, ctx, ctx_d, keep4, keep_stride, xz, Wc, Ur, xz_bias, hs, cs, gates, T,
                    B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, seed, site_attn0, site_in0, step_dev, sync,
-                   guard_out=None):
+                   guard_out=None, out_drop=None):
+        """out_drop = (hd, rate, site0): the Dropout behind the LSTM rides in the chain (tnt_lc_seq_fwd_drop_f32)."""
+        if out_drop is not None:
+            hd, rate_out, site_out0 = out_drop
+            self._call(self.lib.tnt_lc_seq_fwd_drop_f32, "tnt_lc_seq_fwd_drop_f32", _p(F), _p(P), _p(W2), _p(b2), _p(v), _p(bv),
+                       _p(qpre), _p(alpha), _p(ctx), _p(ctx_d), _p(keep4), int(keep_stride), _p(xz), _p(Wc), _p(Ur), _p(xz_bias),
+                       _p(hs), _p(cs), _p(gates), T, B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, int(seed),
+                       int(site_attn0), int(site_in0), _p(step_dev), _p(hd), float(rate_out), int(site_out0), _p(sync),
+                       _p(guard_out), self._s())
+            return
         self._call(self.lib.tnt_lc_seq_fwd_f32, "tnt_lc_seq_fwd_f32", _p(F), _p(P), _p(W2), _p(b2), _p(v), _p(bv), _p(qpre), _p(alpha),
                    _p(ctx), _p(ctx_d), _p(keep4), int(keep_stride), _p(xz), _p(Wc), _p(Ur), _p(xz_bias), _p(hs), _p(cs), _p(gates),
                    T, B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, int(seed), int(site_attn0), int(site_in0),
@@ -313,7 +322,16 @@ class HipBackend:
 
     def lc_seq_bwd(self, F, P, W2, v, qpre, alpha, keep4, keep_stride, dP, dF, dvb, dqpre, Ur, Wc, dout, gates, cs, dz, work, T,
                    B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, seed, site_attn0, site_in0, step_dev, alpha_mse, sync,
-                   guard_out=None):
+                   guard_out=None, out_drop=None):
+        """out_drop = (rate, site0): dout is the gradient of the DROPPED outputs (tnt_lc_seq_bwd_drop_f32)."""
+        if out_drop is not None:
+            rate_out, site_out0 = out_drop
+            self._call(self.lib.tnt_lc_seq_bwd_drop_f32, "tnt_lc_seq_bwd_drop_f32", _p(F), _p(P), _p(W2), _p(v), _p(qpre),
+                       _p(alpha), _p(keep4), int(keep_stride), _p(dP), _p(dF), _p(dvb), _p(dqpre), _p(Ur), _p(Wc), _p(dout),
+                       _p(gates), _p(cs), _p(dz), _p(work), T, B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, int(seed),
+                       int(site_attn0), int(site_in0), _p(step_dev), float(alpha_mse), float(rate_out), int(site_out0),
+                       _p(sync), _p(guard_out), self._s())
+            return
         self._call(self.lib.tnt_lc_seq_bwd_f32, "tnt_lc_seq_bwd_f32", _p(F), _p(P), _p(W2), _p(v), _p(qpre), _p(alpha), _p(keep4),
                    int(keep_stride), _p(dP), _p(dF), _p(dvb), _p(dqpre), _p(Ur), _p(Wc), _p(dout), _p(gates), _p(cs), _p(dz),
                    _p(work), T, B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, int(seed), int(site_attn0), int(site_in0),

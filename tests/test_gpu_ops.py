@@ -1132,12 +1132,19 @@ def test_lc_seq_fwd_equals_step_kernels(be, T, B, R, D, A, r_attn, r_in):
         be.lstm_step_fwd(xz[i], ref["hs"][i], ref["cs"][i], Ur, ref["ctx_d"][i], Wc, D, None, 0, 0, None, ref["hs"][i + 1],
                          ref["cs"][i + 1], None, ref["gates"][i], B, U, xz_bias=zb)
     sync, guard = torch.zeros(1025, dtype=torch.int32, device="cuda"), torch.zeros(1, device="cuda")
+    hd, hd_ref = torch.full((T, B, U), float("nan"), device="cuda"), torch.zeros(T, B, U, device="cuda")
     for rep in range(2):                             # the second launch starts from the state the first one left
+        # (the second one with the output Dropout riding along: tnt_lc_seq_fwd_drop_f32, one site per step from 77)
         be.lc_seq_fwd(F, P, W2, b2, v, bv, got["qpre"], got["alpha"], got["ctx"], got["ctx_d"], keep,
                       B * R * A // 4 if keep is not None else 0, xz, Wc, Ur, zb, got["hs"], got["cs"], got["gates"], T, B, R, D,
-                      A, U, 0.2, r_attn, r_in, lw, seed, s_att, s_in, step_dev, sync, guard)
+                      A, U, 0.2, r_attn, r_in, lw, seed, s_att, s_in, step_dev, sync, guard,
+                      out_drop=(hd, 0.3, 77) if rep else None)
         torch.cuda.synchronize()
         assert int(sync[1024]) == 0 and float(guard) == 0.0
+        if rep:
+            be.dropout(got["hs"][1:].view(T * B, U), hd_ref.view(T * B, U), T * B, U, U, 0, U, 0, 0.3, seed, 77, 0, step_dev,
+                       rows_per_site=B)
+            assert torch.equal(hd, hd_ref) and 0.2 < float((hd == 0).float().mean()) < 0.4
         for k in ref:
             d = (got[k] - ref[k]).abs().max().item()
             assert d <= 2e-5 * max(1.0, ref[k].abs().max().item()), (k, d)
@@ -1166,6 +1173,9 @@ def test_lc_seq_bwd_equals_step_kernels(be, T, B, R, D, A, r_attn, r_in, mse):
     cs = f(T + 1, B, U, sc=0.5)
     seed, s_att, s_in, lw = 4711, 16, 48, D + 20
     step_dev = torch.tensor([3], dtype=torch.int32, device="cuda")
+    dout_raw = dout
+    dout = torch.empty_like(dout_raw)                        # Dropout' behind the LSTM: one site per step from 77
+    be.dropout(dout_raw.view(T * B, U), dout.view(T * B, U), T * B, U, U, 0, U, 0, 0.3, seed, 77, 0, step_dev, rows_per_site=B)
     keep = None
     if r_attn > 0 and T != 2:
         keep = torch.zeros(T, B * R * A // 4, dtype=torch.uint8, device="cuda")
@@ -1192,9 +1202,10 @@ def test_lc_seq_bwd_equals_step_kernels(be, T, B, R, D, A, r_attn, r_in, mse):
         g_dz, g_dq = torch.full((T, B, U, 4), nan, device="cuda"), torch.full((T, B, A), nan, device="cuda")
         g_dP, g_dF, g_dvb = (torch.full((B, R, A), nan, device="cuda"), torch.full((B, R, D), nan, device="cuda"),
                              torch.full((B, A + 1), nan, device="cuda"))
+        # (the second launch receives the UNMASKED output gradient and applies Dropout' itself: tnt_lc_seq_bwd_drop_f32)
         be.lc_seq_bwd(F, P, W2, v, qpre, alpha, keep, B * R * A // 4 if keep is not None else 0, g_dP, g_dF, g_dvb, g_dq, Ur, Wc,
-                      dout, gates, cs, g_dz, work, T, B, R, D, A, U, 0.2, r_attn, r_in, lw, seed, s_att, s_in, step_dev, mse,
-                      sync, guard)
+                      dout_raw if rep else dout, gates, cs, g_dz, work, T, B, R, D, A, U, 0.2, r_attn, r_in, lw, seed, s_att,
+                      s_in, step_dev, mse, sync, guard, out_drop=(0.3, 77) if rep else None)
         torch.cuda.synchronize()
         assert int(sync[1024]) == 0 and float(guard) == 0.0
         for name, got, ref in (("dz", g_dz, r_dz), ("dqpre", g_dq, r_dq), ("dP", g_dP, r_dP), ("dF", g_dF, r_dF),
