@@ -109,6 +109,13 @@ int32_t tnt_dropout_f32(const float* x, float* y, int32_t rows, int32_t cols, in
                         int32_t tmajor_B, int32_t lwidth, int32_t lcol0, int32_t rows_per_site,
                         float rate, uint64_t seed, uint32_t site, uint32_t step,
                         const uint32_t* step_dev, void* stream);
+/* tnt_dropout_f32 (vector form only: cols, ld, lwidth, lcol0 % 4 == 0, 16-byte aligned x / y) with the partials of
+ * tnt_attention_metric_f32(out = NULL) as extra workgroups of the same launch: partial[tnt_attention_metric_parts(T, R)]
+ * from alpha [T][B][R] (lc_NIC.py:365-367). */
+int32_t tnt_dropout_metric_f32(const float* x, float* y, int32_t rows, int32_t cols, int32_t ld, int32_t tmajor_B,
+                               int32_t lwidth, int32_t lcol0, int32_t rows_per_site, float rate, uint64_t seed,
+                               uint32_t site, uint32_t step, const uint32_t* step_dev, const float* alpha,
+                               float* partial, int32_t T, int32_t B, int32_t R, void* stream);
 /* y = mask_b(mask_a(x)): two Dropout masks over the same matrix in one launch, each with its own logical layout, rate and
  * site (arguments as in tnt_dropout_f32, suffix _a / _b), same seed and step -- bit-identical to the two tnt_dropout_f32
  * calls it replaces (the LSTM input mask and the Embedding Dropout of the text rows in the backward pass,

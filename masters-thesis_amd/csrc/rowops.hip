@@ -496,6 +496,73 @@ extern "C" int32_t tnt_dropout_f32(const float* x, float* y, int32_t rows, int32
   return 0;
 }
 
+// tnt_dropout_f32 (vector form) with the attention metric's partials as a rider: blocks [0, nd) are dropout4_kernel with a
+// grid of nd, blocks [nd, nd + T * nc) are attention_metric_kernel's workgroup (t, c) -- partial[t * nc + c] = sum over its
+// 64 regions r of (1 - sum_b alpha[t][b][r])^2, the same summation order (attention.hip).
+__global__ __launch_bounds__(256) void dropout4_metric_kernel(DropArgs a, int nd, const float* alpha, float* partial, int B,
+                                                              int R, int nc) {
+  if ((int)blockIdx.x >= nd) {
+    __shared__ float sb[4][64];
+    const int k = blockIdx.x - nd, t = k / nc, c = k % nc, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = c * 64 + lane;
+    float s = 0.f;
+    if (r < R) {
+#pragma unroll 8
+      for (int b = w; b < B; b += 4) s += alpha[((long)t * B + b) * R + r];
+    }
+    sb[w][lane] = s;
+    __syncthreads();
+    if (w != 0) return;
+    float acc = 0.f;
+    if (r < R) {
+      const float tot = ((sb[0][lane] + sb[1][lane]) + sb[2][lane]) + sb[3][lane];
+      acc = (1.f - tot) * (1.f - tot);
+    }
+    acc = tnt_wave_sum(acc);
+    if (lane == 0) partial[k] = acc;
+    return;
+  }
+  const uint32_t step = a.step + (a.step_dev ? a.step_dev[0] : 0u);
+  const int c4n = a.cols >> 2;
+  const long total = (long)a.rows * c4n;
+  const int T = a.tB > 0 ? a.rows / a.tB : 0;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)nd * 256) {
+    const int r = (int)(e / c4n), c = (int)(e % c4n) * 4;
+    long lrow; uint32_t site;
+    drop_row(a, r, T, lrow, site);
+    const uint64_t le = (uint64_t)lrow * (uint64_t)a.lwidth + (uint64_t)(a.lcol0 + c);
+    bool k[4];
+    tnt_keep4(le, a.rate, a.seed, site, step, k);
+    const long o = (long)r * a.ld + c;
+    const float4 v = *reinterpret_cast<const float4*>(a.x + o);
+    float4 w;
+    w.x = k[0] ? v.x * a.scale : 0.f; w.y = k[1] ? v.y * a.scale : 0.f;
+    w.z = k[2] ? v.z * a.scale : 0.f; w.w = k[3] ? v.w * a.scale : 0.f;
+    *reinterpret_cast<float4*>(a.y + o) = w;
+  }
+}
+
+extern "C" int32_t tnt_dropout_metric_f32(const float* x, float* y, int32_t rows, int32_t cols, int32_t ld, int32_t tmajor_B,
+                                          int32_t lwidth, int32_t lcol0, int32_t rows_per_site, float rate, uint64_t seed,
+                                          uint32_t site, uint32_t step, const uint32_t* step_dev, const float* alpha,
+                                          float* partial, int32_t T, int32_t B, int32_t R, void* stream) {
+  if (rows <= 0 || cols <= 0 || T <= 0 || B <= 0 || R <= 0 || alpha == nullptr || partial == nullptr) return TNT_BADARG(3);
+  const int rsite = rows_per_site > 0 ? rows_per_site : rows;
+  if (tmajor_B > 0 && rsite % tmajor_B != 0) return TNT_BADARG(6);
+  if (rows_per_site > 0 && tmajor_B > 0) return TNT_BADARG(9);
+  if (((cols | ld | lwidth | lcol0) & 3) != 0 || !tnt_aligned16(x) || !tnt_aligned16(y)) return TNT_BADARG(1);
+  if (!(rate >= 0.f && rate < 1.f)) return TNT_BADARG(10);
+  DropArgs a;
+  a.x = x; a.y = y; a.rows = rows; a.cols = cols; a.ld = ld; a.tB = tmajor_B; a.lwidth = lwidth; a.lcol0 = lcol0;
+  a.rows_per_site = rows_per_site; a.rate = rate; a.scale = 1.0f / (1.0f - rate); a.seed = seed; a.site = site;
+  a.step = step; a.step_dev = step_dev;
+  const int nd = ew_blocks((long)rows * (cols / 4)), nc = (R + 63) / 64;
+  hipLaunchKernelGGL(dropout4_metric_kernel, dim3(nd + T * nc), dim3(256), 0, tnt_stream(stream), a, nd, alpha, partial, B, R,
+                     nc);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
 // y = mask_b(mask_a(x)) in one launch: two Dropout masks over the same [rows][cols] matrix, each with its own logical layout
 // (tmajor_B / lwidth / lcol0 / rows_per_site as in tnt_dropout_f32), rate and site; same seed and step.  Vectorised only:
 // cols, ld, lwidth*, lcol0* % 4 == 0 and 16-byte aligned x / y (else TNT_BADARG: issue two tnt_dropout_f32 calls).

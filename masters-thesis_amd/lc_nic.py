@@ -552,8 +552,17 @@ class NIC(ModelBase):
         self.gemm_sk(hs, a.p("time_distributed_nonlinear/kernel"), self.inter, n, H, U, U, H, H,
                 bias=a.p("time_distributed_nonlinear/bias"), pre=self.ipre, act=ACT_LEAKY, slope=0.2)
         inter = self.inter
+        self._metric_parts_ready = False
         if training and self.r_out > 0:
-            be.dropout(self.inter, self.inter_d, n, H, H, B, H, 0, self.r_out, sd, S_OUT, 0, ds)
+            npart = be.attention_metric_parts(T, self.R) if hasattr(be, "dropout_metric") else 0
+            if (self.S == 1 and self.__dict__.get("_defer_sum2") and getattr(self, "fuse_metric_rider", True) and H % 4 == 0
+                    and 0 < npart <= self.metric_part.numel()):
+                # the attention metric's partials (:365-367) ride in this launch: alpha is complete behind the chain
+                be.dropout_metric(self.inter, self.inter_d, n, H, H, B, H, 0, self.r_out, sd, S_OUT, 0, ds, self.alpha,
+                                  self.metric_part, T, B, self.R)
+                self._metric_parts_ready = True
+            else:
+                be.dropout(self.inter, self.inter_d, n, H, H, B, H, 0, self.r_out, sd, S_OUT, 0, ds)
             inter = self.inter_d
         self._inter_used = inter
         self.gemm_sk(inter, a.p("time_distributed_softmax/kernel"), self.logits, n, V, H, H, ldV, ldV,
@@ -573,7 +582,8 @@ class NIC(ModelBase):
             npart = be.attention_metric_parts(T, self.R) if hasattr(be, "attention_metric_parts") else 0
             if self.__dict__.get("_defer_sum2") and want_grad and 0 < npart <= self.metric_part.numel():
                 # fused single-process step: partials only, their total rides in the step-finalize launch
-                be.attention_metric(self.alpha, None, self.metric_part, T, B, self.R)
+                if not self.__dict__.get("_metric_parts_ready"):
+                    be.attention_metric(self.alpha, None, self.metric_part, T, B, self.R)
                 self._metric_deferred = (self.metric_part, self.met[3:4], npart, 1.0 / (T * self.R))
             else:
                 be.attention_metric(self.alpha, self.met[3:4], self.metric_part, T, B, self.R)              # :365-367

@@ -78,6 +78,12 @@ class HipBackend:
         self._call(self.lib.tnt_dropout_f32, "tnt_dropout_f32", _p(x), _p(y), rows, cols, ld, tmajor_B, lwidth, lcol0, rows_per_site,
                                             rate, seed, site, step, _p(step_dev), self._s())
 
+    def dropout_metric(self, x, y, rows, cols, ld, tmajor_B, lwidth, lcol0, rate, seed, site, step, step_dev, alpha, partial,
+                       T, B, R, rows_per_site=0):
+        """dropout + the attention metric's partials (attention_metric(out=None)) in one launch"""
+        self._call(self.lib.tnt_dropout_metric_f32, "tnt_dropout_metric_f32", _p(x), _p(y), rows, cols, ld, tmajor_B, lwidth,
+                   lcol0, rows_per_site, rate, seed, site, step, _p(step_dev), _p(alpha), _p(partial), T, B, R, self._s())
+
     def dropout2(self, x, y, rows, cols, ld, mask_a, mask_b, seed, step, step_dev=None):
         """two masks in one pass; mask_* = (tmajor_B, lwidth, lcol0, rows_per_site, rate, site)"""
         self._call(self.lib.tnt_dropout2_f32, "tnt_dropout2_f32", _p(x), _p(y), rows, cols, ld, *[v for m in (mask_a, mask_b)

@@ -1685,3 +1685,23 @@ def test_sync_batchnorm_pieces(be, rows, C):
         be.batchnorm_dx(dev(dy[sl]), C, xh, dev(gamma), inv, sums[:C], sums[C:], dx, rows, C, 2 * rows)
         close(dx, dx_w[sl].cpu().numpy(), rtol=5e-5)
     close(sums[:C], dg_w.cpu().numpy(), rtol=2e-5); close(sums[C:], db_w.cpu().numpy(), rtol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B,R", [(5, 8, 30), (15, 64, 360), (3, 5, 129)])
+def test_dropout_metric_rider(be, T, B, R):
+    """tnt_dropout_metric_f32 = tnt_dropout_f32 + the partials of tnt_attention_metric_f32 in one launch: both bit-identical
+    to the separate launches (time-major logical layout of the head's Dropout, lc_NIC.py:259)."""
+    rng = np.random.default_rng(T + B + R)
+    H = 64
+    x = dev(rng.standard_normal((T * B, H)))
+    alpha = dev(O.softmax(rng.standard_normal((T, B, R)), axis=-1))
+    step_dev = torch.tensor([5], dtype=torch.int32, device="cuda")
+    y0, y1 = torch.zeros_like(x), torch.full_like(x, float("nan"))
+    npart = be.attention_metric_parts(T, R)
+    p0, p1 = torch.zeros(npart, device="cuda"), torch.full((npart,), float("nan"), device="cuda")
+    be.dropout(x, y0, T * B, H, H, B, H, 0, 0.4, 99, 7, 0, step_dev)
+    be.attention_metric(alpha, None, p0, T, B, R)
+    be.dropout_metric(x, y1, T * B, H, H, B, H, 0, 0.4, 99, 7, 0, step_dev, alpha, p1, T, B, R)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(p0, p1)
