@@ -1845,8 +1845,6 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       g4 = *reinterpret_cast<const float4*>(a.gates + ((long)i * BU + ee) * 4);
       cval = a.cs[(long)(i + 1) * BU + ee]; cprev = a.cs[(long)i * BU + ee];
       dout_t = a.dout[(long)i * BU + ee];
-      if (a.rate_out > 0.f)
-        dout_t = tnt_keep((uint64_t)ee, a.rate_out, a.att.seed, a.site_out0 + (uint32_t)i, step_l) ? dout_t * oscale : 0.f;
     }
     LCT(16);
     if (pmine && i > 0) *pslot(pn) = sentinel;
@@ -1940,6 +1938,9 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
         }
       }
       LCT(18);
+      // (Dropout' of the LSTM outputs: the Philox call sits in front of the wait for the attention role)
+      if (eok && a.rate_out > 0.f)
+        dout_t = tnt_keep((uint64_t)ee, a.rate_out, a.att.seed, a.site_out0 + (uint32_t)i, step_l) ? dout_t * oscale : 0.f;
       // ---- the attention's query gradient of the step behind: dh_att_{i+1} = dq_{i+1} W2^T for this workgroup's units
       // (dq of the 16 samples from buffer par, thread = (row, a))
       {
@@ -1964,6 +1965,8 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
         }
       }
       LCT(19);
+    } else if (eok && a.rate_out > 0.f) {                    // the first step of the chain has no hand-off to wait for
+      dout_t = tnt_keep((uint64_t)ee, a.rate_out, a.att.seed, a.site_out0 + (uint32_t)i, step_l) ? dout_t * oscale : 0.f;
     }
     // ---- cell backward (the arithmetic of bwd_epilogue, lstm.hip)
     __syncthreads();          // every wave has read the dz tiles of the step behind (MFMA operands) before they are rewritten
