@@ -43,8 +43,8 @@ PMC_TRAFFIC = {
               "tnt_dense_dw_adam_f32 20000x512x64": (int((2 * 65998.5 + 120000.0) * 1024), _PMC2),
               "tnt_dense_dw_skinny_f32 20000x512x64": (int((2 * 5568.5 + 40000.0) * 1024), _PMC2)},
     "attention": {"tnt_gemm_f32 NN 960x5001x256": (int((2 * 6575.1 + 18885.0) * 1024), "profiles/r01_gemm_head_c3_pmc.txt"),
-                  "tnt_lc_seq_fwd_f32 T=15 B=64 R=360 U=512": (int((2 * 27789.2 + 18382.3) * 1024), "profiles/r02_pmc_attention_chains.txt"),
-                  "tnt_lc_seq_bwd_f32 T=15 B=64 R=360 U=512": (int((2 * 35036.1 + 48647.1) * 1024), "profiles/r02_pmc_attention_chains.txt")},
+                  "tnt_lc_seq_fwd_drop_f32 T=15 B=64 R=360 U=512": (int((2 * 27789.2 + 18382.3) * 1024), "profiles/r02_pmc_attention_chains.txt"),
+                  "tnt_lc_seq_bwd_drop_f32 T=15 B=64 R=360 U=512": (int((2 * 35036.1 + 48647.1) * 1024), "profiles/r02_pmc_attention_chains.txt")},
 }
 STEP_GFLOP = {"dense": 30.3, "attention": 22.0}          # SURVEY 8d, whole training step
 WORKLOAD_NAME = {
@@ -162,10 +162,13 @@ def _work_model(name, a):
     if name in ("tnt_lstm_seq_fwd_f32", "tnt_lstm_seq_bwd_f32"):
         S, Bq, Uq = a[10], a[11], a[12]
         return f"{name} S={S} B={Bq} U={Uq}", 2.0 * S * Bq * 4 * Uq * Uq, 0.0
-    if name in ("tnt_lc_seq_fwd_f32", "tnt_lc_seq_bwd_f32"):       # config 3's chains: LSTM step + attention step, T times
+    if name in ("tnt_lc_seq_fwd_f32", "tnt_lc_seq_bwd_f32", "tnt_lc_seq_fwd_drop_f32", "tnt_lc_seq_bwd_drop_f32"):
+        # config 3's chains: LSTM step + attention step, T times (the _drop forms carry the LSTM-output Dropout as a
+        # rider; T, B, R, D, A, U sit at the same argument positions in all four, include/tnt_hip.h)
         Tq, Bq, R, D, A, Uq = a[19:25]
+        fwd = "_fwd_" in name
         lstm = 2.0 * Bq * 4 * Uq * (Uq + D)
-        att = (2.0 * Bq * Uq * A + 2.0 * Bq * R * (A + D)) * (1 if name.endswith("fwd_f32") else 2)
+        att = (2.0 * Bq * Uq * A + 2.0 * Bq * R * (A + D)) * (1 if fwd else 2)
         return f"{name} T={Tq} B={Bq} R={R} U={Uq}", Tq * (lstm + att), 0.0
     if name == "tnt_dense_dw_skinny_f32":
         Nq, Eq, Bk = a[3], a[4], a[5]
@@ -253,10 +256,11 @@ def kernel_breakdown(model, batch, workload, reps=20, limit=12):
                 row["traffic_source"] = pmc[1]
         out.append(row)
     out.sort(key=lambda r: -r["us_per_step"])
-    priced = [r for r in out if "bound" in r]
-    dom = priced[0] if priced else {"kernel": out[0]["kernel"], "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": None, "traffic": None}
-    others = [r for r in out if r is not dom][:limit]
+    dom = out[0]                       # the call group with the most device time per step, whatever it is
+    if "bound" not in dom:
+        raise RuntimeError(f"bench.py: the dominant call group '{dom['kernel']}' ({dom['us_per_step']} us/step) has no "
+                           "work model in _work_model(); price it before reporting a roofline")
+    others = out[1:1 + limit]
     total = round(sum(r["us_per_step"] for r in out), 1)
     return dom, others, total
 
