@@ -205,6 +205,8 @@ class H5File:
         if shape is None:
             return name, None
         n = int(np.prod(shape)) if shape else 1
+        if n == 0:                                            # h5py stores `weight_names = []` (a Dropout / InputLayer
+            return name, []                                   # group) as an empty float64 attribute of shape (0,)
         arr = np.frombuffer(b, dtype=dt, count=n, offset=p).reshape(shape)
         if dt.kind == "S":
             vals = [bytes(x).split(b"\0")[0] for x in arr.reshape(-1)]
@@ -252,7 +254,9 @@ def read_keras_weights(path):
     def names(attrs, key):
         if key in attrs and attrs[key] is not None:
             v = attrs[key]
-            return [x.decode("utf8") for x in (v if isinstance(v, list) else [v])]
+            if isinstance(v, np.ndarray):                     # a non-string attribute names nothing (empty float64 array
+                return []                                     # of a layer without weights; also size-0 arrays)
+            return [x.decode("utf8") for x in (v if isinstance(v, list) else [v]) if isinstance(x, (bytes, bytearray))]
         out, i = [], 0                                        # keras splits attributes > 64 KB: layer_names0, layer_names1, ...
         while f"{key}{i}" in attrs:
             out += [x.decode("utf8") for x in attrs[f"{key}{i}"]]

@@ -49,8 +49,46 @@ static void dataset(hid_t grp, const char* name, int rank, const hsize_t* dims, 
   H5Dclose(ds); H5Sclose(s); free(d);
 }
 
+/* h5py writes `weight_names = []` of a layer without weights (Dropout, InputLayer) as np.asarray([]): an EMPTY float64
+ * attribute of shape (0,) */
+static void empty_f64_attr(hid_t obj, const char* name) {
+  hsize_t dims[1] = {0};
+  hid_t s = H5Screate_simple(1, dims, NULL);
+  hid_t a = H5Acreate2(obj, name, H5T_IEEE_F64LE, s, H5P_DEFAULT, H5P_DEFAULT);
+  H5Aclose(a); H5Sclose(s);
+}
+
+/* second fixture (argv[2] == "empty"): dense_a, dropout (no weights), input_1 (no weights), dense_b */
+static int write_with_weightless_layers(const char* path) {
+  hid_t f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+  const char* lnames[4] = {"dense_a", "dropout", "input_1", "dense_b"};
+  str_array_attr(f, "layer_names", lnames, 4);
+  str_scalar_attr(f, "backend", "tensorflow");
+  str_scalar_attr(f, "keras_version", "2.4.0");
+  for (int i = 0; i < 4; ++i) {
+    hid_t g = H5Gcreate2(f, lnames[i], H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    if (i == 1 || i == 2) {
+      empty_f64_attr(g, "weight_names");
+    } else {
+      hid_t g2 = H5Gcreate2(g, lnames[i], H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+      hsize_t d1[2] = {(hsize_t)(3 + i), 4}, d2[1] = {4};
+      dataset(g2, "kernel:0", 2, d1, i); dataset(g2, "bias:0", 1, d2, i);
+      char w[2][64];
+      sprintf(w[0], "%s/kernel:0", lnames[i]); sprintf(w[1], "%s/bias:0", lnames[i]);
+      const char* wn[2] = {w[0], w[1]};
+      str_array_attr(g, "weight_names", wn, 2);
+      H5Gclose(g2);
+    }
+    H5Gclose(g);
+  }
+  H5Fclose(f);
+  printf("wrote %s\n", path);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const char* path = argc > 1 ? argv[1] : "keras_weights_libhdf5.h5";
+  if (argc > 2 && strcmp(argv[2], "empty") == 0) return write_with_weightless_layers(path);
   hid_t f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
   /* 24 layers: more than one symbol-table node in the root group (leaf K = 4 -> 8 entries per node) */
   enum { NL = 24 };
