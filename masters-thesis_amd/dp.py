@@ -72,6 +72,8 @@ def _whole_step_graph(sync, m, key, body):
             sync.one_graph = False
             m._graphs.pop(key, None)
             sync.capture_error = repr(ex)
+            warnings.warn(f"TNT_DP_ONE_GRAPH: capture of the whole data-parallel step failed ({sync.capture_error}); "
+                          "the segmented schedule is used from here on")
             torch.cuda.synchronize()
             return False
         m._graphs[key] = g
@@ -153,9 +155,9 @@ class PipelinedDenseSync:
         def body():
             m._forward(B, T, True); m._loss_metrics(B, T, True); m._bwd_head(B, T)
             w_head, w_x = self._ar(a.grad[head0:]), self._gather(x_all, x_used)
-            m._bwd_seq_lstm(B, T)
+            m._bwd_seq_lstm(B, T); m.join()
             w_lstm = self._ar(a.grad[lstm0:head0])
-            m._bwd_seq_front(B, T)
+            m._bwd_seq_front(B, T); m.join()
             w_front = dist.all_reduce_coalesced([a.grad[front0:lstm0], _sparse_norm_slot(m)], op=dist.ReduceOp.SUM, async_op=True)
             w_dpre = self._gather(dpre_all, m.dpre)
             w_head.wait()
@@ -290,6 +292,12 @@ def attach(model, world=None, bucket_elems=None, pipelined=None, rank=None, sync
     eagerly (no captured segments); per-replica statistics with the pipelined schedules remain the default."""
     world = dist.get_world_size() if world is None else world
     rank = dist.get_rank() if rank is None else rank
+    if model.__dict__.get("agc") and world > 1:
+        # agc.py:25-30 clips the Embedding by the column norms of its UN-merged IndexedSlices rows; across replicas those
+        # are per-rank partial sums that would have to be all-reduced before every rank scales the summed gradient, and
+        # the pipelined schedules update slice by slice without an AGC pass.  Not built: refuse instead of training wrong.
+        raise NotImplementedError("adaptive gradient clipping (enable_agc) is not supported under data parallel: "
+                                  "call enable_agc(None) before dp.attach, or train on one device")
     model.dp_world = world
     model.seed = (int(model.seed) + 0x9E3779B1 * int(rank)) & 0x7FFFFFFFFFFFFFFF
     from .nic import NIC as DenseNIC

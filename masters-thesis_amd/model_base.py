@@ -425,6 +425,8 @@ class ModelBase:
     def enable_agc(self, clip_factor=0.01, eps=1e-3):
         """gradients = agc.adaptive_clip_grad(trainable_variables, gradients, clip_factor, eps) before
         optimizer.apply_gradients -- the (commented-out) call of lc_NIC.py:388.  clip_factor=None switches it off."""
+        if clip_factor is not None and int(self.__dict__.get("dp_world", 1) or 1) > 1:
+            raise NotImplementedError("adaptive gradient clipping is not supported under data parallel (dp.attach)")
         self.agc = None if clip_factor is None else (float(clip_factor), float(eps))
         self._graphs = {}
 
@@ -662,8 +664,11 @@ class ModelBase:
         what = {1: "a barrier timed out", 2: "a launch did not place 32 workgroups on every XCD"}.get(code, "unknown")
         raise DeviceGuardError(
             f"persistent LSTM kernel: device guard tripped (code {code}: {what}).  The results of that step are invalid; "
-            "its optimizer update was skipped, so weights, moments and step counters are unchanged.  The model now uses "
-            "the per-step LSTM kernels: run the step again.")
+            "its optimizer update was skipped, so weights, moments and step counters are unchanged.  NOT unchanged: the "
+            "BatchNorm moving mean / variance, which the forward pass of the faulted step already advanced (a retried step "
+            "applies that 1 % moving-average update a second time), and under data parallel the trip is per rank -- the other "
+            "replicas have applied their update, so re-broadcast the parameters (dp.broadcast_parameters) before going on.  "
+            "The model now uses the per-step LSTM kernels: run the step again.")
 
     def _guarded(self, fn):
         """Inference paths: run ``fn`` (which ends in a host read anyway), check the guard word, and on a trip fall back
