@@ -17,12 +17,26 @@ CCE_EPS = 1e-7       # keras backend.epsilon()
 
 
 # ---------------------------------------------------------------- activations
+# Checker-side hook (tests/test_gpu_fullsize.py): LeakyReLU elements whose pre-activation is within rounding of zero and
+# whose float32 twin on the device landed on the other side of the kink.  {pre.shape: boolean mask}; a masked element
+# takes the OTHER slope, and only if every masked pre-activation is indeed within 1e-6 of zero.  Empty outside that test.
+KINK_FLIPS = {}
+
+
+def _leaky_positive(pre):
+    pos = pre > 0
+    m = KINK_FLIPS.get(pre.shape)
+    if m is not None and m.any() and (np.abs(pre[m]) < 1e-6).all():
+        pos = pos ^ m
+    return pos
+
+
 def act_fwd(pre, act, slope=0.2):
     """LeakyReLU(0.2) instance used as activation: AttemptFour/Model/lc_NIC.py:87,98,142."""
     if act == ACT_NONE:
         return pre
     if act == ACT_LEAKY:
-        return np.where(pre > 0, pre, pre * slope)
+        return np.where(_leaky_positive(pre), pre, pre * slope)
     if act == ACT_RELU:
         return np.maximum(pre, 0)
     if act == ACT_TANH:
@@ -34,7 +48,7 @@ def act_bwd(pre, dy, act, slope=0.2):
     if act == ACT_NONE:
         return dy
     if act == ACT_LEAKY:
-        return np.where(pre > 0, dy, dy * slope)
+        return np.where(_leaky_positive(pre), dy, dy * slope)
     if act == ACT_RELU:
         return np.where(pre > 0, dy, 0 * dy)
     if act == ACT_TANH:

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import models as M
+from oracle import ops as O
 
 pytestmark = pytest.mark.gpu
 
@@ -194,22 +195,29 @@ def _sync_oracle(model, orc, opt, step):
 def _kink_flips(kind, model, w0, data, step, rates):
     """LeakyReLU elements whose float32 pre-activation has the other sign than the float64 oracle's (|pre| ~ 1e-8: a handful
     of the 1.7 M pre-activations of a step land that close to zero every few steps).  The derivative jumps from 1 to 0.2
-    there, so the two sides legitimately back-propagate different values through that one element."""
+    there, so the two sides legitimately back-propagate different values through that one element.
+    -> ({oracle pre-activation shape: boolean mask of the flipped elements, in the oracle's own layout}, count)."""
     orc2 = make_oracle(kind, rates)
     orc2.p = w0
     _, cache = orc2.forward(data, training=True, drop=M.DropCtx(seed=model.seed, step=step, training=True))
     if kind == "dense":
-        pairs = [(model.enc_pre, cache["pre"])]
-    else:
-        pairs = [(model.Ppre, cache["Ppre"]), (model.ipre, np.swapaxes(cache["ipre"], 0, 1)), (model.enc_pre, cache["enc"]["pre"])]
-    flips = 0
-    for mine, ref in pairs:
-        a, b = mine.detach().cpu().numpy().reshape(-1), np.asarray(ref).reshape(-1)
-        assert a.size == b.size
-        bad = (a > 0) != (b > 0)
-        assert np.abs(b[bad]).max(initial=0.0) < 1e-6, "pre-activation sign differs away from zero"
-        flips += int(bad.sum())
-    return flips
+        pairs = [(model.enc_pre, cache["pre"], None)]
+    else:      # the model keeps the head's pre-activation time-major, the oracle batch-major
+        pairs = [(model.Ppre, cache["Ppre"], None), (model.ipre, cache["ipre"], (0, 1)), (model.enc_pre, cache["enc"]["pre"], None)]
+    masks, flips = {}, 0
+    for mine, ref, swap in pairs:
+        ref = np.asarray(ref)
+        view = np.swapaxes(ref, *swap) if swap else ref
+        a = mine.detach().cpu().numpy().reshape(-1)
+        assert a.size == view.size
+        bad = (a.reshape(view.shape) > 0) != (view > 0)
+        assert np.abs(view[bad]).max(initial=0.0) < 1e-6, "pre-activation sign differs away from zero"
+        if bad.any():
+            native = np.ascontiguousarray(np.swapaxes(bad, *swap) if swap else bad)
+            assert native.shape == ref.shape and ref.shape not in masks
+            masks[ref.shape] = native
+            flips += int(bad.sum())
+    return masks, flips
 
 
 @pytest.mark.parametrize("kind", ["dense", "attention"])
@@ -221,7 +229,8 @@ def test_train_step_matches_oracle_at_full_size(kind, dropout):
     post-Adam weights (main.py:97, lc_NIC.py:389).  This is the only place where the kernels that exist only at full
     size -- the persistent LSTM forward (U == 512), lstm_bwd_lds (4U % 1024 == 0), the one-round head GEMM, the skinny
     encoder dW, the in-kernel-reduced gradient GEMMs -- run inside one oracle-checked step.
-    A gradient outside the 1e-4 bound is accepted only if the step is shown to contain a LeakyReLU kink flip (_kink_flips).
+    A gradient outside the 1e-4 bound is accepted only if the step is shown to contain a LeakyReLU kink flip (_kink_flips)
+    AND the oracle re-run with those elements on the model's side of the kink matches every tensor at 1e-4.
     The weights are checked twice: loosely against the oracle's own update (Adam turns a 1e-4 gradient error on a
     near-zero element into a fraction of lr), and tightly (1e-3 of one update) against the float64 Adam formulas
     applied to the gradients the model itself produced, which pins clip-by-norm + Adam + the IndexedSlices norm."""
@@ -248,22 +257,40 @@ def test_train_step_matches_oracle_at_full_size(kind, dropout):
                 continue
             tol = 1e-6 if k == "accuracy" else 1e-4 * abs(res[k]) + 1e-7
             assert abs(got[k] - res[k]) <= tol, (step, k, got[k], res[k])
-        gm, kinks = {}, None
-        for k in names:
-            gm[k] = model.get_gradient(k).astype(np.float64) + 2 * lam[k] * w0[k]
-            if grads.get(k) is None:
-                continue
-            scale = np.abs(grads[k]).max()
-            if k == "attention/V/bias":            # softmax is shift-invariant: the true gradient is 0
-                assert np.abs(gm[k]).max() < 1e-5
-                continue
-            err = np.abs(gm[k] - grads[k]).max()
-            if err > 1e-4 * scale + 1e-10:
-                # only acceptable with a LeakyReLU element on the other side of its kink in this step (see _kink_flips): its
-                # rank-one effect on the gradients is bounded instead (measured: 1.4e-3 of the smallest-scale tensor)
-                if kinks is None:
-                    kinks = _kink_flips(kind, model, w0, data, step, rates)
-                assert 0 < kinks <= 3 and err <= 5e-3 * scale + 1e-10, (step, k, err, scale, kinks)
+        gm = {k: model.get_gradient(k).astype(np.float64) + 2 * lam[k] * w0[k] for k in names}
+
+        def grad_errors(ref):
+            out = {}
+            for k in names:
+                if ref.get(k) is None or k == "attention/V/bias":
+                    continue
+                scale = np.abs(ref[k]).max()
+                err = np.abs(gm[k] - ref[k]).max()
+                if err > 1e-4 * scale + 1e-10:
+                    out[k] = (err, scale)
+            return out
+        if "attention/V/bias" in gm:               # softmax is shift-invariant: the true gradient is 0
+            assert np.abs(gm["attention/V/bias"]).max() < 1e-5
+        bad = grad_errors(grads)
+        if bad:
+            # A gradient outside 1e-4 is accepted on ONE condition: the step contains LeakyReLU elements whose float32
+            # pre-activation sits on the other side of the kink (|pre| < 1e-6, checked), and the float64 oracle RE-RUN from the
+            # same state with exactly those elements forced onto the model's side (oracle.ops.KINK_FLIPS) agrees with every
+            # gradient tensor at the usual 1e-4 -- no tensor gets a looser bound, flipped step or not.
+            masks, kinks = _kink_flips(kind, model, w0, data, step, rates)
+            assert 0 < kinks <= 3, (step, bad, kinks)
+            orc.p = {k: v.copy() for k, v in w0.items()}
+            opt.m, opt.v, opt.t = {k: v.copy() for k, v in m0.items()}, {k: v.copy() for k, v in v0.items()}, step
+            O.KINK_FLIPS.update(masks)
+            try:
+                res2, grads, _ = orc.train_step(data, tgt, opt, M.DropCtx(seed=model.seed, step=step, training=True))
+            finally:
+                O.KINK_FLIPS.clear()
+            for k in res:
+                if k != "lr":
+                    assert abs(res2[k] - res[k]) <= 1e-7 * abs(res[k]) + 1e-10, (step, k)    # the forward value does not move
+            bad = grad_errors(grads)
+            assert not bad, (step, "after forcing the kink flips", kinks, bad)
         # BatchNorm moving statistics
         for k in orc.p:
             if "moving_" in k:

@@ -286,3 +286,36 @@ def test_greedy_shapes_and_masking():
     # masked steps: whole = zeros -> probs = softmax(bias)
     sb = O.softmax(model.p['time_distributed_softmax/bias'])
     assert np.allclose(out[2, :, 0], sb)
+
+
+def test_kink_flip_hook_equals_the_other_side_of_the_kink():
+    """oracle.ops.KINK_FLIPS (the checker-side hook tests/test_gpu_fullsize.py uses when a float32 pre-activation lands on
+    the other side of LeakyReLU's kink): forcing an element with |pre| ~ 1e-9 onto the other slope gives exactly the gradients
+    of the same layer with that pre-activation nudged across zero; elements away from zero are never touched."""
+    from oracle import ops as O
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((6, 9))
+    K = rng.standard_normal((9, 4))
+    b = rng.standard_normal(4)
+    pre0 = x @ K + b
+    b[2] += 1e-9 - pre0[3, 2]                              # pre[3, 2] = +1e-9
+    dy = rng.standard_normal((6, 4))
+    y, pre = O.dense_fwd(x, K, b, O.ACT_LEAKY)
+    assert 0 < pre[3, 2] < 1e-8
+    base = O.dense_bwd(x, K, pre, dy, O.ACT_LEAKY)
+    pre_neg = pre.copy(); pre_neg[3, 2] = -1e-9
+    want = O.dense_bwd(x, K, pre_neg, dy, O.ACT_LEAKY)
+    mask = np.zeros(pre.shape, bool); mask[3, 2] = True
+    O.KINK_FLIPS[pre.shape] = mask
+    try:
+        got = O.dense_bwd(x, K, pre, dy, O.ACT_LEAKY)
+        far = np.zeros(pre.shape, bool); far[0, 0] = True  # |pre| is O(1) there: the hook must refuse the whole mask
+        O.KINK_FLIPS[pre.shape] = far
+        untouched = O.dense_bwd(x, K, pre, dy, O.ACT_LEAKY)
+    finally:
+        O.KINK_FLIPS.clear()
+    for g, w, b0 in zip(got, want, base):
+        assert np.array_equal(g, w)
+    assert not np.array_equal(got[1], base[1])
+    for u, b0 in zip(untouched, base):
+        assert np.array_equal(u, b0)

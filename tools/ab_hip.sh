@@ -11,7 +11,6 @@ trap 'rm -rf "$S"' EXIT
 mkdir -p $S/pkg $S/include
 cp -r masters-thesis_amd/csrc $S/pkg/csrc
 cp include/tnt_hip.h $S/include/
-mkdir -p $S/pkg/csrc/../../include && cp include/tnt_hip.h $S/pkg/csrc/../../include/ 2>/dev/null || true
 cp tools/probe/att_prev.hip.txt $S/pkg/csrc/attention.hip
 (cd $S/pkg/csrc && rm -f attention.o libtnt_hip.so && make > $S/make.log 2>&1)
 python tools/ab_attr.py attention | tail -1
