@@ -153,3 +153,63 @@ def D_tok():
     tok.word_index.update({"<start>": 1, "<end>": 2})
     tok.index_word.update({1: "<start>", 2: "<end>"})
     return tok
+
+
+REF_CAPS = "/root/reference/soloist/Modified-Show-And-Tell-Keras/target_caps.txt"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CAPS), reason="reference corpus not present (GPU box): read in place, never copied")
+def test_tokenizer_pipeline_over_the_reference_corpus():
+    """The only caption corpus the reference holds (4 000 lines, read IN PLACE) through the whole text side of the input
+    contract: build_tokenizer (load_avg_betas.py:184-188: fit, then '<pad>' -> 0), create_pairs' '<start> ... <end>'
+    wrapping (:259-265), texts_to_sequences / pad_sequences / shifted target / to_categorical
+    (data_generator_guse.py:156-163).  Asserted: the invariants those call sites rely on, and the vocabulary against an
+    independent derivation (collections.Counter)."""
+    from collections import Counter
+    with open(REF_CAPS) as f:
+        lines = [l.strip() for l in f if l.strip()]
+    assert len(lines) == 4000
+    texts = ["<start> " + " ".join(w.lower() for w in l.replace(".", " ").replace(",", " ").split(" ") if w) + " <end>" for l in lines]
+    top_k, max_len = 1000, 13
+    filters = '!"#$%&()*+.,-/:;=?@[\\]^_`{|}~\t\n '
+    tok = D.Tokenizer(num_words=top_k, oov_token="<unk>", filters=filters)
+    tok.fit_on_texts(texts)
+    # independent vocabulary: words by count (ties by first occurrence), the OOV token in slot 1; the corpus contains the
+    # literal token '<unk>', and keras' dict(zip(...)) lets its later (count-ranked) index win over the reserved slot
+    cnt = Counter(w for t in texts for w in t.split(" "))
+    assert dict(tok.word_counts) == dict(cnt)
+    ranked = ["<unk>"] + [w for w, _ in sorted(cnt.items(), key=lambda kv: -kv[1])]
+    want = {}
+    for i, w in enumerate(ranked):
+        want[w] = i + 1
+    assert tok.word_index == want
+    assert "<unk>" in cnt and tok.word_index["<unk>"] > 1 and 1 not in tok.index_word
+    assert cnt["<start>"] == 4000 <= cnt["<end>"] and tok.word_index["<end>"] < tok.word_index["<start>"] < 8   # the corpus holds literal <end> tokens too
+    # load_avg_betas.py:187-188
+    tok.word_index["<pad>"] = 0
+    tok.index_word[0] = "<pad>"
+    seqs = tok.texts_to_sequences(texts)
+    assert len(seqs) == 4000
+    flat = np.concatenate([np.asarray(s) for s in seqs])
+    assert flat.min() == 0 and flat.max() < top_k                                # num_words cut-off; '<pad>' -> 0
+    n_rare = sum(c for w, c in cnt.items() if want[w] >= top_k)
+    oov = tok.word_index["<unk>"]                                                # keras: word_index.get(oov_token) -- here NOT 1
+    assert oov < top_k and not (flat == 1).any()
+    assert n_rare > 0 and int((flat == oov).sum()) == n_rare + cnt["<unk>"]      # every cut-off word became the OOV id
+    for t, s in zip(texts[:200], seqs[:200]):
+        ws = t.split(" ")
+        assert len(s) == len(ws) and s[0] == tok.word_index["<start>"] and s[-1] == tok.word_index["<end>"]
+        assert all((i == 0) == (w == "<pad>") for w, i in zip(ws, s))
+    cap = D.pad_sequences(seqs, max_len)                                         # truncating='post', padding='post'
+    assert cap.shape == (4000, max_len) and cap.dtype == np.int32
+    for s, row in zip(seqs, cap):
+        k = min(len(s), max_len)
+        assert list(row[:k]) == s[:k] and not row[k:].any()
+    tgt = D.make_target(cap)
+    assert np.array_equal(tgt[:, :-1], cap[:, 1:]) and not tgt[:, -1].any()
+    oh = D.to_categorical(tgt[:64], top_k)
+    assert oh.shape == (64, max_len, top_k) and oh.dtype == np.float32
+    assert np.array_equal(oh.argmax(-1), tgt[:64]) and np.array_equal(oh.sum(-1), np.ones((64, max_len), np.float32))
+    tok2 = D.tokenizer_from_json(tok.to_json())                                  # load_tokenizer(), :136-138
+    assert tok2.word_index == tok.word_index and tok2.texts_to_sequences(texts) == seqs
+    assert tok2.sequences_to_texts([seqs[0]])[0].split(" ")[0] == "<start>"
