@@ -9,7 +9,10 @@
  *
  * Conventions
  *   - all tensors float32 unless noted; token ids int32; plain device pointers;
- *     the caller owns every buffer and workspace; no allocation, no global state;
+ *     the caller owns every buffer and workspace; no allocation, no global state
+ *     (one documented exception: the two vendor-library A/B entry points tnt_gemm_blas_f32 /
+ *     tnt_gemm_lt_f32 keep a process-wide rocBLAS / hipBLASLt handle and per-shape plans behind a
+ *     mutex, csrc/blas.hip; no default training path calls them);
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work;
  *   - return 0 on success, a negative hipError_t on launch failure, -1000-k for
  *     an argument the kernels do not support (k = argument position);

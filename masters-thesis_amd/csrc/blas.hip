@@ -5,11 +5,17 @@
 // plus a reduce launch (66-80 TF effective; tools/probe/rocblas_probe.cpp, profiles/r01_gemm_design_probe.txt).
 // The fused GEMMs (bias / activation / pre-activation epilogues, the vocabulary-head forward, the encoder) stay on
 // gemm.hip.  Row-major C = op(A) op(B) is issued as the column-major product C^T = op(B)^T op(A)^T.
+// PROCESS-GLOBAL STATE (the one exception to the "no global state" rule of include/tnt_hip.h, documented there): the
+// rocBLAS handle, the hipBLASLt handle and the per-shape hipBLASLt plans live for the life of the process; g_blas_mu
+// serialises their creation and every call that touches them, so the two entry points may be called from any thread.
+// Since round 3 neither is on a default training path (the hand-written kernels of gemm3.hip are); both remain as A/B tools.
 #include "tnt_common.h"
 #include <rocblas/rocblas.h>
+#include <mutex>
 
 namespace {
-rocblas_handle g_handle = nullptr;       // one per process (one process per GPU, one launching thread)
+std::mutex g_blas_mu;
+rocblas_handle g_handle = nullptr;       // one per process (one process per GPU)
 
 int32_t blas_init() {
   if (g_handle) return 0;
@@ -27,6 +33,7 @@ extern "C" int32_t tnt_gemm_blas_f32(const float* A, const float* B, float* C, i
                                      int32_t accumulate, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return TNT_BADARG(4);
   if (transA && transB) return TNT_BADARG(10);
+  std::lock_guard<std::mutex> lock(g_blas_mu);
   if (int32_t rc = blas_init()) return rc;
   if (rocblas_set_stream(g_handle, tnt_stream(stream)) != rocblas_status_success) return -1003;
   const float one = 1.f, beta = accumulate ? 1.f : 0.f;
@@ -71,7 +78,8 @@ struct LtPlan {
   hipblasLtMatmulAlgo_t algo;
   bool ok = false;
 };
-using LtKey = std::tuple<int, int, int, int, int, int, int, int, int>;
+// the bias pointer is part of the key: a plan's descriptor is written once, when the plan is made, and never again
+using LtKey = std::tuple<int, int, int, int, int, int, int, int, const float*>;
 hipblasLtHandle_t g_lt = nullptr;
 std::map<LtKey, LtPlan> g_lt_plans;
 
@@ -88,9 +96,10 @@ extern "C" int32_t tnt_gemm_lt_f32(const float* A, const float* B, float* C, con
                                    void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return TNT_BADARG(5);
   if (transA && transB) return TNT_BADARG(11);
+  std::lock_guard<std::mutex> lock(g_blas_mu);
   if (!g_lt && hipblasLtCreate(&g_lt) != HIPBLAS_STATUS_SUCCESS) { g_lt = nullptr; return -1201; }
   hipStream_t s = tnt_stream(stream);
-  const LtKey key{M, N, K, lda, ldb, ldc, transA, transB, bias != nullptr};
+  const LtKey key{M, N, K, lda, ldb, ldc, transA, transB, bias};
   LtPlan& p = g_lt_plans[key];
   if (!p.ok) {
     const hipblasOperation_t opB = transB ? HIPBLAS_OP_T : HIPBLAS_OP_N, opA = transA ? HIPBLAS_OP_T : HIPBLAS_OP_N;
@@ -167,6 +176,5 @@ extern "C" int32_t tnt_gemm_lt_f32(const float* A, const float* B, float* C, con
                 hipblaslt_ext::getIndexFromAlgo(p.algo));
     }
   }
-  if (bias) hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
   return lt_run(p, p.algo, A, B, C, s) == 0 ? 0 : -1208;
 }

@@ -16,8 +16,11 @@ def batch(rng, B, N, T, V):
     return x, tgt
 
 
+# the fourth case is BASELINE config 1 at its stated size: ShowAndTell/model.py:40-65,125-164 on 4096-d image features
+# (train.py:165-225) with long, padded captions (T = 40, masked tail, loss over i = 1..T-1)
 @pytest.mark.parametrize("sat,drop,dims", [(False, 0.3, (8, 500, 64, 64, 301, 12)), (True, 0.0, (6, 256, 32, 32, 101, 9)),
-                                           (False, 0.0, (64, 5000, 512, 512, 5001, 15))])
+                                           (False, 0.0, (64, 5000, 512, 512, 5001, 15)),
+                                           (True, 0.0, (32, 4096, 512, 512, 5001, 40))])
 def test_tt_parity(sat, drop, dims):
     from masters_thesis_amd import think_and_tell as TT, show_and_tell as SAT
     from masters_thesis_amd.optimizers import Adam
