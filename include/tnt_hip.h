@@ -83,6 +83,18 @@ int32_t tnt_gemm_fused_f32(const float* A, const float* B, float* C, const float
 /* the configuration tnt_gemm_fused_f32 would pick (0 = none) */
 int32_t tnt_gemm_fused_cfg(int32_t M, int32_t N, int32_t K, int32_t transA, int32_t transB, int32_t batch);
 
+/* ---- gemm3 (round 3): the hand-written FP32-MFMA family that carries the step's large products by default --
+ * the vocabulary head forward (NIC.py:143, lc_NIC.py:261) and, under tape.gradient (NIC.py:248-249, lc_NIC.py:386-387),
+ * its kernel / input gradients, the LSTM input projection (NIC.py:138-140) and the LSTM kernel / recurrent-kernel / input
+ * gradients.  C = op(A) op(B) (+ bias[N]); operand conventions of tnt_gemm_f32; A, B, C 16-byte aligned, lda / ldb / ldc
+ * multiples of 4; a K-contiguous operand (A with transA = 0, B with transB = 1) whose K is not a multiple of 4 must have
+ * zeros in the pad columns [K, roundup4(K)) (the layout contract of every buffer of this library).  Exact f32
+ * (v_mfma_f32_16x16x4_f32), fixed summation order: bitwise reproducible.  cfg selects the workgroup tile (table in
+ * csrc/gemm3.hip; tools/gemm3_scan.py). */
+int32_t tnt_gemm3_f32(const float* A, const float* B, float* C, const float* bias, int32_t M, int32_t N, int32_t K,
+                      int32_t lda, int32_t ldb, int32_t ldc, int32_t transA, int32_t transB, int32_t cfg,
+                      void* stream);
+
 /* tuning entry point: tnt_gemm_f32 with the workgroup tile forced to bm x bn (each 64 or 128; anything else =
  * the library's own choice).  Used by tools/gemm_bench.py / gemm_scan.py to calibrate the tile heuristic. */
 int32_t tnt_gemm_f32_tile(const float* A, const float* B, float* C, const float* bias, float* pre,

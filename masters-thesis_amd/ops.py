@@ -65,6 +65,11 @@ class HipBackend:
         self._call(self.lib.tnt_gemm_fused_f32, "tnt_gemm_fused_f32", _p(A), _p(B), _p(C), _p(bias), _p(colsum), _p(A2), _p(C2),
                    M, N, K, lda, ldb, ldc, int(transA), int(transB), cfg, self._s())
 
+    def gemm3(self, A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, cfg=0):
+        """the round-3 FP32-MFMA family (LDS-DMA staged, b128 fragments): C = op(A) op(B) (+ bias)"""
+        self._call(self.lib.tnt_gemm3_f32, "tnt_gemm3_f32", _p(A), _p(B), _p(C), _p(bias), M, N, K, lda, ldb, ldc,
+                   int(transA), int(transB), cfg, self._s())
+
     def gemm_tile(self, A, B, C, M, N, K, lda, ldb, ldc, bm, bn, transA=False, transB=False, bias=None, pre=None,
                   act=ACT_NONE, slope=0.2, accumulate=False, splitk=1, work=None):
         """tnt_gemm_f32 with the workgroup tile forced: (64|128, 64|128) = the tiled kernel, (160, 128) = the
