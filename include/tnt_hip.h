@@ -91,9 +91,24 @@ int32_t tnt_gemm_fused_cfg(int32_t M, int32_t N, int32_t K, int32_t transA, int3
  * zeros in the pad columns [K, roundup4(K)) (the layout contract of every buffer of this library).  Exact f32
  * (v_mfma_f32_16x16x4_f32), fixed summation order: bitwise reproducible.  cfg selects the workgroup tile (table in
  * csrc/gemm3.hip; tools/gemm3_scan.py). */
-int32_t tnt_gemm3_f32(const float* A, const float* B, float* C, const float* bias, int32_t M, int32_t N, int32_t K,
-                      int32_t lda, int32_t ldb, int32_t ldc, int32_t transA, int32_t transB, int32_t cfg,
-                      void* stream);
+int32_t tnt_gemm3_f32(const float* A, const float* B, float* C, const float* bias, float* colsum, const float* A2,
+                      float* C2, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc, int32_t transA,
+                      int32_t transB, int32_t tile, int32_t splitk, float* work, uint32_t* sync, void* stream);
+/* Riders (all nullable): bias [N] added to every row; colsum [N] = sum_k B[k][n] (transA = 1, transB = 0, splitk = 1 only:
+ * B = dY, so this is the bias gradient of the layer whose kernel gradient the product is); A2 / C2 (both or neither): a
+ * second product C2 = op(A2) op(B) with the same dims and strides in the same launch (the LSTM's kernel and
+ * recurrent-kernel gradients share dZ).
+ * splitk > 1: K is split over `splitk` workgroups per output tile, which reduce inside the launch (fixed order).  `work`:
+ * tnt_gemm3_work_floats(M, N, tile, splitk, batch) floats (contents irrelevant); `sync`: tnt_gemm3_sync_words(M, N, tile,
+ * batch) uint32 words, ZERO before the first use and left zero by every launch (the last word is an error flag: nonzero
+ * means a workgroup gave up waiting for its peers -- the launch did not fit the device in one round -- and C is invalid).
+ * batch = 2 with A2 / C2, else 1. */
+/* The (tile, splitk) the library's cost model picks for a shape (batch = 2 for a dual launch; allow_split = 0 restricts
+ * the choice to splitk = 1, which the colsum rider needs). */
+int32_t tnt_gemm3_plan(int32_t M, int32_t N, int32_t K, int32_t transA, int32_t transB, int32_t batch,
+                       int32_t allow_split, int32_t* tile, int32_t* splitk);
+int32_t tnt_gemm3_work_floats(int32_t M, int32_t N, int32_t tile, int32_t splitk, int32_t batch);
+int32_t tnt_gemm3_sync_words(int32_t M, int32_t N, int32_t tile, int32_t batch);
 
 /* tuning entry point: tnt_gemm_f32 with the workgroup tile forced to bm x bn (each 64 or 128; anything else =
  * the library's own choice).  Used by tools/gemm_bench.py / gemm_scan.py to calibrate the tile heuristic. */

@@ -10,11 +10,9 @@
 //    M/N-CONTIGUOUS ("MC": rows run along the output dimension -- B of NN / TN, A of TN).
 //  * Global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no VGPR staging, no ds_write, hardware bounds check
 //    (rows past the matrix read as zero).  A ring of NS K-stages per workgroup, ONE s_barrier per stage.
-//  * ROLE-SPECIALISED WAVES: the workgroup is WGM x WGN consumer waves plus ONE loader wave.  The loader issues every
-//    LDS-DMA piece of a stage (a piece costs its issuing wave ~60-100 cycles in which it can issue nothing else; inside a
-//    consumer's stream that showed up as 10-20 % idle MFMA time) and keeps NS - 1 stages in flight; the consumers'
-//    streams are ds_read_b128 + MFMA only.  Consumers and loader meet at the one barrier per stage: the consumers
-//    arrive when they have read the last fragment of stage s, the loader when its pieces of stage s + 1 have landed.
+//    Every wave issues its share of a stage's pieces behind that barrier, spaced between MFMAs.  (A dedicated loader
+//    wave -- one wave issuing all 26-36 pieces of a stage for four consumer waves -- was built and measured slower on
+//    every shape: one wave cannot issue pieces fast enough; see DESIGN.md.)
 //  * LDS images are written lane-linear (that is what LDS-DMA does); bank conflicts are avoided by permuting the SOURCE
 //    address instead: a KC image [rows][BK] stores 16-byte chunk c of row r at chunk position c ^ sw(r), so that the
 //    ds_read_b128 of one MFMA operand fragment (16 rows x 4 k per 16-lane group) touches every bank once; an MC image
@@ -27,17 +25,25 @@
 //    operands use the same one, so the sum is the plain dot product, in a fixed order.
 //  * Epilogue: with an MC B operand a lane holds four adjacent columns of a row in four accumulators -> one 16-byte
 //    store per row and 64-column group.
-//  * Work decomposition: one workgroup per output tile, tiles dealt XCD-contiguously; `splitk` > 1 splits K over
-//    workgroups that publish their partial tiles (write-through) and then EACH reduce 1/splitk of the tile in split
-//    order (no extra launch, bitwise reproducible) -- see the fix-up section.
+//  * Work decomposition: one workgroup per (output tile, K split), dealt XCD-contiguously so that the S splits of a tile
+//    share an XCD.  With S > 1 the S workgroups of a tile reduce IN the launch: every accumulator tile row (wave w, tile
+//    row tm) has an owner split (w * TM + tm) mod S; a workgroup stores the rows it does not own to the work buffer
+//    (write-through), arrives on the tile's counter, waits for the S arrivals and adds the peers' partials to the rows it
+//    owns, in split order (bitwise reproducible), before the ordinary epilogue.  Each workgroup moves (S-1)/S of a tile
+//    out and in; no reduce launch, no second pass over C.
 #include "tnt_common.h"
 
 namespace {
 
 struct G3Args {
   const float* A; const float* B; float* C; const float* bias;
+  const float* A2; float* C2;   // optional second product C2 = op(A2) op(B) in the same launch (blockIdx.y = 1)
+  float* colsum;                // optional (TN, no split): colsum[n] = sum_k B[k][n]
+  float* work; unsigned* sync;  // split-K exchange: partial tiles; one counter per output tile + an error word
   int M, N, K, lda, ldb, ldc;
-  int nst;                    // K stages per workgroup (a multiple of 2)
+  int nst;                    // K stages in all
+  int splitk, nst_split;      // workgroups per output tile, stages per workgroup
+  int err_word;               // index of the error word in sync
 };
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from the buffer `rsrc` + voff (per lane; out-of-range lanes deliver zeros) to
@@ -68,22 +74,16 @@ template <int CH> __device__ __forceinline__ int g3_sw(int row) {
 // One operand of the product: its LDS image, its LDS-DMA fill and its MFMA fragments.
 //   KC   : K-contiguous (image [EXT][BK], chunk-swizzled) or M/N-contiguous (image [BK][EXT])
 //   EXT  : extent of the workgroup tile along this operand's output dimension
-//   T    : 16-wide MFMA tiles per wave along that dimension
-constexpr int g3_gcd(int a, int b) { return b == 0 ? a : g3_gcd(b, a % b); }
-template <bool KC, int EXT, int T, int BK>
+//   T    : 16-wide MFMA tiles per wave along that dimension;  NW: waves of the workgroup
+template <bool KC, int EXT, int T, int BK, int NW>
 struct G3Op {
   static constexpr int CH = BK / 4;
   static constexpr int BYTES = EXT * BK * 4;
   static constexpr int NI = BYTES / 1024;                 // LDS-DMA pieces (wave-instructions) per stage
+  static constexpr int NIW = (NI + NW - 1) / NW;          // ... per wave (pieces are dealt round-robin)
   static constexpr int G4 = KC ? 0 : T / 4, G2 = KC ? 0 : (T % 4) / 2, G1 = KC ? 0 : T % 2;
-  // Piece j loads image slots 64 j .. 64 j + 63 (a slot = 16 bytes).  The lane -> (row, chunk) pattern of a piece repeats
-  // every P pieces = RP image rows, so a piece's per-lane source offset is  base[j % P] + (j / P) * RP * ld * 4.
-  static constexpr int SPR = KC ? CH : EXT / 4;           // slots per image row
-  static constexpr int P = KC ? (CH >= 4 ? CH / 4 : 1) : SPR / g3_gcd(64, SPR);
-  static constexpr int RP = 64 * P / SPR;
   static_assert(BYTES % 1024 == 0, "stage image must be whole 1 KB LDS-DMA pieces");
   static_assert(!KC || (EXT * CH) % 64 == 0, "KC image: whole pieces of 64 chunks");
-  static_assert((64 * P) % SPR == 0, "a period is whole image rows");
 
   // byte offset inside the matrix of what lane `lane` of piece j loads (k0 = 0); kc4 = first k of its chunk (KC)
   static __device__ __forceinline__ int src_off(int j, int lane, int row0, int ld, int& kc4) {
@@ -100,86 +100,94 @@ struct G3Op {
   }
 };
 
+// L1-bypassing 16-byte load / write-through 16-byte store for the split-K exchange (bytes another workgroup wrote /
+// will read in this launch): buffer_load_dwordx4 ... sc1 / buffer_store_dwordx4 ... sc0 sc1
+__device__ __forceinline__ floatx4 g3_ld4_sc1(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, /*sc1*/ 16));
+}
+__device__ __forceinline__ void g3_st4_wt(__amdgpu_buffer_rsrc_t rs, unsigned off, floatx4 v) {
+  typedef unsigned g3_v4u __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(g3_v4u, v), rs, (int)off, 0, /*sc0 sc1*/ 17);
+}
+
 template <bool A_KC, bool B_KC, int TM, int TN, int WGM, int WGN, int BK, int NS>
-__global__ __launch_bounds__(64 * (WGM * WGN + 1)) void gemm3_kernel(G3Args g) {
-  constexpr int NW = WGM * WGN;                       // consumer waves; wave NW is the loader
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm3_kernel(G3Args g) {
+  constexpr int NW = WGM * WGN;
   constexpr int WM = 16 * TM, WN = 16 * TN, BM = WM * WGM, BN = WN * WGN;
-  using OA = G3Op<A_KC, BM, TM, BK>;
-  using OB = G3Op<B_KC, BN, TN, BK>;
+  using OA = G3Op<A_KC, BM, TM, BK, NW>;
+  using OB = G3Op<B_KC, BN, TN, BK, NW>;
   constexpr int STAGE = OA::BYTES + OB::BYTES;
   constexpr int KB = BK / 16;                         // 16-deep k blocks per stage
   constexpr bool KMASK = A_KC && B_KC;                // NT: the k tail of A must be zeroed by hand (B's then meets zeros)
-  constexpr int NP = OA::NI + OB::NI;                 // pieces per stage
-  static_assert(KB % 2 == 0, "register buffer parity must repeat per stage");
+  constexpr int NPW = OA::NIW + OB::NIW;              // pieces per wave and stage -- the SAME for every wave (vmcnt counts
+  constexpr int SCRATCH = NS * STAGE;                 // them): a wave with no real piece left issues an out-of-range one
+  static_assert(KB % 2 == 0, "register buffer parity must repeat per stage");      // into 1 KB of scratch
+  static_assert((NS - 2) * NPW <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(1024))) unsigned char g3_lds[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int MT = (g.M + BM - 1) / BM, NTl = (g.N + BN - 1) / BN;
-  const int nwg = MT * NTl, bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;       // XCD-contiguous tile order (bijective for any nwg)
-  const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int m0 = (t % MT) * BM, n0 = (t / MT) * BN;
-
-  if (wave == NW) {
-    // =============================================================================================== loader wave
-    // (the extern array is the kernel's only LDS object: byte offsets inside it are LDS addresses)
-    const int rowsA = A_KC ? g.M : g.K, rowsB = B_KC ? g.N : g.K;
-    const g3_v4i rsA = g3_rsrc(g.A, (unsigned)(rowsA * g.lda * 4));
-    const g3_v4i rsB = g3_rsrc(g.B, (unsigned)(rowsB * g.ldb * 4));
-    int baseA[OA::P], baseB[OB::P], kcA[KMASK ? OA::P : 1];
-#pragma unroll
-    for (int v = 0; v < OA::P; ++v) {
-      int kc4;
-      baseA[v] = OA::src_off(v, lane, m0, g.lda, kc4);
-      if constexpr (KMASK) kcA[v] = kc4;
-    }
-#pragma unroll
-    for (int v = 0; v < OB::P; ++v) {
-      int kc4;
-      baseB[v] = OB::src_off(v, lane, n0, g.ldb, kc4);
-    }
-    const int k4 = (g.K + 3) & ~3;
-    // every piece of stage s -> the LDS buffer at byte offset boff.  Stages past the last one are issued too (vmcnt counts
-    // pieces, so every stage must have the same number) with out-of-range offsets: they fetch nothing.
-    auto issue = [&](int s, int boff) __attribute__((always_inline)) {
-      const int k0 = s * BK;
-      const bool live = s < g.nst;
-      const int sa = A_KC ? k0 * 4 : k0 * g.lda * 4, sb = B_KC ? k0 * 4 : k0 * g.ldb * 4;
-#pragma unroll
-      for (int j = 0; j < OA::NI; ++j) {
-        int vo = baseA[j % OA::P] + (j / OA::P) * OA::RP * g.lda * 4 + sa;
-        if constexpr (KMASK) vo = (k0 + kcA[j % OA::P] < k4) ? vo : 0x7fffffff;
-        vo = live ? vo : 0x7fffffff;
-        g3_dma16(rsA, (unsigned)(boff + j * 1024), vo);
-      }
-#pragma unroll
-      for (int j = 0; j < OB::NI; ++j) {
-        int vo = baseB[j % OB::P] + (j / OB::P) * OB::RP * g.ldb * 4 + sb;
-        vo = live ? vo : 0x7fffffff;
-        g3_dma16(rsB, (unsigned)(boff + OA::BYTES + j * 1024), vo);
-      }
-    };
-    constexpr int W0 = (NS - 1) * NP > 63 ? 63 : (NS - 1) * NP;       // vmcnt is a 6-bit counter: a larger count
-    constexpr int W1 = (NS - 2) * NP > 63 ? 63 : (NS - 2) * NP;       // over-waits a little, never under-waits
-#pragma unroll
-    for (int s = 0; s < NS; ++s) issue(s, s * STAGE);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W0) : "memory");         // stage 0 landed
-    __builtin_amdgcn_s_barrier();                                      // barrier 0
-    int bcur = 0;
-    for (int s = 0; s < g.nst; ++s) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W1) : "memory");       // stage s + 1 landed
-      __builtin_amdgcn_s_barrier();                                    // barrier s + 1: the consumers are done with stage s
-      issue(s + NS, bcur);
-      bcur = (bcur + STAGE == NS * STAGE) ? 0 : bcur + STAGE;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return;
-  }
-
-  // ================================================================================================= consumer waves
   const int wm = wave / WGN, wn = wave % WGN;
   const int r = lane & 15, q = lane >> 4;
+  const int MT = (g.M + BM - 1) / BM, NTl = (g.N + BN - 1) / BN;
+  const int S = g.splitk;
+  const int nwg = MT * NTl * S, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;       // XCD-contiguous unit order (bijective for any nwg)
+  const int u = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int t = u / S, z = u - t * S;                          // output tile, K split
+  const int m0 = (t % MT) * BM, n0 = (t / MT) * BN;
+  const bool second = blockIdx.y != 0;                         // the second product of a dual launch
+  const float* Ag = second ? g.A2 : g.A;
+  float* Cg = second ? g.C2 : g.C;
+  const int s_begin = z * g.nst_split;
+  const int s_end = min(g.nst, s_begin + g.nst_split);        // this workgroup's stages [s_begin, s_end)
+  const int nloc = max(s_end - s_begin, 0);
+
+  // ---- LDS-DMA sources (the extern array is the kernel's only LDS object: byte offsets inside it are LDS addresses)
+  const int rowsA = A_KC ? g.M : g.K, rowsB = B_KC ? g.N : g.K;
+  const g3_v4i rsA = g3_rsrc(Ag, (unsigned)(rowsA * g.lda * 4));
+  const g3_v4i rsB = g3_rsrc(g.B, (unsigned)(rowsB * g.ldb * 4));
+  int offA[OA::NIW], offB[OB::NIW], kcA[KMASK ? OA::NIW : 1];
+  {
+    const int ka = s_begin * BK;
+#pragma unroll
+    for (int i = 0; i < OA::NIW; ++i) {
+      int kc4;
+      const int j = wave + i * NW;
+      offA[i] = OA::src_off(j, lane, m0, g.lda, kc4) + (A_KC ? ka * 4 : ka * g.lda * 4);
+      if (OA::NI % NW != 0 && j >= OA::NI) offA[i] = 0x7fffffff;        // a dummy piece: out of range for good
+      if constexpr (KMASK) kcA[i] = kc4 + ka;
+    }
+#pragma unroll
+    for (int i = 0; i < OB::NIW; ++i) {
+      int kc4;
+      const int j = wave + i * NW;
+      offB[i] = OB::src_off(j, lane, n0, g.ldb, kc4) + (B_KC ? ka * 4 : ka * g.ldb * 4);
+      if (OB::NI % NW != 0 && j >= OB::NI) offB[i] = 0x7fffffff;
+    }
+  }
+  const int k_end = min(((g.K + 3) & ~3), s_end * BK);       // first k this workgroup must not multiply (NT mask)
+  const int stepA = A_KC ? BK * 4 : BK * g.lda * 4, stepB = B_KC ? BK * 4 : BK * g.ldb * 4;
+  // Piece p (0 .. NPW-1) of this wave for the NEXT stage not yet issued -> the LDS buffer at byte offset boff; the
+  // per-lane offsets then advance by one stage.  Stages past the workgroup's last one are issued too (every stage has the
+  // same piece count): an MC operand's rows past K are out of range (zeros, no traffic); a KC operand's columns past K
+  // read on into the following rows -- harmless, never multiplied (NT: masked; NN: B's rows there are zero).
+  auto issue_piece = [&](int boff, int p) __attribute__((always_inline)) {
+    if (p < OA::NIW) {
+      const int i = p, j = wave + i * NW;
+      const bool real = (OA::NI % NW == 0) || j < OA::NI;
+      int vo = offA[i];
+      if constexpr (KMASK) { vo = (kcA[i] < k_end) ? vo : 0x7fffffff; kcA[i] += BK; }
+      g3_dma16(rsA, (unsigned)(real ? boff + j * 1024 : SCRATCH), vo);
+      if ((OA::NI % NW == 0) || real) offA[i] += stepA;
+    } else {
+      const int i = p - OA::NIW, j = wave + i * NW;
+      const bool real = (OB::NI % NW == 0) || j < OB::NI;
+      g3_dma16(rsB, (unsigned)(real ? boff + OA::BYTES + j * 1024 : SCRATCH), offB[i]);
+      if ((OB::NI % NW == 0) || real) offB[i] += stepB;
+    }
+  };
+
   // ---- fragment read addresses (bytes inside a stage buffer)
   int fa[A_KC ? KB : 3], fb[B_KC ? KB : 3];
   if constexpr (A_KC) {
@@ -256,15 +264,29 @@ __global__ __launch_bounds__(64 * (WGM * WGN + 1)) void gemm3_kernel(G3Args g) {
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-  // the MFMAs of a block in the order (k-step e, tile row, tile column)
-  auto mma = [&](int rb) __attribute__((always_inline)) {
+  // column sums of B (the bias gradient of the layer whose kernel gradient this product is; TN only): the waves of the
+  // first tile row keep a running sum of the B fragments they hold anyway.  Branch-free (every wave runs the FMAs with a
+  // 0 / 1 factor) so that the pinned block below stays one basic block.
+  constexpr bool CS = !A_KC && !B_KC;
+  float cs[CS ? TN : 1];
+  const float csf = (CS && g.colsum != nullptr && m0 == 0 && wm == 0 && !second) ? 1.f : 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+  for (int tn = 0; tn < (CS ? TN : 1); ++tn) cs[tn] = 0.f;
+  auto colacc = [&](int rb) __attribute__((always_inline)) {
+    if constexpr (CS) {
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+      for (int tn = 0; tn < TN; ++tn)
+        cs[tn] = fmaf((bv[rb][tn][0] + bv[rb][tn][1]) + (bv[rb][tn][2] + bv[rb][tn][3]), csf, cs[tn]);
+    }
+  };
+  // MFMAs i0 .. i1-1 of a block in the order (k-step e, tile row, tile column): 4 TM TN per block
+  auto mma = [&](int rb, int i0, int i1) __attribute__((always_inline)) {
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb][tm][e], bv[rb][tn][e], acc[tm][tn], 0, 0, 0);
+    for (int i = 0; i < 4 * TM * TN; ++i) {
+      if (i < i0 || i >= i1) continue;
+      const int e = i / (TM * TN), tm = (i / TN) % TM, tn = i % TN;
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb][tm][e], bv[rb][tn][e], acc[tm][tn], 0, 0, 0);
+    }
   };
 
   // epilogue operands before the loop (a load still pending in the epilogue serialises the stores behind vmcnt(0))
@@ -291,54 +313,161 @@ __global__ __launch_bounds__(64 * (WGM * WGN + 1)) void gemm3_kernel(G3Args g) {
     bcol[tn] = (g.bias != nullptr && col < g.N) ? g.bias[col] : 0.f;
   }
 
-  // ---- main loop.  Two k blocks live in registers (register buffers 0 / 1; a stage has an even number of blocks, so
-  // every stage starts on register buffer 0).  Block b of a stage multiplies register buffer b & 1 while the fragments of
-  // the next block are read; the LAST block of a stage first retires this wave's reads of the stage (lgkmcnt(0)), meets the
-  // other waves and the loader (whose arrival says: stage s + 1 is in LDS) and reads the first fragments of stage s + 1.
-  // Instruction order is pinned: hipcc otherwise sinks every ds_read down to its first use ("reads; lgkmcnt(0); MFMAs",
-  // ~150 exposed cycles per block with one wave per SIMD); here the reads of the next block go one per MFMA behind the
-  // first MFMAs of this block.
+  // ---- main loop.  A ring of NS LDS buffers, at most NS - 1 stages in flight.  Two k blocks live in registers
+  // (register buffers 0 / 1; a stage has an even number of blocks, so every stage starts on register buffer 0).  Block b of
+  // a stage multiplies register buffer b & 1 while the fragments of the next block are read.  The LAST block of a stage
+  // first retires the stage's LDS traffic (this wave has read all its fragments: lgkmcnt(0); its pieces of the next stage
+  // have landed: vmcnt leaves only the younger stages outstanding), meets the other waves, refills the buffer just freed
+  // with the next stage not yet issued and reads the first fragments of stage s + 1.
+  // Instruction order is pinned.  hipcc otherwise sinks every ds_read down to its first use ("reads; lgkmcnt(0); MFMAs",
+  // ~150 exposed cycles per block with one wave per SIMD): the reads of the next block go one per MFMA behind the first
+  // MFMAs of this block (sched_group_barrier); the LDS-DMA pieces, asm statements the scheduler cannot classify, sit
+  // DMA_GAP MFMAs apart between scheduling fences.
   constexpr int NRD = (A_KC ? TM : 4 * (OA::G4 + OA::G2 + OA::G1)) + (B_KC ? TN : 4 * (OB::G4 + OB::G2 + OB::G1));
   constexpr int NMM = 4 * TM * TN;
-  static_assert(NRD <= NMM, "not enough MFMAs in a block to carry its reads");
-  __builtin_amdgcn_s_barrier();                                        // barrier 0: stage 0 is in LDS
+  constexpr int DMA_GAP = (NMM - NRD) / NPW >= 4 ? 4 : ((NMM - NRD) / NPW >= 2 ? 2 : 1);
+  static_assert(NRD + NPW * DMA_GAP <= NMM, "not enough MFMAs in a block to carry its loads");
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+#pragma unroll
+    for (int p = 0; p < NPW; ++p) issue_piece(s * STAGE, p);
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * NPW) : "memory");       // the first stage has landed
+  __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   fetch(0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
   int bcur = 0;
-  for (int s = 0; s < g.nst; ++s) {
+  for (int s = 0; s < nloc; ++s) {
     const int bnext = (bcur + STAGE == NS * STAGE) ? 0 : bcur + STAGE;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       const int rb = kb & 1;
       if (kb + 1 < KB) {
         fetch(bcur, kb + 1, rb ^ 1);
+        mma(rb, 0, NMM);
+        colacc(rb);
+#pragma unroll
+        for (int i = 0; i < NRD; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMM - NRD, 0);
       } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                  // barrier s + 1
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * NPW) : "memory");
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         fetch(bnext, 0, rb ^ 1);
-      }
-      mma(rb);
+        mma(rb, 0, NRD);
 #pragma unroll
-      for (int i = 0; i < NRD; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int i = 0; i < NRD; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < NPW; ++p) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(bcur, p);
+          mma(rb, NRD + p * DMA_GAP, NRD + (p + 1) * DMA_GAP);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(rb, NRD + NPW * DMA_GAP, NMM);
+        colacc(rb);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, NMM - NRD, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     bcur = bnext;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the pieces issued past the last stage
 
-  // ---- epilogue
+  if constexpr (CS) {
+    if (csf != 0.f) {            // wave-uniform.  Lane group q summed the k rows 16 kb + 4 q + e: fold the four groups
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        float v = cs[tn];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const int col = col_of(tn);
+        if (q == 0 && col < g.N) g.colsum[col] = v;
+      }
+    }
+  }
+
+  // ---- split-K fix-up (see the header): rows owned by another split go out, rows owned by this one take the peers in
+  if (S > 1) {
+    constexpr int ROWB = TN * 64 * 16;                 // bytes of one (wave, tile row): TN tiles x 64 lanes x 16 bytes
+    constexpr int WGB = NW * TM * ROWB;                // bytes of one workgroup's partial tile
+    float* wk = g.work + (second ? (long)nwg * (WGB / 4) : 0);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(wk, 0, (unsigned)(nwg * WGB), 0x00020000);
+    const unsigned my = (unsigned)(u * WGB + wave * TM * ROWB + lane * 16);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      if ((wave * TM + tm) % S == z) continue;         // wave-uniform
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) g3_st4_wt(rw, my + tm * ROWB + tn * 1024, acc[tm][tn]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores ...
+    __syncthreads();                                    // ... before ONE lane arrives for the workgroup
+    unsigned* cnt = g.sync + t + (second ? MT * NTl : 0);
+    if (tid == 0) {
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 22)) {                     // a peer never arrived: flag it, do not hang the grid
+          __hip_atomic_store(g.sync + g.err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      if ((wave * TM + tm) % S != z) continue;
+      // split order, this split's own row (from its registers) in its place; the peers' rows are fetched four splits at a
+      // time so that 4 TN independent 16-byte loads are in flight (one split per trip = S - 1 dependent round trips)
+      floatx4 sum[TN];
+      const unsigned rowoff = (unsigned)(wave * TM * ROWB + lane * 16 + tm * ROWB);
+      for (int zz0 = 0; zz0 < S; zz0 += 4) {
+        floatx4 pv[4][TN];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const int zz = zz0 + d;
+          if (zz < S && zz != z) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) pv[d][tn] = g3_ld4_sc1(rw, (unsigned)((t * S + zz) * WGB) + rowoff + tn * 1024);
+          }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const int zz = zz0 + d;
+          if (zz >= S) break;
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const floatx4 v = (zz == z) ? acc[tm][tn] : pv[d][tn];
+            sum[tn] = (zz == 0) ? v : sum[tn] + v;
+          }
+        }
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = sum[tn];
+    }
+    // re-arm: the LAST workgroup of the tile to get here (every peer has seen the S arrivals) zeroes the counter
+    if (tid == 0) {
+      const unsigned prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev == 2u * (unsigned)S - 1u) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+
+  // ---- epilogue (with S > 1: only the rows this split owns)
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
+    if (S > 1 && (wave * TM + tm) % S != z) continue;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int row = row_of(tm, 4 * q + reg);
       if (row >= g.M) continue;
-      float* crow = g.C + (long)row * g.ldc;
+      float* crow = Cg + (long)row * g.ldc;
       if constexpr (B_KC) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -372,10 +501,22 @@ __global__ __launch_bounds__(64 * (WGM * WGN + 1)) void gemm3_kernel(G3Args g) {
 template <bool A_KC, bool B_KC, int TM, int TN, int WGM, int WGN, int BK, int NS>
 int32_t g3_launch(const G3Args& g0, hipStream_t s) {
   constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
-  constexpr int shmem = NS * (BM + BN) * BK * 4;
+  constexpr int shmem = NS * (BM + BN) * BK * 4 + 1024;
   static_assert(shmem <= 160 * 1024, "LDS ring does not fit");
   G3Args g = g0;
   g.nst = (g.K + BK - 1) / BK;
+  if (g.splitk < 1) g.splitk = 1;
+  if (g.splitk > g.nst) g.splitk = g.nst;
+  g.nst_split = (g.nst + g.splitk - 1) / g.splitk;
+  g.splitk = (g.nst + g.nst_split - 1) / g.nst_split;          // no empty split
+  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  g.err_word = tiles * (g.A2 ? 2 : 1);
+  if (g.splitk > 1) {
+    if (g.work == nullptr || g.sync == nullptr) return TNT_BADARG(17);
+    if ((long)tiles * g.splitk * BM * BN * 4 > (1L << 31)) return TNT_BADARG(17);
+    if (tiles * g.splitk * (g.A2 ? 2 : 1) > 1024) return TNT_BADARG(16);   // the splits of a tile wait for each other: one round only
+    if (g.colsum != nullptr) return TNT_BADARG(7);              // the column-sum rider needs the whole K in one workgroup
+  }
   auto kern = gemm3_kernel<A_KC, B_KC, TM, TN, WGM, WGN, BK, NS>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -383,8 +524,7 @@ int32_t g3_launch(const G3Args& g0, hipStream_t s) {
       return TNT_BADARG(90);
     attr_set = true;
   }
-  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * (WGM * WGN + 1)), shmem, s, g);
+  hipLaunchKernelGGL(kern, dim3(tiles * g.splitk, g.A2 ? 2 : 1), dim3(64 * WGM * WGN), shmem, s, g);
   TNT_LAUNCH_CHECK();
   return 0;
 }
@@ -397,37 +537,116 @@ int32_t g3_layout(const G3Args& g, bool tA, bool tB, hipStream_t s) {
   return TNT_BADARG(12);
 }
 
+struct G3Tile { int bm, bn, lds; float eff; };
+// Workgroup tile, LDS bytes and steady-state MFMA efficiency of configuration `tile` (the table of tnt_gemm3_f32).
+// eff = measured fraction of the FP32-MFMA rate the K loop sustains (slope of time over K, tools/gemm3_scan.py with
+// G3_KSCALE=1; profiles/r03_gemm3_scan.txt): big wave tiles amortise the LDS-DMA pieces and fragment reads best.
+bool g3_tile(int tile, G3Tile& o) {
+  switch (tile) {
+    case 1: o = {160, 128, 3 * 36864 + 1024, 0.93f}; return true;
+    case 2: o = {128, 160, 3 * 36864 + 1024, 0.89f}; return true;
+    case 3: o = {128, 128, 3 * 32768 + 1024, 0.90f}; return true;
+    case 4: o = {128, 80, 3 * 26624 + 1024, 0.88f}; return true;
+    case 5: o = {64, 128, 3 * 24576 + 1024, 0.88f}; return true;
+    case 6: o = {128, 64, 3 * 24576 + 1024, 0.85f}; return true;
+    case 7: o = {64, 64, 3 * 16384 + 1024, 0.82f}; return true;
+    case 8: o = {256, 80, 3 * 43008 + 1024, 0.90f}; return true;
+    case 9: o = {64, 64, 3 * 32768 + 1024, 0.83f}; return true;
+    case 10: o = {64, 128, 3 * 49152 + 1024, 0.88f}; return true;
+    case 11: o = {128, 64, 3 * 49152 + 1024, 0.84f}; return true;
+    default: return false;
+  }
+}
+constexpr int G3_NTILES = 11;
+
+// Estimated launch time in us of (tile, splitk) on a 256-CU gfx950: fixed cost (launch, first stage, epilogue stores) +
+// the busiest CU's MFMA time / eff + the in-launch split-K exchange (a cross-workgroup hand-off costs ~6 us on this chip
+// whatever its size; MI355X_MICROARCH.md price list, "splitk-seam").  Calibrated against tools/gemm3_scan.py.
+double g3_cost(int M, int N, int K, int batch, int tile, int splitk, bool* ok) {
+  G3Tile tl;
+  *ok = false;
+  if (!g3_tile(tile, tl)) return 1e30;
+  const long tiles = (long)((M + tl.bm - 1) / tl.bm) * ((N + tl.bn - 1) / tl.bn);
+  const long units = tiles * splitk * batch;
+  if (splitk > 1 && units > 256) return 1e30;                 // the splits of a tile wait for each other: one round only
+  if (units > 4096) return 1e30;
+  const int bk = tile >= 9 ? 64 : 32;
+  const int nst = (K + bk - 1) / bk, per = (nst + splitk - 1) / splitk;
+  if (splitk > 1 && (per < 4 || (nst + per - 1) / per != splitk)) return 1e30;
+  const int resident = 163840 / tl.lds < 1 ? 1 : 163840 / tl.lds;
+  const long per_cu = (units + 255) / 256;                    // workgroups the busiest CU runs
+  const double t_wg = (double)tl.bm * tl.bn * per * bk * 2.0 / 256.0 / 2400.0;       // us at the full MFMA rate
+  double eff = tl.eff;
+  if (per_cu > 1 && resident > 1) eff = eff * 1.04 > 0.95 ? 0.95 : eff * 1.04;      // co-resident workgroups hide each other's stalls
+  // fixed: launch + the first stages' latency (a 64-deep stage takes longer to land) + the epilogue's stores
+  const double fixed = 4.0 + (bk == 64 ? 0.8 : 0.0) + (double)M * N * batch * 4.0 / 4.0e6;
+  *ok = true;
+  return fixed + per_cu * t_wg / eff + (splitk > 1 ? 6.0 + 0.5 * splitk : 0.0);
+}
+
 }  // namespace
 
-extern "C" int32_t tnt_gemm3_f32(const float* A, const float* B, float* C, const float* bias, int32_t M, int32_t N,
-                                 int32_t K, int32_t lda, int32_t ldb, int32_t ldc, int32_t transA, int32_t transB,
-                                 int32_t cfg, void* stream) {
-  if (M <= 0 || N <= 0 || K <= 0) return TNT_BADARG(5);
-  if (transA && transB) return TNT_BADARG(12);
+extern "C" int32_t tnt_gemm3_work_floats(int32_t M, int32_t N, int32_t tile, int32_t splitk, int32_t batch) {
+  G3Tile tl;
+  if (!g3_tile(tile, tl) || splitk <= 1) return 0;
+  const long tiles = (long)((M + tl.bm - 1) / tl.bm) * ((N + tl.bn - 1) / tl.bn);
+  return (int32_t)(tiles * splitk * tl.bm * tl.bn * (batch > 1 ? 2 : 1));
+}
+extern "C" int32_t tnt_gemm3_sync_words(int32_t M, int32_t N, int32_t tile, int32_t batch) {
+  G3Tile tl;
+  if (!g3_tile(tile, tl)) return 0;
+  return ((M + tl.bm - 1) / tl.bm) * ((N + tl.bn - 1) / tl.bn) * (batch > 1 ? 2 : 1) + 1;
+}
+
+extern "C" int32_t tnt_gemm3_plan(int32_t M, int32_t N, int32_t K, int32_t transA, int32_t transB, int32_t batch,
+                                  int32_t allow_split, int32_t* tile, int32_t* splitk) {
+  if (M <= 0 || N <= 0 || K <= 0 || !tile || !splitk) return TNT_BADARG(1);
+  if (transA && transB) return TNT_BADARG(5);
+  double best = 1e30;
+  *tile = 0; *splitk = 1;
+  const int ss[] = {1, 2, 3, 4, 6, 8};
+  for (int t = 1; t <= G3_NTILES; ++t)
+    for (int s : ss) {
+      if (s > 1 && !allow_split) continue;
+      bool ok;
+      const double c = g3_cost(M, N, K, batch > 1 ? 2 : 1, t, s, &ok);
+      if (ok && c < best) { best = c; *tile = t; *splitk = s; }
+    }
+  return *tile ? 0 : TNT_BADARG(2);
+}
+
+extern "C" int32_t tnt_gemm3_f32(const float* A, const float* B, float* C, const float* bias, float* colsum,
+                                 const float* A2, float* C2, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
+                                 int32_t ldc, int32_t transA, int32_t transB, int32_t tile, int32_t splitk, float* work,
+                                 uint32_t* sync, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return TNT_BADARG(8);
+  if (transA && transB) return TNT_BADARG(15);
   if (!tnt_aligned16(A) || !tnt_aligned16(B) || !tnt_aligned16(C) || lda % 4 || ldb % 4 || ldc % 4) return TNT_BADARG(1);
+  if ((A2 == nullptr) != (C2 == nullptr)) return TNT_BADARG(6);
+  if (A2 && (!tnt_aligned16(A2) || !tnt_aligned16(C2))) return TNT_BADARG(6);
+  if (colsum != nullptr && !(transA && !transB)) return TNT_BADARG(5);
+  if (work && !tnt_aligned16(work)) return TNT_BADARG(15);
   const long rowsA = transA ? K : M, rowsB = transB ? N : K;
   if (rowsA * lda >= (1L << 29) || rowsB * ldb >= (1L << 29)) return TNT_BADARG(2);      // 32-bit buffer offsets
   G3Args g;
-  g.A = A; g.B = B; g.C = C; g.bias = bias;
-  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.nst = 0;
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.work = work; g.sync = sync;
+  g.A2 = A2; g.C2 = C2; g.colsum = colsum;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.nst = 0; g.splitk = splitk;
   hipStream_t s = tnt_stream(stream);
   const bool tA = transA != 0, tB = transB != 0;
-  switch (cfg) {
+  switch (tile) {
     //                  TM TN WGM WGN BK NS
-    case 1: return g3_layout<5, 4, 2, 2, 32, 2>(g, tA, tB, s);       // 160 x 128, 4 waves of 80 x 64
-    case 2: return g3_layout<5, 4, 2, 2, 32, 3>(g, tA, tB, s);
-    case 3: return g3_layout<5, 4, 2, 2, 32, 4>(g, tA, tB, s);
-    case 4: return g3_layout<2, 5, 4, 1, 32, 2>(g, tA, tB, s);       // 128 x  80, 4 waves of 32 x 80
-    case 5: return g3_layout<2, 5, 4, 1, 32, 3>(g, tA, tB, s);
-    case 6: return g3_layout<2, 5, 4, 1, 32, 4>(g, tA, tB, s);
-    case 7: return g3_layout<2, 4, 2, 2, 32, 2>(g, tA, tB, s);       //  64 x 128, 4 waves of 32 x 64
-    case 8: return g3_layout<2, 4, 2, 2, 32, 4>(g, tA, tB, s);
-    case 9: return g3_layout<2, 2, 2, 2, 32, 2>(g, tA, tB, s);       //  64 x  64, 4 waves of 32 x 32
-    case 10: return g3_layout<2, 2, 2, 2, 32, 4>(g, tA, tB, s);
-    case 11: return g3_layout<4, 4, 2, 2, 32, 3>(g, tA, tB, s);      // 128 x 128, 4 waves of 64 x 64
-    case 12: return g3_layout<4, 2, 2, 2, 32, 4>(g, tA, tB, s);      // 128 x  64, 4 waves of 64 x 32
-    case 13: return g3_layout<4, 5, 2, 2, 32, 3>(g, tA, tB, s);      // 128 x 160, 4 waves of 64 x 80
-    case 14: return g3_layout<4, 4, 4, 2, 32, 2>(g, tA, tB, s);      // 256 x 128, 8 waves of 64 x 64
+    case 1: return g3_layout<5, 4, 2, 2, 32, 3>(g, tA, tB, s);       // 160 x 128, 4 waves of 80 x 64
+    case 2: return g3_layout<4, 5, 2, 2, 32, 3>(g, tA, tB, s);       // 128 x 160, 4 waves of 64 x 80
+    case 3: return g3_layout<4, 4, 2, 2, 32, 3>(g, tA, tB, s);       // 128 x 128, 4 waves of 64 x 64
+    case 4: return g3_layout<2, 5, 4, 1, 32, 3>(g, tA, tB, s);       // 128 x  80, 4 waves of 32 x 80
+    case 5: return g3_layout<2, 4, 2, 2, 32, 3>(g, tA, tB, s);       //  64 x 128, 4 waves of 32 x 64
+    case 6: return g3_layout<4, 2, 2, 2, 32, 3>(g, tA, tB, s);       // 128 x  64, 4 waves of 64 x 32
+    case 7: return g3_layout<2, 2, 2, 2, 32, 3>(g, tA, tB, s);       //  64 x  64, 4 waves of 32 x 32
+    case 8: return g3_layout<4, 5, 4, 1, 32, 3>(g, tA, tB, s);       // 256 x  80, 4 waves of 64 x 80
+    case 9: return g3_layout<2, 2, 2, 2, 64, 3>(g, tA, tB, s);       //  64 x  64, 64-deep stages
+    case 10: return g3_layout<2, 4, 2, 2, 64, 3>(g, tA, tB, s);      //  64 x 128
+    case 11: return g3_layout<4, 2, 2, 2, 64, 3>(g, tA, tB, s);      // 128 x  64
     default: return TNT_BADARG(13);
   }
 }

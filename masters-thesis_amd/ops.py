@@ -65,10 +65,28 @@ class HipBackend:
         self._call(self.lib.tnt_gemm_fused_f32, "tnt_gemm_fused_f32", _p(A), _p(B), _p(C), _p(bias), _p(colsum), _p(A2), _p(C2),
                    M, N, K, lda, ldb, ldc, int(transA), int(transB), cfg, self._s())
 
-    def gemm3(self, A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, cfg=0):
-        """the round-3 FP32-MFMA family (LDS-DMA staged, b128 fragments): C = op(A) op(B) (+ bias)"""
-        self._call(self.lib.tnt_gemm3_f32, "tnt_gemm3_f32", _p(A), _p(B), _p(C), _p(bias), M, N, K, lda, ldb, ldc,
-                   int(transA), int(transB), cfg, self._s())
+    def gemm3(self, A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, colsum=None, A2=None, C2=None,
+              tile=1, splitk=1, work=None, sync=None):
+        """the round-3 FP32-MFMA family (LDS-DMA staged, b128 fragments): C = op(A) op(B) (+ bias); riders: column sums of B,
+        a second product sharing B; splitk > 1 reduces the K splits inside the launch (work / sync: gemm3_work_floats /
+        gemm3_sync_words)"""
+        self._call(self.lib.tnt_gemm3_f32, "tnt_gemm3_f32", _p(A), _p(B), _p(C), _p(bias), _p(colsum), _p(A2), _p(C2),
+                   M, N, K, lda, ldb, ldc, int(transA), int(transB), tile, splitk, _p(work), _p(sync), self._s())
+
+    def gemm3_plan(self, M, N, K, transA=False, transB=False, batch=1, allow_split=True):
+        """(tile, splitk) of the library's cost model for this shape"""
+        import ctypes
+        t, s = ctypes.c_int32(0), ctypes.c_int32(1)
+        rc = self.lib.tnt_gemm3_plan(M, N, K, int(transA), int(transB), batch, int(allow_split), ctypes.byref(t), ctypes.byref(s))
+        if rc != 0:
+            raise RuntimeError(f"tnt_gemm3_plan failed: {rc}")
+        return int(t.value), int(s.value)
+
+    def gemm3_work_floats(self, M, N, tile, splitk, batch=1):
+        return int(self.lib.tnt_gemm3_work_floats(M, N, tile, splitk, batch))
+
+    def gemm3_sync_words(self, M, N, tile, batch=1):
+        return int(self.lib.tnt_gemm3_sync_words(M, N, tile, batch))
 
     def gemm_tile(self, A, B, C, M, N, K, lda, ldb, ldc, bm, bn, transA=False, transB=False, bias=None, pre=None,
                   act=ACT_NONE, slope=0.2, accumulate=False, splitk=1, work=None):

@@ -7,7 +7,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import masters_thesis_amd.ops as ops
 be = ops.backend()
-CFGS = [int(c) for c in os.environ.get("G3_CFGS", "1,2,3,4,5,6,7,8,9,10,11,12,13,14").split(",")]
+# candidates: tile[:splitk] ...  (tiles: table of tnt_gemm3_f32 in csrc/gemm3.hip)
+CFGS = [tuple(int(v) for v in c.split(":")) if ":" in c else (int(c), 1)
+        for c in os.environ.get("G3_CFGS", "1,2,3,4,5,6,7,8,1:2,2:2,3:2,3:4,8:2,6:2,1:10,3:8,3:16,6:4").split(",")]
 ROUNDS, REPS = int(os.environ.get("G3_ROUNDS", "5")), int(os.environ.get("G3_REPS", "20"))
 shapes = [  # name, M, N, K, tA, tB, bias
     ("head fwd NN", 960, 5001, 512, 0, 0, 1), ("head dW TN", 512, 5001, 960, 1, 0, 0), ("head dX NT", 960, 512, 5001, 0, 1, 0),
@@ -45,8 +47,28 @@ for name, M, N, K, tA, tB, hb in shapes:
         cands["lt"] = lambda: be.gemm_lt(A, Bm, Cm, M, N, K, lda, ldb, ldc, transA=bool(tA), transB=bool(tB), bias=bias)
     if not hb:
         cands["blas"] = lambda: be.gemm_blas(A, Bm, Cm, M, N, K, lda, ldb, ldc, transA=bool(tA), transB=bool(tB))
-    for c in CFGS:
-        cands[f"g3/{c}"] = (lambda c=c: be.gemm3(A, Bm, Cm, M, N, K, lda, ldb, ldc, transA=bool(tA), transB=bool(tB), bias=bias, cfg=c))
+    dual = bool(tA and not tB and os.environ.get("G3_DUAL"))          # TN: second product + column sums ride along
+    if dual:
+        A2 = torch.zeros_like(A); A2[:, :M].normal_()
+        C2 = torch.zeros(M, ldc, device="cuda"); col = torch.zeros(ldc, device="cuda")
+        want2 = A2[:, :M].t().double() @ opB
+        wantc = opB.sum(0)
+    pt, ps = be.gemm3_plan(M, N, K, bool(tA), bool(tB))
+    plan_key = f"g3/{pt}:{ps}"
+    for tile, sk in CFGS + ([(pt, ps)] if (pt, ps) not in CFGS else []):
+        if dual and sk == 1:
+            def run(tile=tile):
+                be.gemm3(A, Bm, Cm, M, N, K, lda, ldb, ldc, transA=True, transB=False, colsum=col, A2=A2, C2=C2, tile=tile)
+            run.dual = True
+            cands[f"g3x2/{tile}:1"] = run
+        wf = be.gemm3_work_floats(M, N, tile, sk)
+        if sk > 1 and wf <= 0:
+            continue
+        work = torch.empty(max(wf, 4), device="cuda") if sk > 1 else None
+        sync = torch.zeros(be.gemm3_sync_words(M, N, tile) + 1, dtype=torch.int32, device="cuda") if sk > 1 else None
+        cands[f"g3/{tile}:{sk}"] = (lambda tile=tile, sk=sk, work=work, sync=sync: be.gemm3(
+            A, Bm, Cm, M, N, K, lda, ldb, ldc, transA=bool(tA), transB=bool(tB), bias=bias, tile=tile, splitk=sk, work=work, sync=sync))
+        cands[f"g3/{tile}:{sk}"].sync = sync
     status, times = {}, {k: [] for k in cands}
     for k, fn in list(cands.items()):
         Cm.zero_()
@@ -56,11 +78,18 @@ for name, M, N, K, tA, tB, hb in shapes:
         except Exception as e:
             status[k] = "n/a"; del cands[k]; continue
         err = (Cm[:, :N].double() - want).abs().max().item() / scale
+        if getattr(fn, "dual", False):
+            err = max(err, (C2[:, :N].double() - want2).abs().max().item() / want2.abs().max().item(),
+                      (col[:N].double() - wantc).abs().max().item() / wantc.abs().max().item())
         pad_clean = bool((Cm[:, N:] == 0).all().item())
-        status[k] = "ok" if err < 2e-6 * max(1.0, (K / 1024) ** 0.5) * 2 and pad_clean else f"ERR {err:.1e}{'' if pad_clean else ' pad'}"
+        sy = getattr(fn, "sync", None)
+        sync_ok = sy is None or not bool(sy.any().item())
+        status[k] = ("ok" if err < 2e-6 * max(1.0, (K / 1024) ** 0.5) * 2 and pad_clean and sync_ok
+                     else f"ERR {err:.1e}{'' if pad_clean else ' pad'}{'' if sync_ok else ' sync'}")
     for _ in range(ROUNDS):
         for k, fn in cands.items():
             times[k].append(timeit(fn, REPS))
     fl = 2.0 * M * N * K
     res = sorted((statistics.median(v), min(v), k) for k, v in times.items() if v)
-    print(f"{name:15s} {M}x{N}x{K} | " + " ".join(f"[{k} {u:.1f}us(min {mn:.1f}) {fl/u/1e6:.0f}TF {status[k]}]" for u, mn, k in res), flush=True)
+    tf = lambda k, u: fl * (2 if k.startswith("g3x2") else 1) / u / 1e6
+    print(f"{name:15s} {M}x{N}x{K} plan={plan_key} | " + " ".join(f"[{k} {u:.1f}us(min {mn:.1f}) {tf(k, u):.0f}TF {status[k]}]" for u, mn, k in res), flush=True)
