@@ -137,9 +137,12 @@ def _work_model(name, a):
     """(group key, algorithmic FLOPs, algorithmic HBM bytes) of one recorded C-ABI call (argument layouts: include/tnt_hip.h).
     SURVEY 8d: a GEMM is 2*M*N*K FLOPs and reads A, B / writes C once; an LSTM step is 2*B*4U*U FLOPs; the optimizer
     moves 7 words per parameter, the norm pass 2."""
-    if name in ("tnt_gemm_f32", "tnt_gemm_blas_f32", "tnt_gemm_fused_f32", "tnt_gemm_lt_f32"):
+    if name in ("tnt_gemm_f32", "tnt_gemm_blas_f32", "tnt_gemm_fused_f32", "tnt_gemm_lt_f32", "tnt_gemm3_f32"):
         nb = 1
-        if name == "tnt_gemm_lt_f32":
+        if name == "tnt_gemm3_f32":         # (A, B, C, bias, colsum, A2, C2, M, N, K, lda, ldb, ldc, tA, tB, tile, splitk, ...)
+            M, N, K, tA, tB = a[7], a[8], a[9], a[13], a[14]
+            nb = 2 if a[5] else 1
+        elif name == "tnt_gemm_lt_f32":
             M, N, K, tA, tB = a[4], a[5], a[6], a[10], a[11]
         elif name == "tnt_gemm_f32":
             M, N, K, tA, tB = a[5], a[6], a[7], a[11], a[12]
@@ -260,7 +263,7 @@ def kernel_breakdown(model, batch, workload, reps=20, limit=12):
     if "bound" not in dom:
         raise RuntimeError(f"bench.py: the dominant call group '{dom['kernel']}' ({dom['us_per_step']} us/step) has no "
                            "work model in _work_model(); price it before reporting a roofline")
-    others = out[1:1 + limit]
+    others = out[1:] if limit is None else out[1:1 + limit]
     total = round(sum(r["us_per_step"] for r in out), 1)
     return dom, others, total
 

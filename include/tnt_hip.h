@@ -99,9 +99,11 @@ int32_t tnt_gemm3_f32(const float* A, const float* B, float* C, const float* bia
  * second product C2 = op(A2) op(B) with the same dims and strides in the same launch (the LSTM's kernel and
  * recurrent-kernel gradients share dZ).
  * splitk > 1: K is split over `splitk` workgroups per output tile, which reduce inside the launch (fixed order).  `work`:
- * tnt_gemm3_work_floats(M, N, tile, splitk, batch) floats (contents irrelevant); `sync`: tnt_gemm3_sync_words(M, N, tile,
- * batch) uint32 words, ZERO before the first use and left zero by every launch (the last word is an error flag: nonzero
- * means a workgroup gave up waiting for its peers -- the launch did not fit the device in one round -- and C is invalid).
+ * tnt_gemm3_work_floats(M, N, tile, splitk, batch) floats, ARMED once with tnt_gemm3_work_arm (every word = the "not
+ * written yet" pattern) -- every launch leaves it armed, so launches of any shape may share one buffer as long as they run
+ * one after the other; `sync`: tnt_gemm3_sync_words(...) uint32 words (one: an error flag, zero before the first use;
+ * nonzero afterwards means a workgroup gave up waiting for a peer -- the launch did not fit the device in one round -- and
+ * C is invalid).
  * batch = 2 with A2 / C2, else 1. */
 /* The (tile, splitk) the library's cost model picks for a shape (batch = 2 for a dual launch; allow_split = 0 restricts
  * the choice to splitk = 1, which the colsum rider needs). */
@@ -109,6 +111,7 @@ int32_t tnt_gemm3_plan(int32_t M, int32_t N, int32_t K, int32_t transA, int32_t 
                        int32_t allow_split, int32_t* tile, int32_t* splitk);
 int32_t tnt_gemm3_work_floats(int32_t M, int32_t N, int32_t tile, int32_t splitk, int32_t batch);
 int32_t tnt_gemm3_sync_words(int32_t M, int32_t N, int32_t tile, int32_t batch);
+int32_t tnt_gemm3_work_arm(float* work, int64_t floats, void* stream);
 
 /* tuning entry point: tnt_gemm_f32 with the workgroup tile forced to bm x bn (each 64 or 128; anything else =
  * the library's own choice).  Used by tools/gemm_bench.py / gemm_scan.py to calibrate the tile heuristic. */

@@ -32,6 +32,7 @@
 //    owns, in split order (bitwise reproducible), before the ordinary epilogue.  Each workgroup moves (S-1)/S of a tile
 //    out and in; no reduce launch, no second pass over C.
 #include "tnt_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -39,7 +40,7 @@ struct G3Args {
   const float* A; const float* B; float* C; const float* bias;
   const float* A2; float* C2;   // optional second product C2 = op(A2) op(B) in the same launch (blockIdx.y = 1)
   float* colsum;                // optional (TN, no split): colsum[n] = sum_k B[k][n]
-  float* work; unsigned* sync;  // split-K exchange: partial tiles; one counter per output tile + an error word
+  float* work; unsigned* sync;  // split-K exchange: partial tiles (sentinel-armed); sync[0] = error word
   int M, N, K, lda, ldb, ldc;
   int nst;                    // K stages in all
   int splitk, nst_split;      // workgroups per output tile, stages per workgroup
@@ -53,6 +54,7 @@ struct G3Args {
 // (s_waitcnt vmcnt(N) before the barrier that publishes a stage); the compiler's own waits can only over-wait.
 // M0 carries the LDS address and is written in the same statement that uses it.
 typedef int g3_v4i __attribute__((ext_vector_type(4)));
+constexpr int G3_SENTINEL = 0x7FC5EED5;       // "not written yet" in the split-K exchange buffer (a quiet NaN payload)
 __device__ __forceinline__ g3_v4i g3_rsrc(const void* base, unsigned bytes) {
   const unsigned long long p = reinterpret_cast<unsigned long long>(base);
   return g3_v4i{(int)(unsigned)p, (int)(unsigned)((p >> 32) & 0xffffu), (int)bytes, 0x00020000};
@@ -393,70 +395,75 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm3_kernel(G3Args g) {
     }
   }
 
-  // ---- split-K fix-up (see the header): rows owned by another split go out, rows owned by this one take the peers in
+  // ---- split-K fix-up (see the header): rows owned by another split go out, rows owned by this one take the peers in.
+  // THE DATA IS ITS OWN FLAG: every 16-byte granule of the work buffer holds the sentinel (a NaN bit pattern no arithmetic
+  // here produces) unless a producer has written it in THIS launch.  A producer stores its rows write-through and is done
+  // -- no drain, no counter; the owner re-issues its L1-bypassing loads of a row until no word is the sentinel, adds in
+  // split order, and writes the sentinel back, which re-arms the granule for the next launch (launches that share a work
+  // buffer run one after the other on a stream).  One memory round trip each way instead of store-drain + barrier +
+  // counter add + counter poll + barrier + loads (measured: 6-8 us per launch whatever the tile size).
   if (S > 1) {
     constexpr int ROWB = TN * 64 * 16;                 // bytes of one (wave, tile row): TN tiles x 64 lanes x 16 bytes
     constexpr int WGB = NW * TM * ROWB;                // bytes of one workgroup's partial tile
     float* wk = g.work + (second ? (long)nwg * (WGB / 4) : 0);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(wk, 0, (unsigned)(nwg * WGB), 0x00020000);
-    const unsigned my = (unsigned)(u * WGB + wave * TM * ROWB + lane * 16);
+    const unsigned rowoff = (unsigned)(wave * TM * ROWB + lane * 16);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       if ((wave * TM + tm) % S == z) continue;         // wave-uniform
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) g3_st4_wt(rw, my + tm * ROWB + tn * 1024, acc[tm][tn]);
+      for (int tn = 0; tn < TN; ++tn) g3_st4_wt(rw, (unsigned)(u * WGB) + rowoff + tm * ROWB + tn * 1024, acc[tm][tn]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores ...
-    __syncthreads();                                    // ... before ONE lane arrives for the workgroup
-    unsigned* cnt = g.sync + t + (second ? MT * NTl : 0);
-    if (tid == 0) {
-      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned spins = 0;
-      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 22)) {                     // a peer never arrived: flag it, do not hang the grid
-          __hip_atomic_store(g.sync + g.err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-    }
-    __syncthreads();
+    const floatx4 sent4 = __builtin_bit_cast(floatx4, g3_v4i{G3_SENTINEL, G3_SENTINEL, G3_SENTINEL, G3_SENTINEL});
+    bool timed_out = false;
+    // one owned row: pre = the splits before this one, in order; row = pre + row; then the splits behind it, in order
+    // (a + b == b + a exactly, so this is the split-order sum with the own row in its place)
+    auto fix_row = [&](floatx4 (&row)[TN], int tm) __attribute__((always_inline)) {
+      floatx4 pre[TN];
+      for (int zz = 0; zz < S; ++zz) {
+        if (zz == z) {
+          if (zz > 0) {
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      if ((wave * TM + tm) % S != z) continue;
-      // split order, this split's own row (from its registers) in its place; the peers' rows are fetched four splits at a
-      // time so that 4 TN independent 16-byte loads are in flight (one split per trip = S - 1 dependent round trips)
-      floatx4 sum[TN];
-      const unsigned rowoff = (unsigned)(wave * TM * ROWB + lane * 16 + tm * ROWB);
-      for (int zz0 = 0; zz0 < S; zz0 += 4) {
-        floatx4 pv[4][TN];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const int zz = zz0 + d;
-          if (zz < S && zz != z) {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) pv[d][tn] = g3_ld4_sc1(rw, (unsigned)((t * S + zz) * WGB) + rowoff + tn * 1024);
+            for (int tn = 0; tn < TN; ++tn) row[tn] = pre[tn] + row[tn];
           }
+          continue;
         }
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const int zz = zz0 + d;
-          if (zz >= S) break;
+        floatx4 pv[TN];
+        const unsigned peer = (unsigned)((t * S + zz) * WGB) + rowoff + tm * ROWB;
+        for (int spin = 0;; ++spin) {
+          int pending = 0;
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn) {
-            const floatx4 v = (zz == z) ? acc[tm][tn] : pv[d][tn];
-            sum[tn] = (zz == 0) ? v : sum[tn] + v;
+            pv[tn] = g3_ld4_sc1(rw, peer + tn * 1024);
+            const g3_v4i b = __builtin_bit_cast(g3_v4i, pv[tn]);
+            pending |= (b.x == G3_SENTINEL) | (b.y == G3_SENTINEL) | (b.z == G3_SENTINEL) | (b.w == G3_SENTINEL);
           }
+          if (!__any(pending)) break;                   // the wave moves on together
+          if (spin > (1 << 20)) { timed_out = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) g3_st4_wt(rw, peer + tn * 1024, sent4);          // re-arm
+        if (zz < z) {
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) pre[tn] = (zz == 0) ? pv[tn] : pre[tn] + pv[tn];
+        } else {
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) row[tn] = row[tn] + pv[tn];
         }
       }
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = sum[tn];
-    }
-    // re-arm: the LAST workgroup of the tile to get here (every peer has seen the S arrivals) zeroes the counter
-    if (tid == 0) {
-      const unsigned prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (prev == 2u * (unsigned)S - 1u) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    };
+    // compile-time tile-row index (a runtime-indexed accumulator array would live in scratch memory)
+    auto each_row = [&](auto self, auto I) __attribute__((always_inline)) -> void {
+      if constexpr (decltype(I)::value < TM) {
+        constexpr int tm = decltype(I)::value;
+        if ((wave * TM + tm) % S == z) fix_row(acc[tm], tm);
+        self(self, std::integral_constant<int, tm + 1>{});
+      }
+    };
+    each_row(each_row, std::integral_constant<int, 0>{});
+    if (timed_out && lane == 0)                         // a peer never delivered: flag it (C is invalid), never hang
+      __hip_atomic_store(g.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 
   // ---- epilogue (with S > 1: only the rows this split owns)
@@ -510,7 +517,7 @@ int32_t g3_launch(const G3Args& g0, hipStream_t s) {
   g.nst_split = (g.nst + g.splitk - 1) / g.splitk;
   g.splitk = (g.nst + g.nst_split - 1) / g.nst_split;          // no empty split
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  g.err_word = tiles * (g.A2 ? 2 : 1);
+  g.err_word = 0;
   if (g.splitk > 1) {
     if (g.work == nullptr || g.sync == nullptr) return TNT_BADARG(17);
     if ((long)tiles * g.splitk * BM * BN * 4 > (1L << 31)) return TNT_BADARG(17);
@@ -547,7 +554,7 @@ bool g3_tile(int tile, G3Tile& o) {
     case 2: o = {128, 160, 3 * 36864 + 1024, 0.89f}; return true;
     case 3: o = {128, 128, 3 * 32768 + 1024, 0.90f}; return true;
     case 4: o = {128, 80, 3 * 26624 + 1024, 0.88f}; return true;
-    case 5: o = {64, 128, 3 * 24576 + 1024, 0.88f}; return true;
+    case 5: o = {64, 128, 3 * 24576 + 1024, 0.87f}; return true;
     case 6: o = {128, 64, 3 * 24576 + 1024, 0.85f}; return true;
     case 7: o = {64, 64, 3 * 16384 + 1024, 0.82f}; return true;
     case 8: o = {256, 80, 3 * 43008 + 1024, 0.90f}; return true;
@@ -561,7 +568,8 @@ constexpr int G3_NTILES = 11;
 
 // Estimated launch time in us of (tile, splitk) on a 256-CU gfx950: fixed cost (launch, first stage, epilogue stores) +
 // the busiest CU's MFMA time / eff + the in-launch split-K exchange (a cross-workgroup hand-off costs ~6 us on this chip
-// whatever its size; MI355X_MICROARCH.md price list, "splitk-seam").  Calibrated against tools/gemm3_scan.py.
+// whatever its size, even with the data as its own flag; MI355X_MICROARCH.md price list, "splitk-seam").  Calibrated against
+// tools/gemm3_scan.py.
 double g3_cost(int M, int N, int K, int batch, int tile, int splitk, bool* ok) {
   G3Tile tl;
   *ok = false;
@@ -581,7 +589,7 @@ double g3_cost(int M, int N, int K, int batch, int tile, int splitk, bool* ok) {
   // fixed: launch + the first stages' latency (a 64-deep stage takes longer to land) + the epilogue's stores
   const double fixed = 4.0 + (bk == 64 ? 0.8 : 0.0) + (double)M * N * batch * 4.0 / 4.0e6;
   *ok = true;
-  return fixed + per_cu * t_wg / eff + (splitk > 1 ? 6.0 + 0.5 * splitk : 0.0);
+  return fixed + per_cu * t_wg / eff + (splitk > 1 ? 4.5 + 0.4 * splitk : 0.0);
 }
 
 }  // namespace
@@ -593,9 +601,25 @@ extern "C" int32_t tnt_gemm3_work_floats(int32_t M, int32_t N, int32_t tile, int
   return (int32_t)(tiles * splitk * tl.bm * tl.bn * (batch > 1 ? 2 : 1));
 }
 extern "C" int32_t tnt_gemm3_sync_words(int32_t M, int32_t N, int32_t tile, int32_t batch) {
-  G3Tile tl;
-  if (!g3_tile(tile, tl)) return 0;
-  return ((M + tl.bm - 1) / tl.bm) * ((N + tl.bn - 1) / tl.bn) * (batch > 1 ? 2 : 1) + 1;
+  (void)M; (void)N; (void)tile; (void)batch;
+  return 1;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void g3_arm_kernel(g3_v4i* w, long n4) {
+  const g3_v4i v{G3_SENTINEL, G3_SENTINEL, G3_SENTINEL, G3_SENTINEL};
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) w[i] = v;
+}
+}  // namespace
+
+extern "C" int32_t tnt_gemm3_work_arm(float* work, int64_t floats, void* stream) {
+  if (work == nullptr || floats <= 0 || floats % 4 || !tnt_aligned16(work)) return TNT_BADARG(1);
+  const long n4 = floats / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(g3_arm_kernel, dim3((unsigned)blocks), dim3(256), 0, tnt_stream(stream), reinterpret_cast<g3_v4i*>(work), n4);
+  TNT_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int32_t tnt_gemm3_plan(int32_t M, int32_t N, int32_t K, int32_t transA, int32_t transB, int32_t batch,

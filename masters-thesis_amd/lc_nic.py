@@ -665,6 +665,13 @@ class NIC(ModelBase):
             self._bwd_chain_steps(B, T, Wl, Ur, W2, v)
         hprev = self.Hs[:T].view(n, U)
         gWl = a.g("lstm/kernel")
+        if getattr(self, "g3_riders", True) and Et == U and self.gemm3(
+                hprev, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True,
+                colsum=a.g("lstm/bias"), A2=self.text, C2=gWl[D:]):
+            # recurrent-kernel gradient, the text rows of the kernel gradient and the bias gradient in ONE launch: the two
+            # products share dZ, its column sums ride on the fragments the first tile row holds anyway
+            self.gemm_sk(self.ctx_d, self.dZ, gWl[:D], D, 4 * U, n, D, 4 * U, 4 * U, transA=True)
+            return
         self.gemm_sk(hprev, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True)
         self.gemm_sk(self.text, self.dZ, gWl[D:], Et, 4 * U, n, Et, 4 * U, 4 * U, transA=True)
         self.gemm_sk(self.ctx_d, self.dZ, gWl[:D], D, 4 * U, n, D, 4 * U, 4 * U, transA=True)

@@ -344,12 +344,50 @@ class ModelBase:
         need = max([self.pick_splitk(*s) * s[0] * s[1] for s in shapes] + [1])
         self.skwork = self._f(need)
 
+    def _g3_buffers(self, M, N, tile, sk, batch):
+        """Split-K exchange space of tnt_gemm3_f32: ONE work buffer and ONE zeroed counter array per model, shared by every
+        launch (launches of a model run one after the other on its stream, and every launch leaves the counters zero).
+        Grown during eager passes only; growing invalidates captured graphs."""
+        if sk <= 1:
+            return None, None
+        be = self.be
+        wf, sw = be.gemm3_work_floats(M, N, tile, sk, batch), be.gemm3_sync_words(M, N, tile, batch) + 1
+        d = self.__dict__
+        w, sy = d.get("_g3_work"), d.get("_g3_sync")
+        if w is None or w.numel() < wf or sy is None or sy.numel() < sw:
+            if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("gemm3 split-K workspace too small inside a graph capture (run one eager step first)")
+            if w is None or w.numel() < wf:
+                w = d["_g3_work"] = self._f((max(wf, 4) + 3) // 4 * 4)
+                be.gemm3_work_arm(w)
+            if sy is None or sy.numel() < sw:
+                sy = d["_g3_sync"] = torch.zeros(max(sw, 64), dtype=torch.int32, device=self.device)
+            self._graphs = {}
+        return w, sy
+
+    def gemm3(self, A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, colsum=None, A2=None, C2=None):
+        """One product (or two sharing B) on the hand-written FP32-MFMA family of csrc/gemm3.hip, tile and K split from the
+        library's cost model (tnt_gemm3_plan; cached per shape).  True = call issued."""
+        be = self.be
+        if not getattr(self, "use_gemm3", True) or not hasattr(be, "gemm3") or (transA and transB):
+            return False
+        if lda % 4 or ldb % 4 or ldc % 4:
+            return False
+        batch = 2 if A2 is not None else 1
+        key = (M, N, K, bool(transA), bool(transB), batch, colsum is not None)
+        plans = self.__dict__.setdefault("_g3_plans", {})
+        if key not in plans:
+            force = getattr(self, "g3_force", {}).get(key[:6])          # tools / tests: {(M, N, K, tA, tB, batch): (tile, splitk)}
+            plans[key] = force or be.gemm3_plan(M, N, K, transA, transB, batch, allow_split=colsum is None)
+        tile, sk = plans[key]
+        work, sync = self._g3_buffers(M, N, tile, sk, batch)
+        be.gemm3(A, B, C, M, N, K, lda, ldb, ldc, transA=transA, transB=transB, bias=bias, colsum=colsum, A2=A2, C2=C2,
+                 tile=tile, splitk=sk, work=work, sync=sync)
+        return True
+
     def _route_lt(self, A, B, C, M, N, K, lda, ldb, ldc, ws, kw):
-        """hipBLASLt (tnt_gemm_lt_f32) for the vocabulary-sized GEMMs: one dimension of N / K at least 4096, i.e. the
-        head forward and its two gradients.  On MI355X it runs 960x5001x512 / 960x512x5001 / 512x5001x960 at 110-117 TF
-        (gemm.hip's one-round kernel: 92, rocBLAS: 79-92; tools/probe/hipblaslt_probe.cpp), while the LSTM-sized products
-        (every dimension <= 2048) are level or better on rocBLAS and stay there.  A fixed rule, not a timed choice: which
-        kernel multiplies decides the rounding, and results must not depend on a timing race.  True = call issued."""
+        """A/B tool since round 3 (``use_gemm3 = False``): hipBLASLt (tnt_gemm_lt_f32) for the vocabulary-sized GEMMs, i.e. the
+        head forward and its two gradients; rocBLAS for the LSTM-sized ones (gemm_sk below).  True = call issued."""
         be = self.be
         if (not getattr(self, "use_lt", True) or not hasattr(be, "gemm_lt") or kw.get("pre") is not None or kw.get("act", 0)
                 or kw.get("accumulate") or max(N, K) < 4096 or 2.0 * M * N * K < getattr(self, "lt_min_flops", 1e9)):
@@ -364,14 +402,21 @@ class ModelBase:
         """GEMM with the calibrated split-K choice.  ``ws`` selects the split-K workspace (one per
         concurrent branch, see ``side``).  Workspaces grow on demand during eager (warm-up) passes;
         growing one invalidates captured graphs, which are then re-captured."""
-        if self._route_lt(A, B, C, M, N, K, lda, ldb, ldc, ws, kw):
+        # default since round 3: every product without an activation epilogue that is large enough to fill the chip runs on
+        # the hand-written family (csrc/gemm3.hip); the vendor libraries remain as A/B tools (use_gemm3 = False)
+        if (kw.get("pre") is None and kw.get("act", 0) == 0 and not kw.get("accumulate") and 2.0 * M * N * K >= getattr(self, "g3_min_flops", 1e8)
+                and self.gemm3(A, B, C, M, N, K, lda, ldb, ldc, transA=kw.get("transA", False), transB=kw.get("transB", False),
+                               bias=kw.get("bias"))):
+            return
+        if not getattr(self, "use_gemm3", True) and self._route_lt(A, B, C, M, N, K, lda, ldb, ldc, ws, kw):
             return
         plain = kw.get("bias") is None and kw.get("pre") is None and kw.get("act", 0) == 0
         # One shape family where the vendor's pick is poor: NT with a narrow output and a very long K (config 3's
         # head dX = dlogits[960x5001] @ Wo^T[5001x256]: 59 us = 42 TF, against 38 us for the tiled kernel with
         # split-K 16; tools/c3_head_grad_probe.py).  At N = 512 the two are level and the library stays.
         blas_poor = kw.get("transB", False) and not kw.get("transA", False) and N <= 256 and K >= 16 * N
-        if plain and not blas_poor and getattr(self, "use_blas", True) and hasattr(self.be, "gemm_blas"):
+        if (plain and not blas_poor and getattr(self, "use_blas", True) and not getattr(self, "use_gemm3", True)
+                and hasattr(self.be, "gemm_blas")):
             # no fused epilogue (weight / input gradients): the vendor's stream-K sgemm (tnt_gemm_blas_f32) needs no
             # split-K pass + reduce launch on these skinny-output / long-K shapes
             self.be.gemm_blas(A, B, C, M, N, K, lda, ldb, ldc, transA=kw.get("transA", False),

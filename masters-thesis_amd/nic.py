@@ -344,7 +344,10 @@ class NIC(ModelBase):
         U, V, ldV = self.U, self.V, self.ldV
         dlog = self.logits
         Wo = a.p("time_distributed_softmax/kernel")
-        if getattr(self, "fused_head_grads", False) and hasattr(be, "gemm_fused") and \
+        if getattr(self, "g3_riders", True) and self.gemm3(self.Out, dlog, a.g("time_distributed_softmax/kernel"), U, V, T * B,
+                                                        U, ldV, ldV, transA=True, colsum=a.g("time_distributed_softmax/bias")):
+            pass        # dW and, as a rider on the dlogits tiles it streams anyway, the bias gradient: one launch
+        elif getattr(self, "fused_head_grads", False) and hasattr(be, "gemm_fused") and \
                 be.gemm_fused_cfg(U, V, T * B, True, False, 1) > 0:
             be.gemm_fused(self.Out, dlog, a.g("time_distributed_softmax/kernel"), U, V, T * B, U, ldV, ldV, transA=True,
                           colsum=a.g("time_distributed_softmax/bias"))
@@ -393,6 +396,15 @@ class NIC(ModelBase):
             be.lstm_step_bwd(self.dZ[B:2 * B], Ur, self.da_pass, None, self.dc, None, None, None, 0, 0, self.gates[0],
                              self.Cs[1], self.Cs[0], self.dZ[:B], None, None, None, B, U)
         xin = self._xin_used
+        if getattr(self, "g3_riders", True) and E == U and self.gemm3(
+                xin, self.dZ, a.g("lstm/kernel"), E, 4 * U, R1, E, 4 * U, 4 * U, transA=True, colsum=a.g("lstm/bias"),
+                A2=self.Hs, C2=a.g("lstm/recurrent_kernel")):
+            # kernel, recurrent-kernel and bias gradients in ONE launch: the two products share dZ, the column sums of dZ
+            # ride on the fragments the first tile row holds anyway
+            d = self.__dict__.pop("_colsum_deferred", None)
+            if d is not None:
+                be.colsum(*d, self.work2)
+            return
         if getattr(self, "fused_lstm_grads", False) and E == U and hasattr(be, "gemm_fused") and \
                 be.gemm_fused_cfg(U, 4 * U, R1, True, False, 2) > 0:
             # kernel, recurrent-kernel and bias gradients in ONE launch of the one-round GEMM family: the two products

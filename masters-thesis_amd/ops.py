@@ -88,6 +88,10 @@ class HipBackend:
     def gemm3_sync_words(self, M, N, tile, batch=1):
         return int(self.lib.tnt_gemm3_sync_words(M, N, tile, batch))
 
+    def gemm3_work_arm(self, work):
+        """fill a split-K exchange buffer with the "not written yet" pattern (once; every launch leaves it armed)"""
+        self._call(self.lib.tnt_gemm3_work_arm, "tnt_gemm3_work_arm", _p(work), work.numel(), self._s())
+
     def gemm_tile(self, A, B, C, M, N, K, lda, ldb, ldc, bm, bn, transA=False, transB=False, bias=None, pre=None,
                   act=ACT_NONE, slope=0.2, accumulate=False, splitk=1, work=None):
         """tnt_gemm_f32 with the workgroup tile forced: (64|128, 64|128) = the tiled kernel, (160, 128) = the

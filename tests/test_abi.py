@@ -71,3 +71,34 @@ def test_product_has_no_cpu_fallback():
             ops.backend()
     finally:
         ops._backend = old
+
+
+def test_gemm3_plan_is_host_code_and_picks_a_one_round_grid():
+    """tnt_gemm3_plan (the cost model of csrc/gemm3.hip) runs on the host: for a spread of shapes it returns a known tile,
+    a split that leaves no workgroup without K stages, and never a split whose workgroups could not all be resident at
+    once (they wait for each other inside the launch)."""
+    import ctypes
+    from masters_thesis_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    tiles = {1: (160, 128, 32), 2: (128, 160, 32), 3: (128, 128, 32), 4: (128, 80, 32), 5: (64, 128, 32), 6: (128, 64, 32), 7: (64, 64, 32),
+             8: (256, 80, 32), 9: (64, 64, 64), 10: (64, 128, 64), 11: (128, 64, 64)}
+    for M in (5, 64, 256, 512, 960, 1024, 4096):
+        for N in (7, 256, 512, 2048, 5001):
+            for K in (3, 64, 544, 960, 2048, 5001, 20000):
+                for tA, tB in ((0, 0), (1, 0), (0, 1)):
+                    for batch in (1, 2):
+                        for allow in (0, 1):
+                            t, s = ctypes.c_int32(0), ctypes.c_int32(0)
+                            rc = lib.tnt_gemm3_plan(M, N, K, tA, tB, batch, allow, ctypes.byref(t), ctypes.byref(s))
+                            assert rc == 0 and t.value in tiles and s.value >= 1, (M, N, K, tA, tB, batch, allow, rc)
+                            bm, bn, bk = tiles[t.value]
+                            if not allow:
+                                assert s.value == 1
+                            if s.value > 1:
+                                units = -(-M // bm) * -(-N // bn) * s.value * batch
+                                nst = -(-K // bk)
+                                per = -(-nst // s.value)
+                                assert units <= 256 and -(-nst // per) == s.value and per >= 4, (M, N, K, t.value, s.value)
+                                assert lib.tnt_gemm3_work_floats(M, N, t.value, s.value, batch) == units * bm * bn
+    t, s = ctypes.c_int32(0), ctypes.c_int32(0)
+    assert lib.tnt_gemm3_plan(64, 64, 64, 1, 1, 1, 1, ctypes.byref(t), ctypes.byref(s)) != 0        # both transposed: refused

@@ -189,14 +189,28 @@ def test_pipelined_dp_schedule_world1_equals_single_gpu_step():
         dp.attach(b, 1)
         assert isinstance(b.grad_sync, dp.PipelinedDenseSync)
         rng = np.random.default_rng(6)
+        lr = 1e-3
         for step in range(5):
             data, tgt = synth_batch(B, N, T, V, U, rng)
             ra, rb = a.train_step((data, tgt)).as_floats(), b.train_step((data, tgt)).as_floats()
             for k in ra:
                 assert abs(ra[k] - rb[k]) <= 1e-6 * max(1.0, abs(ra[k])), (step, k, ra, rb)
+            if step == 0:
+                # from identical weights the two schedules must produce BIT-IDENTICAL gradients (same kernels, same order);
+                # what may differ is the last bit of a per-variable squared norm: the single-GPU step sums the span partials in
+                # its finalize launch, the schedule per arena slice (seg_sqnorm) -- two summation trees over the same numbers
+                torch.cuda.synchronize()
+                for k, e in a.arena.entries.items():
+                    ga, gb = a.arena.grad[e.off:e.off + e.size], b.arena.grad[e.off:e.off + e.size]
+                    assert torch.equal(ga, gb), k
+                    sa, sb = float(a.arena.sq[e.seg]), float(b.arena.sq[e.seg])
+                    assert abs(sa - sb) <= 4e-7 * abs(sa), (k, sa, sb)
         torch.cuda.synchronize()
+        # ... and that last bit of a clip factor is all that separates the weights: within 1e-3 of ONE Adam step after five
+        # (Adam's m / sqrt(v) turns a 1e-7 relative change of a gradient into up to ~1e-4 of a step on elements whose
+        # successive gradients nearly cancel; measured 3.7e-7 = 3.7e-4 lr on the Embedding, everything else <= 1.2e-7)
         d = (a.arena.theta - b.arena.theta).abs().max().item()
-        assert d <= 1e-7, d
+        assert d <= 1e-3 * lr, d
     finally:
         dist.destroy_process_group()
 

@@ -142,6 +142,143 @@ def test_gemm_fused(be, M, N, K, tA, tB, batch, cs, cfg):
         assert torch.equal(col[N:], torch.full((ldc - N,), 5.0, device="cuda"))
 
 
+G3_TILES = list(range(1, 12))
+
+
+def _g3_operands(M, N, K, tA, tB, seed):
+    """zero-padded operands (the K-contiguous operand's pad columns must be zero: include/tnt_hip.h) + float64 views"""
+    rng = np.random.default_rng(seed)
+    r4 = lambda n: (n + 3) // 4 * 4
+    lda, ldb, ldc = r4(M if tA else K), r4(K if tB else N), r4(N) + 4
+    A = np.zeros(((K if tA else M), lda)); A[:, :(M if tA else K)] = rng.standard_normal(((K if tA else M), (M if tA else K)))
+    A2 = np.zeros_like(A); A2[:, :(M if tA else K)] = rng.standard_normal(((K if tA else M), (M if tA else K)))
+    Bm = np.zeros(((N if tB else K), ldb)); Bm[:, :(K if tB else N)] = rng.standard_normal(((N if tB else K), (K if tB else N)))
+    opA, opA2 = (A[:, :M].T if tA else A[:, :K]), (A2[:, :M].T if tA else A2[:, :K])
+    opB = (Bm[:, :K].T if tB else Bm[:, :N])
+    return (A, A2, Bm, lda, ldb, ldc), (opA, opA2, opB)
+
+
+@pytest.mark.parametrize("M,N,K,tA,tB", [
+    (960, 5001, 512, 0, 0), (512, 5001, 960, 1, 0), (960, 512, 5001, 0, 1), (1024, 512, 2048, 0, 1), (512, 2048, 1024, 1, 0),
+    (64, 501, 120, 1, 0), (120, 501, 64, 0, 0), (120, 64, 501, 0, 1), (37, 101, 50, 0, 0), (37, 101, 50, 1, 0), (37, 101, 50, 0, 1),
+    (161, 129, 33, 0, 0), (5, 7, 3, 0, 1),
+])
+def test_gemm3(be, M, N, K, tA, tB):
+    """tnt_gemm3_f32 (csrc/gemm3.hip: LDS-DMA staged FP32-MFMA family), EVERY tile configuration on every operand layout,
+    ragged edges (rows / columns / K tails that end inside a tile, a 16-byte chunk, a K stage), with the bias rider,
+    against float64 numpy; the padding columns of C stay untouched; results bitwise equal run to run."""
+    (A, A2, Bm, lda, ldb, ldc), (opA, _, opB) = _g3_operands(M, N, K, tA, tB, M + N + K)
+    bias = np.random.default_rng(1).standard_normal(N)
+    want = opA @ opB + bias
+    Ad, Bd, bd = dev(A), dev(Bm), dev(bias)
+    tol = 1e-6 * max(1.0, (K / 256) ** 0.5)
+    for tile in G3_TILES:
+        outs = []
+        for rep in range(3):
+            C = torch.full((M, ldc), 5.0, device="cuda")
+            be.gemm3(Ad, Bd, C, M, N, K, lda, ldb, ldc, transA=bool(tA), transB=bool(tB), bias=bd, tile=tile)
+            outs.append(C)
+        close(outs[0][:, :N], want, rtol=tol)
+        assert torch.equal(outs[0][:, N:], torch.full((M, ldc - N), 5.0, device="cuda")), ("padding columns written", tile)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), ("not reproducible", tile)
+
+
+@pytest.mark.parametrize("M,N,K,tA,tB,S", [
+    (960, 512, 5001, 0, 1, 2), (960, 512, 5001, 0, 1, 4), (1024, 512, 2048, 0, 1, 2), (256, 5001, 960, 1, 0, 2), (960, 2048, 544, 0, 0, 3),
+    (64, 501, 120, 1, 0, 2), (37, 101, 150, 0, 1, 3), (161, 129, 257, 0, 0, 8), (100, 60, 1000, 1, 0, 6),
+])
+def test_gemm3_splitk_in_launch(be, M, N, K, tA, tB, S):
+    """K split over S workgroups per tile with the reduction INSIDE the launch (the sentinel-armed exchange buffer of
+    csrc/gemm3.hip): exact result against float64, bitwise reproducible over launches that reuse ONE work buffer, the buffer
+    fully re-armed after every launch (so launches of other shapes can share it), the error word untouched."""
+    (A, _, Bm, lda, ldb, ldc), (opA, _, opB) = _g3_operands(M, N, K, tA, tB, M * 3 + N + K)
+    want = opA @ opB
+    Ad, Bd = dev(A), dev(Bm)
+    tol = 1e-6 * max(1.0, (K / 256) ** 0.5)
+    for tile in (1, 3, 4, 5, 7, 9):
+        wf = be.gemm3_work_floats(M, N, tile, S)
+        if wf <= 0:
+            continue
+        work = torch.empty((wf + 3) // 4 * 4, device="cuda")
+        be.gemm3_work_arm(work)
+        armed = work.view(torch.int32).clone()
+        assert bool((armed == 0x7FC5EED5).all())
+        sync = torch.zeros(be.gemm3_sync_words(M, N, tile), dtype=torch.int32, device="cuda")
+        outs = []
+        for rep in range(3):
+            C = torch.full((M, ldc), 5.0, device="cuda")
+            try:
+                be.gemm3(Ad, Bd, C, M, N, K, lda, ldb, ldc, transA=bool(tA), transB=bool(tB), tile=tile, splitk=S, work=work, sync=sync)
+            except RuntimeError:          # more workgroups than one round holds: refused (TNT_BADARG), never a hang
+                outs = None
+                break
+            outs.append(C)
+            torch.cuda.synchronize()
+            assert torch.equal(work.view(torch.int32), armed), ("exchange buffer not re-armed", tile, rep)
+        if outs is None:
+            continue
+        assert int(sync.sum()) == 0, ("error word set", tile)
+        close(outs[0][:, :N], want, rtol=tol)
+        assert torch.equal(outs[0][:, N:], torch.full((M, ldc - N), 5.0, device="cuda")), ("padding columns written", tile)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), ("not reproducible", tile)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 2048, 1024), (512, 5001, 960), (64, 256, 128), (64, 501, 120), (37, 101, 50), (130, 70, 333)])
+def test_gemm3_riders(be, M, N, K):
+    """the TN riders of tnt_gemm3_f32: column sums of B (the bias gradient of the layer whose kernel gradient the product
+    is) and a second product sharing B (LSTM kernel + recurrent-kernel gradients, NIC.py:138-140 under tape.gradient) in
+    ONE launch -- each output against float64, padding untouched, bitwise reproducible."""
+    (A, A2, Bm, lda, ldb, ldc), (opA, opA2, opB) = _g3_operands(M, N, K, 1, 0, M + 2 * N + K)
+    Ad, A2d, Bd = dev(A), dev(A2), dev(Bm)
+    tol = 1e-6 * max(1.0, (K / 256) ** 0.5)
+    for tile in G3_TILES:
+        outs = []
+        for rep in range(2):
+            C, C2 = torch.full((M, ldc), 5.0, device="cuda"), torch.full((M, ldc), 5.0, device="cuda")
+            col = torch.full((ldc,), 5.0, device="cuda")
+            be.gemm3(Ad, Bd, C, M, N, K, lda, ldb, ldc, transA=True, colsum=col, A2=A2d, C2=C2, tile=tile)
+            outs.append((C, C2, col))
+        C, C2, col = outs[0]
+        close(C[:, :N], opA @ opB, rtol=tol)
+        close(C2[:, :N], opA2 @ opB, rtol=tol)
+        close(col[:N], opB.sum(0), atol=2e-6 * np.abs(opB).sum(0).max())
+        for x in (C, C2):
+            assert torch.equal(x[:, N:], torch.full((M, ldc - N), 5.0, device="cuda")), tile
+        assert torch.equal(col[N:], torch.full((ldc - N,), 5.0, device="cuda"))
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), ("not reproducible", tile)
+
+
+def test_gemm3_plan_and_bad_arguments(be):
+    """the cost model's pick runs and is exact on every hot-path shape of BASELINE configs 2 and 3; unsupported argument
+    combinations are refused with an error code, never launched"""
+    shapes = [(960, 5001, 512, 0, 0), (512, 5001, 960, 1, 0), (960, 512, 5001, 0, 1), (1024, 2048, 512, 0, 0), (1024, 512, 2048, 0, 1),
+              (960, 5001, 256, 0, 0), (256, 5001, 960, 1, 0), (960, 256, 5001, 0, 1), (960, 2048, 544, 0, 0), (960, 544, 2048, 0, 1),
+              (32, 2048, 960, 1, 0), (512, 256, 960, 1, 0), (960, 512, 256, 0, 1)]
+    for M, N, K, tA, tB in shapes:
+        (A, _, Bm, lda, ldb, ldc), (opA, _, opB) = _g3_operands(M, N, K, tA, tB, 7)
+        tile, S = be.gemm3_plan(M, N, K, bool(tA), bool(tB))
+        assert 1 <= tile <= 11 and 1 <= S <= 8
+        wf = be.gemm3_work_floats(M, N, tile, S)
+        work = torch.empty((max(wf, 4) + 3) // 4 * 4, device="cuda")
+        be.gemm3_work_arm(work)
+        sync = torch.zeros(1, dtype=torch.int32, device="cuda")
+        C = torch.zeros(M, ldc, device="cuda")
+        be.gemm3(dev(A), dev(Bm), C, M, N, K, lda, ldb, ldc, transA=bool(tA), transB=bool(tB), tile=tile, splitk=S, work=work, sync=sync)
+        close(C[:, :N], opA @ opB, rtol=1e-6 * max(1.0, (K / 256) ** 0.5))
+        assert int(sync.sum()) == 0
+    A = torch.zeros(64, 64, device="cuda")
+    with pytest.raises(RuntimeError):
+        be.gemm3(A, A, A, 64, 64, 64, 64, 64, 64, transA=True, transB=True)            # both transposed
+    with pytest.raises(RuntimeError):
+        be.gemm3(A, A, A, 64, 64, 64, 62, 64, 64)                                        # leading dimension not a multiple of 4
+    with pytest.raises(RuntimeError):
+        be.gemm3(A, A, A, 64, 64, 64, 64, 64, 64, splitk=2)                              # split without work / sync
+    with pytest.raises(RuntimeError):
+        be.gemm3(A, A, A, 64, 64, 64, 64, 64, 64, colsum=A)                              # column sums need transA
+    with pytest.raises(RuntimeError):
+        be.gemm3(A, A, A, 64, 64, 64, 64, 64, 64, tile=99)
+
+
 def test_gemm_splitk(be):
     rng = np.random.default_rng(0)
     M, N, K = 64, 512, 20000

@@ -15,6 +15,7 @@ shapes = [  # name, M, N, K, tA, tB, bias
     ("head fwd NN", 960, 5001, 512, 0, 0, 1), ("head dW TN", 512, 5001, 960, 1, 0, 0), ("head dX NT", 960, 512, 5001, 0, 1, 0),
     ("xproj NN", 1024, 2048, 512, 0, 0, 0), ("dU TN", 512, 2048, 1024, 1, 0, 0), ("dXin NT", 1024, 512, 2048, 0, 1, 0),
     ("c3 head fwd NN", 960, 5001, 256, 0, 0, 1), ("c3 head dW TN", 256, 5001, 960, 1, 0, 0), ("c3 head dX NT", 960, 256, 5001, 0, 1, 0),
+    ("c3 inter fwd NN", 960, 256, 512, 0, 0, 1), ("c3 inter dW TN", 512, 256, 960, 1, 0, 0), ("c3 inter dX NT", 960, 512, 256, 0, 1, 0),
     ("c3 xproj NN", 960, 2048, 544, 0, 0, 0), ("c3 dW TN", 544, 2048, 960, 1, 0, 0), ("c3 dXin NT", 960, 544, 2048, 0, 1, 0),
 ]
 if len(sys.argv) > 1:
@@ -45,6 +46,11 @@ for name, M, N, K, tA, tB, hb in shapes:
     cands = {}
     if max(N, K) >= 4096:
         cands["lt"] = lambda: be.gemm_lt(A, Bm, Cm, M, N, K, lda, ldb, ldc, transA=bool(tA), transB=bool(tB), bias=bias)
+    if K < 4096 and N < 4096:
+        sk = 1
+        while sk * 2 * ((M + 63) // 64) * ((N + 63) // 64) <= 1280 and K // (sk * 2) >= 128 and sk < 64 and K >= 256: sk *= 2
+        wk = torch.empty(sk * M * N, device="cuda")
+        cands["old"] = lambda: be.gemm(A, Bm, Cm, M, N, K, lda, ldb, ldc, transA=bool(tA), transB=bool(tB), bias=bias, splitk=sk, work=wk)
     if not hb:
         cands["blas"] = lambda: be.gemm_blas(A, Bm, Cm, M, N, K, lda, ldb, ldc, transA=bool(tA), transB=bool(tB))
     dual = bool(tA and not tB and os.environ.get("G3_DUAL"))          # TN: second product + column sums ride along
@@ -64,7 +70,8 @@ for name, M, N, K, tA, tB, hb in shapes:
         wf = be.gemm3_work_floats(M, N, tile, sk)
         if sk > 1 and wf <= 0:
             continue
-        work = torch.empty(max(wf, 4), device="cuda") if sk > 1 else None
+        work = torch.empty((max(wf, 4) + 3) // 4 * 4, device="cuda") if sk > 1 else None
+        if work is not None: be.gemm3_work_arm(work)
         sync = torch.zeros(be.gemm3_sync_words(M, N, tile) + 1, dtype=torch.int32, device="cuda") if sk > 1 else None
         cands[f"g3/{tile}:{sk}"] = (lambda tile=tile, sk=sk, work=work, sync=sync: be.gemm3(
             A, Bm, Cm, M, N, K, lda, ldb, ldc, transA=bool(tA), transB=bool(tB), bias=bias, tile=tile, splitk=sk, work=work, sync=sync))
