@@ -589,7 +589,9 @@ double g3_cost(int M, int N, int K, int batch, int tile, int splitk, bool* ok) {
   // fixed: launch + the first stages' latency (a 64-deep stage takes longer to land) + the epilogue's stores
   const double fixed = 4.0 + (bk == 64 ? 0.8 : 0.0) + (double)M * N * batch * 4.0 / 4.0e6;
   *ok = true;
-  return fixed + per_cu * t_wg / eff + (splitk > 1 ? 4.5 + 0.4 * splitk : 0.0);
+  // exchange: a fixed hand-off latency + the rows a workgroup sends and fetches ((S-1)/S of its tile each way, ~20 KB/us)
+  const double xch = splitk > 1 ? 4.0 + 0.4 * splitk + tl.bm * tl.bn * 4.0e-3 * (splitk - 1) / splitk / 20.0 : 0.0;
+  return fixed + per_cu * t_wg / eff + xch;
 }
 
 }  // namespace

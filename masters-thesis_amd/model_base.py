@@ -404,7 +404,7 @@ class ModelBase:
         growing one invalidates captured graphs, which are then re-captured."""
         # default since round 3: every product without an activation epilogue that is large enough to fill the chip runs on
         # the hand-written family (csrc/gemm3.hip); the vendor libraries remain as A/B tools (use_gemm3 = False)
-        if (kw.get("pre") is None and kw.get("act", 0) == 0 and not kw.get("accumulate") and 2.0 * M * N * K >= getattr(self, "g3_min_flops", 1e8)
+        if (kw.get("pre") is None and kw.get("act", 0) == 0 and not kw.get("accumulate") and 2.0 * M * N * K >= getattr(self, "g3_min_flops", 3e7)
                 and self.gemm3(A, B, C, M, N, K, lda, ldb, ldc, transA=kw.get("transA", False), transB=kw.get("transB", False),
                                bias=kw.get("bias"))):
             return
