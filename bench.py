@@ -137,6 +137,16 @@ def _work_model(name, a):
     """(group key, algorithmic FLOPs, algorithmic HBM bytes) of one recorded C-ABI call (argument layouts: include/tnt_hip.h).
     SURVEY 8d: a GEMM is 2*M*N*K FLOPs and reads A, B / writes C once; an LSTM step is 2*B*4U*U FLOPs; the optimizer
     moves 7 words per parameter, the norm pass 2."""
+    if name == "tnt_gemm3_pair_f32":        # two products in one launch: (address of tnt_gemm3_desc) x 2
+        from masters_thesis_amd.ops import _G3Desc
+        keys, fl, by = [], 0.0, 0.0
+        for addr in a[:2]:
+            d = _G3Desc.from_address(addr)
+            nb = 2 if d.A2 else 1
+            keys.append(("T" if d.transA else "N") + ("T" if d.transB else "N") + f" {d.M}x{d.N}x{d.K}" + (" x2" if nb == 2 else ""))
+            fl += 2.0 * d.M * d.N * d.K * nb
+            by += 4.0 * (nb * d.M * d.K + d.K * d.N + nb * d.M * d.N)
+        return f"{name} " + " + ".join(keys), fl, by
     if name in ("tnt_gemm_f32", "tnt_gemm_blas_f32", "tnt_gemm_fused_f32", "tnt_gemm_lt_f32", "tnt_gemm3_f32"):
         nb = 1
         if name == "tnt_gemm3_f32":         # (A, B, C, bias, colsum, A2, C2, M, N, K, lda, ldb, ldc, tA, tB, tile, splitk, ...)

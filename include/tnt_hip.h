@@ -113,6 +113,21 @@ int32_t tnt_gemm3_work_floats(int32_t M, int32_t N, int32_t tile, int32_t splitk
 int32_t tnt_gemm3_sync_words(int32_t M, int32_t N, int32_t tile, int32_t batch);
 int32_t tnt_gemm3_work_arm(float* work, int64_t floats, void* stream);
 
+/* Two INDEPENDENT products in one launch (the second one's workgroups start on the CUs the first one's tail leaves idle;
+ * a launch boundary costs a 25-50 us GEMM 4-6 us of ramp-up and drain): fields = the arguments of tnt_gemm3_f32.  The
+ * backward pass has such pairs back to back: the head's kernel gradient + input gradient (both read dlogits; NIC.py:143
+ * under tape.gradient), the LSTM's kernel gradients + input gradient (both read dZ; NIC.py:138-140).  Supported
+ * combinations: tnt_gemm3_pair_supported (else TNT_BADARG: issue two tnt_gemm3_f32 calls).  Two split products need
+ * distinct `work` buffers. */
+typedef struct tnt_gemm3_desc {
+  const float* A; const float* B; float* C; const float* bias; float* colsum; const float* A2; float* C2;
+  int32_t M, N, K, lda, ldb, ldc, transA, transB, tile, splitk;
+  float* work; uint32_t* sync;
+} tnt_gemm3_desc;
+int32_t tnt_gemm3_pair_supported(int32_t tile1, int32_t transA1, int32_t transB1, int32_t tile2, int32_t transA2,
+                                 int32_t transB2);
+int32_t tnt_gemm3_pair_f32(const tnt_gemm3_desc* p, const tnt_gemm3_desc* q, void* stream);
+
 /* tuning entry point: tnt_gemm_f32 with the workgroup tile forced to bm x bn (each 64 or 128; anything else =
  * the library's own choice).  Used by tools/gemm_bench.py / gemm_scan.py to calibrate the tile heuristic. */
 int32_t tnt_gemm_f32_tile(const float* A, const float* B, float* C, const float* bias, float* pre,

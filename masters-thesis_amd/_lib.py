@@ -28,6 +28,8 @@ SIGNATURES = {
     "tnt_gemm3_work_floats": [I32, I32, I32, I32, I32],
     "tnt_gemm3_sync_words": [I32, I32, I32, I32],
     "tnt_gemm3_work_arm": [P, I64, P],
+    "tnt_gemm3_pair_supported": [I32, I32, I32, I32, I32, I32],
+    "tnt_gemm3_pair_f32": [P, P, P],
     "tnt_dropout_mask4_u8": [P, I64, I32, F32, U64, U32, U32, P, P],
     "tnt_dropout_f32": [P, P, I32, I32, I32, I32, I32, I32, I32, F32, U64, U32, U32, P, P],
     "tnt_dropout_metric_f32": [P, P, I32, I32, I32, I32, I32, I32, I32, F32, U64, U32, U32, P, P, P, I32, I32, I32, P],

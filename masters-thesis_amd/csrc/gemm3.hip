@@ -45,6 +45,7 @@ struct G3Args {
   int nst;                    // K stages in all
   int splitk, nst_split;      // workgroups per output tile, stages per workgroup
   int err_word;               // index of the error word in sync
+  int nx;                     // workgroups per product (tiles x splitk)
 };
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from the buffer `rsrc` + voff (per lane; out-of-range lanes deliver zeros) to
@@ -112,8 +113,20 @@ __device__ __forceinline__ void g3_st4_wt(__amdgpu_buffer_rsrc_t rs, unsigned of
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(g3_v4u, v), rs, (int)off, 0, /*sc0 sc1*/ 17);
 }
 
+// One configuration of the family: operand layouts, wave tile (TM x TN MFMA tiles), wave grid, stage depth, ring depth.
+// body(g, bx, by) is the whole workgroup program for unit bx of product by (0, or 1 = the second product of a dual launch).
 template <bool A_KC, bool B_KC, int TM, int TN, int WGM, int WGN, int BK, int NS>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm3_kernel(G3Args g) {
+struct G3Cfg {
+  static constexpr int NTHREADS = 64 * WGM * WGN;
+  static constexpr int BM_ = 16 * TM * WGM, BN_ = 16 * TN * WGN, BK_ = BK;
+  static constexpr int SHMEM = NS * (BM_ + BN_) * BK * 4 + 1024;
+  static constexpr bool TA = !A_KC, TB = B_KC;
+  static_assert(SHMEM <= 160 * 1024, "LDS ring does not fit");
+  static __device__ __forceinline__ void body(const G3Args& g, int bx, int by);
+};
+
+template <bool A_KC, bool B_KC, int TM, int TN, int WGM, int WGN, int BK, int NS>
+__device__ __forceinline__ void G3Cfg<A_KC, B_KC, TM, TN, WGM, WGN, BK, NS>::body(const G3Args& g, const int bx, const int by) {
   constexpr int NW = WGM * WGN;
   constexpr int WM = 16 * TM, WN = 16 * TN, BM = WM * WGM, BN = WN * WGN;
   using OA = G3Op<A_KC, BM, TM, BK, NW>;
@@ -133,12 +146,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm3_kernel(G3Args g) {
   const int r = lane & 15, q = lane >> 4;
   const int MT = (g.M + BM - 1) / BM, NTl = (g.N + BN - 1) / BN;
   const int S = g.splitk;
-  const int nwg = MT * NTl * S, bid = blockIdx.x;
+  const int nwg = MT * NTl * S, bid = bx;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;       // XCD-contiguous unit order (bijective for any nwg)
   const int u = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int t = u / S, z = u - t * S;                          // output tile, K split
   const int m0 = (t % MT) * BM, n0 = (t / MT) * BN;
-  const bool second = blockIdx.y != 0;                         // the second product of a dual launch
+  const bool second = by != 0;                                 // the second product of a dual launch
   const float* Ag = second ? g.A2 : g.A;
   float* Cg = second ? g.C2 : g.C;
   const int s_begin = z * g.nst_split;
@@ -505,12 +518,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm3_kernel(G3Args g) {
   }
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN, int WGM, int WGN, int BK, int NS>
-int32_t g3_launch(const G3Args& g0, hipStream_t s) {
-  constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
-  constexpr int shmem = NS * (BM + BN) * BK * 4 + 1024;
-  static_assert(shmem <= 160 * 1024, "LDS ring does not fit");
-  G3Args g = g0;
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NTHREADS) void gemm3_kernel(G3Args g) { Cfg::body(g, blockIdx.x, blockIdx.y); }
+
+// Two independent products in ONE launch: workgroups [0, n1) run problem 1, the rest problem 2.  A launch boundary costs a
+// GEMM its ramp-up and its drain (~4-6 us of a 25-50 us kernel); back to back in one grid the second problem's workgroups
+// start on the CUs the first one's tail leaves idle.  (Workgroup programs of both configurations in one code object: the
+// register and LDS footprint is the larger of the two.)
+template <class C1, class C2>
+__global__ __launch_bounds__(256) void gemm3_pair_kernel(G3Args g1, G3Args g2, int n1) {
+  static_assert(C1::NTHREADS == 256 && C2::NTHREADS == 256, "pair launches use 4-wave configurations");
+  const int b = blockIdx.x;
+  if (b < n1) C1::body(g1, b % g1.nx, b / g1.nx);
+  else C2::body(g2, (b - n1) % g2.nx, (b - n1) / g2.nx);
+}
+
+// derived launch parameters + argument checks of one problem for configuration Cfg; 0 or an error code
+template <class Cfg>
+int32_t g3_prepare(G3Args& g) {
+  constexpr int BM = Cfg::BM_, BN = Cfg::BN_, BK = Cfg::BK_;
   g.nst = (g.K + BK - 1) / BK;
   if (g.splitk < 1) g.splitk = 1;
   if (g.splitk > g.nst) g.splitk = g.nst;
@@ -518,29 +544,57 @@ int32_t g3_launch(const G3Args& g0, hipStream_t s) {
   g.splitk = (g.nst + g.nst_split - 1) / g.nst_split;          // no empty split
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   g.err_word = 0;
+  g.nx = tiles * g.splitk;
   if (g.splitk > 1) {
     if (g.work == nullptr || g.sync == nullptr) return TNT_BADARG(17);
     if ((long)tiles * g.splitk * BM * BN * 4 > (1L << 31)) return TNT_BADARG(17);
     if (tiles * g.splitk * (g.A2 ? 2 : 1) > 1024) return TNT_BADARG(16);   // the splits of a tile wait for each other: one round only
     if (g.colsum != nullptr) return TNT_BADARG(7);              // the column-sum rider needs the whole K in one workgroup
   }
-  auto kern = gemm3_kernel<A_KC, B_KC, TM, TN, WGM, WGN, BK, NS>;
+  return 0;
+}
+
+template <class Cfg>
+int32_t g3_launch_cfg(const G3Args& g0, hipStream_t s) {
+  G3Args g = g0;
+  if (int32_t rc = g3_prepare<Cfg>(g)) return rc;
+  auto kern = gemm3_kernel<Cfg>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SHMEM) != hipSuccess)
+      return TNT_BADARG(90);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(g.nx, g.A2 ? 2 : 1), dim3(Cfg::NTHREADS), Cfg::SHMEM, s, g);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+template <class C1, class C2>
+int32_t g3_launch_pair(const G3Args& a0, const G3Args& b0, hipStream_t s) {
+  G3Args a = a0, b = b0;
+  if (int32_t rc = g3_prepare<C1>(a)) return rc;
+  if (int32_t rc = g3_prepare<C2>(b)) return rc;
+  const int n1 = a.nx * (a.A2 ? 2 : 1), n2 = b.nx * (b.A2 ? 2 : 1);
+  if ((a.splitk > 1 || b.splitk > 1) && n1 + n2 > 1024) return TNT_BADARG(16);
+  constexpr int shmem = C1::SHMEM > C2::SHMEM ? C1::SHMEM : C2::SHMEM;
+  auto kern = gemm3_pair_kernel<C1, C2>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, shmem) != hipSuccess)
       return TNT_BADARG(90);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles * g.splitk, g.A2 ? 2 : 1), dim3(64 * WGM * WGN), shmem, s, g);
+  hipLaunchKernelGGL(kern, dim3(n1 + n2), dim3(256), shmem, s, a, b, n1);
   TNT_LAUNCH_CHECK();
   return 0;
 }
 
 template <int TM, int TN, int WGM, int WGN, int BK, int NS>
 int32_t g3_layout(const G3Args& g, bool tA, bool tB, hipStream_t s) {
-  if (!tA && !tB) return g3_launch<true, false, TM, TN, WGM, WGN, BK, NS>(g, s);
-  if (tA && !tB) return g3_launch<false, false, TM, TN, WGM, WGN, BK, NS>(g, s);
-  if (!tA && tB) return g3_launch<true, true, TM, TN, WGM, WGN, BK, NS>(g, s);
+  if (!tA && !tB) return g3_launch_cfg<G3Cfg<true, false, TM, TN, WGM, WGN, BK, NS>>(g, s);
+  if (tA && !tB) return g3_launch_cfg<G3Cfg<false, false, TM, TN, WGM, WGN, BK, NS>>(g, s);
+  if (!tA && tB) return g3_launch_cfg<G3Cfg<true, true, TM, TN, WGM, WGN, BK, NS>>(g, s);
   return TNT_BADARG(12);
 }
 
@@ -641,10 +695,10 @@ extern "C" int32_t tnt_gemm3_plan(int32_t M, int32_t N, int32_t K, int32_t trans
   return *tile ? 0 : TNT_BADARG(2);
 }
 
-extern "C" int32_t tnt_gemm3_f32(const float* A, const float* B, float* C, const float* bias, float* colsum,
-                                 const float* A2, float* C2, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
-                                 int32_t ldc, int32_t transA, int32_t transB, int32_t tile, int32_t splitk, float* work,
-                                 uint32_t* sync, void* stream) {
+namespace {
+int32_t g3_fill(G3Args& g, const float* A, const float* B, float* C, const float* bias, float* colsum, const float* A2, float* C2,
+                int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc, int32_t transA, int32_t transB,
+                int32_t splitk, float* work, uint32_t* sync) {
   if (M <= 0 || N <= 0 || K <= 0) return TNT_BADARG(8);
   if (transA && transB) return TNT_BADARG(15);
   if (!tnt_aligned16(A) || !tnt_aligned16(B) || !tnt_aligned16(C) || lda % 4 || ldb % 4 || ldc % 4) return TNT_BADARG(1);
@@ -654,10 +708,19 @@ extern "C" int32_t tnt_gemm3_f32(const float* A, const float* B, float* C, const
   if (work && !tnt_aligned16(work)) return TNT_BADARG(15);
   const long rowsA = transA ? K : M, rowsB = transB ? N : K;
   if (rowsA * lda >= (1L << 29) || rowsB * ldb >= (1L << 29)) return TNT_BADARG(2);      // 32-bit buffer offsets
-  G3Args g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.work = work; g.sync = sync;
   g.A2 = A2; g.C2 = C2; g.colsum = colsum;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.nst = 0; g.splitk = splitk;
+  return 0;
+}
+}  // namespace
+
+extern "C" int32_t tnt_gemm3_f32(const float* A, const float* B, float* C, const float* bias, float* colsum,
+                                 const float* A2, float* C2, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
+                                 int32_t ldc, int32_t transA, int32_t transB, int32_t tile, int32_t splitk, float* work,
+                                 uint32_t* sync, void* stream) {
+  G3Args g;
+  if (int32_t rc = g3_fill(g, A, B, C, bias, colsum, A2, C2, M, N, K, lda, ldb, ldc, transA, transB, splitk, work, sync)) return rc;
   hipStream_t s = tnt_stream(stream);
   const bool tA = transA != 0, tB = transB != 0;
   switch (tile) {
@@ -675,4 +738,31 @@ extern "C" int32_t tnt_gemm3_f32(const float* A, const float* B, float* C, const
     case 11: return g3_layout<4, 2, 2, 2, 64, 3>(g, tA, tB, s);      // 128 x  64
     default: return TNT_BADARG(13);
   }
+}
+
+// Pair launches exist for the combinations a training step has back to back: a TN product (a kernel gradient, with its
+// riders) on tile 4 or 5 followed by an independent NT product (an input gradient) on tile 7 or 5.
+extern "C" int32_t tnt_gemm3_pair_supported(int32_t tile1, int32_t transA1, int32_t transB1, int32_t tile2, int32_t transA2,
+                                            int32_t transB2) {
+  return (transA1 && !transB1 && (tile1 == 4 || tile1 == 5) && !transA2 && transB2 && (tile2 == 7 || tile2 == 5)) ? 1 : 0;
+}
+
+extern "C" int32_t tnt_gemm3_pair_f32(const tnt_gemm3_desc* p, const tnt_gemm3_desc* q, void* stream) {
+  if (p == nullptr || q == nullptr) return TNT_BADARG(1);
+  if (!tnt_gemm3_pair_supported(p->tile, p->transA, p->transB, q->tile, q->transA, q->transB)) return TNT_BADARG(13);
+  G3Args a, b;
+  if (int32_t rc = g3_fill(a, p->A, p->B, p->C, p->bias, p->colsum, p->A2, p->C2, p->M, p->N, p->K, p->lda, p->ldb, p->ldc, p->transA,
+                           p->transB, p->splitk, p->work, p->sync)) return rc;
+  if (int32_t rc = g3_fill(b, q->A, q->B, q->C, q->bias, q->colsum, q->A2, q->C2, q->M, q->N, q->K, q->lda, q->ldb, q->ldc, q->transA,
+                           q->transB, q->splitk, q->work, q->sync)) return rc;
+  if (a.splitk > 1 && b.splitk > 1 && a.work == b.work) return TNT_BADARG(2);       // concurrent exchanges need their own space
+  hipStream_t s = tnt_stream(stream);
+  using TN4 = G3Cfg<false, false, 2, 5, 4, 1, 32, 3>;
+  using TN5 = G3Cfg<false, false, 2, 4, 2, 2, 32, 3>;
+  using NT7 = G3Cfg<true, true, 2, 2, 2, 2, 32, 3>;
+  using NT5 = G3Cfg<true, true, 2, 4, 2, 2, 32, 3>;
+  if (p->tile == 4 && q->tile == 7) return g3_launch_pair<TN4, NT7>(a, b, s);
+  if (p->tile == 4 && q->tile == 5) return g3_launch_pair<TN4, NT5>(a, b, s);
+  if (p->tile == 5 && q->tile == 7) return g3_launch_pair<TN5, NT7>(a, b, s);
+  return g3_launch_pair<TN5, NT5>(a, b, s);
 }

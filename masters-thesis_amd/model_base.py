@@ -344,26 +344,30 @@ class ModelBase:
         need = max([self.pick_splitk(*s) * s[0] * s[1] for s in shapes] + [1])
         self.skwork = self._f(need)
 
-    def _g3_buffers(self, M, N, tile, sk, batch):
-        """Split-K exchange space of tnt_gemm3_f32: ONE work buffer and ONE zeroed counter array per model, shared by every
-        launch (launches of a model run one after the other on its stream, and every launch leaves the counters zero).
+    def _g3_space(self, floats):
+        """Split-K exchange space of tnt_gemm3_f32: ONE armed work buffer and ONE error word per model, shared by every
+        launch (launches of a model run one after the other on its stream, and every launch leaves the buffer armed).
         Grown during eager passes only; growing invalidates captured graphs."""
-        if sk <= 1:
-            return None, None
-        be = self.be
-        wf, sw = be.gemm3_work_floats(M, N, tile, sk, batch), be.gemm3_sync_words(M, N, tile, batch) + 1
         d = self.__dict__
         w, sy = d.get("_g3_work"), d.get("_g3_sync")
-        if w is None or w.numel() < wf or sy is None or sy.numel() < sw:
+        if w is None or w.numel() < floats or sy is None:
             if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("gemm3 split-K workspace too small inside a graph capture (run one eager step first)")
-            if w is None or w.numel() < wf:
-                w = d["_g3_work"] = self._f((max(wf, 4) + 3) // 4 * 4)
-                be.gemm3_work_arm(w)
-            if sy is None or sy.numel() < sw:
-                sy = d["_g3_sync"] = torch.zeros(max(sw, 64), dtype=torch.int32, device=self.device)
+            if w is None or w.numel() < floats:
+                w = d["_g3_work"] = self._f((max(floats, 4) + 3) // 4 * 4)
+                self.be.gemm3_work_arm(w)
+            if sy is None:
+                sy = d["_g3_sync"] = torch.zeros(64, dtype=torch.int32, device=self.device)
             self._graphs = {}
         return w, sy
+
+    def _g3_plan(self, M, N, K, transA, transB, batch, colsum):
+        key = (M, N, K, bool(transA), bool(transB), batch, bool(colsum))
+        plans = self.__dict__.setdefault("_g3_plans", {})
+        if key not in plans:
+            force = getattr(self, "g3_force", {}).get(key[:6])          # tools / tests: {(M, N, K, tA, tB, batch): (tile, splitk)}
+            plans[key] = force or self.be.gemm3_plan(M, N, K, transA, transB, batch, allow_split=not colsum)
+        return plans[key]
 
     def gemm3(self, A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, colsum=None, A2=None, C2=None):
         """One product (or two sharing B) on the hand-written FP32-MFMA family of csrc/gemm3.hip, tile and K split from the
@@ -374,15 +378,49 @@ class ModelBase:
         if lda % 4 or ldb % 4 or ldc % 4:
             return False
         batch = 2 if A2 is not None else 1
-        key = (M, N, K, bool(transA), bool(transB), batch, colsum is not None)
-        plans = self.__dict__.setdefault("_g3_plans", {})
-        if key not in plans:
-            force = getattr(self, "g3_force", {}).get(key[:6])          # tools / tests: {(M, N, K, tA, tB, batch): (tile, splitk)}
-            plans[key] = force or be.gemm3_plan(M, N, K, transA, transB, batch, allow_split=colsum is None)
-        tile, sk = plans[key]
-        work, sync = self._g3_buffers(M, N, tile, sk, batch)
+        tile, sk = self._g3_plan(M, N, K, transA, transB, batch, colsum is not None)
+        work, sync = self._g3_space(be.gemm3_work_floats(M, N, tile, sk, batch)) if sk > 1 else (None, None)
         be.gemm3(A, B, C, M, N, K, lda, ldb, ldc, transA=transA, transB=transB, bias=bias, colsum=colsum, A2=A2, C2=C2,
                  tile=tile, splitk=sk, work=work, sync=sync)
+        return True
+
+    def gemm3_pair(self, p, q):
+        """Two INDEPENDENT products in one launch (tnt_gemm3_pair_f32): p, q = dicts of gemm3's arguments.  True = issued;
+        False = this pair has no co-launch form (the caller issues the two products itself)."""
+        be = self.be
+        if (not getattr(self, "use_gemm3", True) or not getattr(self, "g3_pairs", True) or not hasattr(be, "gemm3_pair")):
+            return False
+        descs, need = [], 0
+        for d in (p, q):
+            if d["lda"] % 4 or d["ldb"] % 4 or d["ldc"] % 4:
+                return False
+            batch = 2 if d.get("A2") is not None else 1
+            tile, sk = self._g3_plan(d["M"], d["N"], d["K"], d.get("transA", False), d.get("transB", False), batch,
+                                     d.get("colsum") is not None)
+            wf = (be.gemm3_work_floats(d["M"], d["N"], tile, sk, batch) + 3) // 4 * 4 if sk > 1 else 0
+            descs.append((d, tile, sk, need, wf))
+            need += wf
+        (d1, t1, _, _, _), (d2, t2, _, _, _) = descs
+        if not be.gemm3_pair_supported(t1, d1.get("transA", False), d1.get("transB", False), t2, d2.get("transA", False),
+                                       d2.get("transB", False)):
+            return False
+        work, sync = self._g3_space(need) if need else (None, None)
+        # the descriptors are passed by address and recorded launch plans re-issue the call later: one descriptor pair per
+        # distinct argument set, kept for the life of the model (same operands -> same objects)
+        ck = tuple((tuple((k, v.data_ptr() if torch.is_tensor(v) else v) for k, v in sorted(d.items())), tile, sk, off)
+                   for d, tile, sk, off, _ in descs) + (work.data_ptr() if need else 0,)
+        keep = self.__dict__.setdefault("_g3_descs", {})
+        if ck in keep:
+            be.gemm3_pair(*keep[ck])
+            return True
+        out = []
+        for d, tile, sk, off, wf in descs:
+            out.append(be.gemm3_desc(d["A"], d["B"], d["C"], d["M"], d["N"], d["K"], d["lda"], d["ldb"], d["ldc"],
+                                     transA=d.get("transA", False), transB=d.get("transB", False), bias=d.get("bias"),
+                                     colsum=d.get("colsum"), A2=d.get("A2"), C2=d.get("C2"), tile=tile, splitk=sk,
+                                     work=work[off:off + wf] if wf else None, sync=sync if wf else None))
+        keep[ck] = (out[0], out[1])
+        be.gemm3_pair(out[0], out[1])
         return True
 
     def _route_lt(self, A, B, C, M, N, K, lda, ldb, ldc, ws, kw):

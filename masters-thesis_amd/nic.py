@@ -344,9 +344,18 @@ class NIC(ModelBase):
         U, V, ldV = self.U, self.V, self.ldV
         dlog = self.logits
         Wo = a.p("time_distributed_softmax/kernel")
+        dw = dict(A=self.Out, B=dlog, C=a.g("time_distributed_softmax/kernel"), M=U, N=V, K=T * B, lda=U, ldb=ldV, ldc=ldV,
+                  transA=True, colsum=a.g("time_distributed_softmax/bias"))
+        dx = dict(A=dlog, B=Wo, C=self.dOut, M=T * B, N=U, K=V, lda=ldV, ldb=ldV, ldc=U, transB=True)
+        if getattr(self, "g3_riders", True) and self.gemm3_pair(dw, dx):
+            # kernel gradient (with the bias gradient as a rider on the dlogits tiles it streams anyway) and input gradient,
+            # the two independent readers of dlogits, in ONE launch
+            if join:
+                self.join()
+            return
         if getattr(self, "g3_riders", True) and self.gemm3(self.Out, dlog, a.g("time_distributed_softmax/kernel"), U, V, T * B,
                                                         U, ldV, ldV, transA=True, colsum=a.g("time_distributed_softmax/bias")):
-            pass        # dW and, as a rider on the dlogits tiles it streams anyway, the bias gradient: one launch
+            pass        # dW and the bias gradient: one launch
         elif getattr(self, "fused_head_grads", False) and hasattr(be, "gemm_fused") and \
                 be.gemm_fused_cfg(U, V, T * B, True, False, 1) > 0:
             be.gemm_fused(self.Out, dlog, a.g("time_distributed_softmax/kernel"), U, V, T * B, U, ldV, ldV, transA=True,
@@ -396,6 +405,19 @@ class NIC(ModelBase):
             be.lstm_step_bwd(self.dZ[B:2 * B], Ur, self.da_pass, None, self.dc, None, None, None, 0, 0, self.gates[0],
                              self.Cs[1], self.Cs[0], self.dZ[:B], None, None, None, B, U)
         xin = self._xin_used
+        self._dxin_done = False
+        if getattr(self, "g3_riders", True) and E == U:
+            dw = dict(A=xin, B=self.dZ, C=a.g("lstm/kernel"), M=E, N=4 * U, K=R1, lda=E, ldb=4 * U, ldc=4 * U, transA=True,
+                      colsum=a.g("lstm/bias"), A2=self.Hs, C2=a.g("lstm/recurrent_kernel"))
+            dx = dict(A=self.dZ, B=a.p("lstm/kernel"), C=self.dXin, M=R1, N=E, K=4 * U, lda=4 * U, ldb=4 * U, ldc=E, transB=True)
+            if self.gemm3_pair(dw, dx):
+                # the LSTM's three parameter gradients AND its input gradient (the four readers of dZ) in ONE launch;
+                # _bwd_seq_front finds dXin done
+                self._dxin_done = True
+                d = self.__dict__.pop("_colsum_deferred", None)
+                if d is not None:
+                    be.colsum(*d, self.work2)
+                return
         if getattr(self, "g3_riders", True) and E == U and self.gemm3(
                 xin, self.dZ, a.g("lstm/kernel"), E, 4 * U, R1, E, 4 * U, 4 * U, transA=True, colsum=a.g("lstm/bias"),
                 A2=self.Hs, C2=a.g("lstm/recurrent_kernel")):
@@ -433,7 +455,8 @@ class NIC(ModelBase):
         N, U, E, V, ldV = self.N, self.U, self.E, self.V, self.ldV
         R1 = (T + 1) * B
         sd, ds = self.seed, self.drop_step
-        self.gemm_sk(self.dZ, a.p("lstm/kernel"), self.dXin, R1, E, 4 * U, 4 * U, 4 * U, E, transB=True)
+        if not self.__dict__.pop("_dxin_done", False):
+            self.gemm_sk(self.dZ, a.p("lstm/kernel"), self.dXin, R1, E, 4 * U, 4 * U, 4 * U, E, transB=True)
         fused = self._fused_tail(B)
         if self.r_lstm > 0:
             if not fused:

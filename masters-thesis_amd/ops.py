@@ -20,6 +20,15 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+import ctypes as _ct
+
+
+class _G3Desc(_ct.Structure):
+    _fields_ = ([(n, _ct.c_void_p) for n in ("A", "B", "C", "bias", "colsum", "A2", "C2")]
+                + [(n, _ct.c_int32) for n in ("M", "N", "K", "lda", "ldb", "ldc", "transA", "transB", "tile", "splitk")]
+                + [(n, _ct.c_void_p) for n in ("work", "sync")])
+
+
 class HipBackend:
     name = "hip"
 
@@ -87,6 +96,23 @@ class HipBackend:
 
     def gemm3_sync_words(self, M, N, tile, batch=1):
         return int(self.lib.tnt_gemm3_sync_words(M, N, tile, batch))
+
+    def gemm3_pair(self, d1, d2):
+        """two independent products in one launch; d1, d2 = gemm3_desc(...)"""
+        import ctypes
+        self._call(self.lib.tnt_gemm3_pair_f32, "tnt_gemm3_pair_f32", ctypes.addressof(d1), ctypes.addressof(d2), self._s())
+
+    def gemm3_pair_supported(self, tile1, tA1, tB1, tile2, tA2, tB2):
+        return bool(self.lib.tnt_gemm3_pair_supported(tile1, int(tA1), int(tB1), tile2, int(tA2), int(tB2)))
+
+    @staticmethod
+    def gemm3_desc(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, colsum=None, A2=None, C2=None, tile=1,
+                   splitk=1, work=None, sync=None):
+        """tnt_gemm3_desc (include/tnt_hip.h); the returned object keeps the tensors alive"""
+        d = _G3Desc(_p(A), _p(B), _p(C), _p(bias), _p(colsum), _p(A2), _p(C2), M, N, K, lda, ldb, ldc, int(transA), int(transB),
+                    tile, splitk, _p(work), _p(sync))
+        d._keep = (A, B, C, bias, colsum, A2, C2, work, sync)
+        return d
 
     def gemm3_work_arm(self, work):
         """fill a split-K exchange buffer with the "not written yet" pattern (once; every launch leaves it armed)"""

@@ -248,6 +248,47 @@ def test_gemm3_riders(be, M, N, K):
         assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), ("not reproducible", tile)
 
 
+@pytest.mark.parametrize("shape1,shape2,t1,t2,S2", [
+    ((512, 5001, 960), (960, 512, 5001), 4, 7, 2), ((512, 2048, 1024), (1024, 512, 2048), 5, 7, 2), ((256, 5001, 960), (960, 256, 5001), 4, 7, 4),
+    ((64, 501, 120), (120, 64, 501), 4, 7, 1), ((64, 256, 128), (128, 64, 256), 5, 5, 2), ((37, 101, 50), (50, 37, 101), 5, 7, 1),
+])
+def test_gemm3_pair(be, shape1, shape2, t1, t2, S2):
+    """tnt_gemm3_pair_f32: a TN product (second product + column sums riding along) and an independent NT product (K split
+    in the launch) as ONE grid -- each output bit-identical to the same product launched on its own."""
+    (M1, N1, K1), (M2, N2, K2) = shape1, shape2
+    (A, A2, Bm, lda, ldb, ldc), _ = _g3_operands(M1, N1, K1, 1, 0, 3)
+    (P, _, Q, ldp, ldq, ldr), (opP, _, opQ) = _g3_operands(M2, N2, K2, 0, 1, 4)
+    Ad, A2d, Bd, Pd, Qd = dev(A), dev(A2), dev(Bm), dev(P), dev(Q)
+    wf = (be.gemm3_work_floats(M2, N2, t2, S2) + 3) // 4 * 4 if S2 > 1 else 0
+    work = torch.empty(max(wf, 4), device="cuda")
+    be.gemm3_work_arm(work)
+    sync = torch.zeros(1, dtype=torch.int32, device="cuda")
+    if S2 > 1 and wf == 0:
+        pytest.skip("no split for this shape")
+    # separately
+    C, C2, col = (torch.full((M1, ldc), 5.0, device="cuda") for _ in range(2)) , None, None
+    C, C2 = C
+    col = torch.full((ldc,), 5.0, device="cuda")
+    R = torch.full((M2, ldr), 5.0, device="cuda")
+    be.gemm3(Ad, Bd, C, M1, N1, K1, lda, ldb, ldc, transA=True, colsum=col, A2=A2d, C2=C2, tile=t1)
+    be.gemm3(Pd, Qd, R, M2, N2, K2, ldp, ldq, ldr, transB=True, tile=t2, splitk=S2, work=work if S2 > 1 else None,
+             sync=sync if S2 > 1 else None)
+    close(R[:, :N2], opP @ opQ, rtol=1e-6 * max(1.0, (K2 / 256) ** 0.5))
+    # as a pair
+    assert be.gemm3_pair_supported(t1, True, False, t2, False, True)
+    for rep in range(2):
+        Cp, C2p, Rp = torch.full((M1, ldc), 5.0, device="cuda"), torch.full((M1, ldc), 5.0, device="cuda"), torch.full((M2, ldr), 5.0, device="cuda")
+        colp = torch.full((ldc,), 5.0, device="cuda")
+        d1 = be.gemm3_desc(Ad, Bd, Cp, M1, N1, K1, lda, ldb, ldc, transA=True, colsum=colp, A2=A2d, C2=C2p, tile=t1)
+        d2 = be.gemm3_desc(Pd, Qd, Rp, M2, N2, K2, ldp, ldq, ldr, transB=True, tile=t2, splitk=S2, work=work if S2 > 1 else None,
+                           sync=sync if S2 > 1 else None)
+        be.gemm3_pair(d1, d2)
+        torch.cuda.synchronize()
+        assert torch.equal(Cp, C) and torch.equal(C2p, C2) and torch.equal(colp, col) and torch.equal(Rp, R), rep
+    assert int(sync.sum()) == 0 and bool((work.view(torch.int32) == 0x7FC5EED5).all())
+    assert not be.gemm3_pair_supported(1, False, False, 7, False, True)
+
+
 def test_gemm3_plan_and_bad_arguments(be):
     """the cost model's pick runs and is exact on every hot-path shape of BASELINE configs 2 and 3; unsupported argument
     combinations are refused with an error code, never launched"""
