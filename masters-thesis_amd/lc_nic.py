@@ -614,8 +614,13 @@ class NIC(ModelBase):
         n = T * B
         sd, ds = self.seed, self.drop_step
         dlog, inter, hs = self.logits, self._inter_used, self._hs_used
-        self.gemm_sk(inter, dlog, a.g("time_distributed_softmax/kernel"), H, V, n, H, ldV, ldV, transA=True)
-        self.gemm_sk(dlog, a.p("time_distributed_softmax/kernel"), self.dinter, n, H, V, ldV, ldV, H, transB=True)
+        # kernel gradient and input gradient of the softmax layer, the two independent readers of dlogits: ONE launch
+        if not (getattr(self, "g3_riders", True) and self.gemm3_pair(
+                dict(A=inter, B=dlog, C=a.g("time_distributed_softmax/kernel"), M=H, N=V, K=n, lda=H, ldb=ldV, ldc=ldV, transA=True),
+                dict(A=dlog, B=a.p("time_distributed_softmax/kernel"), C=self.dinter, M=n, N=H, K=V, lda=ldV, ldb=ldV, ldc=H,
+                     transB=True))):
+            self.gemm_sk(inter, dlog, a.g("time_distributed_softmax/kernel"), H, V, n, H, ldV, ldV, transA=True)
+            self.gemm_sk(dlog, a.p("time_distributed_softmax/kernel"), self.dinter, n, H, V, ldV, ldV, H, transB=True)
         if getattr(self, "fused_head_tail", True) and hasattr(be, "bias_act_drop_bwd") and n <= 2048 and H % 4 == 0:
             # dropout' + LeakyReLU' + the nonlinear layer's bias gradient in one pass over dinter, with the softmax layer's
             # bias gradient (column sums of dlogits) riding in the same launch: 1 launch instead of 4
@@ -665,6 +670,16 @@ class NIC(ModelBase):
             self._bwd_chain_steps(B, T, Wl, Ur, W2, v)
         hprev = self.Hs[:T].view(n, U)
         gWl = a.g("lstm/kernel")
+        self._dtext_done = False
+        if getattr(self, "g3_riders", True) and Et == U and self.gemm3_pair(
+                dict(A=hprev, B=self.dZ, C=a.g("lstm/recurrent_kernel"), M=U, N=4 * U, K=n, lda=U, ldb=4 * U, ldc=4 * U, transA=True,
+                     colsum=a.g("lstm/bias"), A2=self.text, C2=gWl[D:]),
+                dict(A=self.dZ, B=Wl[D:], C=self.dtext, M=n, N=Et, K=4 * U, lda=4 * U, ldb=4 * U, ldc=Et, transB=True)):
+            # the four readers of dZ that fill the chip -- recurrent-kernel gradient, the text rows of the kernel gradient (+ the
+            # bias gradient as a rider) and the text-input gradient (_bwd_emb finds it done) -- in ONE launch
+            self._dtext_done = True
+            self.gemm_sk(self.ctx_d, self.dZ, gWl[:D], D, 4 * U, n, D, 4 * U, 4 * U, transA=True)
+            return
         if getattr(self, "g3_riders", True) and Et == U and self.gemm3(
                 hprev, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True,
                 colsum=a.g("lstm/bias"), A2=self.text, C2=gWl[D:]):
@@ -752,7 +767,8 @@ class NIC(ModelBase):
         n = T * B
         sd, ds = self.seed, self.drop_step
         Wl = a.p("lstm/kernel")
-        self.gemm_sk(self.dZK if self.use_layer_norm else self.dZ, Wl[D:], self.dtext, n, Et, 4 * U, 4 * U, 4 * U, Et, transB=True)
+        if not self.__dict__.pop("_dtext_done", False):
+            self.gemm_sk(self.dZK if self.use_layer_norm else self.dZ, Wl[D:], self.dtext, n, Et, 4 * U, 4 * U, 4 * U, Et, transB=True)
         lstm_in = self.r_lstm > 0 and not self.use_layer_norm
         if (lstm_in and self.r_text > 0 and Et % 4 == 0 and D % 4 == 0 and hasattr(be, "dropout2")
                 and getattr(self, "fused_text_masks", True)):
