@@ -34,17 +34,21 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak
 # HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes), by call
 # group; filled from the summaries committed under profiles/ (None = not collected for that kernel)
-_PMC2 = "profiles/r02_pmc_seq_poll_and_encoder.txt"
+_PMC3 = "profiles/r03_pmc_gemm3_and_chains.txt"
+_kib = lambda fetch, write: int((2 * fetch + write) * 1024)
 PMC_TRAFFIC = {
-    "dense": {"tnt_gemm_f32 NN 960x5001x512": (int((2 * 13029.1 + 18885.8) * 1024), "profiles/r01_gemm_head_pmc_v3.txt"),
-              "tnt_lstm_seq_fwd_f32 S=16 B=64 U=512": (int((2 * 21651.0 + 14232.8) * 1024), _PMC2),
-              "tnt_lstm_seq_bwd_f32 S=16 B=64 U=512": (int((2 * 28719.7 + 23831.9) * 1024), _PMC2),
-              "tnt_dense_fwd_stream_gram_f32 64x512x20000": (int((2 * 22663.2 + 2305.0) * 1024), _PMC2),
-              "tnt_dense_dw_adam_f32 20000x512x64": (int((2 * 65998.5 + 120000.0) * 1024), _PMC2),
-              "tnt_dense_dw_skinny_f32 20000x512x64": (int((2 * 5568.5 + 40000.0) * 1024), _PMC2)},
-    "attention": {"tnt_gemm_f32 NN 960x5001x256": (int((2 * 6575.1 + 18885.0) * 1024), "profiles/r01_gemm_head_c3_pmc.txt"),
-                  "tnt_lc_seq_fwd_drop_f32 T=15 B=64 R=360 U=512": (int((2 * 27789.2 + 18382.3) * 1024), "profiles/r02_pmc_attention_chains.txt"),
-                  "tnt_lc_seq_bwd_drop_f32 T=15 B=64 R=360 U=512": (int((2 * 35036.1 + 48647.1) * 1024), "profiles/r02_pmc_attention_chains.txt")},
+    "dense": {"tnt_gemm3_pair_f32 TN 512x5001x960 + NT 960x512x5001": (_kib(69608.1, 23574.0), _PMC3),
+              "tnt_gemm3_pair_f32 TN 512x2048x1024 x2 + NT 1024x512x2048": (_kib(54473.9, 14344.0), _PMC3),
+              "tnt_gemm3_f32 NN 960x5001x512": (_kib(13164.1, 18885.0), _PMC3),
+              "tnt_gemm3_f32 NN 1024x2048x512": (_kib(10295.9, 8192.0), _PMC3),
+              "tnt_lstm_seq_fwd_f32 S=16 B=64 U=512": (_kib(21653.7, 14246.0), _PMC3),
+              "tnt_lstm_seq_bwd_f32 S=16 B=64 U=512": (_kib(28718.9, 25361.4), _PMC3),
+              "tnt_dense_dw_adam_f32 20000x512x64": (_kib(66176.8, 120000.0), _PMC3)},
+    "attention": {"tnt_lc_seq_fwd_drop_f32 T=15 B=64 R=360 U=512": (_kib(28285.7, 23898.2), _PMC3),
+                  "tnt_lc_seq_bwd_drop_f32 T=15 B=64 R=360 U=512": (_kib(35049.0, 44758.7), _PMC3),
+                  "tnt_gemm3_pair_f32 TN 256x5001x960 + NT 960x256x5001": (_kib(62224.7, 21897.9), _PMC3),
+                  "tnt_gemm3_pair_f32 TN 512x2048x960 x2 + NT 960x512x2048": (_kib(51075.9, 13960.0), _PMC3),
+                  "tnt_gemm3_f32 NN 960x5001x256": (_kib(6616.8, 18885.0), _PMC3)},
 }
 STEP_GFLOP = {"dense": 30.3, "attention": 22.0}          # SURVEY 8d, whole training step
 WORKLOAD_NAME = {
