@@ -335,6 +335,23 @@ def timed_steps(model, batch, steps, warmup, world=1, dist=None, device=None):
     return el, note
 
 
+def dp_world1_rehearsal(args, device):
+    """ms/step of the data-parallel schedule at world size 1 over RCCL (both workloads), next to which the single-process
+    ms_per_step shows what the schedule itself costs (segments, unfused update, dense embedding backward) before any
+    communication.  Run in a child process (it needs a process group; this process keeps its single-GPU state)."""
+    out = {}
+    for wl in ("dense", "attention"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--force-dp", "--workload", wl, "--steps", str(min(args.steps, 200)),
+               "--warmup", str(min(args.warmup, 20)), "--no-cpu-baseline", "--no-config3", "--no-dp-world1"]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env["MASTER_PORT"] = str(29600 + os.getpid() % 300)
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        out[wl] = round(json.loads(lines[-1])["ms_per_step"], 4) if p.returncode == 0 and lines else None
+    return {"ms_per_step": out, "note": "dp.attach(model, 1) over RCCL on this GPU: schedule overhead only, no scaling claim"}
+
+
 def spawn_ranks(args):
     """--gpus N without a launcher: start N ranks with torch.distributed.run as a CHILD process (this process has not
     touched the GPU and never will) and relay rank 0's JSON line."""
@@ -364,6 +381,7 @@ def main():
     ap.add_argument("--no-config3", action="store_true", help="skip the config-3 sub-measurement of the default run")
     ap.add_argument("--host-inputs", action="store_true", help="feed numpy batches (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel schedule even at world size 1 (rehearsal)")
+    ap.add_argument("--no-dp-world1", action="store_true", help="skip the world-size-1 rehearsal of the data-parallel schedule")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -444,6 +462,8 @@ def main():
                               "value": round(B * T * k3 / el3, 1), "unit": "caption-tokens/s", "roofline": dom3,
                               "kernels": others3[:6], "kernel_us_per_step": total3,
                               "step_frac": round(STEP_GFLOP["attention"] / ms3 / MFMA_F32_PEAK_TF, 4)}
+        if world == 1 and not use_dp and not args.no_dp_world1:
+            out["dp_world1"] = dp_world1_rehearsal(args, device)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, host_batch)
         print(json.dumps(out), flush=True)
