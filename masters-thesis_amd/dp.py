@@ -142,12 +142,13 @@ class PipelinedDenseSync:
     # graph.  World-size-1 rehearsal (tools/host_overhead.py --dp): all graphs 0.905 ms/step, this choice 0.854
     # with the host at 0.52 ms/step, all plans 0.847 with the host at 0.69.  The single-GPU step stays ONE graph
     # (0.7195 ms vs 0.7142 as a plan: within noise, and the plan keeps the host 80 % busy).
-    eager = frozenset(os.environ.get("TNT_DP_EAGER", "A,B2,C0,C1,C2").split(","))
+    eager = frozenset(os.environ.get("TNT_DP_EAGER", "A,B2,C,C0,C1,C2").split(","))
 
     def __init__(self, world):
         self.world = world
         self._bufs = {}
         self._slices = None
+        self.split_update = os.environ.get("TNT_DP_SPLIT_UPDATE", "0") == "1"
         self.one_graph = os.environ.get("TNT_DP_ONE_GRAPH", "0") == "1"
         self.capture_error = None
 
@@ -211,16 +212,25 @@ class PipelinedDenseSync:
         w_front, w_dpre = ib.behind(eB2, lambda: (
             dist.all_reduce_coalesced([a.grad[front0:lstm0], _sparse_norm_slot(m)], op=dist.ReduceOp.SUM, async_op=True),
             self._gather(dpre_all, m.dpre)))
-        # the head update needs only its own (long finished) all-reduce: it runs while the small, latency-bound
-        # all-gather of dpre -- the one collective on the critical path -- is in flight
-        w_head.wait()
-        cap(("dpC0", B, T), lambda: (m._tick(), m._update_slice(s_head)))
-        for w in (w_x, w_dpre):
+        if self.split_update:
+            # three update slices, each behind the collectives it needs (the head update runs while the small, latency-bound
+            # all-gather of dpre -- the one collective on the critical path -- is in flight)
+            w_head.wait()
+            cap(("dpC0", B, T), lambda: (m._tick(), m._update_slice(s_head)))
+            for w in (w_x, w_dpre):
+                w.wait()
+            cap(("dpC1", B, T), lambda: (m._bwd_enc(B, T, x_all, dpre_all), m._update_slice(s_enc)))
+            for w in (w_lstm, w_front):
+                w.wait()
+            cap(("dpC2", B, T), lambda: (m._update_slice(s_mid), m.be.l2_total(a.wsq, a.seg_l2, a.nseg, m.met[2:3])))
+            return
+        # default: ONE update behind all collectives -- the encoder gradient from the gathered operands, then the
+        # single-process update sequence (span norms of every variable in one launch, one finalize launch with the tick and
+        # the L2 metric, one clip + Adam launch): 5 launches instead of 14 (world-size-1 rehearsal: -28 us of kernels and
+        # ~-40 us of host-paced gaps; what it gives up is the head update's overlap with the last two collectives)
+        for w in (w_head, w_x, w_dpre, w_lstm, w_front):
             w.wait()
-        cap(("dpC1", B, T), lambda: (m._bwd_enc(B, T, x_all, dpre_all), m._update_slice(s_enc)))
-        for w in (w_lstm, w_front):
-            w.wait()
-        cap(("dpC2", B, T), lambda: (m._update_slice(s_mid), m.be.l2_total(a.wsq, a.seg_l2, a.nseg, m.met[2:3])))
+        cap(("dpC", B, T), lambda: (m._bwd_enc(B, T, x_all, dpre_all), m._update_fused(m.met[2:3])))
 
     def __call__(self, model):          # generic fallback (models without a pipelined schedule)
         make_grad_sync(self.world)(model)
@@ -249,11 +259,12 @@ class PipelinedAttentionSync:
     1.35 / 0.85 with six graphs and 1.32 / 1.14 with A as a plan too; bench.py --force-dp --workload attention: 1.23 ms
     against 1.12 for the single-graph step)."""
     pipelined = True
-    eager = frozenset(os.environ.get("TNT_DP_EAGER", "B2,B3,C0,C1").split(","))
+    eager = frozenset(os.environ.get("TNT_DP_EAGER", "B2,B3,C,C0,C1").split(","))
 
     def __init__(self, world):
         self.world = world
         self._slices = None
+        self.split_update = os.environ.get("TNT_DP_SPLIT_UPDATE", "0") == "1"
         self.one_graph = os.environ.get("TNT_DP_ONE_GRAPH", "0") == "1"
         self.capture_error = None
 
@@ -299,12 +310,17 @@ class PipelinedAttentionSync:
         w_emb = ib.behind(eB2, lambda: dist.all_reduce_coalesced([a.grad[emb0:lstm0], _sparse_norm_slot(m)], op=dist.ReduceOp.SUM,
                                                                async_op=True))
         w_front = ib.behind(eB3, lambda: ar(a.grad[:emb0]))
-        for w in (w_head, w_lstm):
+        if self.split_update:
+            for w in (w_head, w_lstm):
+                w.wait()
+            cap(("dpC0", B, T), lambda: (m._tick(), m._update_slice(sl_tail)))
+            for w in (w_emb, w_front):
+                w.wait()
+            cap(("dpC1", B, T), lambda: (m._update_slice(sl_front), m.be.l2_total(a.wsq, a.seg_l2, a.nseg, m.met[2:3])))
+            return
+        for w in (w_head, w_lstm, w_emb, w_front):      # default: ONE update behind all collectives (see PipelinedDenseSync)
             w.wait()
-        cap(("dpC0", B, T), lambda: (m._tick(), m._update_slice(sl_tail)))
-        for w in (w_emb, w_front):
-            w.wait()
-        cap(("dpC1", B, T), lambda: (m._update_slice(sl_front), m.be.l2_total(a.wsq, a.seg_l2, a.nseg, m.met[2:3])))
+        cap(("dpC", B, T), lambda: m._update_fused(m.met[2:3]))
 
     def __call__(self, model):          # not used by lc_nic.train_step (it calls step); kept for the generic protocol
         make_grad_sync(self.world)(model)
