@@ -128,6 +128,45 @@ int32_t tnt_gemm3_pair_supported(int32_t tile1, int32_t transA1, int32_t transB1
                                  int32_t transB2);
 int32_t tnt_gemm3_pair_f32(const tnt_gemm3_desc* p, const tnt_gemm3_desc* q, void* stream);
 
+/* ---- the optimizer step without a finalize launch (single-process step; optimizer.apply_gradients with clipnorm + Adam,
+ * main.py:97, lc_NIC.py:389).  tnt_step_finalize_f32 -- per-variable norms from the span partials, the step's scalar totals,
+ * the counter tick -- was one dependent launch in front of the update: 12 us of a 500 us step.  Here
+ *   tnt_span_sqnorm_lr_f32 / tnt_dense_gram_norm_spans_lr_f32: the norm launches, with one thread also writing Adam's step
+ *       size lr_t = lr sqrt(1-b2^t)/(1-b1^t), t = *adam_t + 1, for the update that follows;
+ *   tnt_dense_dw_adam_fin_f32: tnt_dense_dw_adam_f32 with the kernel's clip norm summed from partial[2k], k0 <= k < k1, by
+ *       the launch itself;
+ *   tnt_adam_fin_f32: tnt_adam_ring_f32 over spans whose variables' clip norms are summed from `fin->partial` by every
+ *       workgroup that needs one (same order everywhere); ONE extra workgroup files everything tnt_step_finalize_f32 wrote
+ *       (fields of tnt_finalize_desc = its arguments; extra_seg = the variable whose norm is sum(extra_part), -1: none;
+ *       `arrive`: one zeroed uint32, left zero) beside the update; *adam_t and *drop_step advance when the LAST workgroup
+ *       of the launch is done (unless *guard != 0).  Issue order: norm launch, tnt_dense_dw_adam_fin_f32, tnt_adam_fin_f32. */
+typedef struct tnt_finalize_desc {
+  const float* partial; const int32_t* seg_first; const float* seg_l2; float* sq; float* wsq; float* l2_out; int32_t nseg;
+  const float* x0; float* out0; const float* x1; float* out1; int32_t n; float scale;
+  const float* extra_part; float* extra; int32_t n_extra; int32_t extra_seg;
+  const int32_t* ids_src; int32_t* ids_dst; int32_t n_ids;
+  const float* x2; float* out2; int32_t n2; float scale2;
+  int64_t* adam_t; uint32_t* drop_step; const float* lr; float* lr_t; float beta1, beta2; const uint32_t* guard;
+  uint32_t* arrive;
+} tnt_finalize_desc;
+int32_t tnt_span_sqnorm_lr_f32(const float* theta, const float* grad, const int32_t* span_seg, const int64_t* span_off,
+                               const int32_t* span_len, const float* seg_l2, float* partial, int32_t nspan,
+                               const int64_t* adam_t, const float* lr, float* lr_t, float beta1, float beta2, void* stream);
+int32_t tnt_dense_gram_norm_spans_lr_f32(const float* dpre, const float* pre, const float* bias, const float* gx_part,
+                                         int32_t nsplit, const float* w2_part, int32_t nw2, float l2, float* partial,
+                                         int32_t nslot, int32_t Bk, int32_t E, const float* theta, const float* grad,
+                                         const int32_t* span_seg, const int64_t* span_off, const int32_t* span_len,
+                                         const float* seg_l2, float* span_partial, int32_t nspan, const int64_t* adam_t,
+                                         const float* lr, float* lr_t, float beta1, float beta2, void* stream);
+int32_t tnt_dense_dw_adam_fin_f32(const float* x, const float* dpre, float* theta, float* m, float* v, float l2,
+                                  const float* partial, int32_t k0, int32_t k1, const float* sq_override,
+                                  const float* lr_t_dev, float beta1, float beta2, float eps, float clipnorm,
+                                  const uint32_t* guard, int32_t N, int32_t E, int32_t Bk, int32_t ldx, void* stream);
+int32_t tnt_adam_fin_f32(float* theta, float* m, float* v, const float* grad, const int32_t* span_seg,
+                         const int64_t* span_off, const int32_t* span_len, const float* sq_override, int32_t nspan, float eps,
+                         float clipnorm, const tnt_finalize_desc* fin, const float* met, int32_t nmet, float* ring,
+                         int32_t ring_rows, uint32_t* ring_t, void* stream);
+
 /* tuning entry point: tnt_gemm_f32 with the workgroup tile forced to bm x bn (each 64 or 128; anything else =
  * the library's own choice).  Used by tools/gemm_bench.py / gemm_scan.py to calibrate the tile heuristic. */
 int32_t tnt_gemm_f32_tile(const float* A, const float* B, float* C, const float* bias, float* pre,

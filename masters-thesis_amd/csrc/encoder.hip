@@ -10,6 +10,7 @@
 // and runs v_mfma_f32_16x16x4_f32 over it; the backward reuses the same gathered tile as
 // the transposed operand (dW_r = X_r^T dpre_r), so x is never re-laid-out in HBM.
 #include "tnt_common.h"
+#include "tnt_fin.h"
 
 namespace {
 
@@ -306,6 +307,9 @@ struct DwArgs {
   // EPI 1 (squared norms) / EPI 2 (clip + Adam), see dense_dw_skinny_kernel
   float* theta; float* m; float* v; float* partial; int nslot; float lam2;
   const float* sq; const float* sq_override; const float* lr_t_dev; float b1, b2, eps, clipnorm; const uint32_t* guard;
+  // EPI 2 without a finalize launch in front (tnt_dense_dw_adam_fin_f32): the variable's clip norm is summed here, by
+  // every wave, from its span partials fin_partial[2 k], fin_k0 <= k < fin_k1 (tnt_seg_sums: the canonical order)
+  const float* fin_partial; int fin_k0, fin_k1;
 };
 
 // PERM (every wave has all its TPW tiles, TPW = 2 or 4): MFMA column n of tile j is output column TPW n + j of the
@@ -422,20 +426,21 @@ __global__ __launch_bounds__(512) void dense_dw_skinny_kernel(DwArgs a) {
       if (EPI == 2) { m_[r] = *reinterpret_cast<const float4*>(a.m + o); v_[r] = *reinterpret_cast<const float4*>(a.v + o); }
     }
   };
-  if (EPI == 2) {
-    cs = 1.f;
-    if (a.clipnorm > 0.f) {
-      float sqv = a.sq[0];
-      if (a.sq_override && a.sq_override[0] >= 0.f) sqv = a.sq_override[0];
-      cs = a.clipnorm / fmaxf(sqrtf(sqv), a.clipnorm);
-    }
-    lr_t = a.lr_t_dev[0];
-  }
   gload(s);                                            // the first strip's X is in flight while the B fragments load
   load_bq();
   sstore(0);
   gload(s + gridDim.x);
   if (EPI >= 1) tload(s, thn, mmn, vvn);
+  // (behind the first strip's loads: the clip norm may come from a chain of dependent loads, tnt_dense_dw_adam_fin_f32)
+  if (EPI == 2) {
+    cs = 1.f;
+    if (a.clipnorm > 0.f) {
+      float sqv = a.fin_partial ? tnt_seg_sums(a.fin_partial, a.fin_k0, a.fin_k1, lane).x : a.sq[0];
+      if (a.sq_override && a.sq_override[0] >= 0.f) sqv = a.sq_override[0];
+      cs = a.clipnorm / fmaxf(sqrtf(sqv), a.clipnorm);
+    }
+    lr_t = a.lr_t_dev[0];
+  }
   __syncthreads();
   for (; s < nstrip; s += gridDim.x, cur ^= 1) {
     float av[DW_KS];
@@ -749,6 +754,8 @@ constexpr int GN_Q = 4;        // workgroups per row b: 16 columns b' of the Gra
 struct GnSpans {
   const float* theta; const float* grad; const int32_t* span_seg; const int64_t* span_off; const int32_t* span_len;
   const float* seg_l2; float* partial; int nspan;
+  // the "lr job" (optional): Adam's step size for the update that follows, see tnt_span_sqnorm_lr_f32 / tnt_adam_fin_f32
+  const int64_t* adam_t; const float* lr; float* lr_t; float b1, b2;
 };
 
 __global__ __launch_bounds__(256) void dense_gram_norm_kernel(const float* dpre, const float* pre, const float* bias,
@@ -788,6 +795,7 @@ __global__ __launch_bounds__(256) void dense_gram_norm_kernel(const float* dpre,
     return;
   }
   if ((int)blockIdx.x == GN_Q * Bk) {
+    if (sp.lr_t != nullptr && tid == 255) sp.lr_t[0] = tnt_adam_lr_t(sp.adam_t, sp.lr, sp.b1, sp.b2);
     for (int k = tid; k < nslot - GN_Q * Bk; k += 256) {
       const float w = k < nw2 ? w2_part[k] : 0.f;
       partial[2 * (GN_Q * Bk + k)] = 4.f * l2 * l2 * w;
@@ -859,7 +867,22 @@ extern "C" int32_t tnt_dense_gram_norm_spans_f32(const float* dpre, const float*
                                                  float* span_partial, int32_t nspan, void* stream) {
   if (nspan < 0 || (nspan > 0 && (theta == nullptr || grad == nullptr || span_partial == nullptr))) return TNT_BADARG(19);
   return gram_norm_launch(dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E,
-                          GnSpans{theta, grad, span_seg, span_off, span_len, seg_l2, span_partial, nspan}, stream);
+                          GnSpans{theta, grad, span_seg, span_off, span_len, seg_l2, span_partial, nspan, nullptr, nullptr, nullptr,
+                                  0.f, 0.f}, stream);
+}
+
+extern "C" int32_t tnt_dense_gram_norm_spans_lr_f32(const float* dpre, const float* pre, const float* bias,
+                                                    const float* gx_part, int32_t nsplit, const float* w2_part, int32_t nw2,
+                                                    float l2, float* partial, int32_t nslot, int32_t Bk, int32_t E,
+                                                    const float* theta, const float* grad, const int32_t* span_seg,
+                                                    const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
+                                                    float* span_partial, int32_t nspan, const int64_t* adam_t, const float* lr,
+                                                    float* lr_t, float beta1, float beta2, void* stream) {
+  if (nspan < 0 || (nspan > 0 && (theta == nullptr || grad == nullptr || span_partial == nullptr))) return TNT_BADARG(19);
+  if (adam_t == nullptr || lr == nullptr || lr_t == nullptr) return TNT_BADARG(21);
+  return gram_norm_launch(dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E,
+                          GnSpans{theta, grad, span_seg, span_off, span_len, seg_l2, span_partial, nspan, adam_t, lr, lr_t, beta1,
+                                  beta2}, stream);
 }
 
 namespace {
@@ -943,6 +966,24 @@ extern "C" int32_t tnt_dense_dw_adam_f32(const float* x, const float* dpre, floa
   a.x = x; a.dpre = dpre; a.N = N; a.E = E; a.Bk = Bk; a.ldx = ldx;
   a.theta = theta; a.m = m; a.v = v; a.lam2 = 2.f * l2; a.sq = sq; a.sq_override = sq_override; a.lr_t_dev = lr_t_dev;
   a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.clipnorm = clipnorm; a.guard = guard;
+  hipLaunchKernelGGL((dense_dw_skinny_kernel<4, true, 2>), dim3(grid, E / 512), dim3(512), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_dense_dw_adam_fin_f32(const float* x, const float* dpre, float* theta, float* m, float* v, float l2,
+                                             const float* partial, int32_t k0, int32_t k1, const float* sq_override,
+                                             const float* lr_t_dev, float beta1, float beta2, float eps, float clipnorm,
+                                             const uint32_t* guard, int32_t N, int32_t E, int32_t Bk, int32_t ldx, void* stream) {
+  if (int32_t rc = dw_fused_check(x, dpre, N, E, Bk, ldx)) return rc;
+  if (!tnt_aligned16(theta) || !tnt_aligned16(m) || !tnt_aligned16(v) || lr_t_dev == nullptr || partial == nullptr || k0 < 0 || k1 <= k0)
+    return TNT_BADARG(3);
+  const int nstrip = (N + DW_MS - 1) / DW_MS, grid = nstrip < 256 ? nstrip : 256;
+  DwArgs a{};
+  a.x = x; a.dpre = dpre; a.N = N; a.E = E; a.Bk = Bk; a.ldx = ldx;
+  a.theta = theta; a.m = m; a.v = v; a.lam2 = 2.f * l2; a.sq = nullptr; a.sq_override = sq_override; a.lr_t_dev = lr_t_dev;
+  a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.clipnorm = clipnorm; a.guard = guard;
+  a.fin_partial = partial; a.fin_k0 = k0; a.fin_k1 = k1;
   hipLaunchKernelGGL((dense_dw_skinny_kernel<4, true, 2>), dim3(grid, E / 512), dim3(512), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;

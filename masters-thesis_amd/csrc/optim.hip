@@ -9,21 +9,19 @@
 // The arena is cut into spans of <= SPAN elements, each inside one variable ("segment");
 // the host builds the span table once.  Norms are reduced span -> segment in fixed order.
 #include "tnt_common.h"
+#include "tnt_fin.h"
 
 namespace {
 
-struct SpanTab {
-  const int32_t* span_seg;     // segment of span s
-  const int64_t* span_off;     // first element (arena offset, multiple of 4)
-  const int32_t* span_len;     // elements in span (<= SPAN)
-  const int32_t* seg_first;    // [nseg+1] first span of each segment
-  const float* seg_l2;         // L2 lambda per segment
-};
+struct LrJob { const int64_t* adam_t; const float* lr; float* lr_t; float b1, b2; };
 
 __global__ __launch_bounds__(256) void span_sqnorm_kernel(const float* theta, const float* grad, SpanTab t,
-                                                          float* partial, int nspan) {
+                                                          float* partial, int nspan, LrJob lj) {
   __shared__ float s0[4], s1[4];
   const int sp = blockIdx.x;
+  // the "lr job": Adam's step size for the update that follows this launch (the step counter advances at the end of that
+  // update: tnt_adam_fin_f32), one thread of the launch, beside the norms
+  if (lj.lr_t != nullptr && sp == 0 && threadIdx.x == 255) lj.lr_t[0] = tnt_adam_lr_t(lj.adam_t, lj.lr, lj.b1, lj.b2);
   if (sp >= nspan) return;
   const long off = t.span_off[sp];
   const int len = t.span_len[sp];
@@ -130,6 +128,166 @@ __global__ __launch_bounds__(256) void adam_kernel(float* theta, float* m, float
     m[off + i] = mm; v[off + i] = vv;
     theta[off + i] = w - lr_t * mm / (sqrtf(vv) + eps);
   }
+}
+
+// ---- clip + Adam with the step's scalar tail INSIDE the launch (tnt_adam_fin_f32; single-process step).
+// The finalize launch that used to sit in front of the update (12 us of a 500 us step for a few hundred scalars: a dependent
+// launch whose every load is a cold round trip) is gone:
+//  * every span workgroup sums ITS variable's clip norm from the span partials itself (tnt_seg_sums: a few coalesced loads)
+//    (lr_t for the step was left by the norm launch in front of this one: tnt_span_sqnorm_lr_f32 / the Gram-norm launch);
+//  * one extra workgroup (blockIdx 0) files what the host reads -- per-variable norms, L2 metric, loss / accuracy /
+//    extra totals, the Embedding's sparse-norm total, ids -> prev_ids, the metrics ring -- beside the update, off every
+//    critical path;
+//  * the step counters advance when the LAST workgroup of the launch arrives (an atomic ticket), i.e. when nobody reads
+//    them any more; the same workgroup re-arms the ticket.
+struct FinArgs {
+  const float* partial; const int32_t* seg_first; const float* seg_l2; float* sq; float* wsq; float* l2_out; int nseg;
+  const float* x0; float* out0; const float* x1; float* out1; int n; float scale;
+  const float* extra_part; float* extra; int n_extra; int extra_seg;
+  const int32_t* ids_src; int32_t* ids_dst; int n_ids;
+  const float* x2; float* out2; int n2; float scale2;
+  int64_t* adam_t; uint32_t* drop_step; const float* lr; float* lr_t; float b1, b2; const uint32_t* guard;
+  uint32_t* arrive;
+};
+
+__device__ __forceinline__ void fin_arrive_and_tick(const FinArgs& f, unsigned total) {
+  // called by ONE thread of every workgroup of the launch, as its last action
+  const unsigned old = __hip_atomic_fetch_add(f.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (old != total - 1u) return;
+  __hip_atomic_store(f.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (f.guard && f.guard[0] != 0u) return;
+  if (f.drop_step) f.drop_step[0] += 1u;
+  if (f.adam_t) f.adam_t[0] += 1;
+}
+
+__global__ __launch_bounds__(256) void adam_fin_kernel(float* theta, float* m, float* v, const float* grad, SpanTab t,
+                                                       const float* sq_override, int nspan, float eps, float clipnorm,
+                                                       FinArgs f, MetRing r) {
+  // workgroup 0 is the side workgroup: its work is a chain of dependent loads (~8 us end to end), so it is dispatched FIRST
+  // and runs beside the whole update instead of hanging off its last round
+  const int sp = (int)blockIdx.x - 1, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool bad = f.guard && f.guard[0] != 0u;            // the step's forward pass was invalid: leave the model untouched
+  if (sp >= 0) {
+    if (!bad) {
+      const long off = t.span_off[sp];
+      const int len = t.span_len[sp];
+      const int seg = t.span_seg[sp];
+      const int len4 = len & ~3;
+      // the first round of the span's operands is in flight BEFORE the clip norm's chain of dependent loads (span -> variable
+      // -> its partials -> sum): every span workgroup pays that chain, and behind it the chain would add ~1 us to each
+      float4 w0 = {}, g0 = {}, m0 = {}, v0 = {};
+      const bool have0 = tid * 4 < len4;
+      if (have0) {
+        w0 = *reinterpret_cast<const float4*>(theta + off + tid * 4);
+        g0 = *reinterpret_cast<const float4*>(grad + off + tid * 4);
+        m0 = *reinterpret_cast<const float4*>(m + off + tid * 4);
+        v0 = *reinterpret_cast<const float4*>(v + off + tid * 4);
+      }
+      const float lr_t = f.lr_t[0];                        // written by the norm launch in front of this one (its "lr job")
+      const float lam2 = 2.f * f.seg_l2[seg];
+      float cs = 1.f;
+      if (clipnorm > 0.f) {
+        float q;
+        if (seg == f.extra_seg && f.n_extra > 0) {         // the Embedding: norm of the un-merged IndexedSlices rows
+          q = 0.f;
+          for (int i = lane; i < f.n_extra; i += 64) q += f.extra_part[i];
+          q = tnt_wave_sum(q);
+        } else if (sq_override && sq_override[seg] >= 0.f) {
+          q = sq_override[seg];
+        } else {
+          q = tnt_seg_sums(f.partial, f.seg_first[seg], f.seg_first[seg + 1], lane).x;
+        }
+        cs = clipnorm / fmaxf(sqrtf(q), clipnorm);
+      }
+      const float ob1 = 1.f - f.b1, ob2 = 1.f - f.b2;
+      for (int i = tid * 4; i < len4; i += 1024) {
+        float4 wv, g4, mm, vv;
+        if (i == tid * 4) { wv = w0; g4 = g0; mm = m0; vv = v0; }
+        else {
+          wv = *reinterpret_cast<float4*>(theta + off + i);
+          g4 = *reinterpret_cast<const float4*>(grad + off + i);
+          mm = *reinterpret_cast<float4*>(m + off + i);
+          vv = *reinterpret_cast<float4*>(v + off + i);
+        }
+        float* wp = &wv.x; float* mp = &mm.x; float* vp = &vv.x; const float* gp = &g4.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float g = (gp[j] + lam2 * wp[j]) * cs;
+          mp[j] = mp[j] + (g - mp[j]) * ob1;
+          vp[j] = vp[j] + (g * g - vp[j]) * ob2;
+          wp[j] = wp[j] - lr_t * mp[j] / (sqrtf(vp[j]) + eps);
+        }
+        *reinterpret_cast<float4*>(theta + off + i) = wv;
+        *reinterpret_cast<float4*>(m + off + i) = mm;
+        *reinterpret_cast<float4*>(v + off + i) = vv;
+      }
+      for (int i = len4 + tid; i < len; i += 256) {
+        const float wv = theta[off + i];
+        const float g = (grad[off + i] + lam2 * wv) * cs;
+        const float mm = m[off + i] + (g - m[off + i]) * ob1;
+        const float vv = v[off + i] + (g * g - v[off + i]) * ob2;
+        m[off + i] = mm; v[off + i] = vv;
+        theta[off + i] = wv - lr_t * mm / (sqrtf(vv) + eps);
+      }
+    }
+  } else {
+    // ---- the side workgroup: everything the host (and the next step) reads, beside the update
+    __shared__ float sw[5][4];
+    float l = 0.f, s0 = 0.f, s1 = 0.f, e = 0.f, s2 = 0.f;
+    for (int s = tid; s < f.nseg; s += 256) {              // small variables: one per thread (serial span order)
+      const int k0 = f.seg_first[s], k1 = f.seg_first[s + 1];
+      if (k1 - k0 > 8) continue;
+      float q = 0.f, ws = 0.f;
+      for (int k = k0; k < k1; ++k) { q += f.partial[2 * k]; ws += f.partial[2 * k + 1]; }
+      f.sq[s] = q; f.wsq[s] = ws;
+      l += f.seg_l2[s] * ws;
+    }
+    for (int i = tid; i < f.n; i += 256) { s0 += f.x0[i]; if (f.x1) s1 += f.x1[i]; }
+    for (int i = tid; i < f.n2; i += 256) s2 += f.x2[i];
+    for (int i = tid; i < f.n_ids; i += 256) f.ids_dst[i] = f.ids_src[i];
+    if (w == 0 && f.n_extra > 0) {                         // same order as the span workgroups use
+      for (int i = lane; i < f.n_extra; i += 64) e += f.extra_part[i];
+      e = tnt_wave_sum(e);
+      if (lane == 0 && f.extra) f.extra[0] = e;
+    }
+    // large variables: one per wave (tnt_seg_sums order).  A wave looks at 64 variables at a time (one per lane) and then
+    // walks the few that have more than 8 spans -- a per-variable loop costs a dependent load pair per variable, 700+ of them
+    // in the region-wise model.
+    for (int s0w = w * 64; s0w < f.nseg; s0w += 256) {
+      const int sl = s0w + lane;
+      int k0 = 0, k1 = 0;
+      if (sl < f.nseg) { k0 = f.seg_first[sl]; k1 = f.seg_first[sl + 1]; }
+      unsigned long long big = __ballot(k1 - k0 > 8);
+      while (big) {
+        const int j = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int s = s0w + j;
+        const float2 qs = tnt_seg_sums(f.partial, __shfl(k0, j, 64), __shfl(k1, j, 64), lane);
+        if (lane == 0) { f.sq[s] = qs.x; f.wsq[s] = qs.y; l += f.seg_l2[s] * qs.y; }
+      }
+    }
+    l = tnt_wave_sum(l); s0 = tnt_wave_sum(s0); s1 = tnt_wave_sum(s1); s2 = tnt_wave_sum(s2);
+    if (lane == 0) { sw[0][w] = l; sw[1][w] = s0; sw[2][w] = s1; sw[4][w] = s2; }
+    __syncthreads();
+    if (lane == 0 && w < 4) {
+      const int j = w == 3 ? 4 : w;
+      const float tt = (sw[j][0] + sw[j][1]) + (sw[j][2] + sw[j][3]);
+      if (j == 0 && f.l2_out != nullptr) f.l2_out[0] = tt;
+      if (j == 1 && f.n > 0) f.out0[0] = tt * f.scale;
+      if (j == 2 && f.n > 0 && f.x1) f.out1[0] = tt * f.scale;
+      if (j == 4 && f.n2 > 0) f.out2[0] = tt * f.scale2;
+    }
+    __syncthreads();                                       // the totals are written: file the metrics vector in the ring
+    if (r.ring && tid <= r.nmet) {
+      __threadfence_block();
+      const uint32_t rt = r.ring_t[0];
+      float* row = r.ring + (long)(rt % (uint32_t)r.rows) * (r.nmet + 1);
+      if (tid < r.nmet) row[tid] = __hip_atomic_load(r.met + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else { row[r.nmet] = (float)(rt & 0xFFFFFFu); r.ring_t[0] = rt + 1u; }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) fin_arrive_and_tick(f, (unsigned)nspan + 1u);
 }
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* theta, float* mom, const float* grad, SpanTab t,
@@ -402,7 +560,7 @@ extern "C" int32_t tnt_seg_sqnorm_f32(const float* theta, const float* grad, con
   if (nspan <= 0 || nseg <= 0) return 0;
   SpanTab t{span_seg, span_off, span_len, seg_first, seg_l2};
   hipStream_t s = tnt_stream(stream);
-  hipLaunchKernelGGL(span_sqnorm_kernel, dim3(nspan), dim3(256), 0, s, theta, grad, t, partial, nspan);
+  hipLaunchKernelGGL(span_sqnorm_kernel, dim3(nspan), dim3(256), 0, s, theta, grad, t, partial, nspan, LrJob{});
   TNT_LAUNCH_CHECK();
   hipLaunchKernelGGL(seg_finalize_kernel, dim3(nseg), dim3(64), 0, s, partial, t, sq, wsq, nseg);
   TNT_LAUNCH_CHECK();
@@ -498,7 +656,20 @@ extern "C" int32_t tnt_span_sqnorm_f32(const float* theta, const float* grad, co
                                        float* partial, int32_t nspan, void* stream) {
   if (nspan <= 0) return 0;
   SpanTab t{span_seg, span_off, span_len, nullptr, seg_l2};
-  hipLaunchKernelGGL(span_sqnorm_kernel, dim3(nspan), dim3(256), 0, tnt_stream(stream), theta, grad, t, partial, nspan);
+  hipLaunchKernelGGL(span_sqnorm_kernel, dim3(nspan), dim3(256), 0, tnt_stream(stream), theta, grad, t, partial, nspan, LrJob{});
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tnt_span_sqnorm_lr_f32(const float* theta, const float* grad, const int32_t* span_seg,
+                                          const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
+                                          float* partial, int32_t nspan, const int64_t* adam_t, const float* lr, float* lr_t,
+                                          float beta1, float beta2, void* stream) {
+  if (nspan <= 0) return TNT_BADARG(8);
+  if (adam_t == nullptr || lr == nullptr || lr_t == nullptr) return TNT_BADARG(9);
+  SpanTab t{span_seg, span_off, span_len, nullptr, seg_l2};
+  hipLaunchKernelGGL(span_sqnorm_kernel, dim3(nspan), dim3(256), 0, tnt_stream(stream), theta, grad, t, partial, nspan,
+                     LrJob{adam_t, lr, lr_t, beta1, beta2});
   TNT_LAUNCH_CHECK();
   return 0;
 }
@@ -521,6 +692,40 @@ extern "C" int32_t tnt_step_finalize_f32(const float* partial, const int32_t* se
   a.x2 = x2; a.out2 = out2; a.n2 = n2; a.scale2 = scale2;
   a.adam_t = adam_t; a.drop_step = drop_step; a.lr = lr; a.lr_t = lr_t; a.b1 = beta1; a.b2 = beta2; a.guard = guard;
   hipLaunchKernelGGL(step_finalize_kernel, dim3(1), dim3(1024), 0, tnt_stream(stream), a);
+  TNT_LAUNCH_CHECK();
+  return 0;
+}
+
+namespace {
+int32_t fin_fill(FinArgs& f, const tnt_finalize_desc* d) {
+  if (d == nullptr || d->partial == nullptr || d->seg_first == nullptr || d->seg_l2 == nullptr || d->sq == nullptr ||
+      d->wsq == nullptr || d->adam_t == nullptr || d->lr == nullptr || d->arrive == nullptr)
+    return TNT_BADARG(1);
+  if (d->nseg < 0 || d->n < 0 || d->n_extra < 0 || d->n2 < 0 || d->n_ids < 0) return TNT_BADARG(2);
+  if (d->n > 0 && (d->x0 == nullptr || d->out0 == nullptr)) return TNT_BADARG(3);
+  if (d->n2 > 0 && (d->x2 == nullptr || d->out2 == nullptr)) return TNT_BADARG(4);
+  f.partial = d->partial; f.seg_first = d->seg_first; f.seg_l2 = d->seg_l2; f.sq = d->sq; f.wsq = d->wsq; f.l2_out = d->l2_out;
+  f.nseg = d->nseg; f.x0 = d->x0; f.out0 = d->out0; f.x1 = d->x1; f.out1 = d->out1; f.n = d->n; f.scale = d->scale;
+  f.extra_part = d->extra_part; f.extra = d->extra; f.n_extra = d->extra_part ? d->n_extra : 0; f.extra_seg = d->extra_seg;
+  f.ids_src = d->ids_src; f.ids_dst = d->ids_dst; f.n_ids = (d->ids_src && d->ids_dst) ? d->n_ids : 0;
+  f.x2 = d->x2; f.out2 = d->out2; f.n2 = d->n2; f.scale2 = d->scale2;
+  f.adam_t = d->adam_t; f.drop_step = d->drop_step; f.lr = d->lr; f.lr_t = d->lr_t; f.b1 = d->beta1; f.b2 = d->beta2;
+  f.guard = d->guard; f.arrive = d->arrive;
+  return 0;
+}
+}  // namespace
+
+extern "C" int32_t tnt_adam_fin_f32(float* theta, float* m, float* v, const float* grad, const int32_t* span_seg,
+                                    const int64_t* span_off, const int32_t* span_len, const float* sq_override,
+                                    int32_t nspan, float eps, float clipnorm, const tnt_finalize_desc* fin, const float* met,
+                                    int32_t nmet, float* ring, int32_t ring_rows, uint32_t* ring_t, void* stream) {
+  if (nspan < 0) return TNT_BADARG(9);
+  if (ring != nullptr && (met == nullptr || ring_t == nullptr || nmet <= 0 || nmet > 62 || ring_rows <= 0)) return TNT_BADARG(13);
+  FinArgs f;
+  if (int32_t rc = fin_fill(f, fin)) return rc;
+  SpanTab t{span_seg, span_off, span_len, nullptr, nullptr};
+  hipLaunchKernelGGL(adam_fin_kernel, dim3(nspan + 1), dim3(256), 0, tnt_stream(stream), theta, m, v, grad, t, sq_override, nspan,
+                     eps, clipnorm, f, MetRing{met, ring, ring_t, nmet, ring_rows});
   TNT_LAUNCH_CHECK();
   return 0;
 }

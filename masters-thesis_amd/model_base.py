@@ -163,6 +163,10 @@ class ModelBase:
         gd = self._guard_word()
         adam = opt.kind == "adam"
         enc = self.__dict__.pop("_enc_fused", None)
+        # no finalize launch (tnt_adam_fin_f32): the norm launch leaves lr_t, the update launches sum the clip norms they need
+        # from the span partials themselves, one extra workgroup of the Adam launch files the scalars, the counters tick at its end
+        fin = adam and hasattr(be, "adam_fin") and getattr(self, "fused_finalize", True)
+        lr_job = (self.adam_t, self.lr_dev, self.lr_t_dev, opt.beta_1, opt.beta_2) if fin else None
         s1, rest_done = 0, False
         if enc is not None:
             # The dense encoder kernel (segment 0, 59 % of config 2's parameters) never has its gradient written: one
@@ -177,13 +181,18 @@ class ModelBase:
                 # ... with the span norms of every other variable riding in the same launch
                 be.dense_gram_norm(dpre, pre, bias, gx, nsplit, w2, nw2, e.l2, a.partial, s1, rows, E,
                                    spans=(a.theta, a.grad, sp.span_seg[s1:], sp.span_off[s1:], sp.span_len[s1:], a.seg_l2,
-                                          a.partial[2 * s1:], sp.nspan - s1))
+                                          a.partial[2 * s1:], sp.nspan - s1), lr_job=lr_job)
                 rest_done = True
             else:
                 be.dense_dw_sqnorm(x, dpre, a.p(name), e.l2, a.partial, s1, N, E, rows, ldx)
         if not rest_done:
-            be.span_sqnorm(a.theta, a.grad, sp.span_seg[s1:], sp.span_off[s1:], sp.span_len[s1:], a.seg_l2, a.partial[2 * s1:],
-                           sp.nspan - s1)
+            if fin and sp.nspan - s1 > 0:
+                be.span_sqnorm_lr(a.theta, a.grad, sp.span_seg[s1:], sp.span_off[s1:], sp.span_len[s1:], a.seg_l2, a.partial[2 * s1:],
+                                  sp.nspan - s1, *lr_job)
+            else:
+                fin = False
+                be.span_sqnorm(a.theta, a.grad, sp.span_seg[s1:], sp.span_off[s1:], sp.span_len[s1:], a.seg_l2, a.partial[2 * s1:],
+                               sp.nspan - s1)
         kw = dict(x0=d[0], out0=d[1], x1=d[2], out1=d[3], n=d[4], scale=d[5]) if d is not None else {}
         md = self.__dict__.pop("_metric_deferred", None)
         if md is not None:
@@ -194,6 +203,27 @@ class ModelBase:
             kw.update(ids_src=ids, ids_dst=prev, n_ids=nids)
             if sqo is not None:
                 kw.update(extra_part=parts, extra=sqo, n_extra=nparts)
+        if fin:
+            if enc is not None:        # the encoder kernel first: it reads the step counter's lr_t like the Adam launch, which ticks
+                sl = slice(e.off, e.off + e.size)
+                be.dense_dw_adam_fin(x, dpre, a.theta[sl], self.opt_m[sl], self.opt_v[sl], e.l2, a.partial, sp.first_host[e.seg],
+                                     sp.first_host[e.seg + 1], a.sq_override[e.seg:e.seg + 1], self.lr_t_dev, opt.beta_1,
+                                     opt.beta_2, opt.epsilon, clip, N, E, rows, ldx, guard=gd)
+            if "extra_part" in kw:
+                kw["extra_seg"] = self.emb_seg
+            arrive = self.__dict__.get("_fin_arrive")
+            if arrive is None:
+                arrive = self._fin_arrive = torch.zeros(16, dtype=torch.int32, device=self.device)
+            # one descriptor per distinct argument set, alive as long as the model (recorded launch plans re-issue the call)
+            ck = tuple((k, v.data_ptr() if torch.is_tensor(v) else v) for k, v in sorted(kw.items())) + (l2_out.data_ptr(), gd is not None)
+            descs = self.__dict__.setdefault("_fin_descs", {})
+            if ck not in descs:
+                descs[ck] = be.finalize_desc(a.partial, sp.seg_first, a.seg_l2, a.sq, a.wsq, l2_out, a.nseg, arrive,
+                                             adam_t=self.adam_t, drop_step=self.drop_step, lr=self.lr_dev, lr_t=self.lr_t_dev,
+                                             beta1=opt.beta_1, beta2=opt.beta_2, guard=gd, **kw)
+            be.adam_fin(a.theta, self.opt_m, self.opt_v, a.grad, sp.span_seg[s1:], sp.span_off[s1:], sp.span_len[s1:],
+                        a.sq_override, sp.nspan - s1, opt.epsilon, clip, descs[ck], **self._ring_args())
+            return
         be.step_finalize(a.partial, sp.seg_first, a.seg_l2, a.sq, a.wsq, l2_out, a.nseg, adam_t=self.adam_t,
                          drop_step=self.drop_step, lr=self.lr_dev, lr_t=self.lr_t_dev if adam else None,
                          beta1=opt.beta_1 if adam else 0.0, beta2=opt.beta_2 if adam else 0.0, guard=gd, **kw)

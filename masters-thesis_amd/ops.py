@@ -29,6 +29,19 @@ class _G3Desc(_ct.Structure):
                 + [(n, _ct.c_void_p) for n in ("work", "sync")])
 
 
+class _FinDesc(_ct.Structure):
+    """tnt_finalize_desc (include/tnt_hip.h)"""
+    _fields_ = [("partial", _ct.c_void_p), ("seg_first", _ct.c_void_p), ("seg_l2", _ct.c_void_p), ("sq", _ct.c_void_p),
+                ("wsq", _ct.c_void_p), ("l2_out", _ct.c_void_p), ("nseg", _ct.c_int32),
+                ("x0", _ct.c_void_p), ("out0", _ct.c_void_p), ("x1", _ct.c_void_p), ("out1", _ct.c_void_p), ("n", _ct.c_int32),
+                ("scale", _ct.c_float),
+                ("extra_part", _ct.c_void_p), ("extra", _ct.c_void_p), ("n_extra", _ct.c_int32), ("extra_seg", _ct.c_int32),
+                ("ids_src", _ct.c_void_p), ("ids_dst", _ct.c_void_p), ("n_ids", _ct.c_int32),
+                ("x2", _ct.c_void_p), ("out2", _ct.c_void_p), ("n2", _ct.c_int32), ("scale2", _ct.c_float),
+                ("adam_t", _ct.c_void_p), ("drop_step", _ct.c_void_p), ("lr", _ct.c_void_p), ("lr_t", _ct.c_void_p),
+                ("beta1", _ct.c_float), ("beta2", _ct.c_float), ("guard", _ct.c_void_p), ("arrive", _ct.c_void_p)]
+
+
 class HipBackend:
     name = "hip"
 
@@ -320,9 +333,17 @@ class HipBackend:
         self._call(self.lib.tnt_dense_fwd_stream_gram_f32, "tnt_dense_fwd_stream_gram_f32", _p(x), _p(w), _p(part), _p(gx_part),
                    _p(w2_part), B, E, K, ldx, ldw, nsplit, self._s())
 
-    def dense_gram_norm(self, dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E, spans=None):
+    def dense_gram_norm(self, dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E, spans=None, lr_job=None):
         """``spans`` = (theta, grad, span_seg, span_off, span_len, seg_l2, span_partial, nspan): the span norms of the other
-        variables in the same launch (tnt_dense_gram_norm_spans_f32)"""
+        variables in the same launch (tnt_dense_gram_norm_spans_f32); ``lr_job`` = (adam_t, lr, lr_t, beta1, beta2): Adam's
+        step size for the update that follows, written by the same launch (tnt_dense_gram_norm_spans_lr_f32)"""
+        if spans is not None and lr_job is not None:
+            th, gr, sseg, soff, slen, sl2, spart, nspan = spans
+            at, lr, lrt, b1, b2 = lr_job
+            self._call(self.lib.tnt_dense_gram_norm_spans_lr_f32, "tnt_dense_gram_norm_spans_lr_f32", _p(dpre), _p(pre), _p(bias),
+                       _p(gx_part), nsplit, _p(w2_part), nw2, l2, _p(partial), nslot, Bk, E, _p(th), _p(gr), _p(sseg), _p(soff),
+                       _p(slen), _p(sl2), _p(spart), nspan, _p(at), _p(lr), _p(lrt), b1, b2, self._s())
+            return
         if spans is None:
             self._call(self.lib.tnt_dense_gram_norm_f32, "tnt_dense_gram_norm_f32", _p(dpre), _p(pre), _p(bias), _p(gx_part), nsplit,
                        _p(w2_part), nw2, l2, _p(partial), nslot, Bk, E, self._s())
@@ -492,6 +513,35 @@ class HipBackend:
     def span_sqnorm(self, theta, grad, span_seg, span_off, span_len, seg_l2, partial, nspan):
         self._call(self.lib.tnt_span_sqnorm_f32, "tnt_span_sqnorm_f32", _p(theta), _p(grad), _p(span_seg), _p(span_off), _p(span_len),
                    _p(seg_l2), _p(partial), nspan, self._s())
+
+    @staticmethod
+    def finalize_desc(partial, seg_first, seg_l2, sq, wsq, l2_out, nseg, arrive, x0=None, out0=None, x1=None, out1=None, n=0,
+                      scale=1.0, extra_part=None, extra=None, n_extra=0, extra_seg=-1, ids_src=None, ids_dst=None, n_ids=0,
+                      adam_t=None, drop_step=None, lr=None, lr_t=None, beta1=0.0, beta2=0.0, guard=None, x2=None, out2=None,
+                      n2=0, scale2=1.0):
+        """tnt_finalize_desc for adam_fin; the returned object keeps the tensors alive"""
+        d = _FinDesc(_p(partial), _p(seg_first), _p(seg_l2), _p(sq), _p(wsq), _p(l2_out), nseg, _p(x0), _p(out0), _p(x1), _p(out1), n,
+                     scale, _p(extra_part), _p(extra), n_extra, extra_seg, _p(ids_src), _p(ids_dst), n_ids, _p(x2), _p(out2), n2,
+                     scale2, _p(adam_t), _p(drop_step), _p(lr), _p(lr_t), beta1, beta2, _p(guard), _p(arrive))
+        d._keep = (partial, seg_first, seg_l2, sq, wsq, l2_out, x0, out0, x1, out1, extra_part, extra, ids_src, ids_dst, x2, out2,
+                   adam_t, drop_step, lr, lr_t, guard, arrive)
+        return d
+
+    def adam_fin(self, theta, m, v, grad, span_seg, span_off, span_len, sq_override, nspan, eps, clipnorm, fin, met=None, ring=None,
+                 ring_t=None):
+        """clip + Adam with the step's scalar tail inside the launch (fin = finalize_desc(...)); the counters tick at its end"""
+        self._call(self.lib.tnt_adam_fin_f32, "tnt_adam_fin_f32", _p(theta), _p(m), _p(v), _p(grad), _p(span_seg), _p(span_off),
+                   _p(span_len), _p(sq_override), nspan, eps, clipnorm, _ct.addressof(fin), _p(met), met.numel() if met is not None else 0,
+                   _p(ring), ring.shape[0] if ring is not None else 0, _p(ring_t), self._s())
+
+    def span_sqnorm_lr(self, theta, grad, span_seg, span_off, span_len, seg_l2, partial, nspan, adam_t, lr, lr_t, beta1, beta2):
+        self._call(self.lib.tnt_span_sqnorm_lr_f32, "tnt_span_sqnorm_lr_f32", _p(theta), _p(grad), _p(span_seg), _p(span_off),
+                   _p(span_len), _p(seg_l2), _p(partial), nspan, _p(adam_t), _p(lr), _p(lr_t), beta1, beta2, self._s())
+
+    def dense_dw_adam_fin(self, x, dpre, theta, m, v, l2, partial, k0, k1, sq_override, lr_t_dev, beta1, beta2, eps, clipnorm, N, E,
+                          Bk, ldx, guard=None):
+        self._call(self.lib.tnt_dense_dw_adam_fin_f32, "tnt_dense_dw_adam_fin_f32", _p(x), _p(dpre), _p(theta), _p(m), _p(v), l2,
+                   _p(partial), k0, k1, _p(sq_override), _p(lr_t_dev), beta1, beta2, eps, clipnorm, _p(guard), N, E, Bk, ldx, self._s())
 
     def step_finalize(self, partial, seg_first, seg_l2, sq, wsq, l2_out, nseg, x0=None, out0=None, x1=None, out1=None, n=0,
                       scale=1.0, extra_part=None, extra=None, n_extra=0, ids_src=None, ids_dst=None, n_ids=0, adam_t=None,
