@@ -987,7 +987,19 @@ extern "C" int32_t tnt_debug_lc_trace(unsigned long long* out) {
 #define LCT_DECL __shared__ unsigned long long lct_l[64];
 #define LCT_STEP 5
 #define LCT_DUMP(lo, hi) do { if (tid == 0 && rb == 0) for (int q_ = (lo); q_ < (hi); ++q_) lc_trace[q_] = lct_l[q_]; } while (0)
+// per-step timeline of one workgroup per role: [0] entry, [1] behind the launch's flag barrier, [2 + k] the k-th step's mark,
+// [38] loop done, [39] outputs stored (roles: 0 forward attention, 1 forward LSTM, 2 backward attention, 3 backward LSTM)
+__device__ unsigned long long lc_steps[4][40];
+extern "C" int32_t tnt_debug_lc_steps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc_steps), sizeof(lc_steps)) == hipSuccess ? 0 : -1;
+}
+#define LCS_DECL __shared__ unsigned long long lcs_l[40];
+#define LCS(k) do { if (tid == 0 && rb == 0) lcs_l[(k)] = wall_clock64(); } while (0)
+#define LCS_DUMP(role) do { if (tid == 0 && rb == 0) for (int q_ = 0; q_ < 40; ++q_) lc_steps[role][q_] = lcs_l[q_]; } while (0)
 #else
+#define LCS_DECL
+#define LCS(k) do {} while (0)
+#define LCS_DUMP(role) do {} while (0)
 #define LCT(k) do {} while (0)
 #define LCT_DECL
 #define LCT_DUMP(lo, hi) do {} while (0)
@@ -1021,6 +1033,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   // in registers they are 8 of the VGPRs this role spills
   __shared__ __attribute__((aligned(16))) float4 zb_l[512], zx_l[512];
   LCT_DECL
+  LCS_DECL
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
   const int U = a.att.U, B = a.att.B, D = a.att.D, R = a.att.R, A = a.att.A, T = a.T;
@@ -1040,6 +1053,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   const __amdgpu_buffer_rsrc_t cx_rsrc = tnt_rsrc(a.att.ctx_d, (unsigned)((long)T * B * D * 4));
   const float sentinel = __uint_as_float(LC_SENTINEL);
   const AttArgs& g = a.att;
+  LCS(0);
 
   if (ub < 16) {
     // =========================================================== attention role: sample ab
@@ -1068,6 +1082,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       if (tid < D) g.ctx_d[(long)ab * D + tid] = sentinel;
     }
     tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
+    LCS(1);
     const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
     const bool stored = g.keep4 != nullptr && g.rate_attn > 0.f;
     const float scale_a = 1.f / (1.f - g.rate_attn);
@@ -1107,6 +1122,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       }
       __syncthreads();
       LCT(33);
+      if (i < 36) LCS(2 + i);
       // ---- q = LeakyReLU(h W2 + b2)   (the arithmetic of att_fwd_body, operand for operand)
       {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1199,6 +1215,8 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       for (int r = tid; r < R; r += WT) o_alpha[(long)ab * R + r] = es_l[r];
     }
     if (ub == 0) LCT_DUMP(32, 40);
+    LCS(38); LCS(39);
+    if (ub == 0) LCS_DUMP(0);
     tnt_seq_leave(a.sync, xcc, a.guard_out);
     return;
   }
@@ -1260,6 +1278,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
     a.hs[BU + ee] = sentinel;
   }
   tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
+  LCS(1);
   for (int i = 0; i < T; ++i) {
     LCT(48);
     if (eok) {          // x4 = xz[i] (loaded behind the previous step's publish) meets the bias here and leaves the registers
@@ -1432,10 +1451,13 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       if (i + 1 < T) x4 = *reinterpret_cast<const float4*>(a.xz + ((long)(i + 1) * BU + ee) * 4);
     }
     LCT(52);
+    if (i < 36) LCS(2 + i);
     // `red` and ctx_l are rewritten next step only behind barriers that every thread passes after this point
     __syncthreads();
   }
   if (ub == 16) LCT_DUMP(48, 56);
+  LCS(38); LCS(39);
+  if (ub == 16) LCS_DUMP(1);
   tnt_seq_leave(a.sync, xcc, a.guard_out);
 }
 }  // namespace
@@ -1549,6 +1571,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float qs[64], dcs[64], dq_s[64];
   __shared__ float red_l[WW], dv_acc[64], scr[16 * 64];
   LCT_DECL
+  LCS_DECL
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, lr = lane & 15;
   const AttArgs& g = a.att;
@@ -1564,6 +1587,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
     return;
   }
   const int ub = slot.ub, rb = __builtin_amdgcn_readfirstlane((int)xcc);
+  LCS(0);
   const long BU = (long)B * U;
   const float sentinel = __uint_as_float(LC_SENTINEL);
   const float4 sent4 = make_float4(sentinel, sentinel, sentinel, sentinel);
@@ -1606,6 +1630,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       if (tid < A) a.dhx[(long)ab * 64 + tid] = sentinel;         // this thread's element of the dq hand-off: buffer 0 armed
     }
     tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
+    LCS(1);
     const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
     const bool stored = g.keep4 != nullptr && g.rate_attn > 0.f;
     const float scale_a = g.rate_attn > 0.f ? 1.f / (1.f - g.rate_attn) : 1.f;
@@ -1732,10 +1757,12 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
         a.dhx[((long)pi * B + ab) * 64 + tid] = dqp;
       }
       LCT(6);
+      if (T - 1 - i < 36) LCS(2 + T - 1 - i);
       if (tid < A) g.dqpre[((long)i * B + ab) * A + tid] = dqp;        // behind the publish: its drain is off the critical path
       // als / das / qs / scr are rewritten next step; every reader of this step is behind the barriers above
       __syncthreads();
     }
+    LCS(38);
     if (live) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
@@ -1748,6 +1775,8 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       if (tid == 0) g.dvb[(long)ab * (A + 1) + A] = dbv_acc;
     }
     if (ub == 0) LCT_DUMP(0, 16);
+    LCS(39);
+    if (ub == 0) LCS_DUMP(2);
     tnt_seq_leave(a.sync, xcc, a.guard_out);
     return;
   }
@@ -1777,9 +1806,30 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   const int x_rg = lane >> 5, x_cg = (lane >> 2) & 7, x_j = lane & 3;
   float bx[2][2][8][2];                    // [unit block][k half][abid = k quad][m pair]
   if (RB == 8) {
+    // A lane's 64 operands of a block are 64 consecutive floats of ONE row of Ur, a different row per lane: read straight from
+    // memory that is 64 load instructions of 32 cache lines each per wave (measured: 20 us of this kernel's 32 us prologue, the
+    // CU's one address path serialising 16 waves).  Staged instead: the block's [512 rows][64] slab comes in with coalesced
+    // 16-byte loads (a row's 256 bytes by 16 adjacent lanes), is parked in the dynamic LDS block (free until the loop
+    // starts; row stride 65: the 32 rows a wave reads side by side fall into 32 banks) and each lane picks its operands there.
+    constexpr int ULD = 65;
+    static_assert(512 * ULD <= LB_PF_FLOATS, "the staging slab must fit the dynamic LDS block");
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const float* src = a.Ur + ((long)(w * 32 + x_cg * 4 + x_j) * U + (2 * j + q) * 16) * 4;
+      float4 st[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = tid + 1024 * k;                        // chunk c: row c / 16, floats 4 (c % 16) .. + 3
+        st[k] = *reinterpret_cast<const float4*>(a.Ur + ((long)(c >> 4) * U + (2 * j + q) * 16) * 4 + (c & 15) * 4);
+      }
+      if (q == 1) __syncthreads();                           // block 0's operands have been picked
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = tid + 1024 * k;
+        float* d = lb_lds + (c >> 4) * ULD + (c & 15) * 4;
+        d[0] = st[k].x; d[1] = st[k].y; d[2] = st[k].z; d[3] = st[k].w;
+      }
+      __syncthreads();
+      const float* src = lb_lds + (w * 32 + x_cg * 4 + x_j) * ULD;
 #pragma unroll
       for (int kh2 = 0; kh2 < 2; ++kh2)
 #pragma unroll
@@ -1787,6 +1837,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
 #pragma unroll
           for (int pr = 0; pr < 2; ++pr) bx[q][kh2][qd][pr] = src[kh2 * 32 + 4 * qd + 2 * pr + x_rg];
     }
+    __syncthreads();                                         // ... before the block is carved up below
   } else {
     load_bw(0, a.Ur);
     load_bw(1, a.Ur);
@@ -1836,6 +1887,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   }
   if (pmine) *pslot(0) = sentinel;
   tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
+  LCS(1);
   for (int i = T - 1; i >= 0; --i) {
     const int pi = (T - 1 - i) % 3, pn = (pi + 1) % 3;
     // epilogue operands of this step do not depend on the chain: fetch them first
@@ -2014,10 +2066,13 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       }
     }
     LCT(21);
+    if (T - 1 - i < 36) LCS(2 + T - 1 - i);
     // behind the publish (its drain is off the critical path): this step's dz for the weight-gradient GEMMs after the chain
     if (eok) *reinterpret_cast<float4*>(a.dz + ((long)i * BU + ee) * 4) = dz_keep;
   }
   if (ub == 16) LCT_DUMP(16, 32);
+  LCS(38); LCS(39);
+  if (ub == 16) LCS_DUMP(3);
   tnt_seq_leave(a.sync, xcc, a.guard_out);
 }
 }  // namespace

@@ -25,3 +25,16 @@ for title, names in (("forward chain, step 5", fwd), ("backward chain, step 5", 
     print(title)
     for k in sorted(names, key=lambda k: t[k]):
         print(f"  {names[k]:14s} {(t[k] - base) * 10:8d} ns")
+
+# per-step timeline (tnt_debug_lc_steps): entry, behind the launch's flag barrier, every step's mark, loop done, outputs stored
+sb = (ctypes.c_ulonglong * 160)()
+lib.tnt_debug_lc_steps.argtypes = [ctypes.c_void_p]
+assert lib.tnt_debug_lc_steps(sb) == 0
+T = 15          # bench.synth: caption length 16 -> 15 chain steps
+for role, name in enumerate(("forward attention (mark: h in)", "forward LSTM (mark: h out)", "backward attention (mark: dq out)",
+                             "backward LSTM (mark: parts out)")):
+    s = list(sb)[role * 40:(role + 1) * 40]
+    marks = s[2:2 + T]
+    print(f"{name}: entry -> barrier {(s[1] - s[0]) * 10} ns, -> first mark {(marks[0] - s[0]) * 10} ns; step periods (ns): "
+          + " ".join(str((b - a) * 10) for a, b in zip(marks, marks[1:]))
+          + f"; last mark -> loop done {(s[38] - marks[-1]) * 10} ns -> stored {(s[39] - s[38]) * 10} ns; entry -> stored {(s[39] - s[0]) * 10} ns")
