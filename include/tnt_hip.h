@@ -763,14 +763,17 @@ int32_t tnt_attention_step_bwd_f32(const float* dctx_d, const float* F, const fl
  * tnt_lstm_step_fwd_f32(xz[i], hs[i], cs[i], Ur, ctx_d[i], Wc, ... -> hs[i+1], cs[i+1], gates[i]) with xz_bias.
  * hs / cs [T+1][B][U] (slab 0 = initial state), xz [T][B][U][4], qpre [T][B][A], alpha [T][B][R], ctx / ctx_d [T][B][D],
  * gates [T][B][U][4].  U == 512, B <= 128, R <= 512, A % 4 == D % 4 == 0, A, D <= 64, the device census of
- * tnt_lstm_seq_supported.  sync / guard_out: as tnt_lstm_seq_fwd_f32 (same state words). */
+ * tnt_lstm_seq_supported.  work: tnt_lc_seq_fwd_work_floats(B) floats of exchange space (contents irrelevant: the partial
+ * query sums the LSTM workgroups hand to the attention workgroups).  sync / guard_out: as tnt_lstm_seq_fwd_f32 (same state
+ * words). */
+int32_t tnt_lc_seq_fwd_work_floats(int32_t B);
 int32_t tnt_lc_seq_fwd_f32(const float* F, const float* P, const float* W2, const float* b2, const float* v,
                            const float* bv, float* qpre, float* alpha, float* ctx, float* ctx_d, const uint8_t* keep4,
                            int64_t keep_stride, const float* xz, const float* Wc, const float* Ur, const float* xz_bias,
                            float* hs, float* cs, float* gates, int32_t T, int32_t B, int32_t R, int32_t D, int32_t A,
                            int32_t U, float slope, float rate_attn, float rate_in, int32_t in_lwidth, uint64_t seed,
-                           uint32_t site_attn0, uint32_t site_in0, const uint32_t* step_dev, uint32_t* sync,
-                           float* guard_out, void* stream);
+                           uint32_t site_attn0, uint32_t site_in0, const uint32_t* step_dev, float* work,
+                           uint32_t* sync, float* guard_out, void* stream);
 /* the same launch with the Dropout behind the LSTM (lc_NIC.py:256) as a rider: hd [T][B][U] (nullable) receives
  * tnt_dropout_f32(hs[1:], rows_per_site = B, site = site_out0 + i for step i) as the states leave the chain. */
 int32_t tnt_lc_seq_fwd_drop_f32(const float* F, const float* P, const float* W2, const float* b2, const float* v,
@@ -780,7 +783,7 @@ int32_t tnt_lc_seq_fwd_drop_f32(const float* F, const float* P, const float* W2,
                                 int32_t B, int32_t R, int32_t D, int32_t A, int32_t U, float slope, float rate_attn,
                                 float rate_in, int32_t in_lwidth, uint64_t seed, uint32_t site_attn0,
                                 uint32_t site_in0, const uint32_t* step_dev, float* hd, float rate_out,
-                                uint32_t site_out0, uint32_t* sync, float* guard_out, void* stream);
+                                uint32_t site_out0, float* work, uint32_t* sync, float* guard_out, void* stream);
 
 /* ---- the backward chain of the attention captioner as ONE persistent launch (tape.gradient through lc_NIC.py:244-256):
  * for i = T-1 .. 0: tnt_lstm_step_bwd_f32(dz_next = dz[i+1], dh_ext = the attention's query gradient of step i+1,

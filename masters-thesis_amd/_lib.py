@@ -91,11 +91,12 @@ SIGNATURES = {
     "tnt_gru_step_fwd_f32": [P, P, P, P, P, P, I32, I32, P],
     "tnt_gru_step_bwd_f32": [P, P, P, P, P, P, P, P, P, I32, I32, P],
     "tnt_lc_seq_fwd_f32": [P, P, P, P, P, P, P, P, P, P, P, I64, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, F32, F32, F32,
-                           I32, U64, U32, U32, P, P, P, P],
+                           I32, U64, U32, U32, P, P, P, P, P],
+    "tnt_lc_seq_fwd_work_floats": [I32],
     "tnt_lc_seq_bwd_f32": [P, P, P, P, P, P, P, I64, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, F32, F32, F32,
                            I32, U64, U32, U32, P, F32, P, P, P],
     "tnt_lc_seq_fwd_drop_f32": [P, P, P, P, P, P, P, P, P, P, P, I64, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, F32, F32,
-                                F32, I32, U64, U32, U32, P, P, F32, U32, P, P, P],
+                                F32, I32, U64, U32, U32, P, P, F32, U32, P, P, P, P],
     "tnt_lc_seq_bwd_drop_f32": [P, P, P, P, P, P, P, I64, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, F32, F32,
                                 F32, I32, U64, U32, U32, P, F32, F32, U32, P, P, P],
     "tnt_lc_seq_bwd_work_floats": [I32, I32],

@@ -965,6 +965,7 @@ struct LcSeqArgs {
   float* gates;            // [T][B][U][4]
   float* hd;               // nullable [T][B][U]: Dropout(hs[1:]) with one site per step (tnt_dropout_f32, rows_per_site = B)
   float rate_out; uint32_t site_out0;
+  float* qp;               // [3][B][64][16]: the 16 LSTM workgroups' partials of q = h W2 per sample (ring of three)
   int T;
   unsigned* sync; float* guard_out;
 };
@@ -972,6 +973,26 @@ struct LcSeqArgs {
 constexpr unsigned LC_SENTINEL = 0x7FC5EED5u;          // = TNT_SEQ_SENTINEL of lstm.hip
 constexpr int LC_SEQ_LDS_BYTES = 16 * 4 * 16 * 17 * 4 + 16;
 
+// Stores / loads through a buffer resource: the base lives in 4 SGPRs, a lane's address is ONE 32-bit VGPR (its byte offset inside
+// a slab) plus a wave-uniform SGPR offset (the slab of the step).  The chain kernels' LSTM roles keep 64 resident weight
+// registers; with 64-bit pointers per output array the compiler spilled address registers to scratch and reloaded them on the
+// step's critical path (a scratch round trip in front of every hand-off store: measured 2 us).
+typedef unsigned lc_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lc_st1(__amdgpu_buffer_rsrc_t rsrc, float v, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void lc_st4(__amdgpu_buffer_rsrc_t rsrc, float4 v, unsigned voff, unsigned soff) {
+  const lc_u4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ float4 lc_ld4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  const tnt_f4 v = __builtin_bit_cast(tnt_f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 lc_ld4_l2(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {      // sc1: served by L2
+  const tnt_f4 v = __builtin_bit_cast(tnt_f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, /*sc1*/ 16));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ float lc_ld1_l2(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)byte_off, 0, /*sc1*/ 16));
 }
@@ -984,6 +1005,7 @@ extern "C" int32_t tnt_debug_lc_trace(unsigned long long* out) {
 // timestamps are parked in LDS and written out when the workgroup leaves: a global store at a trace point would sit in
 // front of the very s_waitcnt vmcnt(0) it is meant to time
 #define LCT(k) do { if (tid == 0 && rb == 0 && i == LCT_STEP) lct_l[(k)] = wall_clock64(); } while (0)
+#define LCT_T(k, t) do { if (tid == (t) && rb == 0 && i == LCT_STEP) lct_l[(k)] = wall_clock64(); } while (0)
 #define LCT_DECL __shared__ unsigned long long lct_l[64];
 #define LCT_STEP 5
 #define LCT_DUMP(lo, hi) do { if (tid == 0 && rb == 0) for (int q_ = (lo); q_ < (hi); ++q_) lc_trace[q_] = lct_l[q_]; } while (0)
@@ -1001,6 +1023,7 @@ extern "C" int32_t tnt_debug_lc_steps(unsigned long long* out) {
 #define LCS(k) do {} while (0)
 #define LCS_DUMP(role) do {} while (0)
 #define LCT(k) do {} while (0)
+#define LCT_T(k, t) do {} while (0)
 #define LCT_DECL
 #define LCT_DUMP(lo, hi) do {} while (0)
 #endif
@@ -1017,24 +1040,24 @@ extern "C" int32_t tnt_debug_lc_steps(unsigned long long* out) {
 template <int G4, int NP, int RB>
 __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   constexpr int NWF = 16, SS = 8, CK = 32, RPP = WT / G4;
-  constexpr bool W2L = G4 == 8;                         // W2 [U][A <= 32] fits the dynamic LDS block
   extern __shared__ __attribute__((aligned(16))) float lc_lds[];
   float (*red)[4][16][17] = reinterpret_cast<float (*)[4][16][17]>(lc_lds);          // LSTM role: [NWF][4][16][17]
-  float* w2_l = lc_lds;                                                               // attention role: [U][A]
   unsigned* s_slot = reinterpret_cast<unsigned*>(lc_lds + NWF * 4 * 16 * 17);
-  __shared__ __attribute__((aligned(16))) float hs_l[512];
-  __shared__ float es_l[512];
   __shared__ __attribute__((aligned(16))) float wred_l[WW][64];
-  __shared__ __attribute__((aligned(16))) float qs_l[64];
+  __shared__ __attribute__((aligned(16))) float qs_l[64], qe_l[64], zred_l[WW];      // attention role: q, e^{2q}, per-wave sums
   __shared__ float red_l[WW];
+  __shared__ int qbig_l;
+  __shared__ float w2s_l[32 * 64];              // LSTM role: W2 rows of this workgroup's 32 units, [32][64]
+  __shared__ __attribute__((aligned(16))) float ctx_l[16 * 64];                      // LSTM role: the step's context, [row][D]
+  __shared__ float hq_l[16 * 36];               // LSTM role: the h just computed, [row][unit], row stride 36
+  __shared__ __attribute__((aligned(16))) float zc_l[2 * 16 * 132];                  // LSTM role: the context term's two k-halves
   __shared__ float wcb_l[16 * 8 * 64];          // LSTM role: B operands of the context-term MFMAs, [wave][quad slot][lane]
-  __shared__ float ctx_l[16 * 64];                                                    // [16 rows][D]
   // LSTM role, per epilogue thread: the gate bias, and (text projection + bias) of the current step -- parked in LDS: resident
   // in registers they are 8 of the VGPRs this role spills
   __shared__ __attribute__((aligned(16))) float4 zb_l[512], zx_l[512];
   LCT_DECL
   LCS_DECL
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, lr = lane & 15;
   const int U = a.att.U, B = a.att.B, D = a.att.D, R = a.att.R, A = a.att.A, T = a.T;
   const unsigned xcc = tnt_xcc_id();
@@ -1057,17 +1080,27 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
 
   if (ub < 16) {
     // =========================================================== attention role: sample ab
+    // Per step: the 16 LSTM workgroups of the group each leave the 32-unit partial of q = h W2 for this sample (qp, its own
+    // flag); this workgroup sums them, and then ONE pass over its rows does scores, exp and the weighted sum of F together:
+    //   e_r = dropout(tanh(P_r + q)) . v + bv;   x_r = exp(e_r - m);   c = sum_r x_r F_r;   z = sum_r x_r;   ctx = c / z
+    // with m an upper bound of every e_r that is known before the step (bv + sum_a |v_a| / (1 - rate): |tanh| <= 1), so the
+    // softmax needs no maximum, no second pass and no reduction of its own -- z rides in the reduction of c.  Two workgroup
+    // barriers per step (behind q, behind the per-wave sums) instead of nine.  tanh(P + q) = 1 - 2 / (e^{2P} e^{2q} + 1): e^{2P}
+    // is step-invariant and lives in the registers P used to, e^{2q} costs A exps per step, so an element costs ONE
+    // transcendental (the reciprocal) instead of two.  Where that could lose accuracy (|P| or |q| > 40: the product of two
+    // clamped exponentials) the step uses tanh(P + q) itself, and where the bound m is too far above the scores for exp
+    // (2 sum |v| / (1 - rate) > 60) the maximum is reduced as before: both uniform branches, both exercised by the tests.
     const int ab = rb * RB + ub;
     const bool live = ub < RB && ab < B;
     const int c4 = tid % G4, rl = tid / G4;
     const bool cokA = c4 * 4 < A, cokD = c4 * 4 < D;
-    float4 pv[NP], fv[NP];
+    float4 pv[NP], fv[NP];                       // e^{2 P} (P itself when `direct`), F
     float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float b2v = 0.f, bvv = 0.f;
+    float b2v = 0.f, bvv = 0.f, mb = 0.f;
+    bool direct = false, bounded = true;
+    const float scale_a = 1.f / (1.f - g.rate_attn);
     if (live) {
-      if (W2L) {
-        for (int e = tid; e < U * A / 4; e += WT) reinterpret_cast<float4*>(w2_l)[e] = reinterpret_cast<const float4*>(g.W2)[e];
-      }
+      bool big = false;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int r = p * RPP + rl;
@@ -1075,17 +1108,32 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
         fv[p] = (cokD && r < R) ? *reinterpret_cast<const float4*>(g.F + ((long)ab * R + r) * D + c4 * 4)
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+        big = big || !(fabsf(pv[p].x) <= 40.f && fabsf(pv[p].y) <= 40.f && fabsf(pv[p].z) <= 40.f && fabsf(pv[p].w) <= 40.f);
       }
       if (cokA) v4 = *reinterpret_cast<const float4*>(g.v + c4 * 4);
-      if (tid < A) b2v = g.b2[tid];
+      if (tid < 4 * A) b2v = g.b2[tid >> 2];
       bvv = g.bv[0];
       if (tid < D) g.ctx_d[(long)ab * D + tid] = sentinel;
+      if (tid == 0) qbig_l = 0;
+      direct = __syncthreads_or(big ? 1 : 0) != 0;
+      if (!direct) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          pv[p].x = __expf(2.f * pv[p].x); pv[p].y = __expf(2.f * pv[p].y);
+          pv[p].z = __expf(2.f * pv[p].z); pv[p].w = __expf(2.f * pv[p].w);
+        }
+      }
+      const float vsum = adj_sum<G4>(fabsf(v4.x) + fabsf(v4.y) + fabsf(v4.z) + fabsf(v4.w)) * (g.rate_attn > 0.f ? scale_a : 1.f);
+      bounded = 2.f * vsum <= 60.f;
+      mb = bvv + vsum;
+      // the dropout scale rides in v
+      if (g.rate_attn > 0.f) { v4.x *= scale_a; v4.y *= scale_a; v4.z *= scale_a; v4.w *= scale_a; }
     }
     tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
     LCS(1);
     const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
     const bool stored = g.keep4 != nullptr && g.rate_attn > 0.f;
-    const float scale_a = 1.f / (1.f - g.rate_attn);
+    const __amdgpu_buffer_rsrc_t qp_rsrc = tnt_rsrc(a.qp, (unsigned)(3u * (unsigned)B * 1024u * 4u));
     if (live) for (int i = 0; i < T; ++i) {
       float* const o_qpre = g.qpre + (long)i * B * A;
       float* const o_alpha = g.alpha + (long)i * B * R;
@@ -1097,122 +1145,124 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       // the context's input-dropout decision of this step (a Philox call) does not depend on the chain: taken here
       bool kin = true;
       if (tid < D && g.rate_in > 0.f) kin = tnt_keep((uint64_t)ab * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, site_in, step);
-      // this step's keep bits: in flight while h[i] is polled
+      // this step's keep bits: in flight while the q partials are polled
       uint32_t mk[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int r = p * RPP + rl;
-        mk[p] = (stored && cokA && r < R) ? g.keep4[(long)i * a.keep_stride + ((((long)ab * R + r) * A + c4 * 4) >> 2)] : 0u;
+        mk[p] = (stored && cokA && r < R) ? g.keep4[(long)i * a.keep_stride + ((((long)ab * R + r) * A + c4 * 4) >> 2)] : 0xFu;
       }
-      // ---- this sample's h of step i
-      unsigned spins = 0;
-      for (;;) {
-        bool ok = true;
-        for (int k = tid; k < U; k += WT) {
-          const float v = lc_ld1_l2(hs_rsrc, (unsigned)(((long)i * BU + (long)ab * U + k) * 4));
-          hs_l[k] = v;
-          ok = ok && __float_as_uint(v) != LC_SENTINEL;
-        }
-        if (__all(ok)) break;
-        if (++spins > TNT_SEQ_SPIN_LIMIT) {
-          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-      }
-      __syncthreads();
-      LCT(33);
-      if (i < 36) LCS(2 + i);
-      // ---- q = LeakyReLU(h W2 + b2)   (the arithmetic of att_fwd_body, operand for operand)
+      // ---- q[a] = b2[a] + the 16 partials of this sample: thread 4 a + c polls partials 4 c .. 4 c + 3 of column a
       {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cokA) {
-#pragma unroll 4
-          for (int k = rl; k < U; k += RPP) {
-            const float4 wv = W2L ? *reinterpret_cast<const float4*>(w2_l + k * A + c4 * 4)
-                                  : *reinterpret_cast<const float4*>(g.W2 + (long)k * A + c4 * 4);
-            const float hk = hs_l[k];
-            acc.x += hk * wv.x; acc.y += hk * wv.y; acc.z += hk * wv.z; acc.w += hk * wv.w;
+        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool mine = tid < 4 * A;
+        const unsigned off = (unsigned)((((i % 3) * B + ab) * 1024 + tid * 4) * 4);
+        unsigned spins = 0;
+        if (mine) for (;;) {
+          qv = tnt_ld4_l2(qp_rsrc, off);
+          const bool ok = __float_as_uint(qv.x) != LC_SENTINEL && __float_as_uint(qv.y) != LC_SENTINEL &&
+                          __float_as_uint(qv.z) != LC_SENTINEL && __float_as_uint(qv.w) != LC_SENTINEL;
+          if (ok) break;                                     // per lane: a lane leaves the loop when ITS chunk is in
+          if (++spins > TNT_SEQ_SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        }
+        LCT(33);
+        if (i < 36) LCS(2 + i);
+        if (tid < 4 * A) {                                   // whole waves up to the last one (A % 4 == 0: groups of 4 lanes are whole)
+          const float t = adj_sum<4>((qv.x + qv.y) + (qv.z + qv.w)) + b2v;
+          if ((tid & 3) == 0) {
+            const float q = t > 0.f ? t : t * g.slope;
+            o_qpre[(long)ab * A + (tid >> 2)] = t;
+            qs_l[tid >> 2] = q;
+            qe_l[tid >> 2] = __expf(2.f * q);
+            if (!(fabsf(q) <= 40.f)) qbig_l = i + 1;
           }
         }
-        acc.x = stride_sum<G4>(acc.x); acc.y = stride_sum<G4>(acc.y);
-        acc.z = stride_sum<G4>(acc.z); acc.w = stride_sum<G4>(acc.w);
-        if (lane < G4) *reinterpret_cast<float4*>(&wred_l[w][lane * 4]) = acc;
-        __syncthreads();
-        if (tid < A) {
-          float t = b2v;
-#pragma unroll
-          for (int k = 0; k < WW; ++k) t += wred_l[k][tid];
-          o_qpre[(long)ab * A + tid] = t;
-          qs_l[tid] = t > 0.f ? t : t * g.slope;
-        }
-        __syncthreads();
       }
+      __syncthreads();
       LCT(34);
-      // ---- scores
+      // ---- scores, exp and the weighted sums in one pass
+      float ex[NP];
+      float zl = 0.f;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       {
-        const float4 q4 = cokA ? *reinterpret_cast<const float4*>(&qs_l[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool fast = !direct && qbig_l != i + 1;
+        const float4 q4 = cokA ? *reinterpret_cast<const float4*>(fast ? &qe_l[c4 * 4] : &qs_l[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
           const int r = p * RPP + rl;
           float t = 0.f;
           if (cokA && r < R) {
             const long e = ((long)ab * R + r) * A + c4 * 4;
-            float s0 = tnt_tanh(pv[p].x + q4.x), s1 = tnt_tanh(pv[p].y + q4.y), s2 = tnt_tanh(pv[p].z + q4.z), s3 = tnt_tanh(pv[p].w + q4.w);
-            if (g.rate_attn > 0.f) {
-              bool k[4];
-              if (stored) { k[0] = mk[p] & 1u; k[1] = mk[p] & 2u; k[2] = mk[p] & 4u; k[3] = mk[p] & 8u; }
-              else tnt_keep4((uint64_t)e, g.rate_attn, g.seed, site_attn, step, k);
-              s0 = k[0] ? s0 * scale_a : 0.f; s1 = k[1] ? s1 * scale_a : 0.f;
-              s2 = k[2] ? s2 * scale_a : 0.f; s3 = k[3] ? s3 * scale_a : 0.f;
+            float s0, s1, s2, s3;
+            if (fast) {
+              s0 = 1.f - 2.f * __builtin_amdgcn_rcpf(pv[p].x * q4.x + 1.f); s1 = 1.f - 2.f * __builtin_amdgcn_rcpf(pv[p].y * q4.y + 1.f);
+              s2 = 1.f - 2.f * __builtin_amdgcn_rcpf(pv[p].z * q4.z + 1.f); s3 = 1.f - 2.f * __builtin_amdgcn_rcpf(pv[p].w * q4.w + 1.f);
+            } else {
+              const float4 p4 = direct ? pv[p] : *reinterpret_cast<const float4*>(g.P + e);
+              s0 = tnt_tanh(p4.x + q4.x); s1 = tnt_tanh(p4.y + q4.y); s2 = tnt_tanh(p4.z + q4.z); s3 = tnt_tanh(p4.w + q4.w);
             }
-            t = s0 * v4.x + s1 * v4.y + s2 * v4.z + s3 * v4.w;
+            uint32_t kb = mk[p];
+            if (g.rate_attn > 0.f && !stored) {
+              bool k[4];
+              tnt_keep4((uint64_t)e, g.rate_attn, g.seed, site_attn, step, k);
+              kb = (k[0] ? 1u : 0u) | (k[1] ? 2u : 0u) | (k[2] ? 4u : 0u) | (k[3] ? 8u : 0u);
+            }
+            t = ((kb & 1u) ? s0 * v4.x : 0.f) + ((kb & 2u) ? s1 * v4.y : 0.f) + ((kb & 4u) ? s2 * v4.z : 0.f) + ((kb & 8u) ? s3 * v4.w : 0.f);
           }
-          t = adj_sum<G4>(t);
-          if (c4 == 0 && r < R) es_l[r] = t + bvv;
+          ex[p] = adj_sum<G4>(t) + bvv;                      // the score of row r, in every lane of its group
         }
-        __syncthreads();
-      }
-      LCT(35);
-      // ---- softmax over regions
-      float m = -INFINITY;
-      for (int r = tid; r < R; r += WT) m = fmaxf(m, es_l[r]);
-      m = block_max_w(m, red_l);
-      float z = 0.f;
-      for (int r = tid; r < R; r += WT) { const float ex = expf(es_l[r] - m); es_l[r] = ex; z += ex; }
-      z = block_sum_w(z, red_l);
-      const float invz = 1.f / z;
-      for (int r = tid; r < R; r += WT) es_l[r] *= invz;
-      __syncthreads();
-      LCT(36);
-      // ---- context
-      {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float m = mb;
+        if (!bounded) {                                      // uniform: the bound is too far off, reduce the maximum
+          m = -INFINITY;
+#pragma unroll
+          for (int p = 0; p < NP; ++p) if (p * RPP + rl < R) m = fmaxf(m, ex[p]);
+          m = block_max_w(m, red_l);
+        }
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          const int r = p * RPP + rl;
-          const float al = r < R ? es_l[r] : 0.f;
-          acc.x += al * fv[p].x; acc.y += al * fv[p].y; acc.z += al * fv[p].z; acc.w += al * fv[p].w;
+          const float x = p * RPP + rl < R ? __expf(ex[p] - m) : 0.f;
+          ex[p] = x; zl += x;
+          acc.x += x * fv[p].x; acc.y += x * fv[p].y; acc.z += x * fv[p].z; acc.w += x * fv[p].w;
         }
         acc.x = stride_sum<G4>(acc.x); acc.y = stride_sum<G4>(acc.y);
         acc.z = stride_sum<G4>(acc.z); acc.w = stride_sum<G4>(acc.w);
+        zl = stride_sum<G4>(zl);                             // every row of the wave once: the lanes of a group hold the same x
         if (lane < G4) *reinterpret_cast<float4*>(&wred_l[w][lane * 4]) = acc;
-        __syncthreads();
-        if (tid < D) {
-          float t = 0.f;
+        if (lane == 0) zred_l[w] = zl;
+      }
+      __syncthreads();
+      LCT(36);
+      float z = 0.f;
+      {
+        const float4* zr = reinterpret_cast<const float4*>(zred_l);
 #pragma unroll
-          for (int k = 0; k < WW; ++k) t += wred_l[k][tid];
-          const float td = g.rate_in > 0.f ? (kin ? t * (1.f / (1.f - g.rate_in)) : 0.f) : t;
-          // the reset of ctx_d[i+1] (issued at the top of the step, long drained) is in L2 before ctx_d[i] is published;
-          // nothing else of this thread is in flight: the step's other outputs are stored BEHIND the publish
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          o_ctxd[(long)ab * D + tid] = td;
-          o_ctx[(long)ab * D + tid] = t;
-        }
+        for (int k = 0; k < WW / 4; ++k) { const float4 t = zr[k]; z += (t.x + t.y) + (t.z + t.w); }
+      }
+      const float invz = 1.f / z;
+      if (tid < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < WW; ++k) t += wred_l[k][tid];
+        t *= invz;
+        const float td = g.rate_in > 0.f ? (kin ? t * (1.f / (1.f - g.rate_in)) : 0.f) : t;
+        // the reset of ctx_d[i+1] (issued at the top of the step, long drained) is in L2 before ctx_d[i] is published;
+        // this thread's other stores of the step (qpre) are as old
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        o_ctxd[(long)ab * D + tid] = td;
+        o_ctx[(long)ab * D + tid] = t;
       }
       LCT(37);
-      // off the critical path: alpha of this step (es_l is rewritten next step only behind the barrier that follows the h poll)
-      for (int r = tid; r < R; r += WT) o_alpha[(long)ab * R + r] = es_l[r];
+      // off the critical path: alpha of this step
+      if (c4 == 0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int r = p * RPP + rl;
+          if (r < R) o_alpha[(long)ab * R + r] = ex[p] * invz;
+        }
+      }
+      // qs_l / qe_l / wred_l / zred_l are rewritten next step: every reader of this step is in front of the next step's first
+      // barrier, every writer behind it (q) or behind the second one (the sums)
     }
     if (ub == 0) LCT_DUMP(32, 40);
     LCS(38); LCS(39);
@@ -1251,22 +1301,75 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   }
   // the context term ctx[16][D] Wc[D][128 gate columns of this workgroup] runs on the MFMAs (a scalar loop over D is a chain of
   // 2 D dependent LDS round trips: 1.3 us on the critical path at D = 32): wave w owns column tile w & 7 (4 units x 4 gates)
-  // and the contraction quads 2 s + (w >> 3); its B operands are parked in LDS, not in registers (this role spills)
+  // and half kh = w >> 3 of the contraction.  Every wave polls ITS A operands straight into registers -- lane (kq, lr) takes
+  // the float4 ctx_d[row lr][DH kh + 16 u + 4 kq ..] (u < NU), element s & 3 of float4 s >> 2 feeds MFMA s, so the contraction
+  // index of MFMA s is d = DH kh + 16 (s >> 2) + 4 kq + (s & 3) and the B operands are laid out to match -- no LDS round trip
+  // and no workgroup barrier between the hand-off and the MFMAs.  The B operands are parked in LDS, not in registers (this
+  // role spills).
   const int t8 = w & 7, kh = w >> 3;
-  constexpr int NQ = G4 == 8 ? 4 : 8;          // quads per wave: D <= 32 -> 4, D <= 64 -> 8 (operands past D are zero)
+  constexpr int NU = G4 == 8 ? 1 : 2;          // float4 per lane: D <= 32 -> 1, D <= 64 -> 2 (operands past D are zero)
+  constexpr int NQ = 4 * NU, DH = 16 * NU;
 #pragma unroll
   for (int sq = 0; sq < NQ; ++sq) {
-    const int d = (2 * sq + kh) * 4 + kq;
+    const int d = DH * kh + 16 * (sq >> 2) + 4 * kq + (sq & 3);
     wcb_l[(w * 8 + sq) * 64 + lane] = d < D ? a.Wc[((long)d * U + j * 32) * 4 + t8 * 16 + lr] : 0.f;
   }
-  ctx_l[tid] = 0.f;                            // columns past D are never written again: 0 * 0 in the padded MFMA quads
+  // q = h W2 leaves this role in 32-unit partials, [16 rows][32 units] x [32][A] on the MFMAs: wave 8 + t owns column tile t
+  // (16 columns), lane (kq, lr) feeds A[row lr][unit 4 s + kq] from hq_l (row stride 36: conflict-free) and B[unit 4 s + kq][column
+  // 16 t + lr] from w2s_l for the 8 k-steps and receives rows 4 kq .. + 3 of column 16 t + lr.  (A scalar loop -- 32 FMAs per
+  // thread with its operands in LDS -- took 1.5 us here: this role has no registers left to batch the LDS reads in.)
+  // (row stride 64 whatever A is, columns past A zero: every operand address is the lane's base plus a compile-time offset)
+  for (int e = tid; e < 32 * 64; e += WT) w2s_l[e] = (e & 63) < A ? g.W2[(long)(j * 32 + (e >> 6)) * A + (e & 63)] : 0.f;
+  const int qtile = w - 8, qcol = qtile * 16 + lr;
+  const bool qwave = qtile >= 0 && qtile * 16 < A;            // wave-uniform
+  // this lane's element (row 4 kq + r of the block, column qcol, partial j) of ring buffer buf: byte offset qoff + uniform part
+  const __amdgpu_buffer_rsrc_t qw_rsrc = tnt_rsrc(a.qp, (unsigned)(3u * (unsigned)B * 1024u * 4u));
+  const unsigned qoff = (unsigned)((((rb * RB + kq * 4) * 64 + qcol) * 16 + j) * 4);
+  auto qput = [&](int buf, int r, float v) { lc_st1(qw_rsrc, v, qoff, (unsigned)((buf * B + r) * 4096)); };
+  auto qpart = [&]() {
+    floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float qa_[4], qb_[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        qa_[s] = hq_l[lr * 36 + 16 * h + 4 * s + kq];
+        qb_[s] = w2s_l[(16 * h + 4 * s + kq) * 64 + qcol];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa_[s], qb_[s], acc, 0, 0, 0);
+    }
+    return acc;
+  };
+  // this lane's rows of the partial: 4 kq + r, live below RB and inside the batch
+  auto qrow_ok = [&](int r) { return qwave && qcol < A && kq * 4 + r < RB && rb * RB + kq * 4 + r < B; };
+  if (tid < 16 * 32) {                         // q of step 0 comes from the initial state
+    const int r = tid >> 5, u = tid & 31;
+    hq_l[r * 36 + u] = (r < RB && rb * RB + r < B) ? a.hs[(long)(rb * RB + r) * U + j * 32 + u] : 0.f;
+  }
+  __syncthreads();
+  if (qwave) {
+    const floatx4 t = qpart();
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (qrow_ok(r)) {
+        qput(0, r, t[r]);                      // in L2 before the launch's flag barrier: buffer 0 needs no sentinel
+        if (T > 1) qput(1, r, sentinel);
+      }
+  }
   constexpr int ZCLD = 132;
-  float* zc = lc_lds;                      // [2 k-halves][16 rows][ZCLD]: aliases `red`, free between the bulk phase and the next one
+  float* zc = zc_l;                        // [2 k-halves][16 rows][ZCLD] (not in `red`: the waves that do not reduce the bulk
+                                           // partials are already writing here while the others still read them)
   // epilogue threads: (unit block q, row, unit)
   const int eq = tid >> 8, erow = (tid & 255) >> 4, ecol = tid & 15;
   const int eb = rb * RB + erow, eu = (2 * j + eq) * 16 + ecol;
   const bool eok = tid < 512 && erow < RB && eb < B;
   const long ee = (long)eb * U + eu;
+  const unsigned ee4 = (unsigned)(eb * U + eu) * 4u, BU4 = (unsigned)BU * 4u;      // byte offsets inside / between [B][U] slabs
+  const __amdgpu_buffer_rsrc_t cs_rsrc = tnt_rsrc(a.cs, (unsigned)((long)(T + 1) * BU * 4));
+  const __amdgpu_buffer_rsrc_t gt_rsrc = tnt_rsrc(a.gates, (unsigned)((long)T * BU * 16));
+  const __amdgpu_buffer_rsrc_t xz_rsrc = tnt_rsrc(a.xz, (unsigned)((long)T * BU * 16));
+  const __amdgpu_buffer_rsrc_t hd_rsrc = tnt_rsrc(a.hd, a.hd ? (unsigned)((long)T * BU * 4) : 0u);
   float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float cp = 0.f;
   const uint32_t step_l = a.att.step + (a.att.step_dev ? a.att.step_dev[0] : 0u);
@@ -1274,76 +1377,107 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   if (eok) {
     zb_l[tid] = a.zbias ? *reinterpret_cast<const float4*>(a.zbias + (long)eu * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     cp = a.cs[ee];
-    x4 = *reinterpret_cast<const float4*>(a.xz + ee * 4);
-    a.hs[BU + ee] = sentinel;
+    x4 = lc_ld4(xz_rsrc, ee4 * 4u, 0u);
+    lc_st1(hs_rsrc, sentinel, ee4, BU4);
   }
   tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
   LCS(1);
-  for (int i = 0; i < T; ++i) {
+  // Register discipline of this loop.  64 VGPRs hold the resident weights, so everything else a step needs has 64 to live in,
+  // and the compiler's habit of computing every lane-constant index and address ONCE, in front of the loop, and keeping it
+  // for all T steps pushed ~30 of them into scratch -- reloaded on the critical path, a scratch round trip in front of each
+  // hand-off (measured: 2 us in front of the q partial alone).  Each phase therefore derives its indices from an opaque copy of
+  // the thread index (LC_TID: the compiler cannot hoist what depends on it), a handful of integer instructions per phase;
+  // what is wave-uniform (w, the step, slab offsets) is kept scalar.
+#define LC_TID(v) int v = threadIdx.x; asm volatile("" : "+v"(v))
+  for (int i0 = 0; i0 < T; ++i0) {
+    const int i = __builtin_amdgcn_readfirstlane(i0);
     LCT(48);
-    if (eok) {          // x4 = xz[i] (loaded behind the previous step's publish) meets the bias here and leaves the registers
-      const float4 b4 = zb_l[tid];
-      zx_l[tid] = make_float4(x4.x + b4.x, x4.y + b4.y, x4.z + b4.z, x4.w + b4.w);
-    }
-    if (eok && i + 2 <= T) a.hs[(long)(i + 2) * BU + ee] = sentinel;
     bool kout = true;
-    if (eok && a.hd && a.rate_out > 0.f)
-      kout = tnt_keep((uint64_t)ee, a.rate_out, a.att.seed, a.site_out0 + (uint32_t)i, step_l);
+    {
+      LC_TID(t0);
+      const int erow0 = (t0 & 255) >> 4, eb0 = rb * RB + erow0;
+      const bool eok0 = t0 < 512 && erow0 < RB && eb0 < B;
+      const unsigned ee0 = (unsigned)(eb0 * U + (2 * j + (t0 >> 8)) * 16 + (t0 & 15));
+      if (eok0) {       // x4 = xz[i] (loaded behind the previous step's publish) meets the bias here and leaves the registers
+        const float4 b4 = zb_l[t0];
+        zx_l[t0] = make_float4(x4.x + b4.x, x4.y + b4.y, x4.z + b4.z, x4.w + b4.w);
+      }
+      if (eok0 && i + 2 <= T) lc_st1(hs_rsrc, sentinel, ee0 * 4u, (unsigned)(i + 2) * BU4);
+      if (qwave && i + 2 < T) {
+        const int kq0 = (t0 & 63) >> 4, qcol0 = qtile * 16 + (t0 & 15);
+        const unsigned qoff0 = (unsigned)((((rb * RB + kq0 * 4) * 64 + qcol0) * 16 + j) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (qcol0 < A && kq0 * 4 + r < RB && rb * RB + kq0 * 4 + r < B)
+            lc_st1(qw_rsrc, sentinel, qoff0, (unsigned)((((i + 2) % 3) * B + r) * 4096));
+      }
+      if (eok0 && a.hd && a.rate_out > 0.f)
+        kout = tnt_keep((uint64_t)ee0, a.rate_out, a.att.seed, a.site_out0 + (uint32_t)i, step_l);
+    }
     unsigned spins = 0;
     float zs[4] = {0.f, 0.f, 0.f, 0.f};
     if (RB == 8) {
-      // ---- this lane's float4 of h[i]: row rg*4 + j of the block, k = 32 w + 4 cg .. + 3
-      const int xrow = rb * RB + x_rg * 4 + x_j;
-      float4 am = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (;;) {
-        bool ok = true;
-        if (xrow < B) {
-          am = tnt_ld4_l2(hs_rsrc, (unsigned)(((long)i * BU + (long)xrow * U + w * CK + x_cg * 4) * 4));
-          ok = __float_as_uint(am.x) != LC_SENTINEL && __float_as_uint(am.y) != LC_SENTINEL &&
-               __float_as_uint(am.z) != LC_SENTINEL && __float_as_uint(am.w) != LC_SENTINEL;
-        }
-        if (__all(ok)) break;
-        if (++spins > TNT_SEQ_SPIN_LIMIT) {
-          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-      }
-      LCT(49);
-      // ---- h[i] U for both unit blocks (off the critical path: the attention of step i runs meanwhile); the partials of both
-      // blocks go to LDS together -- [block][wave][8 rows][64 + 4 columns] fills `red` exactly -- and meet ONE barrier
       float* rx = &red[0][0][0][0];
+      {
+        // ---- this lane's float4 of h[i]: row rg*4 + j of the block, k = 32 w + 4 cg .. + 3
+        LC_TID(t1);
+        const int l1 = t1 & 63, rg = l1 >> 5, cg = (l1 >> 2) & 7, xj = l1 & 3;
+        const int xrow = rb * RB + rg * 4 + xj;
+        const unsigned hoff = (unsigned)((xrow * U + w * CK + cg * 4) * 4);
+        float4 am = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (;;) {
+          bool ok = true;
+          if (xrow < B) {
+            am = lc_ld4_l2(hs_rsrc, hoff, (unsigned)i * BU4);
+            ok = __float_as_uint(am.x) != LC_SENTINEL && __float_as_uint(am.y) != LC_SENTINEL &&
+                 __float_as_uint(am.z) != LC_SENTINEL && __float_as_uint(am.w) != LC_SENTINEL;
+          }
+          if (__all(ok)) break;
+          if (++spins > TNT_SEQ_SPIN_LIMIT) {
+            if (l1 == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        }
+        LCT(49);
+        // ---- h[i] U for both unit blocks (off the critical path: the attention of step i runs meanwhile); the partials of both
+        // blocks go to LDS together -- [block][wave][8 rows][64 + 4 columns] fills `red` exactly -- and meet ONE barrier
+        float* rw = rx + (w * 8 + rg * 4) * 68 + cg * 4 + xj;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        floatx4 xa[2];
-        xa[0] = (floatx4){0.f, 0.f, 0.f, 0.f}; xa[1] = xa[0];
+        for (int q = 0; q < 2; ++q) {
+          floatx4 xa[2];
+          xa[0] = (floatx4){0.f, 0.f, 0.f, 0.f}; xa[1] = xa[0];
 #define TNT_X4(qd)                                                                                               \
-        xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.x, bx[q][0][qd][0], xa[0], 3, qd, 1);                         \
-        xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.x, bx[q][1][qd][0], xa[1], 3, qd, 1);                         \
-        xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.y, bx[q][0][qd][0], xa[0], 3, qd, 2);                         \
-        xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.y, bx[q][1][qd][0], xa[1], 3, qd, 2);                         \
-        xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.z, bx[q][0][qd][1], xa[0], 3, qd, 1);                         \
-        xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.z, bx[q][1][qd][1], xa[1], 3, qd, 1);                         \
-        xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.w, bx[q][0][qd][1], xa[0], 3, qd, 2);                         \
-        xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.w, bx[q][1][qd][1], xa[1], 3, qd, 2);
-        TNT_X4(0) TNT_X4(1) TNT_X4(2) TNT_X4(3) TNT_X4(4) TNT_X4(5) TNT_X4(6) TNT_X4(7)
+          xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.x, bx[q][0][qd][0], xa[0], 3, qd, 1);                         \
+          xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.x, bx[q][1][qd][0], xa[1], 3, qd, 1);                         \
+          xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.y, bx[q][0][qd][0], xa[0], 3, qd, 2);                         \
+          xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.y, bx[q][1][qd][0], xa[1], 3, qd, 2);                         \
+          xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.z, bx[q][0][qd][1], xa[0], 3, qd, 1);                         \
+          xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.z, bx[q][1][qd][1], xa[1], 3, qd, 1);                         \
+          xa[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.w, bx[q][0][qd][1], xa[0], 3, qd, 2);                         \
+          xa[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(am.w, bx[q][1][qd][1], xa[1], 3, qd, 2);
+          TNT_X4(0) TNT_X4(1) TNT_X4(2) TNT_X4(3) TNT_X4(4) TNT_X4(5) TNT_X4(6) TNT_X4(7)
 #undef TNT_X4
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch)
+          for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            rx[((q * NWF + w) * 8 + x_rg * 4 + r) * 68 + ch * 32 + x_cg * 4 + x_j] = xa[ch][r];
+            for (int r = 0; r < 4; ++r) rw[(q * NWF * 8 + r) * 68 + ch * 32] = xa[ch][r];
+        }
       }
       __syncthreads();
-      if (tid < 512 && erow < 8) {
-        const float* rr = rx + (eq * NWF * 8 + erow) * 68 + ecol * 4;
-        float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+      {
+        LC_TID(t2);
+        const int erow2 = (t2 & 255) >> 4;
+        if (t2 < 512 && erow2 < 8) {
+          const float* rr = rx + ((t2 >> 8) * NWF * 8 + erow2) * 68 + (t2 & 15) * 4;
+          float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < NWF; ++k) {
-          const float4 t = *reinterpret_cast<const float4*>(rr + k * (8 * 68));
-          sacc.x += t.x; sacc.y += t.y; sacc.z += t.z; sacc.w += t.w;
+          for (int k = 0; k < NWF; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(rr + k * (8 * 68));
+            sacc.x += t.x; sacc.y += t.y; sacc.z += t.z; sacc.w += t.w;
+          }
+          zs[0] = sacc.x; zs[1] = sacc.y; zs[2] = sacc.z; zs[3] = sacc.w;
         }
-        zs[0] = sacc.x; zs[1] = sacc.y; zs[2] = sacc.z; zs[3] = sacc.w;
       }
     } else {
     // ---- A fragments = h[i] (this wave's K chunk)
@@ -1397,65 +1531,111 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
       }
     }
     LCT(50);
-    // ---- the attention's context of step i for the 16 samples
-    spins = 0;
-    for (;;) {
-      bool ok = true;
-      for (int e = tid; e < 16 * D; e += WT) {
-        const int r = e / D, d = e - r * D;
-        const float v = (r < RB && rb * RB + r < B) ? lc_ld1_l2(cx_rsrc, (unsigned)((((long)i * B + rb * RB + r) * D + d) * 4)) : 0.f;
-        ctx_l[r * 64 + d] = v;
-        ok = ok && __float_as_uint(v) != LC_SENTINEL;
-      }
-      if (__all(ok)) break;
-      if (++spins > TNT_SEQ_SPIN_LIMIT) {
-        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-    }
-    __syncthreads();
-    LCT(51);
+    // ---- the attention's context of step i.  Polled by as few lanes as cover it (16-byte loads: RB rows x D / 4 chunks --
+    // one wave at the benchmark's size): the rows of a block are a few adjacent cache lines behind ONE L2 channel, and with
+    // every wave of the group's 16 LSTM workgroups polling them the hand-off took 1.4 us instead of 0.5.
     {
-      floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
-      float ca[NQ], cb[NQ];
+      LC_TID(t3);
+      const int l3 = t3 & 63, kq3 = l3 >> 4, lr3 = l3 & 15;
+      float cb[NQ];
 #pragma unroll
-      for (int sq = 0; sq < NQ; ++sq) {         // all operand reads in flight together, then the MFMAs back to back
-        ca[sq] = ctx_l[lr * 64 + (2 * sq + kh) * 4 + kq];
-        cb[sq] = wcb_l[(w * 8 + sq) * 64 + lane];
+      for (int sq = 0; sq < NQ; ++sq) cb[sq] = wcb_l[(w * 8 + sq) * 64 + l3];
+      const int D4 = D >> 2;
+      if (t3 < RB * D4) {                                    // (wave-uniform where RB D / 4 is a multiple of 64; else the tail wave diverges)
+        const int prow_ = t3 / D4, pc_ = t3 - prow_ * D4;
+        const bool pm = rb * RB + prow_ < B;
+        const unsigned coff = (unsigned)((((rb * RB + prow_) * D) + pc_ * 4) * 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        spins = 0;
+        if (pm) for (;;) {
+          v = lc_ld4_l2(cx_rsrc, coff, (unsigned)(i * B * D * 4));
+          const bool ok = __float_as_uint(v.x) != LC_SENTINEL && __float_as_uint(v.y) != LC_SENTINEL &&
+                          __float_as_uint(v.z) != LC_SENTINEL && __float_as_uint(v.w) != LC_SENTINEL;
+          if (ok) break;                                     // per lane: a lane leaves the loop when ITS chunk is in
+          if (++spins > TNT_SEQ_SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        }
+        *reinterpret_cast<float4*>(&ctx_l[prow_ * 64 + pc_ * 4]) = v;
       }
+      __syncthreads();
+      float4 ca[NU];
 #pragma unroll
-      for (int sq = 0; sq < NQ; ++sq) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[sq], cb[sq], acc, 0, 0, 0);
+      for (int u = 0; u < NU; ++u) {
+        const int d0 = DH * kh + 16 * u + 4 * kq3;
+        ca[u] = (lr3 < RB && d0 < D) ? *reinterpret_cast<const float4*>(&ctx_l[lr3 * 64 + d0]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      LCT(51);
+      floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) zc[(kh * 16 + kq * 4 + r) * ZCLD + t8 * 16 + lr] = acc[r];
+      for (int u = 0; u < NU; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[u].x, cb[4 * u + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[u].y, cb[4 * u + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[u].z, cb[4 * u + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[u].w, cb[4 * u + 3], acc, 0, 0, 0);
+      }
+      float* zw = zc + (kh * 16 + kq3 * 4) * ZCLD + t8 * 16 + lr3;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zw[r * ZCLD] = acc[r];
     }
     LCT(53);
     __syncthreads();
     LCT(54);
-    if (eok) {
-      const float4 zx = zx_l[tid];
-      float z[4] = {zx.x + zs[0], zx.y + zs[1], zx.z + zs[2], zx.w + zs[3]};
-      const float4 c0 = *reinterpret_cast<const float4*>(zc + erow * ZCLD + (eq * 16 + ecol) * 4);
-      const float4 c1 = *reinterpret_cast<const float4*>(zc + (16 + erow) * ZCLD + (eq * 16 + ecol) * 4);
-      z[0] += c0.x + c1.x; z[1] += c0.y + c1.y; z[2] += c0.z + c1.z; z[3] += c0.w + c1.w;
-      const float gi = tnt_sigmoid_fast(z[0]), gf = tnt_sigmoid_fast(z[1]), gg = tnt_tanh(z[2]), go = tnt_sigmoid_fast(z[3]);
-      const float c2 = gf * cp + gi * gg;
-      const float h2 = go * tnt_tanh(c2);
-      LCT(55);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's reset of hs[i+2] is in L2 first
-      a.hs[(long)(i + 1) * BU + ee] = h2;
-      a.cs[(long)(i + 1) * BU + ee] = c2;
-      *reinterpret_cast<float4*>(a.gates + ((long)i * BU + ee) * 4) = make_float4(gi, gf, gg, go);
-      if (a.hd) a.hd[(long)i * BU + ee] = kout ? h2 * oscale : 0.f;
-      cp = c2;
-      if (i + 1 < T) x4 = *reinterpret_cast<const float4*>(a.xz + ((long)(i + 1) * BU + ee) * 4);
+    {
+      LC_TID(t4);
+      const int erow4 = (t4 & 255) >> 4, ecol4 = t4 & 15, eq4 = t4 >> 8, eb4 = rb * RB + erow4;
+      if (t4 < 512 && erow4 < RB && eb4 < B) {
+        const unsigned ee4_ = (unsigned)(eb4 * U + (2 * j + eq4) * 16 + ecol4) * 4u;
+        const float4 zx = zx_l[t4];
+        float z[4] = {zx.x + zs[0], zx.y + zs[1], zx.z + zs[2], zx.w + zs[3]};
+        const float4 c0 = *reinterpret_cast<const float4*>(zc + erow4 * ZCLD + (eq4 * 16 + ecol4) * 4);
+        const float4 c1 = *reinterpret_cast<const float4*>(zc + (16 + erow4) * ZCLD + (eq4 * 16 + ecol4) * 4);
+        z[0] += c0.x + c1.x; z[1] += c0.y + c1.y; z[2] += c0.z + c1.z; z[3] += c0.w + c1.w;
+        const float gi = tnt_sigmoid_fast(z[0]), gf = tnt_sigmoid_fast(z[1]), gg = tnt_tanh(z[2]), go = tnt_sigmoid_fast(z[3]);
+        const float c2 = gf * cp + gi * gg;
+        const float h2 = go * tnt_tanh(c2);
+        LCT(55);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's reset of hs[i+2] is in L2 first
+        lc_st1(hs_rsrc, h2, ee4_, (unsigned)(i + 1) * BU4);
+        hq_l[erow4 * 36 + eq4 * 16 + ecol4] = h2;
+        lc_st1(cs_rsrc, c2, ee4_, (unsigned)(i + 1) * BU4);
+        lc_st4(gt_rsrc, make_float4(gi, gf, gg, go), ee4_ * 4u, (unsigned)i * BU4 * 4u);
+        if (a.hd) lc_st1(hd_rsrc, kout ? h2 * oscale : 0.f, ee4_, (unsigned)i * BU4);
+        cp = c2;
+        if (i + 1 < T) x4 = lc_ld4(xz_rsrc, ee4_ * 4u, (unsigned)(i + 1) * BU4 * 4u);
+      }
     }
     LCT(52);
     if (i < 36) LCS(2 + i);
-    // `red` and ctx_l are rewritten next step only behind barriers that every thread passes after this point
+    // `red` is rewritten next step only behind barriers that every thread passes after this point
     __syncthreads();
+    // ---- this workgroup's partial of q for the attention of step i + 1 (the reset of the slot behind it is long drained)
+    LCT_T(56, 512);
+    if (qwave && i + 1 < T) {
+      LC_TID(t5);
+      const int l5 = t5 & 63, kq5 = l5 >> 4, lr5 = l5 & 15, qcol5 = qtile * 16 + lr5;
+      const float* qa_p = hq_l + lr5 * 36 + kq5;
+      const float* qb_p = w2s_l + kq5 * 64 + qcol5;
+      floatx4 t = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float qa_[4], qb_[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) { qa_[s2] = qa_p[16 * h + 4 * s2]; qb_[s2] = qb_p[(16 * h + 4 * s2) * 64]; }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) t = __builtin_amdgcn_mfma_f32_16x16x4f32(qa_[s2], qb_[s2], t, 0, 0, 0);
+      }
+      LCT_T(57, 512);
+      const unsigned qoff5 = (unsigned)((((rb * RB + kq5 * 4) * 64 + qcol5) * 16 + j) * 4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (qcol5 < A && kq5 * 4 + r < RB && rb * RB + kq5 * 4 + r < B)
+          lc_st1(qw_rsrc, t[r], qoff5, (unsigned)((((i + 1) % 3) * B + r) * 4096));
+      LCT_T(58, 512);
+    }
   }
-  if (ub == 16) LCT_DUMP(48, 56);
+#undef LC_TID
+  if (ub == 16) LCT_DUMP(48, 60);
   LCS(38); LCS(39);
   if (ub == 16) LCS_DUMP(1);
   tnt_seq_leave(a.sync, xcc, a.guard_out);
@@ -1469,13 +1649,13 @@ extern "C" int32_t tnt_lc_seq_fwd_drop_f32(const float* F, const float* P, const
                                       int32_t B, int32_t R, int32_t D, int32_t A, int32_t U, float slope, float rate_attn,
                                       float rate_in, int32_t in_lwidth, uint64_t seed, uint32_t site_attn0,
                                       uint32_t site_in0, const uint32_t* step_dev, float* hd, float rate_out,
-                                      uint32_t site_out0, uint32_t* sync, float* guard_out, void* stream) {
-  if (T <= 0 || sync == nullptr || U != 512 || B <= 0 || B > 128) return TNT_BADARG(24);
+                                      uint32_t site_out0, float* work, uint32_t* sync, float* guard_out, void* stream) {
+  if (T <= 0 || sync == nullptr || work == nullptr || U != 512 || B <= 0 || B > 128) return TNT_BADARG(24);
   if (hd && !(rate_out >= 0.f && rate_out < 1.f)) return TNT_BADARG(36);
   if (!wide_ok(R, D, A) || R > 512 || D > 64 || A > 64) return TNT_BADARG(21);
-  if ((long)(T + 1) * B * U * 4 >= (1L << 32)) return TNT_BADARG(19);
+  if ((long)(T + 1) * B * U * 16 >= (1L << 32)) return TNT_BADARG(19);
   if (!tnt_aligned16(P) || !tnt_aligned16(F) || !tnt_aligned16(W2) || !tnt_aligned16(v) || !tnt_aligned16(xz) ||
-      !tnt_aligned16(Wc) || !tnt_aligned16(Ur) || !tnt_aligned16(gates)) return TNT_BADARG(1);
+      !tnt_aligned16(Wc) || !tnt_aligned16(Ur) || !tnt_aligned16(gates) || !tnt_aligned16(ctx_d)) return TNT_BADARG(1);
   LcSeqArgs a{};
   AttArgs& g = a.att;
   g.F = F; g.P = P; g.W2 = W2; g.b2 = b2; g.v = v; g.bv = bv; g.qpre = qpre; g.alpha = alpha; g.ctx = ctx; g.ctx_d = ctx_d;
@@ -1484,6 +1664,7 @@ extern "C" int32_t tnt_lc_seq_fwd_drop_f32(const float* F, const float* P, const
   g.step_dev = step_dev; g.keep4 = keep4;
   a.keep_stride = keep_stride; a.xz = xz; a.Wc = Wc; a.Ur = Ur; a.zbias = xz_bias; a.hs = hs; a.cs = cs; a.gates = gates;
   a.T = T; a.sync = sync; a.guard_out = guard_out; a.hd = hd; a.rate_out = hd ? rate_out : 0.f; a.site_out0 = site_out0;
+  a.qp = work;
   // row passes of the attention phase held in registers: as few as R needs (the LSTM weights are resident next to them)
   const int g4 = (A <= 32 && D <= 32) ? 8 : 16, np = (R + WT / g4 - 1) / (WT / g4);
   void (*kern)(LcSeqArgs) = nullptr;
@@ -1509,12 +1690,14 @@ extern "C" int32_t tnt_lc_seq_fwd_f32(const float* F, const float* P, const floa
                                       const float* Ur, const float* xz_bias, float* hs, float* cs, float* gates, int32_t T,
                                       int32_t B, int32_t R, int32_t D, int32_t A, int32_t U, float slope, float rate_attn,
                                       float rate_in, int32_t in_lwidth, uint64_t seed, uint32_t site_attn0,
-                                      uint32_t site_in0, const uint32_t* step_dev, uint32_t* sync, float* guard_out,
-                                      void* stream) {
+                                      uint32_t site_in0, const uint32_t* step_dev, float* work, uint32_t* sync,
+                                      float* guard_out, void* stream) {
   return tnt_lc_seq_fwd_drop_f32(F, P, W2, b2, v, bv, qpre, alpha, ctx, ctx_d, keep4, keep_stride, xz, Wc, Ur, xz_bias, hs, cs,
                                  gates, T, B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, seed, site_attn0, site_in0,
-                                 step_dev, nullptr, 0.f, 0, sync, guard_out, stream);
+                                 step_dev, nullptr, 0.f, 0, work, sync, guard_out, stream);
 }
+
+extern "C" int32_t tnt_lc_seq_fwd_work_floats(int32_t B) { return B > 0 && B <= 128 ? 3 * B * 1024 : 0; }
 
 // ---------------------------------------------------------------------------------------------------
 // The backward chain of the attention captioner (tape.gradient through lc_NIC.py:244-256: for i = T-1 .. 0 the LSTM step

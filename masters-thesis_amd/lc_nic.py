@@ -352,6 +352,8 @@ class NIC(ModelBase):
         self.lc_xch = None                # exchange space of the persistent backward chain
         if self.__dict__.get("_seq_lstm") and hasattr(self.be, "lc_seq_bwd") and B <= 128:
             self.lc_xch = f(self.be.lc_seq_bwd_work_floats(B, U))
+        if self.__dict__.get("_seq_lstm") and hasattr(self.be, "lc_seq_fwd") and B <= 128:
+            self.lc_fwd_work = f(self.be.lc_seq_fwd_work_floats(B))
         self.colB = f(2 * B)
         # backward
         self.dinter, self.dHs = f(n, H), f(n, U)
@@ -536,7 +538,7 @@ class NIC(ModelBase):
                           B * R * A // 4 if keep is not None else 0, self.XZ, Wl[:D], a.p("lstm/recurrent_kernel"),
                           a.p("lstm/bias"), self.Hs, self.Cs, self.gates, T, B, R, D, A, U, 0.2,
                           self.r_attn if training else 0.0, r_in, D + Et, self.seed, S_ATTN, S_LSTM_IN, self.drop_step,
-                          self.seq_sync, self._guard_out(),
+                          self.lc_fwd_work, self.seq_sync, self._guard_out(),
                           out_drop=(self.Hd, self.r_lstm, S_LSTM_OUT) if self._out_dropped else None)
         else:
             self._out_dropped = False

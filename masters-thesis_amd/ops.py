@@ -381,21 +381,25 @@ class HipBackend:
         self._call(self.lib.tnt_dense_dw_skinny_f32, "tnt_dense_dw_skinny_f32", _p(x), _p(dpre), _p(dw), N, E, Bk, ldx, self._s())
 
     def lc_seq_fwd(self, F, P, W2, b2, v, bv, qpre, alpha, ctx, ctx_d, keep4, keep_stride, xz, Wc, Ur, xz_bias, hs, cs, gates, T,
-                   B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, seed, site_attn0, site_in0, step_dev, sync,
+                   B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, seed, site_attn0, site_in0, step_dev, work, sync,
                    guard_out=None, out_drop=None):
-        """out_drop = (hd, rate, site0): the Dropout behind the LSTM rides in the chain (tnt_lc_seq_fwd_drop_f32)."""
+        """out_drop = (hd, rate, site0): the Dropout behind the LSTM rides in the chain (tnt_lc_seq_fwd_drop_f32);
+        work: lc_seq_fwd_work_floats(B) floats"""
         if out_drop is not None:
             hd, rate_out, site_out0 = out_drop
             self._call(self.lib.tnt_lc_seq_fwd_drop_f32, "tnt_lc_seq_fwd_drop_f32", _p(F), _p(P), _p(W2), _p(b2), _p(v), _p(bv),
                        _p(qpre), _p(alpha), _p(ctx), _p(ctx_d), _p(keep4), int(keep_stride), _p(xz), _p(Wc), _p(Ur), _p(xz_bias),
                        _p(hs), _p(cs), _p(gates), T, B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, int(seed),
-                       int(site_attn0), int(site_in0), _p(step_dev), _p(hd), float(rate_out), int(site_out0), _p(sync),
+                       int(site_attn0), int(site_in0), _p(step_dev), _p(hd), float(rate_out), int(site_out0), _p(work), _p(sync),
                        _p(guard_out), self._s())
             return
         self._call(self.lib.tnt_lc_seq_fwd_f32, "tnt_lc_seq_fwd_f32", _p(F), _p(P), _p(W2), _p(b2), _p(v), _p(bv), _p(qpre), _p(alpha),
                    _p(ctx), _p(ctx_d), _p(keep4), int(keep_stride), _p(xz), _p(Wc), _p(Ur), _p(xz_bias), _p(hs), _p(cs), _p(gates),
                    T, B, R, D, A, U, slope, rate_attn, rate_in, in_lwidth, int(seed), int(site_attn0), int(site_in0),
-                   _p(step_dev), _p(sync), _p(guard_out), self._s())
+                   _p(step_dev), _p(work), _p(sync), _p(guard_out), self._s())
+
+    def lc_seq_fwd_work_floats(self, B):
+        return int(self.lib.tnt_lc_seq_fwd_work_floats(int(B)))
 
     def lc_seq_bwd_work_floats(self, B, U):
         return int(self.lib.tnt_lc_seq_bwd_work_floats(int(B), int(U)))

@@ -38,7 +38,7 @@ def test_header_is_plain_c_abi():
     assert len(d) >= 35
     for name, params in d.items():
         if params:
-            assert params[-1] == "void*" or name in ("tnt_bn_nchunk", "tnt_lstm_seq_supported", "tnt_lstm_seq_bwd_work_floats", "tnt_gemm_fused_cfg", "tnt_embedding_bwd_parts", "tnt_attention_front_bwd_parts", "tnt_attention_metric_parts", "tnt_lc_seq_bwd_work_floats", "tnt_gemm3_work_floats", "tnt_gemm3_sync_words", "tnt_gemm3_plan", "tnt_gemm3_pair_supported"), (name, params[-1])    # trailing stream argument
+            assert params[-1] == "void*" or name in ("tnt_bn_nchunk", "tnt_lstm_seq_supported", "tnt_lstm_seq_bwd_work_floats", "tnt_gemm_fused_cfg", "tnt_embedding_bwd_parts", "tnt_attention_front_bwd_parts", "tnt_attention_metric_parts", "tnt_lc_seq_bwd_work_floats", "tnt_lc_seq_fwd_work_floats", "tnt_gemm3_work_floats", "tnt_gemm3_sync_words", "tnt_gemm3_plan", "tnt_gemm3_pair_supported"), (name, params[-1])    # trailing stream argument
 
 
 def test_library_exports_and_binding_match_the_header():

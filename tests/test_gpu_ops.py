@@ -1311,11 +1311,12 @@ def test_lc_seq_fwd_equals_step_kernels(be, T, B, R, D, A, r_attn, r_in):
                          ref["cs"][i + 1], None, ref["gates"][i], B, U, xz_bias=zb)
     sync, guard = torch.zeros(1025, dtype=torch.int32, device="cuda"), torch.zeros(1, device="cuda")
     hd, hd_ref = torch.full((T, B, U), float("nan"), device="cuda"), torch.zeros(T, B, U, device="cuda")
+    fwork = torch.full((be.lc_seq_fwd_work_floats(B),), 7.0, device="cuda")        # exchange space: contents irrelevant
     for rep in range(2):                             # the second launch starts from the state the first one left
         # (the second one with the output Dropout riding along: tnt_lc_seq_fwd_drop_f32, one site per step from 77)
         be.lc_seq_fwd(F, P, W2, b2, v, bv, got["qpre"], got["alpha"], got["ctx"], got["ctx_d"], keep,
                       B * R * A // 4 if keep is not None else 0, xz, Wc, Ur, zb, got["hs"], got["cs"], got["gates"], T, B, R, D,
-                      A, U, 0.2, r_attn, r_in, lw, seed, s_att, s_in, step_dev, sync, guard,
+                      A, U, 0.2, r_attn, r_in, lw, seed, s_att, s_in, step_dev, fwork, sync, guard,
                       out_drop=(hd, 0.3, 77) if rep else None)
         torch.cuda.synchronize()
         assert int(sync[1024]) == 0 and float(guard) == 0.0
