@@ -978,12 +978,17 @@ constexpr int LC_SEQ_LDS_BYTES = 16 * 4 * 16 * 17 * 4 + 16;
 // registers; with 64-bit pointers per output array the compiler spilled address registers to scratch and reloaded them on the
 // step's critical path (a scratch round trip in front of every hand-off store: measured 2 us).
 typedef unsigned lc_u4 __attribute__((ext_vector_type(4)));
+// a wave-uniform float computed by the vector ALU (a reciprocal of a kernel argument): parked in an SGPR instead of a VGPR
+__device__ __forceinline__ float lc_uniform(float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); }
 __device__ __forceinline__ void lc_st1(__amdgpu_buffer_rsrc_t rsrc, float v, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, (int)voff, (int)soff, 0);
 }
 __device__ __forceinline__ void lc_st4(__amdgpu_buffer_rsrc_t rsrc, float4 v, unsigned voff, unsigned soff) {
   const lc_u4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
   __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ float lc_ld1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
 }
 __device__ __forceinline__ float4 lc_ld4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   const tnt_f4 v = __builtin_bit_cast(tnt_f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
@@ -1098,7 +1103,8 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
     float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float b2v = 0.f, bvv = 0.f, mb = 0.f;
     bool direct = false, bounded = true;
-    const float scale_a = 1.f / (1.f - g.rate_attn);
+    const float scale_a = lc_uniform(1.f / (1.f - g.rate_attn));
+    const float scale_in = lc_uniform(g.rate_in > 0.f ? 1.f / (1.f - g.rate_in) : 1.f);
     if (live) {
       bool big = false;
 #pragma unroll
@@ -1245,7 +1251,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
 #pragma unroll
         for (int k = 0; k < WW; ++k) t += wred_l[k][tid];
         t *= invz;
-        const float td = g.rate_in > 0.f ? (kin ? t * (1.f / (1.f - g.rate_in)) : 0.f) : t;
+        const float td = g.rate_in > 0.f ? (kin ? t * scale_in : 0.f) : t;
         // the reset of ctx_d[i+1] (issued at the top of the step, long drained) is in L2 before ctx_d[i] is published;
         // this thread's other stores of the step (qpre) are as old
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1373,7 +1379,7 @@ __global__ __launch_bounds__(1024) void lc_seq_fwd_kernel(LcSeqArgs a) {
   float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float cp = 0.f;
   const uint32_t step_l = a.att.step + (a.att.step_dev ? a.att.step_dev[0] : 0u);
-  const float oscale = a.rate_out > 0.f ? 1.f / (1.f - a.rate_out) : 1.f;
+  const float oscale = lc_uniform(a.rate_out > 0.f ? 1.f / (1.f - a.rate_out) : 1.f);
   if (eok) {
     zb_l[tid] = a.zbias ? *reinterpret_cast<const float4*>(a.zbias + (long)eu * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     cp = a.cs[ee];
@@ -1739,7 +1745,7 @@ struct LcSeqBwdArgs {
 constexpr int LB_DZLD = 68;
 constexpr int LB_RED_FLOATS = 16 * 4 * 16 * 17;                  // gather sums [2][16][256] / context-part tiles [16 waves][4][16][17]
 constexpr int LB_LDS_FLOATS = 2 * 16 * LB_DZLD + LB_RED_FLOATS;  // LSTM role: dz tiles, reduction buffer
-constexpr int LB_W2LD = 65;                                      // row stride of the LSTM role's W2 slice [32][A <= 64]
+constexpr int LB_W2LD = 68;                                      // row stride of the LSTM role's W2 slice [32][64] (16-byte rows, conflict-free b128 reads)
 constexpr int LB_LSTM_FLOATS = LB_LDS_FLOATS + 32 * LB_W2LD + 16 * 64 + 16 * 2 * 4 * 64;   // + W2 slice + the 16 samples' dq + Wc operands
 constexpr int LB_PF_FLOATS = 35 * 1024;                          // attention role: P, F rows and the dF accumulator of the sample, R (A + 2 D) <= this
 constexpr int LB_LDS_BYTES = (LB_LSTM_FLOATS > LB_PF_FLOATS ? LB_LSTM_FLOATS : LB_PF_FLOATS) * 4 + 16;
@@ -1749,13 +1755,13 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   constexpr int RPP = WT / G4, NTW = 2, NWB = 16;
   extern __shared__ __attribute__((aligned(16))) float lb_lds[];
   unsigned* s_slot = reinterpret_cast<unsigned*>(lb_lds + (LB_LDS_BYTES - 16) / 4);
-  __shared__ float als[512], das[512];
   __shared__ __attribute__((aligned(16))) float wred[WW][64], wred2[WW][64];
-  __shared__ __attribute__((aligned(16))) float qs[64], dcs[64], dq_s[64];
-  __shared__ float red_l[WW], dv_acc[64], scr[16 * 64];
+  __shared__ __attribute__((aligned(16))) float qs[64], qe[64], dcs[4 * 64];
+  __shared__ __attribute__((aligned(16))) float red_l[WW];
+  __shared__ int qbig_l;
   LCT_DECL
   LCS_DECL
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, lr = lane & 15;
   const AttArgs& g = a.att;
   const int U = g.U, B = g.B, D = g.D, R = g.R, A = g.A, T = a.T;
@@ -1787,163 +1793,212 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
 
   if (ub < 16) {
     // =========================================================== attention role: sample ab
-    // the sample's P [R][A] and F [R][D] rows: in LDS for all T steps (the accumulators dP / dF take the registers)
-    float* p_l = lb_lds;
-    float* f_l = lb_lds + R * A;
+    // Everything of the sample that outlives a step stays in registers for all T steps: e^{2P} (tanh(P + q) is recomputed as
+    // 1 - 2 / (e^{2P} e^{2q} + 1), one transcendental per element; P itself where that could lose accuracy, as in the forward
+    // chain), F, and the accumulators dP, dF, dv, dbv -- 48 + 5 registers; the reductions of dv and dbv happen ONCE, behind the
+    // loop.  A step has three workgroup barriers: behind the context gradient (the 16 parts of the LSTM workgroups, summed by 4 D
+    // lanes with 16-byte polls), behind sum_r alpha_r dalpha_r (one value per wave), behind the per-wave sums of dq.  The dF
+    // update and the stores of the step sit behind the publish of dq.
     const int ab = rb * RB + ub;
     const bool live = ub < RB && ab < B;
     const int c4 = tid % G4, rl = tid / G4;
     const bool cokA = c4 * 4 < A, cokD = c4 * 4 < D;
-    float* df_l = f_l + R * D;          // the dF accumulator [R][D] (LDS: 12 more resident VGPRs per lane would spill)
-    float4 dpa[NP];
-    float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pv[NP], fv[NP], dpa[NP], dfa[NP];
+    float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f), dva = make_float4(0.f, 0.f, 0.f, 0.f);
     float dbv_acc = 0.f;
+    bool direct = false;
+    const float scale_a = lc_uniform(g.rate_attn > 0.f ? 1.f / (1.f - g.rate_attn) : 1.f);
+    const float scale_in = lc_uniform(g.rate_in > 0.f ? 1.f / (1.f - g.rate_in) : 1.f);
     if (live) {
-      for (int e = tid; e < R * A / 4; e += WT)
-        reinterpret_cast<float4*>(p_l)[e] = reinterpret_cast<const float4*>(g.P + (long)ab * R * A)[e];
-      for (int e = tid; e < R * D / 4; e += WT)
-        reinterpret_cast<float4*>(f_l)[e] = reinterpret_cast<const float4*>(g.F + (long)ab * R * D)[e];
+      bool big = false;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        dpa[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int r = p * RPP + rl;
+        pv[p] = (cokA && r < R) ? *reinterpret_cast<const float4*>(g.P + ((long)ab * R + r) * A + c4 * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        fv[p] = (cokD && r < R) ? *reinterpret_cast<const float4*>(g.F + ((long)ab * R + r) * D + c4 * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        dpa[p] = make_float4(0.f, 0.f, 0.f, 0.f); dfa[p] = dpa[p];
+        big = big || !(fabsf(pv[p].x) <= 40.f && fabsf(pv[p].y) <= 40.f && fabsf(pv[p].z) <= 40.f && fabsf(pv[p].w) <= 40.f);
       }
-      for (int e = tid; e < R * D / 4; e += WT) reinterpret_cast<float4*>(df_l)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (cokA) v4 = *reinterpret_cast<const float4*>(g.v + c4 * 4);
-      if (tid < 64) dv_acc[tid] = 0.f;
       if (tid < A) a.dhx[(long)ab * 64 + tid] = sentinel;         // this thread's element of the dq hand-off: buffer 0 armed
+      if (tid == 0) qbig_l = -1;
+      direct = __syncthreads_or(big ? 1 : 0) != 0;
+      if (!direct) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          pv[p].x = __expf(2.f * pv[p].x); pv[p].y = __expf(2.f * pv[p].y);
+          pv[p].z = __expf(2.f * pv[p].z); pv[p].w = __expf(2.f * pv[p].w);
+        }
+      }
     }
     tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
     LCS(1);
     const uint32_t step = g.step + (g.step_dev ? g.step_dev[0] : 0u);
     const bool stored = g.keep4 != nullptr && g.rate_attn > 0.f;
-    const float scale_a = g.rate_attn > 0.f ? 1.f / (1.f - g.rate_attn) : 1.f;
-    if (live) for (int i = T - 1; i >= 0; --i) {
+    // per-step operands through buffer resources: one 32-bit lane offset each, the step's slab as a scalar offset
+    const __amdgpu_buffer_rsrc_t al_rsrc = tnt_rsrc(g.alpha_in, (unsigned)((long)T * B * R * 4));
+    const __amdgpu_buffer_rsrc_t kp_rsrc = tnt_rsrc(g.keep4, stored ? (unsigned)((long)T * a.keep_stride) : 0u);
+    const __amdgpu_buffer_rsrc_t qi_rsrc = tnt_rsrc(g.qpre_in, (unsigned)((long)T * B * A * 4));
+    const __amdgpu_buffer_rsrc_t qo_rsrc = tnt_rsrc(g.dqpre, (unsigned)((long)T * B * A * 4));
+    const unsigned al_off = (unsigned)((ab * R + rl) * 4), kp_off = (unsigned)((ab * R + rl) * (A >> 2) + c4);
+    if (live) for (int i0 = T - 1; i0 >= 0; --i0) {
+      const int i = __builtin_amdgcn_readfirstlane(i0);
       const int pi = (T - 1 - i) % 3, pn = (pi + 1) % 3;
       const uint32_t site_attn = g.site_attn + (uint32_t)i, site_in = g.site_in + (uint32_t)i;
-      if (tid < A && i > 0) a.dhx[((long)pn * B + ab) * 64 + tid] = sentinel;
+      if (tid < A && i > 0) lc_st1(dq_rsrc, sentinel, (unsigned)((ab * 64 + tid) * 4), (unsigned)(pn * B * 256));
       LCT(0);
-      bool kin = true;          // input-dropout decision of the context gradient (a Philox call): off the critical path
-      if (tid < D && g.rate_in > 0.f) kin = tnt_keep((uint64_t)ab * (uint64_t)g.in_lwidth + tid, g.rate_in, g.seed, site_in, step);
       // ---- operands of this step that do not depend on the chain
-      for (int r = tid; r < R; r += WT) als[r] = g.alpha_in[((long)i * B + ab) * R + r];
-      float qp = 0.f;
-      if (tid < A) qp = g.qpre_in[((long)i * B + ab) * A + tid];
-      if (tid < 64) qs[tid] = tid < A ? (qp > 0.f ? qp : qp * g.slope) : 0.f;
+      // the context gradient arrives as 16 parts [part][row][d]: thread G4 part + c polls the float4 (part, d = 4 c .. 4 c + 3);
+      // the lanes of a wave that share c are summed by shuffles, lane c < G4 of each polling wave applies the input-dropout
+      // decisions of its 4 elements (Philox calls, taken here) and files the wave's sum
+      constexpr int NWP = 16 * G4 / 64;                      // polling waves
+      const int ppart = tid / G4;                            // (c = c4)
+      const bool pmine = tid < 16 * G4 && cokD;
+      float al[NP];
       uint32_t mk[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int r = p * RPP + rl;
-        mk[p] = (stored && cokA && r < R) ? g.keep4[(long)i * a.keep_stride + ((((long)ab * R + r) * A + c4 * 4) >> 2)] : 0u;
+        al[p] = r < R ? lc_ld1(al_rsrc, al_off + (unsigned)(p * RPP * 4), (unsigned)(i * B * R * 4)) : 0.f;
+        mk[p] = (stored && cokA && r < R) ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(kp_rsrc, (int)(kp_off + (unsigned)(p * RPP * (A >> 2))),
+                                                                                            (int)((long)i * a.keep_stride), 0) : 0xFu;
       }
-      // ---- the 16 context-gradient parts of this sample (thread = (part, d))
-      {
-        float v = 0.f;
-        unsigned spins = 0;
-        const bool mine = tid < 16 * D;
-        const unsigned off = (unsigned)(((((pi * nrb + rb) * 16 + tid / D) * 16 + ub) * 64 + tid % D) * 4);
-        for (;;) {
-          if (mine) v = lc_ld1_l2(pt_rsrc, off);
-          if (__all(!mine || __float_as_uint(v) != LC_SENTINEL)) break;
-          if (poll_fail(spins)) break;
-        }
-        if (mine) scr[tid] = v;
-      }
-      LCT(1);
-      __syncthreads();
-      if (tid < 64) {
-        float dc = 0.f;
-        if (tid < D) {
+      float qp = 0.f;
+      if (tid < A) qp = lc_ld1(qi_rsrc, (unsigned)((ab * A + tid) * 4), (unsigned)(i * B * A * 4));
+      // (the loads above are in flight -- HBM latency -- while the Philox calls run; the memory counter is in-order, so a poll
+      // issued behind loads that are still out would wait for them however early the hand-off lands)
+      bool kin[4] = {true, true, true, true};
+      if (pmine && lane < G4 && g.rate_in > 0.f) {
+        const uint64_t e0 = (uint64_t)ab * (uint64_t)g.in_lwidth + c4 * 4;
+        if ((e0 & 3u) == 0u) tnt_keep4(e0, g.rate_in, g.seed, site_in, step, kin);
+        else {
 #pragma unroll
-          for (int p = 0; p < 16; ++p) dc += scr[p * D + tid];
-          if (g.rate_in > 0.f) dc = kin ? dc * (1.f / (1.f - g.rate_in)) : 0.f;
+          for (int e = 0; e < 4; ++e) kin[e] = tnt_keep(e0 + e, g.rate_in, g.seed, site_in, step);
         }
-        dcs[tid] = dc;
+      }
+      if (tid < A) {
+        const float q = qp > 0.f ? qp : qp * g.slope;
+        qs[tid] = q; qe[tid] = __expf(2.f * q);
+        if (!(fabsf(q) <= 40.f)) qbig_l = i;
+      }
+      // ---- the 16 context-gradient parts of this sample
+      if (tid < 16 * G4) {                                   // whole waves
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned spins = 0;
+        const unsigned off = (unsigned)((((((pi * nrb + rb) * 16 + ppart) * 16 + ub) * 64) + c4 * 4) * 4);
+        LCT(7);
+        if (pmine) for (;;) {
+          v = tnt_ld4_l2(pt_rsrc, off);
+          const bool ok = __float_as_uint(v.x) != LC_SENTINEL && __float_as_uint(v.y) != LC_SENTINEL &&
+                          __float_as_uint(v.z) != LC_SENTINEL && __float_as_uint(v.w) != LC_SENTINEL;
+          if (ok) break;                                     // per lane: a lane leaves the loop when ITS chunk is in
+          if (++spins > TNT_SEQ_SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        }
+        LCT(1);
+#ifdef TNT_LC_TRACE
+        if (tid == 0 && rb == 0 && i == LCT_STEP) lct_l[8] = spins;
+#endif
+        v.x = stride_sum<G4>(v.x); v.y = stride_sum<G4>(v.y); v.z = stride_sum<G4>(v.z); v.w = stride_sum<G4>(v.w);
+        if (lane < G4 && cokD) {
+          if (g.rate_in > 0.f) {
+            v.x = kin[0] ? v.x * scale_in : 0.f; v.y = kin[1] ? v.y * scale_in : 0.f;
+            v.z = kin[2] ? v.z * scale_in : 0.f; v.w = kin[3] ? v.w * scale_in : 0.f;
+          }
+          *reinterpret_cast<float4*>(&dcs[w * 64 + c4 * 4]) = v;
+        }
       }
       __syncthreads();
       LCT(2);
-      // ---- dalpha[r] = dctx . F[r];  dF[r] += alpha[r] dctx   (accumulator in registers)
-      {
-        const float4 dc4 = cokD ? *reinterpret_cast<const float4*>(&dcs[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // ---- dalpha[r] = dctx . F[r] (+ the alpha term of the SAM loss), and the softmax' dot product
+      float4 dc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cokD) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const int r = p * RPP + rl;
-          float t = 0.f;
-          if (cokD && r < R) {
-            const float4 fv = *reinterpret_cast<const float4*>(f_l + r * D + c4 * 4);
-            t = dc4.x * fv.x + dc4.y * fv.y + dc4.z * fv.z + dc4.w * fv.w;
-            const float al = als[r];
-            float4* dfp = reinterpret_cast<float4*>(df_l + r * D + c4 * 4);       // this thread's own element, every step
-            float4 dfv = *dfp;
-            dfv.x += al * dc4.x; dfv.y += al * dc4.y; dfv.z += al * dc4.z; dfv.w += al * dc4.w;
-            *dfp = dfv;
-          }
-          t = adj_sum<G4>(t);
-          if (c4 == 0 && r < R) das[r] = t + g.alpha_mse * (als[r] - 1.f);
+        for (int k = 0; k < NWP; ++k) {
+          const float4 t = *reinterpret_cast<const float4*>(&dcs[k * 64 + c4 * 4]);
+          dc4.x += t.x; dc4.y += t.y; dc4.z += t.z; dc4.w += t.w;
         }
-        __syncthreads();
       }
-      LCT(3);
+      float da[NP];
       float dot = 0.f;
-      for (int r = tid; r < R; r += WT) dot += als[r] * das[r];
-      dot = block_sum_w(dot, red_l);
-      float dbv = 0.f;
-      for (int r = tid; r < R; r += WT) { const float de = als[r] * (das[r] - dot); als[r] = de; dbv += de; }
-      dbv = block_sum_w(dbv, red_l);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const float t = dc4.x * fv[p].x + dc4.y * fv[p].y + dc4.z * fv[p].z + dc4.w * fv[p].w;
+        da[p] = adj_sum<G4>(t) + g.alpha_mse * (al[p] - 1.f);           // rows past R: al = 0, nothing of them is used
+        dot += al[p] * da[p];
+      }
+      dot = tnt_wave_sum(dot) * (1.f / G4);                  // every row sits in G4 lanes: exact scaling
+      if (lane == 0) red_l[w] = dot;
+      __syncthreads();
+      LCT(3);
+      {
+        const float4* rr = reinterpret_cast<const float4*>(red_l);
+        dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < WW / 4; ++k) { const float4 t = rr[k]; dot += (t.x + t.y) + (t.z + t.w); }
+      }
       LCT(4);
       // ---- through e = s_d . v, dropout, tanh
-      float dqp = 0.f;
+      float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
       {
-        const float4 q4 = cokA ? *reinterpret_cast<const float4*>(&qs[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), dq = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool fast = !direct && qbig_l != i;
+        const float4 q4 = cokA ? *reinterpret_cast<const float4*>(fast ? &qe[c4 * 4] : &qs[c4 * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
           const int r = p * RPP + rl;
           if (!(cokA && r < R)) continue;
           const long e = ((long)ab * R + r) * A + c4 * 4;
-          const float4 pv = *reinterpret_cast<const float4*>(p_l + r * A + c4 * 4);
-          const float s0 = tnt_tanh(pv.x + q4.x), s1 = tnt_tanh(pv.y + q4.y), s2 = tnt_tanh(pv.z + q4.z), s3 = tnt_tanh(pv.w + q4.w);
-          bool k[4] = {true, true, true, true};
-          if (stored) { k[0] = mk[p] & 1u; k[1] = mk[p] & 2u; k[2] = mk[p] & 4u; k[3] = mk[p] & 8u; }
-          else if (g.rate_attn > 0.f) tnt_keep4((uint64_t)e, g.rate_attn, g.seed, site_attn, step, k);
-          const float k0 = k[0] ? scale_a : 0.f, k1 = k[1] ? scale_a : 0.f, k2 = k[2] ? scale_a : 0.f, k3 = k[3] ? scale_a : 0.f;
-          const float de = als[r];
-          dv.x += s0 * k0 * de; dv.y += s1 * k1 * de; dv.z += s2 * k2 * de; dv.w += s3 * k3 * de;
+          float s0, s1, s2, s3;
+          if (fast) {
+            s0 = 1.f - 2.f * __builtin_amdgcn_rcpf(pv[p].x * q4.x + 1.f); s1 = 1.f - 2.f * __builtin_amdgcn_rcpf(pv[p].y * q4.y + 1.f);
+            s2 = 1.f - 2.f * __builtin_amdgcn_rcpf(pv[p].z * q4.z + 1.f); s3 = 1.f - 2.f * __builtin_amdgcn_rcpf(pv[p].w * q4.w + 1.f);
+          } else {
+            const float4 p4 = direct ? pv[p] : *reinterpret_cast<const float4*>(g.P + e);
+            s0 = tnt_tanh(p4.x + q4.x); s1 = tnt_tanh(p4.y + q4.y); s2 = tnt_tanh(p4.z + q4.z); s3 = tnt_tanh(p4.w + q4.w);
+          }
+          uint32_t kb = mk[p];
+          if (g.rate_attn > 0.f && !stored) {
+            bool k[4];
+            tnt_keep4((uint64_t)e, g.rate_attn, g.seed, site_attn, step, k);
+            kb = (k[0] ? 1u : 0u) | (k[1] ? 2u : 0u) | (k[2] ? 4u : 0u) | (k[3] ? 8u : 0u);
+          }
+          const float k0 = (kb & 1u) ? scale_a : 0.f, k1 = (kb & 2u) ? scale_a : 0.f, k2 = (kb & 4u) ? scale_a : 0.f, k3 = (kb & 8u) ? scale_a : 0.f;
+          const float de = al[p] * (da[p] - dot);
+          dva.x += s0 * k0 * de; dva.y += s1 * k1 * de; dva.z += s2 * k2 * de; dva.w += s3 * k3 * de;
           const float d0 = de * v4.x * k0 * (1.f - s0 * s0), d1 = de * v4.y * k1 * (1.f - s1 * s1);
           const float d2 = de * v4.z * k2 * (1.f - s2 * s2), d3 = de * v4.w * k3 * (1.f - s3 * s3);
           dpa[p].x += d0; dpa[p].y += d1; dpa[p].z += d2; dpa[p].w += d3;
           dq.x += d0; dq.y += d1; dq.z += d2; dq.w += d3;
+          if (c4 == 0) dbv_acc += de;
         }
-        dv.x = stride_sum<G4>(dv.x); dv.y = stride_sum<G4>(dv.y); dv.z = stride_sum<G4>(dv.z); dv.w = stride_sum<G4>(dv.w);
         dq.x = stride_sum<G4>(dq.x); dq.y = stride_sum<G4>(dq.y); dq.z = stride_sum<G4>(dq.z); dq.w = stride_sum<G4>(dq.w);
-        if (lane < G4) {
-          *reinterpret_cast<float4*>(&wred[w][lane * 4]) = dv;
-          *reinterpret_cast<float4*>(&wred2[w][lane * 4]) = dq;
-        }
-        __syncthreads();
-        if (tid < 64) {
-          if (tid < A) {
-            float tv = 0.f, tq = 0.f;
-#pragma unroll
-            for (int k = 0; k < WW; ++k) { tv += wred[k][tid]; tq += wred2[k][tid]; }
-            dv_acc[tid] += tv;
-            dqp = qp > 0.f ? tq : tq * g.slope;
-          }
-          dq_s[tid] = dqp;
-        }
-        if (tid == 0) dbv_acc += dbv;
-        __syncthreads();
+        if (lane < G4) *reinterpret_cast<float4*>(&wred2[w][lane * 4]) = dq;
       }
+      __syncthreads();
       LCT(5);
       // ---- hand dq = d(query pre-activation) to the LSTM workgroups: each takes dh_att = dq W2^T for its own 32 units
-      if (i > 0 && tid < A) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this thread's reset of the next buffer's element is in L2 first
-        a.dhx[((long)pi * B + ab) * 64 + tid] = dqp;
+      if (tid < A) {
+        float tq = 0.f;
+#pragma unroll
+        for (int k = 0; k < WW; ++k) tq += wred2[k][tid];
+        const float dqp = qp > 0.f ? tq : tq * g.slope;
+        if (i > 0) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's reset of the next buffer's element is in L2 first
+          lc_st1(dq_rsrc, dqp, (unsigned)((ab * 64 + tid) * 4), (unsigned)(pi * B * 256));
+        }
+        lc_st1(qo_rsrc, dqp, (unsigned)((ab * A + tid) * 4), (unsigned)(i * B * A * 4));      // behind the publish: its drain is off the critical path
       }
       LCT(6);
       if (T - 1 - i < 36) LCS(2 + T - 1 - i);
-      if (tid < A) g.dqpre[((long)i * B + ab) * A + tid] = dqp;        // behind the publish: its drain is off the critical path
-      // als / das / qs / scr are rewritten next step; every reader of this step is behind the barriers above
-      __syncthreads();
+      // ---- behind the publish: dF[r] += alpha[r] dctx
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        dfa[p].x += al[p] * dc4.x; dfa[p].y += al[p] * dc4.y; dfa[p].z += al[p] * dc4.z; dfa[p].w += al[p] * dc4.w;
+      }
+      // dcs / qs / qe are rewritten next step in front of its first barrier, by threads that have passed this step's last one
+      // (every reader is in front of that); red_l and wred2 behind the next step's first / second barrier
     }
     LCS(38);
     if (live) {
@@ -1951,11 +2006,20 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       for (int p = 0; p < NP; ++p) {
         const int r = p * RPP + rl;
         if (r < R && cokA) *reinterpret_cast<float4*>(g.dP + ((long)ab * R + r) * A + c4 * 4) = dpa[p];
-        if (r < R && cokD) *reinterpret_cast<float4*>(g.dF + ((long)ab * R + r) * D + c4 * 4) =
-            *reinterpret_cast<const float4*>(df_l + r * D + c4 * 4);
+        if (r < R && cokD) *reinterpret_cast<float4*>(g.dF + ((long)ab * R + r) * D + c4 * 4) = dfa[p];
       }
-      if (tid < A) g.dvb[(long)ab * (A + 1) + tid] = dv_acc[tid];
-      if (tid == 0) g.dvb[(long)ab * (A + 1) + A] = dbv_acc;
+      // dv and dbv: reduced once
+      dva.x = stride_sum<G4>(dva.x); dva.y = stride_sum<G4>(dva.y); dva.z = stride_sum<G4>(dva.z); dva.w = stride_sum<G4>(dva.w);
+      __syncthreads();
+      if (lane < G4) *reinterpret_cast<float4*>(&wred[w][lane * 4]) = dva;
+      const float dbv = block_sum_w(dbv_acc, red_l);
+      if (tid < A) {
+        float tv = 0.f;
+#pragma unroll
+        for (int k = 0; k < WW; ++k) tv += wred[k][tid];
+        g.dvb[(long)ab * (A + 1) + tid] = tv;
+      }
+      if (tid == 0) g.dvb[(long)ab * (A + 1) + A] = dbv;
     }
     if (ub == 0) LCT_DUMP(0, 16);
     LCS(39);
@@ -1968,8 +2032,9 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   const int j = ub - 16;
   float* dzs = lb_lds;                                         // [2][16][LB_DZLD]
   float* red = lb_lds + 2 * 16 * LB_DZLD;                      // [2][NWB][256], later [NWB][4][16][17]
-  float* w2s = lb_lds + LB_LDS_FLOATS;                         // [32][LB_W2LD]: W2[32 j .. 32 j + 32][A]
-  float* dq_l = w2s + 32 * LB_W2LD;                            // [16][64]: dq of the 16 samples, this step
+  float* w2s = lb_lds + LB_LDS_FLOATS;                         // [32][LB_W2LD]: W2[32 j .. 32 j + 32][A], columns past A zero
+  float* dha_l = w2s + 32 * LB_W2LD;                           // [16][36]: dh_att of the 16 samples for this workgroup's 32 units
+  constexpr int NUA = G4 == 8 ? 2 : 4;                         // float4 per lane of a dq row: A <= 32 -> 2, A <= 64 -> 4
   // resident B operands: Ur^T[k][n] = Ur[n][vub * 64 + k], lane (kq, lr) of column tile t holds n = w*32 + t*16 + lr and the
   // contraction indices k = kq*16 + ks (lstm_seq_bwd_kernel's layout)
   float bw[2][NTW][16];
@@ -2029,21 +2094,21 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   // contraction quads 2 w and 2 w + 1 (k = 4 quad + kq), its B operands (Wc[d = 16 t + lr][32 j units][k]) stay in registers
   const int ntile = (D + 15) / 16;
   // (parked in LDS, [wave][quad][tile][lane]: 8 resident VGPRs per lane are 8 more spilled ones in this role)
-  float* wcb_l = dq_l + 16 * 64;                               // [16][2][4][64]
+  float* wcb_l = dha_l + 16 * 64;                              // [16][2][4][64]
 #pragma unroll
   for (int sq = 0; sq < 2; ++sq)
 #pragma unroll
     for (int t = 0; t < 4; ++t)
       wcb_l[((w * 2 + sq) * 4 + t) * 64 + lane] =
           (t * 16 + lr < D) ? a.Wc[((long)(t * 16 + lr) * U + j * 32) * 4 + (2 * w + sq) * 4 + kq] : 0.f;
-  for (int e = tid; e < 32 * A; e += WT) w2s[(e / A) * LB_W2LD + e % A] = g.W2[(long)(j * 32 + e / A) * A + e % A];
+  for (int e = tid; e < 32 * 64; e += WT) w2s[(e >> 6) * LB_W2LD + (e & 63)] = (e & 63) < A ? g.W2[(long)(j * 32 + (e >> 6)) * A + (e & 63)] : 0.f;
   for (int e = tid; e < 2 * 16 * LB_DZLD; e += WT) dzs[e] = 0.f;             // rows past B stay zero
   const int eq = tid >> 8, erow = (tid & 255) >> 4, ecol = tid & 15;
   const int eb = rb * RB + erow, eu = (2 * j + eq) * 16 + ecol;
   const bool eok = tid < 512 && erow < RB && eb < B;
   const long ee = (long)eb * U + eu;
   const uint32_t step_l = a.att.step + (a.att.step_dev ? a.att.step_dev[0] : 0u);
-  const float oscale = a.rate_out > 0.f ? 1.f / (1.f - a.rate_out) : 1.f;
+  const float oscale = lc_uniform(a.rate_out > 0.f ? 1.f / (1.f - a.rate_out) : 1.f);
   const int ridx = ((erow >> 2) * 16 + ecol) * 4 + (erow & 3);
   float dc_c = 0.f;
   // with row blocks of 8 samples only the half of a partial tile that holds rows < 8 (lanes 0..31 of the MFMA's C layout) is
@@ -2059,7 +2124,12 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   // this thread's element (row, d) of this workgroup's context-gradient part in ring buffer buf
   const int prow = tid / D, pd = tid - prow * D;
   const bool pmine = tid < 16 * D;
+  // (layout [buffer][row block][part j][row][d < 64]: a part's row is one coalesced store; with the 16 parts of an element side by
+  // side instead -- every workgroup scattering 4-byte stores into lines it shares with the 15 others -- the hand-off took 1.4 us
+  // instead of 0.4)
   auto pslot = [&](int buf) { return a.parts + ((((long)(buf * nrb + rb) * 16 + j) * 16 + prow) * 64 + pd); };
+  const __amdgpu_buffer_rsrc_t pw_rsrc = tnt_rsrc(a.parts, (unsigned)(3u * nrb * 16u * 1024u * 4u));
+  const __amdgpu_buffer_rsrc_t xw_rsrc = tnt_rsrc(a.xch, (unsigned)(3u * nrb * 32u * 32u * 1024u));
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -2071,54 +2141,124 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   if (pmine) *pslot(0) = sentinel;
   tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
   LCS(1);
-  for (int i = T - 1; i >= 0; --i) {
+  // (register discipline: as in the forward chain -- LC_TID phases, scalar step / slab offsets, buffer addressing)
+#define LC_TID(v) int v = threadIdx.x; asm volatile("" : "+v"(v))
+  const unsigned BU4 = (unsigned)BU * 4u;
+  const __amdgpu_buffer_rsrc_t gt_rsrc = tnt_rsrc(a.gates, (unsigned)((long)T * BU * 16));
+  const __amdgpu_buffer_rsrc_t cs_rsrc = tnt_rsrc(a.cs, (unsigned)((long)(T + 1) * BU * 4));
+  const __amdgpu_buffer_rsrc_t do_rsrc = tnt_rsrc(a.dout, (unsigned)((long)T * BU * 4));
+  const __amdgpu_buffer_rsrc_t dz_rsrc = tnt_rsrc(a.dz, (unsigned)((long)T * BU * 16));
+  const int D4 = D >> 2;
+  for (int i0 = T - 1; i0 >= 0; --i0) {
+    const int i = __builtin_amdgcn_readfirstlane(i0);
     const int pi = (T - 1 - i) % 3, pn = (pi + 1) % 3;
-    // epilogue operands of this step do not depend on the chain: fetch them first
+    // ---- epilogue operands of this step do not depend on the chain: fetch them first; arm the next parts buffer
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float cval = 0.f, cprev = 0.f, dout_t = 0.f;
-    if (eok) {
-      g4 = *reinterpret_cast<const float4*>(a.gates + ((long)i * BU + ee) * 4);
-      cval = a.cs[(long)(i + 1) * BU + ee]; cprev = a.cs[(long)i * BU + ee];
-      dout_t = a.dout[(long)i * BU + ee];
+    {
+      LC_TID(t0);
+      const int erow0 = (t0 & 255) >> 4, eb0 = rb * RB + erow0;
+      if (t0 < 512 && erow0 < RB && eb0 < B) {
+        const unsigned ee0 = (unsigned)(eb0 * U + (2 * j + (t0 >> 8)) * 16 + (t0 & 15));
+        g4 = lc_ld4(gt_rsrc, ee0 * 16u, (unsigned)i * BU4 * 4u);
+        cval = lc_ld1(cs_rsrc, ee0 * 4u, (unsigned)(i + 1) * BU4); cprev = lc_ld1(cs_rsrc, ee0 * 4u, (unsigned)i * BU4);
+        dout_t = lc_ld1(do_rsrc, ee0 * 4u, (unsigned)i * BU4);
+        // (Dropout' of the LSTM outputs: the Philox call sits here, in front of every wait)
+        if (a.rate_out > 0.f)
+          dout_t = tnt_keep((uint64_t)ee0, a.rate_out, a.att.seed, a.site_out0 + (uint32_t)i, step_l) ? dout_t * oscale : 0.f;
+      }
+      if (t0 < 16 * D && i > 0) {
+        const int pr0 = t0 / D, pd0 = t0 - pr0 * D;
+        lc_st1(pw_rsrc, sentinel, (unsigned)((((j * 16 + pr0) * 64) + pd0) * 4), (unsigned)((pn * nrb + rb) * 65536));
+      }
     }
     LCT(16);
-    if (pmine && i > 0) *pslot(pn) = sentinel;
     float da = 0.f;
     if (i < T - 1) {
       const int par = (T - 2 - i) % 3;                       // exchange of dz_{i+1} Ur^T; also the buffer of dh_att_{i+1}
-      if (i > 0) {
+      if (RB == 8) {
+        {
+          LC_TID(t1);
+          const int l1 = t1 & 63, rg = l1 >> 5, cg = (l1 >> 2) & 7, xj = l1 & 3;
+          // this lane's float4 of a tile for workgroup 2 w + (cg >> 2): chunk rg*16 + 4 (cg & 3) + j (where the 16x16 C layout
+          // keeps rows rg*4 .. +3 of column 4 (cg & 3) + j); one chunk per lane and source block
+          const unsigned xoff = (unsigned)(((((w * 2 + (cg >> 2)) * 32) * 256) + (rg * 16 + (cg & 3) * 4 + xj) * 4) * 4);
+          if (i > 0) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          if (RB == 8) *reinterpret_cast<float4*>(xslot8((par + 1) % 3, 2 * j + q)) = sent4;
-          else
+            for (int q = 0; q < 2; ++q)
+              lc_st4(xw_rsrc, sent4, xoff, (unsigned)((((((par + 1) % 3) * nrb + rb) * 32 * 32) + 2 * j + q) * 1024));
+          }
+          floatx4 xa[2];
+          const float* azp = dzs + (rg * 4 + xj) * LB_DZLD + cg * 4;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            float4 am[2];
+#pragma unroll
+            for (int kh2 = 0; kh2 < 2; ++kh2) am[kh2] = *reinterpret_cast<const float4*>(azp + q * 16 * LB_DZLD + kh2 * 32);
+            xa[q] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#define TNT_X4(k2, qd)                                                                                   \
+            xa[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(am[k2].x, bx[q][k2][qd][0], xa[q], 3, qd, 1);          \
+            xa[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(am[k2].y, bx[q][k2][qd][0], xa[q], 3, qd, 2);          \
+            xa[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(am[k2].z, bx[q][k2][qd][1], xa[q], 3, qd, 1);          \
+            xa[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(am[k2].w, bx[q][k2][qd][1], xa[q], 3, qd, 2);
+            TNT_X4(0, 0) TNT_X4(0, 1) TNT_X4(0, 2) TNT_X4(0, 3) TNT_X4(0, 4) TNT_X4(0, 5) TNT_X4(0, 6) TNT_X4(0, 7)
+            TNT_X4(1, 0) TNT_X4(1, 1) TNT_X4(1, 2) TNT_X4(1, 3) TNT_X4(1, 4) TNT_X4(1, 5) TNT_X4(1, 6) TNT_X4(1, 7)
+#undef TNT_X4
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's resets are in L2 first
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            lc_st4(xw_rsrc, make_float4(xa[q][0], xa[q][1], xa[q][2], xa[q][3]), xoff,
+                   (unsigned)((((par * nrb + rb) * 32 * 32) + 2 * j + q) * 1024));
+        }
+        LCT(17);
+        // ---- gather the 32 partial tiles of each of this workgroup's two blocks: wave w sums sources w and w + 16
+        // (both blocks' loads in flight together; `red` holds [2][NWB][256]); only lanes 0..31 of a tile hold rows < 8
+        {
+          LC_TID(t2);
+          const int l2 = t2 & 63;
+          const bool xl2 = l2 < 32;
+          float4 p[2][2];
+          unsigned spins = 0;
+          for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                p[q][h] = xl2 ? lc_ld4_l2(x_rsrc, (unsigned)l2 * 16u,
+                                          (unsigned)(((((par * nrb + rb) * 32 + 2 * j + q) * 32) + w + 16 * h) * 1024))
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                ok = ok && __float_as_uint(p[q][h].x) != LC_SENTINEL && __float_as_uint(p[q][h].y) != LC_SENTINEL &&
+                     __float_as_uint(p[q][h].z) != LC_SENTINEL && __float_as_uint(p[q][h].w) != LC_SENTINEL;
+              }
+            if (__all(ok)) break;
+            if (poll_fail(spins)) break;
+          }
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            *reinterpret_cast<float4*>(red + (q * NWB + w) * 256 + l2 * 4) =
+                make_float4(p[q][0].x + p[q][1].x, p[q][0].y + p[q][1].y, p[q][0].z + p[q][1].z, p[q][0].w + p[q][1].w);
+        }
+        __syncthreads();
+        {
+          LC_TID(t3);
+          const int erow3 = (t3 & 255) >> 4;
+          if (t3 < 512 && erow3 < RB) {
+            const float* rp = red + (t3 >> 8) * NWB * 256 + ((erow3 >> 2) * 16 + (t3 & 15)) * 4 + (erow3 & 3);
+#pragma unroll
+            for (int k = 0; k < NWB; ++k) da += rp[k * 256];
+          }
+        }
+      } else {
+        if (i > 0) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int t = 0; t < NTW; ++t) if (xl) *reinterpret_cast<float4*>(xslot((par + 1) % 3, w * NTW + t, 2 * j + q)) = sent4;
         }
-      }
-      if (RB == 8) {
-        floatx4 xa[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          float4 am[2];
-#pragma unroll
-          for (int kh2 = 0; kh2 < 2; ++kh2)
-            am[kh2] = *reinterpret_cast<const float4*>(dzs + (q * 16 + x_rg * 4 + x_j) * LB_DZLD + kh2 * 32 + x_cg * 4);
-          xa[q] = (floatx4){0.f, 0.f, 0.f, 0.f};
-#define TNT_X4(k2, qd)                                                                                   \
-          xa[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(am[k2].x, bx[q][k2][qd][0], xa[q], 3, qd, 1);          \
-          xa[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(am[k2].y, bx[q][k2][qd][0], xa[q], 3, qd, 2);          \
-          xa[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(am[k2].z, bx[q][k2][qd][1], xa[q], 3, qd, 1);          \
-          xa[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(am[k2].w, bx[q][k2][qd][1], xa[q], 3, qd, 2);
-          TNT_X4(0, 0) TNT_X4(0, 1) TNT_X4(0, 2) TNT_X4(0, 3) TNT_X4(0, 4) TNT_X4(0, 5) TNT_X4(0, 6) TNT_X4(0, 7)
-          TNT_X4(1, 0) TNT_X4(1, 1) TNT_X4(1, 2) TNT_X4(1, 3) TNT_X4(1, 4) TNT_X4(1, 5) TNT_X4(1, 6) TNT_X4(1, 7)
-#undef TNT_X4
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's resets are in L2 first
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-          *reinterpret_cast<float4*>(xslot8(par, 2 * j + q)) = make_float4(xa[q][0], xa[q][1], xa[q][2], xa[q][3]);
-      } else {
-      floatx4 acc[2][NTW];
+        {
+        floatx4 acc[2][NTW];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           float av[16];
@@ -2141,118 +2281,145 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
           for (int t = 0; t < NTW; ++t)
             if (xl) *reinterpret_cast<float4*>(xslot(par, w * NTW + t, 2 * j + q)) = make_float4(acc[q][t][0], acc[q][t][1], acc[q][t][2], acc[q][t][3]);
       }
-      LCT(17);
-      // ---- gather the 32 partial tiles of each of this workgroup's two blocks: wave w sums sources w and w + 16
-      // (both blocks' loads in flight together; `red` holds [2][NWB][256])
-      {
-        const unsigned base = (unsigned)((((par * nrb + rb) * 32 + 2 * j) * 32) * 1024) + (unsigned)lane * 16u;
-        float4 p[2][2];
+        LCT(17);
+        {
+          const unsigned base = (unsigned)((((par * nrb + rb) * 32 + 2 * j) * 32) * 1024) + (unsigned)lane * 16u;
+          float4 p[2][2];
+          unsigned spins = 0;
+          for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                p[q][h] = xl ? tnt_ld4_l2(x_rsrc, base + (unsigned)q * 32u * 1024u + (unsigned)(w + 16 * h) * 1024u)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                ok = ok && __float_as_uint(p[q][h].x) != LC_SENTINEL && __float_as_uint(p[q][h].y) != LC_SENTINEL &&
+                     __float_as_uint(p[q][h].z) != LC_SENTINEL && __float_as_uint(p[q][h].w) != LC_SENTINEL;
+              }
+            if (__all(ok)) break;
+            if (poll_fail(spins)) break;
+          }
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            *reinterpret_cast<float4*>(red + (q * NWB + w) * 256 + lane * 4) =
+                make_float4(p[q][0].x + p[q][1].x, p[q][0].y + p[q][1].y, p[q][0].z + p[q][1].z, p[q][0].w + p[q][1].w);
+          __syncthreads();
+          if (eok) {
+#pragma unroll
+            for (int k = 0; k < NWB; ++k) da += red[(eq * NWB + k) * 256 + ridx];
+          }
+        }
+      }
+      LCT(18);
+      // ---- the attention's query gradient of the step behind: dh_att_{i+1} = dq_{i+1} W2^T for this workgroup's 32 units, on
+      // the MFMAs: wave 8 + t owns unit tile t; lane (kq, lr) polls the float4 dq[row lr][16 u + 4 kq ..] (element e of float4 u
+      // feeds MFMA 4 u + e, whose contraction index is therefore a = 16 u + 4 kq + e) and reads the matching float4 of row
+      // 16 t + lr of the W2 slice; rows 4 kq .. + 3 of unit 16 t + lr go to dha_l for the cell backward below
+      if (w >= 8 && w < 10) {
+        LC_TID(t4);
+        const int l4 = t4 & 63, kq4 = l4 >> 4, lr4 = l4 & 15, tile = w - 8;
+        const int qrow4 = rb * RB + lr4;
+        const bool qm = lr4 < RB && qrow4 < B;
+        float4 qa[NUA], qb[NUA];
+#pragma unroll
+        for (int u = 0; u < NUA; ++u) qb[u] = *reinterpret_cast<const float4*>(w2s + (tile * 16 + lr4) * LB_W2LD + 16 * u + 4 * kq4);
         unsigned spins = 0;
         for (;;) {
           bool ok = true;
 #pragma unroll
-          for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              p[q][h] = xl ? tnt_ld4_l2(x_rsrc, base + (unsigned)q * 32u * 1024u + (unsigned)(w + 16 * h) * 1024u)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-              ok = ok && __float_as_uint(p[q][h].x) != LC_SENTINEL && __float_as_uint(p[q][h].y) != LC_SENTINEL &&
-                   __float_as_uint(p[q][h].z) != LC_SENTINEL && __float_as_uint(p[q][h].w) != LC_SENTINEL;
-            }
+          for (int u = 0; u < NUA; ++u) {
+            qa[u] = (qm && 16 * u + 4 * kq4 < A) ? lc_ld4_l2(dq_rsrc, (unsigned)((qrow4 * 64 + 16 * u + 4 * kq4) * 4), (unsigned)(par * B * 256))
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            ok = ok && __float_as_uint(qa[u].x) != LC_SENTINEL && __float_as_uint(qa[u].y) != LC_SENTINEL &&
+                 __float_as_uint(qa[u].z) != LC_SENTINEL && __float_as_uint(qa[u].w) != LC_SENTINEL;
+          }
           if (__all(ok)) break;
           if (poll_fail(spins)) break;
         }
+        floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-          *reinterpret_cast<float4*>(red + (q * NWB + w) * 256 + lane * 4) =
-              make_float4(p[q][0].x + p[q][1].x, p[q][0].y + p[q][1].y, p[q][0].z + p[q][1].z, p[q][0].w + p[q][1].w);
-        __syncthreads();
-        if (eok) {
+        for (int u = 0; u < NUA; ++u) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[u].x, qb[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[u].y, qb[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[u].z, qb[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[u].w, qb[u].w, acc, 0, 0, 0);
+        }
+        float* dw = dha_l + (kq4 * 4) * 36 + tile * 16 + lr4;
 #pragma unroll
-          for (int k = 0; k < NWB; ++k) da += red[(eq * NWB + k) * 256 + ridx];
-        }
-      }
-      LCT(18);
-      // (Dropout' of the LSTM outputs: the Philox call sits in front of the wait for the attention role)
-      if (eok && a.rate_out > 0.f)
-        dout_t = tnt_keep((uint64_t)ee, a.rate_out, a.att.seed, a.site_out0 + (uint32_t)i, step_l) ? dout_t * oscale : 0.f;
-      // ---- the attention's query gradient of the step behind: dh_att_{i+1} = dq_{i+1} W2^T for this workgroup's units
-      // (dq of the 16 samples from buffer par, thread = (row, a))
-      {
-        float v = 0.f;
-        unsigned spins = 0;
-        const int qr = tid / A, qa = tid - qr * A;
-        const bool mine = tid < 16 * A && qr < RB && rb * RB + qr < B;
-        for (;;) {
-          if (mine) v = lc_ld1_l2(dq_rsrc, (unsigned)((((long)par * B + rb * RB + qr) * 64 + qa) * 4));
-          if (__all(!mine || __float_as_uint(v) != LC_SENTINEL)) break;
-          if (poll_fail(spins)) break;
-        }
-        if (tid < 16 * A) dq_l[qr * 64 + qa] = v;
-        __syncthreads();
-        if (eok) {
-          const float* qrow = dq_l + erow * 64;
-          const float* wrow = w2s + (eq * 16 + ecol) * LB_W2LD;
-          float t = 0.f;
-#pragma unroll 8
-          for (int c = 0; c < A; ++c) t += qrow[c] * wrow[c];
-          da += t;
-        }
+        for (int r = 0; r < 4; ++r) dw[r * 36] = acc[r];
       }
       LCT(19);
-    } else if (eok && a.rate_out > 0.f) {                    // the first step of the chain has no hand-off to wait for
-      dout_t = tnt_keep((uint64_t)ee, a.rate_out, a.att.seed, a.site_out0 + (uint32_t)i, step_l) ? dout_t * oscale : 0.f;
     }
     // ---- cell backward (the arithmetic of bwd_epilogue, lstm.hip)
-    __syncthreads();          // every wave has read the dz tiles of the step behind (MFMA operands) before they are rewritten
+    __syncthreads();          // dh_att is in; every wave has read the dz tiles of the step behind (MFMA operands) before they are rewritten
     float4 dz_keep = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (eok) {
-      const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
-      const float tc = tnt_tanh(cval);
-      const float dh = da + dout_t;
-      const float dgo = dh * tc;
-      const float dc = dc_c + dh * go * (1.f - tc * tc);
-      const float4 dz4 = make_float4(dc * gg * gi * (1.f - gi), dc * cprev * gf * (1.f - gf), dc * gi * (1.f - gg * gg),
-                                     dgo * go * (1.f - go));
-      dc_c = dc * gf;
-      dz_keep = dz4;
-      *reinterpret_cast<float4*>(dzs + (eq * 16 + erow) * LB_DZLD + ecol * 4) = dz4;
+    {
+      LC_TID(t5);
+      const int erow5 = (t5 & 255) >> 4, ecol5 = t5 & 15, eq5 = t5 >> 8;
+      if (t5 < 512 && erow5 < RB && rb * RB + erow5 < B) {
+        if (i < T - 1) da += dha_l[erow5 * 36 + eq5 * 16 + ecol5];
+        const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
+        const float tc = tnt_tanh(cval);
+        const float dh = da + dout_t;
+        const float dgo = dh * tc;
+        const float dc = dc_c + dh * go * (1.f - tc * tc);
+        const float4 dz4 = make_float4(dc * gg * gi * (1.f - gi), dc * cprev * gf * (1.f - gf), dc * gi * (1.f - gg * gg),
+                                       dgo * go * (1.f - go));
+        dc_c = dc * gf;
+        dz_keep = dz4;
+        *reinterpret_cast<float4*>(dzs + (eq5 * 16 + erow5) * LB_DZLD + ecol5 * 4) = dz4;
+      }
     }
     __syncthreads();
     LCT(20);
     // ---- partial context gradient of this workgroup's 32 units: part[row][d] = sum_c dz[row][c] Wc[d][c]
     {
+      LC_TID(t6);
+      const int l6 = t6 & 63, kq6 = l6 >> 4, lr6 = l6 & 15;
       float pa[2];
 #pragma unroll
       for (int sq = 0; sq < 2; ++sq) {
-        const int kk = (2 * w + sq) * 4 + kq;                  // 0..127: block kk / 64, column kk % 64 of its dz tile
-        pa[sq] = dzs[((kk >> 6) * 16 + lr) * LB_DZLD + (kk & 63)];
+        const int kk = (2 * w + sq) * 4 + kq6;                 // 0..127: block kk / 64, column kk % 64 of its dz tile
+        pa[sq] = dzs[((kk >> 6) * 16 + lr6) * LB_DZLD + (kk & 63)];
       }
       float (*pr)[4][16][17] = reinterpret_cast<float (*)[4][16][17]>(red);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         if (t < ntile) {
           floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[0], wcb_l[((w * 2 + 0) * 4 + t) * 64 + lane], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[1], wcb_l[((w * 2 + 1) * 4 + t) * 64 + lane], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[0], wcb_l[((w * 2 + 0) * 4 + t) * 64 + l6], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[1], wcb_l[((w * 2 + 1) * 4 + t) * 64 + l6], acc, 0, 0, 0);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pr[w][t][kq * 4 + r][lr] = acc[r];
+          for (int r = 0; r < 4; ++r) pr[w][t][kq6 * 4 + r][lr6] = acc[r];
         }
       }
       __syncthreads();
-      if (pmine) {
+      LC_TID(t7);
+      if (t7 < 16 * D) {
+        const int pr7 = t7 / D, pd7 = t7 - pr7 * D;
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < NWB; ++k) t += pr[k][pd >> 4][prow][pd & 15];
+        for (int k = 0; k < NWB; ++k) t += pr[k][pd7 >> 4][pr7][pd7 & 15];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's reset of the next buffer's element is in L2 first
-        *pslot(pi) = t;
+        lc_st1(pw_rsrc, t, (unsigned)((((j * 16 + pr7) * 64) + pd7) * 4), (unsigned)((pi * nrb + rb) * 65536));
       }
     }
     LCT(21);
+#ifdef TNT_LC_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // trace build only: when the publish has been acknowledged
+    LCT(22);
+#endif
     if (T - 1 - i < 36) LCS(2 + T - 1 - i);
     // behind the publish (its drain is off the critical path): this step's dz for the weight-gradient GEMMs after the chain
-    if (eok) *reinterpret_cast<float4*>(a.dz + ((long)i * BU + ee) * 4) = dz_keep;
+    {
+      LC_TID(t8);
+      const int erow8 = (t8 & 255) >> 4, eb8 = rb * RB + erow8;
+      if (t8 < 512 && erow8 < RB && eb8 < B)
+        lc_st4(dz_rsrc, dz_keep, (unsigned)(eb8 * U + (2 * j + (t8 >> 8)) * 16 + (t8 & 15)) * 16u, (unsigned)i * BU4 * 4u);
+    }
   }
+#undef LC_TID
   if (ub == 16) LCT_DUMP(16, 32);
   LCS(38); LCS(39);
   if (ub == 16) LCS_DUMP(3);
