@@ -983,9 +983,14 @@ __device__ __forceinline__ float lc_uniform(float x) { return __uint_as_float(__
 __device__ __forceinline__ void lc_st1(__amdgpu_buffer_rsrc_t rsrc, float v, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, (int)voff, (int)soff, 0);
 }
+// HARDWARE HAZARD (gfx950, found the hard way: tools/probe/lc_bwd_dbg.py): a 16-byte buffer store whose soffset is an SGPR must
+// not be followed directly by a VALU write of its first data register -- the store then carries the NEW value in that dword.
+// LLVM's hazard recognizer inserts the wait state only for the immediate-soffset form, so the helper keeps the data registers
+// alive across one s_nop: nothing can be scheduled into the slot behind the store.
 __device__ __forceinline__ void lc_st4(__amdgpu_buffer_rsrc_t rsrc, float4 v, unsigned voff, unsigned soff) {
   const lc_u4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
   __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, (int)voff, (int)soff, 0);
+  asm volatile("s_nop 1" :: "v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w));
 }
 __device__ __forceinline__ float lc_ld1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
@@ -1017,6 +1022,10 @@ extern "C" int32_t tnt_debug_lc_trace(unsigned long long* out) {
 // per-step timeline of one workgroup per role: [0] entry, [1] behind the launch's flag barrier, [2 + k] the k-th step's mark,
 // [38] loop done, [39] outputs stored (roles: 0 forward attention, 1 forward LSTM, 2 backward attention, 3 backward LSTM)
 __device__ unsigned long long lc_steps[4][40];
+__device__ unsigned long long lc_pub[10][32];      // backward, step LCT_STEP, row block 0: [0] dh_att in, [1] parts published, per LSTM workgroup; [2] dq out per attention workgroup; [3] step top, [4] pushed, [5] gathered per LSTM workgroup
+extern "C" int32_t tnt_debug_lc_pub(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc_pub), sizeof(lc_pub)) == hipSuccess ? 0 : -1;
+}
 extern "C" int32_t tnt_debug_lc_steps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc_steps), sizeof(lc_steps)) == hipSuccess ? 0 : -1;
 }
@@ -1893,6 +1902,9 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
           v = tnt_ld4_l2(pt_rsrc, off);
           const bool ok = __float_as_uint(v.x) != LC_SENTINEL && __float_as_uint(v.y) != LC_SENTINEL &&
                           __float_as_uint(v.z) != LC_SENTINEL && __float_as_uint(v.w) != LC_SENTINEL;
+#ifdef TNT_LC_TRACE
+          if (tid == 0 && rb == 0 && i == LCT_STEP && spins < 14) lct_l[40 + spins] = wall_clock64();      // every poll's return
+#endif
           if (ok) break;                                     // per lane: a lane leaves the loop when ITS chunk is in
           if (++spins > TNT_SEQ_SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
           if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
@@ -1991,6 +2003,9 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
         lc_st1(qo_rsrc, dqp, (unsigned)((ab * A + tid) * 4), (unsigned)(i * B * A * 4));      // behind the publish: its drain is off the critical path
       }
       LCT(6);
+#ifdef TNT_LC_TRACE
+      if (tid == 0 && rb == 0 && i == LCT_STEP) lc_pub[2][ub] = wall_clock64();
+#endif
       if (T - 1 - i < 36) LCS(2 + T - 1 - i);
       // ---- behind the publish: dF[r] += alpha[r] dctx
 #pragma unroll
@@ -2021,7 +2036,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       }
       if (tid == 0) g.dvb[(long)ab * (A + 1) + A] = dbv;
     }
-    if (ub == 0) LCT_DUMP(0, 16);
+    if (ub == 0) { LCT_DUMP(0, 16); LCT_DUMP(40, 56); }
     LCS(39);
     if (ub == 0) LCS_DUMP(2);
     tnt_seq_leave(a.sync, xcc, a.guard_out);
@@ -2152,27 +2167,41 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
   for (int i0 = T - 1; i0 >= 0; --i0) {
     const int i = __builtin_amdgcn_readfirstlane(i0);
     const int pi = (T - 1 - i) % 3, pn = (pi + 1) % 3;
-    // ---- epilogue operands of this step do not depend on the chain: fetch them first; arm the next parts buffer
+    // ---- the step's resets first (the next parts buffer, the next exchange buffer), DRAINED (stores are acknowledged by L2 in
+    // ~0.15 us), and only then the epilogue operands of the step (gates, cell states, dout: they come from HBM).  The memory
+    // counter is in-order: with the loads in front, the drain that the tile stores need ("my resets are in L2 before I
+    // publish") also waited for the loads, and the tiles of the waves that own epilogue threads -- those for the first eight
+    // workgroups -- were published an HBM latency late; those workgroups ran 1-2 us behind the others for the whole chain
+    // (profiles/r03_lc_trace.txt) and set its period.
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float cval = 0.f, cprev = 0.f, dout_t = 0.f;
+    float cval = 0.f, cprev = 0.f, dout_t = 0.f, okeep = 1.f;
     {
       LC_TID(t0);
+      if (t0 < 16 * D && i > 0) {
+        const int pr0 = t0 / D, pd0 = t0 - pr0 * D;
+        lc_st1(pw_rsrc, sentinel, (unsigned)((((j * 16 + pr0) * 64) + pd0) * 4), (unsigned)((pn * nrb + rb) * 65536));
+      }
+      if (RB == 8 && i > 0 && i < T - 1) {
+        const int l0 = t0 & 63, rg = l0 >> 5, cg = (l0 >> 2) & 7, xj = l0 & 3;
+        const unsigned xoff = (unsigned)(((((w * 2 + (cg >> 2)) * 32) * 256) + (rg * 16 + (cg & 3) * 4 + xj) * 4) * 4);
+        lc_st4(xw_rsrc, sent4, xoff, (unsigned)((((((T - 2 - i + 1) % 3) * nrb + rb) * 32 * 32) + 2 * j) * 1024));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int erow0 = (t0 & 255) >> 4, eb0 = rb * RB + erow0;
       if (t0 < 512 && erow0 < RB && eb0 < B) {
         const unsigned ee0 = (unsigned)(eb0 * U + (2 * j + (t0 >> 8)) * 16 + (t0 & 15));
         g4 = lc_ld4(gt_rsrc, ee0 * 16u, (unsigned)i * BU4 * 4u);
         cval = lc_ld1(cs_rsrc, ee0 * 4u, (unsigned)(i + 1) * BU4); cprev = lc_ld1(cs_rsrc, ee0 * 4u, (unsigned)i * BU4);
         dout_t = lc_ld1(do_rsrc, ee0 * 4u, (unsigned)i * BU4);
-        // (Dropout' of the LSTM outputs: the Philox call sits here, in front of every wait)
-        if (a.rate_out > 0.f)
-          dout_t = tnt_keep((uint64_t)ee0, a.rate_out, a.att.seed, a.site_out0 + (uint32_t)i, step_l) ? dout_t * oscale : 0.f;
-      }
-      if (t0 < 16 * D && i > 0) {
-        const int pr0 = t0 / D, pd0 = t0 - pr0 * D;
-        lc_st1(pw_rsrc, sentinel, (unsigned)((((j * 16 + pr0) * 64) + pd0) * 4), (unsigned)((pn * nrb + rb) * 65536));
+        // (Dropout' of the LSTM outputs: the Philox call sits here, in front of every wait; its factor meets dout in the cell
+        // backward -- a use of the loaded value up here would stall the step's top on the load's HBM latency)
+        if (a.rate_out > 0.f) okeep = tnt_keep((uint64_t)ee0, a.rate_out, a.att.seed, a.site_out0 + (uint32_t)i, step_l) ? oscale : 0.f;
       }
     }
     LCT(16);
+#ifdef TNT_LC_TRACE
+    if (tid == 0 && rb == 0 && i == LCT_STEP) lc_pub[3][j] = wall_clock64();
+#endif
     float da = 0.f;
     if (i < T - 1) {
       const int par = (T - 2 - i) % 3;                       // exchange of dz_{i+1} Ur^T; also the buffer of dh_att_{i+1}
@@ -2183,11 +2212,6 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
           // this lane's float4 of a tile for workgroup 2 w + (cg >> 2): chunk rg*16 + 4 (cg & 3) + j (where the 16x16 C layout
           // keeps rows rg*4 .. +3 of column 4 (cg & 3) + j); one chunk per lane and source block
           const unsigned xoff = (unsigned)(((((w * 2 + (cg >> 2)) * 32) * 256) + (rg * 16 + (cg & 3) * 4 + xj) * 4) * 4);
-          if (i > 0) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-              lc_st4(xw_rsrc, sent4, xoff, (unsigned)((((((par + 1) % 3) * nrb + rb) * 32 * 32) + 2 * j + q) * 1024));
-          }
           floatx4 xa[2];
           const float* azp = dzs + (rg * 4 + xj) * LB_DZLD + cg * 4;
 #pragma unroll
@@ -2205,40 +2229,44 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
             TNT_X4(1, 0) TNT_X4(1, 1) TNT_X4(1, 2) TNT_X4(1, 3) TNT_X4(1, 4) TNT_X4(1, 5) TNT_X4(1, 6) TNT_X4(1, 7)
 #undef TNT_X4
           }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's resets are in L2 first
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-            lc_st4(xw_rsrc, make_float4(xa[q][0], xa[q][1], xa[q][2], xa[q][3]), xoff,
-                   (unsigned)((((par * nrb + rb) * 32 * 32) + 2 * j + q) * 1024));
+          // (this thread's reset of the buffer behind this one was drained at the top of the step)
+          // The workgroup's two 16-unit blocks are summed HERE and leave as one tile per destination (source slot 2 j): half
+          // the exchange traffic -- a round of the all-to-all was taking 1.3 us at ~0.8 TB/s per XCD, most of the gather.
+          lc_st4(xw_rsrc, make_float4(xa[0][0] + xa[1][0], xa[0][1] + xa[1][1], xa[0][2] + xa[1][2], xa[0][3] + xa[1][3]), xoff,
+                 (unsigned)((((par * nrb + rb) * 32 * 32) + 2 * j) * 1024));
         }
         LCT(17);
-        // ---- gather the 32 partial tiles of each of this workgroup's two blocks: wave w sums sources w and w + 16
-        // (both blocks' loads in flight together; `red` holds [2][NWB][256]); only lanes 0..31 of a tile hold rows < 8
+#ifdef TNT_LC_TRACE
+        if (tid == 0 && rb == 0 && i == LCT_STEP) lc_pub[4][j] = wall_clock64();
+#endif
+        // ---- gather the 16 partial tiles (one per source workgroup) of each of this workgroup's two blocks: wave w takes
+        // source w (both blocks' loads in flight together; `red` holds [2][NWB][256]); only lanes 0..31 of a tile hold rows < 8
         {
           LC_TID(t2);
           const int l2 = t2 & 63;
           const bool xl2 = l2 < 32;
-          float4 p[2][2];
+          float4 p[2];
           unsigned spins = 0;
           for (;;) {
             bool ok = true;
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                p[q][h] = xl2 ? lc_ld4_l2(x_rsrc, (unsigned)l2 * 16u,
-                                          (unsigned)(((((par * nrb + rb) * 32 + 2 * j + q) * 32) + w + 16 * h) * 1024))
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-                ok = ok && __float_as_uint(p[q][h].x) != LC_SENTINEL && __float_as_uint(p[q][h].y) != LC_SENTINEL &&
-                     __float_as_uint(p[q][h].z) != LC_SENTINEL && __float_as_uint(p[q][h].w) != LC_SENTINEL;
-              }
+            for (int q = 0; q < 2; ++q) {
+              p[q] = xl2 ? lc_ld4_l2(x_rsrc, (unsigned)l2 * 16u, (unsigned)(((((par * nrb + rb) * 32 + 2 * j + q) * 32) + 2 * w) * 1024))
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+              ok = ok && __float_as_uint(p[q].x) != LC_SENTINEL && __float_as_uint(p[q].y) != LC_SENTINEL &&
+                   __float_as_uint(p[q].z) != LC_SENTINEL && __float_as_uint(p[q].w) != LC_SENTINEL;
+            }
             if (__all(ok)) break;
             if (poll_fail(spins)) break;
           }
+#ifdef TNT_LC_TRACE
+          if (rb == 0 && i == LCT_STEP && (tid == 0 || tid == 256 || tid == 512)) {      // waves 0, 4, 8: loop exit, rounds
+            const int k_ = tid == 0 ? 6 : (tid == 256 ? 7 : 8);
+            lc_pub[k_][j] = wall_clock64(); if (tid == 256) lc_pub[9][j] = spins + 1;
+          }
+#endif
 #pragma unroll
-          for (int q = 0; q < 2; ++q)
-            *reinterpret_cast<float4*>(red + (q * NWB + w) * 256 + l2 * 4) =
-                make_float4(p[q][0].x + p[q][1].x, p[q][0].y + p[q][1].y, p[q][0].z + p[q][1].z, p[q][0].w + p[q][1].w);
+          for (int q = 0; q < 2; ++q) *reinterpret_cast<float4*>(red + (q * NWB + w) * 256 + l2 * 4) = p[q];
         }
         __syncthreads();
         {
@@ -2312,6 +2340,9 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
         }
       }
       LCT(18);
+#ifdef TNT_LC_TRACE
+      if (tid == 0 && rb == 0 && i == LCT_STEP) lc_pub[5][j] = wall_clock64();
+#endif
       // ---- the attention's query gradient of the step behind: dh_att_{i+1} = dq_{i+1} W2^T for this workgroup's 32 units, on
       // the MFMAs: wave 8 + t owns unit tile t; lane (kq, lr) polls the float4 dq[row lr][16 u + 4 kq ..] (element e of float4 u
       // feeds MFMA 4 u + e, whose contraction index is therefore a = 16 u + 4 kq + e) and reads the matching float4 of row
@@ -2352,6 +2383,9 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       LCT(19);
     }
     // ---- cell backward (the arithmetic of bwd_epilogue, lstm.hip)
+#ifdef TNT_LC_TRACE
+    if (tid == 512 && rb == 0 && i == LCT_STEP) lc_pub[0][j] = wall_clock64();
+#endif
     __syncthreads();          // dh_att is in; every wave has read the dz tiles of the step behind (MFMA operands) before they are rewritten
     float4 dz_keep = make_float4(0.f, 0.f, 0.f, 0.f);
     {
@@ -2361,7 +2395,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
         if (i < T - 1) da += dha_l[erow5 * 36 + eq5 * 16 + ecol5];
         const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
         const float tc = tnt_tanh(cval);
-        const float dh = da + dout_t;
+        const float dh = da + dout_t * okeep;
         const float dgo = dh * tc;
         const float dc = dc_c + dh * go * (1.f - tc * tc);
         const float4 dz4 = make_float4(dc * gg * gi * (1.f - gi), dc * cprev * gf * (1.f - gf), dc * gi * (1.f - gg * gg),
@@ -2407,8 +2441,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
     }
     LCT(21);
 #ifdef TNT_LC_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // trace build only: when the publish has been acknowledged
-    LCT(22);
+    if (tid == 0 && rb == 0 && i == LCT_STEP) lc_pub[1][j] = wall_clock64();
 #endif
     if (T - 1 - i < 36) LCS(2 + T - 1 - i);
     // behind the publish (its drain is off the critical path): this step's dz for the weight-gradient GEMMs after the chain

@@ -16,11 +16,13 @@ lib.tnt_debug_lc_trace.argtypes = [ctypes.c_void_p]
 assert lib.tnt_debug_lc_trace(buf) == 0
 t = list(buf)
 bwd = {0: "A top", 7: "A poll starts", 1: "A parts in", 2: "A dctx", 3: "A dalpha + dot", 4: "A dot summed", 5: "A scores' + dq sums", 6: "A dq out",
-       16: "L top", 17: "L pushed", 18: "L gathered", 19: "L dh in", 20: "L cell", 21: "L parts out", 22: "L parts acked"}
+       16: "L top", 17: "L pushed", 18: "L gathered", 19: "L dh in", 20: "L cell", 21: "L parts out"}
 fwd = {32: "A top", 33: "A q parts in", 34: "A q", 36: "A sums", 37: "A ctx out",
        48: "L top", 49: "L h in", 50: "L h U done", 51: "L ctx in", 53: "L ctx W done", 54: "L synced", 55: "L gates",
        52: "L h out", 56: "L end barrier", 57: "L q part", 58: "L q out"}
-print("backward attention: polls of the parts by thread 0 in that step:", t[8] + 1)
+print("backward attention: polls of the parts by thread 0 in that step:", t[8] + 1, "; returns at (ns after the first):",
+      [(x - t[40]) * 10 for x in t[40:40 + min(t[8] + 1, 14)]], "first return", (t[40] - t[7]) * 10, "ns after the poll started,",
+      (t[40] - t[21]) * 10, "ns after the LSTM workgroup's publish")
 for title, names in (("forward chain, step 5", fwd), ("backward chain, step 5", bwd)):
     base = min(t[k] for k in names if t[k])
     print(title)
@@ -39,3 +41,20 @@ for role, name in enumerate(("forward attention (mark: h in)", "forward LSTM (ma
     print(f"{name}: entry -> barrier {(s[1] - s[0]) * 10} ns, -> first mark {(marks[0] - s[0]) * 10} ns; step periods (ns): "
           + " ".join(str((b - a) * 10) for a, b in zip(marks, marks[1:]))
           + f"; last mark -> loop done {(s[38] - marks[-1]) * 10} ns -> stored {(s[39] - s[38]) * 10} ns; entry -> stored {(s[39] - s[0]) * 10} ns")
+
+pb = (ctypes.c_ulonglong * 320)()
+lib.tnt_debug_lc_pub.argtypes = [ctypes.c_void_p]
+assert lib.tnt_debug_lc_pub(pb) == 0
+pb = list(pb)
+base = min(x for x in pb if x > 1000)
+print("backward step 5, row block 0, ns after the earliest mark:")
+print("  LSTM workgroups: step top     ", [(x - base) * 10 for x in pb[96:112]])
+print("  LSTM workgroups: pushed       ", [(x - base) * 10 for x in pb[128:144]])
+print("  gather loop left by wave 0    ", [(x - base) * 10 for x in pb[192:208]])
+print("  gather loop left by wave 4    ", [(x - base) * 10 for x in pb[224:240]])
+print("  gather loop left by wave 8    ", [(x - base) * 10 for x in pb[256:272]])
+print("  gather rounds of wave 4       ", pb[288:304])
+print("  LSTM workgroups: gathered     ", [(x - base) * 10 for x in pb[160:176]])
+print("  LSTM workgroups: dh_att in    ", [(x - base) * 10 for x in pb[0:16]])
+print("  LSTM workgroups: parts out    ", [(x - base) * 10 for x in pb[32:48]])
+print("  attention workgroups: dq out  ", [(x - base) * 10 for x in pb[64:72]])
