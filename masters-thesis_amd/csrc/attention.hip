@@ -2173,8 +2173,8 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
     // publish") also waited for the loads, and the tiles of the waves that own epilogue threads -- those for the first eight
     // workgroups -- were published an HBM latency late; those workgroups ran 1-2 us behind the others for the whole chain
     // (profiles/r03_lc_trace.txt) and set its period.
-    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float cval = 0.f, cprev = 0.f, dout_t = 0.f, okeep = 1.f;
+    float4 g4;
+    float cval, cprev, dout_t, okeep = 1.f;
     {
       LC_TID(t0);
       if (t0 < 16 * D && i > 0) {
@@ -2186,17 +2186,19 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
         const unsigned xoff = (unsigned)(((((w * 2 + (cg >> 2)) * 32) * 256) + (rg * 16 + (cg & 3) * 4 + xj) * 4) * 4);
         lc_st4(xw_rsrc, sent4, xoff, (unsigned)((((((T - 2 - i + 1) % 3) * nrb + rb) * 32 * 32) + 2 * j) * 1024));
       }
+      LCT(23);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      LCT(24);
+      // The four loads are UNCONDITIONAL (lanes without an epilogue element aim past the end of the buffers and receive zeros): as
+      // the body of an `if` their results met the defaults in copies at the join, and the compiler waited for the loads -- an HBM
+      // latency, 0.8 us -- right here for the copies' sake.  For the same reason the values are laundered where the cell backward
+      // takes them up (the first instructions of tanh(c) had been hoisted up here, behind the load).
       const int erow0 = (t0 & 255) >> 4, eb0 = rb * RB + erow0;
-      if (t0 < 512 && erow0 < RB && eb0 < B) {
-        const unsigned ee0 = (unsigned)(eb0 * U + (2 * j + (t0 >> 8)) * 16 + (t0 & 15));
-        g4 = lc_ld4(gt_rsrc, ee0 * 16u, (unsigned)i * BU4 * 4u);
-        cval = lc_ld1(cs_rsrc, ee0 * 4u, (unsigned)(i + 1) * BU4); cprev = lc_ld1(cs_rsrc, ee0 * 4u, (unsigned)i * BU4);
-        dout_t = lc_ld1(do_rsrc, ee0 * 4u, (unsigned)i * BU4);
-        // (Dropout' of the LSTM outputs: the Philox call sits here, in front of every wait; its factor meets dout in the cell
-        // backward -- a use of the loaded value up here would stall the step's top on the load's HBM latency)
-        if (a.rate_out > 0.f) okeep = tnt_keep((uint64_t)ee0, a.rate_out, a.att.seed, a.site_out0 + (uint32_t)i, step_l) ? oscale : 0.f;
-      }
+      const bool ok0 = t0 < 512 && erow0 < RB && eb0 < B;
+      const unsigned ee0 = ok0 ? (unsigned)(eb0 * U + (2 * j + (t0 >> 8)) * 16 + (t0 & 15)) : 0x07FFFFF0u;     // x 16 bytes: past every buffer
+      g4 = lc_ld4(gt_rsrc, ee0 * 16u, (unsigned)i * BU4 * 4u);
+      cval = lc_ld1(cs_rsrc, ee0 * 4u, (unsigned)(i + 1) * BU4); cprev = lc_ld1(cs_rsrc, ee0 * 4u, (unsigned)i * BU4);
+      dout_t = lc_ld1(do_rsrc, ee0 * 4u, (unsigned)i * BU4);
     }
     LCT(16);
 #ifdef TNT_LC_TRACE
@@ -2239,6 +2241,17 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
 #ifdef TNT_LC_TRACE
         if (tid == 0 && rb == 0 && i == LCT_STEP) lc_pub[4][j] = wall_clock64();
 #endif
+        // (Dropout' of the LSTM outputs: the Philox call -- ~0.8 us of a SIMD for the waves that own epilogue threads: quarter-
+        // rate integer multiplies -- sits HERE, behind the push, while the tiles of the other workgroups are on their way; at the
+        // step's top it delayed exactly those waves' tiles, i.e. the gathers of the workgroups they are for.  Its factor meets dout
+        // in the cell backward.)
+        if (a.rate_out > 0.f) {
+          LC_TID(tk);
+          const int erowk = (tk & 255) >> 4, ebk = rb * RB + erowk;
+          if (tk < 512 && erowk < RB && ebk < B)
+            okeep = tnt_keep((uint64_t)(unsigned)(ebk * U + (2 * j + (tk >> 8)) * 16 + (tk & 15)), a.rate_out, a.att.seed,
+                             a.site_out0 + (uint32_t)i, step_l) ? oscale : 0.f;
+        }
         // ---- gather the 16 partial tiles (one per source workgroup) of each of this workgroup's two blocks: wave w takes
         // source w (both blocks' loads in flight together; `red` holds [2][NWB][256]); only lanes 0..31 of a tile hold rows < 8
         {
@@ -2310,6 +2323,8 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
             if (xl) *reinterpret_cast<float4*>(xslot(par, w * NTW + t, 2 * j + q)) = make_float4(acc[q][t][0], acc[q][t][1], acc[q][t][2], acc[q][t][3]);
       }
         LCT(17);
+        if (eok && a.rate_out > 0.f)
+          okeep = tnt_keep((uint64_t)ee, a.rate_out, a.att.seed, a.site_out0 + (uint32_t)i, step_l) ? oscale : 0.f;
         {
           const unsigned base = (unsigned)((((par * nrb + rb) * 32 + 2 * j) * 32) * 1024) + (unsigned)lane * 16u;
           float4 p[2][2];
@@ -2382,6 +2397,13 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       }
       LCT(19);
     }
+    if (i == T - 1 && a.rate_out > 0.f) {                   // the first step of the chain has no push to sit behind
+      LC_TID(tk);
+      const int erowk = (tk & 255) >> 4, ebk = rb * RB + erowk;
+      if (tk < 512 && erowk < RB && ebk < B)
+        okeep = tnt_keep((uint64_t)(unsigned)(ebk * U + (2 * j + (tk >> 8)) * 16 + (tk & 15)), a.rate_out, a.att.seed,
+                         a.site_out0 + (uint32_t)i, step_l) ? oscale : 0.f;
+    }
     // ---- cell backward (the arithmetic of bwd_epilogue, lstm.hip)
 #ifdef TNT_LC_TRACE
     if (tid == 512 && rb == 0 && i == LCT_STEP) lc_pub[0][j] = wall_clock64();
@@ -2390,6 +2412,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
     float4 dz_keep = make_float4(0.f, 0.f, 0.f, 0.f);
     {
       LC_TID(t5);
+      asm volatile("" : "+v"(g4.x), "+v"(g4.y), "+v"(g4.z), "+v"(g4.w), "+v"(cval), "+v"(cprev), "+v"(dout_t));
       const int erow5 = (t5 & 255) >> 4, ecol5 = t5 & 15, eq5 = t5 >> 8;
       if (t5 < 512 && erow5 < RB && rb * RB + erow5 < B) {
         if (i < T - 1) da += dha_l[erow5 * 36 + eq5 * 16 + ecol5];
@@ -2451,6 +2474,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       if (t8 < 512 && erow8 < RB && eb8 < B)
         lc_st4(dz_rsrc, dz_keep, (unsigned)(eb8 * U + (2 * j + (t8 >> 8)) * 16 + (t8 & 15)) * 16u, (unsigned)i * BU4 * 4u);
     }
+    LCT(25);
   }
 #undef LC_TID
   if (ub == 16) LCT_DUMP(16, 32);

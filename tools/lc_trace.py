@@ -16,7 +16,7 @@ lib.tnt_debug_lc_trace.argtypes = [ctypes.c_void_p]
 assert lib.tnt_debug_lc_trace(buf) == 0
 t = list(buf)
 bwd = {0: "A top", 7: "A poll starts", 1: "A parts in", 2: "A dctx", 3: "A dalpha + dot", 4: "A dot summed", 5: "A scores' + dq sums", 6: "A dq out",
-       16: "L top", 17: "L pushed", 18: "L gathered", 19: "L dh in", 20: "L cell", 21: "L parts out"}
+       16: "L top", 17: "L pushed", 18: "L gathered", 19: "L dh in", 20: "L cell", 21: "L parts out", 25: "L step end", 23: "L resets issued", 24: "L resets drained"}
 fwd = {32: "A top", 33: "A q parts in", 34: "A q", 36: "A sums", 37: "A ctx out",
        48: "L top", 49: "L h in", 50: "L h U done", 51: "L ctx in", 53: "L ctx W done", 54: "L synced", 55: "L gates",
        52: "L h out", 56: "L end barrier", 57: "L q part", 58: "L q out"}
