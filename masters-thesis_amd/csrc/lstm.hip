@@ -672,7 +672,8 @@ struct LstmSeqBwdArgs {
 };
 
 constexpr int SB_DZLD = 68;                                   // row stride of the dz tile in LDS (16-byte rows, 68 % 64 == 4)
-constexpr int SB_LDS_BYTES = 82 * 1024;      // uses 16*68 + 16*256 + 4 floats; > half of the CU's 160 KB requested: one workgroup per CU
+constexpr int SB_LDS_BYTES = 131 * 1024;     // the loop uses 16*68 + 16*256 + 4 floats, the prologue stages the recurrent kernel's slab
+                                             // (512 x 65 floats) here; > half of the CU's 160 KB requested: one workgroup per CU
 
 // POLL: as in lstm_seq_fwd_kernel<POLL> the pushed tiles are their own flags.  The exchange area is a ring of THREE
 // buffers; exchange t (step s = S - 2 - t) uses buffer t % 3.  The thread that writes a 16-byte chunk (dest, src = its
@@ -718,13 +719,34 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
   const int x_rg = lane >> 5, x_cg = (lane >> 2) & 7, x_j = lane & 3;
   float bx[2][8][2];                       // [k half][abid = k quad][m pair]
   if (RB == 8) {
-    const float* src = a.Ur + ((long)(w * 32 + x_cg * 4 + x_j) * U + ub * 16) * 4;
+    // A lane's 32 operands are 64 consecutive floats of ONE row of Ur (every other one), a different row per lane: read
+    // straight from memory that is 32 load instructions of 32 cache lines each per wave, the CU's one address path serialising
+    // 16 waves (the same pattern cost the attention model's backward chain 20 us of prologue).  Staged instead: the block's
+    // [512 rows][64] slab comes in with coalesced 16-byte loads, is parked in the dynamic LDS block (free until the loop starts;
+    // row stride 65: the 32 rows a wave reads side by side fall into 32 banks) and each lane picks its operands there.
+    constexpr int ULD = 65;
+    static_assert(512 * ULD * 4 + 16 <= SB_LDS_BYTES, "the staging slab must fit the dynamic LDS block");
+    float4 st[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = tid + 1024 * k;                          // chunk c: row c / 16, floats 4 (c % 16) .. + 3
+      st[k] = *reinterpret_cast<const float4*>(a.Ur + ((long)(c >> 4) * U + ub * 16) * 4 + (c & 15) * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = tid + 1024 * k;
+      float* d = sb_lds + (c >> 4) * ULD + (c & 15) * 4;
+      d[0] = st[k].x; d[1] = st[k].y; d[2] = st[k].z; d[3] = st[k].w;
+    }
+    __syncthreads();
+    const float* src = sb_lds + (w * 32 + x_cg * 4 + x_j) * ULD;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
       for (int q = 0; q < 8; ++q)
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) bx[kh][q][pr] = src[kh * 32 + 4 * q + 2 * pr + x_rg];
+    __syncthreads();                                         // ... before the block is carved up below
   } else {
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
