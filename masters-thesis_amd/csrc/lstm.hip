@@ -789,15 +789,23 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
     LST(8);
     // epilogue operands of this step do not depend on the chain: fetch them first
     const bool seq = s >= a.mask_s0;
-    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float cval = 0.f, cprev = 0.f, dout_t = 0.f;
+    // Epilogue operands of the step (gates, cell states, dout, the mask id: they come from HBM).  The loads are unconditional
+    // (lanes without an epilogue element read element 0) and their values are laundered where the cell backward takes them up:
+    // as the body of an `if`, or with a use up here (the compare of the mask id), the compiler waits for them at the step's top.
+    // They are issued BEHIND the push (`epi_loads` below): the memory counter is in-order, so in front of it the drain that the
+    // tile stores need would also wait for them, and the tiles of the waves that own epilogue threads would leave an HBM
+    // latency late.  Behind the push the first poll of the gather waits for them instead, a wait that is there anyway.
+    const long ees = eok ? ee : 0;
+    float4 g4;
+    float cval, cprev, dout_t = 0.f;
     int mid = 1;
-    if (eok) {
-      g4 = *reinterpret_cast<const float4*>(a.gates + ((long)s * BU + ee) * 4);
-      cval = a.cs[(long)(s + 1) * BU + ee]; cprev = a.cs[(long)s * BU + ee];
-      if (seq && a.dout_seq) dout_t = a.dout_seq[(long)(s - a.mask_s0) * BU + ee];
-      if (seq && a.mask_ids) mid = a.mask_ids[eb * a.mask_T + (s - a.mask_s0)];
-    }
+    auto epi_loads = [&]() {
+      g4 = *reinterpret_cast<const float4*>(a.gates + ((long)s * BU + ees) * 4);
+      cval = a.cs[(long)(s + 1) * BU + ees]; cprev = a.cs[(long)s * BU + ees];
+      if (seq && a.dout_seq) dout_t = a.dout_seq[(long)(s - a.mask_s0) * BU + ees];
+      if (seq && a.mask_ids) mid = a.mask_ids[(eok ? eb : 0) * a.mask_T + (s - a.mask_s0)];
+    };
+    if (s == S - 1) epi_loads();                             // the first step of the chain has no push
     float da = da_c;
     if (s < S - 1) {
       const int xt = S - 2 - s, par = xt % 3;
@@ -844,6 +852,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
         for (int j = 0; j < NTW; ++j)
           if (xl) *reinterpret_cast<float4*>(xslot(par, w * NTW + j)) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
       }
+      epi_loads();
       LST(9);
       if (!POLL) tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, S - 1 - s), err);
       // ---- gather the 32 partial tiles of this workgroup's block (sc1 loads: stored by other workgroups): wave w sums
@@ -880,6 +889,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
       }
     }
     // ---- cell backward (same arithmetic as bwd_epilogue of the per-step kernel)
+    asm volatile("" : "+v"(g4.x), "+v"(g4.y), "+v"(g4.z), "+v"(g4.w), "+v"(cval), "+v"(cprev), "+v"(dout_t), "+v"(mid));
     if (eok) {
       const bool m = mid != 0;
       const float dout = (seq ? dout_c : 0.f) + dout_t;
