@@ -35,17 +35,19 @@ MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak
 # HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes), by call
 # group; filled from the summaries committed under profiles/ (None = not collected for that kernel)
 _PMC3 = "profiles/r03_pmc_gemm3_and_chains.txt"
+_PMC3C = "profiles/r03_pmc_chains_end_of_round.txt"         # the chain kernels as they stand at the end of the round
 _kib = lambda fetch, write: int((2 * fetch + write) * 1024)
 PMC_TRAFFIC = {
     "dense": {"tnt_gemm3_pair_f32 TN 512x5001x960 + NT 960x512x5001": (_kib(69608.1, 23574.0), _PMC3),
               "tnt_gemm3_pair_f32 TN 512x2048x1024 x2 + NT 1024x512x2048": (_kib(54473.9, 14344.0), _PMC3),
               "tnt_gemm3_f32 NN 960x5001x512": (_kib(13164.1, 18885.0), _PMC3),
               "tnt_gemm3_f32 NN 1024x2048x512": (_kib(10295.9, 8192.0), _PMC3),
-              "tnt_lstm_seq_fwd_f32 S=16 B=64 U=512": (_kib(21653.7, 14246.0), _PMC3),
-              "tnt_lstm_seq_bwd_f32 S=16 B=64 U=512": (_kib(28718.9, 25361.4), _PMC3),
-              "tnt_dense_dw_adam_f32 20000x512x64": (_kib(66176.8, 120000.0), _PMC3)},
-    "attention": {"tnt_lc_seq_fwd_drop_f32 T=15 B=64 R=360 U=512": (_kib(28285.7, 23898.2), _PMC3),
-                  "tnt_lc_seq_bwd_drop_f32 T=15 B=64 R=360 U=512": (_kib(35049.0, 44758.7), _PMC3),
+              "tnt_lstm_seq_fwd_f32 S=16 B=64 U=512": (_kib(21652.8, 14235.6), _PMC3C),
+              "tnt_lstm_seq_bwd_f32 S=16 B=64 U=512": (_kib(28751.5, 23251.5), _PMC3C),
+              "tnt_dense_dw_adam_f32 20000x512x64": (_kib(66176.8, 120000.0), _PMC3),
+              "tnt_dense_dw_adam_fin_f32 20000x512x64": (_kib(66176.8, 120000.0), _PMC3)},      # the same kernel and operands
+    "attention": {"tnt_lc_seq_fwd_drop_f32 T=15 B=64 R=360 U=512": (_kib(27241.6, 15567.1), _PMC3C),
+                  "tnt_lc_seq_bwd_drop_f32 T=15 B=64 R=360 U=512": (_kib(32035.7, 41471.2), _PMC3C),
                   "tnt_gemm3_pair_f32 TN 256x5001x960 + NT 960x256x5001": (_kib(62224.7, 21897.9), _PMC3),
                   "tnt_gemm3_pair_f32 TN 512x2048x960 x2 + NT 960x512x2048": (_kib(51075.9, 13960.0), _PMC3),
                   "tnt_gemm3_f32 NN 960x5001x256": (_kib(6616.8, 18885.0), _PMC3)},
@@ -200,6 +202,9 @@ def _work_model(name, a):
     if name == "tnt_dense_dw_adam_f32":          # ... and clip + Adam on it: theta, m, v read and written, g never stored
         Nq, Eq, Bk = a[14], a[15], a[16]
         return f"{name} {Nq}x{Eq}x{Bk}", 2.0 * Nq * Eq * Bk, 4.0 * (6 * Nq * Eq + Bk * Nq + Bk * Eq)
+    if name == "tnt_dense_dw_adam_fin_f32":      # the same launch without a finalize launch in front (partial, k0, k1 replace sq)
+        Nq, Eq, Bk = a[16], a[17], a[18]
+        return f"{name} {Nq}x{Eq}x{Bk}", 2.0 * Nq * Eq * Bk, 4.0 * (6 * Nq * Eq + Bk * Nq + Bk * Eq)
     if name == "tnt_softmax_cce_f32":
         rows, ld = a[6], a[8]
         return f"{name} {rows}x{a[7]}", 0.0, 8.0 * rows * ld
@@ -235,9 +240,9 @@ def kernel_breakdown(model, batch, workload, reps=20, limit=12):
     groups = {}
     for fn, name, args in rec:
         key, fl, by = _work_model(name, args)
-        if name == "tnt_adam_f32":
+        if name in ("tnt_adam_f32", "tnt_adam_ring_f32", "tnt_adam_fin_f32"):
             fl, by = 0.0, 28.0 * n_param
-        elif name in ("tnt_seg_sqnorm_f32", "tnt_span_sqnorm_f32"):
+        elif name in ("tnt_seg_sqnorm_f32", "tnt_span_sqnorm_f32", "tnt_span_sqnorm_lr_f32"):
             fl, by = 0.0, 8.0 * n_param
         g = groups.setdefault(key, {"calls": 0, "fn": fn, "args": args, "flops": fl, "bytes": by})
         g["calls"] += 1

@@ -1903,7 +1903,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
           const bool ok = __float_as_uint(v.x) != LC_SENTINEL && __float_as_uint(v.y) != LC_SENTINEL &&
                           __float_as_uint(v.z) != LC_SENTINEL && __float_as_uint(v.w) != LC_SENTINEL;
 #ifdef TNT_LC_TRACE
-          if (tid == 0 && rb == 0 && i == LCT_STEP && spins < 14) lct_l[40 + spins] = wall_clock64();      // every poll's return
+          if (tid == 0 && rb == 0 && i == LCT_STEP && spins < 6) lct_l[26 + spins] = wall_clock64();       // the first polls' returns
 #endif
           if (ok) break;                                     // per lane: a lane leaves the loop when ITS chunk is in
           if (++spins > TNT_SEQ_SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
@@ -2036,7 +2036,7 @@ __global__ __launch_bounds__(1024) void lc_seq_bwd_kernel(LcSeqBwdArgs a) {
       }
       if (tid == 0) g.dvb[(long)ab * (A + 1) + A] = dbv;
     }
-    if (ub == 0) { LCT_DUMP(0, 16); LCT_DUMP(40, 56); }
+    if (ub == 0) { LCT_DUMP(0, 16); LCT_DUMP(26, 32); }
     LCS(39);
     if (ub == 0) LCS_DUMP(2);
     tnt_seq_leave(a.sync, xcc, a.guard_out);

@@ -20,9 +20,9 @@ bwd = {0: "A top", 7: "A poll starts", 1: "A parts in", 2: "A dctx", 3: "A dalph
 fwd = {32: "A top", 33: "A q parts in", 34: "A q", 36: "A sums", 37: "A ctx out",
        48: "L top", 49: "L h in", 50: "L h U done", 51: "L ctx in", 53: "L ctx W done", 54: "L synced", 55: "L gates",
        52: "L h out", 56: "L end barrier", 57: "L q part", 58: "L q out"}
-print("backward attention: polls of the parts by thread 0 in that step:", t[8] + 1, "; returns at (ns after the first):",
-      [(x - t[40]) * 10 for x in t[40:40 + min(t[8] + 1, 14)]], "first return", (t[40] - t[7]) * 10, "ns after the poll started,",
-      (t[40] - t[21]) * 10, "ns after the LSTM workgroup's publish")
+print("backward attention: polls of the parts by thread 0 in that step:", t[8] + 1, "; the first ones return at (ns after the first):",
+      [(x - t[26]) * 10 for x in t[26:26 + min(t[8] + 1, 6)]], "; first return", (t[26] - t[7]) * 10, "ns after the poll started,",
+      (t[26] - t[21]) * 10, "ns after the traced LSTM workgroup's publish")
 for title, names in (("forward chain, step 5", fwd), ("backward chain, step 5", bwd)):
     base = min(t[k] for k in names if t[k])
     print(title)

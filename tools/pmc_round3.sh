@@ -12,7 +12,7 @@ for wl in dense attention; do
 done
 cd $R
 for wl in dense attention; do
-  for k in gemm3_pair_kernel gemm3_kernel lstm_seq_fwd_kernel lstm_seq_bwd_kernel lc_seq_fwd_kernel lc_seq_bwd_kernel dense_dw_skinny_kernel adam_kernel; do
+  for k in gemm3_pair_kernel gemm3_kernel lstm_seq_fwd_kernel lstm_seq_bwd_kernel lc_seq_fwd_kernel lc_seq_bwd_kernel dense_dw_skinny_kernel adam_fin_kernel; do
     echo "== $wl $k"; for p in a b c; do python3 tools/pmc_summary.py gpurun_out/pmc3/${wl}_$p $k; done
   done
 done > gpurun_out/pmc3/summary.txt
