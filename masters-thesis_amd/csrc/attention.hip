@@ -348,18 +348,23 @@ __device__ __forceinline__ float block_max_w(float v, float* sh) {
   __syncthreads();
   return r;
 }
-// sum of v over the lanes of a wave that share (lane % G): xor offsets G, 2G, ..., 32
+// sum of v over the lanes of a wave that share (lane % G): xor offsets G, 2G, ..., 32 (DPP / permlane forms, tnt_common.h: exact)
 template <int G>
 __device__ __forceinline__ float stride_sum(float v) {
-#pragma unroll
-  for (int o = G; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  static_assert(G == 8 || G == 16, "lanes per row group");
+  if (G == 8) v += tnt_ror<8>(v);
+  v = tnt_x16_add(v);
+  v = tnt_x32_add(v);
   return v;
 }
-// sum over a group of G adjacent lanes
+// sum over a group of G adjacent lanes, in every lane of the group: 1, 2 exact, then the mirrors (each half already uniform)
 template <int G>
 __device__ __forceinline__ float adj_sum(float v) {
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  static_assert(G == 4 || G == 8 || G == 16, "adjacent lanes per group");
+  v += tnt_x1(v);
+  v += tnt_x2(v);
+  if (G >= 8) v += tnt_hmirror(v);
+  if (G >= 16) v += tnt_mirror(v);
   return v;
 }
 

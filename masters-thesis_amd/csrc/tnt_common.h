@@ -54,14 +54,51 @@ __device__ __forceinline__ float tnt_tanh(float x) {
 // step there, ~0.4 us of a 6.6 us step).
 __device__ __forceinline__ float tnt_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
-// wave-wide (64 lanes) reductions
+// ---- cross-lane exchange without the LDS crossbar.  `__shfl_xor` compiles to ds_bpermute_b32: an LDS-pipe instruction with an
+// address register and ~100 cycles of latency, three to six of them chained in every reduction of the step kernels and the
+// chains.  The DPP forms ride in the VALU instruction itself (v_add_f32_dpp), the gfx950 permlane swaps are one VALU op.
+//   tnt_x1 / tnt_x2     partner lane ^ 1, lane ^ 2            (quad_perm: exact)
+//   tnt_ror<N>          partner (lane + N) % 16 inside the row of 16; = lane ^ 8 for N = 8, and equal in VALUE to lane ^ N for
+//                       N = 4, 2, 1 once the values are periodic in the row with period 2 N (the state of a butterfly reduction
+//                       after its larger steps)
+//   tnt_hmirror / tnt_mirror   partner 7 - i inside the half row / 15 - i inside the row: the other half's value once each half
+//                       (8 lanes / 16 lanes ... ) is uniform, i.e. as the LAST steps of a reduction over adjacent lanes
+//   tnt_x16_add / tnt_x32_add  v + v[lane ^ 16], v + v[lane ^ 32]   (v_permlane16_swap / v_permlane32_swap: exact)
+template <int CTRL>
+__device__ __forceinline__ float tnt_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float tnt_x1(float v) { return tnt_dpp<0xB1>(v); }          // quad_perm:[1,0,3,2]
+__device__ __forceinline__ float tnt_x2(float v) { return tnt_dpp<0x4E>(v); }          // quad_perm:[2,3,0,1]
+template <int N> __device__ __forceinline__ float tnt_ror(float v) { return tnt_dpp<0x120 + N>(v); }   // row_ror:N
+__device__ __forceinline__ float tnt_hmirror(float v) { return tnt_dpp<0x141>(v); }    // row_half_mirror
+__device__ __forceinline__ float tnt_mirror(float v) { return tnt_dpp<0x140>(v); }     // row_mirror
+__device__ __forceinline__ float tnt_x16_add(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float tnt_x32_add(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float tnt_x16_max(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float tnt_x32_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// wave-wide (64 lanes) reductions: the butterfly 32, 16, 8, 4, 2, 1 -- the same partners' VALUES, in the same order, as the
+// __shfl_xor form it replaces (bit-identical results)
 __device__ __forceinline__ float tnt_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = tnt_x32_add(v); v = tnt_x16_add(v);
+  v += tnt_ror<8>(v); v += tnt_ror<4>(v); v += tnt_x2(v); v += tnt_x1(v);
   return v;
 }
 __device__ __forceinline__ float tnt_wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = tnt_x32_max(v); v = tnt_x16_max(v);
+  v = fmaxf(v, tnt_ror<8>(v)); v = fmaxf(v, tnt_ror<4>(v)); v = fmaxf(v, tnt_x2(v)); v = fmaxf(v, tnt_x1(v));
   return v;
 }
