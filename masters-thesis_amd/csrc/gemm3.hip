@@ -741,10 +741,14 @@ extern "C" int32_t tnt_gemm3_f32(const float* A, const float* B, float* C, const
 }
 
 // Pair launches exist for the combinations a training step has back to back: a TN product (a kernel gradient, with its
-// riders) on tile 4 or 5 followed by an independent NT product (an input gradient) on tile 7 or 5.
+// riders) on tile 4, 5 or 7 followed by an independent NT product (an input gradient) on tile 7 or 5, and two independent TN
+// products (two small kernel gradients of the same step) on tiles 5 / 7.
 extern "C" int32_t tnt_gemm3_pair_supported(int32_t tile1, int32_t transA1, int32_t transB1, int32_t tile2, int32_t transA2,
                                             int32_t transB2) {
-  return (transA1 && !transB1 && (tile1 == 4 || tile1 == 5) && !transA2 && transB2 && (tile2 == 7 || tile2 == 5)) ? 1 : 0;
+  const bool tn1 = transA1 && !transB1, tn2 = transA2 && !transB2, nt2 = !transA2 && transB2;
+  if (tn1 && nt2) return ((tile1 == 4 || tile1 == 5 || tile1 == 7) && (tile2 == 7 || tile2 == 5)) ? 1 : 0;
+  if (tn1 && tn2) return ((tile1 == 5 || tile1 == 7) && (tile2 == 5 || tile2 == 7)) ? 1 : 0;
+  return 0;
 }
 
 extern "C" int32_t tnt_gemm3_pair_f32(const tnt_gemm3_desc* p, const tnt_gemm3_desc* q, void* stream) {
@@ -761,8 +765,17 @@ extern "C" int32_t tnt_gemm3_pair_f32(const tnt_gemm3_desc* p, const tnt_gemm3_d
   using TN5 = G3Cfg<false, false, 2, 4, 2, 2, 32, 3>;
   using NT7 = G3Cfg<true, true, 2, 2, 2, 2, 32, 3>;
   using NT5 = G3Cfg<true, true, 2, 4, 2, 2, 32, 3>;
+  using TN7 = G3Cfg<false, false, 2, 2, 2, 2, 32, 3>;
+  if (q->transA) {                                           // TN + TN
+    if (p->tile == 5 && q->tile == 5) return g3_launch_pair<TN5, TN5>(a, b, s);
+    if (p->tile == 5 && q->tile == 7) return g3_launch_pair<TN5, TN7>(a, b, s);
+    if (p->tile == 7 && q->tile == 5) return g3_launch_pair<TN7, TN5>(a, b, s);
+    return g3_launch_pair<TN7, TN7>(a, b, s);
+  }
   if (p->tile == 4 && q->tile == 7) return g3_launch_pair<TN4, NT7>(a, b, s);
   if (p->tile == 4 && q->tile == 5) return g3_launch_pair<TN4, NT5>(a, b, s);
   if (p->tile == 5 && q->tile == 7) return g3_launch_pair<TN5, NT7>(a, b, s);
-  return g3_launch_pair<TN5, NT5>(a, b, s);
+  if (p->tile == 5 && q->tile == 5) return g3_launch_pair<TN5, NT5>(a, b, s);
+  if (p->tile == 7 && q->tile == 7) return g3_launch_pair<TN7, NT7>(a, b, s);
+  return g3_launch_pair<TN7, NT5>(a, b, s);
 }

@@ -616,6 +616,7 @@ class NIC(ModelBase):
         n = T * B
         sd, ds = self.seed, self.drop_step
         dlog, inter, hs = self.logits, self._inter_used, self._hs_used
+        dhs_done = False
         # kernel gradient and input gradient of the softmax layer, the two independent readers of dlogits: ONE launch
         if not (getattr(self, "g3_riders", True) and self.gemm3_pair(
                 dict(A=inter, B=dlog, C=a.g("time_distributed_softmax/kernel"), M=H, N=V, K=n, lda=H, ldb=ldV, ldc=ldV, transA=True),
@@ -629,7 +630,15 @@ class NIC(ModelBase):
             be.bias_act_drop_bwd(self.dinter, self.ipre, self.dinter, a.g("time_distributed_nonlinear/bias"), n, H, H,
                                  ACT_LEAKY, 0.2, B, H, 0, self.r_out, sd, S_OUT, ds,
                                  extra=(dlog, a.g("time_distributed_softmax/bias"), n, V, ldV))
-            self.gemm_sk(hs, self.dinter, a.g("time_distributed_nonlinear/kernel"), U, H, n, U, H, H, transA=True)
+            # kernel gradient and input gradient of the nonlinear layer, the two readers of dinter: ONE launch
+            if getattr(self, "g3_riders", True) and self.gemm3_pair(
+                    dict(A=hs, B=self.dinter, C=a.g("time_distributed_nonlinear/kernel"), M=U, N=H, K=n, lda=U, ldb=H, ldc=H,
+                         transA=True, small=True),
+                    dict(A=self.dinter, B=a.p("time_distributed_nonlinear/kernel"), C=self.dHs, M=n, N=U, K=H, lda=H, ldb=H, ldc=U,
+                         transB=True, small=True)):
+                dhs_done = True
+            else:
+                self.gemm_sk(hs, self.dinter, a.g("time_distributed_nonlinear/kernel"), U, H, n, U, H, H, transA=True)
         else:
             be.colsum(dlog, a.g("time_distributed_softmax/bias"), n, V, ldV, self.work)
             if self.r_out > 0:
@@ -637,7 +646,8 @@ class NIC(ModelBase):
             be.act_bwd(self.ipre, self.dinter, self.dinter, n * H, ACT_LEAKY, 0.2)
             self.gemm_sk(hs, self.dinter, a.g("time_distributed_nonlinear/kernel"), U, H, n, U, H, H, transA=True)
             be.colsum(self.dinter, a.g("time_distributed_nonlinear/bias"), n, H, H, self.work)
-        self.gemm_sk(self.dinter, a.p("time_distributed_nonlinear/kernel"), self.dHs, n, U, H, H, H, U, transB=True)
+        if not dhs_done:
+            self.gemm_sk(self.dinter, a.p("time_distributed_nonlinear/kernel"), self.dHs, n, U, H, H, H, U, transB=True)
         self._dout_masked = not (self.r_lstm > 0 and self._lc_seq_bwd_ok() and (int(getattr(self, "fuse_out_drop", 3)) & 2))
         if self.r_lstm > 0 and self._dout_masked:           # (else Dropout' rides in the backward chain: tnt_lc_seq_bwd_drop_f32)
             be.dropout(self.dHs, self.dHs, n, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds, rows_per_site=B)
@@ -680,7 +690,14 @@ class NIC(ModelBase):
             # the four readers of dZ that fill the chip -- recurrent-kernel gradient, the text rows of the kernel gradient (+ the
             # bias gradient as a rider) and the text-input gradient (_bwd_emb finds it done) -- in ONE launch
             self._dtext_done = True
-            self.gemm_sk(self.ctx_d, self.dZ, gWl[:D], D, 4 * U, n, D, 4 * U, 4 * U, transA=True)
+            # ... and the two small kernel gradients that only need the chain's outputs -- the context rows of the LSTM kernel
+            # and the attention's W2 -- in one launch behind it
+            self._dw2_done = bool(self.gemm3_pair(
+                dict(A=self.ctx_d, B=self.dZ, C=gWl[:D], M=D, N=4 * U, K=n, lda=D, ldb=4 * U, ldc=4 * U, transA=True, small=True),
+                dict(A=hprev, B=self.dqpre, C=a.g("attention/W2/kernel"), M=U, N=A, K=n, lda=U, ldb=A, ldc=A, transA=True,
+                     small=True)))
+            if not self._dw2_done:
+                self.gemm_sk(self.ctx_d, self.dZ, gWl[:D], D, 4 * U, n, D, 4 * U, 4 * U, transA=True)
             return
         if getattr(self, "g3_riders", True) and Et == U and self.gemm3(
                 hprev, self.dZ, a.g("lstm/recurrent_kernel"), U, 4 * U, n, U, 4 * U, 4 * U, transA=True,
@@ -794,7 +811,8 @@ class NIC(ModelBase):
         sd, ds = self.seed, self.drop_step
         hprev = self.Hs[:T].view(n, U)
         # attention parameters
-        self.gemm_sk(hprev, self.dqpre, a.g("attention/W2/kernel"), U, A, n, U, A, A, transA=True)
+        if not self.__dict__.pop("_dw2_done", False):
+            self.gemm_sk(hprev, self.dqpre, a.g("attention/W2/kernel"), U, A, n, U, A, A, transA=True)
         jobs = [(self.dqpre, a.g("attention/W2/bias"), n, A, A), (self.dvb, a.g("attention/V/kernel"), B, A, A + 1),
                 (self.dvb.view(-1)[A:], a.g("attention/V/bias"), B, 1, A + 1)]
         if hasattr(be, "colsum_multi") and n <= 2048 and B <= 2048:

@@ -251,6 +251,7 @@ def test_gemm3_riders(be, M, N, K):
 @pytest.mark.parametrize("shape1,shape2,t1,t2,S2", [
     ((512, 5001, 960), (960, 512, 5001), 4, 7, 2), ((512, 2048, 1024), (1024, 512, 2048), 5, 7, 2), ((256, 5001, 960), (960, 256, 5001), 4, 7, 4),
     ((64, 501, 120), (120, 64, 501), 4, 7, 1), ((64, 256, 128), (128, 64, 256), 5, 5, 2), ((37, 101, 50), (50, 37, 101), 5, 7, 1),
+    ((512, 256, 960), (960, 512, 256), 7, 7, 1), ((512, 256, 960), (960, 512, 256), 7, 5, 2),
 ])
 def test_gemm3_pair(be, shape1, shape2, t1, t2, S2):
     """tnt_gemm3_pair_f32: a TN product (second product + column sums riding along) and an independent NT product (K split
@@ -287,6 +288,41 @@ def test_gemm3_pair(be, shape1, shape2, t1, t2, S2):
         assert torch.equal(Cp, C) and torch.equal(C2p, C2) and torch.equal(colp, col) and torch.equal(Rp, R), rep
     assert int(sync.sum()) == 0 and bool((work.view(torch.int32) == 0x7FC5EED5).all())
     assert not be.gemm3_pair_supported(1, False, False, 7, False, True)
+
+
+@pytest.mark.parametrize("shape1,shape2,t1,t2,S1,S2", [((32, 2048, 960), (512, 32, 960), 5, 7, 4, 8), ((32, 2048, 960), (512, 32, 960), 7, 7, 1, 1),
+                                                        ((64, 64, 100), (20, 40, 30), 7, 5, 1, 1), ((96, 256, 512), (64, 192, 640), 5, 5, 2, 2)])
+def test_gemm3_pair_of_two_kernel_gradients(be, shape1, shape2, t1, t2, S1, S2):
+    """tnt_gemm3_pair_f32 with TWO TN products (two small kernel gradients of one step; each may split K inside the launch, on
+    its own exchange space): every output bit-identical to the same product launched on its own."""
+    outs = []
+    sync = torch.zeros(1, dtype=torch.int32, device="cuda")
+    specs = []
+    for (M, N, K), t, S, seed in ((shape1, t1, S1, 3), (shape2, t2, S2, 4)):
+        (A, _, Bm, lda, ldb, ldc), (opA, _, opB) = _g3_operands(M, N, K, 1, 0, seed)
+        wf = (be.gemm3_work_floats(M, N, t, S) + 3) // 4 * 4 if S > 1 else 0
+        if S > 1 and wf == 0:
+            pytest.skip("no split for this shape")
+        work = torch.empty(max(wf, 4), device="cuda")
+        be.gemm3_work_arm(work)
+        Ad, Bd = dev(A), dev(Bm)
+        C = torch.full((M, ldc), 5.0, device="cuda")
+        be.gemm3(Ad, Bd, C, M, N, K, lda, ldb, ldc, transA=True, tile=t, splitk=S, work=work if S > 1 else None, sync=sync if S > 1 else None)
+        close(C[:, :N], opA @ opB, rtol=1e-6 * max(1.0, (K / 256) ** 0.5))
+        specs.append((Ad, Bd, C, M, N, K, lda, ldb, ldc, t, S, work))
+    assert be.gemm3_pair_supported(t1, True, False, t2, True, False)
+    for rep in range(2):
+        ds, got = [], []
+        for Ad, Bd, C, M, N, K, lda, ldb, ldc, t, S, work in specs:
+            Cp = torch.full((M, ldc), 5.0, device="cuda")
+            got.append(Cp)
+            ds.append(be.gemm3_desc(Ad, Bd, Cp, M, N, K, lda, ldb, ldc, transA=True, tile=t, splitk=S, work=work if S > 1 else None,
+                                    sync=sync if S > 1 else None))
+        be.gemm3_pair(ds[0], ds[1])
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], specs[0][2]) and torch.equal(got[1], specs[1][2]), rep
+    assert int(sync.sum()) == 0
+    assert not be.gemm3_pair_supported(4, True, False, 7, True, False)
 
 
 def test_gemm3_plan_and_bad_arguments(be):
