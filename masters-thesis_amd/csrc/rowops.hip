@@ -1192,6 +1192,10 @@ struct BadArgs {
   const float* x1; float* out1; int rows1, C1, ld1;
 };
 
+// NARROW: a workgroup owns ONE column quad and all rows (one row, i.e. one Philox call, per thread) instead of 8 quads with
+// 7-8 rows per thread: for the few-hundred-column activations of the vocabulary head the wide form put the whole pass on
+// cols / 32 = 8 CUs, each thread walking its rows one Philox call after the other (12.7 us for 960 x 256 elements).
+template <bool NARROW>
 __global__ __launch_bounds__(1024) void bias_act_drop_bwd_kernel(BadArgs a) {
   __shared__ float4 red[128][9];
   __shared__ float sh[32][33];
@@ -1200,8 +1204,15 @@ __global__ __launch_bounds__(1024) void bias_act_drop_bwd_kernel(BadArgs a) {
     const int cl = tid & 31, rl = tid >> 5, c = (blockIdx.x - a.nb0) * 32 + cl;
     float v = 0.f;
     if (c < a.C1) {
-#pragma unroll 8
-      for (int r = rl; r < a.rows1; r += 32) v += a.x1[(long)r * a.ld1 + c];
+      // (all of a lane's loads of a round in flight together: the rows come from HBM / the MALL, and four dependent rounds of
+      // eight were four memory latencies, 8 of this launch's 12.7 us)
+      for (int r = rl; r < a.rows1; r += 32 * 32) {
+        float t[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t[k] = r + 32 * k < a.rows1 ? a.x1[(long)(r + 32 * k) * a.ld1 + c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v += t[k];
+      }
     }
     sh[rl][cl] = v;
     __syncthreads();
@@ -1215,11 +1226,12 @@ __global__ __launch_bounds__(1024) void bias_act_drop_bwd_kernel(BadArgs a) {
   }
   const DropArgs& d = a.d;
   const uint32_t step = d.step + (d.step_dev ? d.step_dev[0] : 0u);
-  const int cq = tid & 7, rl = tid >> 3, c = blockIdx.x * 32 + cq * 4;       // 8 column quads x 128 row lanes
+  const int cq = NARROW ? 0 : tid & 7, rl = NARROW ? tid : tid >> 3;         // wide: 8 column quads x 128 row lanes
+  const int c = NARROW ? blockIdx.x * 4 : blockIdx.x * 32 + cq * 4;
   const int T = d.tB > 0 ? d.rows / d.tB : 0;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < d.cols) {
-    for (int r = rl; r < d.rows; r += 128) {
+    for (int r = rl; r < d.rows; r += NARROW ? 1024 : 128) {
       const long o = (long)r * d.ld + c;
       float4 v = *reinterpret_cast<const float4*>(d.x + o);
       if (d.rate > 0.f) {
@@ -1236,6 +1248,18 @@ __global__ __launch_bounds__(1024) void bias_act_drop_bwd_kernel(BadArgs a) {
       *reinterpret_cast<float4*>(d.y + o) = v;
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
+  }
+  if (NARROW) {                                              // every lane holds the same quad: wave sums, then the 16 waves
+    acc.x = tnt_wave_sum(acc.x); acc.y = tnt_wave_sum(acc.y); acc.z = tnt_wave_sum(acc.z); acc.w = tnt_wave_sum(acc.w);
+    if ((tid & 63) == 0) red[tid >> 6][0] = acc;
+    __syncthreads();
+    if (tid == 0 && c < d.cols) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const float4 u = red[k][0]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+      *reinterpret_cast<float4*>(a.dbias + c) = t;
+    }
+    return;
   }
   red[rl][cq] = acc;
   __syncthreads();
@@ -1261,10 +1285,12 @@ extern "C" int32_t tnt_bias_act_drop_bwd_f32(const float* dy, const float* pre, 
   a.d.x = dy; a.d.y = dx; a.d.rows = rows; a.d.cols = cols; a.d.ld = ld; a.d.tB = tmajor_B; a.d.lwidth = lwidth;
   a.d.lcol0 = lcol0; a.d.rows_per_site = 0; a.d.rate = rate; a.d.scale = 1.0f / (1.0f - rate); a.d.seed = seed;
   a.d.site = site; a.d.step = 0; a.d.step_dev = step_dev;
-  a.pre = pre; a.dbias = dbias; a.act = act; a.slope = slope; a.nb0 = (cols + 31) / 32;
+  const bool narrow = cols <= 1024;                          // up to 256 workgroups of one column quad
+  a.pre = pre; a.dbias = dbias; a.act = act; a.slope = slope; a.nb0 = narrow ? cols / 4 : (cols + 31) / 32;
   a.x1 = x1; a.out1 = out1; a.rows1 = rows1; a.C1 = C1; a.ld1 = ld1;
   const int nb1 = x1 ? (C1 + 31) / 32 : 0;
-  hipLaunchKernelGGL(bias_act_drop_bwd_kernel, dim3(a.nb0 + nb1), dim3(1024), 0, tnt_stream(stream), a);
+  if (narrow) hipLaunchKernelGGL(bias_act_drop_bwd_kernel<true>, dim3(a.nb0 + nb1), dim3(1024), 0, tnt_stream(stream), a);
+  else hipLaunchKernelGGL(bias_act_drop_bwd_kernel<false>, dim3(a.nb0 + nb1), dim3(1024), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
 }

@@ -606,8 +606,12 @@ class NIC(ModelBase):
         data-parallel schedule (dp.PipelinedAttentionSync) issues one all-reduce bucket after each."""
         self._bwd_head(B, T)
         self._bwd_chain(B, T)
-        self._bwd_emb(B, T)
+        # the text branch (input Dropout', sparse Embedding scatter) and the front branch (attention parameters, BatchNorm,
+        # region-wise encoder) only share the chain's outputs: with `branch_streams` they are two parallel branches of the step
+        with self.side(0 if getattr(self, "branch_streams", False) else -1):
+            self._bwd_emb(B, T)
         self._bwd_front(B, T)
+        self.join()
 
     def _bwd_head(self, B, T):
         """vocabulary head: gradients of time_distributed_softmax / time_distributed_nonlinear, dHs."""
