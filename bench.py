@@ -42,12 +42,12 @@ PMC_TRAFFIC = {
               "tnt_gemm3_pair_f32 TN 512x2048x1024 x2 + NT 1024x512x2048": (_kib(54473.9, 14344.0), _PMC3),
               "tnt_gemm3_f32 NN 960x5001x512": (_kib(13164.1, 18885.0), _PMC3),
               "tnt_gemm3_f32 NN 1024x2048x512": (_kib(10295.9, 8192.0), _PMC3),
-              "tnt_lstm_seq_fwd_f32 S=16 B=64 U=512": (_kib(21652.8, 14235.6), _PMC3C),
-              "tnt_lstm_seq_bwd_f32 S=16 B=64 U=512": (_kib(28751.5, 23251.5), _PMC3C),
+              "tnt_lstm_seq_fwd_f32 S=16 B=64 U=512": (_kib(21653.1, 14239.1), _PMC3C),
+              "tnt_lstm_seq_bwd_f32 S=16 B=64 U=512": (_kib(28751.2, 23211.6), _PMC3C),
               "tnt_dense_dw_adam_f32 20000x512x64": (_kib(66176.8, 120000.0), _PMC3),
               "tnt_dense_dw_adam_fin_f32 20000x512x64": (_kib(66176.8, 120000.0), _PMC3)},      # the same kernel and operands
-    "attention": {"tnt_lc_seq_fwd_drop_f32 T=15 B=64 R=360 U=512": (_kib(27241.6, 15567.1), _PMC3C),
-                  "tnt_lc_seq_bwd_drop_f32 T=15 B=64 R=360 U=512": (_kib(32035.7, 41471.2), _PMC3C),
+    "attention": {"tnt_lc_seq_fwd_drop_f32 T=15 B=64 R=360 U=512": (_kib(27245.3, 15566.9), _PMC3C),
+                  "tnt_lc_seq_bwd_drop_f32 T=15 B=64 R=360 U=512": (_kib(32031.3, 39104.4), _PMC3C),
                   "tnt_gemm3_pair_f32 TN 256x5001x960 + NT 960x256x5001": (_kib(62224.7, 21897.9), _PMC3),
                   "tnt_gemm3_pair_f32 TN 512x2048x960 x2 + NT 960x512x2048": (_kib(51075.9, 13960.0), _PMC3),
                   "tnt_gemm3_f32 NN 960x5001x256": (_kib(6616.8, 18885.0), _PMC3)},
