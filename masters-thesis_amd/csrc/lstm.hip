@@ -515,11 +515,35 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
     if (eok) a.hs[BU + ee] = sentinel;
     tnt_seq_group_barrier(bar, ub, tnt_seq_target(slot.epoch, 1), err);
   }
+  // The resident weights were loaded above and the barrier drained the memory counter, but the compiler does not know: it
+  // keeps its own vmcnt(31) ... vmcnt(0) ladder in front of their first uses -- INSIDE the loop, where the final vmcnt(0) then
+  // waits for whatever the step has in flight (the prefetch of the next step's operands).  Launder them once here.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (RB == 8) {
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) asm volatile("" : "+v"(bx[ch][q][pr]));
+  }
+  // The epilogue's operands of step st + 1 (the input projection xz, the mask id) are fetched during step st, BEHIND the poll
+  // of h[st]: the memory counter is in-order, so a load from HBM issued in front of the poll -- as the round-2 kernel did,
+  // right behind the publish -- holds the poll's own return back by its latency in exactly the waves that own epilogue
+  // threads, and the workgroup's barrier waits for them (the compiler also put the compare of the mask id, hence a full
+  // drain, at the step's top).  The publish then waits with vmcnt(N), N = the prefetches this wave has in flight, for its
+  // sentinel reset only.
+  int mid = 1;
+  const long ees = eok ? ee : 0;
+  const int ebs = eok ? eb : 0;
+  const bool have_ids = a.mask_ids != nullptr;
+  if (have_ids && a.mask_s0 <= 0) mid = a.mask_ids[ebs * a.mask_T - a.mask_s0];
   for (int st = 0; st < a.S; ++st) {
     if (POLL && eok && st + 2 <= a.S) a.hs[(long)(st + 2) * BU + ee] = sentinel;       // published by step st + 1
     LST(0);
-    int mid = 1;
-    if (eok && a.mask_ids && st >= a.mask_s0) mid = a.mask_ids[eb * a.mask_T + (st - a.mask_s0)];
+    float4 x4n = make_float4(0.f, 0.f, 0.f, 0.f);
+    int midn = 1;
+    const bool pf_x = st + 1 < a.S, pf_m = have_ids && st + 1 < a.S && st + 1 >= a.mask_s0;      // uniform
     if (RB == 8) {
       // ---- this lane's float4 of h[st]: row rg*4 + j of the block, k = 32 w + 4 cg .. + 3 (sc1 loads, polled)
       const int xrow = rb * RB + x_rg * 4 + x_j;
@@ -541,6 +565,8 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
         if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       }
       LST(1);
+      if (pf_x) x4n = *reinterpret_cast<const float4*>(a.xz + ((long)(st + 1) * BU + ees) * 4);
+      if (pf_m) midn = a.mask_ids[ebs * a.mask_T + (st + 1 - a.mask_s0)];
       floatx4 xa[2];
       xa[0] = (floatx4){0.f, 0.f, 0.f, 0.f}; xa[1] = xa[0];
 #define TNT_X4(q)                                                                                              \
@@ -585,6 +611,8 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
         }
         if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       }
+      if (pf_x) x4n = *reinterpret_cast<const float4*>(a.xz + ((long)(st + 1) * BU + ees) * 4);
+      if (pf_m) midn = a.mask_ids[ebs * a.mask_T + (st + 1 - a.mask_s0)];
       floatx4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = (floatx4){0.f, 0.f, 0.f, 0.f};
@@ -630,14 +658,18 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
       const bool seq = st >= a.mask_s0;
       const float hn = m ? h2 : hp, cn = m ? c2 : cp;
       LST(4);
-      if (POLL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's reset of hs[st+2] is in L2 first
+      if (POLL) {      // this thread's reset of hs[st+2] is in L2 first; the prefetches behind it may stay in flight
+        if (pf_x && pf_m) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (pf_x || pf_m) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       a.hs[(long)(st + 1) * BU + ee] = hn;
       a.cs[(long)(st + 1) * BU + ee] = cn;
       if (a.out && seq) { op = m ? h2 : op; a.out[(long)(st - a.mask_s0) * BU + ee] = op; }
       *reinterpret_cast<float4*>(a.gates + ((long)st * BU + ee) * 4) = make_float4(gi, gf, gg, go);
       hp = hn; cp = cn;
-      if (st + 1 < a.S) x4 = *reinterpret_cast<const float4*>(a.xz + ((long)(st + 1) * BU + ee) * 4);
     }
+    x4 = x4n; mid = midn;
     LST(5);
     if (st + 1 == a.S) break;
     if (POLL) {
