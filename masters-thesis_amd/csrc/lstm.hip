@@ -531,8 +531,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   // of h[st]: the memory counter is in-order, so a load from HBM issued in front of the poll -- as the round-2 kernel did,
   // right behind the publish -- holds the poll's own return back by its latency in exactly the waves that own epilogue
   // threads, and the workgroup's barrier waits for them (the compiler also put the compare of the mask id, hence a full
-  // drain, at the step's top).  The publish then waits with vmcnt(N), N = the prefetches this wave has in flight, for its
-  // sentinel reset only.
+  // drain, at the step's top).
   int mid = 1;
   const long ees = eok ? ee : 0;
   const int ebs = eok ? eb : 0;
@@ -631,8 +630,13 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
       __syncthreads();
     }
     LST(3);
+    // (the prefetched operands change hands HERE, in front of the step's stores: the copy waits for the prefetch -- issued
+    // an MFMA phase ago -- and behind the stores it would also wait for their acknowledgements)
+    const float4 xc = x4;
+    const int midc = mid;
+    x4 = x4n; mid = midn;
     if (eok) {
-      float z[4] = {x4.x + zb.x, x4.y + zb.y, x4.z + zb.z, x4.w + zb.w};
+      float z[4] = {xc.x + zb.x, xc.y + zb.y, xc.z + zb.z, xc.w + zb.w};
       if (RB == 8) {
         const float* rx = &red[0][0][0][0] + erow * 68 + ecol * 4;
         float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -654,22 +658,17 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
       const float gi = tnt_sigmoid_fast(z[0]), gf = tnt_sigmoid_fast(z[1]), gg = tnt_tanh(z[2]), go = tnt_sigmoid_fast(z[3]);
       const float c2 = gf * cp + gi * gg;
       const float h2 = go * tnt_tanh(c2);
-      const bool m = mid != 0;
+      const bool m = midc != 0;
       const bool seq = st >= a.mask_s0;
       const float hn = m ? h2 : hp, cn = m ? c2 : cp;
       LST(4);
-      if (POLL) {      // this thread's reset of hs[st+2] is in L2 first; the prefetches behind it may stay in flight
-        if (pf_x && pf_m) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (pf_x || pf_m) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      if (POLL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's reset of hs[st+2] is in L2 first
       a.hs[(long)(st + 1) * BU + ee] = hn;
       a.cs[(long)(st + 1) * BU + ee] = cn;
       if (a.out && seq) { op = m ? h2 : op; a.out[(long)(st - a.mask_s0) * BU + ee] = op; }
       *reinterpret_cast<float4*>(a.gates + ((long)st * BU + ee) * 4) = make_float4(gi, gf, gg, go);
       hp = hn; cp = cn;
     }
-    x4 = x4n; mid = midn;
     LST(5);
     if (st + 1 == a.S) break;
     if (POLL) {

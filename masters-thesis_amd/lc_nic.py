@@ -657,8 +657,8 @@ class NIC(ModelBase):
             be.dropout(self.dHs, self.dHs, n, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds, rows_per_site=B)
 
     def _lc_seq_bwd_ok(self):
-        """the persistent backward-chain kernel applies (it keeps a sample's P, F and dF rows in LDS:
-        R (A + 2 D) <= 35 K floats, tnt_lc_seq_bwd_f32)."""
+        """the persistent backward-chain kernel applies (tnt_lc_seq_bwd_f32; R (A + 2 D) <= 35 K floats is the entry point's
+        bound from the round-2 kernel, which kept a sample's P, F and dF rows in LDS)."""
         return bool(not self.use_layer_norm and self._lc_seq_ok() and self.__dict__.get("lc_xch") is not None
                     and getattr(self, "use_lc_seq_bwd", True) and self.R * (self.A + 2 * self.D) <= 35 * 1024)
 

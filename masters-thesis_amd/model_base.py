@@ -427,8 +427,8 @@ class ModelBase:
             batch = 2 if d.get("A2") is not None else 1
             tile, sk = self._g3_plan(d["M"], d["N"], d["K"], d.get("transA", False), d.get("transB", False), batch,
                                      d.get("colsum") is not None)
-            if d.get("small"):            # a small product rides along: the 32-deep tile of the same shape has a pair form
-                tile = {9: 7, 10: 5, 6: 7, 11: 7}.get(tile, tile)
+            if d.get("small"):            # a small product rides along: the 32-deep tile of the SAME shape has a pair form
+                tile = {9: 7, 10: 5}.get(tile, tile)      # (same tile count, so the planned split stays valid)
             wf = (be.gemm3_work_floats(d["M"], d["N"], tile, sk, batch) + 3) // 4 * 4 if sk > 1 else 0
             descs.append((d, tile, sk, need, wf))
             need += wf
