@@ -792,8 +792,8 @@ int32_t tnt_lc_seq_fwd_drop_f32(const float* F, const float* P, const float* W2,
  * dvb [B][A+1] accumulated on chip over the T steps and WRITTEN once (no zero fill by the caller).
  * dout [T][B][U], gates / dz [T][B][U][4], cs [T+1][B][U], qpre / dqpre [T][B][A], alpha [T][B][R]; work:
  * tnt_lc_seq_bwd_work_floats(B, U) floats of exchange space (contents irrelevant).  Shape limits, sync and guard_out as
- * tnt_lc_seq_fwd_f32, and R (A + 2 D) <= 35840 (the bound of the round-2 kernel, which kept a sample's P, F and dF rows in
- * LDS; since round 3 they live in registers -- R <= 384 with A, D <= 32, R <= 192 otherwise, without spills). */
+ * tnt_lc_seq_fwd_f32 (a sample's P, F, dP and dF rows live in registers: without spills for R <= 384 with A, D <= 32 and
+ * for R <= 192 otherwise). */
 int32_t tnt_lc_seq_bwd_work_floats(int32_t B, int32_t U);
 int32_t tnt_lc_seq_bwd_f32(const float* F, const float* P, const float* W2, const float* v, const float* qpre,
                            const float* alpha, const uint8_t* keep4, int64_t keep_stride, float* dP, float* dF,

@@ -2524,7 +2524,7 @@ extern "C" int32_t tnt_lc_seq_bwd_drop_f32(const float* F, const float* P, const
   a.xch = work; a.dhx = work + 3 * nrb * 32 * 32 * 256; a.parts = a.dhx + 3 * (int64_t)B * U;
   a.T = T; a.sync = sync; a.guard_out = guard_out;
   const int g4 = (A <= 32 && D <= 32) ? 8 : 16, np = (R + WT / g4 - 1) / (WT / g4);
-  if (np > 6 || R * (A + 2 * D) > LB_PF_FLOATS) return TNT_BADARG(21);
+  if (np > 6) return TNT_BADARG(21);
   void (*kern)(LcSeqBwdArgs) = nullptr;
   if (rb8) {
     if (g4 == 8) kern = np <= 3 ? lc_seq_bwd_kernel<8, 3, 8> : lc_seq_bwd_kernel<8, 6, 8>;

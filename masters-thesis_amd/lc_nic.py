@@ -657,10 +657,9 @@ class NIC(ModelBase):
             be.dropout(self.dHs, self.dHs, n, U, U, 0, U, 0, self.r_lstm, sd, S_LSTM_OUT, 0, ds, rows_per_site=B)
 
     def _lc_seq_bwd_ok(self):
-        """the persistent backward-chain kernel applies (tnt_lc_seq_bwd_f32; R (A + 2 D) <= 35 K floats is the entry point's
-        bound from the round-2 kernel, which kept a sample's P, F and dF rows in LDS)."""
+        """the persistent backward-chain kernel applies (tnt_lc_seq_bwd_f32: the forward chain's shape limits)."""
         return bool(not self.use_layer_norm and self._lc_seq_ok() and self.__dict__.get("lc_xch") is not None
-                    and getattr(self, "use_lc_seq_bwd", True) and self.R * (self.A + 2 * self.D) <= 35 * 1024)
+                    and getattr(self, "use_lc_seq_bwd", True))
 
     def _bwd_chain(self, B, T):
         """the T-step chain (LSTM step backward -> attention step backward) and the LSTM parameter gradients."""
