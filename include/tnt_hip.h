@@ -132,7 +132,10 @@ int32_t tnt_gemm3_pair_f32(const tnt_gemm3_desc* p, const tnt_gemm3_desc* q, voi
  * main.py:97, lc_NIC.py:389).  tnt_step_finalize_f32 -- per-variable norms from the span partials, the step's scalar totals,
  * the counter tick -- was one dependent launch in front of the update: 12 us of a 500 us step.  Here
  *   tnt_span_sqnorm_lr_f32 / tnt_dense_gram_norm_spans_lr_f32: the norm launches, with one thread also writing Adam's step
- *       size lr_t = lr sqrt(1-b2^t)/(1-b1^t), t = *adam_t + 1, for the update that follows;
+ *       size lr_t = lr sqrt(1-b2^t)/(1-b1^t), t = *adam_t + 1, for the update that follows.  `sq_override` (may be NULL:
+ *       everything is read): the per-variable table of externally supplied clip norms the update launches take; a variable
+ *       with sq_override[seg] >= 0 (the Embedding: IndexedSlices norm, lc_NIC.py:386-389) gets no pass over its gradient,
+ *       and sum theta^2 -- consumed only as lambda * sum theta^2 of the L2 metric -- is left 0 where seg_l2[seg] == 0;
  *   tnt_dense_dw_adam_fin_f32: tnt_dense_dw_adam_f32 with the kernel's clip norm summed from partial[2k], k0 <= k < k1, by
  *       the launch itself;
  *   tnt_adam_fin_f32: tnt_adam_ring_f32 over spans whose variables' clip norms are summed from `fin->partial` by every
@@ -151,13 +154,15 @@ typedef struct tnt_finalize_desc {
 } tnt_finalize_desc;
 int32_t tnt_span_sqnorm_lr_f32(const float* theta, const float* grad, const int32_t* span_seg, const int64_t* span_off,
                                const int32_t* span_len, const float* seg_l2, float* partial, int32_t nspan,
-                               const int64_t* adam_t, const float* lr, float* lr_t, float beta1, float beta2, void* stream);
+                               const int64_t* adam_t, const float* lr, float* lr_t, float beta1, float beta2,
+                               const float* sq_override, void* stream);
 int32_t tnt_dense_gram_norm_spans_lr_f32(const float* dpre, const float* pre, const float* bias, const float* gx_part,
                                          int32_t nsplit, const float* w2_part, int32_t nw2, float l2, float* partial,
                                          int32_t nslot, int32_t Bk, int32_t E, const float* theta, const float* grad,
                                          const int32_t* span_seg, const int64_t* span_off, const int32_t* span_len,
                                          const float* seg_l2, float* span_partial, int32_t nspan, const int64_t* adam_t,
-                                         const float* lr, float* lr_t, float beta1, float beta2, void* stream);
+                                         const float* lr, float* lr_t, float beta1, float beta2, const float* sq_override,
+                                         void* stream);
 int32_t tnt_dense_dw_adam_fin_f32(const float* x, const float* dpre, float* theta, float* m, float* v, float l2,
                                   const float* partial, int32_t k0, int32_t k1, const float* sq_override,
                                   const float* lr_t_dev, float beta1, float beta2, float eps, float clipnorm,

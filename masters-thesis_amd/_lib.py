@@ -30,8 +30,8 @@ SIGNATURES = {
     "tnt_gemm3_work_arm": [P, I64, P],
     "tnt_gemm3_pair_supported": [I32, I32, I32, I32, I32, I32],
     "tnt_gemm3_pair_f32": [P, P, P],
-    "tnt_span_sqnorm_lr_f32": [P, P, P, P, P, P, P, I32, P, P, P, F32, F32, P],
-    "tnt_dense_gram_norm_spans_lr_f32": [P, P, P, P, I32, P, I32, F32, P, I32, I32, I32, P, P, P, P, P, P, P, I32, P, P, P, F32, F32, P],
+    "tnt_span_sqnorm_lr_f32": [P, P, P, P, P, P, P, I32, P, P, P, F32, F32, P, P],
+    "tnt_dense_gram_norm_spans_lr_f32": [P, P, P, P, I32, P, I32, F32, P, I32, I32, I32, P, P, P, P, P, P, P, I32, P, P, P, F32, F32, P, P],
     "tnt_dense_dw_adam_fin_f32": [P, P, P, P, P, F32, P, I32, I32, P, P, F32, F32, F32, F32, P, I32, I32, I32, I32, P],
     "tnt_adam_fin_f32": [P, P, P, P, P, P, P, P, I32, F32, F32, P, P, I32, P, I32, P, P],
     "tnt_dropout_mask4_u8": [P, I64, I32, F32, U64, U32, U32, P, P],

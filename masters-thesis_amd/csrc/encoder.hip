@@ -323,7 +323,7 @@ struct DwArgs {
 //   2  clip + Adam on the strip as it leaves the MFMAs: theta, m, v stream through registers one strip ahead (their
 //      loads are issued before the previous strip's stores, so waiting for them never drains the stores), g is never
 //      stored -- 24 bytes per parameter instead of 4 (dW write) + 8 (norm pass) + 28 (Adam).
-template <int TPW, bool PERM, int EPI = 0>       // 16-column tiles per wave; a workgroup covers 8 * TPW * 16 columns (blockIdx.y picks the group)
+template <int TPW, bool PERM, int EPI = 0, bool NTM = false>   // 16-column tiles per wave; a workgroup covers 8 * TPW * 16 columns (blockIdx.y picks the group); NTM: non-temporal moments
 __global__ __launch_bounds__(512) void dense_dw_skinny_kernel(DwArgs a) {
   static_assert(EPI == 0 || (PERM && TPW == 4), "fused epilogues use the vector row layout");
   constexpr int DW_MAXT = TPW;
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(512) void dense_dw_skinny_kernel(DwArgs a) {
     for (int r = 0; r < 4; ++r) {
       const long o = ((long)min(sc * DW_MS + lk * 4 + r, a.N - 1) - lk * 4) * a.E + eoff;
       t[r] = *reinterpret_cast<const float4*>(a.theta + o);
-      if (EPI == 2) { m_[r] = *reinterpret_cast<const float4*>(a.m + o); v_[r] = *reinterpret_cast<const float4*>(a.v + o); }
+      if (EPI == 2) { m_[r] = tnt_ld4<NTM>(a.m + o); v_[r] = tnt_ld4<NTM>(a.v + o); }
     }
   };
   gload(s);                                            // the first strip's X is in flight while the B fragments load
@@ -497,8 +497,8 @@ __global__ __launch_bounds__(512) void dense_dw_skinny_kernel(DwArgs a) {
           }
           const long o = (long)s * DW_MS * a.E + (long)r * a.E + eoff;
           *reinterpret_cast<float4*>(a.theta + o) = th[r];
-          *reinterpret_cast<float4*>(a.m + o) = mm[r];
-          *reinterpret_cast<float4*>(a.v + o) = vv[r];
+          tnt_st4<NTM>(a.m + o, mm[r]);
+          tnt_st4<NTM>(a.v + o, vv[r]);
         }
       }
     }
@@ -756,6 +756,7 @@ struct GnSpans {
   const float* seg_l2; float* partial; int nspan;
   // the "lr job" (optional): Adam's step size for the update that follows, see tnt_span_sqnorm_lr_f32 / tnt_adam_fin_f32
   const int64_t* adam_t; const float* lr; float* lr_t; float b1, b2;
+  const float* ovr;            // optional: see tnt_span_norm (csrc/tnt_fin.h)
 };
 
 __global__ __launch_bounds__(256) void dense_gram_norm_kernel(const float* dpre, const float* pre, const float* bias,
@@ -769,29 +770,8 @@ __global__ __launch_bounds__(256) void dense_gram_norm_kernel(const float* dpre,
     __shared__ float s0[4], s1[4];
     const int s = blockIdx.x - (GN_Q * Bk + 1);
     if (s >= sp.nspan) return;
-    const long off = sp.span_off[s];
-    const int len = sp.span_len[s];
-    const float lam2 = 2.f * sp.seg_l2[sp.span_seg[s]];
-    float q = 0.f, wq = 0.f;
-    const int len4 = len & ~3;
-    for (int i = tid * 4; i < len4; i += 1024) {
-      const float4 g = *reinterpret_cast<const float4*>(sp.grad + off + i);
-      const float4 w = *reinterpret_cast<const float4*>(sp.theta + off + i);
-      const float a0 = g.x + lam2 * w.x, a1 = g.y + lam2 * w.y, a2 = g.z + lam2 * w.z, a3 = g.w + lam2 * w.w;
-      q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
-      wq += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
-    }
-    for (int i = len4 + tid; i < len; i += 256) {
-      const float w = sp.theta[off + i], a0 = sp.grad[off + i] + lam2 * w;
-      q += a0 * a0; wq += w * w;
-    }
-    q = tnt_wave_sum(q); wq = tnt_wave_sum(wq);
-    if ((tid & 63) == 0) { s0[tid >> 6] = q; s1[tid >> 6] = wq; }
-    __syncthreads();
-    if (tid == 0) {
-      sp.partial[2 * s + 0] = s0[0] + s0[1] + s0[2] + s0[3];
-      sp.partial[2 * s + 1] = s1[0] + s1[1] + s1[2] + s1[3];
-    }
+    const SpanTab st{sp.span_seg, sp.span_off, sp.span_len, nullptr, sp.seg_l2};
+    tnt_span_norm(sp.theta, sp.grad, st, s, sp.partial, sp.ovr, s0, s1);
     return;
   }
   if ((int)blockIdx.x == GN_Q * Bk) {
@@ -868,7 +848,7 @@ extern "C" int32_t tnt_dense_gram_norm_spans_f32(const float* dpre, const float*
   if (nspan < 0 || (nspan > 0 && (theta == nullptr || grad == nullptr || span_partial == nullptr))) return TNT_BADARG(19);
   return gram_norm_launch(dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E,
                           GnSpans{theta, grad, span_seg, span_off, span_len, seg_l2, span_partial, nspan, nullptr, nullptr, nullptr,
-                                  0.f, 0.f}, stream);
+                                  0.f, 0.f, nullptr}, stream);
 }
 
 extern "C" int32_t tnt_dense_gram_norm_spans_lr_f32(const float* dpre, const float* pre, const float* bias,
@@ -877,12 +857,13 @@ extern "C" int32_t tnt_dense_gram_norm_spans_lr_f32(const float* dpre, const flo
                                                     const float* theta, const float* grad, const int32_t* span_seg,
                                                     const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
                                                     float* span_partial, int32_t nspan, const int64_t* adam_t, const float* lr,
-                                                    float* lr_t, float beta1, float beta2, void* stream) {
+                                                    float* lr_t, float beta1, float beta2, const float* sq_override,
+                                                    void* stream) {
   if (nspan < 0 || (nspan > 0 && (theta == nullptr || grad == nullptr || span_partial == nullptr))) return TNT_BADARG(19);
   if (adam_t == nullptr || lr == nullptr || lr_t == nullptr) return TNT_BADARG(21);
   return gram_norm_launch(dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E,
                           GnSpans{theta, grad, span_seg, span_off, span_len, seg_l2, span_partial, nspan, adam_t, lr, lr_t, beta1,
-                                  beta2}, stream);
+                                  beta2, sq_override}, stream);
 }
 
 namespace {
@@ -966,7 +947,10 @@ extern "C" int32_t tnt_dense_dw_adam_f32(const float* x, const float* dpre, floa
   a.x = x; a.dpre = dpre; a.N = N; a.E = E; a.Bk = Bk; a.ldx = ldx;
   a.theta = theta; a.m = m; a.v = v; a.lam2 = 2.f * l2; a.sq = sq; a.sq_override = sq_override; a.lr_t_dev = lr_t_dev;
   a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.clipnorm = clipnorm; a.guard = guard;
-  hipLaunchKernelGGL((dense_dw_skinny_kernel<4, true, 2>), dim3(grid, E / 512), dim3(512), 0, tnt_stream(stream), a);
+  if (tnt_stream_policy_nt())
+    hipLaunchKernelGGL((dense_dw_skinny_kernel<4, true, 2, true>), dim3(grid, E / 512), dim3(512), 0, tnt_stream(stream), a);
+  else
+    hipLaunchKernelGGL((dense_dw_skinny_kernel<4, true, 2>), dim3(grid, E / 512), dim3(512), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
 }
@@ -984,7 +968,10 @@ extern "C" int32_t tnt_dense_dw_adam_fin_f32(const float* x, const float* dpre, 
   a.theta = theta; a.m = m; a.v = v; a.lam2 = 2.f * l2; a.sq = nullptr; a.sq_override = sq_override; a.lr_t_dev = lr_t_dev;
   a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.clipnorm = clipnorm; a.guard = guard;
   a.fin_partial = partial; a.fin_k0 = k0; a.fin_k1 = k1;
-  hipLaunchKernelGGL((dense_dw_skinny_kernel<4, true, 2>), dim3(grid, E / 512), dim3(512), 0, tnt_stream(stream), a);
+  if (tnt_stream_policy_nt())
+    hipLaunchKernelGGL((dense_dw_skinny_kernel<4, true, 2, true>), dim3(grid, E / 512), dim3(512), 0, tnt_stream(stream), a);
+  else
+    hipLaunchKernelGGL((dense_dw_skinny_kernel<4, true, 2>), dim3(grid, E / 512), dim3(512), 0, tnt_stream(stream), a);
   TNT_LAUNCH_CHECK();
   return 0;
 }

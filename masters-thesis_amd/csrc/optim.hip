@@ -13,7 +13,7 @@
 
 namespace {
 
-struct LrJob { const int64_t* adam_t; const float* lr; float* lr_t; float b1, b2; };
+struct LrJob { const int64_t* adam_t; const float* lr; float* lr_t; float b1, b2; const float* ovr; };
 
 __global__ __launch_bounds__(256) void span_sqnorm_kernel(const float* theta, const float* grad, SpanTab t,
                                                           float* partial, int nspan, LrJob lj) {
@@ -23,29 +23,7 @@ __global__ __launch_bounds__(256) void span_sqnorm_kernel(const float* theta, co
   // update: tnt_adam_fin_f32), one thread of the launch, beside the norms
   if (lj.lr_t != nullptr && sp == 0 && threadIdx.x == 255) lj.lr_t[0] = tnt_adam_lr_t(lj.adam_t, lj.lr, lj.b1, lj.b2);
   if (sp >= nspan) return;
-  const long off = t.span_off[sp];
-  const int len = t.span_len[sp];
-  const float lam2 = 2.f * t.seg_l2[t.span_seg[sp]];
-  float q = 0.f, wq = 0.f;
-  const int len4 = len & ~3;
-  for (int i = threadIdx.x * 4; i < len4; i += 1024) {
-    const float4 g = *reinterpret_cast<const float4*>(grad + off + i);
-    const float4 w = *reinterpret_cast<const float4*>(theta + off + i);
-    const float a0 = g.x + lam2 * w.x, a1 = g.y + lam2 * w.y, a2 = g.z + lam2 * w.z, a3 = g.w + lam2 * w.w;
-    q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
-    wq += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
-  }
-  for (int i = len4 + threadIdx.x; i < len; i += 256) {
-    const float w = theta[off + i], a0 = grad[off + i] + lam2 * w;
-    q += a0 * a0; wq += w * w;
-  }
-  q = tnt_wave_sum(q); wq = tnt_wave_sum(wq);
-  if ((threadIdx.x & 63) == 0) { s0[threadIdx.x >> 6] = q; s1[threadIdx.x >> 6] = wq; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    partial[2 * sp + 0] = s0[0] + s0[1] + s0[2] + s0[3];
-    partial[2 * sp + 1] = s1[0] + s1[1] + s1[2] + s1[3];
-  }
+  tnt_span_norm(theta, grad, t, sp, partial, lj.ovr, s0, s1);
 }
 
 // one wave per segment: lanes stride over the segment's spans, then a fixed shuffle tree
@@ -160,6 +138,9 @@ __device__ __forceinline__ void fin_arrive_and_tick(const FinArgs& f, unsigned t
   if (f.adam_t) f.adam_t[0] += 1;
 }
 
+constexpr int AF_U = 4;          // rounds of 1024 elements in flight per span workgroup (tnt_adam_fin_f32)
+
+template <bool NT>
 __global__ __launch_bounds__(256) void adam_fin_kernel(float* theta, float* m, float* v, const float* grad, SpanTab t,
                                                        const float* sq_override, int nspan, float eps, float clipnorm,
                                                        FinArgs f, MetRing r) {
@@ -173,16 +154,24 @@ __global__ __launch_bounds__(256) void adam_fin_kernel(float* theta, float* m, f
       const int len = t.span_len[sp];
       const int seg = t.span_seg[sp];
       const int len4 = len & ~3;
-      // the first round of the span's operands is in flight BEFORE the clip norm's chain of dependent loads (span -> variable
-      // -> its partials -> sum): every span workgroup pays that chain, and behind it the chain would add ~1 us to each
-      float4 w0 = {}, g0 = {}, m0 = {}, v0 = {};
-      const bool have0 = tid * 4 < len4;
-      if (have0) {
-        w0 = *reinterpret_cast<const float4*>(theta + off + tid * 4);
-        g0 = *reinterpret_cast<const float4*>(grad + off + tid * 4);
-        m0 = *reinterpret_cast<const float4*>(m + off + tid * 4);
-        v0 = *reinterpret_cast<const float4*>(v + off + tid * 4);
-      }
+      // The span's operands are read AF_U rounds at a time (AF_U x 4 x 16 bytes per lane in flight): with one round per
+      // trip the launch is bound by concurrency x latency, not by HBM (3.4 workgroups per CU x 4 KB per wave in flight
+      // ~ 5 TB/s).  The first group is in flight BEFORE the clip norm's chain of dependent loads (span -> variable -> its
+      // partials -> sum): every span workgroup pays that chain, and behind it the chain would add ~1 us to each.
+      float4 wv[AF_U], g4[AF_U], mm[AF_U], vv[AF_U];
+      auto load = [&](int base) {
+#pragma unroll
+        for (int u = 0; u < AF_U; ++u) {
+          const int i = base + u * 1024;
+          if (i < len4) {
+            wv[u] = *reinterpret_cast<const float4*>(theta + off + i);
+            g4[u] = tnt_ld4<NT>(grad + off + i);
+            mm[u] = tnt_ld4<NT>(m + off + i);
+            vv[u] = tnt_ld4<NT>(v + off + i);
+          }
+        }
+      };
+      load(tid * 4);
       const float lr_t = f.lr_t[0];                        // written by the norm launch in front of this one (its "lr job")
       const float lam2 = 2.f * f.seg_l2[seg];
       float cs = 1.f;
@@ -200,26 +189,25 @@ __global__ __launch_bounds__(256) void adam_fin_kernel(float* theta, float* m, f
         cs = clipnorm / fmaxf(sqrtf(q), clipnorm);
       }
       const float ob1 = 1.f - f.b1, ob2 = 1.f - f.b2;
-      for (int i = tid * 4; i < len4; i += 1024) {
-        float4 wv, g4, mm, vv;
-        if (i == tid * 4) { wv = w0; g4 = g0; mm = m0; vv = v0; }
-        else {
-          wv = *reinterpret_cast<float4*>(theta + off + i);
-          g4 = *reinterpret_cast<const float4*>(grad + off + i);
-          mm = *reinterpret_cast<float4*>(m + off + i);
-          vv = *reinterpret_cast<float4*>(v + off + i);
-        }
-        float* wp = &wv.x; float* mp = &mm.x; float* vp = &vv.x; const float* gp = &g4.x;
+      for (int base = tid * 4; base < len4; base += 1024 * AF_U) {
+        if (base != tid * 4) load(base);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float g = (gp[j] + lam2 * wp[j]) * cs;
-          mp[j] = mp[j] + (g - mp[j]) * ob1;
-          vp[j] = vp[j] + (g * g - vp[j]) * ob2;
-          wp[j] = wp[j] - lr_t * mp[j] / (sqrtf(vp[j]) + eps);
+        for (int u = 0; u < AF_U; ++u) {
+          const int i = base + u * 1024;
+          if (i < len4) {
+            float* wp = &wv[u].x; float* mp = &mm[u].x; float* vp = &vv[u].x; const float* gp = &g4[u].x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float g = (gp[j] + lam2 * wp[j]) * cs;
+              mp[j] = mp[j] + (g - mp[j]) * ob1;
+              vp[j] = vp[j] + (g * g - vp[j]) * ob2;
+              wp[j] = wp[j] - lr_t * mp[j] / (sqrtf(vp[j]) + eps);
+            }
+            *reinterpret_cast<float4*>(theta + off + i) = wv[u];
+            tnt_st4<NT>(m + off + i, mm[u]);
+            tnt_st4<NT>(v + off + i, vv[u]);
+          }
         }
-        *reinterpret_cast<float4*>(theta + off + i) = wv;
-        *reinterpret_cast<float4*>(m + off + i) = mm;
-        *reinterpret_cast<float4*>(v + off + i) = vv;
       }
       for (int i = len4 + tid; i < len; i += 256) {
         const float wv = theta[off + i];
@@ -664,12 +652,12 @@ extern "C" int32_t tnt_span_sqnorm_f32(const float* theta, const float* grad, co
 extern "C" int32_t tnt_span_sqnorm_lr_f32(const float* theta, const float* grad, const int32_t* span_seg,
                                           const int64_t* span_off, const int32_t* span_len, const float* seg_l2,
                                           float* partial, int32_t nspan, const int64_t* adam_t, const float* lr, float* lr_t,
-                                          float beta1, float beta2, void* stream) {
+                                          float beta1, float beta2, const float* sq_override, void* stream) {
   if (nspan <= 0) return TNT_BADARG(8);
   if (adam_t == nullptr || lr == nullptr || lr_t == nullptr) return TNT_BADARG(9);
   SpanTab t{span_seg, span_off, span_len, nullptr, seg_l2};
   hipLaunchKernelGGL(span_sqnorm_kernel, dim3(nspan), dim3(256), 0, tnt_stream(stream), theta, grad, t, partial, nspan,
-                     LrJob{adam_t, lr, lr_t, beta1, beta2});
+                     LrJob{adam_t, lr, lr_t, beta1, beta2, sq_override});
   TNT_LAUNCH_CHECK();
   return 0;
 }
@@ -724,8 +712,12 @@ extern "C" int32_t tnt_adam_fin_f32(float* theta, float* m, float* v, const floa
   FinArgs f;
   if (int32_t rc = fin_fill(f, fin)) return rc;
   SpanTab t{span_seg, span_off, span_len, nullptr, nullptr};
-  hipLaunchKernelGGL(adam_fin_kernel, dim3(nspan + 1), dim3(256), 0, tnt_stream(stream), theta, m, v, grad, t, sq_override, nspan,
-                     eps, clipnorm, f, MetRing{met, ring, ring_t, nmet, ring_rows});
+  if (tnt_stream_policy_nt())
+    hipLaunchKernelGGL(adam_fin_kernel<true>, dim3(nspan + 1), dim3(256), 0, tnt_stream(stream), theta, m, v, grad, t, sq_override,
+                       nspan, eps, clipnorm, f, MetRing{met, ring, ring_t, nmet, ring_rows});
+  else
+    hipLaunchKernelGGL(adam_fin_kernel<false>, dim3(nspan + 1), dim3(256), 0, tnt_stream(stream), theta, m, v, grad, t, sq_override,
+                       nspan, eps, clipnorm, f, MetRing{met, ring, ring_t, nmet, ring_rows});
   TNT_LAUNCH_CHECK();
   return 0;
 }

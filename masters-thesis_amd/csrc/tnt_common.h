@@ -102,3 +102,32 @@ __device__ __forceinline__ float tnt_wave_max(float v) {
   v = fmaxf(v, tnt_ror<8>(v)); v = fmaxf(v, tnt_ror<4>(v)); v = fmaxf(v, tnt_x2(v)); v = fmaxf(v, tnt_x1(v));
   return v;
 }
+
+// 16-byte accesses with an optional non-temporal hint: streams that are touched once per step (the optimizer moments, a
+// gradient being consumed) should not displace what the next kernels re-read from the L2s / the Infinity Cache.
+template <bool NT>
+__device__ __forceinline__ float4 tnt_ld4(const float* p) {
+  if (NT) {
+    const floatx4 v = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+  }
+  return *reinterpret_cast<const float4*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void tnt_st4(float* p, const float4& v) {
+  if (NT) {
+    const floatx4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<floatx4*>(p));
+  } else {
+    *reinterpret_cast<float4*>(p) = v;
+  }
+}
+// Process-wide policy of the streaming optimizer kernels: non-temporal moments / consumed gradient unless TNT_STREAM_NT=0
+// (the A/B switch).  Measured on config 2 (tools/step_breakdown.py, same box): the kernels timed alone, the same launch
+// repeated, are SLOWER non-temporal (fused encoder update 44.4 -> 51.0 us, Adam of the rest 33.7 -> 35.4: a repeated launch
+// finds its own moments in the Infinity Cache), the training step is FASTER, 0.4849 -> 0.4722 ms: 140 MB of moments per step
+// no longer push the weights, gradients and activations (~160 MB) out of the 256 MB cache between their producer and consumer.
+static inline bool tnt_stream_policy_nt() {
+  static const int on = [] { const char* e = getenv("TNT_STREAM_NT"); return e != nullptr && e[0] == '0' ? 0 : 1; }();
+  return on != 0;
+}

@@ -41,6 +41,60 @@ __device__ __forceinline__ float2 tnt_seg_sums(const float* partial, int k0, int
   return make_float2(q, w);
 }
 
+// One span's pair (sum (g + 2 lambda theta)^2, sum theta^2), one 256-thread workgroup, result in thread 0's slot of
+// `partial`.  `ovr` (optional, the norm launches of the fused step): what nobody will read is not loaded --
+//   * a variable whose clip norm is supplied from elsewhere (ovr[seg] >= 0: the Embedding's IndexedSlices norm, filed there
+//     by the previous update and re-filed by this one) needs no pass over its gradient;
+//   * sum theta^2 only feeds the L2 metric lambda * sum theta^2: without a regulariser theta is not read and the slot is 0.
+// For BASELINE config 2 that is 33 MB instead of 58 MB per step behind the norm launch (HBM-bound).
+__device__ __forceinline__ void tnt_span_norm(const float* theta, const float* grad, const SpanTab& t, int sp, float* partial,
+                                              const float* ovr, float* s0, float* s1) {
+  const int tid = threadIdx.x;
+  const long off = t.span_off[sp];
+  const int len = t.span_len[sp];
+  const int seg = t.span_seg[sp];
+  const float lam2 = 2.f * t.seg_l2[seg];
+  const bool need_w = ovr == nullptr || lam2 != 0.f;
+  const bool need_g = ovr == nullptr || !(ovr[seg] >= 0.f);
+  float q = 0.f, wq = 0.f;
+  const int len4 = len & ~3;
+  if (need_g && need_w) {
+#pragma unroll 4
+    for (int i = tid * 4; i < len4; i += 1024) {
+      const float4 g = *reinterpret_cast<const float4*>(grad + off + i);
+      const float4 w = *reinterpret_cast<const float4*>(theta + off + i);
+      const float a0 = g.x + lam2 * w.x, a1 = g.y + lam2 * w.y, a2 = g.z + lam2 * w.z, a3 = g.w + lam2 * w.w;
+      q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+      wq += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+    }
+    for (int i = len4 + tid; i < len; i += 256) {
+      const float w = theta[off + i], a0 = grad[off + i] + lam2 * w;
+      q += a0 * a0; wq += w * w;
+    }
+  } else if (need_g) {                       // lambda == 0: the gradient alone
+#pragma unroll 8
+    for (int i = tid * 4; i < len4; i += 1024) {
+      const float4 g = *reinterpret_cast<const float4*>(grad + off + i);
+      q += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+    }
+    for (int i = len4 + tid; i < len; i += 256) q += grad[off + i] * grad[off + i];
+  } else if (need_w) {                       // norm supplied, regulariser present: sum theta^2 for the L2 metric
+#pragma unroll 8
+    for (int i = tid * 4; i < len4; i += 1024) {
+      const float4 w = *reinterpret_cast<const float4*>(theta + off + i);
+      wq += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+    }
+    for (int i = len4 + tid; i < len; i += 256) wq += theta[off + i] * theta[off + i];
+  }
+  q = tnt_wave_sum(q); wq = tnt_wave_sum(wq);
+  if ((tid & 63) == 0) { s0[tid >> 6] = q; s1[tid >> 6] = wq; }
+  __syncthreads();
+  if (tid == 0) {
+    partial[2 * sp + 0] = s0[0] + s0[1] + s0[2] + s0[3];
+    partial[2 * sp + 1] = s1[0] + s1[1] + s1[2] + s1[3];
+  }
+}
+
 // lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) for the step being applied, t = *adam_t + 1 (the counter is advanced at the END of the
 // update launch, by its last workgroup, when nobody reads it any more)
 __device__ __forceinline__ float tnt_adam_lr_t(const int64_t* adam_t, const float* lr, float b1, float b2) {

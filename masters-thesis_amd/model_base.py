@@ -167,6 +167,9 @@ class ModelBase:
         # from the span partials themselves, one extra workgroup of the Adam launch files the scalars, the counters tick at its end
         fin = adam and hasattr(be, "adam_fin") and getattr(self, "fused_finalize", True)
         lr_job = (self.adam_t, self.lr_dev, self.lr_t_dev, opt.beta_1, opt.beta_2) if fin else None
+        # the norm launch reads only what the update will consume (tnt_span_norm, csrc/tnt_fin.h): no gradient pass for a
+        # variable whose clip norm is supplied through sq_override, no theta pass where there is no regulariser
+        skip = a.sq_override if (fin and not self.__dict__.get("agc") and getattr(self, "norm_skip", True)) else None
         s1, rest_done = 0, False
         if enc is not None:
             # The dense encoder kernel (segment 0, 59 % of config 2's parameters) never has its gradient written: one
@@ -181,14 +184,14 @@ class ModelBase:
                 # ... with the span norms of every other variable riding in the same launch
                 be.dense_gram_norm(dpre, pre, bias, gx, nsplit, w2, nw2, e.l2, a.partial, s1, rows, E,
                                    spans=(a.theta, a.grad, sp.span_seg[s1:], sp.span_off[s1:], sp.span_len[s1:], a.seg_l2,
-                                          a.partial[2 * s1:], sp.nspan - s1), lr_job=lr_job)
+                                          a.partial[2 * s1:], sp.nspan - s1), lr_job=lr_job, **({"skip": skip} if skip is not None else {}))
                 rest_done = True
             else:
                 be.dense_dw_sqnorm(x, dpre, a.p(name), e.l2, a.partial, s1, N, E, rows, ldx)
         if not rest_done:
             if fin and sp.nspan - s1 > 0:
                 be.span_sqnorm_lr(a.theta, a.grad, sp.span_seg[s1:], sp.span_off[s1:], sp.span_len[s1:], a.seg_l2, a.partial[2 * s1:],
-                                  sp.nspan - s1, *lr_job)
+                                  sp.nspan - s1, *lr_job, **({"skip": skip} if skip is not None else {}))
             else:
                 fin = False
                 be.span_sqnorm(a.theta, a.grad, sp.span_seg[s1:], sp.span_off[s1:], sp.span_len[s1:], a.seg_l2, a.partial[2 * s1:],

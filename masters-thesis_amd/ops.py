@@ -333,16 +333,18 @@ class HipBackend:
         self._call(self.lib.tnt_dense_fwd_stream_gram_f32, "tnt_dense_fwd_stream_gram_f32", _p(x), _p(w), _p(part), _p(gx_part),
                    _p(w2_part), B, E, K, ldx, ldw, nsplit, self._s())
 
-    def dense_gram_norm(self, dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E, spans=None, lr_job=None):
+    def dense_gram_norm(self, dpre, pre, bias, gx_part, nsplit, w2_part, nw2, l2, partial, nslot, Bk, E, spans=None, lr_job=None,
+                        skip=None):
         """``spans`` = (theta, grad, span_seg, span_off, span_len, seg_l2, span_partial, nspan): the span norms of the other
         variables in the same launch (tnt_dense_gram_norm_spans_f32); ``lr_job`` = (adam_t, lr, lr_t, beta1, beta2): Adam's
-        step size for the update that follows, written by the same launch (tnt_dense_gram_norm_spans_lr_f32)"""
+        step size for the update that follows, written by the same launch (tnt_dense_gram_norm_spans_lr_f32); ``skip`` = the
+        sq_override table: variables whose clip norm is supplied there get no pass over their gradient (with lr_job only)"""
         if spans is not None and lr_job is not None:
             th, gr, sseg, soff, slen, sl2, spart, nspan = spans
             at, lr, lrt, b1, b2 = lr_job
             self._call(self.lib.tnt_dense_gram_norm_spans_lr_f32, "tnt_dense_gram_norm_spans_lr_f32", _p(dpre), _p(pre), _p(bias),
                        _p(gx_part), nsplit, _p(w2_part), nw2, l2, _p(partial), nslot, Bk, E, _p(th), _p(gr), _p(sseg), _p(soff),
-                       _p(slen), _p(sl2), _p(spart), nspan, _p(at), _p(lr), _p(lrt), b1, b2, self._s())
+                       _p(slen), _p(sl2), _p(spart), nspan, _p(at), _p(lr), _p(lrt), b1, b2, _p(skip), self._s())
             return
         if spans is None:
             self._call(self.lib.tnt_dense_gram_norm_f32, "tnt_dense_gram_norm_f32", _p(dpre), _p(pre), _p(bias), _p(gx_part), nsplit,
@@ -538,9 +540,11 @@ class HipBackend:
                    _p(span_len), _p(sq_override), nspan, eps, clipnorm, _ct.addressof(fin), _p(met), met.numel() if met is not None else 0,
                    _p(ring), ring.shape[0] if ring is not None else 0, _p(ring_t), self._s())
 
-    def span_sqnorm_lr(self, theta, grad, span_seg, span_off, span_len, seg_l2, partial, nspan, adam_t, lr, lr_t, beta1, beta2):
+    def span_sqnorm_lr(self, theta, grad, span_seg, span_off, span_len, seg_l2, partial, nspan, adam_t, lr, lr_t, beta1, beta2,
+                       skip=None):
+        """``skip`` = the sq_override table (or None): see tnt_span_sqnorm_lr_f32"""
         self._call(self.lib.tnt_span_sqnorm_lr_f32, "tnt_span_sqnorm_lr_f32", _p(theta), _p(grad), _p(span_seg), _p(span_off),
-                   _p(span_len), _p(seg_l2), _p(partial), nspan, _p(adam_t), _p(lr), _p(lr_t), beta1, beta2, self._s())
+                   _p(span_len), _p(seg_l2), _p(partial), nspan, _p(adam_t), _p(lr), _p(lr_t), beta1, beta2, _p(skip), self._s())
 
     def dense_dw_adam_fin(self, x, dpre, theta, m, v, l2, partial, k0, k1, sq_override, lr_t_dev, beta1, beta2, eps, clipnorm, N, E,
                           Bk, ldx, guard=None):

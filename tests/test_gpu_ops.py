@@ -770,6 +770,44 @@ def test_onehot_argmax(be):
 
 
 # -------------------------------------------------------------------------- optimizer
+def test_span_sqnorm_lr_reads_only_what_the_update_consumes(be):
+    """tnt_span_sqnorm_lr_f32 with the sq_override table: a variable whose clip norm is supplied (>= 0) gets no gradient
+    pass (slot 0 of its spans = 0), sum theta^2 is 0 where lambda == 0; without the table every slot is the full pair."""
+    from masters_thesis_amd.arena import build_spans
+    rng = np.random.default_rng(12)
+    lens = [20000, 9000, 4096 * 3 + 5, 64]
+    l2 = [0.01, 0.0, 0.0, 3e-5]
+    ovr = [-1.0, 4.0, -1.0, 2.0]
+    offs, total = [], 0
+    for n in lens:
+        offs.append(total)
+        total += (n + 63) // 64 * 64
+    theta, grad = np.zeros(total), np.zeros(total)
+    for o, n in zip(offs, lens):
+        theta[o:o + n] = rng.standard_normal(n); grad[o:o + n] = rng.standard_normal(n) * 0.01
+    sp = build_spans(offs, lens, device="cuda")
+    th, gr, l2d = dev(theta), dev(grad), dev(l2)
+    at = torch.full((1,), 6, dtype=torch.int64, device="cuda")
+    lr, lrt = dev([1e-3]), torch.zeros(1, device="cuda")
+    first = sp.first_host
+    for table in (None, dev(ovr)):
+        part = torch.full((2 * sp.nspan,), 7.0, device="cuda")
+        be.span_sqnorm_lr(th, gr, sp.span_seg, sp.span_off, sp.span_len, l2d, part, sp.nspan, at, lr, lrt, 0.9, 0.98, skip=table)
+        torch.cuda.synchronize()
+        p = part.cpu().numpy().astype(np.float64).reshape(-1, 2)
+        for s, (o, n, lam) in enumerate(zip(offs, lens, l2)):
+            q, w = p[first[s]:first[s + 1], 0].sum(), p[first[s]:first[s + 1], 1].sum()
+            t, g = theta[o:o + n], grad[o:o + n]
+            need_g = table is None or ovr[s] < 0
+            need_w = table is None or lam != 0
+            want_q = ((g + 2 * lam * t) ** 2).sum() if need_g else 0.0
+            want_w = (t * t).sum() if need_w else 0.0
+            assert abs(q - want_q) <= 1e-5 * max(want_q, 1e-30), (s, q, want_q)
+            assert abs(w - want_w) <= 1e-5 * max(want_w, 1e-30), (s, w, want_w)
+    want_lr = 1e-3 * np.sqrt(1 - 0.98 ** 7) / (1 - 0.9 ** 7)
+    assert abs(float(lrt) - want_lr) <= 1e-6 * want_lr
+
+
 def test_optimizer(be):
     from masters_thesis_amd.arena import build_spans
     rng = np.random.default_rng(10)
