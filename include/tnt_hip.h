@@ -446,12 +446,15 @@ int32_t tnt_embedding_fwd_drop2_f32(const float* table, const int32_t* ids, floa
  * the ids of the previous call (tnt_step_finalize_f32 copies them).  E % 4 == 0, 16-byte aligned rows.
  * drop_rate > 0: drows is the gradient w.r.t. the dropped-out Embedding output (the LSTM layer's input dropout of the
  * text call, NIC.py:131,140); the keep mask tnt_embedding_fwd_drop_f32 applied (element (b*T + t) * E + e of stream
- * (drop_seed, drop_site, *drop_step_dev)) is applied to the rows as they are read. */
+ * (drop_seed, drop_site, *drop_step_dev)) is applied to the rows as they are read.
+ * zero_id >= 0 (-1: none): the caller guarantees that every row of drows whose id is zero_id is zero -- Embedding(mask_zero=True)
+ * in front of an LSTM that honours the mask (NIC.py:77,131,140: a masked step passes no gradient to its input); those rows
+ * (~40 % of a padded caption batch, all of ONE id) are not read, dtable[zero_id] is written as zeros. */
 int32_t tnt_embedding_bwd_parts(int32_t B, int32_t T, int32_t E);
 int32_t tnt_embedding_bwd_sparse_f32(const float* drows, const int32_t* ids, const int32_t* prev_ids, float* dtable,
                                      float* sq_part, int32_t B, int32_t T, int32_t E, int32_t ldd, int32_t V,
                                      float drop_rate, uint64_t drop_seed, uint32_t drop_site,
-                                     const uint32_t* drop_step_dev, void* stream);
+                                     const uint32_t* drop_step_dev, int32_t zero_id, void* stream);
 int32_t tnt_embedding_bwd_f32(const float* drows, const int32_t* ids, float* dtable,
                               float* sq_norm, float* rowsq_work, int32_t B, int32_t T,
                               int32_t E, int32_t ldd, int32_t V, void* stream);

@@ -57,7 +57,7 @@ SIGNATURES = {
     "tnt_embedding_bwd_parts": [I32, I32, I32],
     "tnt_attention_front_bwd_parts": [I32, I32, I32],
     "tnt_attention_metric_parts": [I32, I32],
-    "tnt_embedding_bwd_sparse_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, F32, U64, U32, P, P],
+    "tnt_embedding_bwd_sparse_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, F32, U64, U32, P, I32, P],
     "tnt_embedding_bwd_f32": [P, P, P, P, P, I32, I32, I32, I32, I32, P],
     "tnt_lstm_seq_supported": [I32, I32],
     "tnt_lstm_seq_fwd_f32": [P, P, P, P, P, P, I32, I32, P, P, I32, I32, I32, P, P, P],

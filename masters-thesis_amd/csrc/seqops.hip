@@ -204,11 +204,13 @@ __device__ __forceinline__ float4 emb_row4(const float* drows, int k, int B, int
   return v;
 }
 
-constexpr int EBS_W = 16;            // waves per workgroup = ways the duplicate list of an id is split
-
+// EBS_W = waves per workgroup = ways the duplicate list of an id is split: 16 when the padding id's ~400 rows have to be
+// summed, 4 when the caller declares them zero (zero_id) -- then the launch is bound by the dispatch of its 4 B T workgroups,
+// and a quarter of the waves is a quarter of that
+template <int EBS_W>
 __global__ __launch_bounds__(64 * EBS_W) void emb_bwd_sparse_kernel(const float* drows, const int* ids, const int* prev_ids,
                                                                     float* dtable, float* sq_part, int B, int T, int E,
-                                                                    int ldd, int V, EmbDrop drop) {
+                                                                    int ldd, int V, EmbDrop drop, int zero_id) {
   // The critical path of this launch is the owner of the most frequent id (the padding id: ~400 of 960 rows in a caption
   // batch): its row sum is split 16 ways (4 ways cost 9 us for that one workgroup, 2 ways 17).
   constexpr int NT = 64 * EBS_W;
@@ -247,6 +249,14 @@ __global__ __launch_bounds__(64 * EBS_W) void emb_bwd_sparse_kernel(const float*
   }
   __syncthreads();
   if (s_flag) {
+    if (threadIdx.x == 0) sq_part[(long)k * ny + blockIdx.y] = 0.f;
+    return;
+  }
+  if (id == zero_id) {
+    // the caller declares the rows of this id zero (mask_zero Embedding in front of a masked LSTM, NIC.py:131,140: a masked
+    // step passes no gradient to its input): the owner files a zero row without reading the ~40 % of a caption batch that is
+    // padding -- that one row sum was the critical path of the launch
+    if (w == 0 && jok) *reinterpret_cast<float4*>(dtable + (long)id * E + j) = make_float4(0.f, 0.f, 0.f, 0.f);
     if (threadIdx.x == 0) sq_part[(long)k * ny + blockIdx.y] = 0.f;
     return;
   }
@@ -744,14 +754,20 @@ extern "C" int32_t tnt_embedding_bwd_parts(int32_t B, int32_t T, int32_t E) { re
 extern "C" int32_t tnt_embedding_bwd_sparse_f32(const float* drows, const int32_t* ids, const int32_t* prev_ids,
                                                 float* dtable, float* sq_part, int32_t B, int32_t T, int32_t E,
                                                 int32_t ldd, int32_t V, float drop_rate, uint64_t drop_seed,
-                                                uint32_t drop_site, const uint32_t* drop_step_dev, void* stream) {
+                                                uint32_t drop_site, const uint32_t* drop_step_dev, int32_t zero_id,
+                                                void* stream) {
   if (B <= 0 || T <= 0 || E <= 0 || V <= 0) return TNT_BADARG(6);
   if (E % 4 != 0 || ldd % 4 != 0 || !tnt_aligned16(drows) || !tnt_aligned16(dtable)) return TNT_BADARG(1);
   if (prev_ids == nullptr || sq_part == nullptr || prev_ids == ids) return TNT_BADARG(3);
+  if (zero_id >= V) return TNT_BADARG(14);
   if (drop_rate < 0.f || drop_rate >= 1.f) return TNT_BADARG(11);
   const EmbDrop drop{drop_rate, 1.0f / (1.0f - drop_rate), drop_seed, drop_site, drop_step_dev};
-  hipLaunchKernelGGL(emb_bwd_sparse_kernel, dim3(2 * B * T, (E + 255) / 256), dim3(64 * EBS_W), 0, tnt_stream(stream), drows,
-                     ids, prev_ids, dtable, sq_part, B, T, E, ldd, V, drop);
+  if (zero_id >= 0)
+    hipLaunchKernelGGL(emb_bwd_sparse_kernel<4>, dim3(2 * B * T, (E + 255) / 256), dim3(256), 0, tnt_stream(stream), drows,
+                       ids, prev_ids, dtable, sq_part, B, T, E, ldd, V, drop, zero_id);
+  else
+    hipLaunchKernelGGL(emb_bwd_sparse_kernel<16>, dim3(2 * B * T, (E + 255) / 256), dim3(1024), 0, tnt_stream(stream), drows,
+                       ids, prev_ids, dtable, sq_part, B, T, E, ldd, V, drop, zero_id);
   TNT_LAUNCH_CHECK();
   return 0;
 }

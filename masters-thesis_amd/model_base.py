@@ -301,7 +301,7 @@ class ModelBase:
         return bool(self.__dict__.get("_defer_sum2") and self.dp_world == 1 and getattr(self, "sparse_emb_bwd", True)
                     and hasattr(self.be, "embedding_bwd_sparse") and E % 4 == 0 and ldd % 4 == 0)
 
-    def _embedding_bwd(self, drows, ids, name, B, T, E, ldd, V, drop=None):
+    def _embedding_bwd(self, drows, ids, name, B, T, E, ldd, V, drop=None, zero_id=-1):
         """Embedding scatter + IndexedSlices norm.  Inside the fused single-process step (``_defer_sum2``) the sparse
         form runs: no table-wide zero fill (rows touched by the previous step only are cleaned through ``prev_ids``),
         the norm as per-block partials that the step-finalize launch sums.  Anywhere else (data parallel: the all-reduce
@@ -323,6 +323,8 @@ class ModelBase:
         assert drop is None or sparse, "the input-dropout mask can only ride on the sparse form"
         if sparse:
             kw = dict(drop_rate=drop[0], drop_seed=drop[1], drop_site=drop[2], drop_step_dev=drop[3]) if drop else {}
+            if zero_id >= 0 and getattr(self, "emb_skip_masked", True):
+                kw["zero_id"] = zero_id       # rows of the mask id carry no gradient (the caller's guarantee): not read
             be.embedding_bwd_sparse(drows, ids, prev, a.g(name), parts, B, T, E, ldd, V, **kw)
             self._emb_finalize = (parts, None if self.__dict__.get("agc") else sqo, nparts, ids, prev, B * T)
         else:

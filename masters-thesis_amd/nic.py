@@ -478,8 +478,10 @@ class NIC(ModelBase):
         elif self.r_lstm > 0 and not fold:
             be.dropout(self.dXin[B:], self.dXin[B:], T * B, E, E, B, E, 0, self.r_lstm, sd, S_LSTM_IN + 1, 0, ds)
         self._emb_rows = (self.dXin[B:], T * B, E, E, "emb_text/embeddings")
+        # id 0 is the Embedding's mask (mask_zero, NIC.py:77) and the text LSTM honours it: a masked step hands no gradient to
+        # its input row, so the rows of id 0 are zero (BPTT leaves dz = 0 there and dXin = dz W^T)
         self._embedding_bwd(self.dXin[B:], self.cap, "emb_text/embeddings", B, T, E, E, V,
-                            drop=(self.r_lstm, sd, S_LSTM_IN + 1, ds) if fold else None)
+                            drop=(self.r_lstm, sd, S_LSTM_IN + 1, ds) if fold else None, zero_id=0)
         if ride:
             return
         if fused:       # dropout' -> BatchNorm' -> dropout' -> LeakyReLU' -> dpre, encoder bias gradient: one launch

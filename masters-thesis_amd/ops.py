@@ -564,9 +564,10 @@ class HipBackend:
         return int(self.lib.tnt_embedding_bwd_parts(B, T, E))
 
     def embedding_bwd_sparse(self, drows, ids, prev_ids, dtable, sq_part, B, T, E, ldd, V, drop_rate=0.0, drop_seed=0,
-                             drop_site=0, drop_step_dev=None):
+                             drop_site=0, drop_step_dev=None, zero_id=-1):
+        """``zero_id`` >= 0: the caller guarantees that the rows of that id are zero (mask_zero + masked LSTM); they are not read"""
         self._call(self.lib.tnt_embedding_bwd_sparse_f32, "tnt_embedding_bwd_sparse_f32", _p(drows), _p(ids), _p(prev_ids), _p(dtable),
-                   _p(sq_part), B, T, E, ldd, V, drop_rate, int(drop_seed), int(drop_site), _p(drop_step_dev), self._s())
+                   _p(sq_part), B, T, E, ldd, V, drop_rate, int(drop_seed), int(drop_site), _p(drop_step_dev), int(zero_id), self._s())
 
     def agc(self, theta, grad, tab, gsq_cols=None, sq_out=None, clip_factor=0.01, eps=1e-3):
         """unit-wise adaptive gradient clipping over the arena; ``tab`` = arena.AgcTable"""

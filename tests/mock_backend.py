@@ -665,9 +665,12 @@ class MockBackend:
         return B * T * ((E + 255) // 256)
 
     def embedding_bwd_sparse(self, drows, ids, prev_ids, dtable, sq_part, B, T, E, ldd, V, drop_rate=0.0, drop_seed=0,
-                             drop_site=0, drop_step_dev=None):
+                             drop_site=0, drop_step_dev=None, zero_id=-1):
         """include/tnt_hip.h: tnt_embedding_bwd_sparse_f32 from its contract: only rows of ids and prev_ids are touched"""
         idv = np.clip(flat(ids)[:B * T].reshape(B, T), 0, V - 1)
+        if zero_id >= 0:          # the caller's guarantee, checked here: the rows the kernel will not read ARE zero
+            r = mat(drows, T * B, E, ldd).reshape(T, B, E)
+            assert not r[(idv == zero_id).T].any(), "embedding_bwd_sparse: rows of zero_id carry a gradient"
         if drop_rate > 0:         # the mask the forward applied, on a copy (the row buffer itself stays undropped)
             tmp = torch.zeros(T * B, E, dtype=torch.float32)
             tmp.copy_(torch.as_strided(drows, (T * B, E), (ldd, 1)))

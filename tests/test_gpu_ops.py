@@ -611,6 +611,36 @@ def test_embedding_bwd_sparse_over_consecutive_steps(be, B, T, E, V):
         assert torch.equal(prev, idd.reshape(-1))
 
 
+def test_embedding_bwd_sparse_skips_the_rows_of_the_mask_id(be):
+    """zero_id: rows of that id are declared zero by the caller and never read -- poisoned here with NaN to show it; the table
+    equals the dense scatter with those rows at zero, the mask id's own row is written as zeros (also when a previous step
+    left something there), the norm is that of the other rows."""
+    rng = np.random.default_rng(5)
+    B, T, E, V = 64, 15, 512, 5001
+    n = B * T
+    table = torch.full((V, E), 3.0, device="cuda")
+    table[1:] = 0
+    prev = torch.full((n,), -1, dtype=torch.int32, device="cuda"); prev[0] = 0
+    nparts = be.embedding_bwd_parts(B, T, E)
+    parts, sq, none = torch.zeros(nparts, device="cuda"), torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    ids = rng.integers(1, 40, (B, T)).astype(np.int32)
+    for b in range(B):
+        ids[b, rng.integers(3, T):] = 0                         # padded tails
+    drows = rng.standard_normal((T, B, E))
+    clean = drows.copy(); clean[(ids == 0).T] = 0.0
+    drows[(ids == 0).T] = np.nan
+    idd = dev(ids, torch.int32)
+    be.embedding_bwd_sparse(dev(drows.reshape(T * B, E)), idd, prev, table, parts, B, T, E, E, V, zero_id=0)
+    be.step_finalize(none, None, None, None, None, None, 0, extra_part=parts, extra=sq, n_extra=nparts, ids_src=idd,
+                     ids_dst=prev, n_ids=n)
+    torch.cuda.synchronize()
+    want = O.embedding_bwd_dense(np.transpose(clean, (1, 0, 2)), ids, V)
+    assert not torch.isnan(table).any()
+    close(table, want, atol=1e-5 * np.abs(want).max())
+    assert float(table[0].abs().max()) == 0.0
+    assert abs(float(sq) - (clean ** 2).sum()) <= 1e-5 * (clean ** 2).sum()
+
+
 def test_step_finalize(be):
     """tnt_step_finalize_f32 == seg_finalize + l2_total + sum2 + step_tick of the unfused sequence."""
     rng = np.random.default_rng(77)
