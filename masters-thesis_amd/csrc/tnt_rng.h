@@ -8,12 +8,21 @@
 
 struct TntPhilox4 { uint32_t v[4]; };
 
+// 32 x 32 -> 64-bit product as ONE v_mad_u64_u32: hipcc lowers __umulhi(a, b) and a * b to v_mul_hi_u32 + v_mul_lo_u32, two
+// quarter-rate instructions for the two halves of the same product.  64 M Philox calls on MI355X: 174 -> 119 us
+// (tools/probe/philox_mad_probe.hip; identical words).
+__device__ __forceinline__ uint64_t tnt_mul_wide(uint32_t a, uint32_t b) {
+  uint64_t p, carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p), "=s"(carry) : "v"(a), "v"(b));
+  return p;
+}
+
 __device__ __forceinline__ TntPhilox4 tnt_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                          uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint64_t p0 = tnt_mul_wide(0xD2511F53u, c0), p1 = tnt_mul_wide(0xCD9E8D57u, c2);
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
