@@ -36,6 +36,7 @@ MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak
 # group; filled from the summaries committed under profiles/ (None = not collected for that kernel)
 _PMC3 = "profiles/r03_pmc_gemm3_and_chains.txt"
 _PMC3C = "profiles/r03_pmc_chains_end_of_round.txt"         # the chain kernels as they stand at the end of the round
+_PMC3N = "profiles/r03_pmc_end_of_round_nt.txt"             # the optimizer kernels with non-temporal moments (end of round 3)
 _kib = lambda fetch, write: int((2 * fetch + write) * 1024)
 PMC_TRAFFIC = {
     "dense": {"tnt_gemm3_pair_f32 TN 512x5001x960 + NT 960x512x5001": (_kib(69608.1, 23574.0), _PMC3),
@@ -44,13 +45,15 @@ PMC_TRAFFIC = {
               "tnt_gemm3_f32 NN 1024x2048x512": (_kib(10295.9, 8192.0), _PMC3),
               "tnt_lstm_seq_fwd_f32 S=16 B=64 U=512": (_kib(21653.1, 14239.1), _PMC3C),
               "tnt_lstm_seq_bwd_f32 S=16 B=64 U=512": (_kib(28751.2, 23211.6), _PMC3C),
-              "tnt_dense_dw_adam_f32 20000x512x64": (_kib(66176.8, 120000.0), _PMC3),
-              "tnt_dense_dw_adam_fin_f32 20000x512x64": (_kib(66176.8, 120000.0), _PMC3)},      # the same kernel and operands
+              "tnt_dense_dw_adam_f32 20000x512x64": (_kib(66692.6, 120000.0), _PMC3N),
+              "tnt_dense_dw_adam_fin_f32 20000x512x64": (_kib(66692.6, 120000.0), _PMC3N),     # the same kernel and operands
+              "tnt_adam_fin_f32": (_kib(56762.8, 84745.7), _PMC3N)},
     "attention": {"tnt_lc_seq_fwd_drop_f32 T=15 B=64 R=360 U=512": (_kib(27245.3, 15566.9), _PMC3C),
                   "tnt_lc_seq_bwd_drop_f32 T=15 B=64 R=360 U=512": (_kib(32031.3, 39104.4), _PMC3C),
                   "tnt_gemm3_pair_f32 TN 256x5001x960 + NT 960x256x5001": (_kib(62224.7, 21897.9), _PMC3),
                   "tnt_gemm3_pair_f32 TN 512x2048x960 x2 + NT 960x512x2048": (_kib(51075.9, 13960.0), _PMC3),
-                  "tnt_gemm3_f32 NN 960x5001x256": (_kib(6616.8, 18885.0), _PMC3)},
+                  "tnt_gemm3_f32 NN 960x5001x256": (_kib(6616.8, 18885.0), _PMC3),
+                  "tnt_adam_fin_f32": (_kib(53628.8, 79882.9), _PMC3N)},
 }
 STEP_GFLOP = {"dense": 30.3, "attention": 22.0}          # SURVEY 8d, whole training step
 WORKLOAD_NAME = {
