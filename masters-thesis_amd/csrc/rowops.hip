@@ -1385,4 +1385,4 @@ extern "C" int32_t tnt_stage_batch_h16(const uint16_t* x_half, float* x_dst, con
                                     h0, c0, c0_dst, B, T, N, ldx, U, xT_dst, ldt, stream);
 }
 
-extern "C" int32_t tnt_version(void) { return 103; }
+extern "C" int32_t tnt_version(void) { return 104; }

@@ -200,7 +200,7 @@ class PipelinedDenseSync:
 
         cap = lambda key, fn: (m._run_planned if key[0][2:] in self.eager else m._run_captured)(key, fn)
         ib = self.__dict__.get("_ib") or self.__dict__.setdefault("_ib", _IssueBehind(m))
-        cap(("dpA", B, T), lambda: (m._forward(B, T, True), m._loss_metrics(B, T, True), m._bwd_head(B, T)))
+        cap(("dpA", B, T), lambda: _segment_a(m, B, T, defer_totals=not self.split_update))
         eA = ib.mark(0)
         cap(("dpB1", B, T), lambda: (m._bwd_seq_lstm(B, T), m.join()))          # enqueued before the host turns to the collectives
         eB1 = ib.mark(1)
@@ -297,7 +297,7 @@ class PipelinedAttentionSync:
         cap = lambda key, fn: (m._run_planned if key[0][2:] in self.eager else m._run_captured)(key, fn)
 
         ib = self.__dict__.get("_ib") or self.__dict__.setdefault("_ib", _IssueBehind(m))
-        cap(("dpA", B, T), lambda: (m._forward(B, T, True), m._loss_metrics(B, T, True), m._bwd_head(B, T)))
+        cap(("dpA", B, T), lambda: _segment_a(m, B, T, defer_totals=not self.split_update))
         eA = ib.mark(0)
         cap(("dpB1", B, T), lambda: m._bwd_chain(B, T))               # every compute segment is enqueued before the host turns to
         eB1 = ib.mark(1)                                              # the collective behind its predecessor (_IssueBehind)
@@ -324,6 +324,18 @@ class PipelinedAttentionSync:
 
     def __call__(self, model):          # not used by lc_nic.train_step (it calls step); kept for the generic protocol
         make_grad_sync(self.world)(model)
+
+
+def _segment_a(m, B, T, defer_totals):
+    """Segment A of the pipelined schedules: forward + loss + head backward.  ``defer_totals`` (the default one-update form):
+    the step's loss / accuracy (/ attention-metric) totals are not summed by a launch of their own behind the loss kernel but
+    by the finalize work of the update launch at the end of the step (ModelBase._update_fused), as in the single-process step.
+    Only this segment defers: the Embedding backward and the encoder update keep their data-parallel forms."""
+    m._defer_sum2 = bool(defer_totals)
+    try:
+        m._forward(B, T, True); m._loss_metrics(B, T, True); m._bwd_head(B, T)
+    finally:
+        m._defer_sum2 = False
 
 
 def _sparse_norm_slot(model):

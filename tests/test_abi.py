@@ -55,7 +55,7 @@ def test_library_exports_and_binding_match_the_header():
         for i, (ct, ps) in enumerate(zip(sig, params)):
             want = "ptr" if ps.endswith("*") else ps.replace("const ", "")
             assert kind(ct) == want, (name, i, ps, kind(ct))
-    assert lib.tnt_version() >= 103
+    assert lib.tnt_version() >= 104
 
 
 def test_product_has_no_cpu_fallback():
