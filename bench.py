@@ -355,15 +355,17 @@ def dp_world1_rehearsal(args, device):
     ms_per_step shows what the schedule itself costs (segments, unfused update, dense embedding backward) before any
     communication.  Run in a child process (it needs a process group; this process keeps its single-GPU state)."""
     out = {}
-    for wl in ("dense", "attention"):
+    for name, wl, extra in (("dense", "dense", {}), ("attention", "attention", {}),
+                            ("dense_row_sharded_encoder", "dense", {"TNT_DP_SHARD_ENC": "1"})):      # opt-in form (dp.py)
         cmd = [sys.executable, os.path.abspath(__file__), "--force-dp", "--workload", wl, "--steps", str(min(args.steps, 200)),
                "--warmup", str(min(args.warmup, 20)), "--no-cpu-baseline", "--no-config3", "--no-dp-world1"]
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env["MASTER_PORT"] = str(29600 + os.getpid() % 300)
+        env.update(extra)
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
-        out[wl] = round(json.loads(lines[-1])["ms_per_step"], 4) if p.returncode == 0 and lines else None
+        out[name] = round(json.loads(lines[-1])["ms_per_step"], 4) if p.returncode == 0 and lines else None
     return {"ms_per_step": out, "note": "dp.attach(model, 1) over RCCL on this GPU: schedule overhead only, no scaling claim"}
 
 

@@ -142,12 +142,15 @@ class PipelinedDenseSync:
     # graph.  World-size-1 rehearsal (tools/host_overhead.py --dp): all graphs 0.905 ms/step, this choice 0.854
     # with the host at 0.52 ms/step, all plans 0.847 with the host at 0.69.  The single-GPU step stays ONE graph
     # (0.7195 ms vs 0.7142 as a plan: within noise, and the plan keeps the host 80 % busy).
-    eager = frozenset(os.environ.get("TNT_DP_EAGER", "A,B2,C,C0,C1,C2").split(","))
+    eager = frozenset(os.environ.get("TNT_DP_EAGER", "A,B2,C,C0,C1,C2,S1,S2").split(","))
 
-    def __init__(self, world):
+    def __init__(self, world, shard_encoder=None, rank=None):
         self.world = world
         self._bufs = {}
         self._slices = None
+        # row-sharded update of the encoder kernel (opt-in: dp.attach(shard_encoder=True) / TNT_DP_SHARD_ENC=1), see step()
+        self.shard_encoder = (os.environ.get("TNT_DP_SHARD_ENC", "0") == "1") if shard_encoder is None else bool(shard_encoder)
+        self.rank = rank
         self.split_update = os.environ.get("TNT_DP_SPLIT_UPDATE", "0") == "1"
         self.one_graph = os.environ.get("TNT_DP_ONE_GRAPH", "0") == "1"
         self.capture_error = None
@@ -224,6 +227,34 @@ class PipelinedDenseSync:
                 w.wait()
             cap(("dpC2", B, T), lambda: (m._update_slice(s_mid), m.be.l2_total(a.wsq, a.seg_l2, a.nseg, m.met[2:3])))
             return
+        if self._shard_ok(m):
+            # Row-sharded encoder update (opt-in until a multi-GPU node has timed it against the default):
+            # every rank forms N / G rows of dW from the gathered operands -- the single-process product's work instead of G
+            # times it (segment C1 at world-8 operand sizes: 160 us against 54 fused, profiles/r03_dp_c1_at_world8_operand_sizes.txt)
+            # --, the variable's clip norm is an 8-byte all-reduce of the shards' (sum g^2, sum theta^2) pairs, Adam runs on the
+            # shard (1 / G of the optimizer traffic of 59 % of the parameters), and the updated rows are all-gathered: 41 MB x (G-1)/G
+            # per rank that the NEXT step's first launch waits for -- the price, and the reason this is not the default unmeasured.
+            # The moments of the other shards' rows are never touched on this rank (they live on their owner).
+            G, rank = self.world, (dist.get_rank() if self.rank is None else self.rank)
+            nr = m.N // G
+            r0 = rank * nr
+            for w in (w_x, w_dpre):
+                w.wait()
+            cap(("dpS1", B, T), lambda: m._enc_shard_grad(x_all, dpre_all, r0, nr))
+            eS = ib.mark(3)
+            w_n = ib.behind(eS, lambda: self._ar(a.partial[0:2]))
+            for w in (w_head, w_lstm, w_front, w_n):
+                w.wait()
+            cap(("dpS2", B, T), lambda: (m._update_fused(m.met[2:3], skip_first=True), m._enc_shard_adam(r0, nr)))
+            e0 = a.entries["dense_img/kernel"]
+            whole, mine = a.theta[e0.off:e0.off + e0.size], a.theta[e0.off + r0 * m.E:e0.off + (r0 + nr) * m.E]
+            if dist.get_backend() == "gloo":         # (its all_gather takes a list of outputs: the shard goes through a copy)
+                send = m._enc_shard["send"]
+                send.copy_(mine)
+                self._gather(whole, send).wait()
+            else:                                    # RCCL in place: rank r's input IS slot r of the output
+                dist.all_gather_into_tensor(whole, mine, async_op=True).wait()
+            return
         # default: ONE update behind all collectives -- the encoder gradient from the gathered operands, then the
         # single-process update sequence (span norms of every variable in one launch, one finalize launch with the tick and
         # the L2 metric, one clip + Adam launch): 5 launches instead of 14 (world-size-1 rehearsal: -28 us of kernels and
@@ -231,6 +262,13 @@ class PipelinedDenseSync:
         for w in (w_head, w_x, w_dpre, w_lstm, w_front):
             w.wait()
         cap(("dpC", B, T), lambda: (m._bwd_enc(B, T, x_all, dpre_all), m._update_fused(m.met[2:3])))
+
+    def _shard_ok(self, m):
+        """the row-sharded encoder update applies: opted in, equal 16-byte-aligned shards, Adam, no adaptive clipping"""
+        opt = m.optimizer
+        return bool(self.shard_encoder and not self.split_update and m.N % self.world == 0 and (m.N // self.world) % 4 == 0
+                    and opt is not None and opt.kind == "adam" and not m.__dict__.get("agc")
+                    and m.arena.entries["dense_img/kernel"].seg == 0 and hasattr(m.be, "step_finalize"))
 
     def __call__(self, model):          # generic fallback (models without a pipelined schedule)
         make_grad_sync(self.world)(model)
@@ -345,7 +383,7 @@ def _sparse_norm_slot(model):
     return model.arena.sq_override[seg:seg + 1]
 
 
-def attach(model, world=None, bucket_elems=None, pipelined=None, rank=None, sync_bn=False):
+def attach(model, world=None, bucket_elems=None, pipelined=None, rank=None, sync_bn=False, shard_encoder=None):
     """Make ``model`` data-parallel over the default process group.  The dense-encoder NIC and the attention NIC
     (incl. its multi-subject form) get their pipelined schedules unless pipelined=False; every other model the
     generic one (all-reduce of the whole arena between backward and update).
@@ -356,7 +394,10 @@ def attach(model, world=None, bucket_elems=None, pipelined=None, rank=None, sync
     sync_bn=True: BatchNorm statistics over the GLOBAL batch (ModelBase._bn_fwd / _bn_bwd: an all-gather of the chunk
     partials in the forward, an all-reduce of two sums per channel in the backward), which extends that contract to
     BatchNorm encoders.  The collectives sit inside the forward / backward pass, so such a model runs the generic schedule
-    eagerly (no captured segments); per-replica statistics with the pipelined schedules remain the default."""
+    eagerly (no captured segments); per-replica statistics with the pipelined schedules remain the default.
+    shard_encoder=True (dense-encoder NIC; default: TNT_DP_SHARD_ENC): the encoder kernel's update is row-sharded over the
+    ranks (PipelinedDenseSync.step).  Every rank keeps the complete, identical kernel; only the optimizer moments of a shard
+    live on its owner alone."""
     world = dist.get_world_size() if world is None else world
     rank = dist.get_rank() if rank is None else rank
     if model.__dict__.get("agc") and world > 1:
@@ -378,7 +419,7 @@ def attach(model, world=None, bucket_elems=None, pipelined=None, rank=None, sync
     if pipelined is None:
         pipelined = dense or att
     if pipelined and dense:
-        model.grad_sync = PipelinedDenseSync(world)
+        model.grad_sync = PipelinedDenseSync(world, shard_encoder=shard_encoder, rank=rank)
     elif pipelined and att:
         model.grad_sync = PipelinedAttentionSync(world)
     else:

@@ -143,10 +143,13 @@ class ModelBase:
             be.sgd(a.theta, self.opt_m, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.sq, a.sq_override,
                    sp.nspan, 0.0, self.lr_dev, opt.momentum, clip, guard=gd)
 
-    def _update_fused(self, l2_out):
+    def _update_fused(self, l2_out, skip_first=False):
         """single-process update: [AGC] -> span norms -> ONE finalize launch (per-variable norms, L2 metric, the step's
         loss / accuracy totals if the model deferred them, step tick) -> clip + Adam / SGD.  Replaces the five dependent
-        launches seg_finalize, l2_total, sum2, step_tick of the unfused sequence (each ~4.6 us inside the graph)."""
+        launches seg_finalize, l2_total, sum2, step_tick of the unfused sequence (each ~4.6 us inside the graph).
+        ``skip_first`` (dp.PipelinedDenseSync with a row-sharded encoder kernel): variable 0 is updated by the caller, its
+        (sum g^2, sum theta^2) pair sits in partial[0:2] with the variable's other slots zero -- the finalize work files it
+        like any other, the norm / update launches here start behind it."""
         be, a, sp, opt = self.be, self.arena, self.arena.spans, self.optimizer
         self._apply_agc()
         d = self.__dict__.pop("_sum2_deferred", None)
@@ -171,6 +174,10 @@ class ModelBase:
         # variable whose clip norm is supplied through sq_override, no theta pass where there is no regulariser
         skip = a.sq_override if (fin and not self.__dict__.get("agc") and getattr(self, "norm_skip", True)) else None
         s1, rest_done = 0, False
+        if skip_first:
+            if enc is not None or not adam:
+                raise RuntimeError("skip_first needs Adam and an encoder gradient that the caller handles")
+            s1 = sp.first_host[1]
         if enc is not None:
             # The dense encoder kernel (segment 0, 59 % of config 2's parameters) never has its gradient written: one
             # pass of the skinny product leaves its norm partials in the variable's span slots, a second one applies

@@ -522,6 +522,42 @@ class NIC(ModelBase):
         else:
             self.gemm_sk(x, dpre, a.g("dense_img/kernel"), self.N, self.E, rows, self.ldx, self.E, self.E, transA=True)
 
+    # ---- row-sharded update of the encoder kernel under data parallel (dp.PipelinedDenseSync(shard_encoder=True)): rank r forms
+    # rows [r0, r0 + nr) of dW = X_all^T dpre_all from the gathered operands (N / G rows: the single-process product's work
+    # instead of G times it), the variable's clip norm is one 8-byte all-reduce of the shards' (sum g^2, sum theta^2), Adam runs
+    # on the shard (1 / G of the 246 MB the update of this variable moves) and the updated rows are all-gathered.
+    def _enc_shard_state(self, r0, nr):
+        st = self.__dict__.get("_enc_shard")
+        if st is None or st["key"] != (r0, nr):
+            from .arena import build_spans
+            a, e = self.arena, self.arena.entries["dense_img/kernel"]
+            assert e.seg == 0 and e.off == 0
+            sp = build_spans([e.off + r0 * self.E], [nr * self.E], self.device)
+            st = self._enc_shard = dict(key=(r0, nr), sp=sp, scratch=self._f(2 * sp.nspan), send=self._f(nr * self.E))
+            a.partial[:2 * a.spans.first_host[1]].zero_()          # the variable's slots: only [0:2] carries data from here on
+        return st
+
+    def _enc_shard_grad(self, x_all, dpre_all, r0, nr):
+        """rows [r0, r0 + nr) of the encoder kernel's global-batch gradient + the shard's norm pair -> arena.partial[0:2]"""
+        be, a = self.be, self.arena
+        st = self._enc_shard_state(r0, nr)
+        sp = st["sp"]
+        rows = x_all.shape[0]
+        self.gemm_sk(x_all[:, r0:], dpre_all, a.g("dense_img/kernel")[r0:r0 + nr], nr, self.E, rows, self.ldx, self.E, self.E,
+                     transA=True)
+        be.seg_sqnorm(a.theta, a.grad, sp.span_seg, sp.span_off, sp.span_len, sp.seg_first, a.seg_l2, st["scratch"],
+                      a.partial[0:1], a.partial[1:2], None, sp.nspan, 1)
+
+    def _enc_shard_adam(self, r0, nr):
+        """clip (norm of the WHOLE variable: arena.partial[0], all-reduced) + Adam on the shard; the updated rows -> send buffer"""
+        be, a, opt = self.be, self.arena, self.optimizer
+        st = self._enc_shard_state(r0, nr)
+        sp = st["sp"]
+        clip = opt.clipnorm if opt.clipnorm is not None else 0.0
+        be.adam(a.theta, self.opt_m, self.opt_v, a.grad, sp.span_seg, sp.span_off, sp.span_len, a.seg_l2, a.partial[0:1],
+                a.sq_override, sp.nspan, 0.0, self.lr_t_dev, opt.beta_1, opt.beta_2, opt.epsilon, clip, guard=self._guard_word())
+        return st["send"]
+
     # ------------------------------------------------------------------ steps
     def _train_graph(self, B, T):
         self._forward(B, T, True)

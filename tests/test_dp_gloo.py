@@ -283,3 +283,80 @@ def test_fit_logs_and_stop_flag_agree_across_ranks():
     assert res[0][0] == res[1][0] == 2, (res[0][0], res[1][0])
     for a, b in zip(res[0][1], res[1][1]):
         assert a.keys() == b.keys() and all(abs(a[k] - b[k]) < 1e-12 for k in a)
+
+
+def _worker_shard(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import masters_thesis_amd.ops as ops
+    from masters_thesis_amd import dp
+    from masters_thesis_amd.optimizers import Adam
+    from mock_backend import MockBackend
+    from helpers import synth_batch
+    ops.set_backend(MockBackend())
+    model = _make_n24(seed=100 + rank)
+    model.compile(Adam(1e-3, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    dp.attach(model, shard_encoder=True)
+    rng = np.random.default_rng(7)
+    d = DIMS
+    out = []
+    for step in range(3):
+        data, tgt = synth_batch(world * d["B"], 24, d["T"], d["V"], d["U"], rng)
+        sl = slice(rank * d["B"], (rank + 1) * d["B"])
+        m = model.train_step((tuple(a[sl] for a in data), tgt[sl]))
+        out.append({k: float(v) for k, v in dp.allreduce_metrics(m).items()})
+    sharded = model.grad_sync._shard_ok(model)
+    q.put((rank, model.get_weights_dict(), out, sharded))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _make_n24(seed):
+    d = DIMS
+    from masters_thesis_amd.nic import NIC
+    return NIC(24, d["U"], d["E"], d["V"], d["T"], 0.0, 0.0, 0.0, 0.01, 3e-5, 1e-5, norm="layer", device="cpu", seed=seed)
+
+
+def test_dp2_row_sharded_encoder_update_equals_single_process():
+    """dp.attach(shard_encoder=True): each of two ranks forms HALF the rows of the encoder kernel's gradient from the gathered
+    operands, the clip norm is the all-reduced pair of shard norms, Adam runs on the shard, the updated rows are all-gathered --
+    three steps (the moments of a shard live on its owner only) train like ONE process on the concatenated batch, replicas
+    identical, L2 metric (sum theta^2 of the whole kernel) included."""
+    world, port = 2, 35500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_shard, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, w, out, sharded = q.get(timeout=120)
+        res[r] = (w, out, sharded)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][2] and res[1][2], "the sharded path did not apply"
+    for k in res[0][0]:
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
+    sys.path.insert(0, HERE)
+    import masters_thesis_amd.ops as ops
+    from masters_thesis_amd.optimizers import Adam
+    from mock_backend import MockBackend
+    from helpers import synth_batch
+    old = ops._backend
+    ops.set_backend(MockBackend())
+    try:
+        ref = _make_n24(seed=100)
+        ref.compile(Adam(1e-3, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+        rng = np.random.default_rng(7)
+        d = DIMS
+        for step in range(3):
+            data, tgt = synth_batch(world * d["B"], 24, d["T"], d["V"], d["U"], rng)
+            m = ref.train_step((data, tgt)).as_floats()
+            assert abs(m["loss"] - res[0][1][step]["loss"]) < 1e-5
+            assert abs(m["L2"] - res[0][1][step]["L2"]) < 1e-6 * max(1.0, abs(m["L2"])), (step, m["L2"], res[0][1][step]["L2"])
+        for k, v in ref.get_weights_dict().items():
+            assert np.allclose(res[0][0][k], v, rtol=1e-4, atol=2e-6), (k, np.abs(res[0][0][k] - v).max())
+    finally:
+        ops.set_backend(old)

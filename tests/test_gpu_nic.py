@@ -218,6 +218,36 @@ def test_pipelined_dp_schedule_world1_equals_single_gpu_step():
         dist.destroy_process_group()
 
 
+def test_row_sharded_encoder_update_world1_equals_single_gpu_step():
+    """dp.attach(shard_encoder=True) at world size 1 over RCCL on the HIP kernels: the shard is the whole kernel, so the schedule
+    (shard product on gemm3, shard norm -> 8-byte all-reduce, everything else through the fused update behind variable 0, shard
+    Adam, all-gather of the rows) must train like the single-GPU step; world size 2 against one process: tests/test_dp_gloo.py."""
+    import socket
+    import torch.distributed as dist
+    from masters_thesis_amd import dp
+    a, b, (B, N, T, V, U, E) = _twin_models()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        dp.attach(b, 1, shard_encoder=True)
+        assert isinstance(b.grad_sync, dp.PipelinedDenseSync) and b.grad_sync._shard_ok(b)
+        rng = np.random.default_rng(6)
+        lr = 1e-3
+        for step in range(5):
+            data, tgt = synth_batch(B, N, T, V, U, rng)
+            ra, rb = a.train_step((data, tgt)).as_floats(), b.train_step((data, tgt)).as_floats()
+            for k in ra:
+                assert abs(ra[k] - rb[k]) <= 1e-6 * max(1.0, abs(ra[k])), (step, k, ra, rb)
+        torch.cuda.synchronize()
+        d = (a.arena.theta - b.arena.theta).abs().max().item()
+        assert d <= 1e-3 * lr, d
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("betas_dtype", ["float32", "float16"])
 def test_pinned_prefetcher_feeds_the_step(betas_dtype):
     """data.PinnedPrefetcher (pinned double-buffered H2D on a side stream; optionally float16 betas on the wire, widened
