@@ -151,6 +151,7 @@ class PipelinedDenseSync:
         # row-sharded update of the encoder kernel (opt-in: dp.attach(shard_encoder=True) / TNT_DP_SHARD_ENC=1), see step()
         self.shard_encoder = (os.environ.get("TNT_DP_SHARD_ENC", "0") == "1") if shard_encoder is None else bool(shard_encoder)
         self.rank = rank
+        self.dpre_ride = os.environ.get("TNT_DP_DPRE_RIDE", "1") == "1"
         self.split_update = os.environ.get("TNT_DP_SPLIT_UPDATE", "0") == "1"
         self.one_graph = os.environ.get("TNT_DP_ONE_GRAPH", "0") == "1"
         self.capture_error = None
@@ -174,6 +175,22 @@ class PipelinedDenseSync:
             self._bufs[key] = (torch.zeros(G * B, m.ldx, dtype=torch.float32, device=m.device),
                                torch.zeros(G * B, m.E, dtype=torch.float32, device=m.device))
         x_all, dpre_all = self._bufs[key]
+        # The gathered dpre is the LAST operand the update waits for, behind the last gradient bucket on RCCL's stream: two
+        # collectives in a row, each a launch latency of its own.  It rides in that bucket's all-reduce instead (dpre_ride): the
+        # model writes its dpre straight into ITS block of dpre_all, the other blocks are zero, and a SUM over the ranks is
+        # the gather, bit for bit (x + 0 + ... + 0); G B E extra floats in a 10 MB launch.  The blocks of the other ranks are
+        # re-zeroed at the top of the next step (they hold this step's result until then).
+        ride = self.dpre_ride and not self.split_update
+        if ride:
+            rank = dist.get_rank() if self.rank is None else self.rank
+            mine = dpre_all[rank * B:(rank + 1) * B]
+            if m.dpre.data_ptr() != mine.data_ptr():
+                m.dpre = mine                     # (captured segments bake the pointer in: drop them once)
+                m._graphs = {}
+            if rank > 0:
+                dpre_all[:rank * B].zero_()
+            if rank < G - 1:
+                dpre_all[(rank + 1) * B:].zero_()
         e = a.entries
         if self._slices is None:
             sg = {k: v.seg for k, v in e.items()}
@@ -212,9 +229,14 @@ class PipelinedDenseSync:
         eB2 = ib.mark(2)
         w_lstm = ib.behind(eB1, lambda: self._ar(a.grad[lstm0:head0]))
         # the 40-byte sparse-norm vector rides in the same launch as the last gradient bucket
-        w_front, w_dpre = ib.behind(eB2, lambda: (
-            dist.all_reduce_coalesced([a.grad[front0:lstm0], _sparse_norm_slot(m)], op=dist.ReduceOp.SUM, async_op=True),
-            self._gather(dpre_all, m.dpre)))
+        if ride:
+            w_front = ib.behind(eB2, lambda: dist.all_reduce_coalesced([a.grad[front0:lstm0], _sparse_norm_slot(m), dpre_all],
+                                                                       op=dist.ReduceOp.SUM, async_op=True))
+            w_dpre = w_front
+        else:
+            w_front, w_dpre = ib.behind(eB2, lambda: (
+                dist.all_reduce_coalesced([a.grad[front0:lstm0], _sparse_norm_slot(m)], op=dist.ReduceOp.SUM, async_op=True),
+                self._gather(dpre_all, m.dpre)))
         if self.split_update:
             # three update slices, each behind the collectives it needs (the head update runs while the small, latency-bound
             # all-gather of dpre -- the one collective on the critical path -- is in flight)
