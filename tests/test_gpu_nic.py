@@ -1,6 +1,8 @@
 """Model-level parity on the GPU: NIC (BASELINE config 2) through the real HIP kernels against
 the float64 oracle -- per-token probabilities/logit-derived loss within 1e-4 relative, identical
 greedy captions, gradients and post-Adam weights over several steps (hipGraph replay included)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -216,6 +218,27 @@ def test_pipelined_dp_schedule_world1_equals_single_gpu_step():
         assert d <= 1e-3 * lr, d
     finally:
         dist.destroy_process_group()
+
+
+def test_stream_policy_is_a_cache_hint_only():
+    """TNT_STREAM_NT (non-temporal optimizer moments, read once per process by the library): three training steps of the
+    config-2 shaped model with the policy off and on, each in its own process, leave bit-identical weights."""
+    import subprocess, sys
+    code = ("import sys, os, hashlib, numpy as np, torch; sys.path.insert(0, '.'); sys.path.insert(0, 'tests');"
+            "from masters_thesis_amd.nic import NIC; from masters_thesis_amd.optimizers import Adam; from helpers import synth_batch;"
+            "m = NIC(2048, 512, 512, 301, 6, 0.0, 0.2, 0.2, 0.01, 3e-5, 1e-5, device='cuda', seed=3);"
+            "m.compile(Adam(1e-3, beta_2=0.98, epsilon=1e-8, clipnorm=0.1)); rng = np.random.default_rng(1);"
+            "[m.train_step(synth_batch(16, 2048, 6, 301, 512, rng)) for _ in range(3)]; torch.cuda.synchronize();"
+            "print('H', hashlib.sha1(m.arena.theta.cpu().numpy().tobytes()).hexdigest(),"
+            " hashlib.sha1(m.opt_v.cpu().numpy().tobytes()).hexdigest())")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for nt in ("0", "1"):
+        env = dict(os.environ, TNT_STREAM_NT=nt)
+        p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out.append([ln for ln in p.stdout.splitlines() if ln.startswith("H ")][-1])
+    assert out[0] == out[1], out
 
 
 def test_row_sharded_encoder_update_world1_equals_single_gpu_step():
