@@ -25,6 +25,8 @@ import subprocess
 import sys
 import time
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # (the runtime's default here; explicit: masters-thesis_amd/__init__.py)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
