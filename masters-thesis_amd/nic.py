@@ -591,7 +591,15 @@ class NIC(ModelBase):
         self._enc_grad_stale = None
         ring = False
         if self.grad_sync is None:
-            run = self._run_planned if getattr(self, "plan_step", False) else self._run_captured
+            # The step is replayed as a recorded launch plan (ModelBase._run_planned), not as a hipGraph: with 15 (dense) / 32
+            # (attention) launches a step the host re-issues them in ~15 % of the step's time and every launch starts ~0.2-0.4 us
+            # earlier than as a graph node (0.4650 -> 0.4588 and 0.5666 -> 0.5626 ms/step, tools/probe/plan_bench.py: separate
+            # models, repeated, spread 0.0005).  ``plan_step = False`` restores the graph.  A plan re-issues backend launches
+            # only, so it is used where the step is nothing else: the sparse Embedding backward (the dense form hands its ids on
+            # with a tensor copy, which a graph captures and a plan would drop).
+            plan = (getattr(self, "plan_step", True) and self.E % 4 == 0 and getattr(self, "sparse_emb_bwd", True)
+                    and hasattr(self.be, "embedding_bwd_sparse"))
+            run = self._run_planned if plan else self._run_captured
             ring = self._run_step(run, ("train", B, T), lambda: self._train_and_update_graph(B, T))
             self._enc_grad_stale = self.__dict__.get("_enc_last_fused")
         elif getattr(self.grad_sync, "pipelined", False):
