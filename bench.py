@@ -458,6 +458,10 @@ def main():
             "config": {"workload": WORKLOAD_NAME[args.workload], "global_batch": B * world, "seq_len": T,
                        "parallelism": f"dp{world}", "final_loss": round(last["loss"], 4), "step_ms_p10_p50_p90": pct},
         }
+        # how the step's launches are re-issued: recorded launch plans (ModelBase._run_planned) or a hipGraph
+        plans = [k for k, v in model._graphs.items() if isinstance(v, tuple)]
+        out["config"]["replay"] = ("launch plan" if plans and len(plans) == len(model._graphs) else
+                                   "launch plans + hipGraph segments" if plans else "hipGraph")
         if seq_note:
             out["config"]["note"] = seq_note
         if not use_dp:
