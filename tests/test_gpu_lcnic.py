@@ -50,6 +50,31 @@ def test_train_parity(dims, rates, norm):
             assert np.abs(w - v).max() <= 2e-2 * 1e-3 + 1e-4 * np.abs(v).max(), (step, k, np.abs(w - v).max())
 
 
+def test_launch_plan_replay_equals_graph_replay():
+    """The attention model's default replay form (a recorded launch plan, ModelBase._run_planned) against the captured hipGraph
+    (plan_step = False): the same launches, so weights, moments and metrics stay bit-identical over eager -> record / capture ->
+    replay -> replay steps, dropout and the persistent chains included."""
+    from masters_thesis_amd.optimizers import Adam
+    dims = DIMS[1]
+    B, N, R, D, A, U, Et, V, T = dims
+    rates = (0.1, 0.2, 0.2, 0.2, 0.2, 0.2)
+    a, _ = build(np.random.default_rng(52), rates, dims)
+    b, _ = build(np.random.default_rng(52), rates, dims)
+    b.plan_step = False
+    for m in (a, b):
+        m.compile(Adam(learning_rate=1e-3, beta_1=0.9, beta_2=0.98, epsilon=1e-8, clipnorm=0.1))
+    rng = np.random.default_rng(5)
+    for step in range(5):
+        data, tgt = synth_batch(B, N, T, V, U, rng)
+        ra, rb = a.train_step((data, tgt)).as_floats(), b.train_step((data, tgt)).as_floats()
+        assert ra == rb, (step, ra, rb)
+    assert any(isinstance(v, tuple) for v in a._graphs.values()), "model a did not replay a launch plan"
+    assert not any(isinstance(v, tuple) for v in b._graphs.values())
+    torch.cuda.synchronize()
+    assert torch.equal(a.arena.theta, b.arena.theta)
+    assert torch.equal(a.opt_m, b.opt_m) and torch.equal(a.opt_v, b.opt_v)
+
+
 @pytest.mark.parametrize("dims", DIMS)
 def test_train_parity_with_adaptive_gradient_clipping(dims):
     """lc_NIC with the agc call of lc_NIC.py:388 switched on (agc.py:20-38)."""
