@@ -161,6 +161,7 @@ def test_launch_plan_replay_equals_graph_replay():
     against the captured hipGraph: same launches, so weights, optimizer state and metrics stay bit-identical over
     eager -> record/capture -> replay -> replay steps, dropout included."""
     a, b, (B, N, T, V, U, E) = _twin_models()
+    a.plan_step = False                      # a: the captured hipGraph; b: the default since round 3, the recorded launch plan
     b._run_captured = b._run_planned
     rng = np.random.default_rng(5)
     for step in range(5):
@@ -168,7 +169,8 @@ def test_launch_plan_replay_equals_graph_replay():
         ra, rb = a.train_step((data, tgt)).as_floats(), b.train_step((data, tgt)).as_floats()
         assert ra == rb, (step, ra, rb)
     plans = [v for v in b._graphs.values() if isinstance(v, tuple)]
-    assert plans and len(plans[0][1]) > 40           # the step really was replayed from a recorded plan
+    assert plans and len(plans[0][1]) >= 10          # the step really was replayed from a recorded plan
+    assert not any(isinstance(v, tuple) for v in a._graphs.values())
     torch.cuda.synchronize()
     assert torch.equal(a.arena.theta, b.arena.theta)
     assert torch.equal(a.opt_m, b.opt_m) and torch.equal(a.opt_v, b.opt_v)
